@@ -1,0 +1,307 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (imported from
+/root/reference, build container only -- the reference never ships to the GPU box).
+
+  python tools/make_golden.py            # writes tests/golden/{g1_tiny,g2_cfg1,g3_shards}.npz
+
+Fixtures are data only: seeded inputs (or the seed that regenerates them through
+cvc.synth) and the outputs/gradients the reference produced.  SURVEY.md section 8(c).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import types
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/anet-video-captioning"
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(ROOT, "cyclical-visual-captioning_amd"))
+sys.path.insert(0, REF)
+_tb = types.ModuleType("tensorboardX")
+_tb.SummaryWriter = object
+sys.modules["tensorboardX"] = _tb
+
+import torch.nn as nn  # noqa: E402
+from cvc import synth  # noqa: E402
+from model.modules import AdditiveSoftAttention, SoftAttention  # noqa: E402  (reference)
+from model.decoder_core import TopDownDecoderCore, AttenedDecoderCore  # noqa: E402
+from model.localizer_core import LocalizerNoLSTMCore  # noqa: E402
+from model.captioner import DecodeAndGroundCaptionerGVDROI  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(4)
+
+
+def make_opts(d: synth.Dims, **over):
+    o = argparse.Namespace(
+        vocab_size=d.V, itow={str(i): "w%d" % i for i in range(d.V)}, wtoi={"UNK": synth.UNK_IDX},
+        seq_length=d.T, seq_per_img=1, rnn_size=d.R, input_encoding_size=d.E, att_hid_size=d.A,
+        drop_prob_lm=0.5, softattn_type="additive", softmax_temp=1.0, localizer_softmax_temp=1.0,
+        global_img_in_attn_lstm=1, embedding_vocab_plus_1=False, train_decoder_only=False)
+    for k, v in over.items():
+        setattr(o, k, v)
+    return o
+
+
+class FeatureStub(nn.Module):
+    """Stands in for RegionalFeatureExtractorGVD (captioner.py:31-34 allows roi_extractor=):
+    returns pre-projected features in the order of backbone.py:350-351."""
+
+    def __init__(self, d, feats):
+        super().__init__()
+        self.vis_embed = nn.Sequential(nn.Embedding(d.DET + 1, d.G), nn.ReLU(), nn.Dropout(0.5))
+        self.vis_classifiers_bias = nn.Parameter(torch.zeros(d.DET + 1))
+        self.feats = feats
+
+    def forward(self, *a, **k):
+        f = self.feats
+        return (f["fc_feats"], f["conv_feats"], f["p_conv_feats"], f["pool_feats"], f["p_pool_feats"],
+                f["g_pool_feats"], f["pnt_mask"], None, None, torch.zeros(()))
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def build_reference_model(d, sd_np, feats_t, **opt_over):
+    opts = make_opts(d, **opt_over)
+    model = DecodeAndGroundCaptionerGVDROI(opts, roi_extractor=FeatureStub(d, feats_t))
+    model.device = torch.device("cpu")
+    missing, unexpected = model.load_state_dict({k: t(v) for k, v in sd_np.items()}, strict=False)
+    assert not unexpected, unexpected
+    assert not missing, missing
+    model.eval()
+    return model
+
+
+def model_call(model, batch_t, feats_t, lang_eval=False):
+    B = feats_t["fc_feats"].size(0)
+    segs = torch.zeros(B, 1, 1)
+    return model(segs, batch_t["input_seq"], batch_t["gt_seq"], batch_t["num"], batch_t["proposals"],
+                 batch_t["gt_bboxs"], batch_t["box_mask"], torch.zeros(B, 1, 1), batch_t["frm_mask"],
+                 batch_t["sample_idx"], feats_t["pnt_mask"], lang_eval)
+
+
+FEAT_GRAD_KEYS = ("fc_feats", "conv_feats", "p_conv_feats", "pool_feats", "p_pool_feats", "g_pool_feats")
+
+
+def grads_of(model, feats_t, loss):
+    for p in model.parameters():
+        p.grad = None
+    for k in FEAT_GRAD_KEYS:
+        feats_t[k].grad = None
+    loss.backward()
+    g = OrderedDict()
+    for n, p in model.named_parameters():
+        g["grad." + n] = None if p.grad is None else p.grad.detach().clone().numpy()
+    for k in FEAT_GRAD_KEYS:
+        gg = feats_t[k].grad
+        g["grad.in." + k] = None if gg is None else gg.detach().clone().numpy()
+    return g
+
+
+def feats_to_torch(feats_np, requires_grad):
+    ft = {k: t(v) for k, v in feats_np.items()}
+    if requires_grad:
+        for k in FEAT_GRAD_KEYS:
+            ft[k].requires_grad_(True)
+    return ft
+
+
+def put(out, prefix, d):
+    for k, v in d.items():
+        if v is None:
+            out[prefix + k + ".is_none"] = np.asarray(1)
+        else:
+            out[prefix + k] = v.detach().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+
+
+def loss_mix(losses, xe=0.5, w_att2=0.0, w_cls=0.0, cons=0.5):
+    lm, att2, _g, cls = [x.mean() for x in losses[:4]]
+    loss = xe * lm + w_att2 * att2 + w_cls * cls
+    if len(losses) > 4:
+        loss = loss + cons * losses[4].mean()
+    return loss
+
+
+# ------------------------------------------------------------------------------------ G1
+def g1_tiny(path):
+    d = synth.CONFIGS["tiny"]
+    seed = 1234
+    sd = synth.hot_path_state_dict(d, seed)
+    feats_np = synth.clip_features(d, seed, full_mask_clip=2)
+    batch_np = synth.label_glue_batch(d, seed)
+    out = OrderedDict()
+    out["meta.seed"] = np.asarray(seed)
+    put(out, "sd.", sd)
+    put(out, "feats.", feats_np)
+    put(out, "batch.", batch_np)
+
+    # ---- module-level vectors (a1, a2, a3, a5, a6) with non-trivial state
+    B, N, F, R, A, E = d.B, d.N, d.F, d.R, d.A, d.E
+    h = t(synth.normal((B, R), seed, "unit.h") * 0.5)
+    emb = t(np.maximum(synth.normal((B, E), seed, "unit.emb"), 0))
+    st_h = t(synth.normal((2, B, R), seed, "unit.state_h") * 0.5)
+    st_c = t(synth.normal((2, B, R), seed, "unit.state_c") * 0.5)
+    fmask = t(synth.uniform((B, N), seed, "unit.fmask") < 0.4)
+    put(out, "unit.", dict(h=h, emb=emb, state_h=st_h, state_c=st_c, fmask=fmask))
+    ft = feats_to_torch(feats_np, False)
+    mask = ft["pnt_mask"][:, 1:]
+    opts = make_opts(d)
+
+    add = AdditiveSoftAttention(R, A)
+    add.load_state_dict({k.split("soft_attn.")[1]: t(v) for k, v in sd.items() if k.startswith("decoder_core.soft_attn.")})
+    ctx, a, fm = add(h, ft["p_pool_feats"], context=ft["pool_feats"], mask=mask, proposal_frame_mask=fmask)
+    put(out, "a1.regions.", dict(ctx=ctx, attn=a, fm=fm))
+    ctx, a, fm = add(h, ft["p_conv_feats"], context=ft["conv_feats"])
+    put(out, "a1.frames.", dict(ctx=ctx, attn=a))
+    ctx, a, fm = add(h, ft["p_pool_feats"], mask=mask)  # context=None -> weighted proj_context
+    put(out, "a1.noctx.", dict(ctx=ctx, attn=a))
+
+    for temp in (1.0, 2.5):
+        dot = SoftAttention(E, A, temp=temp)
+        dot.load_state_dict({k.split("soft_attn.")[1]: t(v) for k, v in sd.items() if k.startswith("localizer_core.soft_attn.")})
+        ctx, a, fm = dot(emb, ft["p_pool_feats"], context=ft["pool_feats"], mask=mask, proposal_frame_mask=fmask)
+        put(out, "a2.temp%g." % temp, dict(ctx=ctx, attn=a, fm=fm))
+
+    core = TopDownDecoderCore(opts)
+    core.load_state_dict({k[len("decoder_core."):]: t(v) for k, v in sd.items() if k.startswith("decoder_core.")})
+    core.eval()
+    o, st, ra, fma, wp = core(emb, ft["fc_feats"], ft["conv_feats"], ft["p_conv_feats"], ft["pool_feats"],
+                              ft["p_pool_feats"], mask, (st_h, st_c), proposal_frame_mask=fmask)
+    put(out, "a3.", dict(out=o, h=st[0], c=st[1], roi_attn=ra, fm=fma, ctx_r=wp))
+    # (global_img_in_attn_lstm=0 cannot run in the reference: the cell is always built with
+    #  E+2R inputs, decoder_core.py:14, so the 2-way concat of :48 shape-mismatches.)
+    rec = AttenedDecoderCore(opts, core.att_lstm, core.lang_lstm)
+    rec.eval()
+    lp = t(synth.normal((B, R), seed, "unit.loc_pool"))
+    lc = t(synth.normal((B, R), seed, "unit.loc_conv"))
+    put(out, "unit.", dict(loc_pool=lp, loc_conv=lc))
+    o, st = rec(emb, ft["fc_feats"], lp, lc, (st_h, st_c))
+    put(out, "a5.", dict(out=o, h=st[0], c=st[1]))
+
+    loc = LocalizerNoLSTMCore(opts)
+    loc.load_state_dict({k[len("localizer_core."):]: t(v) for k, v in sd.items() if k.startswith("localizer_core.")})
+    a, b_, c_, _ = loc(emb, ft["fc_feats"], ft["conv_feats"], ft["p_conv_feats"], ft["pool_feats"],
+                       ft["p_pool_feats"], mask, None, None, proposal_frame_mask=fmask)
+    put(out, "a6.", dict(loc_pool=a, loc_conv=b_, prob=c_))
+
+    # ---- a8 greedy sample, with the per-step log-probs captured by a hook on logit
+    ft = feats_to_torch(feats_np, False)
+    bt = {k: t(v) for k, v in batch_np.items()}
+    model = build_reference_model(d, sd, ft)
+    logits = []
+    hk = model.logit.register_forward_hook(lambda m, i, o: logits.append(o.detach().clone()))
+    with torch.no_grad():
+        seq, att2, _ = model_call(model, bt, ft, True)
+    hk.remove()
+    put(out, "a8.", dict(seq=seq, att2_weights=att2, logp=torch.log_softmax(torch.stack(logits, 1), 2)))
+
+    # ---- a9 cyclical forward + grads (eval mode); a10 ground weights via hook
+    for name, over, mix in (("a9.cyc.", dict(), dict()),
+                            ("a9.sup.", dict(), dict(w_att2=0.05)),
+                            ("a9.dec.", dict(train_decoder_only=True), dict(cons=0.0))):
+        ft = feats_to_torch(feats_np, True)
+        model = build_reference_model(d, sd, ft, **over)
+        grabbed = {}
+        orig = model._grounder
+
+        def spy(xt, att_feats, mask, bias=None, min_value=-1e8, _o=orig, _g=grabbed):
+            r = _o(xt, att_feats, mask, bias, min_value)
+            _g["ground_weights"] = r.detach().clone()
+            return r
+        model._grounder = spy
+        losses = model_call(model, bt, ft, False)
+        put(out, name, {"loss%d" % i: l for i, l in enumerate(losses)})
+        put(out, name, grabbed)
+        loss = loss_mix(losses, **mix)
+        put(out, name, dict(total=loss))
+        put(out, name, grads_of(model, ft, loss))
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+# ------------------------------------------------------------------------------------ G2
+def g2_cfg1(path):
+    d = synth.CONFIGS["cfg1"]
+    seed = 1235
+    sd = synth.hot_path_state_dict(d, seed)
+    feats_np = synth.clip_features(d, seed)
+    batch_np = synth.label_glue_batch(d, seed)
+    out = OrderedDict()
+    out["meta.seed"] = np.asarray(seed)
+    ft = feats_to_torch(feats_np, False)
+    bt = {k: t(v) for k, v in batch_np.items()}
+    model = build_reference_model(d, sd, ft)
+    logits = []
+    hk = model.logit.register_forward_hook(lambda m, i, o: logits.append(o.detach().clone()))
+    with torch.no_grad():
+        seq, att2, _ = model_call(model, bt, ft, True)
+    hk.remove()
+    logp = torch.log_softmax(torch.stack(logits, 1), 2)
+    top8 = torch.topk(logp, 8, dim=2)
+    put(out, "a8.", dict(seq=seq, att2_weights=att2, top8_logp=top8[0], top8_idx=top8[1]))
+
+    ft = feats_to_torch(feats_np, True)
+    model = build_reference_model(d, sd, ft)
+    losses = model_call(model, bt, ft, False)
+    put(out, "a9.cyc.", {"loss%d" % i: l for i, l in enumerate(losses)})
+    loss = loss_mix(losses)
+    g = grads_of(model, ft, loss)
+    for k, v in g.items():
+        if v is None:
+            out["a9.cyc." + k + ".is_none"] = np.asarray(1)
+            continue
+        flat = v.reshape(-1)
+        idx = synth.randint((16,), seed, "sample." + k, 0, flat.size)
+        out["a9.cyc." + k + ".norm"] = np.asarray(np.sqrt((flat.astype(np.float64) ** 2).sum()))
+        out["a9.cyc." + k + ".idx"] = idx
+        out["a9.cyc." + k + ".val"] = flat[idx]
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+# ------------------------------------------------------------------------------------ G3
+def g3_shards(path):
+    """Per-shard losses/grads for a 4-clip tiny batch split 2 ways: the mean over shards is what a
+    G-way data-parallel step must all-reduce to (DataParallel semantics)."""
+    import dataclasses
+    d = dataclasses.replace(synth.CONFIGS["tiny"], B=4)
+    seed = 1236
+    sd = synth.hot_path_state_dict(d, seed)
+    feats_np = synth.clip_features(d, seed)
+    batch_np = synth.label_glue_batch(d, seed)
+    out = OrderedDict()
+    out["meta.seed"] = np.asarray(seed)
+    shard_grads = []
+    for s, sl in enumerate((slice(0, 2), slice(2, 4), slice(0, 4))):
+        name = "shard%d." % s if s < 2 else "full."
+        ft = feats_to_torch({k: v[sl] for k, v in feats_np.items()}, True)
+        bt = {k: t(v[sl]) for k, v in batch_np.items()}
+        model = build_reference_model(d, sd, ft)
+        losses = model_call(model, bt, ft, False)
+        put(out, name, {"loss%d" % i: l for i, l in enumerate(losses)})
+        g = grads_of(model, ft, loss_mix(losses))
+        g = {k: v for k, v in g.items() if not k.startswith("grad.in.")}
+        put(out, name, g)
+        if s < 2:
+            shard_grads.append(g)
+    mean = {k: (None if shard_grads[0][k] is None else (shard_grads[0][k] + shard_grads[1][k]) / 2)
+            for k in shard_grads[0]}
+    put(out, "mean.", mean)
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    gdir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(gdir, exist_ok=True)
+    g1_tiny(os.path.join(gdir, "g1_tiny.npz"))
+    g2_cfg1(os.path.join(gdir, "g2_cfg1.npz"))
+    g3_shards(os.path.join(gdir, "g3_shards.npz"))
