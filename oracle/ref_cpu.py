@@ -205,9 +205,9 @@ def beam_search(P: Dict[str, Tensor], feats: Dict[str, Tensor], T: int, unk_idx:
     V = P["logit.weight"].size(0)
     mask = feats["pnt_mask"][:, 1:]
     rep = lambda x: x.repeat_interleave(beam, 0)
-    fc, conv, pconv, pool, ppool, m = (rep(feats[k]) for k in
-                                       ("fc_feats", "conv_feats", "p_conv_feats", "pool_feats", "p_pool_feats"))\
-        + (rep(mask),)
+    fc, conv, pconv, pool, ppool = [rep(feats[k]) for k in
+                                    ("fc_feats", "conv_feats", "p_conv_feats", "pool_feats", "p_pool_feats")]
+    m = rep(mask)
     state = init_hidden(B * beam, R)
     words = torch.zeros(B * beam, dtype=torch.long)
     scores = torch.zeros(B, beam)
