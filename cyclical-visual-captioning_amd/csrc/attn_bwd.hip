@@ -1,0 +1,174 @@
+// Attention backward with score recompute, and the grounder.
+//
+// Nothing of size [rows, n, A] is ever saved by the forward (the reference's autograd keeps the
+// tanh output, O(B T (N+F) A)): the backward re-streams proj_context once, recomputes
+// tanh(proj_n + q) in registers and reduces d_q over n inside the workgroup.  Three passes:
+//   1. d_attn[row, n] = d_ctx[row, :] . ctx[clip, n, :]      (the forward's DOT score pass)
+//   2. softmax backward per row: d_s = attn * (d_attn - <attn, d_attn>) + d_fm
+//      (the reference fills masks on .data, modules.py:124-144, so autograd routes the full
+//       gradient through masked positions; attn == 0 there unless the whole row is masked)
+//   3. score backward: d_q[row, :], per-row partials of d_w_alpha, optional d_proj.
+// plus the optional outer product d_ctx_feats[clip, n, :] += attn[row, n] d_ctx[row, :].
+// Reductions are ordered (LDS, fixed wave order; no float atomics): run-to-run deterministic.
+#include "attn_scores.h"
+#include <math.h>
+
+namespace {
+
+constexpr int WG = 256;
+
+__device__ __forceinline__ float block_sum4(float v, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(WG) void softmax_bwd_kernel(const float* attn, const float* d_fm, int n, int have_da,
+                                                         float* d_scores) {
+    __shared__ float red[4];
+    const size_t o = (size_t)blockIdx.x * n;
+    float dot = 0.f;
+    if (have_da)
+        for (int i = threadIdx.x; i < n; i += WG) dot += attn[o + i] * d_scores[o + i];
+    dot = block_sum4(dot, red);
+    for (int i = threadIdx.x; i < n; i += WG) {
+        float ds = have_da ? attn[o + i] * (d_scores[o + i] - dot) : 0.f;
+        if (d_fm != nullptr) ds += d_fm[o + i];
+        d_scores[o + i] = ds;
+    }
+}
+
+struct ScoreBwdArgs {
+    const float* q;        // [rows, A]
+    const float* w_a;      // [A]
+    const float* proj;     // [nclip, n, A]
+    const float* d_scores; // [rows, n]
+    float* d_q;            // [rows, A]
+    float* d_w_part;       // [rows, A] or null
+    float* d_proj;         // [nclip, n, A] accumulate, or null
+    float inv_temp;
+    int nq, n, A;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(WG) void attn_score_bwd_kernel(ScoreBwdArgs a) {
+    __shared__ f32x4 part[2][4][64];
+    const int clip = blockIdx.y, cb = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int A = a.A, n = a.n;
+    const int col = cb * 256 + lane * 4;
+    const bool ok = col < A;
+    const float* P = a.proj + (size_t)clip * n * A + col;
+    float* dP = a.d_proj != nullptr ? a.d_proj + (size_t)clip * n * A + col : nullptr;
+    f32x4 w4 = {0, 0, 0, 0};
+    if (KIND == CVC_ATTN_ADDITIVE && ok) w4 = ld4(a.w_a + col);
+    for (int qi = 0; qi < a.nq; ++qi) {
+        const size_t row = (size_t)clip * a.nq + qi;
+        f32x4 q4 = ok ? ld4(a.q + row * A + col) : f32x4{0, 0, 0, 0};
+        f32x4 dq = {0, 0, 0, 0}, dw = {0, 0, 0, 0};
+        const float* ds_row = a.d_scores + row * n;
+        if (ok) {
+#pragma unroll 4
+            for (int i = wave; i < n; i += 4) {
+                const float ds = ds_row[i];
+                const f32x4 p = ld4(P + (size_t)i * A);
+                f32x4 dpre;
+                if (KIND == CVC_ATTN_ADDITIVE) {
+                    f32x4 t;
+                    t.x = fast_tanh(p.x + q4.x); t.y = fast_tanh(p.y + q4.y);
+                    t.z = fast_tanh(p.z + q4.z); t.w = fast_tanh(p.w + q4.w);
+                    dpre = ds * w4 * (1.f - t * t);
+                    dw += ds * t;
+                    dq += dpre;
+                } else {
+                    const float g = ds * a.inv_temp;
+                    dpre = g * q4;
+                    dq += g * p;
+                }
+                if (dP != nullptr) st4(dP + (size_t)i * A, ld4(dP + (size_t)i * A) + dpre);
+            }
+        }
+        __syncthreads();
+        part[0][wave][lane] = dq;
+        part[1][wave][lane] = dw;
+        __syncthreads();
+        if (wave == 0 && ok) {
+            st4(a.d_q + row * A + col, (part[0][0][lane] + part[0][1][lane]) + (part[0][2][lane] + part[0][3][lane]));
+            if (KIND == CVC_ATTN_ADDITIVE && a.d_w_part != nullptr)
+                st4(a.d_w_part + row * A + col,
+                    (part[1][0][lane] + part[1][1][lane]) + (part[1][2][lane] + part[1][3][lane]));
+        }
+    }
+}
+
+__global__ __launch_bounds__(WG) void ctxfeat_bwd_kernel(const float* attn, const float* d_ctx, int nq, int n, int R,
+                                                         float* d_feat) {
+    const int clip = blockIdx.y, cb = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = cb * 256 + lane * 4;
+    if (col >= R) return;
+    float* D = d_feat + (size_t)clip * n * R + col;
+    for (int qi = 0; qi < nq; ++qi) {
+        const size_t row = (size_t)clip * nq + qi;
+        const f32x4 g = ld4(d_ctx + row * R + col);
+        for (int i = wave; i < n; i += 4) st4(D + (size_t)i * R, ld4(D + (size_t)i * R) + attn[row * n + i] * g);
+    }
+}
+
+__global__ __launch_bounds__(WG) void grounder_epilogue_kernel(const float* bias, const uint8_t* mask, size_t total,
+                                                               float* out) {
+    const size_t i = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (i >= total) return;
+    float v = out[i];
+    if (bias != nullptr) v += bias[i];
+    if (mask != nullptr && mask[i] != 0) v = CVC_MIN_VALUE;
+    out[i] = v;
+}
+
+}  // namespace
+
+extern "C" int cvc_attn_bwd(int kind, const float* q, const float* w_a, float inv_temp, const float* proj,
+                            const float* ctx, const float* attn, const float* d_ctx, const float* d_fm, int nclip, int nq,
+                            int n, int A, int R, float* d_scores, float* d_q, float* d_w_part, float* d_proj,
+                            float* d_ctxfeat, cvc_stream_t stream) {
+    if (!q || !proj || !ctx || !attn || !d_scores || !d_q || nclip < 1 || nq < 1 || n < 1 || (A & 3) || (R & 3))
+        return CVC_E_BADARG;
+    if (kind != CVC_ATTN_ADDITIVE && kind != CVC_ATTN_DOT) return CVC_E_BADARG;
+    if (kind == CVC_ATTN_ADDITIVE && !w_a) return CVC_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = nclip * nq;
+    if (d_ctx != nullptr) {
+        cvc_attn_set s{};
+        s.proj = ctx; s.ctx = ctx; s.scores = d_scores; s.attn = d_scores; s.n = n;
+        int rc = run_scores(CVC_ATTN_DOT, d_ctx, nullptr, nullptr, 1.f, &s, 1, nclip, nq, R, st);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(rows), dim3(WG), 0, st, attn, d_fm, n, d_ctx != nullptr ? 1 : 0, d_scores);
+    ScoreBwdArgs a{q, w_a, proj, d_scores, d_q, d_w_part, d_proj, inv_temp, nq, n, A};
+    dim3 grid((A + 255) / 256, nclip);
+    if (kind == CVC_ATTN_ADDITIVE) hipLaunchKernelGGL(attn_score_bwd_kernel<CVC_ATTN_ADDITIVE>, grid, dim3(WG), 0, st, a);
+    else hipLaunchKernelGGL(attn_score_bwd_kernel<CVC_ATTN_DOT>, grid, dim3(WG), 0, st, a);
+    if (d_ctxfeat != nullptr && d_ctx != nullptr)
+        hipLaunchKernelGGL(ctxfeat_bwd_kernel, dim3((R + 255) / 256, nclip), dim3(WG), 0, st, attn, d_ctx, nq, n, R,
+                           d_ctxfeat);
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_grounder_fwd(const float* xt, const float* feats, const float* bias, const uint8_t* mask, int B, int T,
+                                int N, int G, float* out, cvc_stream_t stream) {
+    if (!xt || !feats || !out || B < 1 || T < 1 || N < 1 || (G & 3)) return CVC_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    cvc_attn_set s{};
+    s.proj = feats; s.ctx = feats; s.scores = out; s.attn = out; s.n = N;
+    int rc = run_scores(CVC_ATTN_DOT, xt, nullptr, nullptr, 1.f, &s, 1, B, T, G, st);
+    if (rc) return rc;
+    if (bias != nullptr || mask != nullptr) {
+        const size_t total = (size_t)B * T * N;
+        hipLaunchKernelGGL(grounder_epilogue_kernel, dim3((unsigned)((total + WG - 1) / WG)), dim3(WG), 0, st, bias, mask,
+                           total, out);
+    }
+    return cvc_launch_status();
+}

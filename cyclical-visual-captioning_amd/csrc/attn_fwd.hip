@@ -1,0 +1,132 @@
+// Region / frame attention forward for the caption decoder (model/modules.py:24-159 in the
+// reference) as two streaming kernels, both HBM-bound:
+//
+//   1. attn_scores_kernel : one pass over proj_context [nclip, n, A].  A wave owns a feature
+//      row at a time (1 KiB-per-instruction coalesced dwordx4 loads, next row prefetched),
+//      the clip's query vectors q (and alpha_net's weight) sit in LDS and are shared by all
+//      rows / all beams; add -> tanh -> dot(w) happens in registers, one wave reduction per
+//      (row, query).  Writes masked pre-softmax scores (+ the frame-masked copy).
+//   2. attn_wsum_kernel   : softmax over n (recomputed per workgroup from the scores, a few
+//      KB) and one pass over context [nclip, n, R]: a workgroup owns (query row, 256-column
+//      block), its 4 waves split n, each lane carries 4 columns; partial sums meet in LDS.
+//      Both feature sets of a decoder step (regions + frames) are handled in one launch and
+//      their contexts are summed in registers (decoder_core.py:59).
+//
+// Every feature byte is read exactly once per clip-step: algorithmic bytes per clip-step
+// = 4 (N+F)(A+R) + N  (SURVEY.md section 8(d)).
+#include "attn_scores.h"
+#include <math.h>
+
+namespace {
+
+constexpr int WG = 256;
+
+struct WsumArgs {
+    cvc_attn_set set[2];
+    int nsets, nq, R;
+    float* ctx_sum;               // [rows, R] or null
+};
+
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = is_max ? wave_max(v) : wave_sum(v);
+    __syncthreads();                         // red[] may still be read from a previous call
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float r = red[0];
+#pragma unroll
+    for (int w = 1; w < WG / 64; ++w) r = is_max ? fmaxf(r, red[w]) : r + red[w];
+    return r;
+}
+
+__global__ __launch_bounds__(WG) void attn_wsum_kernel(WsumArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* part = reinterpret_cast<f32x4*>(smem);      // [4 waves][64 lanes]
+    float* red = smem + 4 * 64 * 4;                    // [4]
+    float* a_s = red + 16;                             // [n_max]
+    const int row = blockIdx.y, cb = blockIdx.x;
+    const int clip = row / a.nq;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int R = a.R;
+    const int col = cb * 256 + lane * 4;
+    const bool col_ok = col < R;
+    f32x4 total = {0, 0, 0, 0};
+
+    for (int s = 0; s < a.nsets; ++s) {
+        const cvc_attn_set& S = a.set[s];
+        const int n = S.n;
+        const float* sc = S.scores + (size_t)row * n;
+        // softmax over n (torch.softmax: exp(x - max) / sum)
+        float m = -INFINITY;
+        for (int i = tid; i < n; i += WG) m = fmaxf(m, sc[i]);
+        m = block_reduce(m, red, true);
+        float sum = 0.f;
+        for (int i = tid; i < n; i += WG) {
+            float e = expf(sc[i] - m);
+            a_s[i] = e;
+            sum += e;
+        }
+        sum = block_reduce(sum, red, false);
+        for (int i = tid; i < n; i += WG) {
+            float p = a_s[i] / sum;
+            a_s[i] = p;
+            if (cb == 0) S.attn[(size_t)row * n + i] = p;
+        }
+        __syncthreads();
+        if (S.ctx_out == nullptr && a.ctx_sum == nullptr) continue;
+
+        const float* C = S.ctx + (size_t)clip * n * R + col;
+        f32x4 acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+        if (col_ok) {
+            int i = wave;
+            for (; i + 12 < n; i += 16) {
+                f32x4 c0 = ld4(C + (size_t)i * R), c1 = ld4(C + (size_t)(i + 4) * R);
+                f32x4 c2 = ld4(C + (size_t)(i + 8) * R), c3 = ld4(C + (size_t)(i + 12) * R);
+                acc0 += a_s[i] * c0;
+                acc1 += a_s[i + 4] * c1;
+                acc2 += a_s[i + 8] * c2;
+                acc3 += a_s[i + 12] * c3;
+            }
+            for (; i < n; i += 4) acc0 += a_s[i] * ld4(C + (size_t)i * R);
+        }
+        part[wave * 64 + lane] = (acc0 + acc1) + (acc2 + acc3);
+        __syncthreads();
+        if (wave == 0 && col_ok) {
+            f32x4 v = (part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]);
+            if (S.ctx_out != nullptr) st4(S.ctx_out + (size_t)row * R + col, v);
+            total += v;
+        }
+        __syncthreads();
+    }
+    if (a.ctx_sum != nullptr && wave == 0 && col_ok) st4(a.ctx_sum + (size_t)row * R + col, total);
+}
+
+}  // namespace
+
+extern "C" int cvc_attn_fwd(int kind, const float* q, const float* w_a, const float* b_a, float inv_temp,
+                            const cvc_attn_set* sets, int nsets, int nclip, int nq, int A, int R,
+                            float* ctx_sum, cvc_stream_t stream) {
+    if (nsets < 1 || nsets > 2 || nclip < 1 || nq < 1 || (A & 3) || (R & 3) || q == nullptr) return CVC_E_BADARG;
+    if (kind == CVC_ATTN_ADDITIVE && w_a == nullptr) return CVC_E_BADARG;
+    if (kind != CVC_ATTN_ADDITIVE && kind != CVC_ATTN_DOT) return CVC_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    int n_max = 0;
+    for (int s = 0; s < nsets; ++s) {
+        if (sets[s].n < 1 || !sets[s].proj || !sets[s].ctx || !sets[s].scores || !sets[s].attn) return CVC_E_BADARG;
+        if ((sets[s].frame_masked != nullptr) != (sets[s].frame_mask != nullptr)) return CVC_E_BADARG;
+        n_max = sets[s].n > n_max ? sets[s].n : n_max;
+    }
+    // ---- pass 1: masked pre-softmax scores
+    int rc = run_scores(kind, q, w_a, b_a, inv_temp, sets, nsets, nclip, nq, A, st);
+    if (rc != 0) return rc;
+    // ---- pass 2: softmax + weighted sum of context rows
+    WsumArgs wa;
+    wa.set[0] = sets[0];
+    wa.set[1] = nsets > 1 ? sets[1] : sets[0];
+    wa.nsets = nsets; wa.nq = nq; wa.R = R; wa.ctx_sum = ctx_sum;
+    const size_t lds2 = (4 * 64 * 4 + 16 + n_max) * sizeof(float);
+    if (lds2 > 64 * 1024) return CVC_E_TOOBIG;
+    dim3 g2((R + 255) / 256, nclip * nq);
+    hipLaunchKernelGGL(attn_wsum_kernel, g2, dim3(WG), lds2, st, wa);
+    return cvc_launch_status();
+}

@@ -1,0 +1,339 @@
+// Word-embedding lookup, vocabulary head (log-softmax, greedy top-2 with UNK suppression,
+// masked NLL and its fused backward), beam bookkeeping and LSTM pointwise backward.
+// Reference: model/captioner.py:53-68 (embed), :266/:361/:437 (log_softmax(logit)),
+// :415-422 (top-2 / UNK rule), misc/utils.py:132-146,181-192 (masked NLL).
+// All of it is small elementwise / row-reduction work next to the streaming kernels; the
+// point is to keep it on the device and inside the captured decode graph.
+#include "cvc_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int WG = 256;
+
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// ------------------------------------------------------------------ embedding
+__global__ __launch_bounds__(WG) void embed_relu_fwd_kernel(const float* table, const int64_t* idx, const float* drop,
+                                                            int M, int E, float* out) {
+    const int m = blockIdx.y;
+    const int e = (blockIdx.x * WG + threadIdx.x) * 4;
+    if (e >= E) return;
+    f32x4 v = ld4(table + (size_t)idx[m] * E + e);
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    if (drop != nullptr) v *= ld4(drop + (size_t)m * E + e);
+    st4(out + (size_t)m * E + e, v);
+}
+
+// one thread owns one embedding column and walks the rows in order: duplicates of a word
+// accumulate sequentially -> deterministic, no atomics
+__global__ __launch_bounds__(WG) void embed_relu_bwd_kernel(const float* table, const int64_t* idx, const float* drop,
+                                                            const float* d_out, int M, int E, float* d_table) {
+    const int e = blockIdx.x * WG + threadIdx.x;
+    if (e >= E) return;
+    for (int m = 0; m < M; ++m) {
+        const size_t row = (size_t)idx[m] * E + e;
+        float g = d_out[(size_t)m * E + e];
+        if (drop != nullptr) g *= drop[(size_t)m * E + e];
+        if (table[row] > 0.f) d_table[row] += g;
+    }
+}
+
+// ------------------------------------------------------------------ log-softmax / top-2 / NLL
+__global__ __launch_bounds__(WG) void log_softmax_kernel(const float* logits, int V, float* logp) {
+    __shared__ float red[4];
+    const float* x = logits + (size_t)blockIdx.x * V;
+    float* y = logp + (size_t)blockIdx.x * V;
+    float m = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += WG) m = fmaxf(m, x[v]);
+    m = block_max(m, red);
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V; v += WG) s += expf(x[v] - m);
+    s = block_sum(s, red);
+    const float lse = m + logf(s);
+    for (int v = threadIdx.x; v < V; v += WG) y[v] = x[v] - lse;
+}
+
+// d_x = d_y - exp(y) * sum(d_y)   (y = log_softmax(x))
+__global__ __launch_bounds__(WG) void log_softmax_bwd_kernel(const float* logp, const float* d_logp, int V, float* d_logits) {
+    __shared__ float red[4];
+    const size_t o = (size_t)blockIdx.x * V;
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V; v += WG) s += d_logp[o + v];
+    s = block_sum(s, red);
+    for (int v = threadIdx.x; v < V; v += WG) d_logits[o + v] = d_logp[o + v] - expf(logp[o + v]) * s;
+}
+
+// d_logp[m, :] = 0 except d_logp[m, target[m]] = -w[m] * g[0]
+__global__ __launch_bounds__(WG) void nll_bwd_kernel(const int64_t* target, const float* w, const float* g, int V,
+                                                     float* d_logp) {
+    const int m = blockIdx.y;
+    const int v = blockIdx.x * WG + threadIdx.x;
+    if (v >= V) return;
+    d_logp[(size_t)m * V + v] = v == (int)target[m] ? -w[m] * g[0] : 0.f;
+}
+
+struct Top2 { float v1; int i1; float v2; int i2; };
+__device__ __forceinline__ bool better(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
+__device__ __forceinline__ Top2 merge(Top2 a, Top2 b) {
+    Top2 r;
+    if (better(a.v1, a.i1, b.v1, b.i1)) {
+        r.v1 = a.v1; r.i1 = a.i1;
+        if (better(a.v2, a.i2, b.v1, b.i1)) { r.v2 = a.v2; r.i2 = a.i2; } else { r.v2 = b.v1; r.i2 = b.i1; }
+    } else {
+        r.v1 = b.v1; r.i1 = b.i1;
+        if (better(b.v2, b.i2, a.v1, a.i1)) { r.v2 = b.v2; r.i2 = b.i2; } else { r.v2 = a.v1; r.i2 = a.i1; }
+    }
+    return r;
+}
+
+__global__ __launch_bounds__(WG) void top2_unk_kernel(const float* logits, int V, int unk, int64_t* word, int wstride,
+                                                      float* logprob) {
+    __shared__ float red[4];
+    __shared__ Top2 tred[4];
+    const int row = blockIdx.x;
+    const float* x = logits + (size_t)row * V;
+    Top2 t{-INFINITY, 0x7fffffff, -INFINITY, 0x7fffffff};
+    for (int v = threadIdx.x; v < V; v += WG) {
+        const float xv = x[v];
+        if (better(xv, v, t.v1, t.i1)) { t.v2 = t.v1; t.i2 = t.i1; t.v1 = xv; t.i1 = v; }
+        else if (better(xv, v, t.v2, t.i2)) { t.v2 = xv; t.i2 = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Top2 u;
+        u.v1 = __shfl_xor(t.v1, o, 64); u.i1 = __shfl_xor(t.i1, o, 64);
+        u.v2 = __shfl_xor(t.v2, o, 64); u.i2 = __shfl_xor(t.i2, o, 64);
+        t = merge(t, u);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) tred[wave] = t;
+    __syncthreads();
+    t = merge(merge(tred[0], tred[1]), merge(tred[2], tred[3]));
+    const float m = t.v1;
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V; v += WG) s += expf(x[v] - m);
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        const bool use2 = (t.i1 == unk) && V > 1;        // captioner.py:417-421
+        word[(size_t)row * wstride] = use2 ? t.i2 : t.i1;
+        if (logprob != nullptr) logprob[row] = (use2 ? t.v2 : t.v1) - (m + logf(s));
+    }
+}
+
+__global__ __launch_bounds__(WG) void nll_fwd_kernel(const float* logp, const int64_t* target, const float* w, int M, int V,
+                                                     float* loss_sum) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int m = threadIdx.x; m < M; m += WG) {
+        const float wm = w[m];
+        if (wm != 0.f) s -= wm * logp[(size_t)m * V + target[m]];
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) loss_sum[0] += s;
+}
+
+__global__ __launch_bounds__(WG) void nll_logsoftmax_bwd_kernel(const float* logp, const int64_t* target, const float* w,
+                                                                float scale, int V, float* d_logits) {
+    const int m = blockIdx.y;
+    const int v = blockIdx.x * WG + threadIdx.x;
+    if (v >= V) return;
+    const float g = scale * w[m];
+    const size_t o = (size_t)m * V + v;
+    d_logits[o] = g == 0.f ? 0.f : g * (expf(logp[o]) - (v == (int)target[m] ? 1.f : 0.f));
+}
+
+// ------------------------------------------------------------------ LSTM pointwise backward
+__global__ __launch_bounds__(WG) void lstm_pointwise_bwd_kernel(const float* d_h, const float* d_c, const float* gates,
+                                                                const float* c_prev, const float* c_new, int M, int R,
+                                                                float* d_gates, float* d_c_prev) {
+    const int j = blockIdx.x * WG + threadIdx.x;
+    const int m = blockIdx.y;
+    if (j >= R) return;
+    const size_t o = (size_t)m * R + j, g0 = (size_t)m * 4 * R + j;
+    const float ig = gates[g0], fg = gates[g0 + R], gg = gates[g0 + 2 * R], og = gates[g0 + 3 * R];
+    const float tc = tanhf(c_new[o]);
+    const float dh = d_h != nullptr ? d_h[o] : 0.f;
+    const float dcn = (d_c != nullptr ? d_c[o] : 0.f) + dh * og * (1.f - tc * tc);
+    d_gates[g0] = dcn * gg * ig * (1.f - ig);
+    d_gates[g0 + R] = dcn * c_prev[o] * fg * (1.f - fg);
+    d_gates[g0 + 2 * R] = dcn * ig * (1.f - gg * gg);
+    d_gates[g0 + 3 * R] = dh * tc * og * (1.f - og);
+    d_c_prev[o] = dcn * fg;
+}
+
+// ------------------------------------------------------------------ beam bookkeeping
+// One workgroup per clip.  Candidate (k, v) scores: score[k] + logit[k,v] - lse[k]; -inf for
+// v == unk; a finished hypothesis only offers (k, 0) at its carried score.
+__global__ __launch_bounds__(WG) void beam_select_kernel(const float* logits, const float* score_in, const uint8_t* done_in,
+                                                         int beam, int V, int unk, int first_step, int64_t* parent,
+                                                         int64_t* word, float* score_out, uint8_t* done_out) {
+    __shared__ float red[4];
+    __shared__ float lse[16];
+    __shared__ float bestv[4];
+    __shared__ int besti[4];
+    __shared__ int chosen[16];
+    const int b = blockIdx.x;
+    const float* x = logits + (size_t)b * beam * V;
+    for (int k = 0; k < beam; ++k) {
+        float m = -INFINITY;
+        for (int v = threadIdx.x; v < V; v += WG) m = fmaxf(m, x[(size_t)k * V + v]);
+        m = block_max(m, red);
+        float s = 0.f;
+        for (int v = threadIdx.x; v < V; v += WG) s += expf(x[(size_t)k * V + v] - m);
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) lse[k] = m + logf(s);
+    }
+    __syncthreads();
+    const int total = beam * V;
+    for (int sel = 0; sel < beam; ++sel) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int c = threadIdx.x; c < total; c += WG) {
+            const int k = c / V, v = c - k * V;
+            float sc = score_in[b * beam + k];
+            if (first_step && k > 0) sc = -INFINITY;
+            float cand;
+            if (done_in[b * beam + k]) cand = v == 0 ? sc : -INFINITY;
+            else cand = v == unk ? -INFINITY : sc + (x[c] - lse[k]);
+            bool taken = false;
+            for (int t = 0; t < sel; ++t) taken |= chosen[t] == c;
+            if (!taken && better(cand, c, bv, bi)) { bv = cand; bi = c; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        __syncthreads();
+        if (lane == 0) { bestv[wave] = bv; besti[wave] = bi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (better(bestv[w], besti[w], bv, bi)) { bv = bestv[w]; bi = besti[w]; }
+            chosen[sel] = bi;
+            const int k = bi / V, v = bi - k * V;
+            parent[b * beam + sel] = k;
+            word[b * beam + sel] = v;
+            score_out[b * beam + sel] = bv;
+            done_out[b * beam + sel] = (done_in[b * beam + k] != 0 || v == 0) ? 1 : 0;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(WG) void gather_rows_kernel(const float* src, const int64_t* parent, int beam, int width,
+                                                         float* dst) {
+    const int r = blockIdx.y;
+    const int c = (blockIdx.x * WG + threadIdx.x) * 4;
+    if (c >= width) return;
+    const size_t s = (size_t)((r / beam) * beam + (int)parent[r]) * width + c;
+    st4(dst + (size_t)r * width + c, ld4(src + s));
+}
+
+}  // namespace
+
+extern "C" const char* cvc_version(void) { return "cvc_hip 0.1 gfx950"; }
+
+extern "C" int cvc_embed_relu_fwd(const float* table, const int64_t* idx, const float* drop, int M, int E, float* out,
+                                  cvc_stream_t stream) {
+    if (!table || !idx || !out || M < 1 || E < 4 || (E & 3)) return CVC_E_BADARG;
+    hipLaunchKernelGGL(embed_relu_fwd_kernel, dim3((E / 4 + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, table, idx,
+                       drop, M, E, out);
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_embed_relu_bwd(const float* table, const int64_t* idx, const float* drop, const float* d_out, int M,
+                                  int E, float* d_table, cvc_stream_t stream) {
+    if (!table || !idx || !d_out || !d_table || M < 1 || E < 1) return CVC_E_BADARG;
+    hipLaunchKernelGGL(embed_relu_bwd_kernel, dim3((E + WG - 1) / WG), dim3(WG), 0, (hipStream_t)stream, table, idx, drop,
+                       d_out, M, E, d_table);
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_log_softmax_fwd(const float* logits, int M, int V, float* logp, cvc_stream_t stream) {
+    if (!logits || !logp || M < 1 || V < 1) return CVC_E_BADARG;
+    hipLaunchKernelGGL(log_softmax_kernel, dim3(M), dim3(WG), 0, (hipStream_t)stream, logits, V, logp);
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_log_softmax_bwd(const float* logp, const float* d_logp, int M, int V, float* d_logits,
+                                   cvc_stream_t stream) {
+    if (!logp || !d_logp || !d_logits || M < 1 || V < 1) return CVC_E_BADARG;
+    hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3(M), dim3(WG), 0, (hipStream_t)stream, logp, d_logp, V, d_logits);
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_nll_bwd(const int64_t* target, const float* w, const float* g, int M, int V, float* d_logp,
+                           cvc_stream_t stream) {
+    if (!target || !w || !g || !d_logp || M < 1 || V < 1) return CVC_E_BADARG;
+    hipLaunchKernelGGL(nll_bwd_kernel, dim3((V + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, target, w, g, V, d_logp);
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_top2_unk(const float* logits, int M, int V, int unk_idx, int64_t* word, int word_stride,
+                            float* logprob, cvc_stream_t stream) {
+    if (!logits || !word || M < 1 || V < 1 || word_stride < 1) return CVC_E_BADARG;
+    hipLaunchKernelGGL(top2_unk_kernel, dim3(M), dim3(WG), 0, (hipStream_t)stream, logits, V, unk_idx, word, word_stride,
+                       logprob);
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_nll_fwd(const float* logp, const int64_t* target, const float* w, int M, int V, float* loss_sum,
+                           cvc_stream_t stream) {
+    if (!logp || !target || !w || !loss_sum || M < 1 || V < 1) return CVC_E_BADARG;
+    hipLaunchKernelGGL(nll_fwd_kernel, dim3(1), dim3(WG), 0, (hipStream_t)stream, logp, target, w, M, V, loss_sum);
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_nll_logsoftmax_bwd(const float* logp, const int64_t* target, const float* w, float scale, int M, int V,
+                                      float* d_logits, cvc_stream_t stream) {
+    if (!logp || !target || !w || !d_logits || M < 1 || V < 1) return CVC_E_BADARG;
+    hipLaunchKernelGGL(nll_logsoftmax_bwd_kernel, dim3((V + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, logp,
+                       target, w, scale, V, d_logits);
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_lstm_pointwise_bwd(const float* d_h, const float* d_c, const float* gates, const float* c_prev,
+                                      const float* c_new, int M, int R, float* d_gates, float* d_c_prev,
+                                      cvc_stream_t stream) {
+    if (!gates || !c_prev || !c_new || !d_gates || !d_c_prev || M < 1 || R < 1) return CVC_E_BADARG;
+    hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3((R + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, d_h, d_c,
+                       gates, c_prev, c_new, M, R, d_gates, d_c_prev);
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_beam_select(const float* logits, const float* score_in, const uint8_t* done_in, int B, int beam, int V,
+                               int unk_idx, int first_step, int64_t* parent, int64_t* word, float* score_out,
+                               uint8_t* done_out, cvc_stream_t stream) {
+    if (!logits || !score_in || !done_in || !parent || !word || !score_out || !done_out) return CVC_E_BADARG;
+    if (B < 1 || beam < 1 || beam > 16 || V < 1 || (long long)beam * V > 0x7ffffff0LL) return CVC_E_BADARG;
+    hipLaunchKernelGGL(beam_select_kernel, dim3(B), dim3(WG), 0, (hipStream_t)stream, logits, score_in, done_in, beam, V,
+                       unk_idx, first_step, parent, word, score_out, done_out);
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_gather_rows(const float* src, const int64_t* parent, int rows, int beam, int width, float* dst,
+                               cvc_stream_t stream) {
+    if (!src || !parent || !dst || rows < 1 || beam < 1 || width < 4 || (width & 3)) return CVC_E_BADARG;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((width / 4 + WG - 1) / WG, rows), dim3(WG), 0, (hipStream_t)stream, src,
+                       parent, beam, width, dst);
+    return cvc_launch_status();
+}

@@ -1,0 +1,215 @@
+"""Inference decode driver: the T-step greedy / beam caption loop as a flat, pre-bound list of
+kernel launches (reference model/captioner.py:384-443, `_sample`).
+
+Per step (7 launches, nothing returns to the host, no allocation):
+  att-LSTM  : concat-GEMM over [h_lang(t-1) | fc | relu(Emb[word])] + h_att(t-1), fused cell update
+  h2attn    : q = W_h h_att + b_h
+  attention : score pass over p_pool/p_conv, softmax + weighted-sum pass over pool/conv
+  lang-LSTM : concat-GEMM over [ctx_regions + ctx_frames | h_att] + h_lang(t-1), fused cell update
+  logits    : W_o h_lang + b_o
+  word      : top-2 with UNK suppression (greedy) or beam selection + state gather
+The whole loop can be captured once into a HIP graph (torch.cuda.CUDAGraph) and replayed.
+Dropout is inactive (model.eval(), trainer.py:158).  State buffers ping-pong so that no kernel
+writes a tensor another workgroup of the same launch still reads.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from . import hip
+
+
+class DecodeWeights:
+    """Flat views of the hot-path parameters under the reference's state_dict names."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], softattn_type: str = "additive"):
+        g = lambda k: sd[k].detach().contiguous()
+        self.w_ih_att, self.w_hh_att = g("decoder_core.att_lstm.weight_ih"), g("decoder_core.att_lstm.weight_hh")
+        self.b_ih_att, self.b_hh_att = g("decoder_core.att_lstm.bias_ih"), g("decoder_core.att_lstm.bias_hh")
+        self.w_ih_lang, self.w_hh_lang = g("decoder_core.lang_lstm.weight_ih"), g("decoder_core.lang_lstm.weight_hh")
+        self.b_ih_lang, self.b_hh_lang = g("decoder_core.lang_lstm.bias_ih"), g("decoder_core.lang_lstm.bias_hh")
+        self.w_h, self.b_h = g("decoder_core.soft_attn.h2attn.weight"), g("decoder_core.soft_attn.h2attn.bias")
+        self.kind = hip.ATTN_ADDITIVE if softattn_type == "additive" else hip.ATTN_DOT
+        if self.kind == hip.ATTN_ADDITIVE:
+            self.w_a = g("decoder_core.soft_attn.alpha_net.weight").reshape(-1)
+            self.b_a = g("decoder_core.soft_attn.alpha_net.bias")
+        else:
+            self.w_a = self.b_a = None
+        self.embed = g("embed.0.weight")
+        self.w_o, self.b_o = g("logit.weight"), g("logit.bias")
+        self.R = self.w_hh_att.shape[1]
+        self.A = self.w_h.shape[0]
+        self.E = self.embed.shape[1]
+        self.V = self.w_o.shape[0]
+        for t in vars(self).values():
+            if isinstance(t, torch.Tensor) and (not t.is_cuda or t.dtype != torch.float32):
+                raise RuntimeError("DecodeWeights: parameters must be fp32 tensors on the GPU (no CPU fallback)")
+
+
+def _segs(items):
+    arr = (hip.GemmSeg * len(items))()
+    for i, (x, idx, w, relu) in enumerate(items):
+        arr[i] = hip.GemmSeg(x.data_ptr(), None if idx is None else idx.data_ptr(), w.data_ptr(), w.shape[1], x.stride(0),
+                             w.stride(0), 1 if relu else 0)
+    return arr
+
+
+class DecodeEngine:
+    """Binds weights + one batch of clip features to preallocated state and a launch list."""
+
+    def __init__(self, weights: DecodeWeights, feats: Dict[str, torch.Tensor], T: int, unk_idx: int, beam: int = 1,
+                 inv_temp: float = 1.0):
+        W = self.W = weights
+        self.T, self.unk, self.beam = int(T), int(unk_idx), int(beam)
+        fc, conv, pconv = feats["fc_feats"], feats["conv_feats"], feats["p_conv_feats"]
+        pool, ppool = feats["pool_feats"], feats["p_pool_feats"]
+        mask = feats["pnt_mask"][:, 1:] if feats["pnt_mask"].shape[1] == pool.shape[1] + 1 else feats["pnt_mask"]
+        self.B, self.N, self.F = pool.shape[0], pool.shape[1], conv.shape[1]
+        B, N, Fr, R, A, V = self.B, self.N, self.F, W.R, W.A, W.V
+        dev = pool.device
+        for name, t, shape in (("fc_feats", fc, (B, R)), ("conv_feats", conv, (B, Fr, R)), ("p_conv_feats", pconv, (B, Fr, A)),
+                               ("pool_feats", pool, (B, N, R)), ("p_pool_feats", ppool, (B, N, A))):
+            if tuple(t.shape) != shape:
+                raise RuntimeError(f"DecodeEngine: {name} has shape {tuple(t.shape)}, expected {shape}")
+            hip._dev(t, name=name)
+        self.mask = hip._mask(mask)
+        self.feats = (fc, conv, pconv, pool, ppool)
+        rows = self.rows = B * self.beam
+        f32 = dict(device=dev, dtype=torch.float32)
+        z = lambda *s: torch.zeros(*s, **f32)
+        # ping-pong recurrent state: index t & 1 is read, (t+1) & 1 is written
+        self.h_att, self.c_att = [z(rows, R), z(rows, R)], [z(rows, R), z(rows, R)]
+        self.h_lang, self.c_lang = [z(rows, R), z(rows, R)], [z(rows, R), z(rows, R)]
+        self.q = z(rows, A)
+        self.scores_r, self.scores_f = z(rows, N), z(rows, Fr)
+        self.attn_f = z(rows, Fr)
+        self.ctx_sum = z(rows, R)
+        self.logits = z(rows, V)
+        self.att_steps = z(self.T, rows, N)                       # post-softmax region attention per step
+        self.words = torch.zeros(self.T + 1, rows, dtype=torch.int64, device=dev)   # words[0] = BOS = 0
+        self.logprob = z(self.T, rows)
+        # fc is per clip; beams of a clip read the same row through a row-gather index
+        self.fc = fc
+        self.clip_of_row = torch.arange(rows, device=dev, dtype=torch.int64) // self.beam
+        if self.beam > 1:
+            self.score = z(2, rows)
+            self.done = torch.zeros(2, rows, dtype=torch.uint8, device=dev)
+            self.parent = torch.zeros(self.T, rows, dtype=torch.int64, device=dev)
+            self.gather_tmp = [z(rows, R) for _ in range(4)]
+        self.inv_temp = float(inv_temp)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self._keep: List = []
+        self._launches = self._build()
+
+    # ------------------------------------------------------------------ launch list
+    def _build(self):
+        L, W = hip.lib(), self.W
+        B, N, Fr, R, A, E, V, rows, beam = self.B, self.N, self.F, W.R, W.A, W.E, W.V, self.rows, self.beam
+        fc, conv, pconv, pool, ppool = self.feats
+        ptr = lambda t: None if t is None else t.data_ptr()
+        out = []
+        for t in range(self.T):
+            rd, wr = t & 1, (t + 1) & 1
+            # att-LSTM: [h_lang(t-1) | fc | relu(Emb[word_t])] x W_ih  +  h_att(t-1) x W_hh
+            seg_att = _segs([(self.h_lang[rd], None, W.w_ih_att[:, 0:R], False),
+                             (fc, self.clip_of_row if beam > 1 else None, W.w_ih_att[:, R:2 * R], False),
+                             (W.embed, self.words[t], W.w_ih_att[:, 2 * R:2 * R + E], True),
+                             (self.h_att[rd], None, W.w_hh_att, False)])
+            out.append((L.cvc_lstm_cell_fwd, (seg_att, 4, ptr(W.b_ih_att), ptr(W.b_hh_att), ptr(self.c_att[rd]), rows, R,
+                                              ptr(self.h_att[wr]), ptr(self.c_att[wr]), None)))
+            seg_q = _segs([(self.h_att[wr], None, W.w_h, False)])
+            out.append((L.cvc_linear_fwd, (seg_q, 1, ptr(W.b_h), None, rows, A, ptr(self.q), A)))
+            sets = (hip.AttnSet * 2)()
+            sets[0] = hip.AttnSet(ptr(ppool), ptr(pool), ptr(self.mask), None, ptr(self.scores_r), None,
+                                  ptr(self.att_steps[t]), None, N)
+            sets[1] = hip.AttnSet(ptr(pconv), ptr(conv), None, None, ptr(self.scores_f), None, ptr(self.attn_f), None, Fr)
+            out.append((L.cvc_attn_fwd, (W.kind, ptr(self.q), ptr(W.w_a), ptr(W.b_a), self.inv_temp, sets, 2, B, beam, A, R,
+                                         ptr(self.ctx_sum))))
+            seg_lang = _segs([(self.ctx_sum, None, W.w_ih_lang[:, 0:R], False),
+                              (self.h_att[wr], None, W.w_ih_lang[:, R:2 * R], False),
+                              (self.h_lang[rd], None, W.w_hh_lang, False)])
+            out.append((L.cvc_lstm_cell_fwd, (seg_lang, 3, ptr(W.b_ih_lang), ptr(W.b_hh_lang), ptr(self.c_lang[rd]), rows, R,
+                                              ptr(self.h_lang[wr]), ptr(self.c_lang[wr]), None)))
+            seg_o = _segs([(self.h_lang[wr], None, W.w_o, False)])
+            out.append((L.cvc_linear_fwd, (seg_o, 1, ptr(W.b_o), None, rows, V, ptr(self.logits), V)))
+            if beam == 1:
+                out.append((L.cvc_top2_unk, (ptr(self.logits), rows, V, self.unk, ptr(self.words[t + 1]), 1,
+                                             ptr(self.logprob[t]))))
+            else:
+                srd, swr = t & 1, (t + 1) & 1
+                out.append((L.cvc_beam_select, (ptr(self.logits), ptr(self.score[srd]), ptr(self.done[srd]), B, beam, V,
+                                                self.unk, 1 if t == 0 else 0, ptr(self.parent[t]), ptr(self.words[t + 1]),
+                                                ptr(self.score[swr]), ptr(self.done[swr]))))
+                # reorder the freshly written state rows by parent (gather into tmp, copy back)
+                for i, buf in enumerate((self.h_att[wr], self.c_att[wr], self.h_lang[wr], self.c_lang[wr])):
+                    out.append((L.cvc_gather_rows, (ptr(buf), ptr(self.parent[t]), rows, beam, R, ptr(self.gather_tmp[i]))))
+                    out.append(("copy", (buf, self.gather_tmp[i])))
+            self._keep += [seg_att, seg_q, sets, seg_lang, seg_o]
+        return out
+
+    def _reset(self):
+        for bufs in (self.h_att, self.c_att, self.h_lang, self.c_lang):
+            bufs[0].zero_()
+        self.words[0].zero_()
+        if self.beam > 1:
+            self.score.zero_()
+            self.done.zero_()
+
+    def _run_launches(self):
+        stream = torch.cuda.current_stream().cuda_stream
+        for fn, args in self._launches:
+            if fn == "copy":
+                args[0].copy_(args[1])
+                continue
+            rc = fn(*args, stream)
+            if rc != 0:
+                hip._check(rc, fn.__name__)
+
+    def capture(self):
+        """Capture the T-step loop into a HIP graph (launch-bound inner loop -> one replay)."""
+        self._reset()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._run_launches()          # warm-up outside capture (module load, lazy init)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._reset()
+            self._run_launches()
+        self.graph = g
+        return self
+
+    def run(self):
+        """One full T-step decode.  Returns (seq [B,T] int64, att2_weights [B,T,N]) -- views of
+        engine-owned buffers (clone to keep across runs)."""
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._reset()
+            self._run_launches()
+        if self.beam == 1:
+            return self.words[1:].t(), self.att_steps.permute(1, 0, 2)
+        return self._backtrack()
+
+    def _backtrack(self):
+        """Rank-0 hypothesis of every clip: follow parent pointers from the last step."""
+        B, beam, T, N = self.B, self.beam, self.T, self.N
+        words = self.words[1:].view(T, B, beam)
+        parent = self.parent.view(T, B, beam)
+        att = self.att_steps.view(T, B, beam, N)
+        k = torch.zeros(B, dtype=torch.int64, device=words.device)
+        ar = torch.arange(B, device=words.device)
+        seq, atts = [], []
+        for t in range(T - 1, -1, -1):
+            seq.append(words[t, ar, k])
+            k_parent = parent[t, ar, k]
+            atts.append(att[t, ar, k_parent])     # attention was computed for the parent row at step t
+            k = k_parent
+        seq.reverse()
+        atts.reverse()
+        final_scores = self.score[self.T & 1].view(B, beam)
+        return torch.stack(seq, 1), torch.stack(atts, 1), final_scores

@@ -1,0 +1,287 @@
+"""Autograd-aware ops of the caption-decode hot path, each backed by the HIP kernels in
+libcvc_hip.so (cvc.hip).  Forward passes and the fused / recomputing backward passes are
+hand-written kernels; the backward's plain dense GEMMs (dX = dY W, dW = dY^T X) go to the
+vendor library through torch.mm (rocBLAS/hipBLASLt), which is what those are for.
+
+No CPU path: every op raises if handed CPU tensors (cvc.hip._dev).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import hip
+
+Tensor = torch.Tensor
+
+
+def _c(t: Optional[Tensor]) -> Optional[Tensor]:
+    return None if t is None else t.contiguous()
+
+
+# ------------------------------------------------------------------------------- linear
+class _Linear(torch.autograd.Function):
+    """y = cat(xs) W^T + b with the concat virtual (nn.Linear over torch.cat)."""
+
+    @staticmethod
+    def forward(ctx, weight: Tensor, bias: Optional[Tensor], *xs: Tensor):
+        xs = [_c(x) for x in xs]
+        M = xs[0].shape[0]
+        segs, k0 = [], 0
+        for x in xs:
+            segs.append({"x": x, "w": weight[:, k0:k0 + x.shape[1]]})
+            k0 += x.shape[1]
+        assert k0 == weight.shape[1], (k0, weight.shape)
+        y = hip.linear_fwd(segs, bias, M, weight.shape[0])
+        ctx.save_for_backward(weight, *xs)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        weight, *xs = ctx.saved_tensors
+        dy = dy.contiguous()
+        d_w = d_b = None
+        if ctx.needs_input_grad[0]:
+            d_w = torch.mm(dy.t(), torch.cat(xs, 1) if len(xs) > 1 else xs[0])
+        if ctx.has_bias and ctx.needs_input_grad[1]:
+            d_b = dy.sum(0)
+        d_xs, k0 = [], 0
+        for i, x in enumerate(xs):
+            k = x.shape[1]
+            d_xs.append(torch.mm(dy, weight[:, k0:k0 + k]) if ctx.needs_input_grad[2 + i] else None)
+            k0 += k
+        return (d_w, d_b, *d_xs)
+
+
+def linear(xs, weight: Tensor, bias: Optional[Tensor] = None) -> Tensor:
+    if isinstance(xs, Tensor):
+        xs = [xs]
+    lead = xs[0].shape[:-1]
+    if len(lead) != 1:
+        xs = [x.reshape(-1, x.shape[-1]) for x in xs]
+    y = _Linear.apply(weight, bias, *xs)
+    return y if len(lead) == 1 else y.reshape(*lead, -1)
+
+
+# ------------------------------------------------------------------------------- LSTM cell
+class _LstmCell(torch.autograd.Function):
+    """nn.LSTMCell over a virtual concat of input segments (decoder_core.py:45-50, 59-61)."""
+
+    @staticmethod
+    def forward(ctx, w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, *xs):
+        xs = [_c(x) for x in xs]
+        h_prev, c_prev = _c(h_prev), _c(c_prev)
+        segs, k0 = [], 0
+        for x in xs:
+            segs.append({"x": x, "w": w_ih[:, k0:k0 + x.shape[1]]})
+            k0 += x.shape[1]
+        assert k0 == w_ih.shape[1], ("LSTM input width mismatch", k0, tuple(w_ih.shape))
+        segs.append({"x": h_prev, "w": w_hh})
+        need_bwd = any(ctx.needs_input_grad)
+        h, c, gates = hip.lstm_cell_fwd(segs, b_ih, b_hh, c_prev, want_gates=need_bwd)
+        if need_bwd:
+            ctx.save_for_backward(w_ih, w_hh, h_prev, c_prev, c, gates, *xs)
+        return h, c
+
+    @staticmethod
+    def backward(ctx, d_h, d_c):
+        w_ih, w_hh, h_prev, c_prev, c_new, gates, *xs = ctx.saved_tensors
+        d_gates, d_c_prev = hip.lstm_pointwise_bwd(_c(d_h), _c(d_c), gates, c_prev, c_new)
+        ni = ctx.needs_input_grad
+        d_w_ih = torch.mm(d_gates.t(), torch.cat(xs, 1) if len(xs) > 1 else xs[0]) if ni[0] else None
+        d_w_hh = torch.mm(d_gates.t(), h_prev) if ni[1] else None
+        d_b = d_gates.sum(0) if (ni[2] or ni[3]) else None
+        d_h_prev = torch.mm(d_gates, w_hh) if ni[4] else None
+        d_xs, k0 = [], 0
+        for i, x in enumerate(xs):
+            k = x.shape[1]
+            d_xs.append(torch.mm(d_gates, w_ih[:, k0:k0 + k]) if ni[6 + i] else None)
+            k0 += k
+        return (d_w_ih, d_w_hh, d_b if ni[2] else None, d_b if ni[3] else None, d_h_prev,
+                d_c_prev if ni[5] else None, *d_xs)
+
+
+def lstm_cell(xs: Sequence[Tensor], h_prev: Tensor, c_prev: Tensor, w_ih, w_hh, b_ih, b_hh) -> Tuple[Tensor, Tensor]:
+    return _LstmCell.apply(w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, *xs)
+
+
+# ------------------------------------------------------------------------------- attention
+class _Attention(torch.autograd.Function):
+    """Soft attention over 1 or 2 feature sets sharing the query (modules.py:24-159).
+
+    outputs: ctx_total [rows,R] (sum over sets), then per set: ctx_s, attn_s, frame_masked_s
+    (frame_masked_s is a dummy 0-d tensor when no proposal_frame_mask was given)."""
+
+    @staticmethod
+    def forward(ctx, kind: int, inv_temp: float, nq: int, masks, q, w_a, b_a, *feats):
+        nsets = len(feats) // 2
+        q = _c(q)
+        nclip = feats[0].shape[0]
+        sets = []
+        for s in range(nsets):
+            m, fmk = masks[s]
+            sets.append({"proj": _c(feats[2 * s]), "ctx": _c(feats[2 * s + 1]), "mask": m, "frame_mask": fmk})
+        w_flat = None if w_a is None else w_a.reshape(-1)
+        outs, ctx_sum = hip.attn_fwd(kind, q, w_flat, b_a, inv_temp, sets, nclip, nq, want_ctx=True, want_sum=nsets > 1)
+        ctx.kind, ctx.inv_temp, ctx.nq, ctx.nsets, ctx.nclip = kind, inv_temp, nq, nsets, nclip
+        ctx.save_for_backward(q, w_a, *[t for s in sets for t in (s["proj"], s["ctx"])], *[o[2] for o in outs])
+        ctx.set_materialize_grads(False)
+        res = [ctx_sum if nsets > 1 else outs[0][3]]
+        non_diff = []
+        for (scores, fm, attn, ctx_out) in outs:
+            fm_out = fm if fm is not None else q.new_zeros(())
+            res += [ctx_out, attn, fm_out]
+            non_diff.append(attn)
+        ctx.mark_non_differentiable(*non_diff)
+        return tuple(res)
+
+    @staticmethod
+    def backward(ctx, d_total, *d_outs):
+        q, w_a, *rest = ctx.saved_tensors
+        nsets = ctx.nsets
+        feats, attns = rest[:2 * nsets], rest[2 * nsets:]
+        ni = ctx.needs_input_grad   # (kind, inv_temp, nq, masks, q, w_a, b_a, *feats)
+        w_flat = None if w_a is None else w_a.reshape(-1)
+        d_q = None
+        d_w = None
+        d_b = None
+        d_feats: List[Optional[Tensor]] = []
+        for s in range(nsets):
+            d_ctx_s, _d_attn, d_fm = d_outs[3 * s], d_outs[3 * s + 1], d_outs[3 * s + 2]
+            d_ctx = d_ctx_s
+            if d_total is not None:
+                d_ctx = d_total if d_ctx is None else d_ctx + d_total
+            if d_fm is not None and d_fm.dim() == 0:
+                d_fm = None
+            if d_ctx is None and d_fm is None:
+                d_feats += [None, None]
+                continue
+            proj, cfeat = feats[2 * s], feats[2 * s + 1]
+            want_dp, want_dc = ni[7 + 2 * s], ni[8 + 2 * s]
+            same = proj.data_ptr() == cfeat.data_ptr()
+            d_scores, d_q_s, d_w_part, d_proj, d_cf = hip.attn_bwd(
+                ctx.kind, q, w_flat, ctx.inv_temp, proj, cfeat, attns[s], _c(d_ctx), _c(d_fm), ctx.nclip, ctx.nq,
+                want_dp, want_dc, ni[5])
+            d_q = d_q_s if d_q is None else d_q + d_q_s
+            if ctx.kind == hip.ATTN_ADDITIVE:
+                if ni[5]:
+                    dw = d_w_part.sum(0)
+                    d_w = dw if d_w is None else d_w + dw
+                if ni[6]:
+                    db = d_scores.sum().reshape(1)
+                    d_b = db if d_b is None else d_b + db
+            if same and d_proj is not None and d_cf is not None:
+                d_proj = d_proj + d_cf
+                d_cf = None
+            d_feats += [d_proj, d_cf]
+        if d_w is not None:
+            d_w = d_w.reshape(w_a.shape)
+        return (None, None, None, None, d_q if ni[4] else None, d_w, d_b, *d_feats)
+
+
+def attention(kind: int, q: Tensor, w_a: Optional[Tensor], b_a: Optional[Tensor], inv_temp: float,
+              sets: Sequence[Tuple[Tensor, Tensor, Optional[Tensor], Optional[Tensor]]]):
+    """sets: (proj_context, context, mask, proposal_frame_mask) per feature set.
+    Returns (ctx_total, [(ctx_s, attn_s, frame_masked_s or None)])."""
+    nclip = sets[0][0].shape[0]
+    nq = q.shape[0] // nclip
+    assert nq * nclip == q.shape[0], "query rows must be a multiple of the number of clips"
+    masks = tuple((s[2], s[3]) for s in sets)
+    feats = [t for s in sets for t in (s[0], s[1])]
+    res = _Attention.apply(kind, float(inv_temp), nq, masks, q, w_a, b_a, *feats)
+    out = []
+    for i, s in enumerate(sets):
+        c, a, fm = res[1 + 3 * i], res[2 + 3 * i], res[3 + 3 * i]
+        out.append((c, a, fm if s[3] is not None else None))
+    return res[0], out
+
+
+# ------------------------------------------------------------------------------- embedding / vocab head
+class _EmbedRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, table, idx, drop):
+        idx = idx.contiguous()
+        out = hip.embed_relu_fwd(table, idx, drop)
+        ctx.save_for_backward(table, idx, drop if drop is not None else table.new_zeros(()))
+        ctx.has_drop = drop is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        table, idx, drop = ctx.saved_tensors
+        return hip.embed_relu_bwd(table, idx, drop if ctx.has_drop else None, d_out.contiguous()), None, None
+
+
+def embed_relu(table: Tensor, idx: Tensor, drop: Optional[Tensor] = None) -> Tensor:
+    """relu(Embedding(idx)) (* dropout keep-mask / (1-p)), captioner.py:53-68."""
+    shape = idx.shape
+    out = _EmbedRelu.apply(table, idx.reshape(-1), drop)
+    return out.reshape(*shape, -1)
+
+
+class _LogSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = hip.log_softmax_fwd(x.contiguous())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return hip.log_softmax_bwd(y, dy.contiguous())
+
+
+def log_softmax(x: Tensor) -> Tensor:
+    """F.log_softmax(x, dim=-1) for [M, V]."""
+    lead = x.shape[:-1]
+    y = _LogSoftmax.apply(x.reshape(-1, x.shape[-1]))
+    return y.reshape(*lead, -1)
+
+
+class _MaskedNLLSum(torch.autograd.Function):
+    """sum_m w[m] * -logp[m, target[m]]  (misc/utils.py:139-146 before the mean)."""
+
+    @staticmethod
+    def forward(ctx, logp, target, w):
+        logp, target, w = logp.contiguous(), target.contiguous(), w.contiguous()
+        ctx.save_for_backward(target, w)
+        ctx.V = logp.shape[1]
+        return hip.nll_fwd(logp, target, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        target, w = ctx.saved_tensors
+        return hip.nll_bwd(target, w, g.contiguous().reshape(1), ctx.V), None, None
+
+
+def masked_nll_sum(logp: Tensor, target: Tensor, w: Tensor) -> Tensor:
+    return _MaskedNLLSum.apply(logp, target.reshape(-1), w.reshape(-1))
+
+
+class _Grounder(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xt, feats, bias, mask):
+        xt, feats = xt.contiguous(), feats.contiguous()
+        bias = None if bias is None else bias.contiguous()
+        out = hip.grounder_fwd(xt, feats, bias, mask)
+        ctx.save_for_backward(xt, feats, mask if mask is not None else xt.new_zeros((), dtype=torch.bool))
+        ctx.has_mask, ctx.has_bias = mask is not None, bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        xt, feats, mask = ctx.saved_tensors
+        # captioner.py:171 masks with an autograd-visible masked_fill_: no gradient at filled slots
+        d = d_out.masked_fill(mask, 0) if ctx.has_mask else d_out
+        ni = ctx.needs_input_grad
+        d_xt = torch.bmm(d, feats) if ni[0] else None
+        d_feats = torch.bmm(d.transpose(1, 2), xt) if ni[1] else None
+        return d_xt, d_feats, d if (ctx.has_bias and ni[2]) else None, None
+
+
+def grounder(xt: Tensor, feats: Tensor, bias: Optional[Tensor], mask: Optional[Tensor]) -> Tensor:
+    """captioner.py:132-173, dot-product branch."""
+    return _Grounder.apply(xt, feats, bias, mask)

@@ -1,0 +1,301 @@
+"""ctypes binding of libcvc_hip.so (include/cvc_hip.h) -- the only door between the host-side
+module mirrors and the gfx950 kernels.
+
+There is NO CPU fallback: if the library is missing or a tensor is not a contiguous fp32 CUDA
+(ROCm) tensor, calls raise.  PyTorch is used for device memory and streams only; the pointers
+handed over are raw `data_ptr()`s and the current HIP stream handle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcvc_hip.so")
+
+ATTN_ADDITIVE, ATTN_DOT = 0, 1
+
+
+class AttnSet(C.Structure):
+    _fields_ = [("proj", C.c_void_p), ("ctx", C.c_void_p), ("mask", C.c_void_p), ("frame_mask", C.c_void_p),
+                ("scores", C.c_void_p), ("frame_masked", C.c_void_p), ("attn", C.c_void_p), ("ctx_out", C.c_void_p),
+                ("n", C.c_int)]
+
+
+class GemmSeg(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("idx", C.c_void_p), ("w", C.c_void_p),
+                ("k", C.c_int), ("ldx", C.c_int), ("ldw", C.c_int), ("relu", C.c_int)]
+
+
+_P, _I, _F = C.c_void_p, C.c_int, C.c_float
+# name -> argtypes, exactly the declarations of include/cvc_hip.h (tests/test_cabi.py checks both)
+SIGNATURES = {
+    "cvc_attn_fwd": [_I, _P, _P, _P, _F, C.POINTER(AttnSet), _I, _I, _I, _I, _I, _P, _P],
+    "cvc_attn_bwd": [_I, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "cvc_linear_fwd": [C.POINTER(GemmSeg), _I, _P, _P, _I, _I, _P, _I, _P],
+    "cvc_lstm_cell_fwd": [C.POINTER(GemmSeg), _I, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "cvc_lstm_pointwise_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
+    "cvc_embed_relu_fwd": [_P, _P, _P, _I, _I, _P, _P],
+    "cvc_embed_relu_bwd": [_P, _P, _P, _P, _I, _I, _P, _P],
+    "cvc_log_softmax_fwd": [_P, _I, _I, _P, _P],
+    "cvc_log_softmax_bwd": [_P, _P, _I, _I, _P, _P],
+    "cvc_nll_bwd": [_P, _P, _P, _I, _I, _P, _P],
+    "cvc_top2_unk": [_P, _I, _I, _I, _P, _I, _P, _P],
+    "cvc_nll_fwd": [_P, _P, _P, _I, _I, _P, _P],
+    "cvc_nll_logsoftmax_bwd": [_P, _P, _P, _F, _I, _I, _P, _P],
+    "cvc_grounder_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "cvc_beam_select": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "cvc_gather_rows": [_P, _P, _I, _I, _I, _P, _P],
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libcvc_hip.so (built by build_hip.py / __graft_entry__.build()).  Fails loudly."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python cyclical-visual-captioning_amd/build_hip.py` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the caption-decode hot path.")
+        l = C.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.argtypes = argtypes
+            fn.restype = C.c_int
+        l.cvc_version.restype = C.c_char_p
+        l.cvc_version.argtypes = []
+        _lib = l
+    return _lib
+
+
+def version() -> str:
+    return lib().cvc_version().decode()
+
+
+def _check(rc: int, name: str):
+    if rc != 0:
+        kind = {-1: "bad argument (size/alignment precondition)", -2: "dimension not covered by the kernel templates"}.get(
+            rc, f"hipError_t {rc}")
+        raise RuntimeError(f"{name} failed: {kind}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: Optional[torch.Tensor], dtype=torch.float32, name="tensor") -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"cvc.hip: {name} must live on the GPU (no CPU fallback for the hot path)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"cvc.hip: {name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"cvc.hip: {name} must be contiguous")
+    return t.data_ptr()
+
+
+def _mask(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """bool / uint8 mask -> contiguous uint8 view (one byte per element)."""
+    if t is None:
+        return None
+    if t.dtype == torch.bool:
+        t = t.contiguous().view(torch.uint8)
+    elif t.dtype != torch.uint8:
+        t = (t != 0).contiguous().view(torch.uint8)
+    return t.contiguous()
+
+
+# --------------------------------------------------------------------------- attention
+def attn_fwd(kind: int, q: torch.Tensor, w_a: Optional[torch.Tensor], b_a: Optional[torch.Tensor], inv_temp: float,
+             sets: Sequence[dict], nclip: int, nq: int, want_ctx: bool = True, want_sum: bool = False):
+    """sets: dicts with proj [nclip,n,A], ctx [nclip,n,R], mask, frame_mask.  Returns
+    ([(scores, frame_masked, attn, ctx_out)], ctx_sum)."""
+    rows, A = q.shape
+    assert rows == nclip * nq
+    R = sets[0]["ctx"].shape[2]
+    arr = (AttnSet * len(sets))()
+    outs, keep = [], []
+    for i, s in enumerate(sets):
+        n = s["proj"].shape[1]
+        assert s["proj"].shape == (nclip, n, A) and s["ctx"].shape == (nclip, n, R), (s["proj"].shape, s["ctx"].shape)
+        m, fmk = _mask(s.get("mask")), _mask(s.get("frame_mask"))
+        if m is not None:
+            assert m.shape == (nclip, n)
+        if fmk is not None:
+            assert fmk.shape == (rows, n)
+        scores = torch.empty(rows, n, device=q.device, dtype=torch.float32)
+        attn = torch.empty_like(scores)
+        fm = torch.empty_like(scores) if fmk is not None else None
+        ctx_out = torch.empty(rows, R, device=q.device, dtype=torch.float32) if want_ctx else None
+        arr[i] = AttnSet(_dev(s["proj"], name="proj"), _dev(s["ctx"], name="ctx"), _dev(m, torch.uint8), _dev(fmk, torch.uint8),
+                         _dev(scores), _dev(fm), _dev(attn), _dev(ctx_out), n)
+        keep += [m, fmk]
+        outs.append((scores, fm, attn, ctx_out))
+    ctx_sum = torch.empty(rows, R, device=q.device, dtype=torch.float32) if want_sum else None
+    _check(lib().cvc_attn_fwd(kind, _dev(q, name="q"), _dev(w_a), _dev(b_a), float(inv_temp), arr, len(sets), nclip, nq, A, R,
+                              _dev(ctx_sum), _stream()), "cvc_attn_fwd")
+    return outs, ctx_sum
+
+
+def attn_bwd(kind: int, q, w_a, inv_temp: float, proj, ctx, attn, d_ctx, d_fm, nclip: int, nq: int,
+             want_d_proj: bool, want_d_ctxfeat: bool, want_d_w: bool):
+    rows, A = q.shape
+    n, R = proj.shape[1], ctx.shape[2]
+    d_scores = torch.empty(rows, n, device=q.device, dtype=torch.float32)
+    d_q = torch.empty_like(q)
+    d_w_part = torch.empty_like(q) if (want_d_w and kind == ATTN_ADDITIVE) else None
+    d_proj = torch.zeros_like(proj) if want_d_proj else None
+    d_ctxfeat = torch.zeros_like(ctx) if (want_d_ctxfeat and d_ctx is not None) else None
+    _check(lib().cvc_attn_bwd(kind, _dev(q), _dev(w_a), float(inv_temp), _dev(proj), _dev(ctx), _dev(attn), _dev(d_ctx),
+                              _dev(d_fm), nclip, nq, n, A, R, _dev(d_scores), _dev(d_q), _dev(d_w_part), _dev(d_proj),
+                              _dev(d_ctxfeat), _stream()), "cvc_attn_bwd")
+    return d_scores, d_q, d_w_part, d_proj, d_ctxfeat
+
+
+# --------------------------------------------------------------------------- skinny GEMM / LSTM cell
+def _segs(segs: Sequence[dict], M: int):
+    """segs: dicts {x: [M,k] (or table with idx), w: [Nout, k] (a column slice is fine), idx, relu}."""
+    arr = (GemmSeg * len(segs))()
+    for i, s in enumerate(segs):
+        x, w = s["x"], s["w"]
+        k = w.shape[1]
+        if x.stride(-1) != 1 or w.stride(-1) != 1:
+            raise RuntimeError("cvc.hip: GEMM segments must have unit inner stride")
+        idx = s.get("idx")
+        if idx is None:
+            assert x.shape[0] == M and x.shape[1] == k, (x.shape, M, k)
+        else:
+            assert idx.shape == (M,) and x.shape[1] == k
+            _dev(idx, torch.int64, "idx")
+        for t_ in (x, w):
+            if not t_.is_cuda or t_.dtype != torch.float32:
+                raise RuntimeError("cvc.hip: GEMM operands must be fp32 GPU tensors (no CPU fallback)")
+        arr[i] = GemmSeg(x.data_ptr(), None if idx is None else idx.data_ptr(), w.data_ptr(), k, x.stride(0), w.stride(0),
+                         1 if s.get("relu") else 0)
+    return arr
+
+
+def linear_fwd(segs: Sequence[dict], bias: Optional[torch.Tensor], M: int, Nout: int, bias2=None, out=None):
+    dev = segs[0]["w"].device
+    y = out if out is not None else torch.empty(M, Nout, device=dev, dtype=torch.float32)
+    arr = _segs(segs, M)
+    _check(lib().cvc_linear_fwd(arr, len(segs), _dev(bias), _dev(bias2), M, Nout, _dev(y), y.stride(0), _stream()),
+           "cvc_linear_fwd")
+    return y
+
+
+def lstm_cell_fwd(segs: Sequence[dict], b_ih, b_hh, c_prev, want_gates: bool = False, h_out=None, c_out=None):
+    M, R = c_prev.shape
+    h = h_out if h_out is not None else torch.empty_like(c_prev)
+    c = c_out if c_out is not None else torch.empty_like(c_prev)
+    gates = torch.empty(M, 4 * R, device=c_prev.device, dtype=torch.float32) if want_gates else None
+    arr = _segs(segs, M)
+    _check(lib().cvc_lstm_cell_fwd(arr, len(segs), _dev(b_ih), _dev(b_hh), _dev(c_prev), M, R, _dev(h), _dev(c), _dev(gates),
+                                   _stream()), "cvc_lstm_cell_fwd")
+    return h, c, gates
+
+
+def lstm_pointwise_bwd(d_h, d_c, gates, c_prev, c_new):
+    M, R = c_prev.shape
+    d_gates = torch.empty_like(gates)
+    d_c_prev = torch.empty_like(c_prev)
+    _check(lib().cvc_lstm_pointwise_bwd(_dev(d_h), _dev(d_c), _dev(gates), _dev(c_prev), _dev(c_new), M, R, _dev(d_gates),
+                                        _dev(d_c_prev), _stream()), "cvc_lstm_pointwise_bwd")
+    return d_gates, d_c_prev
+
+
+# --------------------------------------------------------------------------- embedding / vocabulary head
+def embed_relu_fwd(table, idx, drop=None):
+    M, E = idx.shape[0], table.shape[1]
+    out = torch.empty(M, E, device=table.device, dtype=torch.float32)
+    _check(lib().cvc_embed_relu_fwd(_dev(table), _dev(idx, torch.int64), _dev(drop), M, E, _dev(out), _stream()),
+           "cvc_embed_relu_fwd")
+    return out
+
+
+def embed_relu_bwd(table, idx, drop, d_out):
+    d_table = torch.zeros_like(table)
+    _check(lib().cvc_embed_relu_bwd(_dev(table), _dev(idx, torch.int64), _dev(drop), _dev(d_out), idx.shape[0],
+                                    table.shape[1], _dev(d_table), _stream()), "cvc_embed_relu_bwd")
+    return d_table
+
+
+def log_softmax_fwd(logits, out=None):
+    M, V = logits.shape
+    out = out if out is not None else torch.empty_like(logits)
+    _check(lib().cvc_log_softmax_fwd(_dev(logits), M, V, _dev(out), _stream()), "cvc_log_softmax_fwd")
+    return out
+
+
+def log_softmax_bwd(logp, d_logp):
+    M, V = logp.shape
+    d = torch.empty_like(logp)
+    _check(lib().cvc_log_softmax_bwd(_dev(logp), _dev(d_logp), M, V, _dev(d), _stream()), "cvc_log_softmax_bwd")
+    return d
+
+
+def nll_bwd(target, w, g, V: int):
+    M = target.shape[0]
+    d = torch.empty(M, V, device=w.device, dtype=torch.float32)
+    _check(lib().cvc_nll_bwd(_dev(target, torch.int64), _dev(w), _dev(g), M, V, _dev(d), _stream()), "cvc_nll_bwd")
+    return d
+
+
+def top2_unk(logits, unk_idx: int, word_out: torch.Tensor, word_stride: int = 1, logprob: Optional[torch.Tensor] = None):
+    """word_out: int64 tensor whose element m*word_stride (from its data_ptr) receives row m's word."""
+    M, V = logits.shape
+    assert word_out.dtype == torch.int64 and word_out.is_cuda
+    _check(lib().cvc_top2_unk(_dev(logits), M, V, int(unk_idx), word_out.data_ptr(), int(word_stride), _dev(logprob),
+                              _stream()), "cvc_top2_unk")
+
+
+def nll_fwd(logp, target, w):
+    M, V = logp.shape
+    loss = torch.zeros(1, device=logp.device, dtype=torch.float32)
+    _check(lib().cvc_nll_fwd(_dev(logp), _dev(target, torch.int64), _dev(w), M, V, _dev(loss), _stream()), "cvc_nll_fwd")
+    return loss
+
+
+def nll_logsoftmax_bwd(logp, target, w, scale: float):
+    M, V = logp.shape
+    d = torch.empty_like(logp)
+    _check(lib().cvc_nll_logsoftmax_bwd(_dev(logp), _dev(target, torch.int64), _dev(w), float(scale), M, V, _dev(d),
+                                        _stream()), "cvc_nll_logsoftmax_bwd")
+    return d
+
+
+def grounder_fwd(xt, feats, bias, mask):
+    B, T, G = xt.shape
+    N = feats.shape[1]
+    out = torch.empty(B, T, N, device=xt.device, dtype=torch.float32)
+    m = _mask(mask)
+    _check(lib().cvc_grounder_fwd(_dev(xt), _dev(feats), _dev(bias), _dev(m, torch.uint8), B, T, N, G, _dev(out), _stream()),
+           "cvc_grounder_fwd")
+    return out
+
+
+def beam_select(logits, score_in, done_in, B: int, beam: int, unk_idx: int, first_step: bool):
+    V = logits.shape[1]
+    dev = logits.device
+    parent = torch.empty(B * beam, dtype=torch.int64, device=dev)
+    word = torch.empty(B * beam, dtype=torch.int64, device=dev)
+    score = torch.empty(B * beam, dtype=torch.float32, device=dev)
+    done = torch.empty(B * beam, dtype=torch.uint8, device=dev)
+    _check(lib().cvc_beam_select(_dev(logits), _dev(score_in), _dev(done_in, torch.uint8), B, beam, V, int(unk_idx),
+                                 1 if first_step else 0, parent.data_ptr(), word.data_ptr(), _dev(score),
+                                 _dev(done, torch.uint8), _stream()), "cvc_beam_select")
+    return parent, word, score, done
+
+
+def gather_rows(src, parent, beam: int):
+    rows, width = src.shape
+    dst = torch.empty_like(src)
+    _check(lib().cvc_gather_rows(_dev(src), _dev(parent, torch.int64), rows, beam, width, _dev(dst), _stream()),
+           "cvc_gather_rows")
+    return dst

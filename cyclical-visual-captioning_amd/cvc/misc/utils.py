@@ -1,0 +1,146 @@
+"""Criteria, label glue and small helpers -- the parts of the reference's misc/utils.py the
+caption hot path touches: LMCriterion / LanguageCriterion
+(misc/utils.py:127-192), bbox_overlaps / bbox_target (:335-373), update_values (:58-63),
+decode_sequence (:100-116), AverageMeter (:501-517).  The dead NBT image utilities are not
+reproduced.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import functional as F_
+
+
+def update_values(dict_from, dict_to):
+    """YAML overlay: non-None values of dict_from win, recursively (reference :58-63)."""
+    for key, value in dict_from.items():
+        if isinstance(value, dict):
+            update_values(dict_from[key], dict_to[key])
+        elif value is not None:
+            dict_to[key] = dict_from[key]
+
+
+def decode_sequence(itow, itod, ltow, itoc, wtod, seq, vocab_size, opt):
+    """Word indices -> sentences, stopping at the first 0 (reference :100-116; the unused
+    detection-vocabulary arguments are kept for signature compatibility)."""
+    out = []
+    for row in seq.tolist():
+        words = []
+        for ix in row:
+            if ix == 0:
+                break
+            words.append(itow[str(ix)])
+        # the reference emits a separating blank before it sees the terminating 0
+        txt = ' '.join(words)
+        if len(words) < len(row) and len(words) > 0:
+            txt += ' '
+        out.append(txt)
+    return out
+
+
+def _text_mask(target):
+    m = target.gt(0)
+    return torch.cat([torch.ones_like(m[:, :1]), m[:, :-1]], 1)   # includes the first EOS (:135-137)
+
+
+def _masked_nll_mean(txt_input, target):
+    mask = _text_mask(target)
+    w = mask.reshape(-1).to(torch.float32)
+    total = F_.masked_nll_sum(txt_input, target.reshape(-1), w)
+    count = w.sum()
+    return (total / count).reshape(())
+
+
+class LMCriterion(nn.Module):
+    """reference misc/utils.py:127-172"""
+
+    def __init__(self, opt):
+        super().__init__()
+        self.vocab_size = opt.vocab_size
+
+    def forward(self, txt_input, att2_weights, ground_weights, target, att2_target, input_seq):
+        assert torch.sum(target >= self.vocab_size) == 0
+        loss = _masked_nll_mean(txt_input, target)
+        if att2_target.sum() != 0:
+            # supervised attention / grounding losses (w_att2 = 0 by default)
+            att2_loss = -torch.mean(torch.masked_select(F.log_softmax(att2_weights, dim=2), att2_target))
+            ground_loss = -torch.mean(torch.masked_select(F.log_softmax(ground_weights, dim=2), att2_target))
+        else:
+            att2_loss = torch.zeros(1, device=loss.device)
+            ground_loss = torch.zeros(1, device=loss.device)
+        return loss, att2_loss, ground_loss
+
+
+class LanguageCriterion(nn.Module):
+    """reference misc/utils.py:175-192"""
+
+    def forward(self, txt_input, target):
+        return _masked_nll_mean(txt_input, target)
+
+
+def bbox_overlaps(rois, gt_box, frm_mask):
+    """IoU of proposals [B,N,>=5] vs GT boxes [B,K,>=5] (reference :335-338 ->
+    misc/bbox_transform.py:224-272): +1-pixel convention, zero where frm_mask, 0 for degenerate GT
+    boxes, -1 for degenerate proposals."""
+    a, g = rois[:, :, :4], gt_box[:, :, :4]
+    gx, gy = g[:, :, 2] - g[:, :, 0] + 1, g[:, :, 3] - g[:, :, 1] + 1
+    ax, ay = a[:, :, 2] - a[:, :, 0] + 1, a[:, :, 3] - a[:, :, 1] + 1
+    iw = (torch.min(a[:, :, None, 2], g[:, None, :, 2]) - torch.max(a[:, :, None, 0], g[:, None, :, 0]) + 1).clamp(min=0)
+    ih = (torch.min(a[:, :, None, 3], g[:, None, :, 3]) - torch.max(a[:, :, None, 1], g[:, None, :, 1]) + 1).clamp(min=0)
+    inter = iw * ih
+    ov = inter / ((ax * ay).unsqueeze(2) + (gx * gy).unsqueeze(1) - inter)
+    ov = ov * (~frm_mask).to(ov.dtype)
+    ov = ov.masked_fill(((gx == 1) & (gy == 1)).unsqueeze(1).expand_as(ov), 0)
+    ov = ov.masked_fill(((ax == 1) & (ay == 1)).unsqueeze(2).expand_as(ov), -1)
+    return ov
+
+
+def bbox_target(mask, overlaps, seq, seq_update, vocab_size):
+    """Per-word proposal labels (reference :351-373): proposal n is positive for the word if it
+    overlaps (IoU > 0.5) a GT box that grounds the word.  Also reproduces the (deprecated)
+    seq_update side effect."""
+    B = overlaps.size(0)
+    ov = overlaps.masked_fill(mask.reshape(B, 1, -1).expand_as(overlaps), 0)
+    labels = ov.max(2)[0] > 0.5
+    no_proposal_idx = (labels.sum(1) > 0) != (seq[:, 2] > 0)
+    if no_proposal_idx.sum() > 0:
+        seq_update[:, 0][no_proposal_idx] = seq_update[:, 3][no_proposal_idx]
+        seq_update[:, 1][no_proposal_idx] = 0
+        seq_update[:, 2][no_proposal_idx] = 0
+    return labels
+
+
+class AverageMeter(object):
+    """reference :501-517"""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.val = self.avg = self.sum = self.count = 0
+
+    def update(self, val, n=1):
+        self.val = val
+        self.sum += val * n
+        self.count += n
+        self.avg = self.sum / self.count
+
+
+def set_tb_logger(log_dir, exp_name, resume):
+    """TensorBoard writer if tensorboardX / torch.utils.tensorboard is importable, else None
+    (the reference hard-requires tensorboardX, cycle_utils.py:14-23)."""
+    import os
+    import shutil
+    path = log_dir + '/' + exp_name
+    if not resume and os.path.exists(path):
+        shutil.rmtree(path, ignore_errors=True)
+    try:
+        from tensorboardX import SummaryWriter
+    except ImportError:
+        try:
+            from torch.utils.tensorboard import SummaryWriter
+        except ImportError:
+            return None
+    return SummaryWriter(log_dir=path)

@@ -1,0 +1,243 @@
+"""Decode-and-ground captioner -- drop-in for the reference's model/captioner.py
+(`DecodeAndGroundCaptionerGVDROI`): same constructor, same 11-tensor forward, same
+state_dict keys, same returns (a tuple of [1]-shaped losses in training, `(seq, att2_weights,
+None)` in inference).  What differs is where the arithmetic runs:
+
+* inference (`_sample`, reference :384-443) goes through cvc.decode.DecodeEngine: a flat list of
+  HIP launches per step, no host round trips, optional HIP-graph replay; `beam_size > 1` (which
+  the reference only asserts away, trainer.py:218) is implemented per SURVEY.md section 7;
+* training (`_forward_3_loops`, reference :196-382) runs the same three loops through the
+  autograd ops of cvc.functional, with the localizer loop (no recurrence) and both vocabulary
+  projections batched over T.
+
+The once-per-clip encoder (`roi_extractor`, reference model/backbone.py) is outside the hot path:
+pass any module with the reference extractor's call/return contract (the reference class itself
+works); `PrecomputedRegionFeatures` below feeds pre-extracted features.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import functional as F_
+from ..decode import DecodeEngine, DecodeWeights
+from ..misc import utils
+from .decoder_core import AttenedDecoderCore, TopDownDecoderCore
+from .localizer_core import LocalizerNoLSTMCore
+
+
+class PrecomputedRegionFeatures(nn.Module):
+    """Stand-in for the once-per-clip encoder when features are pre-extracted / pre-projected
+    (the benchmark's input contract).  Owns the two encoder tensors the captioner's grounder
+    reads (`vis_embed.0.weight`, `vis_classifiers_bias`, reference backbone.py:55,140) and
+    returns, in the order of backbone.py:350-351, the feature dict handed in as `segs_feat`."""
+
+    KEYS = ("fc_feats", "conv_feats", "p_conv_feats", "pool_feats", "p_pool_feats", "g_pool_feats", "pnt_mask")
+
+    def __init__(self, detect_size: int, vis_encoding_size: int, drop_prob: float = 0.5):
+        super().__init__()
+        self.vis_embed = nn.Sequential(nn.Embedding(detect_size + 1, vis_encoding_size), nn.ReLU(), nn.Dropout(drop_prob))
+        self.vis_classifiers_bias = nn.Parameter(torch.zeros(detect_size + 1))
+
+    def forward(self, segs_feat, proposals=None, num=None, mask_boxes=None, region_feats=None, gt_boxes=None,
+                overlaps=None, sample_idx=None, eval_obj_ground=False, replicate_feat=True):
+        if not isinstance(segs_feat, dict):
+            raise TypeError("PrecomputedRegionFeatures expects the feature dict as the first model input")
+        f = segs_feat
+        cls_loss = f.get("cls_loss", f["fc_feats"].new_zeros(()))
+        return (f["fc_feats"], f["conv_feats"], f["p_conv_feats"], f["pool_feats"], f["p_pool_feats"], f["g_pool_feats"],
+                f["pnt_mask"], overlaps, None, cls_loss)
+
+
+class DecodeAndGroundCaptionerGVDROI(nn.Module):
+    """reference model/captioner.py:16-443"""
+
+    def __init__(self, opts, pretrained_decoder=None, embed=None, logit=None, roi_extractor=None):
+        super().__init__()
+        self.opts = opts
+        self.vocab_size = opts.vocab_size
+        self.ix_to_word = getattr(opts, "itow", None)
+        if roi_extractor is None:
+            raise ValueError(
+                "roi_extractor is required: the once-per-clip region/frame encoder (reference model/backbone.py) is "
+                "outside the MI355X hot path.  Pass the reference's RegionalFeatureExtractorGVD, or "
+                "cvc.model.captioner.PrecomputedRegionFeatures for pre-extracted features.")
+        self.roi_feat_extractor = roi_extractor
+        self.seq_length = opts.seq_length
+        self.seq_per_img = opts.seq_per_img
+        self.decoder_num_layers = 2
+        self.localizer_num_layers = 1
+        self.rnn_size = opts.rnn_size
+        self.ss_prob = 0.0
+        self.iou_threshold = 0.5
+
+        self.decoder_core = TopDownDecoderCore(opts) if pretrained_decoder is None else pretrained_decoder
+        vocab_rows = opts.vocab_size + 1 if opts.embedding_vocab_plus_1 else opts.vocab_size
+        if embed is None:
+            embed = nn.Sequential(nn.Embedding(vocab_rows, opts.input_encoding_size), nn.ReLU(),
+                                  nn.Dropout(opts.drop_prob_lm))
+        self.embed = embed
+        self.logit = nn.Linear(opts.rnn_size, vocab_rows) if logit is None else logit
+        self.localizer_core = LocalizerNoLSTMCore(opts)
+        # reconstructor shares the decoder's two LSTM cells (reference :86-87)
+        self.attended_roi_decoder_core = AttenedDecoderCore(opts, self.decoder_core.att_lstm, self.decoder_core.lang_lstm)
+        self.critLM = utils.LMCriterion(opts)
+        self.unk_idx = int(opts.wtoi['UNK'])
+        self.xe_criterion = utils.LanguageCriterion()
+        self.beam_size = int(getattr(opts, "beam_size", 1))
+        self.use_hip_graph = bool(getattr(opts, "hip_graph", False))
+
+    # ------------------------------------------------------------------ small pieces
+    @property
+    def device(self):
+        return self.logit.weight.device
+
+    def init_hidden(self, batch_size, num_layers):
+        """reference :96-101"""
+        z = torch.zeros(num_layers, batch_size, self.rnn_size, device=self.device)
+        return (z, z.clone())
+
+    def _embed(self, word):
+        """embed = Embedding -> ReLU -> Dropout (reference :53-68); lookup+ReLU(+mask) is one kernel."""
+        drop_p = self.embed[2].p if (self.training and len(self.embed) > 2) else 0.0
+        table = self.embed[0].weight
+        drop = None
+        if drop_p > 0:
+            shape = tuple(word.shape) + (table.shape[1],)
+            drop = torch.bernoulli(torch.full(shape, 1.0 - drop_p, device=table.device)).div_(1.0 - drop_p)
+            drop = drop.reshape(-1, table.shape[1])
+        return F_.embed_relu(table, word, drop)
+
+    def _logprobs(self, output):
+        """F.log_softmax(self.logit(output), dim=1) (reference :266, :361, :437)"""
+        return F_.log_softmax(F_.linear(output, self.logit.weight, self.logit.bias))
+
+    def _grounder(self, xt, att_feats, mask, bias=None, min_value=-1e8):
+        """reference :132-173, dot-product branch (the captioner owns no alpha_net)."""
+        assert xt.size(-1) == att_feats.size(-1)
+        B, S, _ = xt.size()
+        R = att_feats.size(1)
+        if mask.dim() == 2:
+            mask = mask.unsqueeze(1).expand(B, S, R)
+        elif mask.dim() != 3:
+            raise NotImplementedError
+        if bias is not None:
+            assert bias.numel() == B * S * R
+        return F_.grounder(xt, att_feats, bias, mask)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, segs_feat, input_seq, gt_caption, num, proposals, gt_boxes, mask_boxes, region_feats, frm_mask,
+                sample_idx, pnt_mask, lang_eval=False, teacher_forcing=False):
+        """reference :175-194"""
+        if lang_eval is False or teacher_forcing:
+            return self._forward_3_loops(segs_feat, input_seq, proposals, gt_caption, num, mask_boxes, gt_boxes,
+                                         region_feats, frm_mask, sample_idx, pnt_mask)
+        return self._sample(segs_feat, input_seq, proposals, gt_caption, num, mask_boxes, gt_boxes, region_feats,
+                            frm_mask, sample_idx, pnt_mask)
+
+    def _encode(self, segs_feat, proposals, num, mask_boxes, region_feats, gt_boxes, frm_mask, sample_idx, pnt_mask):
+        overlaps = utils.bbox_overlaps(proposals.data, gt_boxes.data, (frm_mask | pnt_mask[:, 1:].unsqueeze(-1)).data)
+        return overlaps, self.roi_feat_extractor(segs_feat, proposals, num, mask_boxes, region_feats, gt_boxes, overlaps,
+                                                 sample_idx)
+
+    def _forward_3_loops(self, segs_feat, input_seq, proposals, gt_caption, num, mask_boxes, gt_boxes, region_feats,
+                         frm_mask, sample_idx, pnt_mask):
+        """reference :196-382"""
+        batch_size = proposals.size(0)
+        num_rois = proposals.size(1)
+        T = self.seq_length
+        gt_caption = gt_caption[:, :self.seq_per_img, :].clone().view(-1, gt_caption.size(2))
+        gt_caption = torch.cat((gt_caption.new_zeros(gt_caption.size(0), 1), gt_caption), 1)     # BOS = 0
+        input_seq = input_seq.view(-1, input_seq.size(2), input_seq.size(3))
+        input_seq_update = input_seq.data.clone()
+        B = gt_caption.size(0)
+
+        overlaps, (fc_feats, conv_feats, p_conv_feats, pool_feats, p_pool_feats, g_pool_feats, pnt_mask, _ov, _cls_pred,
+                   cls_loss) = self._encode(segs_feat, proposals, num, mask_boxes, region_feats, gt_boxes, frm_mask,
+                                            sample_idx, pnt_mask)
+        region_mask = pnt_mask[:, 1:].contiguous()
+
+        # ---- Loop A: teacher-forced decode (sequential: LSTM recurrence)            reference :242-270
+        state = self.init_hidden(B, self.decoder_num_layers)
+        emb_all = self._embed(gt_caption[:, :T])                                     # [B, T, E], one launch
+        outputs, masked_attn, roi_labels, frm_mask_output = [], [], [], []
+        for t in range(T):
+            roi_labels.append(utils.bbox_target(mask_boxes[:, :, :, t + 1], overlaps, input_seq[:, t + 1],
+                                                input_seq_update[:, t + 1], self.vocab_size).view(B, -1))
+            box_mask = mask_boxes[:, 0, :, t + 1].contiguous().unsqueeze(1).expand(batch_size, num_rois, mask_boxes.size(2))
+            frm_on_prop = torch.sum(~(box_mask | frm_mask), dim=2) <= 0
+            frm_on_prop = torch.cat((frm_on_prop.new_zeros(batch_size, 1), frm_on_prop), dim=1) | pnt_mask.bool()
+            frm_mask_output.append(frm_on_prop)
+            output, state, _roi_attn, frame_masked_attn, _wp = self.decoder_core(
+                emb_all[:, t], fc_feats, conv_feats, p_conv_feats, pool_feats, p_pool_feats, region_mask, state,
+                proposal_frame_mask=frm_on_prop[:, 1:].contiguous(), with_sentinel=False)
+            outputs.append(output)
+            masked_attn.append(frame_masked_attn)
+        att2_weights = torch.stack(masked_attn, dim=1)                               # pre-softmax (:273)
+        lang_outputs = self._logprobs(torch.stack(outputs, 1).view(B * T, -1)).view(B, T, -1)   # all T at once
+        roi_labels = torch.stack(roi_labels, 1)
+        frm_mask_output = torch.stack(frm_mask_output, 1)
+
+        # ---- grounder over all T                                                      reference :282-294
+        xt_clamp = torch.clamp(input_seq[:, 1:T + 1, 0].clone() - self.vocab_size, min=0)
+        xt_all = self.roi_feat_extractor.vis_embed(xt_clamp)
+        if hasattr(self.roi_feat_extractor, 'vis_classifiers_bias'):
+            bias = self.roi_feat_extractor.vis_classifiers_bias[xt_clamp].type(xt_all.type()).unsqueeze(2).expand(
+                B, T, num_rois)
+        else:
+            bias = 0
+        ground_weights = self._grounder(xt_all, g_pool_feats, frm_mask_output[:, :, 1:], bias + att2_weights)
+
+        target = gt_caption[:, 1:T + 1].clone()
+        if self.opts.train_decoder_only:                                              # reference :297-307
+            lm_loss, att2_loss, ground_loss = self.critLM(lang_outputs.view(-1, lang_outputs.size(2)), att2_weights,
+                                                          ground_weights, target, roi_labels[:, :T, :].clone(),
+                                                          input_seq[:, 1:T + 1, 0].clone())
+            return lm_loss.reshape(1), att2_loss.reshape(1), ground_loss.reshape(1), cls_loss.reshape(1)
+
+        # ---- argmax cut, Loop B: localize (no recurrence -> all T in one attention call)  :313-338
+        _, output_seq = lang_outputs.max(2)
+        loc_emb = self._embed(output_seq)                                            # [B, T, E]
+        loc_pool, loc_conv, _prob = self.localizer_core.forward_all_steps(loc_emb, conv_feats, p_conv_feats, pool_feats,
+                                                                           p_pool_feats, region_mask)
+
+        # ---- Loop C: reconstruct from the localized regions (sequential)             reference :348-362
+        state = self.init_hidden(B, self.decoder_num_layers)
+        emb_all_c = self._embed(gt_caption[:, :T]) if self.training else emb_all      # fresh dropout mask in training
+        rec_outputs = []
+        for t in range(T):
+            output, state = self.attended_roi_decoder_core(emb_all_c[:, t], fc_feats, loc_pool[:, t], loc_conv[:, t],
+                                                           state, with_sentinel=False)
+            rec_outputs.append(output)
+        consistent_outputs = self._logprobs(torch.stack(rec_outputs, 1).view(B * T, -1))
+
+        lm_loss, att2_loss, ground_loss = self.critLM(lang_outputs.view(-1, lang_outputs.size(2)), att2_weights,
+                                                      ground_weights, target, roi_labels[:, :T, :].clone(),
+                                                      input_seq[:, 1:T + 1, 0].clone())
+        lm_recon_loss = self.xe_criterion(consistent_outputs, target)
+        return (lm_loss.reshape(1), att2_loss.reshape(1), ground_loss.reshape(1), cls_loss.reshape(1),
+                lm_recon_loss.reshape(1))
+
+    # ------------------------------------------------------------------ inference
+    def decode_weights(self) -> DecodeWeights:
+        sd = {k: v for k, v in self.state_dict().items()}
+        return DecodeWeights(sd, getattr(self.opts, "softattn_type", "additive"))
+
+    @torch.no_grad()
+    def _sample(self, segs_feat, seq, proposals, gt_caption, num, mask_boxes, gt_boxes, region_feats, frm_mask, sample_idx,
+                pnt_mask, beam_size: Optional[int] = None):
+        """reference :384-443: exactly seq_length decoder steps from BOS, no EOS early exit, UNK
+        suppressed; returns (seq [B,T], att2_weights [B,T,N] post-softmax, None)."""
+        _ov, (fc_feats, conv_feats, p_conv_feats, pool_feats, p_pool_feats, _g, pnt_mask, _o, _c, _l) = self._encode(
+            segs_feat, proposals, num, mask_boxes, region_feats, gt_boxes, frm_mask, sample_idx, pnt_mask)
+        feats = dict(fc_feats=fc_feats.contiguous(), conv_feats=conv_feats.contiguous(), p_conv_feats=p_conv_feats.contiguous(),
+                     pool_feats=pool_feats.contiguous(), p_pool_feats=p_pool_feats.contiguous(), pnt_mask=pnt_mask)
+        beam = self.beam_size if beam_size is None else int(beam_size)
+        temp = float(getattr(self.opts, "softmax_temp", 1.0))
+        engine = DecodeEngine(self.decode_weights(), feats, self.seq_length, self.unk_idx, beam=beam, inv_temp=1.0 / temp)
+        if self.use_hip_graph:
+            engine.capture()
+        res = engine.run()
+        return res[0].clone(), res[1].clone(), None

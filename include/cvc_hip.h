@@ -1,0 +1,169 @@
+/*
+ * cvc_hip.h -- C-ABI of libcvc_hip.so: the MI355X (gfx950) kernels behind the cyclical
+ * visual-captioning decode / localize / reconstruct hot path.
+ *
+ * The reference has no FFI: its replaceable units are torch nn.Module classes
+ * (SURVEY.md section 8(b)).  The host-side mirrors of those classes
+ * (cyclical-visual-captioning_amd/cvc/model/) bind these entry points through ctypes;
+ * INTEGRATION.md shows the stub a reference maintainer would add.  Every entry point
+ *   - takes raw DEVICE pointers, plain sizes and the HIP stream to launch on (no torch types),
+ *   - allocates nothing, is re-entrant, and is graph-capturable (launches only),
+ *   - expects fp32 row-major contiguous data, bool masks as one byte per element, word
+ *     indices as int64,
+ *   - returns 0 on success, a positive hipError_t from the launch, or a negative CVC_E_* for
+ *     argument errors (the Python shim raises RuntimeError on non-zero).
+ *
+ * Paths below are relative to /root/reference/anet-video-captioning/.
+ */
+#ifndef CVC_HIP_H
+#define CVC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* cvc_stream_t; /* hipStream_t */
+
+#define CVC_E_BADARG (-1)   /* a size/alignment precondition is violated            */
+#define CVC_E_TOOBIG (-2)   /* a dimension exceeds what the kernel templates cover  */
+
+#define CVC_ATTN_ADDITIVE 0 /* model/modules.py:100-159 AdditiveSoftAttention.forward */
+#define CVC_ATTN_DOT 1      /* model/modules.py:24-76   SoftAttention.forward         */
+
+/* library / build info: returns a static string "cvc_hip <version> gfx950" */
+const char* cvc_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Attention over one or two feature sets that share the query (regions + frames,
+ * model/decoder_core.py:54-56, model/localizer_core.py:36-39).
+ * rows = nclip * nq query rows; row r belongs to clip r / nq (nq > 1: beams of a clip or
+ * the T localizer queries of a clip share the clip's features).
+ */
+typedef struct {
+    const float* proj;          /* [nclip, n, A]   proj_context                                  */
+    const float* ctx;           /* [nclip, n, R]   context (== proj with R == A when context=None) */
+    const uint8_t* mask;        /* [nclip, n] 1 = masked (-1e8, modules.py:129) or NULL          */
+    const uint8_t* frame_mask;  /* [rows, n]  proposal_frame_mask (modules.py:131-144) or NULL   */
+    float* scores;              /* [rows, n]  out: masked PRE-softmax scores (workspace)         */
+    float* frame_masked;        /* [rows, n]  out: pre-softmax copy filled at frame_mask, or NULL */
+    float* attn;                /* [rows, n]  out: softmax over n                                */
+    float* ctx_out;             /* [rows, R]  out: sum_n attn * ctx, or NULL                     */
+    int n;
+} cvc_attn_set;
+
+/* q [rows, A] is h2attn(h) (bias included).  kind ADDITIVE: s = w_a . tanh(proj_n + q) + b_a[0]
+ * (b_a: DEVICE pointer to alpha_net.bias, nullable = 0; a host float would force a sync)
+ * (no temperature, modules.py:120); kind DOT: s = (proj_n . q) * inv_temp (modules.py:34-37).
+ * ctx_sum [rows, R] (nullable) receives the sum of the sets' contexts
+ * (weighted_pool_feat + attn_conv, decoder_core.py:59).  Requires A % 4 == 0, R % 4 == 0. */
+int cvc_attn_fwd(int kind, const float* q, const float* w_a, const float* b_a, float inv_temp,
+                 const cvc_attn_set* sets, int nsets, int nclip, int nq, int A, int R,
+                 float* ctx_sum, cvc_stream_t stream);
+
+/* Backward of cvc_attn_fwd for ONE set, scores recomputed from proj (nothing but attn is
+ * saved).  Inputs: d_ctx [rows,R] (nullable), d_fm [rows,n] gradient of the frame_masked
+ * output (nullable).  Outputs: d_scores [rows,n] (gradient of the pre-softmax scores; its sum
+ * is d_b_alpha); d_q [rows,A] (overwritten); d_w_part [rows,A] per-row partials of d_w_alpha
+ * (additive only, nullable; the caller sums over rows -- keeps the reduction ordered);
+ * d_proj [nclip,n,A] / d_ctxfeat [nclip,n,R] (ACCUMULATED into: caller zero-fills; nullable). */
+int cvc_attn_bwd(int kind, const float* q, const float* w_a, float inv_temp,
+                 const float* proj, const float* ctx, const float* attn,
+                 const float* d_ctx, const float* d_fm,
+                 int nclip, int nq, int n, int A, int R,
+                 float* d_scores, float* d_q, float* d_w_part,
+                 float* d_proj, float* d_ctxfeat, cvc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Skinny GEMM over a virtual concat of K-segments:  Y[m, n] = sum_s X_s[m, :] . W_s[n, :]
+ * (torch.cat + nn.Linear / nn.LSTMCell input GEMMs, decoder_core.py:45-50,59-61,
+ * captioner.py:266).  Weights stream once from HBM through fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32, exact fp32 fma chain); M <= 64.
+ */
+typedef struct {
+    const float* x;      /* [M, k] leading dim ldx; with idx: table [*, k] read at row idx[m] */
+    const int64_t* idx;  /* optional row gather (nn.Embedding, captioner.py:53-68) or NULL     */
+    const float* w;      /* [Nout, >=k] leading dim ldw, pointing at this segment's first column */
+    int k, ldx, ldw;
+    int relu;            /* max(0, x) on load (the embedding's ReLU)                            */
+} cvc_gemm_seg;
+
+/* y[M, Nout] (ld ldy) = concat-GEMM + bias[Nout] (nullable) + bias2[Nout] (nullable) */
+int cvc_linear_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, const float* bias2,
+                   int M, int Nout, float* y, int ldy, cvc_stream_t stream);
+
+/* nn.LSTMCell (gate order i,f,g,o; decoder_core.py:14,27,50,61): gates = concat-GEMM with
+ * Nout = 4R + b_ih + b_hh; c' = sig(f) c + sig(i) tanh(g); h' = sig(o) tanh(c').
+ * c_prev/h_out/c_out are [M, R] contiguous.  gates_out [M, 4R] (nullable) receives the
+ * ACTIVATED gates (i,f,g,o) for the backward pass.  Requires R % 8 == 0. */
+int cvc_lstm_cell_fwd(const cvc_gemm_seg* segs, int nsegs, const float* b_ih, const float* b_hh,
+                      const float* c_prev, int M, int R, float* h_out, float* c_out,
+                      float* gates_out, cvc_stream_t stream);
+
+/* LSTM pointwise backward: from d_h, d_c (nullable = 0), saved activated gates [M,4R],
+ * c_prev, c_new -> d_gates [M,4R] (pre-activation) and d_c_prev [M,R]. */
+int cvc_lstm_pointwise_bwd(const float* d_h, const float* d_c, const float* gates,
+                           const float* c_prev, const float* c_new, int M, int R,
+                           float* d_gates, float* d_c_prev, cvc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Word embedding and vocabulary head (captioner.py:53-68, 72-76, 266, 415-422).
+ */
+/* out[m, :] = relu(table[idx[m], :]) * (drop ? drop[m, :] : 1) */
+int cvc_embed_relu_fwd(const float* table, const int64_t* idx, const float* drop, int M, int E,
+                       float* out, cvc_stream_t stream);
+/* d_table[idx[m], :] += (table[idx[m], :] > 0) * drop * d_out[m, :]   (atomic accumulate) */
+int cvc_embed_relu_bwd(const float* table, const int64_t* idx, const float* drop,
+                       const float* d_out, int M, int E, float* d_table, cvc_stream_t stream);
+
+/* In-place-capable row log-softmax: logp[m, :] = logits[m, :] - logsumexp(logits[m, :]) */
+int cvc_log_softmax_fwd(const float* logits, int M, int V, float* logp, cvc_stream_t stream);
+
+/* d_logits = d_logp - exp(logp) * rowsum(d_logp) */
+int cvc_log_softmax_bwd(const float* logp, const float* d_logp, int M, int V, float* d_logits,
+                        cvc_stream_t stream);
+
+/* Greedy word selection with UNK suppression (captioner.py:415-422): per row the top-2 of
+ * logits; pick #2 iff #1 == unk_idx; ties -> lowest index.  word[m*word_stride] (int64),
+ * logprob[m] = logit - logsumexp (nullable). */
+int cvc_top2_unk(const float* logits, int M, int V, int unk_idx, int64_t* word, int word_stride,
+                 float* logprob, cvc_stream_t stream);
+
+/* Masked NLL over a [M, V] log-prob matrix (misc/utils.py:132-146, 181-192):
+ * loss_sum[0] += sum_m w[m] * -logp[m, target[m]];  with d_logits (nullable, [M,V]):
+ * d_logits[m, v] = scale * w[m] * (exp(logp[m,v]) - [v == target[m]]) -- the fused
+ * log_softmax+NLL backward. */
+int cvc_nll_fwd(const float* logp, const int64_t* target, const float* w, int M, int V,
+                float* loss_sum, cvc_stream_t stream);
+/* d_logp[m, v] = -w[m] * g[0] at v == target[m], else 0 (g: device scalar upstream gradient) */
+int cvc_nll_bwd(const int64_t* target, const float* w, const float* g, int M, int V, float* d_logp,
+                cvc_stream_t stream);
+int cvc_nll_logsoftmax_bwd(const float* logp, const int64_t* target, const float* w, float scale,
+                           int M, int V, float* d_logits, cvc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Grounder (captioner.py:132-173, dot-product branch): out[b,t,n] = xt[b,t,:] . feats[b,n,:]
+ * + bias[b,t,n], filled with -1e8 where mask[b,t,n].
+ */
+int cvc_grounder_fwd(const float* xt, const float* feats, const float* bias, const uint8_t* mask,
+                     int B, int T, int N, int G, float* out, cvc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Beam bookkeeping (build-defined, SURVEY.md section 7 "Beam-search specification"):
+ * per clip select the `beam` best of beam*V candidates score[b,k] + logp[b,k,v] with
+ * logp[unk] = -inf, finished hypotheses frozen (only v = 0 at +0).  Outputs parent[b,k],
+ * word[b,k] (int64), new score[b,k]; ties -> lowest flat (k, v) index.
+ */
+int cvc_beam_select(const float* logits, const float* score_in, const uint8_t* done_in,
+                    int B, int beam, int V, int unk_idx, int first_step,
+                    int64_t* parent, int64_t* word, float* score_out, uint8_t* done_out,
+                    cvc_stream_t stream);
+/* dst[r, :] = src[(r / beam) * beam + parent[r], :] for r in [0, rows)  (state reorder) */
+int cvc_gather_rows(const float* src, const int64_t* parent, int rows, int beam, int width,
+                    float* dst, cvc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVC_HIP_H */

@@ -1,0 +1,271 @@
+"""GPU parity tests (pytest -m gpu): the HIP path, called through the C-ABI (cvc.hip ->
+libcvc_hip.so), against (1) the golden vectors captured from the reference and (2) the CPU oracle
+on the same seeded inputs.
+
+Tolerances (fp32, different reduction orders: MFMA k-permuted fma chains, wave/LDS tree sums,
+hardware exp/rcp in tanh/sigmoid): 2e-5 abs+rel on single-op outputs, 1e-4 on anything that went
+through T recurrent steps or a log-softmax over V, 2e-4 rel on gradients (SURVEY.md section 7 "Hard parts" 1).
+"""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+from cvc import synth
+
+pytestmark = pytest.mark.gpu
+
+OP_TOL = dict(rtol=2e-5, atol=2e-5)
+SEQ_TOL = dict(rtol=1e-4, atol=1e-4)
+GRAD_TOL = dict(rtol=2e-4, atol=2e-5)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("the gpu-marked tests need a visible MI355X (torch.cuda.is_available() is False)")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def lib(dev):
+    from cvc import hip
+    hip.lib()   # fails loudly if the extension is missing
+    return hip
+
+
+def close(a, b, **tol):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    np.testing.assert_allclose(a, b, **tol)
+
+
+@pytest.fixture(scope="module")
+def tiny(g1, dev, lib):
+    from helpers import build_model, to_dev
+    d = synth.CONFIGS["tiny"]
+    sd = g1.sub("sd.")
+    model = build_model(d, sd, dev)
+    return d, model, to_dev(g1.sub("feats."), dev), to_dev(g1.sub("batch."), dev), to_dev(g1.sub("unit."), dev)
+
+
+# ------------------------------------------------------------------ single ops vs golden (a1..a7)
+def test_a1_additive_attention_golden(tiny, g1):
+    d, model, f, _, u = tiny
+    att = model.decoder_core.soft_attn
+    mask = f["pnt_mask"][:, 1:]
+    ctx, a, fm = att(u["h"], f["p_pool_feats"], context=f["pool_feats"], mask=mask, proposal_frame_mask=u["fmask"])
+    close(ctx, g1["a1.regions.ctx"], **OP_TOL); close(a, g1["a1.regions.attn"], **OP_TOL); close(fm, g1["a1.regions.fm"], **OP_TOL)
+    close(a[2], np.full(d.N, 1.0 / d.N, np.float32), rtol=1e-6, atol=0)            # all-masked clip: uniform
+    assert float(a[0][mask[0]].abs().max()) == 0.0                                # masked -> exactly 0
+    ctx, a, fm = att(u["h"], f["p_conv_feats"], context=f["conv_feats"])
+    close(ctx, g1["a1.frames.ctx"], **OP_TOL); close(a, g1["a1.frames.attn"], **OP_TOL); assert fm is None
+    ctx, a, _ = att(u["h"], f["p_pool_feats"], mask=mask)
+    close(ctx, g1["a1.noctx.ctx"], **OP_TOL); close(a, g1["a1.noctx.attn"], **OP_TOL)
+
+
+@pytest.mark.parametrize("temp", [1.0, 2.5])
+def test_a2_dot_attention_golden(tiny, g1, temp):
+    d, model, f, _, u = tiny
+    att = model.localizer_core.soft_attn
+    att.temp = temp
+    ctx, a, fm = att(u["emb"], f["p_pool_feats"], context=f["pool_feats"], mask=f["pnt_mask"][:, 1:],
+                     proposal_frame_mask=u["fmask"])
+    att.temp = 1.0
+    pre = "a2.temp%g." % temp
+    close(ctx, g1[pre + "ctx"], **OP_TOL); close(a, g1[pre + "attn"], **OP_TOL); close(fm, g1[pre + "fm"], **OP_TOL)
+
+
+def test_a3_decoder_step_golden(tiny, g1):
+    d, model, f, _, u = tiny
+    out, (h, c), ra, fm, ctx_r = model.decoder_core(u["emb"], f["fc_feats"], f["conv_feats"], f["p_conv_feats"],
+                                                    f["pool_feats"], f["p_pool_feats"], f["pnt_mask"][:, 1:],
+                                                    (u["state_h"], u["state_c"]), proposal_frame_mask=u["fmask"])
+    for k, v in dict(out=out, h=h, c=c, roi_attn=ra, fm=fm, ctx_r=ctx_r).items():
+        close(v, g1["a3." + k], **OP_TOL)
+
+
+def test_a5_reconstructor_step_golden(tiny, g1):
+    d, model, f, _, u = tiny
+    out, (h, c) = model.attended_roi_decoder_core(u["emb"], f["fc_feats"], u["loc_pool"], u["loc_conv"],
+                                                  (u["state_h"], u["state_c"]))
+    close(out, g1["a5.out"], **OP_TOL); close(h, g1["a5.h"], **OP_TOL); close(c, g1["a5.c"], **OP_TOL)
+
+
+def test_a6_localizer_step_golden(tiny, g1):
+    d, model, f, _, u = tiny
+    lp, lc, prob, st = model.localizer_core(u["emb"], f["fc_feats"], f["conv_feats"], f["p_conv_feats"], f["pool_feats"],
+                                            f["p_pool_feats"], f["pnt_mask"][:, 1:], "state", None, proposal_frame_mask=u["fmask"])
+    assert st == "state"
+    close(lp, g1["a6.loc_pool"], **OP_TOL); close(lc, g1["a6.loc_conv"], **OP_TOL); close(prob, g1["a6.prob"], **OP_TOL)
+
+
+def test_a7_embed_logits_vs_oracle(tiny, g1, dev):
+    from oracle import ref_cpu as O
+    d, model, f, _, u = tiny
+    P = O.to_torch(g1.sub("sd."))
+    words = torch.tensor([0, 7, synth.UNK_IDX], device=dev)
+    close(model._embed(words), O.embed(P, words.cpu()), rtol=0, atol=0)            # gather + relu: bit-exact
+    out = u["state_h"][1]
+    close(model._logprobs(out), O.logits_logsoftmax(P, out.cpu()), **OP_TOL)
+
+
+# ------------------------------------------------------------------ greedy decode (a8)
+def test_a8_greedy_tiny_golden(tiny, g1):
+    from helpers import model_call, tie_aware_seq_equal
+    d, model, f, b, _ = tiny
+    seq, att, none = model_call(model, f, b, True)
+    assert none is None and seq.shape == (d.B, d.T) and seq.dtype == torch.int64
+    n = tie_aware_seq_equal(seq.cpu().numpy(), g1["a8.seq"], g1["a8.logp"])
+    assert n == d.B * d.T
+    close(att, g1["a8.att2_weights"], **SEQ_TOL)
+    assert not (seq == synth.UNK_IDX).any()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_a8_greedy_cfg1_golden(g2, dev, lib, graph):
+    from helpers import build_model, to_dev, model_call
+    d = synth.CONFIGS["cfg1"]
+    seed = int(g2["meta.seed"])
+    model = build_model(d, synth.hot_path_state_dict(d, seed), dev, hip_graph=graph)
+    f, b = to_dev(synth.clip_features(d, seed), dev), to_dev(synth.label_glue_batch(d, seed), dev)
+    seq, att, _ = model_call(model, f, b, True)
+    np.testing.assert_array_equal(seq.cpu().numpy(), g2["a8.seq"])      # margins in G2 are >> fp32 noise
+    close(att, g2["a8.att2_weights"], **SEQ_TOL)
+    # run-to-run bitwise determinism (ordered reductions, no float atomics)
+    seq2, att2, _ = model_call(model, f, b, True)
+    assert torch.equal(seq, seq2) and torch.equal(att, att2)
+
+
+def test_a8_greedy_cfg2_vs_oracle_and_properties(dev, lib):
+    """BASELINE config 2 (the benchmarked size): decode on the GPU, oracle on the host CPU
+    (a few seconds), plus size-independent properties."""
+    from helpers import to_dev, tie_aware_seq_equal
+    from oracle import ref_cpu as O
+    from cvc.decode import DecodeEngine, DecodeWeights
+    d = synth.CONFIGS["cfg2"]
+    sd = synth.hot_path_state_dict(d, 1236)
+    f_np = synth.clip_features(d, 1236)
+    with torch.no_grad():
+        seq_o, att_o, _, logp_o = O.greedy_sample(O.to_torch(sd), O.to_torch(f_np), d.T, synth.UNK_IDX, return_logprobs=True)
+    W = DecodeWeights(to_dev(sd, dev))
+    f = to_dev(f_np, dev)
+    eng = DecodeEngine(W, f, d.T, synth.UNK_IDX).capture()
+    seq, att = eng.run()
+    seq, att = seq.clone(), att.clone()
+    n = tie_aware_seq_equal(seq.cpu().numpy(), seq_o.numpy(), logp_o.numpy())
+    assert n >= 0.98 * d.B * d.T
+    same = (seq.cpu() == seq_o).all(1)
+    close(att[same.to(dev)], att_o[same], **SEQ_TOL)
+    # properties: rows sum to 1; masked regions carry exactly 0 weight
+    close(att.sum(2), torch.ones(d.B, d.T), rtol=1e-5, atol=1e-5)
+    m = f["pnt_mask"][:, 1:]
+    assert float(att.permute(0, 2, 1)[m].abs().max()) == 0.0
+    # replay determinism
+    seq2, att2 = eng.run()
+    assert torch.equal(seq, seq2) and torch.equal(att, att2)
+    # permuting the clips permutes the outputs (clips are independent units)
+    perm = torch.randperm(d.B, generator=torch.Generator().manual_seed(0)).to(dev)
+    fp = {k: v[perm].contiguous() for k, v in f.items()}
+    seq_p, att_p = DecodeEngine(W, fp, d.T, synth.UNK_IDX).run()
+    assert torch.equal(seq_p, seq[perm])
+    close(att_p, att[perm], rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------ cyclical training forward/backward (a9, a10, a11)
+@pytest.mark.parametrize("variant,over,mix", [
+    ("a9.cyc.", dict(), dict(xe=0.5, w_att2=0.0, cons=0.5)),
+    ("a9.sup.", dict(), dict(xe=0.5, w_att2=0.05, cons=0.5)),
+    ("a9.dec.", dict(train_decoder_only=True), dict(xe=0.5, w_att2=0.0, cons=0.0)),
+])
+def test_a9_cyclical_tiny_golden(g1, dev, lib, variant, over, mix):
+    from helpers import build_model, to_dev, model_call
+    d = synth.CONFIGS["tiny"]
+    model = build_model(d, g1.sub("sd."), dev, **over)
+    f, b = to_dev(g1.sub("feats."), dev), to_dev(g1.sub("batch."), dev)
+    fkeys = ("fc_feats", "conv_feats", "p_conv_feats", "pool_feats", "p_pool_feats", "g_pool_feats")
+    for k in fkeys:
+        f[k].requires_grad_(True)
+    gold = g1.sub(variant)
+    losses = model_call(model, f, b, False)
+    assert len(losses) == (4 if over else 5)
+    for i, l in enumerate(losses):
+        assert l.shape == (1,)
+        close(l, gold["loss%d" % i].reshape(1), **SEQ_TOL)
+    loss = mix["xe"] * losses[0].mean() + mix["w_att2"] * losses[1].mean()
+    if len(losses) > 4:
+        loss = loss + mix["cons"] * losses[4].mean()
+    close(loss, gold["total"], **SEQ_TOL)
+    loss.backward()
+    params = dict(model.named_parameters())
+    n = 0
+    for k, v in gold.items():
+        if not k.startswith("grad."):
+            continue
+        name = k[len("grad."):]
+        g = f[name[3:]].grad if name.startswith("in.") else params[name].grad
+        if v is None:
+            assert g is None or float(g.abs().max()) == 0.0, name
+        else:
+            assert g is not None, name
+            close(g, v, **GRAD_TOL)
+            n += 1
+    assert n > 10
+
+
+def test_a9_cyclical_cfg1_golden(g2, dev, lib):
+    from helpers import build_model, to_dev, model_call
+    d = synth.CONFIGS["cfg1"]
+    seed = int(g2["meta.seed"])
+    model = build_model(d, synth.hot_path_state_dict(d, seed), dev)
+    f, b = to_dev(synth.clip_features(d, seed), dev), to_dev(synth.label_glue_batch(d, seed), dev)
+    losses = model_call(model, f, b, False)
+    gold = g2.sub("a9.cyc.")
+    for i, l in enumerate(losses):
+        close(l, gold["loss%d" % i].reshape(1), **SEQ_TOL)
+    (0.5 * losses[0].mean() + 0.5 * losses[4].mean()).backward()
+    params = dict(model.named_parameters())
+    for k, v in gold.items():
+        if k.endswith(".norm") and not k.startswith("grad.in."):
+            name = k[len("grad."):-len(".norm")]
+            g = params[name].grad
+            np.testing.assert_allclose(float(g.double().norm()), float(v), rtol=1e-3, atol=1e-7)
+            idx = torch.from_numpy(gold["grad." + name + ".idx"]).to(dev)
+            close(g.reshape(-1)[idx], gold["grad." + name + ".val"], rtol=2e-3, atol=1e-6)
+    for dead in ("decoder_core.i2h_2.weight", "decoder_core.localied_fc.weight",
+                 "attended_roi_decoder_core.soft_attn.h2attn.weight"):
+        assert params[dead].grad is None
+
+
+# ------------------------------------------------------------------ beam search (build-defined)
+def test_beam_vs_oracle(tiny, g1, dev):
+    from oracle import ref_cpu as O
+    from cvc.decode import DecodeEngine
+    d, model, f, _, _ = tiny
+    P, fo = O.to_torch(g1.sub("sd.")), O.to_torch(g1.sub("feats."))
+    W = model.decode_weights()
+    for beam in (1, 3):
+        with torch.no_grad():
+            seq_o, att_o, sc_o = O.beam_search(P, fo, d.T, synth.UNK_IDX, beam)
+        if beam == 1:
+            seq, att = DecodeEngine(W, f, d.T, synth.UNK_IDX, beam=1).run()
+            # greedy never freezes after EOS; the beam rule does: compare up to the first EOS
+            for bi in range(d.B):
+                s = seq_o[bi].tolist()
+                L = (s.index(0) + 1) if 0 in s else d.T
+                assert seq[bi, :L].tolist() == s[:L]
+        else:
+            seq, att, sc = DecodeEngine(W, f, d.T, synth.UNK_IDX, beam=beam).run()
+            np.testing.assert_array_equal(seq.cpu().numpy(), seq_o.numpy())
+            close(att, att_o, **SEQ_TOL)
+            close(sc, sc_o, **SEQ_TOL)
+            assert bool((sc[:, :-1] >= sc[:, 1:]).all())
+
+
+def test_product_path_has_no_cpu_fallback(lib):
+    from cvc import functional as F_
+    x = torch.zeros(4, 8)
+    w = torch.zeros(8, 8)
+    with pytest.raises(RuntimeError, match="GPU"):
+        F_.linear(x, w, None)
