@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Headline benchmark: caption decode-steps/sec (B x T per full greedy decode) on MI355X.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3                      # BASELINE config 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch: the full T-step greedy decode of B clips
+(embed, att-LSTM, both attentions, lang-LSTM, vocab projection, word selection per decode step),
+features and weights resident in HBM, replayed from one HIP graph.  value = clips x T x ranks x
+steps / max-over-ranks wall time.  Clips are independent: ranks decode disjoint batches, no
+collective on the data path (weak scaling).
+
+Extra objects in the JSON line:
+  roofline      -- the dominant kernel (largest share of the step's GPU time), achieved
+                   algorithmic bytes (or flops) per launch / its average duration measured with HIP
+                   events in this process; `kernels` lists every kernel of the step the same way.
+  cpu_baseline  -- the CPU oracle (torch fp32, the reference's own ATen op sequence) timed on this
+                   box's host cores on the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "cyclical-visual-captioning_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec); ~6.3 TB/s measured achievable
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--config", default="cfg2", help="cvc.synth.CONFIGS key (cfg2 = B=64,N=100,D=2048,T=20 greedy)")
+    for k in ("B", "N", "F", "R", "A", "E", "V", "T"):
+        p.add_argument("--" + k, type=int, default=None)
+    p.add_argument("--beam", type=int, default=1)
+    p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-repeats", type=int, default=3)
+    p.add_argument("--seed", type=int, default=1234)
+    return p.parse_args()
+
+
+def algorithmic_work(d, beam):
+    """Per-launch algorithmic bytes / flops of every kernel of one decode step (DESIGN.md section 4;
+    SURVEY.md section 8(d) per-unit figures x the units one launch processes = B clips)."""
+    B, N, F, R, A, E, V = d.B, d.N, d.F, d.R, d.A, d.E, d.V
+    rows = B * beam
+    w = {}
+    w["attn_scores"] = dict(bound="hbm", bytes=4 * B * (N + F) * A + B * N + 4 * rows * (A + N + F))
+    w["attn_wsum"] = dict(bound="hbm", bytes=4 * B * (N + F) * R + 4 * rows * (N + F + R))
+    k_att = E + 3 * R
+    w["att_lstm"] = dict(bound="hbm", bytes=4 * (4 * R * k_att + 8 * R) + 4 * rows * (k_att + 3 * R), flops=2 * rows * 4 * R * k_att)
+    w["lang_lstm"] = dict(bound="hbm", bytes=4 * (4 * R * 3 * R + 8 * R) + 4 * rows * (3 * R + 3 * R), flops=2 * rows * 4 * R * 3 * R)
+    w["h2attn"] = dict(bound="hbm", bytes=4 * (A * R + A) + 4 * rows * (R + A), flops=2 * rows * A * R)
+    w["logits"] = dict(bound="hbm", bytes=4 * (V * R + V) + 4 * rows * (R + V), flops=2 * rows * V * R)
+    w["word_select"] = dict(bound="hbm", bytes=4 * rows * V)
+    return w
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import dataclasses
+    from cvc import synth
+    from cvc.decode import DecodeEngine, DecodeWeights
+    from cvc import hip
+    hip.lib()
+
+    d = synth.CONFIGS[args.config]
+    over = {k: getattr(args, k) for k in ("B", "N", "F", "R", "A", "E", "V", "T") if getattr(args, k) is not None}
+    if over:
+        d = dataclasses.replace(d, **over)
+    seed = args.seed + rank                       # every rank decodes its own clips
+    sd_np = synth.hot_path_state_dict(d, args.seed)
+    feats_np = synth.clip_features(d, seed)
+    W = DecodeWeights({k: torch.from_numpy(v).to(dev) for k, v in sd_np.items()})
+    feats = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in feats_np.items()}
+    eng = DecodeEngine(W, feats, d.T, synth.UNK_IDX, beam=args.beam)
+    if not args.no_graph:
+        eng.capture()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.run()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.run()
+    torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0
+    sync_all()
+    t = torch.tensor([t_local], device=dev, dtype=torch.float64)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    units = d.B * d.T * world * args.steps
+    value = units / elapsed
+
+    # ---- per-kernel durations with HIP events on the launch stream (eager pass, same buffers)
+    kernels, roof = [], None
+    if rank == 0:
+        work = algorithmic_work(d, args.beam)
+        acc = {}
+        eng.run_timed()                            # warm
+        for _ in range(3):
+            for k, v in eng.run_timed().items():
+                acc.setdefault(k, []).extend(v)
+        step_ms = sum(float(np.mean(v)) for v in acc.values())
+        for name, ms in acc.items():
+            avg = float(np.mean(ms))
+            wk = work.get(name)
+            ent = dict(kernel=name, avg_us=round(avg * 1e3, 2), launches_per_decode=len(ms) // 3,
+                       share=round(avg * (len(ms) // 3) / (d.T * step_ms), 4) if step_ms > 0 else None)
+            if wk:
+                gbs = wk["bytes"] / (avg * 1e-3) / 1e9
+                ent.update(bound=wk["bound"], algorithmic_bytes=wk["bytes"], achieved_GBs=round(gbs, 1),
+                           frac_hbm=round(gbs / HBM_PEAK_GBS, 4))
+                if "flops" in wk:
+                    tf = wk["flops"] / (avg * 1e-3) / 1e12
+                    ent.update(achieved_TFLOPs=round(tf, 2), frac_mfma_f32=round(tf / MFMA_F32_PEAK_TFLOPS, 4))
+            kernels.append(ent)
+        kernels.sort(key=lambda e: -(e["share"] or 0))
+        dom = next(e for e in kernels if "achieved_GBs" in e)
+        traffic = None
+        tf_path = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-derived HBM bytes per launch, if collected
+        if os.path.exists(tf_path):
+            try:
+                traffic = json.load(open(tf_path)).get(dom["kernel"])
+            except Exception:
+                traffic = None
+        roof = dict(kernel=dom["kernel"], bound="hbm", achieved=dom["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=dom["frac_hbm"], traffic=traffic, avg_us=dom["avg_us"])
+
+    # ---- CPU baseline: the oracle on this box's host cores, same workload (rank 0, N=1 only)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import ref_cpu as O
+        ncores = os.cpu_count() or 1
+        torch.set_num_threads(ncores)
+        P_cpu, f_cpu = O.to_torch(sd_np), O.to_torch(feats_np)
+        best = None
+        with torch.no_grad():
+            fn = (lambda: O.greedy_sample(P_cpu, f_cpu, d.T, synth.UNK_IDX)) if args.beam == 1 else \
+                (lambda: O.beam_search(P_cpu, f_cpu, d.T, synth.UNK_IDX, args.beam))
+            fn()
+            for _ in range(args.cpu_repeats):
+                c0 = time.perf_counter()
+                fn()
+                dt = time.perf_counter() - c0
+                best = dt if best is None else min(best, dt)
+        cpu = dict(value=round(d.B * d.T / best, 1), unit="decode-steps/s", cores=torch.get_num_threads(), kind="port",
+                   sample=f"one full decode of the same workload (B={d.B}, T={d.T}), warm-up 1, best of {args.cpu_repeats}; "
+                          f"torch {torch.__version__} CPU, {ncores} host cores", seconds=round(best, 3))
+
+    if rank == 0:
+        line = {
+            "metric": "caption decode-steps/sec (BxT) at N=100,D=2048", "value": round(value, 1), "unit": "decode-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: greedy caption decode" if args.beam == 1 else f"{args.config}: beam={args.beam} caption decode",
+                       "B_per_gpu": d.B, "N": d.N, "F": d.F, "D": d.R, "A": d.A, "E": d.E, "V": d.V, "T": d.T, "beam": args.beam,
+                       "hip_graph": not args.no_graph, "parallelism": f"clips sharded over {world} rank(s), no collective"},
+            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        if cpu:
+            line["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

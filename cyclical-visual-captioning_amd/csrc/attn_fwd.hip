@@ -103,23 +103,32 @@ __global__ __launch_bounds__(WG) void attn_wsum_kernel(WsumArgs a) {
 
 }  // namespace
 
-extern "C" int cvc_attn_fwd(int kind, const float* q, const float* w_a, const float* b_a, float inv_temp,
-                            const cvc_attn_set* sets, int nsets, int nclip, int nq, int A, int R,
-                            float* ctx_sum, cvc_stream_t stream) {
-    if (nsets < 1 || nsets > 2 || nclip < 1 || nq < 1 || (A & 3) || (R & 3) || q == nullptr) return CVC_E_BADARG;
-    if (kind == CVC_ATTN_ADDITIVE && w_a == nullptr) return CVC_E_BADARG;
-    if (kind != CVC_ATTN_ADDITIVE && kind != CVC_ATTN_DOT) return CVC_E_BADARG;
-    hipStream_t st = (hipStream_t)stream;
-    int n_max = 0;
+static int check_sets(const cvc_attn_set* sets, int nsets, int nclip, int nq, int A, int R, int* n_max) {
+    if (sets == nullptr || nsets < 1 || nsets > 2 || nclip < 1 || nq < 1 || (A & 3) || (R & 3)) return CVC_E_BADARG;
+    *n_max = 0;
     for (int s = 0; s < nsets; ++s) {
         if (sets[s].n < 1 || !sets[s].proj || !sets[s].ctx || !sets[s].scores || !sets[s].attn) return CVC_E_BADARG;
         if ((sets[s].frame_masked != nullptr) != (sets[s].frame_mask != nullptr)) return CVC_E_BADARG;
-        n_max = sets[s].n > n_max ? sets[s].n : n_max;
+        *n_max = sets[s].n > *n_max ? sets[s].n : *n_max;
     }
-    // ---- pass 1: masked pre-softmax scores
-    int rc = run_scores(kind, q, w_a, b_a, inv_temp, sets, nsets, nclip, nq, A, st);
-    if (rc != 0) return rc;
-    // ---- pass 2: softmax + weighted sum of context rows
+    return 0;
+}
+
+extern "C" int cvc_attn_scores(int kind, const float* q, const float* w_a, const float* b_a, float inv_temp,
+                               const cvc_attn_set* sets, int nsets, int nclip, int nq, int A, cvc_stream_t stream) {
+    int n_max;
+    int rc = check_sets(sets, nsets, nclip, nq, A, 0, &n_max);
+    if (rc) return rc;
+    if (q == nullptr || (kind == CVC_ATTN_ADDITIVE && w_a == nullptr)) return CVC_E_BADARG;
+    if (kind != CVC_ATTN_ADDITIVE && kind != CVC_ATTN_DOT) return CVC_E_BADARG;
+    return run_scores(kind, q, w_a, b_a, inv_temp, sets, nsets, nclip, nq, A, (hipStream_t)stream);
+}
+
+extern "C" int cvc_attn_wsum(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum,
+                             cvc_stream_t stream) {
+    int n_max;
+    int rc = check_sets(sets, nsets, nclip, nq, 0, R, &n_max);
+    if (rc) return rc;
     WsumArgs wa;
     wa.set[0] = sets[0];
     wa.set[1] = nsets > 1 ? sets[1] : sets[0];
@@ -127,6 +136,14 @@ extern "C" int cvc_attn_fwd(int kind, const float* q, const float* w_a, const fl
     const size_t lds2 = (4 * 64 * 4 + 16 + n_max) * sizeof(float);
     if (lds2 > 64 * 1024) return CVC_E_TOOBIG;
     dim3 g2((R + 255) / 256, nclip * nq);
-    hipLaunchKernelGGL(attn_wsum_kernel, g2, dim3(WG), lds2, st, wa);
+    hipLaunchKernelGGL(attn_wsum_kernel, g2, dim3(WG), lds2, (hipStream_t)stream, wa);
     return cvc_launch_status();
+}
+
+extern "C" int cvc_attn_fwd(int kind, const float* q, const float* w_a, const float* b_a, float inv_temp,
+                            const cvc_attn_set* sets, int nsets, int nclip, int nq, int A, int R,
+                            float* ctx_sum, cvc_stream_t stream) {
+    int rc = cvc_attn_scores(kind, q, w_a, b_a, inv_temp, sets, nsets, nclip, nq, A, stream);
+    if (rc) return rc;
+    return cvc_attn_wsum(sets, nsets, nclip, nq, R, ctx_sum, stream);
 }

@@ -118,35 +118,38 @@ class DecodeEngine:
                              (fc, self.clip_of_row if beam > 1 else None, W.w_ih_att[:, R:2 * R], False),
                              (W.embed, self.words[t], W.w_ih_att[:, 2 * R:2 * R + E], True),
                              (self.h_att[rd], None, W.w_hh_att, False)])
-            out.append((L.cvc_lstm_cell_fwd, (seg_att, 4, ptr(W.b_ih_att), ptr(W.b_hh_att), ptr(self.c_att[rd]), rows, R,
-                                              ptr(self.h_att[wr]), ptr(self.c_att[wr]), None)))
+            out.append(("att_lstm", L.cvc_lstm_cell_fwd, (seg_att, 4, ptr(W.b_ih_att), ptr(W.b_hh_att), ptr(self.c_att[rd]),
+                                                          rows, R, ptr(self.h_att[wr]), ptr(self.c_att[wr]), None)))
             seg_q = _segs([(self.h_att[wr], None, W.w_h, False)])
-            out.append((L.cvc_linear_fwd, (seg_q, 1, ptr(W.b_h), None, rows, A, ptr(self.q), A)))
+            out.append(("h2attn", L.cvc_linear_fwd, (seg_q, 1, ptr(W.b_h), None, rows, A, ptr(self.q), A)))
             sets = (hip.AttnSet * 2)()
             sets[0] = hip.AttnSet(ptr(ppool), ptr(pool), ptr(self.mask), None, ptr(self.scores_r), None,
                                   ptr(self.att_steps[t]), None, N)
             sets[1] = hip.AttnSet(ptr(pconv), ptr(conv), None, None, ptr(self.scores_f), None, ptr(self.attn_f), None, Fr)
-            out.append((L.cvc_attn_fwd, (W.kind, ptr(self.q), ptr(W.w_a), ptr(W.b_a), self.inv_temp, sets, 2, B, beam, A, R,
-                                         ptr(self.ctx_sum))))
+            out.append(("attn_scores", L.cvc_attn_scores, (W.kind, ptr(self.q), ptr(W.w_a), ptr(W.b_a), self.inv_temp, sets, 2,
+                                                           B, beam, A)))
+            out.append(("attn_wsum", L.cvc_attn_wsum, (sets, 2, B, beam, R, ptr(self.ctx_sum))))
             seg_lang = _segs([(self.ctx_sum, None, W.w_ih_lang[:, 0:R], False),
                               (self.h_att[wr], None, W.w_ih_lang[:, R:2 * R], False),
                               (self.h_lang[rd], None, W.w_hh_lang, False)])
-            out.append((L.cvc_lstm_cell_fwd, (seg_lang, 3, ptr(W.b_ih_lang), ptr(W.b_hh_lang), ptr(self.c_lang[rd]), rows, R,
-                                              ptr(self.h_lang[wr]), ptr(self.c_lang[wr]), None)))
+            out.append(("lang_lstm", L.cvc_lstm_cell_fwd, (seg_lang, 3, ptr(W.b_ih_lang), ptr(W.b_hh_lang), ptr(self.c_lang[rd]),
+                                                           rows, R, ptr(self.h_lang[wr]), ptr(self.c_lang[wr]), None)))
             seg_o = _segs([(self.h_lang[wr], None, W.w_o, False)])
-            out.append((L.cvc_linear_fwd, (seg_o, 1, ptr(W.b_o), None, rows, V, ptr(self.logits), V)))
+            out.append(("logits", L.cvc_linear_fwd, (seg_o, 1, ptr(W.b_o), None, rows, V, ptr(self.logits), V)))
             if beam == 1:
-                out.append((L.cvc_top2_unk, (ptr(self.logits), rows, V, self.unk, ptr(self.words[t + 1]), 1,
-                                             ptr(self.logprob[t]))))
+                out.append(("word_select", L.cvc_top2_unk, (ptr(self.logits), rows, V, self.unk, ptr(self.words[t + 1]), 1,
+                                                            ptr(self.logprob[t]))))
             else:
                 srd, swr = t & 1, (t + 1) & 1
-                out.append((L.cvc_beam_select, (ptr(self.logits), ptr(self.score[srd]), ptr(self.done[srd]), B, beam, V,
-                                                self.unk, 1 if t == 0 else 0, ptr(self.parent[t]), ptr(self.words[t + 1]),
-                                                ptr(self.score[swr]), ptr(self.done[swr]))))
+                out.append(("word_select", L.cvc_beam_select, (ptr(self.logits), ptr(self.score[srd]), ptr(self.done[srd]), B,
+                                                               beam, V, self.unk, 1 if t == 0 else 0, ptr(self.parent[t]),
+                                                               ptr(self.words[t + 1]), ptr(self.score[swr]),
+                                                               ptr(self.done[swr]))))
                 # reorder the freshly written state rows by parent (gather into tmp, copy back)
                 for i, buf in enumerate((self.h_att[wr], self.c_att[wr], self.h_lang[wr], self.c_lang[wr])):
-                    out.append((L.cvc_gather_rows, (ptr(buf), ptr(self.parent[t]), rows, beam, R, ptr(self.gather_tmp[i]))))
-                    out.append(("copy", (buf, self.gather_tmp[i])))
+                    out.append(("beam_reorder", L.cvc_gather_rows, (ptr(buf), ptr(self.parent[t]), rows, beam, R,
+                                                                    ptr(self.gather_tmp[i]))))
+                    out.append(("beam_reorder", "copy", (buf, self.gather_tmp[i])))
             self._keep += [seg_att, seg_q, sets, seg_lang, seg_o]
         return out
 
@@ -158,15 +161,31 @@ class DecodeEngine:
             self.score.zero_()
             self.done.zero_()
 
-    def _run_launches(self):
+    def _run_launches(self, timers=None):
+        """timers: optional dict name -> list of (start_event, end_event), filled per launch
+        (HIP events on the launch stream; used by bench.py for per-kernel durations)."""
         stream = torch.cuda.current_stream().cuda_stream
-        for fn, args in self._launches:
+        for name, fn, args in self._launches:
+            if timers is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             if fn == "copy":
                 args[0].copy_(args[1])
-                continue
-            rc = fn(*args, stream)
-            if rc != 0:
-                hip._check(rc, fn.__name__)
+            else:
+                rc = fn(*args, stream)
+                if rc != 0:
+                    hip._check(rc, name)
+            if timers is not None:
+                e1.record()
+                timers.setdefault(name, []).append((e0, e1))
+
+    def run_timed(self):
+        """One eager decode with a HIP-event pair around every launch.  Returns name -> list of ms."""
+        timers = {}
+        self._reset()
+        self._run_launches(timers)
+        torch.cuda.synchronize()
+        return {k: [a.elapsed_time(b) for a, b in v] for k, v in timers.items()}
 
     def capture(self):
         """Capture the T-step loop into a HIP graph (launch-bound inner loop -> one replay)."""

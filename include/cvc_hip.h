@@ -62,6 +62,14 @@ int cvc_attn_fwd(int kind, const float* q, const float* w_a, const float* b_a, f
                  const cvc_attn_set* sets, int nsets, int nclip, int nq, int A, int R,
                  float* ctx_sum, cvc_stream_t stream);
 
+/* The two passes of cvc_attn_fwd as separate entry points (cvc_attn_fwd == scores then wsum):
+ * pass 1 streams proj [nclip,n,A] once and writes sets[].scores / frame_masked;
+ * pass 2 softmaxes sets[].scores into sets[].attn and streams ctx [nclip,n,R] once. */
+int cvc_attn_scores(int kind, const float* q, const float* w_a, const float* b_a, float inv_temp,
+                    const cvc_attn_set* sets, int nsets, int nclip, int nq, int A, cvc_stream_t stream);
+int cvc_attn_wsum(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum,
+                  cvc_stream_t stream);
+
 /* Backward of cvc_attn_fwd for ONE set, scores recomputed from proj (nothing but attn is
  * saved).  Inputs: d_ctx [rows,R] (nullable), d_fm [rows,n] gradient of the frame_masked
  * output (nullable).  Outputs: d_scores [rows,n] (gradient of the pre-softmax scores; its sum
