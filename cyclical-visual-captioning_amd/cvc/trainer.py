@@ -1,0 +1,180 @@
+"""Train / eval harness with the reference's hooks (trainer.py:26-373): the 12-tuple batch
+contract, the per-batch trimming, the 11-tensor model call, the loss mix (ground_loss is returned
+but never optimised), zero_grad -> backward -> [gradient all-reduce] -> clip_grad_norm_(0.1) ->
+step.  Reference bugs are not copied: `next(it)` instead of `.next()`, the
+reconstruction-loss meter is updated, grounding stats are only logged when they exist.
+
+Caption / grounding scoring lives in external toolkits the reference vendors as (empty)
+submodules; pass `scorer(predictions, grd_output, opts) -> dict` to get language stats.
+"""
+from __future__ import annotations
+
+import time
+from collections import defaultdict
+
+import torch
+import torch.nn as nn
+
+from .distributed import GradReducer
+from .misc import utils
+from .misc.utils import AverageMeter
+
+
+def _trim(t, n, dim=1):
+    return t.narrow(dim, 0, n)
+
+
+class Trainer:
+    def __init__(self, opts, dataset, model, optimizer, train_loader, val_loader, scorer=None, grad_reducer=None):
+        self.opts = opts
+        self.dataset = dataset
+        self.model = model
+        self.optimizer = optimizer
+        self.train_loader = train_loader
+        self.val_loader = val_loader
+        self.scorer = scorer
+        self.grad_reducer = grad_reducer
+        self.device = next(model.parameters()).device
+
+    # ------------------------------------------------------------------ batch plumbing
+    def _prepare(self, batch, train: bool):
+        seg_feat, iseq, gts_seq, num, proposals, bboxs, box_mask, seg_id, region_feat, frm_mask, sample_idx, ppl_mask = batch
+        n_prop = max(int(num[:, 1].max()), 1)
+        proposals, ppl_mask, region_feat = _trim(proposals, n_prop), _trim(ppl_mask, n_prop), _trim(region_feat, n_prop)
+        if train:
+            n_box = max(int(num[:, 2].max()), 1)
+            bboxs, box_mask = _trim(bboxs, n_box), _trim(box_mask, n_box, 2)
+            frm_mask = _trim(_trim(frm_mask, n_prop), n_box, 2)
+        dev = self.device
+        to = lambda x: x.to(dev) if isinstance(x, torch.Tensor) else x
+        seg = {k: to(v) for k, v in seg_feat.items()} if isinstance(seg_feat, dict) else seg_feat.float().to(dev)
+        mask_ppls = to(ppl_mask)
+        pnt_mask = torch.cat((mask_ppls.new_zeros(mask_ppls.size(0), 1), mask_ppls), dim=1)
+        return dict(segs_feat=seg, input_seqs=to(iseq), gt_seqs=to(gts_seq), num=to(num), ppls=to(proposals),
+                    gt_bboxs=to(bboxs), mask_bboxs=to(box_mask), ppls_feat=to(region_feat), mask_frms=to(frm_mask),
+                    sample_idx=to(sample_idx).type_as(to(iseq)), pnt_mask=pnt_mask, seg_id=seg_id)
+
+    def _call(self, b, lang_eval=False):
+        return self.model(b["segs_feat"], b["input_seqs"], b["gt_seqs"], b["num"], b["ppls"], b["gt_bboxs"], b["mask_bboxs"],
+                          b["ppls_feat"], b["mask_frms"], b["sample_idx"], b["pnt_mask"], lang_eval)
+
+    def loss_mix(self, out):
+        """trainer.py:92-109"""
+        o = self.opts
+        lm_loss, att2_loss, _ground_loss, cls_loss = [x.mean() for x in out[:4]]
+        loss = o.xe_loss_weight * lm_loss + o.w_att2 * att2_loss + o.w_cls * cls_loss
+        lm_recon = out[4].mean() if len(out) > 4 else torch.zeros((), device=lm_loss.device)
+        if len(out) > 4:
+            loss = loss + o.caption_consistency_loss_weight * lm_recon
+        return loss, lm_loss, att2_loss, cls_loss, lm_recon
+
+    def train_step(self, batch):
+        b = self._prepare(batch, True)
+        if self.opts.att_model != 'cyclical':
+            raise ValueError('Unknown att_model: {}'.format(self.opts.att_model))
+        out = self._call(b)
+        loss, lm, att2, cls, rec = self.loss_mix(out)
+        self.optimizer.zero_grad()
+        loss.backward()
+        if self.grad_reducer is not None:
+            self.grad_reducer.finalize()                     # the one exchange step of the path
+        nn.utils.clip_grad_norm_(self.model.parameters(), self.opts.grad_clip)
+        self.optimizer.step()
+        return loss.detach(), lm.detach(), att2.detach(), cls.detach(), rec.detach()
+
+    # ------------------------------------------------------------------ epoch loops
+    def train(self, epoch, tb_logger=None):
+        meters = {k: AverageMeter() for k in ("batch", "data", "lm", "attn", "cls", "recon")}
+        self.model.train()
+        it = iter(self.train_loader)
+        end = time.time()
+        n_steps = len(self.train_loader) - 1                 # the reference drops the last batch (:55)
+        for step in range(n_steps):
+            meters["data"].update(time.time() - end)
+            _, lm, att2, cls, rec = self.train_step(next(it))
+            n = self.opts.batch_size * self.opts.seq_per_img
+            meters["lm"].update(lm.item(), n); meters["attn"].update(att2.item(), n)
+            meters["cls"].update(cls.item(), n); meters["recon"].update(rec.item(), n)
+            meters["batch"].update(time.time() - end)
+            end = time.time()
+            if step % self.opts.disp_interval == 0:
+                print('Epoch: [{0}][{1}/{2}]\tTime {b.val:.3f} ({b.avg:.3f})\tData {d.val:.3f} ({d.avg:.3f})\t'
+                      'LM Loss {l.val:.4f} ({l.avg:.4f})\tAttn Loss {a.val:.4f} ({a.avg:.4f})\t'
+                      'Cls Loss {c.val:.4f} ({c.avg:.4f})\tRecon Loss {r.val:.4f} ({r.avg:.4f})'.format(
+                          epoch, step, n_steps, b=meters["batch"], d=meters["data"], l=meters["lm"], a=meters["attn"],
+                          c=meters["cls"], r=meters["recon"]))
+        if tb_logger:
+            tb_logger.add_scalar('train/learning_rate', self.optimizer.param_groups[0]['lr'], epoch)
+            tb_logger.add_scalar('train/lm_loss', meters["lm"].avg, epoch)
+            tb_logger.add_scalar('train/attn_loss', meters["attn"].avg, epoch)
+            tb_logger.add_scalar('train/cls_loss', meters["cls"].avg, epoch)
+            tb_logger.add_scalar('train/lm_recon_loss', meters["recon"].avg, epoch)
+
+    def eval(self, epoch, tb_logger=None):
+        """Greedy (or beam) decode of the validation split -> predictions in the densecap JSON
+        layout (trainer.py:276-286) -> optional external scorer."""
+        self.model.eval()
+        predictions = defaultdict(list)
+        grd_output = defaultdict(dict)
+        o = self.opts
+        ds = self.dataset
+        with torch.no_grad():
+            for batch in self.val_loader:
+                b = self._prepare(batch, False)
+                seq, att2_weights, _ = self._call(b, True)
+                if getattr(o, "eval_obj_grounding", False):
+                    assert o.beam_size == 1, 'only support beam_size is 1'
+                    self._collect_grounding(b, seq, att2_weights, grd_output)
+                sents = utils.decode_sequence(ds.itow, getattr(ds, "itod", None), getattr(ds, "ltow", None),
+                                              getattr(ds, "itoc", None), getattr(ds, "wtod", None), seq.data, o.vocab_size, o)
+                for k, sent in enumerate(sents):
+                    vid_idx, seg_idx = b["seg_id"][k].split('_segment_')
+                    predictions[vid_idx].append({'sentence': sent, 'segment': str(int(seg_idx))})
+        lang_stats = {}
+        if self.scorer is not None:
+            lang_stats = self.scorer(predictions, grd_output, o) or {}
+            if tb_logger:
+                for k, v in lang_stats.items():
+                    tb_logger.add_scalar('eval/' + k, v, epoch)
+        self.predictions = predictions
+        return lang_stats
+
+    def _collect_grounding(self, b, seq, att2_weights, grd_output):
+        """Per generated word, the most attended proposal of every sampled frame (trainer.py:217-248)."""
+        o = self.opts
+        B = seq.size(0)
+        ppls = b["ppls"]
+        att2_ind = torch.max(att2_weights.view(B, att2_weights.size(1), o.num_sampled_frm, o.num_prop_per_frm), dim=-1)[1]
+        boxes = torch.gather(ppls.view(-1, o.num_sampled_frm, o.num_prop_per_frm, 7).permute(0, 2, 1, 3).contiguous(), 1,
+                             att2_ind.unsqueeze(-1).expand(B, att2_ind.size(1), o.num_sampled_frm, ppls.size(-1)))
+        lemma_det = {o.wtol[k]: i for k, i in o.wtod.items() if k in o.wtol}
+        for i in range(B):
+            vid_id, seg_idx = b["seg_id"][i].split('_segment_')
+            res = {'clss': [], 'idx_in_sent': [], 'bbox_for_all_frames': []}
+            for j in range(seq.size(1)):
+                w = seq[i, j].item()
+                if w == 0:
+                    break
+                lemma = o.wtol[o.itow[str(w)]]
+                if lemma in lemma_det:
+                    res['bbox_for_all_frames'].append(boxes[i, j, :, :4].tolist())
+                    res['clss'].append(o.itod[lemma_det[lemma]])
+                    res['idx_in_sent'].append(j)
+            grd_output[vid_id][str(int(seg_idx))] = res
+
+
+def build_optimizer(model, opt):
+    """One param group per tensor; 0.1x LR for ctx2pool_grd / vis_embed (reference main.py:171-191)."""
+    params = []
+    for key, value in dict(model.named_parameters()).items():
+        if not value.requires_grad:
+            continue
+        lr = opt.learning_rate * (0.1 if ('ctx2pool_grd' in key or 'vis_embed' in key) else 1.0)
+        params.append({'params': [value], 'lr': lr, 'weight_decay': opt.weight_decay, 'betas': (opt.optim_alpha, opt.optim_beta)})
+    if opt.optim == 'sgd':
+        return torch.optim.SGD([{k: v for k, v in p.items() if k != 'betas'} for p in params], lr=opt.learning_rate, momentum=0.9)
+    if opt.optim == 'adam':
+        return torch.optim.Adam(params)
+    if opt.optim == 'adamax':
+        return torch.optim.Adamax(params)
+    raise ValueError('Unknown optimizer: {}'.format(opt.optim))

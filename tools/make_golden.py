@@ -299,9 +299,52 @@ def g3_shards(path):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+# ------------------------------------------------------------------------------------ G4 (config surface)
+def g4_config_surface(path):
+    """state_dict key/shape list of the reference model and the routing performed by its stage-2
+    warm-start loader (cycle_utils.py:30-101), captured by tagging every checkpoint tensor."""
+    import json
+    import pickle
+    import tempfile
+    from cycle_utils import resume_decoder_roiextractor
+    d = synth.CONFIGS["tiny"]
+    sd = synth.hot_path_state_dict(d, 1)
+    ft = feats_to_torch(synth.clip_features(d, 1), False)
+    model = build_reference_model(d, sd, ft)
+    keys = {k: list(v.shape) for k, v in model.state_dict().items()}
+    # tag: every checkpoint tensor is filled with its own ordinal
+    ckpt = OrderedDict()
+    for i, (k, v) in enumerate(model.state_dict().items()):
+        ckpt[k] = torch.full_like(v, float(i + 1)) if v.dtype.is_floating_point else v.clone()
+    order = list(ckpt.keys())
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "baseline"))
+    torch.save(ckpt, os.path.join(tmp, "baseline", "model-best.pth"))
+    with open(os.path.join(tmp, "baseline", "infos_-best.pkl"), "wb") as f:
+        pickle.dump({"epoch": 7}, f)
+    opts = make_opts(d, checkpoint_dir=tmp + "/", id="", resume_embed=1, resume_logit=1, resume_roi_extractor=1)
+    decoder = TopDownDecoderCore(opts)
+    embed = nn.Sequential(nn.Embedding(d.V, d.E), nn.ReLU(), nn.Dropout(0.5))
+    logit = nn.Linear(d.R, d.V)
+    roi = FeatureStub(d, ft)
+    resume_decoder_roiextractor(opts, "baseline", decoder, embed, logit, roi)
+    routing = {}
+    for name, mod in (("decoder_core", decoder), ("embed", embed), ("logit", logit), ("roi_feat_extractor", roi)):
+        for k, v in mod.state_dict().items():
+            routing[name + "." + k] = order[int(round(float(v.reshape(-1)[0]))) - 1]
+    json.dump({"state_dict": keys, "warm_start_routing": routing, "start_epoch": opts.start_epoch},
+              open(path, "w"), indent=1, sort_keys=True)
+    print("wrote", path)
+
+
 if __name__ == "__main__":
     gdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gdir, exist_ok=True)
-    g1_tiny(os.path.join(gdir, "g1_tiny.npz"))
-    g2_cfg1(os.path.join(gdir, "g2_cfg1.npz"))
-    g3_shards(os.path.join(gdir, "g3_shards.npz"))
+    only = sys.argv[1:]
+    jobs = {"g1": lambda: g1_tiny(os.path.join(gdir, "g1_tiny.npz")),
+            "g2": lambda: g2_cfg1(os.path.join(gdir, "g2_cfg1.npz")),
+            "g3": lambda: g3_shards(os.path.join(gdir, "g3_shards.npz")),
+            "g4": lambda: g4_config_surface(os.path.join(gdir, "config_surface.json"))}
+    for name, job in jobs.items():
+        if not only or name in only:
+            job()
