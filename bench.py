@@ -52,6 +52,25 @@ def parse():
     return p.parse_args()
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (os.cpu_count() reports the whole host and oversubscribes a containerised run)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def algorithmic_work(d, beam):
     """Per-launch algorithmic bytes / flops of every kernel of one decode step (DESIGN.md section 4;
     SURVEY.md section 8(d) per-unit figures x the units one launch processes = B clips)."""
@@ -166,7 +185,7 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import ref_cpu as O
-        ncores = os.cpu_count() or 1
+        ncores = usable_cores()
         torch.set_num_threads(ncores)
         P_cpu, f_cpu = O.to_torch(sd_np), O.to_torch(feats_np)
         best = None
