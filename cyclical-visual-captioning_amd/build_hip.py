@@ -45,6 +45,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
         objs.append(obj)
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-c", src, "-o", obj]
+        cmd += os.environ.get("CVC_EXTRA_HIPCC_FLAGS", "").split()      # e.g. -DCVC_ABL=1 for ablation builds
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))

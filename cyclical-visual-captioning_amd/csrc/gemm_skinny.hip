@@ -32,6 +32,7 @@ struct GemmArgs {
     const float* bias;
     const float* bias2;
     const float* c_prev;
+    const float* gate_bias;   // lstm: optional per-row additive gate term [M, 4R] (loop-invariant inputs hoisted)
     float* y;                 // linear: y [M, ldy]; lstm: h_out [M, R]
     float* c_out;
     float* gates_out;
@@ -84,6 +85,90 @@ __device__ __forceinline__ void mma_chunk(const Frag<MT>& f, f32x16 (&acc)[MT]) 
     }
 }
 
+// Combine the NW partial 32 x (MT*32) tiles through LDS in a fixed order (run-to-run
+// deterministic) and finish: bias (+ LSTM cell update).  `red` needs min(NW,4)*32*(MT*32+1) floats.
+template <int MT, int NW, bool LSTM>
+__device__ __forceinline__ void combine_and_store(f32x16 (&acc)[MT], float* red, const GemmArgs& a) {
+    constexpr int LDM = MT * 32 + 1;
+    constexpr int NRED = NW > 4 ? 4 : NW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kh = lane >> 5;
+    const int M = a.M, R = a.R;
+    // ---- combine the NW partial tiles (fixed order => run-to-run deterministic)
+    // D layout of 32x32 MFMA: lane holds col = lane & 31 (batch), rows (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    auto spill = [&](int slot) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                red[(slot * 32 + row) * LDM + mt * 32 + i] = acc[mt][r];
+            }
+    };
+    if (NW > 4) {
+        if (wave >= 4) spill(wave - 4);
+        __syncthreads();
+        if (wave < 4) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    acc[mt][r] += red[(wave * 32 + row) * LDM + mt * 32 + i];
+                }
+        }
+        __syncthreads();
+        if (wave < 4) spill(wave);
+    } else {
+        spill(wave);
+    }
+    __syncthreads();
+
+    if (LSTM) {
+        // unit u -> (hidden jj in 0..7, batch row m); reads along m are conflict-free
+        const int j0 = blockIdx.x * 8;
+        for (int u = tid; u < 8 * MT * 32; u += NW * 64) {
+            const int m = u % (MT * 32), jj = u / (MT * 32);
+            if (m >= M) continue;
+            const int j = j0 + jj;
+            float pre[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v = 0.f;
+#pragma unroll
+                for (int w = 0; w < NRED; ++w) v += red[(w * 32 + g * 8 + jj) * LDM + m];
+                if (a.bias != nullptr) v += a.bias[g * R + j];
+                if (a.bias2 != nullptr) v += a.bias2[g * R + j];
+                if (a.gate_bias != nullptr) v += a.gate_bias[(size_t)m * 4 * R + g * R + j];
+                pre[g] = v;
+            }
+            const float ig = fast_sigmoid(pre[0]), fg = fast_sigmoid(pre[1]);
+            const float gg = fast_tanh(pre[2]), og = fast_sigmoid(pre[3]);
+            const float c2 = fg * a.c_prev[(size_t)m * R + j] + ig * gg;
+            a.c_out[(size_t)m * R + j] = c2;
+            a.y[(size_t)m * R + j] = og * fast_tanh(c2);
+            if (a.gates_out != nullptr) {
+                float* go = a.gates_out + (size_t)m * 4 * R + j;
+                go[0] = ig; go[R] = fg; go[2 * R] = gg; go[3 * R] = og;
+            }
+        }
+    } else {
+        // unit u -> (n local in 0..31 fastest, batch row m): coalesced stores along n
+        const int n0 = blockIdx.x * 32;
+        for (int u = tid; u < 32 * MT * 32; u += NW * 64) {
+            const int nl = u & 31, m = u >> 5;
+            const int n = n0 + nl;
+            if (m >= M || n >= a.Nout) continue;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NRED; ++w) v += red[(w * 32 + nl) * LDM + m];
+            if (a.bias != nullptr) v += a.bias[n];
+            if (a.bias2 != nullptr) v += a.bias2[n];
+            a.y[(size_t)m * a.ldy + n] = v;
+        }
+    }
+}
+
 // MT = number of 32-row batch tiles (M <= 32*MT); NW = waves per workgroup (K split)
 template <int MT, int NW, bool LSTM>
 __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(GemmArgs a) {
@@ -132,79 +217,217 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(GemmArgs a) {
         it += NW;
     }
 
-    // ---- combine the NW partial tiles (fixed order => run-to-run deterministic)
-    // D layout of 32x32 MFMA: lane holds col = lane & 31 (batch), rows (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-    auto spill = [&](int slot) {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                red[(slot * 32 + row) * LDM + mt * 32 + i] = acc[mt][r];
-            }
-    };
-    if (NW > 4) {
-        if (wave >= 4) spill(wave - 4);
-        __syncthreads();
-        if (wave < 4) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                    acc[mt][r] += red[(wave * 32 + row) * LDM + mt * 32 + i];
-                }
-        }
-        __syncthreads();
-        if (wave < 4) spill(wave);
-    } else {
-        spill(wave);
-    }
-    __syncthreads();
-
-    if (LSTM) {
-        // unit u -> (hidden jj in 0..7, batch row m); reads along m are conflict-free
-        const int j0 = blockIdx.x * 8;
-        for (int u = tid; u < 8 * MT * 32; u += NW * 64) {
-            const int m = u % (MT * 32), jj = u / (MT * 32);
-            if (m >= M) continue;
-            const int j = j0 + jj;
-            float pre[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float v = 0.f;
-#pragma unroll
-                for (int w = 0; w < NRED; ++w) v += red[(w * 32 + g * 8 + jj) * LDM + m];
-                pre[g] = v + a.bias[g * R + j] + a.bias2[g * R + j];
-            }
-            const float ig = fast_sigmoid(pre[0]), fg = fast_sigmoid(pre[1]);
-            const float gg = fast_tanh(pre[2]), og = fast_sigmoid(pre[3]);
-            const float c2 = fg * a.c_prev[(size_t)m * R + j] + ig * gg;
-            a.c_out[(size_t)m * R + j] = c2;
-            a.y[(size_t)m * R + j] = og * fast_tanh(c2);
-            if (a.gates_out != nullptr) {
-                float* go = a.gates_out + (size_t)m * 4 * R + j;
-                go[0] = ig; go[R] = fg; go[2 * R] = gg; go[3 * R] = og;
-            }
-        }
-    } else {
-        // unit u -> (n local in 0..31 fastest, batch row m): coalesced stores along n
-        const int n0 = blockIdx.x * 32;
-        for (int u = tid; u < 32 * MT * 32; u += NW * 64) {
-            const int nl = u & 31, m = u >> 5;
-            const int n = n0 + nl;
-            if (m >= M || n >= a.Nout) continue;
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < NRED; ++w) v += red[(w * 32 + nl) * LDM + m];
-            if (a.bias != nullptr) v += a.bias[n];
-            if (a.bias2 != nullptr) v += a.bias2[n];
-            a.y[(size_t)m * a.ldy + n] = v;
-        }
-    }
+    combine_and_store<MT, NW, LSTM>(acc, red, a);
 }
 
-int fill_args(GemmArgs& a, const cvc_gemm_seg* segs, int nsegs) {
+// ------------------------------------------------------------------------------------------
+// Fast path (every segment's k a multiple of 32): wave-private LDS rings, no workgroup barrier
+// in the K loop.
+//
+// Why: the direct-load kernel above fetches MFMA fragments as 32 rows x 16 B per instruction and
+// keeps the texture-address path busier than the matrix pipe (measured 196 us for the cfg2
+// att-LSTM = 24 % of the fp32 MFMA rate).  A first LDS version with workgroup-wide 128-k stages and
+// two barriers per stage reached 48 % (98 us): only one 16 KB weight stage in flight per CU and
+// every wave stalling at the same barrier.  Here:
+//   * 4 waves per workgroup (one per SIMD) split K by 32-k chunks (chunk c -> wave c mod 4), and
+//     each wave owns a private 3-slot LDS ring: it copies ITS chunk (32 weight rows + MT*32
+//     activation rows, 128 B = one full cache line per row) with LDS-DMA
+//     (global_load_lds_dwordx4: 8 rows x 128 B per wave instruction), keeps two chunks in flight
+//     (counted s_waitcnt vmcnt, ~32 KB of weights in flight per CU) and reads its fragments back
+//     with ds_read_b128 -- wave-local ordering only, so waves drift apart and the MFMA pipe of a
+//     SIMD never waits for a neighbour;
+//   * LDS image is lane-linear per DMA instruction, so the bank-conflict fix sits on the SOURCE
+//     address: 16-B slot s of row r holds k-quad s ^ ((r >> 1) & 7); the fragment read applies the
+//     same XOR, which spreads the 16 rows of a ds_read_b128 lane group over 16 distinct slots;
+//   * fragments of chunk j+1 are read while the 32 MFMAs of chunk j issue (two accumulators
+//     alternate, so the 64-cycle v_mfma_f32_32x32x2_f32 issues back to back);
+//   * the four 32 x M partial tiles meet in the ordered LDS reduction shared with the generic kernel.
+constexpr int RK = 32;                                     // k per chunk
+constexpr int RING = 3;
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+template <int MT>
+struct RFrag {
+    f32x4 w[2];
+    f32x4 x[MT][2];
+};
+
+template <int MT, bool LSTM>
+__global__ __launch_bounds__(256) void skinny_gemm_ring_kernel(GemmArgs a) {
+    constexpr int NW = 4;
+    constexpr int ROWS = 32 + MT * 32;
+    constexpr int STAGE = ROWS * RK * 4;                   // 8 / 12 KB
+    constexpr int NLOAD = ROWS / 8;                        // DMA instructions per chunk: 8 / 12
+    constexpr int RED_BYTES = NW * 32 * (MT * 32 + 1) * 4;
+    constexpr int LDS_BYTES = NW * RING * STAGE > RED_BYTES ? NW * RING * STAGE : RED_BYTES;
+    __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, kh = lane >> 5;
+    const int M = a.M, R = a.R;
+    char* ring = lds + wave * RING * STAGE;
+
+    // ---- staging geometry: DMA instruction u of an operand covers rows 8u .. 8u+7 (128 B each);
+    // this lane copies 16 B: row 8u + (lane >> 3), slot lane & 7 <- k-quad slot ^ ((row >> 1) & 7).
+    const int prow = lane >> 3;
+    const int kq0 = ((lane & 7) ^ (lane >> 4)) * 4;        // u even: (row >> 1) & 7 = lane >> 4
+    const int kq1 = ((lane & 7) ^ (4 + (lane >> 4))) * 4;  // u odd
+
+    // fragment addresses: row i (weights) / mt*32 + i (activations); this lane's 16 k of the chunk
+    // are k-quads 4*kh .. 4*kh+3 -> physical slots q ^ ((i >> 1) & 7).  (A 32x32x2 MFMA wants
+    // A[i][k = lane >> 5]: lanes 0-31 carry k 0..15 of the chunk, lanes 32-63 k 16..31.)
+    const int fsw = (i >> 1) & 7;
+    int fo[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) fo[q] = i * (RK * 4) + (((4 * kh + q) ^ fsw) & 7) * 16;
+
+    auto read_frags = [&](RFrag<MT>(&f)[2], int slot) __attribute__((always_inline)) {
+        const char* base = ring + slot * STAGE;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                f[h].w[p] = *reinterpret_cast<const f32x4*>(base + fo[2 * h + p]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    f[h].x[mt][p] = *reinterpret_cast<const f32x4*>(base + 4096 + mt * 4096 + fo[2 * h + p]);
+            }
+    };
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+    // relu (embedding segment) is applied branch-free when the fragment is consumed
+    auto mma = [&](const RFrag<MT>(&f)[2], float lo) __attribute__((always_inline)) {
+#if defined(CVC_ABL) && CVC_ABL == 2
+        // ablation: no MFMA (memory pipeline only); keep the fragments live
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                asm volatile("" ::"v"(f[h].w[p]));
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(f[h].x[mt][p]));
+            }
+        return;
+#endif
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[h].w[p][e], fmaxf(f[h].x[mt][p][e], lo), acc[mt], 0, 0, 0);
+    };
+
+    // ---- K loop: segment by segment (the decode engine passes ONE pre-concatenated segment, so the
+    // pipeline below never restarts there); inside a segment everything is affine in the chunk index.
+    for (int sg = 0; sg < a.nsegs; ++sg) {
+        const cvc_gemm_seg g = a.seg[sg];
+        const int nchunk = g.k / RK;
+        const int n_my = nchunk > wave ? (nchunk - wave + NW - 1) / NW : 0;     // local chunks wave, wave+4, ...
+        if (n_my == 0) continue;
+        const float lo = g.relu ? 0.f : -__builtin_inff();
+        // per-lane element offsets of the rows this lane copies (32-bit, checked on the host)
+        unsigned woff[4], xoff[4 * MT];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int wrow = LSTM ? u * R + (int)blockIdx.x * 8 + prow : min((int)blockIdx.x * 32 + 8 * u + prow, a.Nout - 1);
+            woff[u] = (unsigned)wrow * (unsigned)g.ldw + ((u & 1) ? kq1 : kq0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4 * MT; ++u) {
+            const int m = min(8 * u + prow, M - 1);
+            const unsigned xr = g.idx != nullptr ? (unsigned)g.idx[m] : (unsigned)m;
+            xoff[u] = xr * (unsigned)g.ldx + ((u & 1) ? kq1 : kq0);
+        }
+        const float* wp = g.w + wave * RK;          // chunk c of this wave starts at k = (wave + c*NW) * RK
+        const float* xp = g.x + wave * RK;
+
+        // issue the 4 + 4*MT DMA instructions of this wave's local chunk c into ring slot c % RING
+        auto stage = [&](int c) __attribute__((always_inline)) {
+#if defined(CVC_ABL) && CVC_ABL == 1
+            if (c >= 0) return;       // ablation: no DMA (MFMA + LDS only)
+#endif
+            char* base = ring + (c % RING) * STAGE;
+            const float* wc = wp + (size_t)c * (NW * RK);
+            const float* xc = xp + (size_t)c * (NW * RK);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(wc + woff[u]), (lds_ptr_t)(base + u * 1024), 16, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 4 * MT; ++u)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(xc + xoff[u]), (lds_ptr_t)(base + 4096 + u * 1024), 16, 0, 0);
+        };
+
+        // one steady-state step: chunk c is in `cur`; put chunk c+2 in flight, pull chunk c+1 into `nxt`,
+        // multiply chunk c.  The directives ask the scheduler to issue the DMA / address math and the
+        // LDS reads in the shadow of the 64-cycle MFMAs instead of serialising them after the block.
+        auto step = [&](const RFrag<MT>(&cur)[2], RFrag<MT>(&nxt)[2], int c) __attribute__((always_inline)) {
+            stage(c + 2);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+            read_frags(nxt, (c + 1) % RING);
+            mma(cur, lo);
+#pragma unroll
+            for (int q = 0; q < NLOAD; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // VALU (addresses, relu)
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (LDS-DMA)
+            }
+#pragma unroll
+            for (int q = 0; q < NLOAD; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
+            }
+        };
+
+        RFrag<MT> fa[2], fb[2];
+        // the previous segment's LDS reads are complete (consumed by its MFMAs): slots are free
+        stage(0);
+        if (n_my > 1) stage(1);
+        if (n_my > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        read_frags(fa, 0);
+        int c = 0;
+        for (; c + 3 < n_my; c += 2) {       // steady state, unrolled by two: fragment registers are statically named
+            step(fa, fb, c);
+            step(fb, fa, c + 1);
+        }
+        while (c < n_my) {                   // drain (at most 3 chunks left; chunk c is in fa)
+            if (c + 2 < n_my) stage(c + 2);
+            if (c + 1 < n_my) {
+                if (c + 2 < n_my) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                read_frags(fb, (c + 1) % RING);
+            }
+            mma(fa, lo);
+            ++c;
+            if (c >= n_my) break;
+            if (c + 2 < n_my) stage(c + 2);
+            if (c + 1 < n_my) {
+                if (c + 2 < n_my) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                read_frags(fa, (c + 1) % RING);
+            }
+            mma(fb, lo);
+            ++c;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();                                       // rings are dead: LDS becomes the reduction buffer
+    combine_and_store<MT, NW, LSTM>(acc, reinterpret_cast<float*>(lds), a);
+}
+
+int fill_args(GemmArgs& a, const cvc_gemm_seg* segs, int nsegs, int chunk) {
     if (nsegs < 1 || nsegs > MAXSEG) return CVC_E_BADARG;
     a.nsegs = nsegs;
     a.prefix[0] = 0;
@@ -214,7 +437,7 @@ int fill_args(GemmArgs& a, const cvc_gemm_seg* segs, int nsegs) {
             if (g.k < 4 || (g.k & 3) || (g.ldx & 3) || (g.ldw & 3) || !g.x || !g.w) return CVC_E_BADARG;
             if (((uintptr_t)g.x & 15) || ((uintptr_t)g.w & 15)) return CVC_E_BADARG;
             a.seg[s] = g;
-            a.prefix[s + 1] = a.prefix[s] + (g.k + KC - 1) / KC;
+            a.prefix[s + 1] = a.prefix[s] + (g.k + chunk - 1) / chunk;
         } else {
             a.seg[s] = segs[0];
             a.prefix[s + 1] = a.prefix[s];
@@ -224,13 +447,32 @@ int fill_args(GemmArgs& a, const cvc_gemm_seg* segs, int nsegs) {
     return 0;
 }
 
+// LDS-DMA fast path needs whole 32-k chunks (full 128-B lines per row) and at most one gather segment
+bool fast_ok(const cvc_gemm_seg* segs, int nsegs, int Nout_rows) {
+    int gathers = 0;
+    for (int s = 0; s < nsegs; ++s) {
+        if (segs[s].k % RK) return false;
+        if ((segs[s].ldx & 3) || (segs[s].ldw & 3)) return false;
+        if ((long long)Nout_rows * segs[s].ldw >= (1LL << 32) - 64) return false;   // 32-bit element offsets
+        gathers += segs[s].idx != nullptr;
+    }
+    return gathers <= 1;
+}
+
 template <bool LSTM>
-int launch(const GemmArgs& a, int blocks, hipStream_t st) {
-    if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_kernel<1, 8, LSTM>), dim3(blocks), dim3(512), 0, st, a);
-    else if (a.M <= 64) hipLaunchKernelGGL((skinny_gemm_kernel<2, 8, LSTM>), dim3(blocks), dim3(512), 0, st, a);
-    else return CVC_E_TOOBIG;
+int launch(const GemmArgs& a, int blocks, bool fast, hipStream_t st) {
+    if (a.M > 64) return CVC_E_TOOBIG;
+    if (fast) {
+        if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_ring_kernel<1, LSTM>), dim3(blocks), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((skinny_gemm_ring_kernel<2, LSTM>), dim3(blocks), dim3(256), 0, st, a);
+    } else {
+        if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_kernel<1, 8, LSTM>), dim3(blocks), dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((skinny_gemm_kernel<2, 8, LSTM>), dim3(blocks), dim3(512), 0, st, a);
+    }
     return cvc_launch_status();
 }
+
+int g_force_generic = 0;   // test hook: cvc_gemm_force_generic(1) routes everything to the direct-load kernel
 
 }  // namespace
 
@@ -247,21 +489,22 @@ extern "C" int cvc_linear_fwd(const cvc_gemm_seg* segs, int nsegs, const float* 
             tmp[s] = segs[s];
             if (tmp[s].idx) tmp[s].idx += m0; else tmp[s].x += (size_t)m0 * tmp[s].ldx;
         }
-        int rc = fill_args(a, tmp, nsegs);
+        const bool fast = !g_force_generic && fast_ok(tmp, nsegs, Nout);
+        int rc = fill_args(a, tmp, nsegs, fast ? RK : KC);
         if (rc) return rc;
         a.M = M - m0 < 64 ? M - m0 : 64; a.Nout = Nout; a.R = 0;
-        a.bias = bias; a.bias2 = bias2; a.c_prev = nullptr;
+        a.bias = bias; a.bias2 = bias2; a.c_prev = nullptr; a.gate_bias = nullptr;
         a.y = y + (size_t)m0 * ldy; a.c_out = nullptr; a.gates_out = nullptr; a.ldy = ldy;
-        rc = launch<false>(a, (Nout + 31) / 32, (hipStream_t)stream);
+        rc = launch<false>(a, (Nout + 31) / 32, fast, (hipStream_t)stream);
         if (rc) return rc;
     }
     return 0;
 }
 
 extern "C" int cvc_lstm_cell_fwd(const cvc_gemm_seg* segs, int nsegs, const float* b_ih, const float* b_hh,
-                                 const float* c_prev, int M, int R, float* h_out, float* c_out,
-                                 float* gates_out, cvc_stream_t stream) {
-    if (M < 1 || R < 8 || (R & 7) || !b_ih || !b_hh || !c_prev || !h_out || !c_out) return CVC_E_BADARG;
+                                 const float* gate_bias, const float* c_prev, int M, int R, float* h_out,
+                                 float* c_out, float* gates_out, cvc_stream_t stream) {
+    if (M < 1 || R < 8 || (R & 7) || !c_prev || !h_out || !c_out) return CVC_E_BADARG;
     for (int m0 = 0; m0 < M; m0 += 64) {
         GemmArgs a{};
         cvc_gemm_seg tmp[MAXSEG];
@@ -270,14 +513,22 @@ extern "C" int cvc_lstm_cell_fwd(const cvc_gemm_seg* segs, int nsegs, const floa
             tmp[s] = segs[s];
             if (tmp[s].idx) tmp[s].idx += m0; else tmp[s].x += (size_t)m0 * tmp[s].ldx;
         }
-        int rc = fill_args(a, tmp, nsegs);
+        const bool fast = !g_force_generic && fast_ok(tmp, nsegs, 4 * R);
+        int rc = fill_args(a, tmp, nsegs, fast ? RK : KC);
         if (rc) return rc;
         a.M = M - m0 < 64 ? M - m0 : 64; a.Nout = 4 * R; a.R = R;
         a.bias = b_ih; a.bias2 = b_hh; a.c_prev = c_prev + (size_t)m0 * R;
+        a.gate_bias = gate_bias ? gate_bias + (size_t)m0 * 4 * R : nullptr;
         a.y = h_out + (size_t)m0 * R; a.c_out = c_out + (size_t)m0 * R;
         a.gates_out = gates_out ? gates_out + (size_t)m0 * 4 * R : nullptr; a.ldy = R;
-        rc = launch<true>(a, R / 8, (hipStream_t)stream);
+        rc = launch<true>(a, R / 8, fast, (hipStream_t)stream);
         if (rc) return rc;
     }
     return 0;
+}
+
+extern "C" int cvc_gemm_force_generic(int on) {
+    const int prev = g_force_generic;
+    g_force_generic = on ? 1 : 0;
+    return prev;
 }

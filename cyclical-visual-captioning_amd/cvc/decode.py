@@ -2,7 +2,7 @@
 kernel launches (reference model/captioner.py:384-443, `_sample`).
 
 Per step (7 launches, nothing returns to the host, no allocation):
-  att-LSTM  : concat-GEMM over [h_lang(t-1) | fc | relu(Emb[word])] + h_att(t-1), fused cell update
+  att-LSTM  : concat-GEMM over [h_lang(t-1) | relu(Emb[word])] + h_att(t-1) + hoisted fc gate term, fused cell update
   h2attn    : q = W_h h_att + b_h
   attention : score pass over p_pool/p_conv, softmax + weighted-sum pass over pool/conv
   lang-LSTM : concat-GEMM over [ctx_regions + ctx_frames | h_att] + h_lang(t-1), fused cell update
@@ -88,6 +88,7 @@ class DecodeEngine:
         self.attn_f = z(rows, Fr)
         self.ctx_sum = z(rows, R)
         self.logits = z(rows, V)
+        self.gate_fc = z(rows, 4 * R)      # step-invariant part of the att-LSTM gates: fc x W_ih[:, R:2R] + b_ih + b_hh
         self.att_steps = z(self.T, rows, N)                       # post-softmax region attention per step
         self.words = torch.zeros(self.T + 1, rows, dtype=torch.int64, device=dev)   # words[0] = BOS = 0
         self.logprob = z(self.T, rows)
@@ -111,14 +112,19 @@ class DecodeEngine:
         fc, conv, pconv, pool, ppool = self.feats
         ptr = lambda t: None if t is None else t.data_ptr()
         out = []
+        # fc_feats does not change over the T steps (decoder_core.py:46): its gate contribution and the
+        # two bias vectors are computed once per decode, inside the timed/captured region
+        seg_fc = _segs([(fc, self.clip_of_row if beam > 1 else None, W.w_ih_att[:, R:2 * R], False)])
+        out.append(("gate_fc", L.cvc_linear_fwd, (seg_fc, 1, ptr(W.b_ih_att), ptr(W.b_hh_att), rows, 4 * R, ptr(self.gate_fc),
+                                                  4 * R)))
+        self._keep.append(seg_fc)
         for t in range(self.T):
             rd, wr = t & 1, (t + 1) & 1
-            # att-LSTM: [h_lang(t-1) | fc | relu(Emb[word_t])] x W_ih  +  h_att(t-1) x W_hh
+            # att-LSTM: [h_lang(t-1) | relu(Emb[word_t])] x W_ih  +  h_att(t-1) x W_hh  + gate_fc
             seg_att = _segs([(self.h_lang[rd], None, W.w_ih_att[:, 0:R], False),
-                             (fc, self.clip_of_row if beam > 1 else None, W.w_ih_att[:, R:2 * R], False),
                              (W.embed, self.words[t], W.w_ih_att[:, 2 * R:2 * R + E], True),
                              (self.h_att[rd], None, W.w_hh_att, False)])
-            out.append(("att_lstm", L.cvc_lstm_cell_fwd, (seg_att, 4, ptr(W.b_ih_att), ptr(W.b_hh_att), ptr(self.c_att[rd]),
+            out.append(("att_lstm", L.cvc_lstm_cell_fwd, (seg_att, 3, None, None, ptr(self.gate_fc), ptr(self.c_att[rd]),
                                                           rows, R, ptr(self.h_att[wr]), ptr(self.c_att[wr]), None)))
             seg_q = _segs([(self.h_att[wr], None, W.w_h, False)])
             out.append(("h2attn", L.cvc_linear_fwd, (seg_q, 1, ptr(W.b_h), None, rows, A, ptr(self.q), A)))
@@ -132,8 +138,9 @@ class DecodeEngine:
             seg_lang = _segs([(self.ctx_sum, None, W.w_ih_lang[:, 0:R], False),
                               (self.h_att[wr], None, W.w_ih_lang[:, R:2 * R], False),
                               (self.h_lang[rd], None, W.w_hh_lang, False)])
-            out.append(("lang_lstm", L.cvc_lstm_cell_fwd, (seg_lang, 3, ptr(W.b_ih_lang), ptr(W.b_hh_lang), ptr(self.c_lang[rd]),
-                                                           rows, R, ptr(self.h_lang[wr]), ptr(self.c_lang[wr]), None)))
+            out.append(("lang_lstm", L.cvc_lstm_cell_fwd, (seg_lang, 3, ptr(W.b_ih_lang), ptr(W.b_hh_lang), None,
+                                                           ptr(self.c_lang[rd]), rows, R, ptr(self.h_lang[wr]),
+                                                           ptr(self.c_lang[wr]), None)))
             seg_o = _segs([(self.h_lang[wr], None, W.w_o, False)])
             out.append(("logits", L.cvc_linear_fwd, (seg_o, 1, ptr(W.b_o), None, rows, V, ptr(self.logits), V)))
             if beam == 1:

@@ -38,7 +38,8 @@ SIGNATURES = {
     "cvc_attn_wsum": [C.POINTER(AttnSet), _I, _I, _I, _I, _P, _P],
     "cvc_attn_bwd": [_I, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "cvc_linear_fwd": [C.POINTER(GemmSeg), _I, _P, _P, _I, _I, _P, _I, _P],
-    "cvc_lstm_cell_fwd": [C.POINTER(GemmSeg), _I, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "cvc_gemm_force_generic": [_I],
+    "cvc_lstm_cell_fwd": [C.POINTER(GemmSeg), _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "cvc_lstm_pointwise_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     "cvc_embed_relu_fwd": [_P, _P, _P, _I, _I, _P, _P],
     "cvc_embed_relu_bwd": [_P, _P, _P, _P, _I, _I, _P, _P],
@@ -192,14 +193,19 @@ def linear_fwd(segs: Sequence[dict], bias: Optional[torch.Tensor], M: int, Nout:
     return y
 
 
-def lstm_cell_fwd(segs: Sequence[dict], b_ih, b_hh, c_prev, want_gates: bool = False, h_out=None, c_out=None):
+def gemm_force_generic(on: bool) -> bool:
+    return bool(lib().cvc_gemm_force_generic(1 if on else 0))
+
+
+def lstm_cell_fwd(segs: Sequence[dict], b_ih, b_hh, c_prev, want_gates: bool = False, h_out=None, c_out=None,
+                  gate_bias=None):
     M, R = c_prev.shape
     h = h_out if h_out is not None else torch.empty_like(c_prev)
     c = c_out if c_out is not None else torch.empty_like(c_prev)
     gates = torch.empty(M, 4 * R, device=c_prev.device, dtype=torch.float32) if want_gates else None
     arr = _segs(segs, M)
-    _check(lib().cvc_lstm_cell_fwd(arr, len(segs), _dev(b_ih), _dev(b_hh), _dev(c_prev), M, R, _dev(h), _dev(c), _dev(gates),
-                                   _stream()), "cvc_lstm_cell_fwd")
+    _check(lib().cvc_lstm_cell_fwd(arr, len(segs), _dev(b_ih), _dev(b_hh), _dev(gate_bias), _dev(c_prev), M, R, _dev(h),
+                                   _dev(c), _dev(gates), _stream()), "cvc_lstm_cell_fwd")
     return h, c, gates
 
 

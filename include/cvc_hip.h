@@ -101,13 +101,21 @@ typedef struct {
 int cvc_linear_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, const float* bias2,
                    int M, int Nout, float* y, int ldy, cvc_stream_t stream);
 
+/* Test hook: route every concat-GEMM to the generic direct-load kernel (on != 0) instead of the
+ * LDS-DMA fast path that is taken when all segment widths are multiples of 128.  Returns the
+ * previous setting.  Both kernels compute the same sums in different k-orders. */
+int cvc_gemm_force_generic(int on);
+
 /* nn.LSTMCell (gate order i,f,g,o; decoder_core.py:14,27,50,61): gates = concat-GEMM with
  * Nout = 4R + b_ih + b_hh; c' = sig(f) c + sig(i) tanh(g); h' = sig(o) tanh(c').
  * c_prev/h_out/c_out are [M, R] contiguous.  gates_out [M, 4R] (nullable) receives the
- * ACTIVATED gates (i,f,g,o) for the backward pass.  Requires R % 8 == 0. */
+ * ACTIVATED gates (i,f,g,o) for the backward pass.  b_ih / b_hh are nullable; gate_bias
+ * [M, 4R] (nullable) is a per-row additive pre-activation term: the decode loop hoists the
+ * step-invariant part of the gate GEMM (fc_feats x W_ih[:, R:2R] + biases, decoder_core.py:46)
+ * out of the T loop and passes it here.  Requires R % 8 == 0. */
 int cvc_lstm_cell_fwd(const cvc_gemm_seg* segs, int nsegs, const float* b_ih, const float* b_hh,
-                      const float* c_prev, int M, int R, float* h_out, float* c_out,
-                      float* gates_out, cvc_stream_t stream);
+                      const float* gate_bias, const float* c_prev, int M, int R, float* h_out,
+                      float* c_out, float* gates_out, cvc_stream_t stream);
 
 /* LSTM pointwise backward: from d_h, d_c (nullable = 0), saved activated gates [M,4R],
  * c_prev, c_new -> d_gates [M,4R] (pre-activation) and d_c_prev [M,R]. */

@@ -111,6 +111,60 @@ def test_a7_embed_logits_vs_oracle(tiny, g1, dev):
     close(model._logprobs(out), O.logits_logsoftmax(P, out.cpu()), **OP_TOL)
 
 
+# ------------------------------------------------------------------ concat-GEMM kernels (both code paths)
+@pytest.mark.parametrize("M,Nout,ks,gather", [
+    (64, 8192, (2048, 2048, 1024, 2048), True),     # att-LSTM shape of cfg2 (LDS-DMA fast path)
+    (64, 5000, (2048,), False),                     # logits: Nout not a multiple of 32
+    (17, 1024, (2048,), False),                     # ragged M, one 32-row tile
+    (33, 520, (128, 256), False),                   # ragged M, two tiles, ragged Nout
+    (5, 96, (36, 20), True),                        # generic path: k not a multiple of 128
+    (64, 64, (4,), False),                          # minimum k
+])
+def test_concat_gemm_vs_fp64(dev, lib, M, Nout, ks, gather):
+    g = torch.Generator(device="cpu").manual_seed(M * 1000 + Nout)
+    K = sum(ks)
+    w = (torch.randn(Nout, K, generator=g) / K ** 0.5).to(dev)
+    bias = torch.randn(Nout, generator=g).to(dev)
+    xs, segs, k0 = [], [], 0
+    for si, k in enumerate(ks):
+        if gather and si == len(ks) - 1:
+            table = torch.randn(50, k, generator=g).to(dev)
+            idx = torch.randint(0, 50, (M,), generator=g).to(dev)
+            segs.append({"x": table, "idx": idx, "w": w[:, k0:k0 + k], "relu": True})
+            xs.append(torch.relu(table[idx]))
+        else:
+            x = torch.randn(M, k, generator=g).to(dev)
+            segs.append({"x": x, "w": w[:, k0:k0 + k]})
+            xs.append(x)
+        k0 += k
+    ref = (torch.cat(xs, 1).double() @ w.double().t() + bias.double()).float()
+    outs = []
+    for force in (False, True):
+        lib.gemm_force_generic(force)
+        try:
+            outs.append(lib.linear_fwd(segs, bias, M, Nout))
+        finally:
+            lib.gemm_force_generic(False)
+        close(outs[-1], ref, rtol=2e-5, atol=2e-5)
+    # LSTM epilogue on the same operands (Nout = 4R)
+    if Nout % 32 == 0 and (Nout // 4) % 8 == 0:
+        R = Nout // 4
+        c_prev = torch.randn(M, R, generator=g).to(dev)
+        b2 = torch.randn(Nout, generator=g).to(dev)
+        gates = ref.double() + b2.double()
+        i_, f_, g_, o_ = gates.chunk(4, 1)
+        c_ref = torch.sigmoid(f_) * c_prev.double() + torch.sigmoid(i_) * torch.tanh(g_)
+        h_ref = torch.sigmoid(o_) * torch.tanh(c_ref)
+        for force in (False, True):
+            lib.gemm_force_generic(force)
+            try:
+                h, c, act = lib.lstm_cell_fwd(segs, bias, b2, c_prev, want_gates=True)
+            finally:
+                lib.gemm_force_generic(False)
+            close(h, h_ref.float(), rtol=2e-5, atol=2e-5); close(c, c_ref.float(), rtol=2e-5, atol=2e-5)
+            close(act[:, :R], torch.sigmoid(i_).float(), rtol=2e-5, atol=2e-5)
+
+
 # ------------------------------------------------------------------ greedy decode (a8)
 def test_a8_greedy_tiny_golden(tiny, g1):
     from helpers import model_call, tie_aware_seq_equal
