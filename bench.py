@@ -85,7 +85,7 @@ def algorithmic_work(d, beam):
     w["lang_lstm"] = dict(bound="hbm", bytes=4 * (4 * R * 3 * R + 8 * R) + 4 * rows * (3 * R + 3 * R), flops=2 * rows * 4 * R * 3 * R)
     w["h2attn"] = dict(bound="hbm", bytes=4 * (A * R + A) + 4 * rows * (R + A), flops=2 * rows * A * R)
     w["logits"] = dict(bound="hbm", bytes=4 * (V * R + V) + 4 * rows * (R + V), flops=2 * rows * V * R)
-    w["word_select"] = dict(bound="hbm", bytes=4 * rows * V)
+    w["word_select"] = dict(bound="hbm", bytes=4 * rows * 6 * ((V + 31) // 32) + 4 * rows * E)
     return w
 
 

@@ -124,6 +124,17 @@ extern "C" int cvc_attn_scores(int kind, const float* q, const float* w_a, const
     return run_scores(kind, q, w_a, b_a, inv_temp, sets, nsets, nclip, nq, A, (hipStream_t)stream);
 }
 
+extern "C" int cvc_attn_scores_qparts(int kind, const float* q_parts, int q_nparts, const float* q_bias, const float* w_a,
+                                      const float* b_a, float inv_temp, const cvc_attn_set* sets, int nsets, int nclip,
+                                      int nq, int A, cvc_stream_t stream) {
+    int n_max;
+    int rc = check_sets(sets, nsets, nclip, nq, A, 0, &n_max);
+    if (rc) return rc;
+    if (q_parts == nullptr || q_nparts < 1 || (kind == CVC_ATTN_ADDITIVE && w_a == nullptr)) return CVC_E_BADARG;
+    if (kind != CVC_ATTN_ADDITIVE && kind != CVC_ATTN_DOT) return CVC_E_BADARG;
+    return run_scores(kind, q_parts, w_a, b_a, inv_temp, sets, nsets, nclip, nq, A, (hipStream_t)stream, q_nparts, q_bias);
+}
+
 extern "C" int cvc_attn_wsum(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum,
                              cvc_stream_t stream) {
     int n_max;

@@ -11,7 +11,10 @@ constexpr int SCORE_WG = 256;
 struct ScoreArgs {
     cvc_attn_set set[2];
     int chunks0;                   // blockIdx.x < chunks0 -> set 0 else set 1
-    const float* q;                // [nclip*nq, A]
+    const float* q;                // [q_nparts][nclip*nq, A]: partial sums of the query GEMM (split-K), summed on load
+    const float* q_bias;           // [A] added once (h2attn.bias) or null
+    int q_nparts;
+    long long q_part_stride;
     const float* w_a;              // [A] (additive)
     const float* b_a;              // device scalar (alpha_net.bias) or null
     float inv_temp;
@@ -31,7 +34,13 @@ __global__ __launch_bounds__(SCORE_WG) void attn_scores_kernel(ScoreArgs a) {
     const int A = a.A, nq = a.nq, n = S.n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    for (int i = tid * 4; i < nq * A; i += SCORE_WG * 4) st4(q_s + i, ld4(a.q + ((size_t)clip * a.nq_total + a.q0) * A + i));
+    for (int i = tid * 4; i < nq * A; i += SCORE_WG * 4) {
+        const float* src = a.q + ((size_t)clip * a.nq_total + a.q0) * A + i;
+        f32x4 v = ld4(src);
+        for (int p = 1; p < a.q_nparts; ++p) v += ld4(src + (size_t)p * a.q_part_stride);
+        if (a.q_bias != nullptr) v += ld4(a.q_bias + (i % A));
+        st4(q_s + i, v);
+    }
     if (KIND == CVC_ATTN_ADDITIVE)
         for (int i = tid * 4; i < A; i += SCORE_WG * 4) st4(w_s + i, ld4(a.w_a + i));
     __syncthreads();
@@ -111,7 +120,8 @@ int launch_scores(const ScoreArgs& a, dim3 grid, size_t lds, hipStream_t st) {
 // Launch the score pass for `sets` (1 or 2), splitting long query lists so that the queries of
 // a clip (plus alpha_net's weight) fit 64 KB of LDS.
 inline int run_scores(int kind, const float* q, const float* w_a, const float* b_a, float inv_temp,
-                      const cvc_attn_set* sets, int nsets, int nclip, int nq, int A, hipStream_t st) {
+                      const cvc_attn_set* sets, int nsets, int nclip, int nq, int A, hipStream_t st,
+                      int q_nparts = 1, const float* q_bias = nullptr) {
     int q_per_launch = (int)((64 * 1024) / ((size_t)A * 4)) - 1;
     if (q_per_launch < 1) return CVC_E_TOOBIG;
     if (q_per_launch > nq) q_per_launch = nq;
@@ -121,6 +131,7 @@ inline int run_scores(int kind, const float* q, const float* w_a, const float* b
     sa.chunks0 = (sets[0].n + ROWS_PER_WG - 1) / ROWS_PER_WG;
     const int chunks1 = nsets > 1 ? (sets[1].n + ROWS_PER_WG - 1) / ROWS_PER_WG : 0;
     sa.q = q; sa.w_a = w_a; sa.b_a = b_a; sa.inv_temp = inv_temp; sa.A = A; sa.nq_total = nq;
+    sa.q_nparts = q_nparts < 1 ? 1 : q_nparts; sa.q_bias = q_bias; sa.q_part_stride = (long long)nclip * nq * A;
     dim3 g1(sa.chunks0 + chunks1, nclip);
     for (int q0 = 0; q0 < nq; q0 += q_per_launch) {
         sa.q0 = q0;

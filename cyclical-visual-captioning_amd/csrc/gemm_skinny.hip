@@ -18,6 +18,7 @@
 //     shuffles; the k-order inside a chunk is permuted, which fp32 addition tolerates).
 //     Partial 32 x M tiles are combined through LDS in a fixed order (deterministic).
 #include "cvc_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -37,6 +38,9 @@ struct GemmArgs {
     float* c_out;
     float* gates_out;
     int ldy;
+    int ksplit;               // linear only: blockIdx.y = K slice; slice sp writes y + sp * split_stride (bias in slice 0)
+    long long split_stride;
+    float* top2_part;         // linear only: per-(block,row) partial {top1 v,i, top2 v,i, max, sumexp} of the block's 32 columns
 };
 
 template <int MT>
@@ -86,9 +90,10 @@ __device__ __forceinline__ void mma_chunk(const Frag<MT>& f, f32x16 (&acc)[MT]) 
 }
 
 // Combine the NW partial 32 x (MT*32) tiles through LDS in a fixed order (run-to-run
-// deterministic) and finish: bias (+ LSTM cell update).  `red` needs min(NW,4)*32*(MT*32+1) floats.
+// deterministic) and finish: bias (+ LSTM cell update).  `red` needs min(NW,4)*32*(MT*32+1) floats,
+// `scratch` 4*64*6 floats (word-selection partials).
 template <int MT, int NW, bool LSTM>
-__device__ __forceinline__ void combine_and_store(f32x16 (&acc)[MT], float* red, const GemmArgs& a) {
+__device__ __forceinline__ void combine_and_store(f32x16 (&acc)[MT], float* red, float* scratch, const GemmArgs& a) {
     constexpr int LDM = MT * 32 + 1;
     constexpr int NRED = NW > 4 ? 4 : NW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -155,16 +160,61 @@ __device__ __forceinline__ void combine_and_store(f32x16 (&acc)[MT], float* red,
     } else {
         // unit u -> (n local in 0..31 fastest, batch row m): coalesced stores along n
         const int n0 = blockIdx.x * 32;
-        for (int u = tid; u < 32 * MT * 32; u += NW * 64) {
-            const int nl = u & 31, m = u >> 5;
-            const int n = n0 + nl;
-            if (m >= M || n >= a.Nout) continue;
-            float v = 0.f;
+        const bool lead = blockIdx.y == 0;                      // K slice 0 carries the bias
+        float* y = a.y != nullptr ? a.y + (long long)blockIdx.y * a.split_stride : nullptr;
+        if (y != nullptr) {
+            for (int u = tid; u < 32 * MT * 32; u += NW * 64) {
+                const int nl = u & 31, m = u >> 5;
+                const int n = n0 + nl;
+                if (m >= M || n >= a.Nout) continue;
+                float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < NRED; ++w) v += red[(w * 32 + nl) * LDM + m];
-            if (a.bias != nullptr) v += a.bias[n];
-            if (a.bias2 != nullptr) v += a.bias2[n];
-            a.y[(size_t)m * a.ldy + n] = v;
+                for (int w = 0; w < NRED; ++w) v += red[(w * 32 + nl) * LDM + m];
+                if (lead && a.bias != nullptr) v += a.bias[n];
+                if (lead && a.bias2 != nullptr) v += a.bias2[n];
+                y[(size_t)m * a.ldy + n] = v;
+            }
+        }
+        if (a.top2_part != nullptr) {
+            // fused word-selection partial (captioner.py:415-422 needs only the top-2 and the
+            // log-sum-exp of a row).  Wave w scans columns 8w .. 8w+7 of the block for row m = lane
+            // (LDS reads along m: conflict-free); the four wave records of a row are merged by wave 0.
+            float v1 = -__builtin_inff(), v2 = -__builtin_inff(), mx = -__builtin_inff(), se = 0.f;
+            int i1 = 0x7fffffff, i2 = 0x7fffffff;
+            const int m = lane < MT * 32 ? lane : MT * 32 - 1;
+            if (wave < 4) {
+                for (int nl = wave * 8; nl < wave * 8 + 8; ++nl) {
+                    const int n = n0 + nl;
+                    if (n >= a.Nout) break;
+                    float v = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NRED; ++w) v += red[(w * 32 + nl) * LDM + m];
+                    if (a.bias != nullptr) v += a.bias[n];
+                    if (a.bias2 != nullptr) v += a.bias2[n];
+                    if (v > v1) { v2 = v1; i2 = i1; v1 = v; i1 = n; }   // n ascending: ties keep the lower index
+                    else if (v > v2) { v2 = v; i2 = n; }
+                    const float nm = fmaxf(mx, v);
+                    se = se * __expf(mx - nm) + __expf(v - nm);
+                    mx = nm;
+                }
+                float* r4 = scratch + ((size_t)wave * 64 + lane) * 6;
+                r4[0] = v1; r4[1] = __int_as_float(i1); r4[2] = v2; r4[3] = __int_as_float(i2); r4[4] = mx; r4[5] = se;
+            }
+            __syncthreads();
+            if (wave == 0 && lane < M) {
+                for (int w = 1; w < 4; ++w) {                           // waves hold ascending column ranges
+                    const float* r4 = scratch + ((size_t)w * 64 + lane) * 6;
+                    const float u1 = r4[0], u2 = r4[2];
+                    const int j1 = __float_as_int(r4[1]), j2 = __float_as_int(r4[3]);
+                    if (u1 > v1) { if (v1 >= u2) { v2 = v1; i2 = i1; } else { v2 = u2; i2 = j2; } v1 = u1; i1 = j1; }
+                    else if (u1 > v2) { v2 = u1; i2 = j1; }
+                    const float nm = fmaxf(mx, r4[4]);
+                    se = (nm == -__builtin_inff()) ? 0.f : se * __expf(mx - nm) + r4[5] * __expf(r4[4] - nm);
+                    mx = nm;
+                }
+                float* rec = a.top2_part + ((size_t)blockIdx.x * 64 + lane) * 6;
+                rec[0] = v1; rec[1] = __int_as_float(i1); rec[2] = v2; rec[3] = __int_as_float(i2); rec[4] = mx; rec[5] = se;
+            }
         }
     }
 }
@@ -174,7 +224,7 @@ template <int MT, int NW, bool LSTM>
 __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(GemmArgs a) {
     constexpr int LDM = MT * 32 + 1;
     constexpr int NRED = NW > 4 ? 4 : NW;               // tiles resident in LDS at once
-    __shared__ float red[NRED * 32 * LDM];
+    __shared__ float red[NRED * 32 * LDM + 4 * 64 * 6];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, kh = lane >> 5;
     const int M = a.M, R = a.R;
@@ -183,6 +233,25 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(GemmArgs a) {
     int wrow;
     if (LSTM) wrow = (i >> 3) * R + blockIdx.x * 8 + (i & 7);
     else wrow = min((int)blockIdx.x * 32 + i, a.Nout - 1);
+    if (!LSTM && a.ksplit > 1) {
+        // K slice of this workgroup: whole chunks [lo, hi) of every segment
+        a.prefix[0] = 0;
+#pragma unroll
+        for (int s = 0; s < MAXSEG; ++s) {
+            if (s < a.nsegs) {
+                const int nch = (a.seg[s].k + KC - 1) / KC;
+                const int lo = nch * (int)blockIdx.y / a.ksplit, hi = nch * ((int)blockIdx.y + 1) / a.ksplit;
+                const int klo = lo * KC, khi = min(hi * KC, a.seg[s].k);
+                a.seg[s].w += klo;
+                a.seg[s].x += klo;
+                a.seg[s].k = max(khi - klo, 0);
+                a.prefix[s + 1] = a.prefix[s] + (hi - lo);
+            } else {
+                a.prefix[s + 1] = a.prefix[s];
+            }
+        }
+        a.total_chunks = a.prefix[a.nsegs];
+    }
     size_t wrow_off[MAXSEG];
     const float* xrow[MT][MAXSEG];
 #pragma unroll
@@ -217,7 +286,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(GemmArgs a) {
         it += NW;
     }
 
-    combine_and_store<MT, NW, LSTM>(acc, red, a);
+    combine_and_store<MT, NW, LSTM>(acc, red, red + NRED * 32 * LDM, a);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -242,6 +311,9 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_kernel(GemmArgs a) {
 //   * fragments of chunk j+1 are read while the 32 MFMAs of chunk j issue (two accumulators
 //     alternate, so the 64-cycle v_mfma_f32_32x32x2_f32 issues back to back);
 //   * the four 32 x M partial tiles meet in the ordered LDS reduction shared with the generic kernel.
+#ifndef CVC_W_AUX
+#define CVC_W_AUX 2   // weights are streamed once per launch by exactly one CU: non-temporal (aux = nt)
+#endif
 constexpr int RK = 32;                                     // k per chunk
 constexpr int RING = 3;
 
@@ -261,7 +333,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_ring_kernel(GemmArgs a) {
     constexpr int STAGE = ROWS * RK * 4;                   // 8 / 12 KB
     constexpr int NLOAD = ROWS / 8;                        // DMA instructions per chunk: 8 / 12
     constexpr int RED_BYTES = NW * 32 * (MT * 32 + 1) * 4;
-    constexpr int LDS_BYTES = NW * RING * STAGE > RED_BYTES ? NW * RING * STAGE : RED_BYTES;
+    constexpr int LDS_BYTES = NW * RING * STAGE > RED_BYTES + 6144 ? NW * RING * STAGE : RED_BYTES + 6144;
     __shared__ __attribute__((aligned(16))) char lds[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -302,8 +374,9 @@ __global__ __launch_bounds__(256) void skinny_gemm_ring_kernel(GemmArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
-    // relu (embedding segment) is applied branch-free when the fragment is consumed
-    auto mma = [&](const RFrag<MT>(&f)[2], float lo) __attribute__((always_inline)) {
+    // relu (embedding segment only) is applied when the fragment is consumed
+    auto mma = [&](const RFrag<MT>(&f)[2], auto relu_tag) __attribute__((always_inline)) {
+        constexpr bool RELU = decltype(relu_tag)::value;
 #if defined(CVC_ABL) && CVC_ABL == 2
         // ablation: no MFMA (memory pipeline only); keep the fragments live
 #pragma unroll
@@ -324,107 +397,118 @@ __global__ __launch_bounds__(256) void skinny_gemm_ring_kernel(GemmArgs a) {
                 for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[h].w[p][e], fmaxf(f[h].x[mt][p][e], lo), acc[mt], 0, 0, 0);
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[h].w[p][e], RELU ? fmaxf(f[h].x[mt][p][e], 0.f) : f[h].x[mt][p][e],
+                                                                       acc[mt], 0, 0, 0);
     };
 
     // ---- K loop: segment by segment (the decode engine passes ONE pre-concatenated segment, so the
     // pipeline below never restarts there); inside a segment everything is affine in the chunk index.
     for (int sg = 0; sg < a.nsegs; ++sg) {
-        const cvc_gemm_seg g = a.seg[sg];
+        cvc_gemm_seg g = a.seg[sg];
+        if (!LSTM && a.ksplit > 1) {                            // K slice of this workgroup (whole chunks)
+            const int nch = g.k / RK;
+            const int lo = nch * (int)blockIdx.y / a.ksplit, hi = nch * ((int)blockIdx.y + 1) / a.ksplit;
+            g.w += lo * RK;
+            g.x += lo * RK;
+            g.k = (hi - lo) * RK;
+        }
         const int nchunk = g.k / RK;
         const int n_my = nchunk > wave ? (nchunk - wave + NW - 1) / NW : 0;     // local chunks wave, wave+4, ...
         if (n_my == 0) continue;
-        const float lo = g.relu ? 0.f : -__builtin_inff();
-        // per-lane element offsets of the rows this lane copies (32-bit, checked on the host)
-        unsigned woff[4], xoff[4 * MT];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int wrow = LSTM ? u * R + (int)blockIdx.x * 8 + prow : min((int)blockIdx.x * 32 + 8 * u + prow, a.Nout - 1);
-            woff[u] = (unsigned)wrow * (unsigned)g.ldw + ((u & 1) ? kq1 : kq0);
-        }
-#pragma unroll
-        for (int u = 0; u < 4 * MT; ++u) {
-            const int m = min(8 * u + prow, M - 1);
-            const unsigned xr = g.idx != nullptr ? (unsigned)g.idx[m] : (unsigned)m;
-            xoff[u] = xr * (unsigned)g.ldx + ((u & 1) ? kq1 : kq0);
-        }
-        const float* wp = g.w + wave * RK;          // chunk c of this wave starts at k = (wave + c*NW) * RK
-        const float* xp = g.x + wave * RK;
+        auto run_segment = [&](auto relu_tag) __attribute__((always_inline)) {
+            // per-lane BYTE offsets of the rows this lane copies: 32-bit (checked on the host) so that the DMA
+            // uses the scalar-base + vector-offset form and the K loop spends no VALU on addresses
+            unsigned woff[4], xoff[4 * MT];
+    #pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int wrow = LSTM ? u * R + (int)blockIdx.x * 8 + prow : min((int)blockIdx.x * 32 + 8 * u + prow, a.Nout - 1);
+                woff[u] = ((unsigned)wrow * (unsigned)g.ldw + ((u & 1) ? kq1 : kq0)) * 4u;
+            }
+    #pragma unroll
+            for (int u = 0; u < 4 * MT; ++u) {
+                const int m = min(8 * u + prow, M - 1);
+                const unsigned xr = g.idx != nullptr ? (unsigned)g.idx[m] : (unsigned)m;
+                xoff[u] = (xr * (unsigned)g.ldx + ((u & 1) ? kq1 : kq0)) * 4u;
+            }
+            const char* wp = reinterpret_cast<const char*>(g.w + wave * RK);   // chunk c of this wave: k = (wave + c*NW) * RK
+            const char* xp = reinterpret_cast<const char*>(g.x + wave * RK);
 
-        // issue the 4 + 4*MT DMA instructions of this wave's local chunk c into ring slot c % RING
-        auto stage = [&](int c) __attribute__((always_inline)) {
-#if defined(CVC_ABL) && CVC_ABL == 1
-            if (c >= 0) return;       // ablation: no DMA (MFMA + LDS only)
-#endif
-            char* base = ring + (c % RING) * STAGE;
-            const float* wc = wp + (size_t)c * (NW * RK);
-            const float* xc = xp + (size_t)c * (NW * RK);
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(wc + woff[u]), (lds_ptr_t)(base + u * 1024), 16, 0, 0);
-#pragma unroll
-            for (int u = 0; u < 4 * MT; ++u)
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(xc + xoff[u]), (lds_ptr_t)(base + 4096 + u * 1024), 16, 0, 0);
+            // issue the 4 + 4*MT DMA instructions of this wave's local chunk c into ring slot c % RING
+            auto stage = [&](int c) __attribute__((always_inline)) {
+    #if defined(CVC_ABL) && CVC_ABL == 1
+                if (c >= 0) return;       // ablation: no DMA (MFMA + LDS only)
+    #endif
+                char* base = ring + (c % RING) * STAGE;
+                const char* wc = wp + (size_t)c * (NW * RK * 4);
+                const char* xc = xp + (size_t)c * (NW * RK * 4);
+    #pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(wc + woff[u]), (lds_ptr_t)(base + u * 1024), 16, 0, CVC_W_AUX);
+    #pragma unroll
+                for (int u = 0; u < 4 * MT; ++u)
+                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(xc + xoff[u]), (lds_ptr_t)(base + 4096 + u * 1024), 16, 0, 0);
+            };
+
+            // one steady-state step: chunk c is in `cur`; put chunk c+2 in flight, pull chunk c+1 into `nxt`,
+            // multiply chunk c.  The directives ask the scheduler to issue the DMA / address math and the
+            // LDS reads in the shadow of the 64-cycle MFMAs instead of serialising them after the block.
+            auto step = [&](const RFrag<MT>(&cur)[2], RFrag<MT>(&nxt)[2], int c) __attribute__((always_inline)) {
+                stage(c + 2);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+                read_frags(nxt, (c + 1) % RING);
+                mma(cur, relu_tag);
+    #pragma unroll
+                for (int q = 0; q < NLOAD; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (LDS-DMA)
+                }
+    #pragma unroll
+                for (int q = 0; q < NLOAD; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
+                }
+            };
+
+            RFrag<MT> fa[2], fb[2];
+            // the previous segment's LDS reads are complete (consumed by its MFMAs): slots are free
+            stage(0);
+            if (n_my > 1) stage(1);
+            if (n_my > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            read_frags(fa, 0);
+            int c = 0;
+            for (; c + 3 < n_my; c += 2) {       // steady state, unrolled by two: fragment registers are statically named
+                step(fa, fb, c);
+                step(fb, fa, c + 1);
+            }
+            while (c < n_my) {                   // drain (at most 3 chunks left; chunk c is in fa)
+                if (c + 2 < n_my) stage(c + 2);
+                if (c + 1 < n_my) {
+                    if (c + 2 < n_my) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    read_frags(fb, (c + 1) % RING);
+                }
+                mma(fa, relu_tag);
+                ++c;
+                if (c >= n_my) break;
+                if (c + 2 < n_my) stage(c + 2);
+                if (c + 1 < n_my) {
+                    if (c + 2 < n_my) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    read_frags(fa, (c + 1) % RING);
+                }
+                mma(fb, relu_tag);
+                ++c;
+            }
         };
-
-        // one steady-state step: chunk c is in `cur`; put chunk c+2 in flight, pull chunk c+1 into `nxt`,
-        // multiply chunk c.  The directives ask the scheduler to issue the DMA / address math and the
-        // LDS reads in the shadow of the 64-cycle MFMAs instead of serialising them after the block.
-        auto step = [&](const RFrag<MT>(&cur)[2], RFrag<MT>(&nxt)[2], int c) __attribute__((always_inline)) {
-            stage(c + 2);
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
-            read_frags(nxt, (c + 1) % RING);
-            mma(cur, lo);
-#pragma unroll
-            for (int q = 0; q < NLOAD; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);   // VALU (addresses, relu)
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (LDS-DMA)
-            }
-#pragma unroll
-            for (int q = 0; q < NLOAD; ++q) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
-            }
-        };
-
-        RFrag<MT> fa[2], fb[2];
-        // the previous segment's LDS reads are complete (consumed by its MFMAs): slots are free
-        stage(0);
-        if (n_my > 1) stage(1);
-        if (n_my > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        read_frags(fa, 0);
-        int c = 0;
-        for (; c + 3 < n_my; c += 2) {       // steady state, unrolled by two: fragment registers are statically named
-            step(fa, fb, c);
-            step(fb, fa, c + 1);
-        }
-        while (c < n_my) {                   // drain (at most 3 chunks left; chunk c is in fa)
-            if (c + 2 < n_my) stage(c + 2);
-            if (c + 1 < n_my) {
-                if (c + 2 < n_my) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                read_frags(fb, (c + 1) % RING);
-            }
-            mma(fa, lo);
-            ++c;
-            if (c >= n_my) break;
-            if (c + 2 < n_my) stage(c + 2);
-            if (c + 1 < n_my) {
-                if (c + 2 < n_my) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                read_frags(fa, (c + 1) % RING);
-            }
-            mma(fb, lo);
-            ++c;
-        }
+        if (g.relu) run_segment(std::true_type{}); else run_segment(std::false_type{});
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();                                       // rings are dead: LDS becomes the reduction buffer
-    combine_and_store<MT, NW, LSTM>(acc, reinterpret_cast<float*>(lds), a);
+    combine_and_store<MT, NW, LSTM>(acc, reinterpret_cast<float*>(lds), reinterpret_cast<float*>(lds + RED_BYTES), a);
 }
 
 int fill_args(GemmArgs& a, const cvc_gemm_seg* segs, int nsegs, int chunk) {
@@ -462,12 +546,13 @@ bool fast_ok(const cvc_gemm_seg* segs, int nsegs, int Nout_rows) {
 template <bool LSTM>
 int launch(const GemmArgs& a, int blocks, bool fast, hipStream_t st) {
     if (a.M > 64) return CVC_E_TOOBIG;
+    const dim3 grid(blocks, LSTM || a.ksplit < 1 ? 1 : a.ksplit);
     if (fast) {
-        if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_ring_kernel<1, LSTM>), dim3(blocks), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((skinny_gemm_ring_kernel<2, LSTM>), dim3(blocks), dim3(256), 0, st, a);
+        if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_ring_kernel<1, LSTM>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((skinny_gemm_ring_kernel<2, LSTM>), grid, dim3(256), 0, st, a);
     } else {
-        if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_kernel<1, 8, LSTM>), dim3(blocks), dim3(512), 0, st, a);
-        else hipLaunchKernelGGL((skinny_gemm_kernel<2, 8, LSTM>), dim3(blocks), dim3(512), 0, st, a);
+        if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_kernel<1, 8, LSTM>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((skinny_gemm_kernel<2, 8, LSTM>), grid, dim3(512), 0, st, a);
     }
     return cvc_launch_status();
 }
@@ -476,29 +561,50 @@ int g_force_generic = 0;   // test hook: cvc_gemm_force_generic(1) routes everyt
 
 }  // namespace
 
-extern "C" int cvc_linear_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, const float* bias2,
-                              int M, int Nout, float* y, int ldy, cvc_stream_t stream) {
-    if (M < 1 || Nout < 1 || y == nullptr || ldy < Nout) return CVC_E_BADARG;
-    // M > 64: walk the batch in 64-row slabs (weights are re-streamed per slab; the decode
+static int linear_impl(const cvc_gemm_seg* segs, int nsegs, const float* bias, const float* bias2, int M, int Nout,
+                       float* y, int ldy, int ksplit, long long split_stride, float* top2_part, hipStream_t st) {
+    if (M < 1 || Nout < 1 || (y == nullptr && top2_part == nullptr) || (y != nullptr && ldy < Nout)) return CVC_E_BADARG;
+    if (nsegs < 1 || nsegs > MAXSEG || ksplit < 1) return CVC_E_BADARG;
+    if ((ksplit > 1 || top2_part != nullptr) && M > 64) return CVC_E_TOOBIG;
+    // M > 64: walk the batch in 64-row slabs (weights are re-streamed per slab; the greedy decode
     // path never gets here, beam/training shapes do until the wide kernel lands)
     for (int m0 = 0; m0 < M; m0 += 64) {
         GemmArgs a{};
         cvc_gemm_seg tmp[MAXSEG];
-        if (nsegs < 1 || nsegs > MAXSEG) return CVC_E_BADARG;
         for (int s = 0; s < nsegs; ++s) {
             tmp[s] = segs[s];
             if (tmp[s].idx) tmp[s].idx += m0; else tmp[s].x += (size_t)m0 * tmp[s].ldx;
+            if (ksplit > 1 && tmp[s].idx != nullptr) return CVC_E_BADARG;
         }
         const bool fast = !g_force_generic && fast_ok(tmp, nsegs, Nout);
         int rc = fill_args(a, tmp, nsegs, fast ? RK : KC);
         if (rc) return rc;
         a.M = M - m0 < 64 ? M - m0 : 64; a.Nout = Nout; a.R = 0;
         a.bias = bias; a.bias2 = bias2; a.c_prev = nullptr; a.gate_bias = nullptr;
-        a.y = y + (size_t)m0 * ldy; a.c_out = nullptr; a.gates_out = nullptr; a.ldy = ldy;
-        rc = launch<false>(a, (Nout + 31) / 32, fast, (hipStream_t)stream);
+        a.y = y ? y + (size_t)m0 * ldy : nullptr; a.c_out = nullptr; a.gates_out = nullptr; a.ldy = ldy;
+        a.ksplit = ksplit; a.split_stride = split_stride; a.top2_part = top2_part;
+        rc = launch<false>(a, (Nout + 31) / 32, fast, st);
         if (rc) return rc;
     }
     return 0;
+}
+
+extern "C" int cvc_linear_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, const float* bias2,
+                              int M, int Nout, float* y, int ldy, cvc_stream_t stream) {
+    return linear_impl(segs, nsegs, bias, bias2, M, Nout, y, ldy, 1, 0, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int cvc_linear_splitk_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, int M, int Nout,
+                                     int ksplit, float* y_parts, cvc_stream_t stream) {
+    if (M > 64 || ksplit < 1 || ksplit > 64) return CVC_E_BADARG;
+    return linear_impl(segs, nsegs, bias, nullptr, M, Nout, y_parts, Nout, ksplit, (long long)M * Nout, nullptr,
+                       (hipStream_t)stream);
+}
+
+extern "C" int cvc_linear_top2_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, int M, int Nout,
+                                   float* y_or_null, float* top2_part, cvc_stream_t stream) {
+    if (top2_part == nullptr) return CVC_E_BADARG;
+    return linear_impl(segs, nsegs, bias, nullptr, M, Nout, y_or_null, Nout, 1, 0, top2_part, (hipStream_t)stream);
 }
 
 extern "C" int cvc_lstm_cell_fwd(const cvc_gemm_seg* segs, int nsegs, const float* b_ih, const float* b_hh,
@@ -521,6 +627,7 @@ extern "C" int cvc_lstm_cell_fwd(const cvc_gemm_seg* segs, int nsegs, const floa
         a.gate_bias = gate_bias ? gate_bias + (size_t)m0 * 4 * R : nullptr;
         a.y = h_out + (size_t)m0 * R; a.c_out = c_out + (size_t)m0 * R;
         a.gates_out = gates_out ? gates_out + (size_t)m0 * 4 * R : nullptr; a.ldy = R;
+        a.ksplit = 1; a.split_stride = 0; a.top2_part = nullptr;
         rc = launch<true>(a, R / 8, fast, (hipStream_t)stream);
         if (rc) return rc;
     }

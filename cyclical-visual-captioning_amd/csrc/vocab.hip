@@ -136,6 +136,58 @@ __global__ __launch_bounds__(WG) void top2_unk_kernel(const float* logits, int V
     }
 }
 
+// Final stage of the fused vocabulary head: merge the per-block partial records written by the logits
+// GEMM epilogue ({top1 v,i, top2 v,i, max, sumexp} per 32-column block and row), apply the UNK rule,
+// emit the word, its log-prob, and (optionally) next step's embedded word relu(Emb[word]).
+__global__ __launch_bounds__(WG) void top2_final_kernel(const float* part, int nblocks, int unk, int64_t* word, int wstride,
+                                                        float* logprob, const float* table, int E, float* emb_out, int emb_ld) {
+    __shared__ float red[4];
+    __shared__ Top2 tred[4];
+    __shared__ int chosen;
+    const int row = blockIdx.x;
+    Top2 t{-INFINITY, 0x7fffffff, -INFINITY, 0x7fffffff};
+    float mx = -INFINITY;
+    for (int b = threadIdx.x; b < nblocks; b += WG) {
+        const float* rec = part + ((size_t)b * 64 + row) * 6;
+        Top2 u{rec[0], __float_as_int(rec[1]), rec[2], __float_as_int(rec[3])};
+        t = merge(t, u);
+        mx = fmaxf(mx, rec[4]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Top2 u;
+        u.v1 = __shfl_xor(t.v1, o, 64); u.i1 = __shfl_xor(t.i1, o, 64);
+        u.v2 = __shfl_xor(t.v2, o, 64); u.i2 = __shfl_xor(t.i2, o, 64);
+        t = merge(t, u);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) tred[wave] = t;
+    mx = block_max(mx, red);                       // (contains the barriers that publish tred)
+    t = merge(merge(tred[0], tred[1]), merge(tred[2], tred[3]));
+    float se = 0.f;
+    for (int b = threadIdx.x; b < nblocks; b += WG) {
+        const float* rec = part + ((size_t)b * 64 + row) * 6;
+        se += rec[5] * expf(rec[4] - mx);
+    }
+    se = block_sum(se, red);
+    if (threadIdx.x == 0) {
+        const bool use2 = (t.i1 == unk) && t.i2 != 0x7fffffff;          // captioner.py:417-421
+        const int w = use2 ? t.i2 : t.i1;
+        word[(size_t)row * wstride] = w;
+        if (logprob != nullptr) logprob[row] = (use2 ? t.v2 : t.v1) - (mx + logf(se));
+        chosen = w;
+    }
+    if (emb_out != nullptr) {
+        __syncthreads();
+        const float* src = table + (size_t)chosen * E;
+        for (int e = threadIdx.x * 4; e < E; e += WG * 4) {
+            f32x4 v = ld4(src + e);
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            st4(emb_out + (size_t)row * emb_ld + e, v);
+        }
+    }
+}
+
 __global__ __launch_bounds__(WG) void nll_fwd_kernel(const float* logp, const int64_t* target, const float* w, int M, int V,
                                                      float* loss_sum) {
     __shared__ float red[4];
@@ -293,6 +345,16 @@ extern "C" int cvc_top2_unk(const float* logits, int M, int V, int unk_idx, int6
     if (!logits || !word || M < 1 || V < 1 || word_stride < 1) return CVC_E_BADARG;
     hipLaunchKernelGGL(top2_unk_kernel, dim3(M), dim3(WG), 0, (hipStream_t)stream, logits, V, unk_idx, word, word_stride,
                        logprob);
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_top2_final(const float* part, int nblocks, int M, int unk_idx, int64_t* word, int word_stride,
+                              float* logprob, const float* table, int E, float* emb_out, int emb_ld,
+                              cvc_stream_t stream) {
+    if (!part || !word || nblocks < 1 || M < 1 || M > 64 || word_stride < 1) return CVC_E_BADARG;
+    if (emb_out != nullptr && (!table || E < 4 || (E & 3) || (emb_ld & 3) || emb_ld < E)) return CVC_E_BADARG;
+    hipLaunchKernelGGL(top2_final_kernel, dim3(M), dim3(WG), 0, (hipStream_t)stream, part, nblocks, unk_idx, word, word_stride,
+                       logprob, table, E, emb_out, emb_ld);
     return cvc_launch_status();
 }
 

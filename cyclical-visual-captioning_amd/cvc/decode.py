@@ -89,6 +89,10 @@ class DecodeEngine:
         self.ctx_sum = z(rows, R)
         self.logits = z(rows, V)
         self.gate_fc = z(rows, 4 * R)      # step-invariant part of the att-LSTM gates: fc x W_ih[:, R:2R] + b_ih + b_hh
+        self.QSPLIT = 8                    # h2attn runs split-K over the chip; attn_scores sums the slices
+        self.q_parts = z(self.QSPLIT, rows, A)
+        self.emb = z(rows, W.E)            # relu(Emb[word_t]), written by the word-selection kernel of step t-1
+        self.top2_part = z((V + 31) // 32, 64, 6)
         self.att_steps = z(self.T, rows, N)                       # post-softmax region attention per step
         self.words = torch.zeros(self.T + 1, rows, dtype=torch.int64, device=dev)   # words[0] = BOS = 0
         self.logprob = z(self.T, rows)
@@ -118,22 +122,34 @@ class DecodeEngine:
         out.append(("gate_fc", L.cvc_linear_fwd, (seg_fc, 1, ptr(W.b_ih_att), ptr(W.b_hh_att), rows, 4 * R, ptr(self.gate_fc),
                                                   4 * R)))
         self._keep.append(seg_fc)
+        if beam == 1 and rows <= 64:
+            out.append(("embed_bos", L.cvc_embed_relu_fwd, (ptr(W.embed), ptr(self.words[0]), None, rows, E, ptr(self.emb))))
         for t in range(self.T):
             rd, wr = t & 1, (t + 1) & 1
             # att-LSTM: [h_lang(t-1) | relu(Emb[word_t])] x W_ih  +  h_att(t-1) x W_hh  + gate_fc
+            fused_head = beam == 1 and rows <= 64
             seg_att = _segs([(self.h_lang[rd], None, W.w_ih_att[:, 0:R], False),
+                             (self.emb, None, W.w_ih_att[:, 2 * R:2 * R + E], False) if fused_head else
                              (W.embed, self.words[t], W.w_ih_att[:, 2 * R:2 * R + E], True),
                              (self.h_att[rd], None, W.w_hh_att, False)])
             out.append(("att_lstm", L.cvc_lstm_cell_fwd, (seg_att, 3, None, None, ptr(self.gate_fc), ptr(self.c_att[rd]),
                                                           rows, R, ptr(self.h_att[wr]), ptr(self.c_att[wr]), None)))
             seg_q = _segs([(self.h_att[wr], None, W.w_h, False)])
-            out.append(("h2attn", L.cvc_linear_fwd, (seg_q, 1, ptr(W.b_h), None, rows, A, ptr(self.q), A)))
+            split_q = rows <= 64
+            if split_q:
+                out.append(("h2attn", L.cvc_linear_splitk_fwd, (seg_q, 1, None, rows, A, self.QSPLIT, ptr(self.q_parts))))
+            else:
+                out.append(("h2attn", L.cvc_linear_fwd, (seg_q, 1, ptr(W.b_h), None, rows, A, ptr(self.q), A)))
             sets = (hip.AttnSet * 2)()
             sets[0] = hip.AttnSet(ptr(ppool), ptr(pool), ptr(self.mask), None, ptr(self.scores_r), None,
                                   ptr(self.att_steps[t]), None, N)
             sets[1] = hip.AttnSet(ptr(pconv), ptr(conv), None, None, ptr(self.scores_f), None, ptr(self.attn_f), None, Fr)
-            out.append(("attn_scores", L.cvc_attn_scores, (W.kind, ptr(self.q), ptr(W.w_a), ptr(W.b_a), self.inv_temp, sets, 2,
-                                                           B, beam, A)))
+            if split_q:
+                out.append(("attn_scores", L.cvc_attn_scores_qparts, (W.kind, ptr(self.q_parts), self.QSPLIT, ptr(W.b_h),
+                                                                      ptr(W.w_a), ptr(W.b_a), self.inv_temp, sets, 2, B, beam, A)))
+            else:
+                out.append(("attn_scores", L.cvc_attn_scores, (W.kind, ptr(self.q), ptr(W.w_a), ptr(W.b_a), self.inv_temp, sets,
+                                                               2, B, beam, A)))
             out.append(("attn_wsum", L.cvc_attn_wsum, (sets, 2, B, beam, R, ptr(self.ctx_sum))))
             seg_lang = _segs([(self.ctx_sum, None, W.w_ih_lang[:, 0:R], False),
                               (self.h_att[wr], None, W.w_ih_lang[:, R:2 * R], False),
@@ -142,8 +158,18 @@ class DecodeEngine:
                                                            ptr(self.c_lang[rd]), rows, R, ptr(self.h_lang[wr]),
                                                            ptr(self.c_lang[wr]), None)))
             seg_o = _segs([(self.h_lang[wr], None, W.w_o, False)])
-            out.append(("logits", L.cvc_linear_fwd, (seg_o, 1, ptr(W.b_o), None, rows, V, ptr(self.logits), V)))
-            if beam == 1:
+            if fused_head:
+                # vocabulary projection with the top-2 / log-sum-exp partials in its epilogue ([B,V] logits are
+                # never written), then merge + UNK rule + next step's embedded word
+                out.append(("logits", L.cvc_linear_top2_fwd, (seg_o, 1, ptr(W.b_o), rows, V, None, ptr(self.top2_part))))
+                out.append(("word_select", L.cvc_top2_final, (ptr(self.top2_part), (V + 31) // 32, rows, self.unk,
+                                                              ptr(self.words[t + 1]), 1, ptr(self.logprob[t]), ptr(W.embed), E,
+                                                              ptr(self.emb), E)))
+            else:
+                out.append(("logits", L.cvc_linear_fwd, (seg_o, 1, ptr(W.b_o), None, rows, V, ptr(self.logits), V)))
+            if fused_head:
+                pass
+            elif beam == 1:
                 out.append(("word_select", L.cvc_top2_unk, (ptr(self.logits), rows, V, self.unk, ptr(self.words[t + 1]), 1,
                                                             ptr(self.logprob[t]))))
             else:

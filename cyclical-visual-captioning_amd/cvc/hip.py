@@ -35,6 +35,10 @@ _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 SIGNATURES = {
     "cvc_attn_fwd": [_I, _P, _P, _P, _F, C.POINTER(AttnSet), _I, _I, _I, _I, _I, _P, _P],
     "cvc_attn_scores": [_I, _P, _P, _P, _F, C.POINTER(AttnSet), _I, _I, _I, _I, _P],
+    "cvc_attn_scores_qparts": [_I, _P, _I, _P, _P, _P, _F, C.POINTER(AttnSet), _I, _I, _I, _I, _P],
+    "cvc_linear_splitk_fwd": [C.POINTER(GemmSeg), _I, _P, _I, _I, _I, _P, _P],
+    "cvc_linear_top2_fwd": [C.POINTER(GemmSeg), _I, _P, _I, _I, _P, _P, _P],
+    "cvc_top2_final": [_P, _I, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P],
     "cvc_attn_wsum": [C.POINTER(AttnSet), _I, _I, _I, _I, _P, _P],
     "cvc_attn_bwd": [_I, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "cvc_linear_fwd": [C.POINTER(GemmSeg), _I, _P, _P, _I, _I, _P, _I, _P],

@@ -69,6 +69,12 @@ int cvc_attn_scores(int kind, const float* q, const float* w_a, const float* b_a
                     const cvc_attn_set* sets, int nsets, int nclip, int nq, int A, cvc_stream_t stream);
 int cvc_attn_wsum(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum,
                   cvc_stream_t stream);
+/* Pass 1 with the query given as q_nparts partial sums [q_nparts][rows, A] of a split-K h2attn GEMM
+ * (cvc_linear_splitk_fwd) plus its bias q_bias [A] (nullable): the partials are summed while the
+ * query is loaded into LDS, so the small query GEMM can spread over the whole chip. */
+int cvc_attn_scores_qparts(int kind, const float* q_parts, int q_nparts, const float* q_bias, const float* w_a,
+                           const float* b_a, float inv_temp, const cvc_attn_set* sets, int nsets, int nclip,
+                           int nq, int A, cvc_stream_t stream);
 
 /* Backward of cvc_attn_fwd for ONE set, scores recomputed from proj (nothing but attn is
  * saved).  Inputs: d_ctx [rows,R] (nullable), d_fm [rows,n] gradient of the frame_masked
@@ -100,6 +106,24 @@ typedef struct {
 /* y[M, Nout] (ld ldy) = concat-GEMM + bias[Nout] (nullable) + bias2[Nout] (nullable) */
 int cvc_linear_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, const float* bias2,
                    int M, int Nout, float* y, int ldy, cvc_stream_t stream);
+
+/* Split-K variant for small Nout (h2attn: Nout = A): K slice s of every segment writes its partial
+ * product to y_parts + s * M * Nout (slice 0 carries the bias); the consumer sums the slices.
+ * M <= 64, no gather segments. */
+int cvc_linear_splitk_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, int M, int Nout,
+                          int ksplit, float* y_parts, cvc_stream_t stream);
+
+/* Vocabulary projection with the word-selection partials fused into the epilogue
+ * (captioner.py:437 + :415-422): every 32-column block writes, per row, {top-1 value, index, top-2
+ * value, index, max, sum exp} to top2_part [ceil(Nout/32)][64][6]; y (nullable) receives the
+ * logits only if asked.  cvc_top2_final merges the partials: UNK rule, word (int64, strided),
+ * log-prob (nullable), and optionally next step's embedded word emb_out[row,:E] =
+ * relu(table[word]) (captioner.py:424).  M <= 64. */
+int cvc_linear_top2_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, int M, int Nout,
+                        float* y_or_null, float* top2_part, cvc_stream_t stream);
+int cvc_top2_final(const float* part, int nblocks, int M, int unk_idx, int64_t* word, int word_stride,
+                   float* logprob, const float* table, int E, float* emb_out, int emb_ld,
+                   cvc_stream_t stream);
 
 /* Test hook: route every concat-GEMM to the generic direct-load kernel (on != 0) instead of the
  * LDS-DMA fast path that is taken when all segment widths are multiples of 128.  Returns the

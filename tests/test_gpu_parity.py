@@ -111,6 +111,64 @@ def test_a7_embed_logits_vs_oracle(tiny, g1, dev):
     close(model._logprobs(out), O.logits_logsoftmax(P, out.cpu()), **OP_TOL)
 
 
+# ------------------------------------------------------------------ attention fwd + recomputing bwd, ragged shapes
+@pytest.mark.parametrize("kind", ["additive", "dot"])
+@pytest.mark.parametrize("nclip,nq,N,A,R", [
+    (3, 1, 37, 20, 28),          # nothing is a multiple of the tile sizes
+    (2, 5, 130, 1024, 512),      # 5 beams share a clip's features
+    (2, 20, 9, 16, 32),          # the T localizer queries of a clip in one call
+    (1, 1, 1, 4, 4),             # a single region
+    (4, 1, 600, 260, 2052),      # A, R just past a 256-column block
+])
+def test_attention_fwd_bwd_vs_oracle(dev, lib, kind, nclip, nq, N, A, R):
+    from cvc import functional as F_
+    from oracle import ref_cpu as O
+    g = torch.Generator().manual_seed(N * 7 + A)
+    rows = nclip * nq
+    q = torch.randn(rows, A, generator=g)
+    proj = torch.randn(nclip, N, A, generator=g)
+    ctx = torch.randn(nclip, N, R, generator=g)
+    w_a = torch.randn(1, A, generator=g) * 0.3
+    b_a = torch.randn(1, generator=g)
+    mask = torch.rand(nclip, N, generator=g) < 0.3
+    if nclip > 1:
+        mask[1] = True                                             # one fully masked clip
+    fmask = torch.rand(rows, N, generator=g) < 0.3
+    d_ctx = torch.randn(rows, R, generator=g)
+    d_fm = torch.randn(rows, N, generator=g) * 0.1
+    temp = 1.7
+
+    def run(device, hip_path):
+        t = lambda x: x.clone().to(device).requires_grad_(x.dtype.is_floating_point)
+        q_, proj_, ctx_, w_, b_ = t(q), t(proj), t(ctx), t(w_a), t(b_a)
+        m_, fm_ = mask.to(device), fmask.to(device)
+        if hip_path:
+            if kind == "additive":
+                _, ((c, a, fm),) = F_.attention(lib.ATTN_ADDITIVE, q_, w_, b_, 1.0, [(proj_, ctx_, m_, fm_)])
+            else:
+                _, ((c, a, fm),) = F_.attention(lib.ATTN_DOT, q_, None, None, 1.0 / temp, [(proj_, ctx_, m_, fm_)])
+        else:
+            # oracle: identity "h2attn" so that q is the query itself; beams/queries expand the clip
+            eye, zero = torch.eye(A), torch.zeros(A)
+            pe, ce, me = (x.repeat_interleave(nq, 0) for x in (proj_, ctx_, m_))
+            if kind == "additive":
+                c, a, fm = O.additive_attention(q_, pe, ce, me, fm_, eye, zero, w_, b_)
+            else:
+                c, a, fm = O.dot_attention(q_, pe, ce, me, fm_, eye, zero, temp)
+        ((c * d_ctx.to(device)).sum() + (fm * d_fm.to(device)).sum()).backward()
+        grads = [q_.grad, proj_.grad, ctx_.grad] + ([w_.grad, b_.grad] if kind == "additive" else [])
+        return [x.detach().cpu() for x in (c, a, fm)] + [x.detach().cpu() for x in grads]
+
+    got, want = run(dev, True), run("cpu", False)
+    names = ["ctx", "attn", "frame_masked", "d_q", "d_proj", "d_ctx_feats", "d_w_alpha", "d_b_alpha"]
+    for n, a_, b_ in zip(names, got, want):
+        tol = dict(rtol=2e-4, atol=2e-4) if n.startswith("d_") else OP_TOL
+        np.testing.assert_allclose(a_.numpy(), b_.numpy(), err_msg=n, **tol)
+    close(got[1].sum(1), torch.ones(rows), rtol=1e-5, atol=1e-5)       # softmax rows sum to one
+    if nclip > 1:
+        close(got[1][nq:2 * nq], torch.full((nq, N), 1.0 / N), rtol=1e-5, atol=0)   # all-masked clip: uniform
+
+
 # ------------------------------------------------------------------ concat-GEMM kernels (both code paths)
 @pytest.mark.parametrize("M,Nout,ks,gather", [
     (64, 8192, (2048, 2048, 1024, 2048), True),     # att-LSTM shape of cfg2 (LDS-DMA fast path)
