@@ -45,6 +45,8 @@ def parse():
     for k in ("B", "N", "F", "R", "A", "E", "V", "T"):
         p.add_argument("--" + k, type=int, default=None)
     p.add_argument("--beam", type=int, default=1)
+    p.add_argument("--mode", default="decode", choices=["decode", "train"],
+                   help="decode = headline metric (default); train = cyclical fwd+bwd+all-reduce+Adam step (configs 3-ii / 4)")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-repeats", type=int, default=3)
@@ -89,6 +91,57 @@ def algorithmic_work(d, beam):
     return w
 
 
+def run_train(args, d, dev, rank, world):
+    """Cyclical training step (BASELINE configs 3-ii / 4): decode -> localize -> reconstruct forward,
+    backward, one RCCL gradient all-reduce (world > 1), clip_grad_norm_(0.1), Adam.  Train-mode dropout."""
+    import argparse as ap
+    from cvc import synth, opts as cvc_opts
+    from cvc.model.captioner import DecodeAndGroundCaptionerGVDROI, PrecomputedRegionFeatures
+    from cvc.trainer import Trainer, build_optimizer
+    from cvc.distributed import GradReducer
+    o = cvc_opts.parse_opt([])
+    o.vocab_size, o.itow, o.wtoi = d.V, {str(i): "w%d" % i for i in range(d.V)}, {"UNK": synth.UNK_IDX}
+    o.seq_length, o.rnn_size, o.input_encoding_size, o.att_hid_size = d.T, d.R, d.E, d.A
+    o.detect_size, o.vis_encoding_size, o.train_decoder_only = d.DET, d.G, False
+    o.xe_loss_weight, o.caption_consistency_loss_weight, o.learning_rate, o.batch_size = 0.5, 0.5, 1e-4, d.B
+    model = DecodeAndGroundCaptionerGVDROI(o, roi_extractor=PrecomputedRegionFeatures(d.DET, d.G))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.hot_path_state_dict(d, args.seed).items()}, strict=False)
+    model = model.to(dev).train()
+    optim = build_optimizer(model, o)
+    reducer = GradReducer(model.named_parameters()) if world > 1 else None
+    tr = Trainer(o, None, model, optim, None, None, grad_reducer=reducer)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    feats = {k: t(v) for k, v in synth.clip_features(d, args.seed + rank).items()}
+    b = {k: t(v) for k, v in synth.label_glue_batch(d, args.seed + rank).items()}
+    batch = (feats, b["input_seq"], b["gt_seq"], b["num"], b["proposals"], b["gt_bboxs"], b["box_mask"],
+             ["v_x_segment_%02d" % i for i in range(d.B)], torch.zeros(d.B, d.N, 1), b["frm_mask"], b["sample_idx"],
+             feats["pnt_mask"][:, 1:])
+    import torch.distributed as dist
+    for _ in range(args.warmup):
+        tr.train_step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = tr.train_step(batch)[0]
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    el = float(el.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "cyclical train decode-steps/sec (BxT per fwd+bwd+update)", "value": round(d.B * d.T * world * args.steps / el, 1),
+            "unit": "decode-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "samples_per_s": round(d.B * world * args.steps / el, 2), "loss": float(loss),
+            "config": {"workload": f"{args.config}: cyclical train step (decode+localize+reconstruct fwd, bwd, Adam)",
+                       "B_per_gpu": d.B, "N": d.N, "F": d.F, "D": d.R, "T": d.T,
+                       "parallelism": f"dp{world}: clips sharded, one RCCL gradient all-reduce per step"}}), flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,6 +167,12 @@ def main():
     over = {k: getattr(args, k) for k in ("B", "N", "F", "R", "A", "E", "V", "T") if getattr(args, k) is not None}
     if over:
         d = dataclasses.replace(d, **over)
+    if args.mode == "train":
+        run_train(args, d, dev, rank, world)
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
     seed = args.seed + rank                       # every rank decodes its own clips
     sd_np = synth.hot_path_state_dict(d, args.seed)
     feats_np = synth.clip_features(d, seed)

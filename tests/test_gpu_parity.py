@@ -162,7 +162,9 @@ def test_attention_fwd_bwd_vs_oracle(dev, lib, kind, nclip, nq, N, A, R):
     got, want = run(dev, True), run("cpu", False)
     names = ["ctx", "attn", "frame_masked", "d_q", "d_proj", "d_ctx_feats", "d_w_alpha", "d_b_alpha"]
     for n, a_, b_ in zip(names, got, want):
-        tol = dict(rtol=2e-4, atol=2e-4) if n.startswith("d_") else OP_TOL
+        # unscaled randn queries give dot-product scores of magnitude ~sqrt(A): exp() amplifies the fp32
+        # rounding of a 1024-term dot product, so the forward bound here is 1e-4 rather than OP_TOL
+        tol = dict(rtol=2e-4, atol=2e-4) if n.startswith("d_") else dict(rtol=1e-4, atol=1e-4)
         np.testing.assert_allclose(a_.numpy(), b_.numpy(), err_msg=n, **tol)
     close(got[1].sum(1), torch.ones(rows), rtol=1e-5, atol=1e-5)       # softmax rows sum to one
     if nclip > 1:
