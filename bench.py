@@ -223,23 +223,32 @@ def main():
                        share=round(float(np.sum(ms)) / 3 / decode_ms, 4) if decode_ms > 0 else None)
             if wk:
                 gbs = wk["bytes"] / (avg * 1e-3) / 1e9
-                ent.update(bound=wk["bound"], algorithmic_bytes=wk["bytes"], achieved_GBs=round(gbs, 1),
-                           frac_hbm=round(gbs / HBM_PEAK_GBS, 4))
+                ent.update(algorithmic_bytes=wk["bytes"], achieved_GBs=round(gbs, 1), frac_hbm=round(gbs / HBM_PEAK_GBS, 4))
+                bound = "hbm"
                 if "flops" in wk:
                     tf = wk["flops"] / (avg * 1e-3) / 1e12
-                    ent.update(achieved_TFLOPs=round(tf, 2), frac_mfma_f32=round(tf / MFMA_F32_PEAK_TFLOPS, 4))
+                    ent.update(algorithmic_flops=wk["flops"], achieved_TFLOPs=round(tf, 2), frac_mfma_f32=round(tf / MFMA_F32_PEAK_TFLOPS, 4))
+                    # the binding roof is the one with the larger floor time
+                    if wk["flops"] / (MFMA_F32_PEAK_TFLOPS * 1e12) > wk["bytes"] / (HBM_PEAK_GBS * 1e9):
+                        bound = "mfma"
+                ent["bound"] = bound
             kernels.append(ent)
         kernels.sort(key=lambda e: -(e["share"] or 0))
         dom = next(e for e in kernels if "achieved_GBs" in e)
         traffic = None
-        tf_path = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-derived HBM bytes per launch, if collected
-        if os.path.exists(tf_path):
+        tf_path = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-derived HBM bytes per launch (cfg2), if collected
+        if os.path.exists(tf_path) and args.config == "cfg2" and not over and args.beam == 1:
             try:
                 traffic = json.load(open(tf_path)).get(dom["kernel"])
             except Exception:
                 traffic = None
-        roof = dict(kernel=dom["kernel"], bound="hbm", achieved=dom["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=dom["frac_hbm"], traffic=traffic, avg_us=dom["avg_us"])
+        if dom["bound"] == "mfma":
+            roof = dict(kernel=dom["kernel"], bound="mfma", achieved=dom["achieved_TFLOPs"], peak=MFMA_F32_PEAK_TFLOPS,
+                        unit="TFLOP/s", frac=dom["frac_mfma_f32"], traffic=traffic, avg_us=dom["avg_us"],
+                        hbm_frac=dom["frac_hbm"])
+        else:
+            roof = dict(kernel=dom["kernel"], bound="hbm", achieved=dom["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=dom["frac_hbm"], traffic=traffic, avg_us=dom["avg_us"])
 
     # ---- CPU baseline: the oracle on this box's host cores, same workload (rank 0, N=1 only)
     cpu = None

@@ -25,6 +25,7 @@ struct WsumArgs {
     cvc_attn_set set[2];
     int nsets, nq, R;
     float* ctx_sum;               // [rows, R] or null
+    int ctx_quad;                 // 1: ctx_sum is written in the GEMM's quad layout [R/4][64][4] (rows <= 64)
 };
 
 __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
@@ -98,7 +99,10 @@ __global__ __launch_bounds__(WG) void attn_wsum_kernel(WsumArgs a) {
         }
         __syncthreads();
     }
-    if (a.ctx_sum != nullptr && wave == 0 && col_ok) st4(a.ctx_sum + (size_t)row * R + col, total);
+    if (a.ctx_sum != nullptr && wave == 0 && col_ok) {
+        if (a.ctx_quad) st4(a.ctx_sum + ((size_t)(col >> 2) * 64 + row) * 4, total);
+        else st4(a.ctx_sum + (size_t)row * R + col, total);
+    }
 }
 
 }  // namespace
@@ -135,15 +139,29 @@ extern "C" int cvc_attn_scores_qparts(int kind, const float* q_parts, int q_npar
     return run_scores(kind, q_parts, w_a, b_a, inv_temp, sets, nsets, nclip, nq, A, (hipStream_t)stream, q_nparts, q_bias);
 }
 
+static int wsum_impl(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum, int ctx_quad,
+                     cvc_stream_t stream);
+
 extern "C" int cvc_attn_wsum(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum,
                              cvc_stream_t stream) {
+    return wsum_impl(sets, nsets, nclip, nq, R, ctx_sum, 0, stream);
+}
+
+extern "C" int cvc_attn_wsum_quad(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum_q,
+                                  cvc_stream_t stream) {
+    if (ctx_sum_q == nullptr || nclip * nq > 64) return CVC_E_BADARG;
+    return wsum_impl(sets, nsets, nclip, nq, R, ctx_sum_q, 1, stream);
+}
+
+static int wsum_impl(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum, int ctx_quad,
+                     cvc_stream_t stream) {
     int n_max;
     int rc = check_sets(sets, nsets, nclip, nq, 0, R, &n_max);
     if (rc) return rc;
     WsumArgs wa;
     wa.set[0] = sets[0];
     wa.set[1] = nsets > 1 ? sets[1] : sets[0];
-    wa.nsets = nsets; wa.nq = nq; wa.R = R; wa.ctx_sum = ctx_sum;
+    wa.nsets = nsets; wa.nq = nq; wa.R = R; wa.ctx_sum = ctx_sum; wa.ctx_quad = ctx_quad;
     const size_t lds2 = (4 * 64 * 4 + 16 + n_max) * sizeof(float);
     if (lds2 > 64 * 1024) return CVC_E_TOOBIG;
     dim3 g2((R + 255) / 256, nclip * nq);

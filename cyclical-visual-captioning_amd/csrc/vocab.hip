@@ -183,7 +183,8 @@ __global__ __launch_bounds__(WG) void top2_final_kernel(const float* part, int n
         for (int e = threadIdx.x * 4; e < E; e += WG * 4) {
             f32x4 v = ld4(src + e);
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            st4(emb_out + (size_t)row * emb_ld + e, v);
+            if (emb_ld > 0) st4(emb_out + (size_t)row * emb_ld + e, v);
+            else st4(emb_out + ((size_t)(e >> 2) * 64 + row) * 4, v);       // emb_ld == 0: quad layout [E/4][64][4]
         }
     }
 }
@@ -352,7 +353,7 @@ extern "C" int cvc_top2_final(const float* part, int nblocks, int M, int unk_idx
                               float* logprob, const float* table, int E, float* emb_out, int emb_ld,
                               cvc_stream_t stream) {
     if (!part || !word || nblocks < 1 || M < 1 || M > 64 || word_stride < 1) return CVC_E_BADARG;
-    if (emb_out != nullptr && (!table || E < 4 || (E & 3) || (emb_ld & 3) || emb_ld < E)) return CVC_E_BADARG;
+    if (emb_out != nullptr && (!table || E < 4 || (E & 3) || (emb_ld & 3) || (emb_ld != 0 && emb_ld < E))) return CVC_E_BADARG;
     hipLaunchKernelGGL(top2_final_kernel, dim3(M), dim3(WG), 0, (hipStream_t)stream, part, nblocks, unk_idx, word, word_stride,
                        logprob, table, E, emb_out, emb_ld);
     return cvc_launch_status();

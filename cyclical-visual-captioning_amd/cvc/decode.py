@@ -57,6 +57,37 @@ def _segs(items):
     return arr
 
 
+def pack_weights(w: torch.Tensor, lstm_R: Optional[int] = None) -> torch.Tensor:
+    """[Nout, K] row-major -> MFMA-fragment-native [ceil(Nout/32)][K/4][32][4] (include/cvc_hip.h, "Packed
+    path").  For an LSTM gate matrix (Nout = 4R) block b holds the 4 gates of hidden units 8b..8b+7."""
+    n, k = w.shape
+    assert k % 32 == 0, k
+    if lstm_R is not None:
+        R = lstm_R
+        assert n == 4 * R and R % 8 == 0
+        i = torch.arange(32, device=w.device)
+        rows = ((i >> 3) * R + (i & 7)).view(1, 32) + (torch.arange(R // 8, device=w.device) * 8).view(-1, 1)
+        w = w[rows.reshape(-1)]
+        nb = R // 8
+    else:
+        nb = (n + 31) // 32
+        if nb * 32 != n:
+            w = torch.cat([w, w.new_zeros(nb * 32 - n, k)], 0)
+    return w.view(nb, 32, k // 4, 4).permute(0, 2, 1, 3).contiguous()
+
+
+def to_quad(x: torch.Tensor) -> torch.Tensor:
+    """[M<=64, K] row-major -> activation quad layout [K/4][64][4] (rows beyond M are zero)."""
+    m, k = x.shape
+    out = x.new_zeros(k // 4, 64, 4)
+    out[:, :m] = x.view(m, k // 4, 4).permute(1, 0, 2)
+    return out
+
+
+def from_quad(xq: torch.Tensor, m: int) -> torch.Tensor:
+    return xq[:, :m].permute(1, 0, 2).reshape(m, -1)
+
+
 class DecodeEngine:
     """Binds weights + one batch of clip features to preallocated state and a launch list."""
 
@@ -107,7 +138,69 @@ class DecodeEngine:
         self.inv_temp = float(inv_temp)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self._keep: List = []
-        self._launches = self._build()
+        self.packed = self.beam == 1 and rows <= 64 and R % 32 == 0 and W.E % 32 == 0 and A % 32 == 0
+        if self.packed:
+            self._alloc_packed()
+            self._launches = self._build_packed()
+        else:
+            self._launches = self._build()
+
+    # ------------------------------------------------------------------ packed path (greedy, rows <= 64)
+    def _alloc_packed(self):
+        """Fragment-native operands: packed weight copies (once per checkpoint binding) and the
+        recurrent activations as two ping-pong concat buffers in quad layout:
+          XA = [h_lang(t-1) | relu(Emb[word_t]) | h_att(t-1)]   (att-LSTM input, K = 2R + E)
+          XL = [ctx_regions + ctx_frames | h_att(t) | h_lang(t-1)]  (lang-LSTM input, K = 3R)"""
+        W, R, E = self.W, self.W.R, self.W.E
+        dev = self.fc.device
+        if not hasattr(W, "p_att"):
+            W.p_att = pack_weights(torch.cat([W.w_ih_att[:, 0:R], W.w_ih_att[:, 2 * R:2 * R + E], W.w_hh_att], 1), R)
+            W.p_lang = pack_weights(torch.cat([W.w_ih_lang, W.w_hh_lang], 1), R)
+            W.p_h = pack_weights(W.w_h)
+            W.p_o = pack_weights(W.w_o)
+        zq = lambda k: torch.zeros(k // 4, 64, 4, device=dev, dtype=torch.float32)
+        self.XA, self.XL = [zq(2 * R + E), zq(2 * R + E)], [zq(3 * R), zq(3 * R)]
+        self.cA, self.cL = [zq(R), zq(R)], [zq(R), zq(R)]
+        bos = torch.relu(W.embed[0]).view(1, E).expand(self.rows, E).contiguous()
+        self.XA0_init = zq(2 * R + E)
+        self.XA0_init[R // 4:(R + E) // 4] = to_quad(bos)
+
+    def _build_packed(self):
+        L, W = hip.lib(), self.W
+        B, N, Fr, R, A, E, V, rows = self.B, self.N, self.F, W.R, W.A, W.E, W.V, self.rows
+        fc, conv, pconv, pool, ppool = self.feats
+        ptr = lambda t: None if t is None else t.data_ptr()
+        qoff = lambda buf, k0: buf.data_ptr() + (k0 // 4) * 64 * 4 * 4        # byte address of quad k0/4
+        out = []
+        seg_fc = _segs([(fc, None, W.w_ih_att[:, R:2 * R], False)])
+        out.append(("gate_fc", L.cvc_linear_fwd, (seg_fc, 1, ptr(W.b_ih_att), ptr(W.b_hh_att), rows, 4 * R, ptr(self.gate_fc),
+                                                  4 * R)))
+        self._keep.append(seg_fc)
+        nblk_v = (V + 31) // 32
+        for t in range(self.T):
+            rd, wr = t & 1, (t + 1) & 1
+            XA_r, XA_w, XL_r, XL_w = self.XA[rd], self.XA[wr], self.XL[rd], self.XL[wr]
+            out.append(("att_lstm", L.cvc_packed_lstm_fwd, (ptr(W.p_att), ptr(XA_r), 2 * R + E, None, None, ptr(self.gate_fc),
+                                                            ptr(self.cA[rd]), rows, R, qoff(XL_r, R), qoff(XA_w, R + E),
+                                                            ptr(self.cA[wr]))))
+            out.append(("h2attn", L.cvc_packed_linear_fwd, (ptr(W.p_h), qoff(XL_r, R), R, None, rows, A, self.QSPLIT,
+                                                            ptr(self.q_parts), A, None)))
+            sets = (hip.AttnSet * 2)()
+            sets[0] = hip.AttnSet(ptr(ppool), ptr(pool), ptr(self.mask), None, ptr(self.scores_r), None,
+                                  ptr(self.att_steps[t]), None, N)
+            sets[1] = hip.AttnSet(ptr(pconv), ptr(conv), None, None, ptr(self.scores_f), None, ptr(self.attn_f), None, Fr)
+            out.append(("attn_scores", L.cvc_attn_scores_qparts, (W.kind, ptr(self.q_parts), self.QSPLIT, ptr(W.b_h), ptr(W.w_a),
+                                                                  ptr(W.b_a), self.inv_temp, sets, 2, B, 1, A)))
+            out.append(("attn_wsum", L.cvc_attn_wsum_quad, (sets, 2, B, 1, R, ptr(XL_r))))
+            out.append(("lang_lstm", L.cvc_packed_lstm_fwd, (ptr(W.p_lang), ptr(XL_r), 3 * R, ptr(W.b_ih_lang), ptr(W.b_hh_lang),
+                                                             None, ptr(self.cL[rd]), rows, R, ptr(XA_w), qoff(XL_w, 2 * R),
+                                                             ptr(self.cL[wr]))))
+            out.append(("logits", L.cvc_packed_linear_fwd, (ptr(W.p_o), ptr(XA_w), R, ptr(W.b_o), rows, V, 1, None, V,
+                                                            ptr(self.top2_part))))
+            out.append(("word_select", L.cvc_top2_final, (ptr(self.top2_part), nblk_v, rows, self.unk, ptr(self.words[t + 1]), 1,
+                                                          ptr(self.logprob[t]), ptr(W.embed), E, qoff(XA_w, R), 0)))
+            self._keep.append(sets)
+        return out
 
     # ------------------------------------------------------------------ launch list
     def _build(self):
@@ -187,6 +280,13 @@ class DecodeEngine:
         return out
 
     def _reset(self):
+        if self.packed:
+            self.XA[0].copy_(self.XA0_init)
+            self.XL[0].zero_()
+            self.cA[0].zero_()
+            self.cL[0].zero_()
+            self.words[0].zero_()
+            return
         for bufs in (self.h_att, self.c_att, self.h_lang, self.c_lang):
             bufs[0].zero_()
         self.words[0].zero_()

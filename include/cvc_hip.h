@@ -69,6 +69,9 @@ int cvc_attn_scores(int kind, const float* q, const float* w_a, const float* b_a
                     const cvc_attn_set* sets, int nsets, int nclip, int nq, int A, cvc_stream_t stream);
 int cvc_attn_wsum(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum,
                   cvc_stream_t stream);
+/* Pass 2 writing the summed context in the packed-GEMM activation layout [R/4][64][4] (rows <= 64) */
+int cvc_attn_wsum_quad(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum_q,
+                       cvc_stream_t stream);
 /* Pass 1 with the query given as q_nparts partial sums [q_nparts][rows, A] of a split-K h2attn GEMM
  * (cvc_linear_splitk_fwd) plus its bias q_bias [A] (nullable): the partials are summed while the
  * query is loaded into LDS, so the small query GEMM can spread over the whole chip. */
@@ -118,12 +121,29 @@ int cvc_linear_splitk_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias
  * value, index, max, sum exp} to top2_part [ceil(Nout/32)][64][6]; y (nullable) receives the
  * logits only if asked.  cvc_top2_final merges the partials: UNK rule, word (int64, strided),
  * log-prob (nullable), and optionally next step's embedded word emb_out[row,:E] =
- * relu(table[word]) (captioner.py:424).  M <= 64. */
+ * relu(table[word]) (captioner.py:424; emb_ld == 0 selects the quad layout [E/4][64][4]).  M <= 64. */
 int cvc_linear_top2_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, int M, int Nout,
                         float* y_or_null, float* top2_part, cvc_stream_t stream);
 int cvc_top2_final(const float* part, int nblocks, int M, int unk_idx, int64_t* word, int word_stride,
                    float* logprob, const float* table, int E, float* emb_out, int emb_ld,
                    cvc_stream_t stream);
+
+/* Packed path of the decode engine: both operands stored MFMA-fragment-native so that waves load
+ * them straight into registers (no LDS) and keep CVC_PACKED_DEPTH x 4 KB of weights in flight each.
+ *   wp : weights packed [ceil(Nout/32)][K/4][32][4] (LSTM: block b holds rows (i>>3)*R + 8b + (i&7));
+ *        built once per checkpoint by cvc.decode.pack_weights -- the K-concat of the reference's
+ *        torch.cat inputs is baked into the column order.
+ *   xq : activations [K/4][64][4] ("quad" layout, 64 = padded batch rows), pointing at the first
+ *        quad of this GEMM's K range; written by the producers (these kernels' epilogues,
+ *        cvc_attn_wsum_quad, cvc_top2_final with emb_ld == 0).
+ * K % 32 == 0, M <= 64.  LSTM: cell state c in quad layout [R/4][64][4]; h' goes to up to two quad
+ * destinations (the next consumers' K ranges).  Linear: y row-major (split-K slices at stride
+ * M*ldy, bias in slice 0) and/or the fused word-selection partials (see cvc_linear_top2_fwd). */
+int cvc_packed_lstm_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
+                        const float* gate_bias, const float* c_prev_q, int M, int R, float* h_dst1_q,
+                        float* h_dst2_q, float* c_out_q, cvc_stream_t stream);
+int cvc_packed_linear_fwd(const float* wp, const float* xq, int K, const float* bias, int M, int Nout,
+                          int ksplit, float* y, int ldy, float* top2_part, cvc_stream_t stream);
 
 /* Test hook: route every concat-GEMM to the generic direct-load kernel (on != 0) instead of the
  * LDS-DMA fast path that is taken when all segment widths are multiples of 128.  Returns the

@@ -1,0 +1,59 @@
+// Microbenchmarks for the two roofs the decode path is priced against (run on the GPU box):
+//   fp32 MFMA issue rate (v_mfma_f32_32x32x2_f32, 1/2 waves per SIMD, all CUs) and read-only HBM
+//   streaming (dwordx4 loads, 1 GiB buffer > Infinity Cache).  Build: hipcc --offload-arch=gfx950 -O3 tools/peaks.hip -o peaks
+#include <hip/hip_runtime.h>
+#include <cstdio>
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__global__ __launch_bounds__(512) void mfma_loop(float* out, int iters, float a, float b) {
+    f32x16 acc0 = {0}, acc1 = {0};
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, acc1, 0, 0, 0);
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc0[0] + acc1[3];
+}
+
+__global__ __launch_bounds__(256) void read_stream(const f32x4* __restrict__ in, size_t n, float* out) {
+    f32x4 s = {0, 0, 0, 0};
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        f32x4 a = in[i], b = in[i + stride], c = in[i + 2 * stride], d = in[i + 3 * stride];
+        s += (a + b) + (c + d);
+    }
+    for (; i < n; i += stride) s += in[i];
+    if (s.x + s.y + s.z + s.w == 12345.678f) out[0] = 1.f;
+}
+
+int main() {
+    float* out; hipMalloc(&out, 1 << 22);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int wps = 1; wps <= 2; ++wps) {
+        const int iters = 4000, blocks = 256, threads = 256 * wps;
+        mfma_loop<<<blocks, threads>>>(out, 10, 1.f, 2.f);
+        hipEventRecord(e0);
+        mfma_loop<<<blocks, threads>>>(out, iters, 1.f, 2.f);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        double flops = 2.0 * 32 * 32 * 2 * 32.0 * iters * (threads / 64) * blocks;
+        double cyc_per_mfma = ms * 1e-3 * 2.4e9 / (32.0 * iters * wps);
+        printf("mfma_f32_32x32x2 %d wave/SIMD: %.1f TFLOP/s (%.1f cycles@2.4GHz per MFMA per SIMD => eff. clock %.2f GHz if 64 cyc)\n",
+               wps, flops / (ms * 1e-3) / 1e12, cyc_per_mfma, 2.4 * 64.0 / cyc_per_mfma);
+    }
+    const size_t bytes = 1ull << 30;
+    f32x4* buf; hipMalloc(&buf, bytes); hipMemset(buf, 1, bytes);
+    for (int blocks : {2048, 4096, 8192}) {
+        read_stream<<<blocks, 256>>>(buf, bytes / 16, out);
+        hipEventRecord(e0);
+        for (int r = 0; r < 5; ++r) read_stream<<<blocks, 256>>>(buf, bytes / 16, out);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("read-only stream, %d blocks: %.2f TB/s\n", blocks, 5.0 * bytes / (ms * 1e-3) / 1e12);
+    }
+    return 0;
+}
