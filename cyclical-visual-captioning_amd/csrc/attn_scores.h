@@ -5,7 +5,10 @@
 
 namespace {
 
-constexpr int ROWS_PER_WG = 32;   // score kernel: 4 waves x 8 rows
+#ifndef CVC_SCORE_ROWS
+#define CVC_SCORE_ROWS 32
+#endif
+constexpr int ROWS_PER_WG = CVC_SCORE_ROWS;   // score kernel: rows per workgroup (4 waves, interleaved)
 constexpr int SCORE_WG = 256;
 
 struct ScoreArgs {

@@ -739,28 +739,34 @@ __global__ __launch_bounds__(256) void skinny_gemm_packed_kernel(PackedArgs a) {
     // counted vmcnt(N) of the oldest slot to a near-full drain.
     PFrag<MT> ring[DEPTH];
     if (n_my >= DEPTH) {
+        // slots 0 .. DEPTH-2 are filled up front; every step multiplies slot s while it (re)fills the slot
+        // consumed one step earlier, the 12 loads spread between the 32 MFMAs of the step
 #pragma unroll
-        for (int s = 0; s < DEPTH; ++s) load(ring[s], s);
+        for (int s = 0; s < DEPTH - 1; ++s) load(ring[s], s);
         int j = 0;
-        for (; j + 2 * DEPTH <= n_my; j += DEPTH) {
+        for (; j + 2 * DEPTH - 1 <= n_my; j += DEPTH) {
 #pragma unroll
             for (int s = 0; s < DEPTH; ++s) {
+                load(ring[(s + DEPTH - 1) % DEPTH], j + s + DEPTH - 1);
                 mma(ring[s]);
-                load(ring[s], j + s + DEPTH);
-                // keep the refill of slot s right behind its MFMAs: left alone, the scheduler sinks all
-                // DEPTH x 12 loads to the end of the iteration and the next iteration waits a full latency
+#pragma unroll
+                for (int g = 0; g < 4 + 4 * MT; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU (addresses)
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // drain: DEPTH <= n_my - j < 2*DEPTH chunks left, the first DEPTH of them in flight
+        // drain: chunks j .. n_my-1 (fewer than 2*DEPTH-1 left); slots 0..DEPTH-2 hold chunks j..j+DEPTH-2
 #pragma unroll
         for (int s = 0; s < DEPTH; ++s) {
-            mma(ring[s]);
-            if (j + s + DEPTH < n_my) load(ring[s], j + s + DEPTH);
+            if (j + s + DEPTH - 1 < n_my) load(ring[(s + DEPTH - 1) % DEPTH], j + s + DEPTH - 1);
+            if (j + s < n_my) mma(ring[s]);
         }
 #pragma unroll
-        for (int s = 0; s < DEPTH; ++s)
-            if (j + s + DEPTH < n_my) mma(ring[s]);
+        for (int s = 0; s < DEPTH - 1; ++s)
+            if (j + DEPTH + s < n_my) mma(ring[s]);
     } else {
         for (int j = 0; j < n_my; ++j) {                       // short K: no pipeline
             load(ring[0], j);
