@@ -231,42 +231,45 @@ __global__ __launch_bounds__(WG) void lstm_pointwise_bwd_kernel(const float* d_h
 }
 
 // ------------------------------------------------------------------ beam bookkeeping
-// One workgroup per clip.  Candidate (k, v) scores: score[k] + logit[k,v] - lse[k]; -inf for
-// v == unk; a finished hypothesis only offers (k, 0) at its carried score.
-__global__ __launch_bounds__(WG) void beam_select_kernel(const float* logits, const float* score_in, const uint8_t* done_in,
-                                                         int beam, int V, int unk, int first_step, int64_t* parent,
-                                                         int64_t* word, float* score_out, uint8_t* done_out) {
+// Candidate (k, v) scores: score[k] + logit[k,v] - lse[k]; -inf for v == unk; a finished hypothesis
+// only offers (k, 0) at its carried score.  The `beam` best of a clip's beam*V candidates are among the
+// per-row top-`beam`, so stage 1 (one workgroup per hypothesis row, values cached in registers) finds
+// those and stage 2 (one workgroup per clip) merges beam*beam candidates.  Ties -> lowest flat (k, v).
+constexpr int BEAM_MAX = 8;
+constexpr int ROW_CACHE = 32;        // values per thread kept in registers: V <= 256 * 32
+
+__global__ __launch_bounds__(WG) void beam_rowtop_kernel(const float* logits, int beam, int V, int unk, float* cand_v,
+                                                         int* cand_i, float* lse_out) {
     __shared__ float red[4];
-    __shared__ float lse[16];
     __shared__ float bestv[4];
     __shared__ int besti[4];
-    __shared__ int chosen[16];
-    const int b = blockIdx.x;
-    const float* x = logits + (size_t)b * beam * V;
-    for (int k = 0; k < beam; ++k) {
-        float m = -INFINITY;
-        for (int v = threadIdx.x; v < V; v += WG) m = fmaxf(m, x[(size_t)k * V + v]);
-        m = block_max(m, red);
-        float s = 0.f;
-        for (int v = threadIdx.x; v < V; v += WG) s += expf(x[(size_t)k * V + v] - m);
-        s = block_sum(s, red);
-        if (threadIdx.x == 0) lse[k] = m + logf(s);
+    __shared__ int winner;
+    const int row = blockIdx.x;
+    const float* x = logits + (size_t)row * V;
+    float vals[ROW_CACHE];
+    float m = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < ROW_CACHE; ++u) {
+        const int v = threadIdx.x + u * WG;
+        vals[u] = v < V ? x[v] : -INFINITY;
+        m = fmaxf(m, vals[u]);
     }
-    __syncthreads();
-    const int total = beam * V;
+    m = block_max(m, red);
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < ROW_CACHE; ++u) s += expf(vals[u] - m);       // exp(-inf) = 0 for padding
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) lse_out[row] = m + logf(s);
+#pragma unroll
+    for (int u = 0; u < ROW_CACHE; ++u)
+        if (threadIdx.x + u * WG == unk) vals[u] = -INFINITY;
     for (int sel = 0; sel < beam; ++sel) {
         float bv = -INFINITY;
         int bi = 0x7fffffff;
-        for (int c = threadIdx.x; c < total; c += WG) {
-            const int k = c / V, v = c - k * V;
-            float sc = score_in[b * beam + k];
-            if (first_step && k > 0) sc = -INFINITY;
-            float cand;
-            if (done_in[b * beam + k]) cand = v == 0 ? sc : -INFINITY;
-            else cand = v == unk ? -INFINITY : sc + (x[c] - lse[k]);
-            bool taken = false;
-            for (int t = 0; t < sel; ++t) taken |= chosen[t] == c;
-            if (!taken && better(cand, c, bv, bi)) { bv = cand; bi = c; }
+#pragma unroll
+        for (int u = 0; u < ROW_CACHE; ++u) {
+            const int v = threadIdx.x + u * WG;
+            if (v < V && better(vals[u], v, bv, bi)) { bv = vals[u]; bi = v; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -281,14 +284,61 @@ __global__ __launch_bounds__(WG) void beam_select_kernel(const float* logits, co
         if (threadIdx.x == 0) {
             for (int w = 1; w < 4; ++w)
                 if (better(bestv[w], besti[w], bv, bi)) { bv = bestv[w]; bi = besti[w]; }
-            chosen[sel] = bi;
-            const int k = bi / V, v = bi - k * V;
-            parent[b * beam + sel] = k;
-            word[b * beam + sel] = v;
-            score_out[b * beam + sel] = bv;
-            done_out[b * beam + sel] = (done_in[b * beam + k] != 0 || v == 0) ? 1 : 0;
+            cand_v[row * BEAM_MAX + sel] = bv;
+            cand_i[row * BEAM_MAX + sel] = bi;
+            winner = bi;
         }
         __syncthreads();
+        const int wv = winner;
+#pragma unroll
+        for (int u = 0; u < ROW_CACHE; ++u)
+            if (threadIdx.x + u * WG == wv) vals[u] = -INFINITY;   // taken
+    }
+}
+
+__global__ __launch_bounds__(64) void beam_merge_kernel(const float* cand_v, const int* cand_i, const float* lse,
+                                                        const float* score_in, const uint8_t* done_in, int beam, int V,
+                                                        int first_step, int64_t* parent, int64_t* word, float* score_out,
+                                                        uint8_t* done_out) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    // lane -> candidate (k = lane / beam, r = lane % beam), beam*beam <= 64
+    const int k = lane / beam, r = lane - k * beam;
+    float cv = -INFINITY;
+    int flat = 0x7fffffff;
+    if (k < beam) {
+        const int row = b * beam + k;
+        float sc = score_in[row];
+        if (first_step && k > 0) sc = -INFINITY;
+        if (done_in[row]) {
+            // frozen hypothesis: candidates (k, 0) at the carried score, every other (k, v) at -inf; keep the
+            // -inf fillers at distinct low flat indices so that tie-breaking matches a full scan
+            cv = r == 0 ? sc : -INFINITY;
+            flat = k * V + r;
+            if (r > 0) flat = k * V + (r == 0 ? 0 : r);
+        } else {
+            const float v = cand_v[row * BEAM_MAX + r];
+            const int vi = cand_i[row * BEAM_MAX + r];
+            cv = (v == -INFINITY || sc == -INFINITY) ? -INFINITY : sc + (v - lse[row]);
+            flat = vi == 0x7fffffff ? 0x7fffffff : k * V + vi;
+        }
+    }
+    for (int sel = 0; sel < beam; ++sel) {
+        float bv = cv;
+        int bi = flat;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) {
+            const int kk = bi / V, vv = bi - kk * V;
+            parent[b * beam + sel] = kk;
+            word[b * beam + sel] = vv;
+            score_out[b * beam + sel] = bv;
+            done_out[b * beam + sel] = (done_in[b * beam + kk] != 0 || vv == 0) ? 1 : 0;
+        }
+        if (flat == bi) { cv = -INFINITY; flat = 0x7fffffff; }      // taken (flat indices are unique)
     }
 }
 
@@ -385,11 +435,18 @@ extern "C" int cvc_lstm_pointwise_bwd(const float* d_h, const float* d_c, const 
 
 extern "C" int cvc_beam_select(const float* logits, const float* score_in, const uint8_t* done_in, int B, int beam, int V,
                                int unk_idx, int first_step, int64_t* parent, int64_t* word, float* score_out,
-                               uint8_t* done_out, cvc_stream_t stream) {
-    if (!logits || !score_in || !done_in || !parent || !word || !score_out || !done_out) return CVC_E_BADARG;
-    if (B < 1 || beam < 1 || beam > 16 || V < 1 || (long long)beam * V > 0x7ffffff0LL) return CVC_E_BADARG;
-    hipLaunchKernelGGL(beam_select_kernel, dim3(B), dim3(WG), 0, (hipStream_t)stream, logits, score_in, done_in, beam, V,
-                       unk_idx, first_step, parent, word, score_out, done_out);
+                               uint8_t* done_out, float* workspace, cvc_stream_t stream) {
+    if (!logits || !score_in || !done_in || !parent || !word || !score_out || !done_out || !workspace) return CVC_E_BADARG;
+    if (B < 1 || beam < 1 || beam > BEAM_MAX || V < beam + 1 || V > WG * ROW_CACHE) return CVC_E_BADARG;
+    // workspace: [rows*8] candidate values, [rows*8] candidate indices, [rows] lse   (rows = B*beam)
+    const int rows = B * beam;
+    float* cand_v = workspace;
+    int* cand_i = reinterpret_cast<int*>(workspace + (size_t)rows * BEAM_MAX);
+    float* lse = workspace + (size_t)rows * BEAM_MAX * 2;
+    hipLaunchKernelGGL(beam_rowtop_kernel, dim3(rows), dim3(WG), 0, (hipStream_t)stream, logits, beam, V, unk_idx, cand_v,
+                       cand_i, lse);
+    hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, cand_v, cand_i, lse, score_in, done_in,
+                       beam, V, first_step, parent, word, score_out, done_out);
     return cvc_launch_status();
 }
 

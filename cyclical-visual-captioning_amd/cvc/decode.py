@@ -135,6 +135,7 @@ class DecodeEngine:
             self.done = torch.zeros(2, rows, dtype=torch.uint8, device=dev)
             self.parent = torch.zeros(self.T, rows, dtype=torch.int64, device=dev)
             self.gather_tmp = [z(rows, R) for _ in range(4)]
+            self.beam_ws = z(17 * rows)
         self.inv_temp = float(inv_temp)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self._keep: List = []
@@ -258,19 +259,17 @@ class DecodeEngine:
                 out.append(("word_select", L.cvc_top2_final, (ptr(self.top2_part), (V + 31) // 32, rows, self.unk,
                                                               ptr(self.words[t + 1]), 1, ptr(self.logprob[t]), ptr(W.embed), E,
                                                               ptr(self.emb), E)))
-            else:
-                out.append(("logits", L.cvc_linear_fwd, (seg_o, 1, ptr(W.b_o), None, rows, V, ptr(self.logits), V)))
-            if fused_head:
-                pass
             elif beam == 1:
+                out.append(("logits", L.cvc_linear_fwd, (seg_o, 1, ptr(W.b_o), None, rows, V, ptr(self.logits), V)))
                 out.append(("word_select", L.cvc_top2_unk, (ptr(self.logits), rows, V, self.unk, ptr(self.words[t + 1]), 1,
                                                             ptr(self.logprob[t]))))
             else:
+                out.append(("logits", L.cvc_linear_fwd, (seg_o, 1, ptr(W.b_o), None, rows, V, ptr(self.logits), V)))
                 srd, swr = t & 1, (t + 1) & 1
                 out.append(("word_select", L.cvc_beam_select, (ptr(self.logits), ptr(self.score[srd]), ptr(self.done[srd]), B,
                                                                beam, V, self.unk, 1 if t == 0 else 0, ptr(self.parent[t]),
                                                                ptr(self.words[t + 1]), ptr(self.score[swr]),
-                                                               ptr(self.done[swr]))))
+                                                               ptr(self.done[swr]), ptr(self.beam_ws))))
                 # reorder the freshly written state rows by parent (gather into tmp, copy back)
                 for i, buf in enumerate((self.h_att[wr], self.c_att[wr], self.h_lang[wr], self.c_lang[wr])):
                     out.append(("beam_reorder", L.cvc_gather_rows, (ptr(buf), ptr(self.parent[t]), rows, beam, R,

@@ -57,7 +57,7 @@ SIGNATURES = {
     "cvc_nll_fwd": [_P, _P, _P, _I, _I, _P, _P],
     "cvc_nll_logsoftmax_bwd": [_P, _P, _P, _F, _I, _I, _P, _P],
     "cvc_grounder_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
-    "cvc_beam_select": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "cvc_beam_select": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "cvc_gather_rows": [_P, _P, _I, _I, _I, _P, _P],
 }
 
@@ -302,9 +302,10 @@ def beam_select(logits, score_in, done_in, B: int, beam: int, unk_idx: int, firs
     word = torch.empty(B * beam, dtype=torch.int64, device=dev)
     score = torch.empty(B * beam, dtype=torch.float32, device=dev)
     done = torch.empty(B * beam, dtype=torch.uint8, device=dev)
+    ws = torch.empty(17 * B * beam, dtype=torch.float32, device=dev)
     _check(lib().cvc_beam_select(_dev(logits), _dev(score_in), _dev(done_in, torch.uint8), B, beam, V, int(unk_idx),
                                  1 if first_step else 0, parent.data_ptr(), word.data_ptr(), _dev(score),
-                                 _dev(done, torch.uint8), _stream()), "cvc_beam_select")
+                                 _dev(done, torch.uint8), _dev(ws), _stream()), "cvc_beam_select")
     return parent, word, score, done
 
 

@@ -212,13 +212,14 @@ int cvc_grounder_fwd(const float* xt, const float* feats, const float* bias, con
 /* ---------------------------------------------------------------------------------------
  * Beam bookkeeping (build-defined, SURVEY.md section 7 "Beam-search specification"):
  * per clip select the `beam` best of beam*V candidates score[b,k] + logp[b,k,v] with
- * logp[unk] = -inf, finished hypotheses frozen (only v = 0 at +0).  Outputs parent[b,k],
+ * logp[unk] = -inf, finished hypotheses frozen (only v = 0 at +0); beam <= 8, beam < V <= 8192.
+ * Two stages: per-row top-`beam` (one workgroup per hypothesis), then a per-clip merge.  Outputs parent[b,k],
  * word[b,k] (int64), new score[b,k]; ties -> lowest flat (k, v) index.
  */
 int cvc_beam_select(const float* logits, const float* score_in, const uint8_t* done_in,
                     int B, int beam, int V, int unk_idx, int first_step,
                     int64_t* parent, int64_t* word, float* score_out, uint8_t* done_out,
-                    cvc_stream_t stream);
+                    float* workspace /* >= 17 * B * beam floats */, cvc_stream_t stream);
 /* dst[r, :] = src[(r / beam) * beam + parent[r], :] for r in [0, rows)  (state reorder) */
 int cvc_gather_rows(const float* src, const int64_t* parent, int rows, int beam, int width,
                     float* dst, cvc_stream_t stream);
