@@ -113,7 +113,7 @@ def run_train(args, d, dev, rank, world):
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     feats = {k: t(v) for k, v in synth.clip_features(d, args.seed + rank).items()}
     b = {k: t(v) for k, v in synth.label_glue_batch(d, args.seed + rank).items()}
-    batch = (feats, b["input_seq"], b["gt_seq"], b["num"], b["proposals"], b["gt_bboxs"], b["box_mask"],
+    batch = (feats, b["input_seq"], b["gt_seq"], b["num"].cpu(), b["proposals"], b["gt_bboxs"], b["box_mask"],
              ["v_x_segment_%02d" % i for i in range(d.B)], torch.zeros(d.B, d.N, 1), b["frm_mask"], b["sample_idx"],
              feats["pnt_mask"][:, 1:])
     import torch.distributed as dist

@@ -40,18 +40,29 @@ __global__ __launch_bounds__(WG) void embed_relu_fwd_kernel(const float* table, 
     st4(out + (size_t)m * E + e, v);
 }
 
-// one thread owns one embedding column and walks the rows in order: duplicates of a word
-// accumulate sequentially -> deterministic, no atomics
-__global__ __launch_bounds__(WG) void embed_relu_bwd_kernel(const float* table, const int64_t* idx, const float* drop,
-                                                            const float* d_out, int M, int E, float* d_table) {
-    const int e = blockIdx.x * WG + threadIdx.x;
+// Deterministic scatter-add without atomics and without a host round trip: the host passes a stable argsort
+// of the word indices, so the rows of one word are contiguous in `order`; workgroup r does nothing unless
+// row r starts a run, in which case it sums the run in (original) order and writes that word's gradient row.
+__global__ __launch_bounds__(WG) void embed_relu_bwd_kernel(const float* table, const int64_t* idx, const int64_t* order,
+                                                            const float* drop, const float* d_out, int M, int E,
+                                                            float* d_table) {
+    const int r0 = blockIdx.y;
+    const int64_t w = idx[order[r0]];
+    if (r0 > 0 && idx[order[r0 - 1]] == w) return;            // not the first row of its word
+    const int e = (blockIdx.x * WG + threadIdx.x) * 4;
     if (e >= E) return;
-    for (int m = 0; m < M; ++m) {
-        const size_t row = (size_t)idx[m] * E + e;
-        float g = d_out[(size_t)m * E + e];
-        if (drop != nullptr) g *= drop[(size_t)m * E + e];
-        if (table[row] > 0.f) d_table[row] += g;
+    f32x4 acc = {0, 0, 0, 0};
+    for (int r = r0; r < M; ++r) {
+        const int64_t m = order[r];
+        if (idx[m] != w) break;
+        f32x4 g = ld4(d_out + (size_t)m * E + e);
+        if (drop != nullptr) g *= ld4(drop + (size_t)m * E + e);
+        acc += g;
     }
+    const f32x4 t = ld4(table + (size_t)w * E + e);
+    acc.x = t.x > 0.f ? acc.x : 0.f; acc.y = t.y > 0.f ? acc.y : 0.f;
+    acc.z = t.z > 0.f ? acc.z : 0.f; acc.w = t.w > 0.f ? acc.w : 0.f;
+    st4(d_table + (size_t)w * E + e, acc);
 }
 
 // ------------------------------------------------------------------ log-softmax / top-2 / NLL
@@ -363,11 +374,11 @@ extern "C" int cvc_embed_relu_fwd(const float* table, const int64_t* idx, const 
     return cvc_launch_status();
 }
 
-extern "C" int cvc_embed_relu_bwd(const float* table, const int64_t* idx, const float* drop, const float* d_out, int M,
-                                  int E, float* d_table, cvc_stream_t stream) {
-    if (!table || !idx || !d_out || !d_table || M < 1 || E < 1) return CVC_E_BADARG;
-    hipLaunchKernelGGL(embed_relu_bwd_kernel, dim3((E + WG - 1) / WG), dim3(WG), 0, (hipStream_t)stream, table, idx, drop,
-                       d_out, M, E, d_table);
+extern "C" int cvc_embed_relu_bwd(const float* table, const int64_t* idx, const int64_t* order, const float* drop,
+                                  const float* d_out, int M, int E, float* d_table, cvc_stream_t stream) {
+    if (!table || !idx || !order || !d_out || !d_table || M < 1 || E < 4 || (E & 3)) return CVC_E_BADARG;
+    hipLaunchKernelGGL(embed_relu_bwd_kernel, dim3((E / 4 + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, table, idx, order,
+                       drop, d_out, M, E, d_table);
     return cvc_launch_status();
 }
 

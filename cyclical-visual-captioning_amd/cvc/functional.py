@@ -20,6 +20,56 @@ def _c(t: Optional[Tensor]) -> Optional[Tensor]:
     return None if t is None else t.contiguous()
 
 
+# ------------------------------------------------------------------------------- deferred weight gradients
+class _WeightGradBatcher:
+    """A weight used at every time step (LSTM cells, h2attn: 2 x T uses per training step) would
+    otherwise get T skinny dW = dY_t^T X_t GEMMs (contraction over 64 rows each) plus T full-size
+    accumulations.  Instead each backward call stashes (dY_t, X_t); the LAST call of the backward pass
+    (use counter reaches zero) does ONE GEMM over all stashed steps (contraction over T x B rows) and
+    returns it as its own gradient while the other calls return None -- autograd's sum is unchanged.
+    If some uses never receive a gradient the leftovers are flushed into .grad by an end-of-backward
+    callback."""
+
+    def __init__(self):
+        self.uses = {}        # key -> outstanding forward uses
+        self.stash = {}       # key -> list of tuples of tensors
+        self.owner = {}       # key -> (weight tensors..., flush function)
+        self._callback_armed = False
+
+    def note_use(self, key):
+        self.uses[key] = self.uses.get(key, 0) + 1
+
+    def add(self, key, item, owner, flush_fn):
+        """Returns the flushed gradients when this was the last outstanding use, else None."""
+        self.stash.setdefault(key, []).append(item)
+        self.owner[key] = (owner, flush_fn)
+        self.uses[key] = self.uses.get(key, 1) - 1
+        if not self._callback_armed:
+            self._callback_armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+        if self.uses[key] <= 0:
+            items = self.stash.pop(key)
+            self.uses.pop(key, None)
+            self.owner.pop(key, None)
+            return flush_fn(items)
+        return None
+
+    def _end_of_backward(self):
+        self._callback_armed = False
+        for key in list(self.stash):
+            items = self.stash.pop(key)
+            owner, flush_fn = self.owner.pop(key)
+            self.uses.pop(key, None)
+            grads = flush_fn(items)
+            for w, g in zip(owner, grads):
+                if w is not None and g is not None and w.requires_grad:
+                    w.grad = g if w.grad is None else w.grad + g
+        self.uses.clear()
+
+
+_BATCHER = _WeightGradBatcher()
+
+
 # ------------------------------------------------------------------------------- linear
 class _Linear(torch.autograd.Function):
     """y = cat(xs) W^T + b with the concat virtual (nn.Linear over torch.cat)."""
@@ -34,18 +84,32 @@ class _Linear(torch.autograd.Function):
             k0 += x.shape[1]
         assert k0 == weight.shape[1], (k0, weight.shape)
         y = hip.linear_fwd(segs, bias, M, weight.shape[0])
-        ctx.save_for_backward(weight, *xs)
+        ctx.save_for_backward(weight, bias, *xs)
         ctx.has_bias = bias is not None
+        ctx.key = ("linear", weight.data_ptr())
+        if weight.requires_grad:
+            _BATCHER.note_use(ctx.key)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        weight, *xs = ctx.saved_tensors
+        weight, bias, *xs = ctx.saved_tensors
         dy = dy.contiguous()
         d_w = d_b = None
         if ctx.needs_input_grad[0]:
-            d_w = torch.mm(dy.t(), torch.cat(xs, 1) if len(xs) > 1 else xs[0])
-        if ctx.has_bias and ctx.needs_input_grad[1]:
+            x = torch.cat(xs, 1) if len(xs) > 1 else xs[0]
+
+            def flush(items):
+                D = torch.cat([i[0] for i in items], 0) if len(items) > 1 else items[0][0]
+                X = torch.cat([i[1] for i in items], 0) if len(items) > 1 else items[0][1]
+                return torch.mm(D.t(), X), (D.sum(0) if ctx.has_bias else None)
+
+            res = _BATCHER.add(ctx.key, (dy, x), (weight, bias), flush)
+            if res is not None:
+                d_w, d_b = res
+                if not (ctx.has_bias and ctx.needs_input_grad[1]):
+                    d_b = None
+        elif ctx.has_bias and ctx.needs_input_grad[1]:
             d_b = dy.sum(0)
         d_xs, k0 = [], 0
         for i, x in enumerate(xs):
@@ -82,17 +146,36 @@ class _LstmCell(torch.autograd.Function):
         need_bwd = any(ctx.needs_input_grad)
         h, c, gates = hip.lstm_cell_fwd(segs, b_ih, b_hh, c_prev, want_gates=need_bwd)
         if need_bwd:
-            ctx.save_for_backward(w_ih, w_hh, h_prev, c_prev, c, gates, *xs)
+            ctx.save_for_backward(w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, c, gates, *xs)
+            ctx.key = ("lstm", w_ih.data_ptr())
+            ctx.defer = bool(ctx.needs_input_grad[0] and ctx.needs_input_grad[1])
+            if ctx.defer:
+                _BATCHER.note_use(ctx.key)
         return h, c
 
     @staticmethod
     def backward(ctx, d_h, d_c):
-        w_ih, w_hh, h_prev, c_prev, c_new, gates, *xs = ctx.saved_tensors
+        w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, c_new, gates, *xs = ctx.saved_tensors
         d_gates, d_c_prev = hip.lstm_pointwise_bwd(_c(d_h), _c(d_c), gates, c_prev, c_new)
         ni = ctx.needs_input_grad
-        d_w_ih = torch.mm(d_gates.t(), torch.cat(xs, 1) if len(xs) > 1 else xs[0]) if ni[0] else None
-        d_w_hh = torch.mm(d_gates.t(), h_prev) if ni[1] else None
-        d_b = d_gates.sum(0) if (ni[2] or ni[3]) else None
+        d_w_ih = d_w_hh = d_b = None
+        if ctx.defer:
+            x = torch.cat(xs, 1) if len(xs) > 1 else xs[0]
+
+            def flush(items):
+                D = torch.cat([i[0] for i in items], 0) if len(items) > 1 else items[0][0]
+                X = torch.cat([i[1] for i in items], 0) if len(items) > 1 else items[0][1]
+                Hp = torch.cat([i[2] for i in items], 0) if len(items) > 1 else items[0][2]
+                db = D.sum(0)
+                return torch.mm(D.t(), X), torch.mm(D.t(), Hp), db, db
+
+            res = _BATCHER.add(ctx.key, (d_gates, x, h_prev), (w_ih, w_hh, b_ih, b_hh), flush)
+            if res is not None:
+                d_w_ih, d_w_hh, d_b, _ = res
+        else:
+            d_w_ih = torch.mm(d_gates.t(), torch.cat(xs, 1) if len(xs) > 1 else xs[0]) if ni[0] else None
+            d_w_hh = torch.mm(d_gates.t(), h_prev) if ni[1] else None
+            d_b = d_gates.sum(0) if (ni[2] or ni[3]) else None
         d_h_prev = torch.mm(d_gates, w_hh) if ni[4] else None
         d_xs, k0 = [], 0
         for i, x in enumerate(xs):

@@ -49,7 +49,7 @@ SIGNATURES = {
     "cvc_lstm_cell_fwd": [C.POINTER(GemmSeg), _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "cvc_lstm_pointwise_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     "cvc_embed_relu_fwd": [_P, _P, _P, _I, _I, _P, _P],
-    "cvc_embed_relu_bwd": [_P, _P, _P, _P, _I, _I, _P, _P],
+    "cvc_embed_relu_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P],
     "cvc_log_softmax_fwd": [_P, _I, _I, _P, _P],
     "cvc_log_softmax_bwd": [_P, _P, _I, _I, _P, _P],
     "cvc_nll_bwd": [_P, _P, _P, _I, _I, _P, _P],
@@ -236,8 +236,9 @@ def embed_relu_fwd(table, idx, drop=None):
 
 def embed_relu_bwd(table, idx, drop, d_out):
     d_table = torch.zeros_like(table)
-    _check(lib().cvc_embed_relu_bwd(_dev(table), _dev(idx, torch.int64), _dev(drop), _dev(d_out), idx.shape[0],
-                                    table.shape[1], _dev(d_table), _stream()), "cvc_embed_relu_bwd")
+    order = torch.argsort(idx, stable=True)                      # rows grouped by word, original order inside a group
+    _check(lib().cvc_embed_relu_bwd(_dev(table), _dev(idx, torch.int64), _dev(order, torch.int64), _dev(drop), _dev(d_out),
+                                    idx.shape[0], table.shape[1], _dev(d_table), _stream()), "cvc_embed_relu_bwd")
     return d_table
 
 

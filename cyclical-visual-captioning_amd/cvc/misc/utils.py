@@ -105,10 +105,11 @@ def bbox_target(mask, overlaps, seq, seq_update, vocab_size):
     ov = overlaps.masked_fill(mask.reshape(B, 1, -1).expand_as(overlaps), 0)
     labels = ov.max(2)[0] > 0.5
     no_proposal_idx = (labels.sum(1) > 0) != (seq[:, 2] > 0)
-    if no_proposal_idx.sum() > 0:
-        seq_update[:, 0][no_proposal_idx] = seq_update[:, 3][no_proposal_idx]
-        seq_update[:, 1][no_proposal_idx] = 0
-        seq_update[:, 2][no_proposal_idx] = 0
+    # same writes as the reference's guarded block, expressed without a host-side `if .sum() > 0` (a
+    # device->host sync per decode step that would keep the launch queue from running ahead)
+    seq_update[:, 0] = torch.where(no_proposal_idx, seq_update[:, 3], seq_update[:, 0])
+    seq_update[:, 1] = torch.where(no_proposal_idx, torch.zeros_like(seq_update[:, 1]), seq_update[:, 1])
+    seq_update[:, 2] = torch.where(no_proposal_idx, torch.zeros_like(seq_update[:, 2]), seq_update[:, 2])
     return labels
 
 

@@ -173,8 +173,11 @@ int cvc_lstm_pointwise_bwd(const float* d_h, const float* d_c, const float* gate
 /* out[m, :] = relu(table[idx[m], :]) * (drop ? drop[m, :] : 1) */
 int cvc_embed_relu_fwd(const float* table, const int64_t* idx, const float* drop, int M, int E,
                        float* out, cvc_stream_t stream);
-/* d_table[idx[m], :] += (table[idx[m], :] > 0) * drop * d_out[m, :]   (atomic accumulate) */
-int cvc_embed_relu_bwd(const float* table, const int64_t* idx, const float* drop,
+/* d_table[w, :] = (table[w, :] > 0) * sum_{m: idx[m] == w} drop[m, :] * d_out[m, :] for every word w that
+ * occurs; no atomics and no host round trip: `order` [M] is a stable argsort of idx, so the rows of a word
+ * are contiguous in it and the workgroup of a run's first row sums the run in order.  Rows of d_table for
+ * words that do not occur are left untouched (caller zero-fills). */
+int cvc_embed_relu_bwd(const float* table, const int64_t* idx, const int64_t* order, const float* drop,
                        const float* d_out, int M, int E, float* d_table, cvc_stream_t stream);
 
 /* In-place-capable row log-softmax: logp[m, :] = logits[m, :] - logsumexp(logits[m, :]) */
