@@ -159,26 +159,34 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
                                             sample_idx, pnt_mask)
         region_mask = pnt_mask[:, 1:].contiguous()
 
+        # ---- label glue for all T steps at once (reference :246-260 does it per step; none of it depends on
+        # the recurrence): per-word proposal labels and the frame mask on proposals
+        tgt_steps = slice(1, T + 1)
+        bm = mask_boxes[:, :, :, tgt_steps]                                           # [B, seq_per_img, K, T]
+        ov = overlaps.unsqueeze(1).masked_fill(bm[:, 0].permute(0, 2, 1).unsqueeze(2).expand(B, T, num_rois, -1), 0)
+        roi_labels = ov.max(3)[0] > 0.5                                                # [B, T, N]   (utils.bbox_target)
+        no_prop = (roi_labels.sum(2) > 0) != (input_seq[:, tgt_steps, 2] > 0)          # deprecated seq_update side effect
+        upd = input_seq_update[:, tgt_steps]
+        upd[..., 0] = torch.where(no_prop, upd[..., 3], upd[..., 0])
+        upd[..., 1] = torch.where(no_prop, torch.zeros_like(upd[..., 1]), upd[..., 1])
+        upd[..., 2] = torch.where(no_prop, torch.zeros_like(upd[..., 2]), upd[..., 2])
+        box_mask_t = bm[:, 0].permute(0, 2, 1).unsqueeze(2)                            # [B, T, 1, K]
+        frm_on_prop = torch.sum(~(box_mask_t | frm_mask.unsqueeze(1)), dim=3) <= 0     # [B, T, N]
+        frm_mask_output = torch.cat((frm_on_prop.new_zeros(B, T, 1), frm_on_prop), dim=2) | pnt_mask.bool().unsqueeze(1)
+        step_fmask = frm_mask_output[:, :, 1:].permute(1, 0, 2).contiguous()           # [T, B, N]
+
         # ---- Loop A: teacher-forced decode (sequential: LSTM recurrence)            reference :242-270
         state = self.init_hidden(B, self.decoder_num_layers)
         emb_all = self._embed(gt_caption[:, :T])                                     # [B, T, E], one launch
-        outputs, masked_attn, roi_labels, frm_mask_output = [], [], [], []
+        outputs, masked_attn = [], []
         for t in range(T):
-            roi_labels.append(utils.bbox_target(mask_boxes[:, :, :, t + 1], overlaps, input_seq[:, t + 1],
-                                                input_seq_update[:, t + 1], self.vocab_size).view(B, -1))
-            box_mask = mask_boxes[:, 0, :, t + 1].contiguous().unsqueeze(1).expand(batch_size, num_rois, mask_boxes.size(2))
-            frm_on_prop = torch.sum(~(box_mask | frm_mask), dim=2) <= 0
-            frm_on_prop = torch.cat((frm_on_prop.new_zeros(batch_size, 1), frm_on_prop), dim=1) | pnt_mask.bool()
-            frm_mask_output.append(frm_on_prop)
             output, state, _roi_attn, frame_masked_attn, _wp = self.decoder_core(
                 emb_all[:, t], fc_feats, conv_feats, p_conv_feats, pool_feats, p_pool_feats, region_mask, state,
-                proposal_frame_mask=frm_on_prop[:, 1:].contiguous(), with_sentinel=False)
+                proposal_frame_mask=step_fmask[t], with_sentinel=False)
             outputs.append(output)
             masked_attn.append(frame_masked_attn)
         att2_weights = torch.stack(masked_attn, dim=1)                               # pre-softmax (:273)
         lang_outputs = self._logprobs(torch.stack(outputs, 1).view(B * T, -1)).view(B, T, -1)   # all T at once
-        roi_labels = torch.stack(roi_labels, 1)
-        frm_mask_output = torch.stack(frm_mask_output, 1)
 
         # ---- grounder over all T                                                      reference :282-294
         xt_clamp = torch.clamp(input_seq[:, 1:T + 1, 0].clone() - self.vocab_size, min=0)
