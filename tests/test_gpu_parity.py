@@ -395,6 +395,51 @@ def test_beam5_cfg1_vs_oracle(dev, lib):
     close(att[same.to(dev)], att_o[same], **SEQ_TOL)
 
 
+def test_cfg5_dims_beam_and_greedy_vs_oracle(dev, lib):
+    """BASELINE config 5 dimensions (N=300, D=4096, A=E=2048: the widest template instantiations, 8 KB
+    feature rows) at a reduced clip count / step count so that the CPU oracle finishes in seconds."""
+    import dataclasses
+    from helpers import to_dev, tie_aware_seq_equal
+    from oracle import ref_cpu as O
+    from cvc.decode import DecodeEngine, DecodeWeights
+    d = dataclasses.replace(synth.CONFIGS["cfg5"], B=3, T=5, F=96)
+    sd, f_np = synth.hot_path_state_dict(d, 55), synth.clip_features(d, 55)
+    P, fo = O.to_torch(sd), O.to_torch(f_np)
+    W, f = DecodeWeights(to_dev(sd, dev)), to_dev(f_np, dev)
+    with torch.no_grad():
+        seq_o, att_o, _, logp_o = O.greedy_sample(P, fo, d.T, synth.UNK_IDX, return_logprobs=True)
+        seq_b, att_b, sc_b = O.beam_search(P, fo, d.T, synth.UNK_IDX, 5)
+    seq, att = DecodeEngine(W, f, d.T, synth.UNK_IDX).run()
+    assert tie_aware_seq_equal(seq.cpu().numpy(), seq_o.numpy(), logp_o.numpy()) == d.B * d.T
+    close(att, att_o, **SEQ_TOL)
+    seq5, att5, sc5 = DecodeEngine(W, f, d.T, synth.UNK_IDX, beam=5).run()
+    close(sc5[:, 0], sc_b[:, 0], rtol=2e-4, atol=2e-4)
+    same = (seq5.cpu() == seq_b).all(1)
+    assert int(same.sum()) >= d.B - 1
+    close(att5[same.to(dev)], att_b[same], **SEQ_TOL)
+
+
+def test_dot_product_decoder_variant(g1, dev, lib):
+    """opts.softattn_type != 'additive' (reference decoder_core.py:24-25): SoftAttention inside the decoder, with
+    softmax_temp applied (modules.py:37)."""
+    from helpers import to_dev
+    from oracle import ref_cpu as O
+    from cvc.decode import DecodeEngine, DecodeWeights
+    d = synth.CONFIGS["tiny"]
+    sd = {k: v for k, v in synth.hot_path_state_dict(d, 3, softattn_type="dot").items()}
+    f_np = synth.clip_features(d, 3, full_mask_clip=2)
+    # make the dot-product scores O(1) so that the comparison is not dominated by exp() of huge scores
+    sd["decoder_core.soft_attn.h2attn.weight"] = sd["decoder_core.soft_attn.h2attn.weight"] * np.float32(0.3)
+    with torch.no_grad():
+        seq_o, att_o, _, logp_o = O.greedy_sample(O.to_torch(sd), O.to_torch(f_np), d.T, synth.UNK_IDX, softattn_type="dot",
+                                                  temp=2.0, return_logprobs=True)
+    eng = DecodeEngine(DecodeWeights(to_dev(sd, dev), softattn_type="dot"), to_dev(f_np, dev), d.T, synth.UNK_IDX,
+                       inv_temp=1.0 / 2.0)
+    seq, att = eng.run()
+    np.testing.assert_array_equal(seq.cpu().numpy(), seq_o.numpy())
+    close(att, att_o, **SEQ_TOL)
+
+
 def test_product_path_has_no_cpu_fallback(lib):
     from cvc import functional as F_
     x = torch.zeros(4, 8)
