@@ -108,7 +108,7 @@ def run_train(args, d, dev, rank, world):
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.hot_path_state_dict(d, args.seed).items()}, strict=False)
     model = model.to(dev).train()
     optim = build_optimizer(model, o)
-    reducer = GradReducer(model.named_parameters()) if world > 1 else None
+    reducer = GradReducer(model.named_parameters()) if torch.distributed.is_initialized() else None
     tr = Trainer(o, None, model, optim, None, None, grad_reducer=reducer)
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     feats = {k: t(v) for k, v in synth.clip_features(d, args.seed + rank).items()}
@@ -117,17 +117,18 @@ def run_train(args, d, dev, rank, world):
              ["v_x_segment_%02d" % i for i in range(d.B)], torch.zeros(d.B, d.N, 1), b["frm_mask"], b["sample_idx"],
              feats["pnt_mask"][:, 1:])
     import torch.distributed as dist
+    dist_on = dist.is_available() and dist.is_initialized()
     for _ in range(args.warmup):
         tr.train_step(batch)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = tr.train_step(batch)[0]
     torch.cuda.synchronize()
     el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     el = float(el.item())
@@ -151,9 +152,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # under torchrun (RANK set) the process group is always initialised, also for a single rank, so that the
+    # barrier / max-over-ranks path is the same code at every N
+    dist_on = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -169,7 +174,7 @@ def main():
         d = dataclasses.replace(d, **over)
     if args.mode == "train":
         run_train(args, d, dev, rank, world)
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
             dist.destroy_process_group()
         return
@@ -184,7 +189,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
             dist.barrier()
             torch.cuda.synchronize()
@@ -199,7 +204,7 @@ def main():
     t_local = time.perf_counter() - t0
     sync_all()
     t = torch.tensor([t_local], device=dev, dtype=torch.float64)
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -284,7 +289,7 @@ def main():
         if cpu:
             line["gpu_over_cpu"] = round(value / cpu["value"], 1)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         dist.destroy_process_group()
 
