@@ -1,0 +1,94 @@
+"""Property tests (hypothesis) for the host-side logic that needs no GPU: packed layouts, clip sharding, the
+seeded generator, the oracle's attention invariants, the YAML overlay."""
+import copy
+
+import numpy as np
+import torch
+from hypothesis import given, settings, strategies as st
+
+from cvc import synth
+from cvc.decode import from_quad, pack_weights, to_quad
+from cvc.distributed import shard_range
+from cvc.misc.utils import update_values
+from oracle import ref_cpu as O
+
+FAST = settings(max_examples=40, deadline=None)
+
+
+@FAST
+@given(m=st.integers(1, 64), kq=st.integers(1, 12))
+def test_quad_layout_roundtrip(m, kq):
+    x = torch.arange(m * kq * 4, dtype=torch.float32).view(m, kq * 4)
+    q = to_quad(x)
+    assert q.shape == (kq, 64, 4)
+    assert torch.equal(from_quad(q, m), x)
+    assert float(q[:, m:].abs().sum()) == 0.0                      # padded rows are zero
+
+
+@FAST
+@given(nrow=st.integers(1, 100), kc=st.integers(1, 3), lstm=st.booleans(), data=st.data())
+def test_pack_weights_is_the_documented_permutation(nrow, kc, lstm, data):
+    k = 32 * kc
+    if lstm:
+        R = 8 * data.draw(st.integers(1, 4))
+        w = torch.randn(4 * R, k)
+        p = pack_weights(w, R)
+        assert p.shape == (R // 8, k // 4, 32, 4)
+        b, q, i, e = (data.draw(st.integers(0, n - 1)) for n in (R // 8, k // 4, 32, 4))
+        assert p[b, q, i, e] == w[(i >> 3) * R + b * 8 + (i & 7), q * 4 + e]
+    else:
+        w = torch.randn(nrow, k)
+        p = pack_weights(w)
+        nb = (nrow + 31) // 32
+        assert p.shape == (nb, k // 4, 32, 4)
+        flat = p.permute(0, 2, 1, 3).reshape(nb * 32, k)
+        assert torch.equal(flat[:nrow], w) and float(flat[nrow:].abs().sum()) == 0.0
+
+
+@FAST
+@given(n=st.integers(0, 500), world=st.integers(1, 8))
+def test_shard_ranges_partition_the_batch(n, world):
+    sl = [shard_range(n, r, world) for r in range(world)]
+    assert sl[0].start == 0 and sl[-1].stop == n
+    assert all(a.stop == b.start for a, b in zip(sl, sl[1:]))
+    sizes = [s.stop - s.start for s in sl]
+    assert max(sizes) - min(sizes) <= 1
+
+
+@FAST
+@given(seed=st.integers(0, 2 ** 31 - 1), n=st.integers(1, 300))
+def test_generator_is_a_pure_function_of_seed_and_stream(seed, n):
+    a = synth.uniform((n,), seed, "s", -1, 1)
+    b = synth.uniform((n,), seed, "s", -1, 1)
+    c = synth.uniform((n,), seed, "t", -1, 1)
+    assert np.array_equal(a, b) and (n < 4 or not np.array_equal(a, c))
+    assert a.dtype == np.float32 and (a >= -1).all() and (a < 1).all()
+    big = synth.uniform((n + 7,), seed, "s", -1, 1)
+    assert np.array_equal(big[:n], a)                               # counter based: a prefix is stable
+
+
+@settings(max_examples=25, deadline=None)
+@given(B=st.integers(1, 4), N=st.integers(1, 9), A=st.integers(1, 6), R=st.integers(1, 6), data=st.data())
+def test_oracle_attention_invariants(B, N, A, R, data):
+    g = torch.Generator().manual_seed(data.draw(st.integers(0, 1000)))
+    h, P, C = torch.randn(B, R, generator=g), torch.randn(B, N, A, generator=g), torch.randn(B, N, R, generator=g)
+    wh, bh, wa, ba = torch.randn(A, R, generator=g), torch.randn(A, generator=g), torch.randn(1, A, generator=g), torch.randn(1, generator=g)
+    mask = torch.rand(B, N, generator=g) < 0.4
+    ctx, a, _ = O.additive_attention(h, P, C, mask, None, wh, bh, wa, ba)
+    assert torch.allclose(a.sum(1), torch.ones(B), atol=1e-5)
+    for b in range(B):
+        if mask[b].all():
+            assert torch.allclose(a[b], torch.full((N,), 1.0 / N), atol=1e-6)       # finite mask value: uniform
+        else:
+            assert float(a[b][mask[b]].abs().max() if mask[b].any() else 0.0) == 0.0
+    perm = torch.randperm(B, generator=g)
+    ctx_p, a_p, _ = O.additive_attention(h[perm], P[perm], C[perm], mask[perm], None, wh, bh, wa, ba)
+    assert torch.allclose(ctx_p, ctx[perm], atol=1e-6) and torch.allclose(a_p, a[perm], atol=1e-6)
+
+
+def test_yaml_overlay_semantics():
+    base = {"a": 1, "b": {"c": 2, "d": 3}, "e": 5}
+    over = {"a": None, "b": {"c": 7}, "e": 0}
+    got = copy.deepcopy(base)
+    update_values(over, got)
+    assert got == {"a": 1, "b": {"c": 7, "d": 3}, "e": 0}           # None keeps the old value, nested dicts recurse
