@@ -1,0 +1,51 @@
+"""Synthetic stand-in for the ActivityNet-Entities loader (reference misc/dataloader_anet.py, out of scope: the
+216 GB dataset is not available).  Items follow the reference's 12-tuple batch contract
+with one difference: position 0 carries the clip's PRE-EXTRACTED features (a dict) instead of raw frame features,
+because the once-per-clip encoder is outside the hot path."""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+from . import synth
+
+
+class SyntheticCaptionDataset(Dataset):
+    def __init__(self, dims: synth.Dims, n_clips: int, seed: int = 0, split: str = "training"):
+        self.d = dataclasses.replace(dims, B=n_clips)
+        self.split = split
+        self.feats = synth.clip_features(self.d, seed)
+        self.glue = synth.label_glue_batch(self.d, seed)
+        self.itow = {str(i): "w%d" % i for i in range(dims.V)}
+        self.wtoi = {"UNK": synth.UNK_IDX}
+        self.itod = {i: "cls%d" % i for i in range(1, dims.DET + 1)}
+        self.ltow, self.itoc, self.wtod = {}, {}, {}
+        self.vocab_size = dims.V
+
+    def __len__(self):
+        return self.d.B
+
+    def __getitem__(self, i):
+        t = lambda x: torch.from_numpy(np.ascontiguousarray(x))
+        f = {k: t(v[i]) for k, v in self.feats.items()}
+        g = self.glue
+        return (f, t(g["input_seq"][i]), t(g["gt_seq"][i]), t(g["num"][i]), t(g["proposals"][i]), t(g["gt_bboxs"][i]),
+                t(g["box_mask"][i]), "v_synth%05d_segment_%02d" % (i, 0), torch.zeros(self.d.N, 1), t(g["frm_mask"][i]),
+                t(g["sample_idx"][i]), t(self.feats["pnt_mask"][i][1:]))
+
+
+def collate(items):
+    """default_collate for the tensors, dict-of-stacks for the feature dict, list for the ids."""
+    cols = list(zip(*items))
+    out = []
+    for j, col in enumerate(cols):
+        if isinstance(col[0], dict):
+            out.append({k: torch.stack([c[k] for c in col]) for k in col[0]})
+        elif isinstance(col[0], str):
+            out.append(list(col))
+        else:
+            out.append(torch.stack(col))
+    return tuple(out)

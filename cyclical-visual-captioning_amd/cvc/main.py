@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Entry point with the reference's control flow (main.py:37-280): options + YAML overlay, seeds, data, model,
+optimizer (one group per tensor), epoch loop train -> eval -> ReduceLROnPlateau -> checkpoints (`model.pth`,
+`model-best.pth`, `infos_*.pkl`, `histories_*.pkl`).  Differences: one process per GPU (torchrun) with an RCCL
+gradient all-reduce instead of nn.DataParallel; the dataset is the synthetic stand-in unless a loader is injected.
+
+  python -m cvc.main --path_opt cfgs/cyclical.yml --synthetic_clips 256 --max_epochs 2
+"""
+from __future__ import annotations
+
+import os
+import pickle
+import random
+import sys
+
+import numpy as np
+import torch
+from torch.optim.lr_scheduler import ReduceLROnPlateau
+from torch.utils.data import DataLoader
+
+from . import opts as cvc_opts
+from . import synth
+from .data_synth import SyntheticCaptionDataset, collate
+from .distributed import GradReducer, init_from_env, shard_range
+from .misc import utils
+from .model.create_model import build_model
+from .trainer import Trainer, build_optimizer
+
+
+def main(argv=None):
+    parser = cvc_opts.build_parser()
+    parser.add_argument("--synthetic_clips", type=int, default=128)
+    parser.add_argument("--no_cfg", action="store_true", help="skip the YAML overlay (pure CLI)")
+    opt = parser.parse_args(argv)
+    if not opt.no_cfg:
+        opt = cvc_opts.load_cfg(opt)
+    rank, world, local_rank = init_from_env(opt.dist_backend) if "RANK" in os.environ else (0, 1, 0)
+    device = torch.device("cuda", local_rank) if torch.cuda.is_available() else None
+    if device is None:
+        raise SystemExit("cvc.main needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(device)
+    random.seed(opt.seed); np.random.seed(opt.seed); torch.manual_seed(opt.seed)     # reference main.py:63-67
+
+    dims = synth.Dims(B=opt.batch_size, N=opt.num_prop_per_frm, F=opt.t_attn_size, R=opt.rnn_size, A=opt.att_hid_size,
+                      E=opt.input_encoding_size, T=opt.seq_length, G=opt.vis_encoding_size, K=min(8, opt.num_prop_per_frm))
+    full = SyntheticCaptionDataset(dims, opt.synthetic_clips, opt.seed, opt.train_split)
+    sl = shard_range(len(full), rank, world)                                          # clips are sharded across ranks
+    train_set = torch.utils.data.Subset(full, range(sl.start, sl.stop))
+    per_rank_bs = max(1, opt.batch_size // world)
+    loader = DataLoader(train_set, batch_size=per_rank_bs, shuffle=True, num_workers=0, collate_fn=collate, drop_last=True)
+    val_loader = DataLoader(train_set, batch_size=per_rank_bs, shuffle=False, num_workers=0, collate_fn=collate)
+    # fields the reference injects into opt from the dataset (main.py:100-114)
+    opt.vocab_size, opt.itow, opt.wtoi, opt.itod, opt.detect_size = full.vocab_size, full.itow, full.wtoi, full.itod, dims.DET
+
+    model = build_model(opt, device)
+    optimizer = build_optimizer(model, opt)
+    reducer = GradReducer(model.named_parameters()) if world > 1 else None
+    trainer = Trainer(opt, full, model, optimizer, loader, val_loader, grad_reducer=reducer)
+    scheduler = ReduceLROnPlateau(optimizer, 'max', patience=opt.patience, min_lr=opt.min_lr)
+    tb = utils.set_tb_logger(opt.tb_log_dir, opt.exp_name, opt.resume) if (rank == 0 and opt.tensorboard and not opt.inference_only) else None
+
+    save_dir = os.path.join(opt.checkpoint_path, opt.exp_name)
+    best = None
+    for epoch in range(getattr(opt, "start_epoch", 0), opt.max_epochs):
+        if not opt.inference_only:
+            trainer.train(epoch, tb)
+        stats = trainer.eval(epoch, tb) if (epoch % max(opt.val_every_epoch, 1) == 0) else {}
+        score = stats.get("CIDEr", 0.0)
+        scheduler.step(score)
+        if rank == 0 and not opt.inference_only:
+            os.makedirs(save_dir, exist_ok=True)
+            torch.save(model.state_dict(), os.path.join(save_dir, "model.pth"))
+            infos = {"epoch": epoch, "best_val_score": best, "opt": {k: v for k, v in vars(opt).items() if _picklable(v)}}
+            with open(os.path.join(save_dir, "infos_" + opt.id + ".pkl"), "wb") as f:
+                pickle.dump(infos, f)
+            if best is None or score > best:
+                best = score
+                torch.save(model.state_dict(), os.path.join(save_dir, "model-best.pth"))
+                with open(os.path.join(save_dir, "infos_" + opt.id + "-best.pkl"), "wb") as f:
+                    pickle.dump(infos, f)
+        if opt.inference_only:
+            break
+    return 0
+
+
+def _picklable(v):
+    try:
+        pickle.dumps(v)
+        return True
+    except Exception:
+        return False
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -56,3 +56,21 @@ def test_eval_after_training_returns_reference_tuple():
     seq, att, none = tr._call(b, True)
     assert none is None and seq.shape == (d.B, d.T) and att.shape == (d.B, d.T, d.N)
     assert torch.allclose(att.sum(2), torch.ones(d.B, d.T, device=dev), atol=1e-5)
+
+
+def test_main_entry_point_one_epoch(tmp_path):
+    """cvc.main: options -> synthetic dataset -> model -> Trainer.train/eval -> checkpoints with the reference's
+    file names and state_dict keys."""
+    import json
+    import os
+    from cvc import main as cvc_main
+    from conftest import GOLDEN
+    rc = cvc_main.main(["--no_cfg", "--max_epochs", "1", "--batch_size", "4", "--synthetic_clips", "12", "--num_prop_per_frm", "7",
+                        "--t_attn_size", "5", "--rnn_size", "32", "--att_hid_size", "16", "--input_encoding_size", "16",
+                        "--seq_length", "4", "--vis_encoding_size", "24", "--tensorboard", "0", "--disp_interval", "100",
+                        "--checkpoint_path", str(tmp_path) + "/", "--exp_name", "t", "--learning_rate", "0.001"])
+    assert rc == 0
+    sd = torch.load(os.path.join(tmp_path, "t", "model-best.pth"), map_location="cpu")
+    ref_keys = set(json.load(open(os.path.join(GOLDEN, "config_surface.json")))["state_dict"])
+    assert set(sd.keys()) == ref_keys
+    assert os.path.exists(os.path.join(tmp_path, "t", "infos_-best.pkl"))
