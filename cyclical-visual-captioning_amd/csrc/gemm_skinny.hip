@@ -707,6 +707,9 @@ __global__ __launch_bounds__(256) void skinny_gemm_packed_kernel(PackedArgs a) {
     constexpr size_t WSTEP = (size_t)NW * 8 * 128, XSTEP = (size_t)NW * 8 * 256;   // floats per wave-chunk step
 
     auto load = [&](PFrag<MT>& f, int j) __attribute__((always_inline)) {
+#if defined(CVC_PABL) && CVC_PABL == 1
+        if (j > 0) { asm volatile("" : "+v"(f.w[0])); return; }     // ablation: only the first chunk is ever loaded (MFMA side only)
+#endif
         const float* w = wl + (size_t)j * WSTEP;
         const float* x = xl + (size_t)j * XSTEP;
 #pragma unroll
@@ -724,6 +727,15 @@ __global__ __launch_bounds__(256) void skinny_gemm_packed_kernel(PackedArgs a) {
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
     auto mma = [&](const PFrag<MT>& f) __attribute__((always_inline)) {
+#if defined(CVC_PABL) && CVC_PABL == 2
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                               // ablation: memory side only, keep the loads live
+            asm volatile("" ::"v"(f.w[q]));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(f.x[mt][q]));
+        }
+        return;
+#endif
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
