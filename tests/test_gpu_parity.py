@@ -440,6 +440,40 @@ def test_dot_product_decoder_variant(g1, dev, lib):
     close(att, att_o, **SEQ_TOL)
 
 
+@pytest.mark.parametrize("B,N,F", [(1, 1, 1), (33, 50, 17), (63, 129, 5), (64, 1000, 64), (5, 3, 300)])
+def test_decode_ragged_batch_and_region_counts(dev, lib, B, N, F):
+    """Edge shapes of the packed decode path (M < 64 padding, one / two MFMA row tiles, a single region, N beyond
+    one softmax pass per thread) vs the CPU oracle; R = 64, A = E = 32 keep the oracle fast."""
+    import dataclasses
+    from helpers import to_dev, tie_aware_seq_equal
+    from oracle import ref_cpu as O
+    from cvc.decode import DecodeEngine, DecodeWeights
+    d = dataclasses.replace(synth.CONFIGS["tiny"], B=B, N=N, F=F, R=64, A=32, E=32, V=97, T=6)
+    sd, f_np = synth.hot_path_state_dict(d, 11), synth.clip_features(d, 11, full_mask_clip=0 if B > 1 else None)
+    with torch.no_grad():
+        seq_o, att_o, _, logp_o = O.greedy_sample(O.to_torch(sd), O.to_torch(f_np), d.T, synth.UNK_IDX, return_logprobs=True)
+    eng = DecodeEngine(DecodeWeights(to_dev(sd, dev)), to_dev(f_np, dev), d.T, synth.UNK_IDX)
+    assert eng.packed
+    seq, att = eng.run()
+    n_exact = tie_aware_seq_equal(seq.cpu().numpy(), seq_o.numpy(), logp_o.numpy())
+    assert n_exact >= 0.95 * B * d.T
+    same = (seq.cpu() == seq_o).all(1)
+    close(att[same.to(dev)], att_o[same], **SEQ_TOL)
+
+
+def test_bad_arguments_are_rejected_not_executed(dev, lib):
+    """The C-ABI returns CVC_E_BADARG for violated preconditions; the binding raises."""
+    x = torch.zeros(4, 6, device=dev)                                  # k = 6 is not a multiple of 4
+    w = torch.zeros(8, 6, device=dev)
+    with pytest.raises(RuntimeError, match="bad argument"):
+        lib.linear_fwd([{"x": x, "w": w}], None, 4, 8)
+    with pytest.raises(RuntimeError, match="contiguous|GPU|float32"):
+        lib.log_softmax_fwd(torch.zeros(4, 8, device=dev).t())
+    with pytest.raises(RuntimeError, match="bad argument"):
+        lib.lstm_cell_fwd([{"x": torch.zeros(2, 8, device=dev), "w": torch.zeros(4 * 12, 8, device=dev)}], None, None,
+                          torch.zeros(2, 12, device=dev))            # R = 12 is not a multiple of 8
+
+
 def test_product_path_has_no_cpu_fallback(lib):
     from cvc import functional as F_
     x = torch.zeros(4, 8)
