@@ -48,6 +48,7 @@ def parse():
     p.add_argument("--mode", default="decode", choices=["decode", "train"],
                    help="decode = headline metric (default); train = cyclical fwd+bwd+all-reduce+Adam step (configs 3-ii / 4)")
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--train-graph", action="store_true", help="--mode train: capture the whole training step in a HIP graph")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-repeats", type=int, default=3)
     p.add_argument("--seed", type=int, default=1234)
@@ -107,7 +108,7 @@ def run_train(args, d, dev, rank, world):
     model = DecodeAndGroundCaptionerGVDROI(o, roi_extractor=PrecomputedRegionFeatures(d.DET, d.G))
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.hot_path_state_dict(d, args.seed).items()}, strict=False)
     model = model.to(dev).train()
-    optim = build_optimizer(model, o)
+    optim = build_optimizer(model, o, capturable=args.train_graph)
     reducer = GradReducer(model.named_parameters()) if torch.distributed.is_initialized() else None
     tr = Trainer(o, None, model, optim, None, None, grad_reducer=reducer)
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
@@ -118,14 +119,15 @@ def run_train(args, d, dev, rank, world):
              feats["pnt_mask"][:, 1:])
     import torch.distributed as dist
     dist_on = dist.is_available() and dist.is_initialized()
+    step = tr.train_step_graphed if args.train_graph else tr.train_step
     for _ in range(args.warmup):
-        tr.train_step(batch)
+        step(batch)
     torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = tr.train_step(batch)[0]
+        loss = step(batch)[0]
     torch.cuda.synchronize()
     el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
     if dist_on:

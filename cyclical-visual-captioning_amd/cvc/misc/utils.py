@@ -61,15 +61,16 @@ class LMCriterion(nn.Module):
         self.vocab_size = opt.vocab_size
 
     def forward(self, txt_input, att2_weights, ground_weights, target, att2_target, input_seq):
-        assert torch.sum(target >= self.vocab_size) == 0
+        if not torch.cuda.is_current_stream_capturing():
+            assert torch.sum(target >= self.vocab_size) == 0                  # reference :134 (host check; skipped under capture)
         loss = _masked_nll_mean(txt_input, target)
-        if att2_target.sum() != 0:
-            # supervised attention / grounding losses (w_att2 = 0 by default)
-            att2_loss = -torch.mean(torch.masked_select(F.log_softmax(att2_weights, dim=2), att2_target))
-            ground_loss = -torch.mean(torch.masked_select(F.log_softmax(ground_weights, dim=2), att2_target))
-        else:
-            att2_loss = torch.zeros(1, device=loss.device)
-            ground_loss = torch.zeros(1, device=loss.device)
+        # supervised attention / grounding losses (w_att2 = 0 by default).  The reference
+        # branches on `att2_target.sum() != 0` and uses masked_select (:150-162); the same value without a host round
+        # trip or a data-dependent shape: -sum(log_softmax * target) / max(count, 1), which is 0 when nothing is labelled.
+        tgt = att2_target.to(att2_weights.dtype)
+        count = tgt.sum().clamp(min=1.0)
+        att2_loss = (-(F.log_softmax(att2_weights, dim=2) * tgt).sum() / count).reshape(1)
+        ground_loss = (-(F.log_softmax(ground_weights, dim=2) * tgt).sum() / count).reshape(1)
         return loss, att2_loss, ground_loss
 
 

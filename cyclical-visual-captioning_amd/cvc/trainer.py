@@ -35,6 +35,7 @@ class Trainer:
         self.scorer = scorer
         self.grad_reducer = grad_reducer
         self.device = next(model.parameters()).device
+        self._graph = None            # HIP-graph state of train_step_graphed
 
     # ------------------------------------------------------------------ batch plumbing
     def _prepare(self, batch, train: bool):
@@ -81,6 +82,48 @@ class Trainer:
         nn.utils.clip_grad_norm_(self.model.parameters(), self.opts.grad_clip)
         self.optimizer.step()
         return loss.detach(), lm.detach(), att2.detach(), cls.detach(), rec.detach()
+
+    # ------------------------------------------------------------------ HIP-graph training step
+    def _core_step(self, b):
+        out = self._call(b)
+        loss, lm, att2, cls, rec = self.loss_mix(out)
+        self.optimizer.zero_grad(set_to_none=False)
+        loss.backward()
+        if self.grad_reducer is not None:
+            self.grad_reducer.finalize()
+        nn.utils.clip_grad_norm_(self.model.parameters(), self.opts.grad_clip)
+        self.optimizer.step()
+        return torch.stack([loss.detach().reshape(()), lm.detach().reshape(()), att2.detach().reshape(()),
+                            cls.detach().reshape(()), rec.detach().reshape(())])
+
+    def train_step_graphed(self, batch):
+        """Same step as train_step, captured once into a HIP graph and replayed: the per-step Python / launch overhead
+        (~7k launches) disappears.  Requirements: constant batch shapes (inputs are copied into static buffers), an
+        optimizer built with capturable=True (build_optimizer(..., capturable=True)), single rank or a reducer without
+        hooks.  Returns a static tensor [loss, lm, att2, cls, recon] (clone to keep)."""
+        b = self._prepare(batch, True)
+        if self._graph is None:
+            static = {k: (v.clone() if isinstance(v, torch.Tensor) else ({kk: vv.clone() for kk, vv in v.items()} if isinstance(v, dict) else v))
+                      for k, v in b.items()}
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(3):                                  # warm-up on a side stream (allocator, lazy init, Adam state)
+                    self._core_step(static)
+            torch.cuda.current_stream().wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                res = self._core_step(static)
+            self._graph = (g, static, res)
+        g, static, res = self._graph
+        for k, v in b.items():
+            if isinstance(v, torch.Tensor):
+                static[k].copy_(v)
+            elif isinstance(v, dict):
+                for kk, vv in v.items():
+                    static[k][kk].copy_(vv)
+        g.replay()
+        return res
 
     # ------------------------------------------------------------------ epoch loops
     def train(self, epoch, tb_logger=None):
@@ -163,8 +206,9 @@ class Trainer:
             grd_output[vid_id][str(int(seg_idx))] = res
 
 
-def build_optimizer(model, opt):
-    """One param group per tensor; 0.1x LR for ctx2pool_grd / vis_embed (reference main.py:171-191)."""
+def build_optimizer(model, opt, capturable: bool = False):
+    """One param group per tensor; 0.1x LR for ctx2pool_grd / vis_embed (reference main.py:171-191).
+    capturable=True keeps Adam's step counters on the device (needed by Trainer.train_step_graphed)."""
     params = []
     for key, value in dict(model.named_parameters()).items():
         if not value.requires_grad:
@@ -174,7 +218,7 @@ def build_optimizer(model, opt):
     if opt.optim == 'sgd':
         return torch.optim.SGD([{k: v for k, v in p.items() if k != 'betas'} for p in params], lr=opt.learning_rate, momentum=0.9)
     if opt.optim == 'adam':
-        return torch.optim.Adam(params)
+        return torch.optim.Adam(params, capturable=capturable)
     if opt.optim == 'adamax':
         return torch.optim.Adamax(params)
     raise ValueError('Unknown optimizer: {}'.format(opt.optim))

@@ -74,3 +74,25 @@ def test_main_entry_point_one_epoch(tmp_path):
     ref_keys = set(json.load(open(os.path.join(GOLDEN, "config_surface.json")))["state_dict"])
     assert set(sd.keys()) == ref_keys
     assert os.path.exists(os.path.join(tmp_path, "t", "infos_-best.pkl"))
+
+
+def test_graphed_train_step_equals_eager():
+    """Trainer.train_step_graphed (whole step in one HIP graph) reproduces the eager step sequence (dropout off so that
+    both are deterministic; the graphed path runs 3 warm-up steps before capture)."""
+    dev = torch.device("cuda:0")
+    d = synth.CONFIGS["tiny"]
+    losses = {}
+    for mode in ("eager", "graph"):
+        o, model, batch, Trainer, build_optimizer = _setup(dev, d, train_decoder_only=False)
+        model.eval()
+        tr = Trainer(o, None, model, build_optimizer(model, o, capturable=(mode == "graph")), None, None)
+        tr.model.eval()
+        if mode == "eager":
+            seq = []
+            for _ in range(6):
+                b = tr._prepare(batch, True)
+                seq.append(tr._core_step(b)[0].item())
+            losses[mode] = seq[3:]
+        else:
+            losses[mode] = [tr.train_step_graphed(batch)[0].item() for _ in range(3)]
+    np.testing.assert_allclose(losses["graph"], losses["eager"], rtol=1e-5, atol=1e-6)
