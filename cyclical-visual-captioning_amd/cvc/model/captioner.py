@@ -230,8 +230,17 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
 
     # ------------------------------------------------------------------ inference
     def decode_weights(self) -> DecodeWeights:
-        sd = {k: v for k, v in self.state_dict().items()}
-        return DecodeWeights(sd, getattr(self.opts, "softattn_type", "additive"))
+        """Flat (and, on first use by the packed decode path, fragment-packed) views of the hot-path parameters.
+        Cached until any parameter is modified in place (optimizer step, load_state_dict), detected through the
+        tensors' version counters, so an evaluation loop binds / packs the checkpoint once."""
+        params = [p for _, p in sorted(self.state_dict(keep_vars=True).items())]
+        key = tuple((p.data_ptr(), p._version) for p in params)
+        cached = getattr(self, "_decode_cache", None)
+        if cached is None or cached[0] != key:
+            sd = {k: v for k, v in self.state_dict().items()}
+            cached = (key, DecodeWeights(sd, getattr(self.opts, "softattn_type", "additive")))
+            self._decode_cache = cached
+        return cached[1]
 
     @torch.no_grad()
     def _sample(self, segs_feat, seq, proposals, gt_caption, num, mask_boxes, gt_boxes, region_feats, frm_mask, sample_idx,

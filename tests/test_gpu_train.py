@@ -96,3 +96,22 @@ def test_graphed_train_step_equals_eager():
         else:
             losses[mode] = [tr.train_step_graphed(batch)[0].item() for _ in range(3)]
     np.testing.assert_allclose(losses["graph"], losses["eager"], rtol=1e-5, atol=1e-6)
+
+
+def test_decode_weights_cache_follows_parameter_updates():
+    dev = torch.device("cuda:0")
+    d = synth.CONFIGS["tiny"]
+    o, model, batch, Trainer, build_optimizer = _setup(dev, d)
+    tr = Trainer(o, None, model, build_optimizer(model, o), None, None)
+    model.eval()
+    w1 = model.decode_weights()
+    assert model.decode_weights() is w1                                   # unchanged parameters: same binding
+    b = tr._prepare(batch, False)
+    seq1, att1, _ = tr._call(b, True)
+    model.train()
+    tr.train_step(batch)                                                  # optimizer step bumps the version counters
+    model.eval()
+    w2 = model.decode_weights()
+    assert w2 is not w1
+    seq2, att2, _ = tr._call(b, True)
+    assert not torch.equal(att1, att2)                                    # the decode sees the updated weights
