@@ -705,13 +705,22 @@ __global__ __launch_bounds__(256) void skinny_gemm_packed_kernel(PackedArgs a) {
     const float* wl = a.wp + ((size_t)blockIdx.x * a.nquad * 32 + i) * 4 + (size_t)(c0 + wave) * 8 * 128 + kh * 4 * 128;
     const float* xl = a.xq + (size_t)i * 4 + (size_t)(c0 + wave) * 8 * 256 + kh * 4 * 256;
     constexpr size_t WSTEP = (size_t)NW * 8 * 128, XSTEP = (size_t)NW * 8 * 256;   // floats per wave-chunk step
+#ifndef CVC_ROT_MUL
+#define CVC_ROT_MUL 5
+#endif
+    const int rot = n_my > 0 ? (int)((blockIdx.x * CVC_ROT_MUL) % (unsigned)n_my) : 0;
 
     auto load = [&](PFrag<MT>& f, int j) __attribute__((always_inline)) {
 #if defined(CVC_PABL) && CVC_PABL == 1
         if (j > 0) { asm volatile("" : "+v"(f.w[0])); return; }     // ablation: only the first chunk is ever loaded (MFMA side only)
 #endif
-        const float* w = wl + (size_t)j * WSTEP;
-        const float* x = xl + (size_t)j * XSTEP;
+        // every workgroup walks K from a different starting chunk: all 256 of them read the SAME activation lines,
+        // and in lock step they would queue on the same L2 channels (the order of a wave's partial sums changes
+        // with the block index, the result of a given block is still deterministic)
+        int jr = j + rot;
+        jr = jr >= n_my ? jr - n_my : jr;
+        const float* w = wl + (size_t)jr * WSTEP;
+        const float* x = xl + (size_t)jr * XSTEP;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f.w[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + q * 128));
