@@ -31,9 +31,13 @@ def main(argv=None):
     parser = cvc_opts.build_parser()
     parser.add_argument("--synthetic_clips", type=int, default=128)
     parser.add_argument("--no_cfg", action="store_true", help="skip the YAML overlay (pure CLI)")
+    parser.add_argument("--synthetic_raw", action="store_true",
+                        help="feed raw frame / region features through the once-per-clip encoder (model/backbone.py) "
+                             "instead of pre-extracted features")
     opt = parser.parse_args(argv)
     if not opt.no_cfg:
         opt = cvc_opts.load_cfg(opt)
+    opt.test_mode = opt.val_split in ["testing", "hidden_test"]                       # reference main.py:57
     rank, world, local_rank = init_from_env(opt.dist_backend) if "RANK" in os.environ else (0, 1, 0)
     device = torch.device("cuda", local_rank) if torch.cuda.is_available() else None
     if device is None:
@@ -43,7 +47,7 @@ def main(argv=None):
 
     dims = synth.Dims(B=opt.batch_size, N=opt.num_prop_per_frm, F=opt.t_attn_size, R=opt.rnn_size, A=opt.att_hid_size,
                       E=opt.input_encoding_size, T=opt.seq_length, G=opt.vis_encoding_size, K=min(8, opt.num_prop_per_frm))
-    full = SyntheticCaptionDataset(dims, opt.synthetic_clips, opt.seed, opt.train_split)
+    full = SyntheticCaptionDataset(dims, opt.synthetic_clips, opt.seed, opt.train_split, raw=opt.synthetic_raw)
     sl = shard_range(len(full), rank, world)                                          # clips are sharded across ranks
     train_set = torch.utils.data.Subset(full, range(sl.start, sl.stop))
     per_rank_bs = max(1, opt.batch_size // world)
@@ -51,6 +55,11 @@ def main(argv=None):
     val_loader = DataLoader(train_set, batch_size=per_rank_bs, shuffle=False, num_workers=0, collate_fn=collate)
     # fields the reference injects into opt from the dataset (main.py:100-114)
     opt.vocab_size, opt.itow, opt.wtoi, opt.itod, opt.detect_size = full.vocab_size, full.itow, full.wtoi, full.itod, dims.DET
+    if opt.synthetic_raw:
+        if opt.att_feat_size != opt.vis_encoding_size:
+            raise SystemExit("--synthetic_raw needs att_feat_size == vis_encoding_size (fc7 is square, backbone.py:115)")
+        opt.glove_clss, opt.glove_vg_cls = torch.from_numpy(full.glove_clss), torch.from_numpy(full.glove_vg_cls)
+        opt.vg_cls, opt.detectron_tables = full.vg_cls, full.tables
 
     model = build_model(opt, device)
     optimizer = build_optimizer(model, opt)

@@ -1,17 +1,22 @@
-"""Model factory -- the reference's model/create_model.py:11-37, with the once-per-clip encoder
-injected (it is outside the hot path: pass `roi_extractor_factory`, default = pre-extracted
-features)."""
+"""Model factory -- the reference's model/create_model.py:11-37.  The once-per-clip encoder is
+`RegionalFeatureExtractorGVD` as in the reference whenever the data loader has put the GloVe tables on
+`opts` (main.py:104-105 of the reference); runs on pre-extracted features (the benchmark's input
+contract, `opts.precomputed_features`) get `PrecomputedRegionFeatures`.  `roi_extractor_factory`
+injects anything else."""
 from __future__ import annotations
 
 import torch.nn as nn
 
 from ..cycle_utils import resume_decoder_roiextractor
+from .backbone import RegionalFeatureExtractorGVD
 from .captioner import DecodeAndGroundCaptionerGVDROI, PrecomputedRegionFeatures
 from .decoder_core import TopDownDecoderCore
 
 
 def _default_extractor(opts):
-    return PrecomputedRegionFeatures(opts.detect_size, opts.vis_encoding_size, opts.drop_prob_lm)
+    if getattr(opts, "precomputed_features", not hasattr(opts, "glove_clss")):
+        return PrecomputedRegionFeatures(opts.detect_size, opts.vis_encoding_size, opts.drop_prob_lm)
+    return RegionalFeatureExtractorGVD(opts)
 
 
 def build_model(opts, device, roi_extractor_factory=_default_extractor):

@@ -232,3 +232,60 @@ def label_glue_batch(d: Dims, seed: int = 1234) -> "OrderedDict[str, np.ndarray]
     o["num"] = num
     o["sample_idx"] = np.tile(np.asarray([[0, d.F]], dtype=np.int64), (B, 1))
     return o
+
+
+# ------------------------------------------------------------------ once-per-clip encoder (section 8(f) rank 1)
+SEG_FEAT_DIM = 3072   # 2048 rgb + 1024 motion, hard-coded in the reference (backbone.py:68,73,328)
+
+
+def detectron_tables(d: Dims, seed: int = 1234, n_vg: int = 9) -> "OrderedDict[str, np.ndarray]":
+    """Synthetic stand-ins for the four Detectron pickles and the two GloVe tables the encoder's
+    constructor reads (backbone.py:110-146; opts.glove_clss / glove_vg_cls from the data loader)."""
+    o: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    k = np.float32(1.0 / np.sqrt(d.G))
+    o["fc7_w"] = uniform((d.G, d.G), seed, "fc7_w", -k, k)
+    o["fc7_b"] = uniform((d.G,), seed, "fc7_b", -k, k)
+    o["cls_score_w"] = normal((n_vg, d.G), seed, "cls_score_w") * np.float32(0.5)
+    o["cls_score_b"] = normal((n_vg,), seed, "cls_score_b") * np.float32(0.5)
+    o["glove_clss"] = normal((d.DET + 1, 300), seed, "glove_clss")
+    o["glove_vg_cls"] = normal((n_vg, 300), seed, "glove_vg_cls")
+    return o
+
+
+# projections feeding the attention scores get a gain so that attention over encoder outputs is not uniform
+ENCODER_GAIN = {"ctx2pool_fc.weight": 6.0, "ctx2att_fc.weight": 8.0, "fc_embed.0.weight": 0.3, "pool_embed.0.weight": 0.5}
+
+
+def encoder_fill(name: str, shape, seed: int = 1234) -> np.ndarray:
+    """Deterministic value for one encoder state_dict entry (both the golden generator and the
+    tests call this, so weights never need to be stored in a fixture)."""
+    shape = tuple(int(s) for s in shape)
+    if name.endswith("num_batches_tracked"):
+        return np.asarray(3, dtype=np.int64)
+    if name.endswith("running_var"):
+        return uniform(shape, seed, "enc." + name, 0.5, 1.5)
+    if name.endswith("running_mean"):
+        return normal(shape, seed, "enc." + name) * np.float32(0.1)
+    fan = shape[-1] if len(shape) > 1 else shape[0]
+    k = np.float32(ENCODER_GAIN.get(name, 1.0) / np.sqrt(max(fan, 1)))
+    return uniform(shape, seed, "enc." + name, -k, k)
+
+
+ENCODER_CTOR_KEYS = ("vis_embed.0.weight", "vis_classifiers_bias", "ctx2pool_grd.0.weight", "ctx2pool_grd.0.bias",
+                     "det_fc.0.weight")
+
+
+def encoder_inputs(d: Dims, seed: int = 1234) -> "OrderedDict[str, np.ndarray]":
+    """Raw clip inputs of RegionalFeatureExtractorGVD.forward (backbone.py:296-298) on top of
+    `label_glue_batch`: ragged proposal counts, segment info and sampled-frame windows."""
+    o = label_glue_batch(d, seed)
+    B, N, F = d.B, d.N, d.F
+    o["segs_feat"] = np.maximum(normal((B, F, SEG_FEAT_DIM), seed, "segs_feat"), 0) * np.float32(0.5)
+    o["region_feats"] = np.maximum(normal((B, N, d.G), seed, "region_feats"), 0)
+    o["num"][:, 1] = N - (np.arange(B) * 2) % (N // 2 + 1)          # ragged proposal counts, clip 0 full
+    o["num"][:, 3:7] = uniform((B, 4), seed, "seg_info", 0, 1)
+    lo = randint((B,), seed, "sample_lo", 0, max(F // 3, 1))
+    hi = F - randint((B,), seed, "sample_hi", 0, max(F // 3, 1))
+    o["sample_idx"] = np.stack([lo, hi], axis=1).astype(np.int64)
+    o["pnt_mask_in"] = np.arange(N + 1)[None, :] > o["num"][:, 1:2]
+    return o

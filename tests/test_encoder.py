@@ -1,0 +1,160 @@
+"""Once-per-clip encoder mirror (cvc/model/backbone.py) against the reference's own outputs
+(tests/golden/g5_encoder.npz, made by tools/make_golden.py g5 from
+/root/reference/anet-video-captioning/model/backbone.py).  The encoder is library work (torch
+GEMMs + GRU), so the stand-alone checks run on CPU as well; the end-to-end check drives the HIP hot
+path behind it and is GPU-only."""
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from cvc import synth
+from conftest import Golden
+from helpers import make_opts, to_dev
+
+D = synth.CONFIGS["tiny"]
+OUT = ("fc_feats", "conv_feats", "p_conv_feats", "pool_feats", "p_pool_feats", "g_pool_feats", "pnt_mask",
+       "overlaps_expanded")
+
+
+@pytest.fixture(scope="module")
+def g5():
+    return Golden("g5_encoder.npz")
+
+
+def encoder_opts(tmp_path, tables, seq_per_img=1, **over):
+    wdir = tmp_path / "detectron_weights"
+    wdir.mkdir(exist_ok=True)
+    for k in ("fc7_w", "fc7_b", "cls_score_w", "cls_score_b"):
+        with open(wdir / (k + ".pkl"), "wb") as f:
+            pickle.dump(tables[k], f)
+    base = dict(test_mode=False)
+    base.update(over)
+    return make_opts(D, seq_per_img=seq_per_img, enable_BUTD=False, att_input_mode="both",
+                     num_sampled_frm=4, finetune_cnn=False, att_feat_size=D.G, fc_feat_size=synth.SEG_FEAT_DIM,
+                     t_attn_size=D.F, second_drop_prob=0.3, att_model="topdown", t_attn_mode="bigru",
+                     itod={i + 1: "d%d" % i for i in range(D.DET)},
+                     vg_cls=["vg%d" % i for i in range(tables["glove_vg_cls"].shape[0])],
+                     glove_clss=torch.from_numpy(tables["glove_clss"]),
+                     glove_vg_cls=torch.from_numpy(tables["glove_vg_cls"]),
+                     detectron_weights_dir=str(wdir), **base)
+
+
+def build_encoder(tmp_path, seed, seq_per_img=1, **over):
+    from cvc.model.backbone import RegionalFeatureExtractorGVD
+    enc = RegionalFeatureExtractorGVD(encoder_opts(tmp_path, synth.detectron_tables(D, seed), seq_per_img, **over))
+    ctor = {k: v.detach().clone() for k, v in enc.state_dict().items() if k in synth.ENCODER_CTOR_KEYS}
+    sd = {k: (ctor[k] if k in ctor else torch.from_numpy(np.asarray(synth.encoder_fill(k, v.shape, seed))))
+          for k, v in enc.state_dict().items()}
+    enc.load_state_dict(sd)
+    return enc.eval(), ctor
+
+
+def run_encoder(enc, inp, overlaps):
+    return enc(inp["segs_feat"], inp["proposals"], inp["num"], inp["box_mask"], inp["region_feats"], inp["gt_bboxs"],
+               overlaps, inp["sample_idx"])
+
+
+def probe_loss(outs):
+    fc, conv, pconv, pool, ppool, g = outs[:6]
+    return (0.01 * fc.sum() + conv.pow(2).mean() + pconv.mean() + pool.pow(2).mean() + ppool.pow(2).mean()
+            + g.pow(2).mean() + outs[9].sum())
+
+
+def test_constructor_matches_reference(g5, tmp_path):
+    seed = int(g5["meta.seed"])
+    _, ctor = build_encoder(tmp_path, seed)
+    want = g5.sub("s2.ctor.")
+    assert set(want) == set(ctor)
+    for k, v in want.items():
+        np.testing.assert_array_equal(ctor[k].numpy(), v, err_msg=k)
+
+
+def test_missing_detectron_pickles_fail_loudly(tmp_path):
+    from cvc.model.backbone import RegionalFeatureExtractorGVD
+    o = encoder_opts(tmp_path, synth.detectron_tables(D, 1))
+    o.detectron_weights_dir = str(tmp_path / "nowhere")
+    with pytest.raises(FileNotFoundError):
+        RegionalFeatureExtractorGVD(o)
+
+
+@pytest.mark.parametrize("case,S,over", [("s2.", 2, {}), ("s1test.", 1, {"test_mode": True})])
+def test_forward_matches_reference(g5, tmp_path, case, S, over):
+    seed = int(g5["meta.seed"])
+    enc, _ = build_encoder(tmp_path, seed, S, collect_cls_pred=True, **over)
+    inp = to_dev(synth.encoder_inputs(D, seed), "cpu")
+    res = run_encoder(enc, inp, torch.from_numpy(g5["overlaps"]))
+    want = g5.sub(case + "out.")
+    for k, got in zip(OUT, res[:8]):
+        if got.dtype == torch.bool:
+            np.testing.assert_array_equal(got.numpy(), want[k], err_msg=k)
+        else:
+            np.testing.assert_allclose(got.detach().numpy(), want[k], rtol=1e-5, atol=2e-6, err_msg=k)
+    np.testing.assert_allclose(res[9].detach().numpy().reshape(-1), want["cls_loss"].reshape(-1), rtol=1e-5, atol=1e-6)
+    if not over:
+        np.testing.assert_array_equal(res[8].numpy(), want["cls_pred"])
+
+
+def test_gradients_match_reference(g5, tmp_path):
+    seed = int(g5["meta.seed"])
+    enc, _ = build_encoder(tmp_path, seed, 2)
+    inp = to_dev(synth.encoder_inputs(D, seed), "cpu")
+    probe_loss(run_encoder(enc, inp, torch.from_numpy(g5["overlaps"]))).backward()
+    want = g5.sub("s2.grad.")
+    params = dict(enc.named_parameters())
+    assert set(k[:-len(".norm")] if k.endswith(".norm") else k for k in want) == set(params)
+    for k, v in want.items():
+        if v is None:
+            assert params[k].grad is None, k
+        else:
+            got = params[k[:-len(".norm")]].grad.double().norm().item()
+            assert got == pytest.approx(float(v), rel=1e-4, abs=1e-7), k
+
+
+def test_no_positive_targets_gives_zero_loss(tmp_path):
+    enc, _ = build_encoder(tmp_path, 5)
+    inp = to_dev(synth.encoder_inputs(D, 5), "cpu")
+    res = run_encoder(enc, inp, torch.zeros(D.B, D.N, D.K))
+    assert float(res[9].detach()) == 0.0
+    assert torch.isfinite(res[3]).all()
+
+
+@pytest.mark.gpu
+def test_encoder_plus_hot_path_end_to_end(g5, tmp_path):
+    """reference captioner over the reference encoder == HIP hot path over the mirrored encoder."""
+    from cvc.model.captioner import DecodeAndGroundCaptionerGVDROI
+    dev = torch.device("cuda:0")
+    seed = int(g5["meta.seed"])
+    enc, _ = build_encoder(tmp_path, seed, 1)
+    model = DecodeAndGroundCaptionerGVDROI(make_opts(D), roi_extractor=enc)
+    sd = {k: torch.from_numpy(v) for k, v in synth.hot_path_state_dict(D, seed).items()
+          if not k.startswith("roi_feat_extractor.")}
+    sd.update({"roi_feat_extractor." + k: v for k, v in enc.state_dict().items()})
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    b = to_dev(synth.encoder_inputs(D, seed), dev)
+
+    def call(lang_eval):
+        return model(b["segs_feat"], b["input_seq"], b["gt_seq"], b["num"], b["proposals"], b["gt_bboxs"], b["box_mask"],
+                     b["region_feats"], b["frm_mask"], b["sample_idx"], b["pnt_mask_in"], lang_eval)
+    with torch.no_grad():
+        seq, att2, _ = call(True)
+    np.testing.assert_array_equal(seq.cpu().numpy(), g5["e2e.seq"])
+    np.testing.assert_allclose(att2.cpu().numpy(), g5["e2e.att2_weights"], rtol=1e-4, atol=2e-5)
+    # MIOpen's RNN backward needs the GRU in training mode; switch its inter-layer dropout off to stay deterministic
+    model.roi_feat_extractor.context_enc.train()
+    model.roi_feat_extractor.context_enc.dropout = 0.0
+    losses = call(False)
+    for i, l in enumerate(losses):
+        assert float(l.detach().mean()) == pytest.approx(float(g5["e2e.loss%d" % i][0]), rel=2e-5, abs=2e-6), i
+    lm, a2, _g, cls, rec = [x.mean() for x in losses]
+    (0.5 * lm + 0.05 * a2 + 0.1 * cls + 0.5 * rec).backward()
+    params = dict(model.named_parameters())
+    for k, v in g5.sub("e2e.grad.").items():
+        if v is None:
+            p = params[k]
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+        else:
+            got = params[k[:-len(".norm")]].grad.double().norm().item()
+            assert got == pytest.approx(float(v), rel=2e-4, abs=1e-6), k

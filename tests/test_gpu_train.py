@@ -76,6 +76,24 @@ def test_main_entry_point_one_epoch(tmp_path):
     assert os.path.exists(os.path.join(tmp_path, "t", "infos_-best.pkl"))
 
 
+def test_main_entry_point_raw_features_through_encoder(tmp_path):
+    """Same loop fed raw frame / region features: build_model picks the mirrored once-per-clip encoder
+    (cvc/model/backbone.py) and its parameters are trained and checkpointed under the reference's key names."""
+    import os
+    from cvc import main as cvc_main
+    rc = cvc_main.main(["--no_cfg", "--synthetic_raw", "--max_epochs", "1", "--batch_size", "4", "--synthetic_clips", "8",
+                        "--num_prop_per_frm", "7", "--t_attn_size", "5", "--rnn_size", "32", "--att_hid_size", "16",
+                        "--input_encoding_size", "16", "--seq_length", "4", "--vis_encoding_size", "24", "--att_feat_size", "24",
+                        "--tensorboard", "0", "--disp_interval", "100", "--checkpoint_path", str(tmp_path) + "/",
+                        "--exp_name", "raw", "--learning_rate", "0.001"])
+    assert rc == 0
+    sd = torch.load(os.path.join(tmp_path, "raw", "model-best.pth"), map_location="cpu")
+    for k in ("roi_feat_extractor.context_enc.weight_hh_l1_reverse", "roi_feat_extractor.att_embed.1.0.weight",
+              "roi_feat_extractor.att_embed_aux.0.running_var", "roi_feat_extractor.pool_embed.0.weight",
+              "roi_feat_extractor.vis_classifiers_bias", "decoder_core.lang_lstm.weight_hh"):
+        assert k in sd, k
+
+
 def test_graphed_train_step_equals_eager():
     """Trainer.train_step_graphed (whole step in one HIP graph) reproduces the eager step sequence (dropout off so that
     both are deterministic; the graphed path runs 3 warm-up steps before capture)."""

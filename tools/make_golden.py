@@ -337,6 +337,110 @@ def g4_config_surface(path):
     print("wrote", path)
 
 
+# ------------------------------------------------------------------------------------ G5 (once-per-clip encoder)
+def encoder_opts(d, tables, seq_per_img, **over):
+    o = make_opts(d, seq_per_img=seq_per_img, test_mode=False, enable_BUTD=False, att_input_mode="both",
+                  num_sampled_frm=4, finetune_cnn=False, att_feat_size=d.G, fc_feat_size=synth.SEG_FEAT_DIM,
+                  detect_size=d.DET, vis_encoding_size=d.G, t_attn_size=d.F, second_drop_prob=0.3,
+                  att_model="topdown", t_attn_mode="bigru", itod={i + 1: "d%d" % i for i in range(d.DET)},
+                  vg_cls=["vg%d" % i for i in range(tables["glove_vg_cls"].shape[0])],
+                  glove_clss=t(tables["glove_clss"]), glove_vg_cls=t(tables["glove_vg_cls"]))
+    for k, v in over.items():
+        setattr(o, k, v)
+    return o
+
+
+def build_reference_encoder(d, tables, seed, seq_per_img, **over):
+    import pickle
+    import tempfile
+    from model.backbone import RegionalFeatureExtractorGVD
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "data", "detectron_weights"))
+    for k in ("fc7_w", "fc7_b", "cls_score_w", "cls_score_b"):
+        with open(os.path.join(tmp, "data", "detectron_weights", k + ".pkl"), "wb") as f:
+            pickle.dump(tables[k], f)
+    cwd = os.getcwd()
+    os.chdir(tmp)
+    try:
+        enc = RegionalFeatureExtractorGVD(encoder_opts(d, tables, seq_per_img, **over))
+    finally:
+        os.chdir(cwd)
+    enc.device = torch.device("cpu")
+    ctor = {k: v.detach().clone() for k, v in enc.state_dict().items() if k in synth.ENCODER_CTOR_KEYS}
+    sd = {k: (ctor[k] if k in ctor else t(synth.encoder_fill(k, v.shape, seed))) for k, v in enc.state_dict().items()}
+    enc.load_state_dict(sd)
+    enc.eval()
+    return enc, ctor
+
+
+ENC_OUT = ("fc_feats", "conv_feats", "p_conv_feats", "pool_feats", "p_pool_feats", "g_pool_feats", "pnt_mask",
+           "overlaps_expanded")
+
+
+def encoder_probe_loss(outs):
+    fc, conv, pconv, pool, ppool, g = outs[:6]
+    return (0.01 * fc.sum() + conv.pow(2).mean() + pconv.mean() + pool.pow(2).mean() + ppool.pow(2).mean()
+            + g.pow(2).mean() + outs[9].sum())
+
+
+def g5_encoder(path):
+    import misc.utils as ref_utils
+    d = synth.CONFIGS["tiny"]
+    seed = 1237
+    tables = synth.detectron_tables(d, seed)
+    inp = synth.encoder_inputs(d, seed)
+    out = OrderedDict()
+    out["meta.seed"] = np.asarray(seed)
+    bt = {k: t(v) for k, v in inp.items()}
+    overlaps = ref_utils.bbox_overlaps(bt["proposals"], bt["gt_bboxs"],
+                                       (bt["frm_mask"] | bt["pnt_mask_in"][:, 1:].unsqueeze(-1)))
+    out["overlaps"] = overlaps.numpy()
+    for name, S, over in (("s2.", 2, {}), ("s1test.", 1, dict(test_mode=True))):
+        enc, ctor = build_reference_encoder(d, tables, seed, S, **over)
+        put(out, name + "ctor.", ctor)
+        res = enc(bt["segs_feat"], bt["proposals"], bt["num"], bt["box_mask"], bt["region_feats"], bt["gt_bboxs"],
+                  overlaps, bt["sample_idx"])
+        put(out, name + "out.", dict(zip(ENC_OUT, res[:8])))
+        out[name + "out.cls_loss"] = res[9].detach().numpy()
+        if not over:
+            out[name + "out.cls_pred"] = res[8].numpy()
+            encoder_probe_loss(res).backward()
+            for n, p in enc.named_parameters():
+                if p.grad is None:
+                    out[name + "grad." + n + ".is_none"] = np.asarray(1)
+                else:
+                    out[name + "grad." + n + ".norm"] = np.asarray(p.grad.double().norm().item())
+    # ---- end to end: the reference captioner on top of the reference encoder (seq_per_img 1)
+    sd = synth.hot_path_state_dict(d, seed)
+    enc, _ = build_reference_encoder(d, tables, seed, 1)
+    model = DecodeAndGroundCaptionerGVDROI(make_opts(d), roi_extractor=enc)
+    model.device = torch.device("cpu")
+    dec = {k: t(v) for k, v in sd.items() if not k.startswith("roi_feat_extractor.")}
+    dec.update({"roi_feat_extractor." + k: v for k, v in enc.state_dict().items()})
+    model.load_state_dict(dec)
+    model.eval()
+
+    def call(lang_eval):
+        return model(bt["segs_feat"], bt["input_seq"], bt["gt_seq"], bt["num"], bt["proposals"], bt["gt_bboxs"],
+                     bt["box_mask"], bt["region_feats"], bt["frm_mask"], bt["sample_idx"], bt["pnt_mask_in"], lang_eval)
+    with torch.no_grad():
+        seq, att2, _ = call(True)
+    put(out, "e2e.", dict(seq=seq, att2_weights=att2))
+    losses = call(False)
+    put(out, "e2e.", {"loss%d" % i: l for i, l in enumerate(losses)})
+    loss = loss_mix(losses, w_att2=0.05, w_cls=0.1)
+    for p in model.parameters():
+        p.grad = None
+    loss.backward()
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            out["e2e.grad." + n + ".is_none"] = np.asarray(1)
+        else:
+            out["e2e.grad." + n + ".norm"] = np.asarray(p.grad.double().norm().item())
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
     gdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gdir, exist_ok=True)
@@ -344,7 +448,8 @@ if __name__ == "__main__":
     jobs = {"g1": lambda: g1_tiny(os.path.join(gdir, "g1_tiny.npz")),
             "g2": lambda: g2_cfg1(os.path.join(gdir, "g2_cfg1.npz")),
             "g3": lambda: g3_shards(os.path.join(gdir, "g3_shards.npz")),
-            "g4": lambda: g4_config_surface(os.path.join(gdir, "config_surface.json"))}
+            "g4": lambda: g4_config_surface(os.path.join(gdir, "config_surface.json")),
+            "g5": lambda: g5_encoder(os.path.join(gdir, "g5_encoder.npz"))}
     for name, job in jobs.items():
         if not only or name in only:
             job()
