@@ -1,0 +1,259 @@
+// Backward-data GEMM of the skinny layers:  dX[M<=64, N] = dY[M, K] * W[K, N]   (fp32, MFMA 32x32x2).
+//
+// Replaces `torch.mm(d_gates, w_hh)` / `torch.mm(d_gates, w_ih[:, k0:k1])` in the backward of the two
+// LSTM cells (autograd of nn.LSTMCell, reference model/decoder_core.py:45-50, 59-61, 99-108): one launch
+// per cell for every input segment that needs a gradient, the weights read once in their checkpoint
+// layout.  W is row-major [K, ldw] (K = 4R gate rows), so for this product its rows ARE coalesced along
+// N: a lane's 16-byte load W[k][n0+4i .. n0+4i+3] feeds four MFMA column tiles (tile c holds columns
+// n0 + 4i + c), and dY arrives in the quad layout [K/4][64][4] (written by cvc_lstm_pointwise_bwd), the
+// same fragment-native activation layout the packed forward kernel uses.
+//
+//   workgroup = 128 output columns x one K slice, 4 waves interleaved over the slice's 8-row groups;
+//   per group and wave: 4 weight loads + MT activation loads (16 B / lane) -> 16*MT MFMAs;
+//   register ring of DEPTH groups, steady-state loads unconditional (counted vmcnt, see gemm_skinny.hip);
+//   ordered cross-wave sum in LDS, K slices written as partial planes, summed in a fixed order by
+//   nn_reduce_kernel (bitwise reproducible).
+#include "cvc_common.h"
+
+namespace {
+
+constexpr int NN_MAX_SEG = 6;
+#ifndef CVC_NN_DEPTH
+#define CVC_NN_DEPTH 3
+#endif
+constexpr int NN_DEPTH = CVC_NN_DEPTH;
+#ifndef CVC_NN_WGS
+#define CVC_NN_WGS 2     // workgroups per CU the register budget is held to
+#endif
+
+struct NNSeg {
+    const float* w;     // column 0 of this range inside a row-major [K, ldw] matrix
+    float* dst;         // [M, ld_dst]
+    int ldw, ncols, ld_dst, slab0;   // slab0: first 128-column slab of the segment in the launch
+};
+
+struct NNArgs {
+    const float* xq;    // dY, quad layout [K/4][64][4]
+    float* part;        // [ksplit][M][ntot] partial planes (unused when ksplit == 1)
+    int K, M, nseg, ksplit, ntot, nslab;
+    NNSeg seg[NN_MAX_SEG];
+};
+
+template <int MT>
+struct NNFrag {
+    f32x4 w[4];
+    f32x4 x[MT];
+};
+
+template <int MT>
+__global__ __launch_bounds__(256, CVC_NN_WGS) void skinny_gemm_nn_kernel(NNArgs a) {
+    constexpr int NW = 4;
+    constexpr int LDM = MT * 32 + 1;
+    __shared__ float red[2 * 128 * LDM];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, kh = lane >> 5;
+
+    // 1-D grid, K slice fastest (measured: no difference to slab-fastest on MI355X; kept because the
+    // workgroups that share a dY slice then start together)
+    const int kslice = (int)blockIdx.x % a.ksplit, slab = (int)blockIdx.x / a.ksplit;
+    // which segment does this slab belong to (uniform; a loop, not a select chain, so it stays in SGPRs)
+    int s = 0;
+    for (int t = 1; t < a.nseg; ++t)
+        if (slab >= a.seg[t].slab0) s = t;
+    const NNSeg sg = a.seg[s];
+    const int n0 = (slab - sg.slab0) * 128;
+    // lanes past the segment's last column re-read its last quad (never stored)
+    int col = n0 + 4 * i;
+    col = col + 4 <= sg.ncols ? col : sg.ncols - 4;
+
+    const int ngroup = a.K >> 3;
+    const int g_lo = ngroup * kslice / a.ksplit, g_hi = ngroup * (kslice + 1) / a.ksplit;
+    const int ng = g_hi - g_lo;
+    const int n_my = ng > wave ? (ng - wave + NW - 1) / NW : 0;      // groups g_lo + wave + 4*j
+    const size_t ldw = (size_t)sg.ldw;
+    // running per-lane pointers (4 weight rows + the activation quad), advanced by one wave step per load:
+    // no per-load index arithmetic, which keeps the kernel under 256 registers -> two workgroups per CU
+    const float* wp[4];
+    wp[0] = sg.w + (size_t)((g_lo + wave) * 8 + kh * 4) * ldw + col;
+#pragma unroll
+    for (int e = 1; e < 4; ++e) wp[e] = wp[e - 1] + ldw;
+    const float* xp = a.xq + ((size_t)((g_lo + wave) * 2 + kh) * 64 + i) * 4;
+    const size_t WSTEP = (size_t)NW * 8 * ldw;
+    constexpr size_t XSTEP = (size_t)NW * 2 * 256;
+
+    auto load = [&](NNFrag<MT>& f) __attribute__((always_inline)) {
+#if defined(CVC_NN_ABL) && CVC_NN_ABL == 1
+        if (xp != a.xq + ((size_t)((g_lo + wave) * 2 + kh) * 64 + i) * 4) { xp += XSTEP; asm volatile("" : "+v"(f.w[0])); return; }   // ablation: MFMA side only
+#endif
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f.w[e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp[e]));
+            wp[e] += WSTEP;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) f.x[mt] = ld4(xp + mt * 128);
+        xp += XSTEP;
+    };
+
+    f32x16 acc[4][MT];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][mt][r] = 0.f;
+
+    auto mma = [&](const NNFrag<MT>& f) __attribute__((always_inline)) {
+#if defined(CVC_NN_ABL) && CVC_NN_ABL == 2
+#pragma unroll
+        for (int e = 0; e < 4; ++e) asm volatile("" ::"v"(f.w[e]));                    // ablation: memory side only
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(f.x[mt]));
+        return;
+#endif
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[c][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w[e][c], f.x[mt][e], acc[c][mt], 0, 0, 0);
+    };
+
+    NNFrag<MT> ring[NN_DEPTH];
+    if (n_my >= NN_DEPTH) {
+#pragma unroll
+        for (int t = 0; t < NN_DEPTH - 1; ++t) load(ring[t]);
+        int j = 0;
+        for (; j + 2 * NN_DEPTH - 1 <= n_my; j += NN_DEPTH) {
+#pragma unroll
+            for (int t = 0; t < NN_DEPTH; ++t) {
+                load(ring[(t + NN_DEPTH - 1) % NN_DEPTH]);
+                mma(ring[t]);
+#pragma unroll
+                for (int g = 0; g < 4 + MT; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 16 * MT / (4 + MT), 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                    // VMEM read
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                    // VALU (addresses)
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NN_DEPTH; ++t) {
+            if (j + t + NN_DEPTH - 1 < n_my) load(ring[(t + NN_DEPTH - 1) % NN_DEPTH]);
+            if (j + t < n_my) mma(ring[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < NN_DEPTH - 1; ++t)
+            if (j + NN_DEPTH + t < n_my) mma(ring[t]);
+    } else {
+        for (int j = 0; j < n_my; ++j) {
+            load(ring[0]);
+            mma(ring[0]);
+        }
+    }
+
+    // ---- cross-wave sum, fixed order (w0 + w2) + (w1 + w3), through two LDS planes A / B
+    // (acc reg r -> column-tile row (r&3) + 8*(r>>2) + 4*kh, i.e. output column 4*row + c; lane&31 -> batch row).
+    // Reads are issued 16 at a time (one accumulator vector) so that LDS latency is paid once per vector.
+    float* const planeA = red;
+    float* const planeB = red + 128 * LDM;
+    auto put = [&](float* plane) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    plane[(4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + c) * LDM + mt * 32 + i] = acc[c][mt][r];
+    };
+    auto add = [&](const float* plane) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x16 t;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[r] = plane[(4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + c) * LDM + mt * 32 + i];
+                acc[c][mt] += t;
+            }
+    };
+    if (wave == 2) put(planeA);
+    if (wave == 3) put(planeB);
+    __syncthreads();
+    if (wave == 0) add(planeA);
+    if (wave == 1) { add(planeB); put(planeB); }
+    __syncthreads();
+    if (wave == 0) { add(planeB); put(planeA); }
+    __syncthreads();
+
+    const int M = a.M;
+    float* out;
+    size_t ld;
+    int cbase;
+    if (a.ksplit > 1) {
+        out = a.part + (size_t)kslice * M * a.ntot;
+        ld = (size_t)a.ntot;
+        cbase = sg.slab0 * 128 + n0;          // plane columns are slab-padded: segment s starts at slab0 * 128
+    } else {
+        out = sg.dst;
+        ld = (size_t)sg.ld_dst;
+        cbase = n0;
+    }
+    const int nvalid = sg.ncols - n0 < 128 ? sg.ncols - n0 : 128;
+    for (int u = tid; u < 128 * MT * 32; u += NW * 64) {
+        const int nl = u & 127, m = u >> 7;
+        if (m >= M || nl >= nvalid) continue;
+        out[(size_t)m * ld + cbase + nl] = red[nl * LDM + m];
+    }
+}
+
+// dst[seg][m][n] = sum over planes, fixed order
+__global__ __launch_bounds__(256) void nn_reduce_kernel(NNArgs a) {
+    const int m = blockIdx.y;
+    const int cq = blockIdx.x * 256 + threadIdx.x;       // float4 column index inside the padded plane
+    const int c = cq * 4;
+    if (c >= a.ntot) return;
+    int s = 0;
+    for (int t = 1; t < a.nseg; ++t)
+        if (c >= a.seg[t].slab0 * 128) s = t;
+    const NNSeg sg = a.seg[s];
+    const int n = c - sg.slab0 * 128;
+    if (n >= sg.ncols) return;
+    const float* p = a.part + (size_t)m * a.ntot + c;
+    f32x4 v = ld4(p);
+    for (int k = 1; k < a.ksplit; ++k) v += ld4(p + (size_t)k * a.M * a.ntot);
+    st4(sg.dst + (size_t)m * sg.ld_dst + n, v);
+}
+
+}  // namespace
+
+extern "C" int cvc_linear_nn_fwd(const float* dy_q, int K, int M, const cvc_nn_seg* segs, int nsegs, int ksplit,
+                                 float* workspace, cvc_stream_t stream) {
+    if (!dy_q || !segs || nsegs < 1 || nsegs > NN_MAX_SEG || M < 1 || M > 64 || K < 8 || (K & 7) || ksplit < 1)
+        return CVC_E_BADARG;
+    if (ksplit > K / 8) ksplit = K / 8;
+    NNArgs a{};
+    a.xq = dy_q; a.K = K; a.M = M; a.nseg = nsegs; a.ksplit = ksplit; a.part = workspace;
+    int slab = 0;
+    for (int s = 0; s < nsegs; ++s) {
+        const cvc_nn_seg& g = segs[s];
+        if (!g.w || !g.dst || g.ncols < 4 || (g.ncols & 3) || (g.ldw & 3) || (g.ld_dst & 3) || g.ldw < g.ncols ||
+            g.ld_dst < g.ncols || ((uintptr_t)g.w & 15) || ((uintptr_t)g.dst & 15))
+            return CVC_E_BADARG;
+        a.seg[s].w = g.w; a.seg[s].dst = g.dst; a.seg[s].ldw = g.ldw; a.seg[s].ncols = g.ncols; a.seg[s].ld_dst = g.ld_dst;
+        a.seg[s].slab0 = slab;
+        slab += (g.ncols + 127) / 128;
+    }
+    a.nslab = slab;
+    a.ntot = slab * 128;
+    if (ksplit > 1 && !workspace) return CVC_E_BADARG;
+    const dim3 grid(slab * ksplit);
+    if (M <= 32) hipLaunchKernelGGL((skinny_gemm_nn_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((skinny_gemm_nn_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (ksplit > 1)
+        hipLaunchKernelGGL(nn_reduce_kernel, dim3((a.ntot / 4 + 255) / 256, M), dim3(256), 0, (hipStream_t)stream, a);
+    return cvc_launch_status();
+}

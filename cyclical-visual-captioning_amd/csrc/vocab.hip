@@ -225,7 +225,7 @@ __global__ __launch_bounds__(WG) void nll_logsoftmax_bwd_kernel(const float* log
 // ------------------------------------------------------------------ LSTM pointwise backward
 __global__ __launch_bounds__(WG) void lstm_pointwise_bwd_kernel(const float* d_h, const float* d_c, const float* gates,
                                                                 const float* c_prev, const float* c_new, int M, int R,
-                                                                float* d_gates, float* d_c_prev) {
+                                                                float* d_gates, float* d_c_prev, float* d_gates_q) {
     const int j = blockIdx.x * WG + threadIdx.x;
     const int m = blockIdx.y;
     if (j >= R) return;
@@ -234,11 +234,20 @@ __global__ __launch_bounds__(WG) void lstm_pointwise_bwd_kernel(const float* d_h
     const float tc = tanhf(c_new[o]);
     const float dh = d_h != nullptr ? d_h[o] : 0.f;
     const float dcn = (d_c != nullptr ? d_c[o] : 0.f) + dh * og * (1.f - tc * tc);
-    d_gates[g0] = dcn * gg * ig * (1.f - ig);
-    d_gates[g0 + R] = dcn * c_prev[o] * fg * (1.f - fg);
-    d_gates[g0 + 2 * R] = dcn * ig * (1.f - gg * gg);
-    d_gates[g0 + 3 * R] = dh * tc * og * (1.f - og);
+    const float d0 = dcn * gg * ig * (1.f - ig), d1 = dcn * c_prev[o] * fg * (1.f - fg);
+    const float d2 = dcn * ig * (1.f - gg * gg), d3 = dh * tc * og * (1.f - og);
+    d_gates[g0] = d0;
+    d_gates[g0 + R] = d1;
+    d_gates[g0 + 2 * R] = d2;
+    d_gates[g0 + 3 * R] = d3;
     d_c_prev[o] = dcn * fg;
+    if (d_gates_q != nullptr) {                      // column g*R + j -> quad (g*R + j)/4, element j&3 (R % 4 == 0)
+        const size_t q0 = ((size_t)(j >> 2) * 64 + m) * 4 + (j & 3), qs = (size_t)(R >> 2) * 256;
+        d_gates_q[q0] = d0;
+        d_gates_q[q0 + qs] = d1;
+        d_gates_q[q0 + 2 * qs] = d2;
+        d_gates_q[q0 + 3 * qs] = d3;
+    }
 }
 
 // ------------------------------------------------------------------ beam bookkeeping
@@ -437,10 +446,11 @@ extern "C" int cvc_nll_logsoftmax_bwd(const float* logp, const int64_t* target, 
 
 extern "C" int cvc_lstm_pointwise_bwd(const float* d_h, const float* d_c, const float* gates, const float* c_prev,
                                       const float* c_new, int M, int R, float* d_gates, float* d_c_prev,
-                                      cvc_stream_t stream) {
+                                      float* d_gates_q, cvc_stream_t stream) {
     if (!gates || !c_prev || !c_new || !d_gates || !d_c_prev || M < 1 || R < 1) return CVC_E_BADARG;
+    if (d_gates_q != nullptr && (M > 64 || (R & 3))) return CVC_E_BADARG;
     hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3((R + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, d_h, d_c,
-                       gates, c_prev, c_new, M, R, d_gates, d_c_prev);
+                       gates, c_prev, c_new, M, R, d_gates, d_c_prev, d_gates_q);
     return cvc_launch_status();
 }
 

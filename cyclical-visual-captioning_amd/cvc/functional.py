@@ -156,8 +156,17 @@ class _LstmCell(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_h, d_c):
         w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, c_new, gates, *xs = ctx.saved_tensors
-        d_gates, d_c_prev = hip.lstm_pointwise_bwd(_c(d_h), _c(d_c), gates, c_prev, c_new)
         ni = ctx.needs_input_grad
+        M, K = gates.shape
+        # dX ranges that need a gradient: (weight, first column, width) in the order h_prev, xs...
+        ranges, k0 = ([(w_hh, 0, w_hh.shape[1])] if ni[4] else []), 0
+        for i, x in enumerate(xs):
+            if ni[6 + i]:
+                ranges.append((w_ih, k0, x.shape[1]))
+            k0 += x.shape[1]
+        use_nn = bool(ranges) and hip.linear_nn_ok(M, K, ranges)
+        pw = hip.lstm_pointwise_bwd(_c(d_h), _c(d_c), gates, c_prev, c_new, want_quad=use_nn)
+        d_gates, d_c_prev = pw[0], pw[1]
         d_w_ih = d_w_hh = d_b = None
         if ctx.defer:
             x = torch.cat(xs, 1) if len(xs) > 1 else xs[0]
@@ -176,12 +185,17 @@ class _LstmCell(torch.autograd.Function):
             d_w_ih = torch.mm(d_gates.t(), torch.cat(xs, 1) if len(xs) > 1 else xs[0]) if ni[0] else None
             d_w_hh = torch.mm(d_gates.t(), h_prev) if ni[1] else None
             d_b = d_gates.sum(0) if (ni[2] or ni[3]) else None
-        d_h_prev = torch.mm(d_gates, w_hh) if ni[4] else None
-        d_xs, k0 = [], 0
-        for i, x in enumerate(xs):
-            k = x.shape[1]
-            d_xs.append(torch.mm(d_gates, w_ih[:, k0:k0 + k]) if ni[6 + i] else None)
-            k0 += k
+        if use_nn:                      # every needed dX from one pass over the weights (csrc/gemm_nn.hip)
+            got = iter(hip.linear_nn(pw[2], M, K, ranges))
+            d_h_prev = next(got) if ni[4] else None
+            d_xs = [next(got) if ni[6 + i] else None for i in range(len(xs))]
+        else:                           # widths the kernel does not take (not multiples of 4): library GEMM
+            d_h_prev = torch.mm(d_gates, w_hh) if ni[4] else None
+            d_xs, k0 = [], 0
+            for i, x in enumerate(xs):
+                k = x.shape[1]
+                d_xs.append(torch.mm(d_gates, w_ih[:, k0:k0 + k]) if ni[6 + i] else None)
+                k0 += k
         return (d_w_ih, d_w_hh, d_b if ni[2] else None, d_b if ni[3] else None, d_h_prev,
                 d_c_prev if ni[5] else None, *d_xs)
 

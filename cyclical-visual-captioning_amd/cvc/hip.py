@@ -30,6 +30,10 @@ class GemmSeg(C.Structure):
                 ("k", C.c_int), ("ldx", C.c_int), ("ldw", C.c_int), ("relu", C.c_int)]
 
 
+class NNSeg(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("dst", C.c_void_p), ("ldw", C.c_int), ("ncols", C.c_int), ("ld_dst", C.c_int)]
+
+
 _P, _I, _F = C.c_void_p, C.c_int, C.c_float
 # name -> argtypes, exactly the declarations of include/cvc_hip.h (tests/test_cabi.py checks both)
 SIGNATURES = {
@@ -47,7 +51,8 @@ SIGNATURES = {
     "cvc_linear_fwd": [C.POINTER(GemmSeg), _I, _P, _P, _I, _I, _P, _I, _P],
     "cvc_gemm_force_generic": [_I],
     "cvc_lstm_cell_fwd": [C.POINTER(GemmSeg), _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
-    "cvc_lstm_pointwise_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
+    "cvc_lstm_pointwise_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "cvc_linear_nn_fwd": [_P, _I, _I, C.POINTER(NNSeg), _I, _I, _P, _P],
     "cvc_embed_relu_fwd": [_P, _P, _P, _I, _I, _P, _P],
     "cvc_embed_relu_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P],
     "cvc_log_softmax_fwd": [_P, _I, _I, _P, _P],
@@ -216,13 +221,43 @@ def lstm_cell_fwd(segs: Sequence[dict], b_ih, b_hh, c_prev, want_gates: bool = F
     return h, c, gates
 
 
-def lstm_pointwise_bwd(d_h, d_c, gates, c_prev, c_new):
+def lstm_pointwise_bwd(d_h, d_c, gates, c_prev, c_new, want_quad=False):
+    """-> d_gates [M,4R], d_c_prev [M,R] (+ d_gates in the quad layout [R][64][4] for linear_nn when asked)."""
     M, R = c_prev.shape
     d_gates = torch.empty_like(gates)
     d_c_prev = torch.empty_like(c_prev)
+    d_gates_q = torch.empty(R, 64, 4, device=gates.device, dtype=torch.float32) if want_quad else None
     _check(lib().cvc_lstm_pointwise_bwd(_dev(d_h), _dev(d_c), _dev(gates), _dev(c_prev), _dev(c_new), M, R, _dev(d_gates),
-                                        _dev(d_c_prev), _stream()), "cvc_lstm_pointwise_bwd")
-    return d_gates, d_c_prev
+                                        _dev(d_c_prev), _dev(d_gates_q), _stream()), "cvc_lstm_pointwise_bwd")
+    return (d_gates, d_c_prev, d_gates_q) if want_quad else (d_gates, d_c_prev)
+
+
+def linear_nn_ok(M, K, ranges):
+    """Shapes cvc_linear_nn_fwd accepts (everything else keeps the library GEMM)."""
+    return M <= 64 and K % 8 == 0 and all(
+        n >= 4 and n % 4 == 0 and w.stride(0) % 4 == 0 and w.stride(1) == 1 and c0 % 4 == 0 and w.data_ptr() % 16 == 0
+        for (w, c0, n) in ranges)
+
+
+def linear_nn(dy_q, M, K, ranges, ksplit=None):
+    """dX_s[M, n_s] = dY[M, K] @ W_s[:, c0_s : c0_s + n_s] for every (W_s, c0_s, n_s) in `ranges`, one launch.
+    dy_q: dY in the quad layout [K/4][64][4] (lstm_pointwise_bwd(want_quad=True))."""
+    arr = (NNSeg * len(ranges))()
+    outs, keep = [], []
+    slabs = 0
+    for i, (w, c0, n) in enumerate(ranges):
+        assert w.shape[0] == K and w.is_cuda and w.dtype == torch.float32
+        out = torch.empty(M, n, device=w.device, dtype=torch.float32)
+        arr[i] = NNSeg(w.data_ptr() + 4 * c0, out.data_ptr(), w.stride(0), n, n)
+        outs.append(out)
+        slabs += (n + 127) // 128
+    # K slices: one resident round of workgroups (the kernel fits two per CU = 512 on the chip) and >= 16 8-row
+    # groups per wave in every slice
+    if ksplit is None:
+        ksplit = max(1, min(K // 8 // 64, 512 // slabs))
+    ws = torch.empty(ksplit * M * slabs * 128, device=dy_q.device, dtype=torch.float32) if ksplit > 1 else None
+    _check(lib().cvc_linear_nn_fwd(_dev(dy_q), K, M, arr, len(ranges), ksplit, _dev(ws), _stream()), "cvc_linear_nn_fwd")
+    return outs
 
 
 # --------------------------------------------------------------------------- embedding / vocabulary head

@@ -119,6 +119,8 @@ _BUILD = [
     ("--hip_graph", dict(type=int, default=1)),             # capture the T-step decode loop in a HIP graph
     ("--dist_backend", dict(type=str, default="nccl")),     # "nccl" is RCCL on ROCm; "gloo" for CPU tests
     ("--warm_start_mode", dict(type=str, default="reference")),  # "reference" = suffix/last-wins, "corrected"
+    ("--results_dir", dict(type=str, default="results")),   # where eval writes the densecap / grounding JSON
+    ("--detectron_weights_dir", dict(type=str, default="data/detectron_weights")),  # fc7 / cls_score pickles
 ]
 
 

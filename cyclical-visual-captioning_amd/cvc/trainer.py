@@ -9,6 +9,8 @@ submodules; pass `scorer(predictions, grd_output, opts) -> dict` to get language
 """
 from __future__ import annotations
 
+import json
+import os
 import time
 from collections import defaultdict
 
@@ -174,6 +176,11 @@ class Trainer:
                     vid_idx, seg_idx = b["seg_id"][k].split('_segment_')
                     predictions[vid_idx].append({'sentence': sent, 'segment': str(int(seg_idx))})
         lang_stats = {}
+        self.submission_file = self.attn_file = None
+        if getattr(o, "language_eval", False) and o.val_split != 'hidden_test':
+            self.submission_file = write_densecap_json(predictions, o)
+        if getattr(o, "eval_obj_grounding", False):
+            self.attn_file = write_grounding_json(grd_output, o)
         if self.scorer is not None:
             lang_stats = self.scorer(predictions, grd_output, o) or {}
             if tb_logger:
@@ -204,6 +211,31 @@ class Trainer:
                     res['clss'].append(o.itod[lemma_det[lemma]])
                     res['idx_in_sent'].append(j)
             grd_output[vid_id][str(int(seg_idx))] = res
+
+
+def _results_path(o, stem):
+    d = getattr(o, "results_dir", "results")
+    os.makedirs(d, exist_ok=True)
+    return os.path.join(d, stem + '-' + o.val_split + '-' + o.id + '.json')
+
+
+def write_densecap_json(predictions, o):
+    """The ActivityNet dense-captioning submission file the external scorer reads (trainer.py:279-286)."""
+    path = _results_path(o, 'densecap')
+    with open(path, 'w') as f:
+        json.dump({'version': 'VERSION 1.0', 'results': predictions,
+                   'external_data': {'used': 'true', 'details': 'Visual Genome for Faster R-CNN pre-training'}}, f)
+    return path
+
+
+def write_grounding_json(grd_output, o):
+    """Per-word grounding boxes of the generated sentences for the ANet-Entities scorer (trainer.py:318-329)."""
+    path = _results_path(o, 'attn-gen-sent-results')
+    with open(path, 'w') as f:
+        json.dump({'results': grd_output, 'eval_mode': 'gen',
+                   'external_data': {'used': True,
+                                     'details': 'Object detector pre-trained on Visual Genome on object detection task.'}}, f)
+    return path
 
 
 def build_optimizer(model, opt, capturable: bool = False):

@@ -162,10 +162,26 @@ int cvc_lstm_cell_fwd(const cvc_gemm_seg* segs, int nsegs, const float* b_ih, co
                       float* c_out, float* gates_out, cvc_stream_t stream);
 
 /* LSTM pointwise backward: from d_h, d_c (nullable = 0), saved activated gates [M,4R],
- * c_prev, c_new -> d_gates [M,4R] (pre-activation) and d_c_prev [M,R]. */
+ * c_prev, c_new -> d_gates [M,4R] (pre-activation) and d_c_prev [M,R].  d_gates_q (nullable)
+ * receives a second copy of d_gates in the quad layout [4R/4][64][4] that cvc_linear_nn_fwd reads
+ * (M <= 64, R % 4 == 0 when given). */
 int cvc_lstm_pointwise_bwd(const float* d_h, const float* d_c, const float* gates,
                            const float* c_prev, const float* c_new, int M, int R,
-                           float* d_gates, float* d_c_prev, cvc_stream_t stream);
+                           float* d_gates, float* d_c_prev, float* d_gates_q, cvc_stream_t stream);
+
+/* Backward-data product of the skinny layers, autograd of nn.LSTMCell / nn.Linear
+ * (decoder_core.py:45-50, 59-61, 99-108):  dst_s[M, ncols_s] = dY[M, K] x W_s[K, ncols_s]  for up to 6
+ * column ranges s of row-major weights (the checkpoint layout, K = output rows of the layer), one
+ * launch.  dy_q is dY in the quad layout [K/4][64][4]; M <= 64, K % 8 == 0, ncols / ldw / ld_dst
+ * multiples of 4, pointers 16-byte aligned.  ksplit > 1 splits K over workgroups: workspace must
+ * hold ksplit * M * sum_s(ceil(ncols_s / 128) * 128) floats; the planes are summed in a fixed order. */
+typedef struct cvc_nn_seg {
+    const float* w;      /* first column of the range inside a row-major [K, ldw] matrix */
+    float* dst;          /* [M, ld_dst] */
+    int ldw, ncols, ld_dst;
+} cvc_nn_seg;
+int cvc_linear_nn_fwd(const float* dy_q, int K, int M, const cvc_nn_seg* segs, int nsegs, int ksplit,
+                      float* workspace, cvc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Word embedding and vocabulary head (captioner.py:53-68, 72-76, 266, 415-422).

@@ -12,7 +12,7 @@ from cvc import opts as cvc_opts
 from cvc import synth
 from conftest import GOLDEN
 
-BUILD_ONLY = {"hip_graph", "dist_backend", "warm_start_mode"}
+BUILD_ONLY = {"hip_graph", "dist_backend", "warm_start_mode", "results_dir", "detectron_weights_dir"}
 
 
 @pytest.fixture(scope="module")
@@ -131,3 +131,24 @@ def test_missing_roi_extractor_is_a_loud_error():
     from cvc.model.captioner import DecodeAndGroundCaptionerGVDROI
     with pytest.raises(ValueError, match="roi_extractor"):
         DecodeAndGroundCaptionerGVDROI(make_opts(synth.CONFIGS["tiny"]))
+
+
+def test_eval_output_files_follow_the_reference_layout(tmp_path):
+    """densecap / grounding JSON written by Trainer.eval (reference trainer.py:279-286, 318-329)."""
+    import argparse
+    import json
+    from collections import defaultdict
+    from cvc.trainer import write_densecap_json, write_grounding_json
+    o = argparse.Namespace(results_dir=str(tmp_path / "results"), val_split="validation", id="x1")
+    pred = defaultdict(list)
+    pred["v_abc"].append({"sentence": "a man rides", "segment": "3"})
+    p = write_densecap_json(pred, o)
+    assert p.endswith("results/densecap-validation-x1.json")
+    d = json.load(open(p))
+    assert d["version"] == "VERSION 1.0" and d["results"] == {"v_abc": [{"sentence": "a man rides", "segment": "3"}]}
+    assert d["external_data"] == {"used": "true", "details": "Visual Genome for Faster R-CNN pre-training"}
+    grd = {"v_abc": {"3": {"clss": ["man"], "idx_in_sent": [1], "bbox_for_all_frames": [[[0, 0, 5, 5]]]}}}
+    p = write_grounding_json(grd, o)
+    assert p.endswith("results/attn-gen-sent-results-validation-x1.json")
+    d = json.load(open(p))
+    assert d["eval_mode"] == "gen" and d["results"] == grd and d["external_data"]["used"] is True

@@ -225,6 +225,39 @@ def test_concat_gemm_vs_fp64(dev, lib, M, Nout, ks, gather):
             close(act[:, :R], torch.sigmoid(i_).float(), rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("M,R,widths", [
+    (64, 2048, (2048, 2048, 2048, 1024)),           # lang/att-LSTM of cfg2: h_prev + three input ranges
+    (64, 2048, (2048, 1024)),                       # some inputs need no gradient (pre-extracted fc_feats)
+    (17, 256, (256, 260, 36)),                      # ragged M, widths not multiples of 128
+    (33, 32, (32, 32, 16)),                         # the tiny fixture's shapes: K = 128, one K slice
+    (1, 8, (4,)),                                   # minimum
+])
+def test_backward_data_gemm_vs_fp64(dev, lib, M, R, widths):
+    """cvc_lstm_pointwise_bwd (quad output) -> cvc_linear_nn_fwd: dX ranges of the LSTM cell's backward."""
+    g = torch.Generator(device="cpu").manual_seed(M * 7 + R)
+    K = 4 * R
+    gates = torch.rand(M, K, generator=g).to(dev) * 0.8 + 0.1
+    c_prev, c_new = torch.randn(M, R, generator=g).to(dev), torch.randn(M, R, generator=g).to(dev)
+    d_h, d_c = torch.randn(M, R, generator=g).to(dev), torch.randn(M, R, generator=g).to(dev)
+    d_gates, d_c_prev, dq = lib.lstm_pointwise_bwd(d_h, d_c, gates, c_prev, c_new, want_quad=True)
+    d_gates2, d_c_prev2 = lib.lstm_pointwise_bwd(d_h, d_c, gates, c_prev, c_new)
+    assert torch.equal(d_gates, d_gates2) and torch.equal(d_c_prev, d_c_prev2)
+    assert torch.equal(dq.permute(1, 0, 2).reshape(64, K)[:M], d_gates)          # quad layout = [K/4][64][4]
+    w_hh = (torch.randn(K, widths[0], generator=g) / K ** 0.5).to(dev)
+    w_ih = (torch.randn(K, sum(widths[1:]) + 8, generator=g) / K ** 0.5).to(dev)  # +8: a leading range that is skipped
+    ranges, c0 = [(w_hh, 0, widths[0])], 8
+    for n in widths[1:]:
+        ranges.append((w_ih, c0, n))
+        c0 += n
+    assert lib.linear_nn_ok(M, K, ranges)
+    outs = lib.linear_nn(dq, M, K, ranges)
+    again = lib.linear_nn(dq, M, K, ranges)
+    for (w, c, n), o, o2 in zip(ranges, outs, again):
+        ref = (d_gates.double() @ w[:, c:c + n].double()).float()
+        close(o, ref, rtol=2e-5, atol=2e-5)
+        assert torch.equal(o, o2)                                               # fixed-order K-slice sum
+
+
 # ------------------------------------------------------------------ greedy decode (a8)
 def test_a8_greedy_tiny_golden(tiny, g1):
     from helpers import model_call, tie_aware_seq_equal

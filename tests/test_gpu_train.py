@@ -68,12 +68,15 @@ def test_main_entry_point_one_epoch(tmp_path):
     rc = cvc_main.main(["--no_cfg", "--max_epochs", "1", "--batch_size", "4", "--synthetic_clips", "12", "--num_prop_per_frm", "7",
                         "--t_attn_size", "5", "--rnn_size", "32", "--att_hid_size", "16", "--input_encoding_size", "16",
                         "--seq_length", "4", "--vis_encoding_size", "24", "--tensorboard", "0", "--disp_interval", "100",
-                        "--checkpoint_path", str(tmp_path) + "/", "--exp_name", "t", "--learning_rate", "0.001"])
+                        "--checkpoint_path", str(tmp_path) + "/", "--exp_name", "t", "--learning_rate", "0.001",
+                        "--language_eval", "--results_dir", str(tmp_path / "results"), "--id", "t1"])
     assert rc == 0
+    dense = json.load(open(tmp_path / "results" / "densecap-validation-t1.json"))
+    assert len(dense["results"]) == 12 and all("sentence" in r[0] for r in dense["results"].values())
     sd = torch.load(os.path.join(tmp_path, "t", "model-best.pth"), map_location="cpu")
     ref_keys = set(json.load(open(os.path.join(GOLDEN, "config_surface.json")))["state_dict"])
     assert set(sd.keys()) == ref_keys
-    assert os.path.exists(os.path.join(tmp_path, "t", "infos_-best.pkl"))
+    assert os.path.exists(os.path.join(tmp_path, "t", "infos_t1-best.pkl"))
 
 
 def test_main_entry_point_raw_features_through_encoder(tmp_path):
