@@ -145,6 +145,7 @@ class _LstmCell(torch.autograd.Function):
         segs.append({"x": h_prev, "w": w_hh})
         need_bwd = any(ctx.needs_input_grad)
         h, c, gates = hip.lstm_cell_fwd(segs, b_ih, b_hh, c_prev, want_gates=need_bwd)
+        ctx.set_materialize_grads(False)          # an unused h or c arrives as None, not as a zero-filled tensor
         if need_bwd:
             ctx.save_for_backward(w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, c, gates, *xs)
             ctx.key = ("lstm", w_ih.data_ptr())
@@ -157,6 +158,8 @@ class _LstmCell(torch.autograd.Function):
     def backward(ctx, d_h, d_c):
         w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, c_new, gates, *xs = ctx.saved_tensors
         ni = ctx.needs_input_grad
+        if d_h is None and d_c is None:
+            d_h = torch.zeros_like(c_new)         # (keeps the deferred-weight-gradient use count exact)
         M, K = gates.shape
         # dX ranges that need a gradient: (weight, first column, width) in the order h_prev, xs...
         ranges, k0 = ([(w_hh, 0, w_hh.shape[1])] if ni[4] else []), 0
@@ -169,16 +172,17 @@ class _LstmCell(torch.autograd.Function):
         d_gates, d_c_prev = pw[0], pw[1]
         d_w_ih = d_w_hh = d_b = None
         if ctx.defer:
-            x = torch.cat(xs, 1) if len(xs) > 1 else xs[0]
-
             def flush(items):
+                # one cat per operand over all stashed steps (the input segments are only joined here, once)
                 D = torch.cat([i[0] for i in items], 0) if len(items) > 1 else items[0][0]
-                X = torch.cat([i[1] for i in items], 0) if len(items) > 1 else items[0][1]
-                Hp = torch.cat([i[2] for i in items], 0) if len(items) > 1 else items[0][2]
+                Hp = torch.cat([i[1] for i in items], 0) if len(items) > 1 else items[0][1]
+                nseg = len(items[0]) - 2
+                cols = [torch.cat([i[2 + k] for i in items], 0) if len(items) > 1 else items[0][2 + k] for k in range(nseg)]
+                X = torch.cat(cols, 1) if nseg > 1 else cols[0]
                 db = D.sum(0)
                 return torch.mm(D.t(), X), torch.mm(D.t(), Hp), db, db
 
-            res = _BATCHER.add(ctx.key, (d_gates, x, h_prev), (w_ih, w_hh, b_ih, b_hh), flush)
+            res = _BATCHER.add(ctx.key, (d_gates, h_prev, *xs), (w_ih, w_hh, b_ih, b_hh), flush)
             if res is not None:
                 d_w_ih, d_w_hh, d_b, _ = res
         else:
@@ -225,6 +229,13 @@ class _Attention(torch.autograd.Function):
         ctx.kind, ctx.inv_temp, ctx.nq, ctx.nsets, ctx.nclip = kind, inv_temp, nq, nsets, nclip
         ctx.save_for_backward(q, w_a, *[t for s in sets for t in (s["proj"], s["ctx"])], *[o[2] for o in outs])
         ctx.set_materialize_grads(False)
+        # alpha_net's weight / bias gradients are row sums over every step's partials: defer them like the GEMM weights
+        ctx.defer = bool(kind == hip.ATTN_ADDITIVE and w_a is not None and w_a.requires_grad and b_a is not None
+                         and b_a.requires_grad)
+        ctx.b_a_ref = b_a
+        if ctx.defer:
+            ctx.key = ("attn", w_a.data_ptr())
+            _BATCHER.note_use(ctx.key)
         res = [ctx_sum if nsets > 1 else outs[0][3]]
         non_diff = []
         for (scores, fm, attn, ctx_out) in outs:
@@ -245,6 +256,7 @@ class _Attention(torch.autograd.Function):
         d_w = None
         d_b = None
         d_feats: List[Optional[Tensor]] = []
+        stash_w, stash_b = [], []
         for s in range(nsets):
             d_ctx_s, _d_attn, d_fm = d_outs[3 * s], d_outs[3 * s + 1], d_outs[3 * s + 2]
             d_ctx = d_ctx_s
@@ -262,7 +274,10 @@ class _Attention(torch.autograd.Function):
                 ctx.kind, q, w_flat, ctx.inv_temp, proj, cfeat, attns[s], _c(d_ctx), _c(d_fm), ctx.nclip, ctx.nq,
                 want_dp, want_dc, ni[5])
             d_q = d_q_s if d_q is None else d_q + d_q_s
-            if ctx.kind == hip.ATTN_ADDITIVE:
+            if ctx.kind == hip.ATTN_ADDITIVE and ctx.defer:
+                stash_w.append(d_w_part)
+                stash_b.append(d_scores.reshape(-1))
+            elif ctx.kind == hip.ATTN_ADDITIVE:
                 if ni[5]:
                     dw = d_w_part.sum(0)
                     d_w = dw if d_w is None else d_w + dw
@@ -273,7 +288,16 @@ class _Attention(torch.autograd.Function):
                 d_proj = d_proj + d_cf
                 d_cf = None
             d_feats += [d_proj, d_cf]
-        if d_w is not None:
+        if ctx.kind == hip.ATTN_ADDITIVE and ctx.defer:
+            def flush(items):
+                dw = torch.cat([t for it in items for t in it[0]], 0).sum(0).reshape(w_a.shape)
+                db = torch.cat([t for it in items for t in it[1]], 0).sum().reshape(1)
+                return dw, db
+
+            got = _BATCHER.add(ctx.key, (stash_w, stash_b), (w_a, ctx.b_a_ref), flush)
+            if got is not None:
+                d_w, d_b = got
+        elif d_w is not None:
             d_w = d_w.reshape(w_a.shape)
         return (None, None, None, None, d_q if ni[4] else None, d_w, d_b, *d_feats)
 
