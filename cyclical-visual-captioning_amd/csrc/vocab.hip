@@ -212,14 +212,57 @@ __global__ __launch_bounds__(WG) void nll_fwd_kernel(const float* logp, const in
     if (threadIdx.x == 0) loss_sum[0] += s;
 }
 
-__global__ __launch_bounds__(WG) void nll_logsoftmax_bwd_kernel(const float* logp, const int64_t* target, const float* w,
-                                                                float scale, int V, float* d_logits) {
+// Fused vocabulary criterion: one pass over a row of raw logits gives its log-sum-exp, its argmax (ties -> lowest
+// index, what torch.max over the log-probs returns) and the row's weighted NLL; no [M, V] log-prob matrix is written.
+__global__ __launch_bounds__(WG) void vocab_nll_fwd_kernel(const float* logits, const int64_t* target, const float* w, int V,
+                                                           float* lse_out, int64_t* argmax, float* row_loss) {
+    __shared__ float red[4];
+    __shared__ int ired[4];
+    const int row = blockIdx.x;
+    const float* x = logits + (size_t)row * V;
+    float m = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int v = threadIdx.x; v < V; v += WG) {
+        const float xv = x[v];
+        if (xv > m) { m = xv; mi = v; }                       // ascending v per thread: first occurrence wins
+    }
+    const float bm = block_max(m, red);
+    int cand = m == bm ? mi : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) ired[threadIdx.x >> 6] = cand;
+    __syncthreads();
+    const int best = min(min(ired[0], ired[1]), min(ired[2], ired[3]));
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V; v += WG) s += expf(x[v] - bm);
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        const float lse = bm + logf(s);
+        lse_out[row] = lse;
+        if (argmax != nullptr) argmax[row] = best;
+        const float wm = w[row];
+        row_loss[row] = wm != 0.f ? wm * (lse - x[target[row]]) : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(WG) void row_sum_kernel(const float* row_loss, int M, float* loss_sum) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int m = threadIdx.x; m < M; m += WG) s += row_loss[m];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) loss_sum[0] = s;
+}
+
+// d_logits[m, v] = g[0] * w[m] * (softmax(logits[m])[v] - [v == target[m]])
+__global__ __launch_bounds__(WG) void vocab_nll_bwd_kernel(const float* logits, const float* lse, const int64_t* target,
+                                                           const float* w, const float* g, int V, float* d_logits) {
     const int m = blockIdx.y;
     const int v = blockIdx.x * WG + threadIdx.x;
     if (v >= V) return;
-    const float g = scale * w[m];
+    const float gw = g[0] * w[m];
     const size_t o = (size_t)m * V + v;
-    d_logits[o] = g == 0.f ? 0.f : g * (expf(logp[o]) - (v == (int)target[m] ? 1.f : 0.f));
+    d_logits[o] = gw == 0.f ? 0.f : gw * (expf(logits[o] - lse[m]) - (v == (int)target[m] ? 1.f : 0.f));
 }
 
 // ------------------------------------------------------------------ LSTM pointwise backward
@@ -436,11 +479,20 @@ extern "C" int cvc_nll_fwd(const float* logp, const int64_t* target, const float
     return cvc_launch_status();
 }
 
-extern "C" int cvc_nll_logsoftmax_bwd(const float* logp, const int64_t* target, const float* w, float scale, int M, int V,
-                                      float* d_logits, cvc_stream_t stream) {
-    if (!logp || !target || !w || !d_logits || M < 1 || V < 1) return CVC_E_BADARG;
-    hipLaunchKernelGGL(nll_logsoftmax_bwd_kernel, dim3((V + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, logp,
-                       target, w, scale, V, d_logits);
+extern "C" int cvc_vocab_nll_fwd(const float* logits, const int64_t* target, const float* w, int M, int V, float* lse,
+                                 int64_t* argmax, float* row_loss, float* loss_sum, cvc_stream_t stream) {
+    if (!logits || !target || !w || !lse || !row_loss || !loss_sum || M < 1 || V < 1) return CVC_E_BADARG;
+    hipLaunchKernelGGL(vocab_nll_fwd_kernel, dim3(M), dim3(WG), 0, (hipStream_t)stream, logits, target, w, V, lse, argmax,
+                       row_loss);
+    hipLaunchKernelGGL(row_sum_kernel, dim3(1), dim3(WG), 0, (hipStream_t)stream, row_loss, M, loss_sum);
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_vocab_nll_bwd(const float* logits, const float* lse, const int64_t* target, const float* w,
+                                 const float* g, int M, int V, float* d_logits, cvc_stream_t stream) {
+    if (!logits || !lse || !target || !w || !g || !d_logits || M < 1 || V < 1) return CVC_E_BADARG;
+    hipLaunchKernelGGL(vocab_nll_bwd_kernel, dim3((V + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, logits, lse,
+                       target, w, g, V, d_logits);
     return cvc_launch_status();
 }
 

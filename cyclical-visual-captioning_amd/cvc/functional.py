@@ -382,6 +382,29 @@ def masked_nll_sum(logp: Tensor, target: Tensor, w: Tensor) -> Tensor:
     return _MaskedNLLSum.apply(logp, target.reshape(-1), w.reshape(-1))
 
 
+class _VocabNLL(torch.autograd.Function):
+    """Masked NLL sum + per-row argmax straight from raw logits: log_softmax, the NLL gather and the cycle's
+    argmax cut (captioner.py:266, :313; misc/utils.py:139-146) in one pass, no [M, V] log-prob matrix."""
+
+    @staticmethod
+    def forward(ctx, logits, target, w):
+        logits, target, w = logits.contiguous(), target.contiguous(), w.contiguous()
+        loss, lse, amax = hip.vocab_nll_fwd(logits, target, w)
+        ctx.save_for_backward(logits, lse, target, w)
+        ctx.mark_non_differentiable(amax)
+        return loss, amax
+
+    @staticmethod
+    def backward(ctx, g, _g_amax):
+        logits, lse, target, w = ctx.saved_tensors
+        return hip.vocab_nll_bwd(logits, lse, target, w, g.contiguous().reshape(1)), None, None
+
+
+def vocab_nll(logits: Tensor, target: Tensor, w: Tensor) -> Tuple[Tensor, Tensor]:
+    """-> (sum_m w[m] * -log_softmax(logits)[m, target[m]]  as a [1] tensor,  argmax over V per row [M] int64)."""
+    return _VocabNLL.apply(logits, target.reshape(-1), w.reshape(-1))
+
+
 class _Grounder(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xt, feats, bias, mask):

@@ -60,7 +60,8 @@ SIGNATURES = {
     "cvc_nll_bwd": [_P, _P, _P, _I, _I, _P, _P],
     "cvc_top2_unk": [_P, _I, _I, _I, _P, _I, _P, _P],
     "cvc_nll_fwd": [_P, _P, _P, _I, _I, _P, _P],
-    "cvc_nll_logsoftmax_bwd": [_P, _P, _P, _F, _I, _I, _P, _P],
+    "cvc_vocab_nll_fwd": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P],
+    "cvc_vocab_nll_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P],
     "cvc_grounder_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "cvc_beam_select": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "cvc_gather_rows": [_P, _P, _I, _I, _I, _P, _P],
@@ -313,11 +314,24 @@ def nll_fwd(logp, target, w):
     return loss
 
 
-def nll_logsoftmax_bwd(logp, target, w, scale: float):
-    M, V = logp.shape
-    d = torch.empty_like(logp)
-    _check(lib().cvc_nll_logsoftmax_bwd(_dev(logp), _dev(target, torch.int64), _dev(w), float(scale), M, V, _dev(d),
-                                        _stream()), "cvc_nll_logsoftmax_bwd")
+def vocab_nll_fwd(logits, target, w, want_argmax=True):
+    """-> loss_sum [1], lse [M], argmax [M] int64 (or None)"""
+    M, V = logits.shape
+    dev = logits.device
+    lse = torch.empty(M, device=dev, dtype=torch.float32)
+    row_loss = torch.empty(M, device=dev, dtype=torch.float32)
+    loss = torch.empty(1, device=dev, dtype=torch.float32)
+    amax = torch.empty(M, device=dev, dtype=torch.int64) if want_argmax else None
+    _check(lib().cvc_vocab_nll_fwd(_dev(logits), _dev(target, torch.int64), _dev(w), M, V, _dev(lse), _dev(amax, torch.int64),
+                                   _dev(row_loss), _dev(loss), _stream()), "cvc_vocab_nll_fwd")
+    return loss, lse, amax
+
+
+def vocab_nll_bwd(logits, lse, target, w, g):
+    M, V = logits.shape
+    d = torch.empty_like(logits)
+    _check(lib().cvc_vocab_nll_bwd(_dev(logits), _dev(lse), _dev(target, torch.int64), _dev(w), _dev(g), M, V, _dev(d),
+                                   _stream()), "cvc_vocab_nll_bwd")
     return d
 
 

@@ -53,6 +53,13 @@ def _masked_nll_mean(txt_input, target):
     return (total / count).reshape(())
 
 
+def _masked_nll_mean_from_logits(logits, target):
+    """Same value as _masked_nll_mean(log_softmax(logits), target), plus the per-row argmax, from one fused pass."""
+    w = _text_mask(target).reshape(-1).to(torch.float32)
+    total, argmax = F_.vocab_nll(logits, target.reshape(-1), w)
+    return (total / w.sum()).reshape(()), argmax.view(target.shape)
+
+
 class LMCriterion(nn.Module):
     """reference misc/utils.py:127-172"""
 
@@ -64,6 +71,18 @@ class LMCriterion(nn.Module):
         if not torch.cuda.is_current_stream_capturing():
             assert torch.sum(target >= self.vocab_size) == 0                  # reference :134 (host check; skipped under capture)
         loss = _masked_nll_mean(txt_input, target)
+        return (loss, *self.attention_losses(att2_weights, ground_weights, att2_target))
+
+    def from_logits(self, logits, att2_weights, ground_weights, target, att2_target, input_seq):
+        """forward() fed raw logits instead of log-probs: -> (lm_loss, att2_loss, ground_loss, argmax [B, T]).
+        SURVEY section 8(f) rank 2: the criterion folded into the vocabulary head's epilogue pass."""
+        if not torch.cuda.is_current_stream_capturing():
+            assert torch.sum(target >= self.vocab_size) == 0
+        loss, argmax = _masked_nll_mean_from_logits(logits, target)
+        return (loss, *self.attention_losses(att2_weights, ground_weights, att2_target), argmax)
+
+    @staticmethod
+    def attention_losses(att2_weights, ground_weights, att2_target):
         # supervised attention / grounding losses (w_att2 = 0 by default; SURVEY section 8(f) rank 2).  The reference
         # branches on `att2_target.sum() != 0` and uses masked_select (:150-162); the same value without a host round
         # trip or a data-dependent shape: -sum(log_softmax * target) / max(count, 1), which is 0 when nothing is labelled.
@@ -71,7 +90,7 @@ class LMCriterion(nn.Module):
         count = tgt.sum().clamp(min=1.0)
         att2_loss = (-(F.log_softmax(att2_weights, dim=2) * tgt).sum() / count).reshape(1)
         ground_loss = (-(F.log_softmax(ground_weights, dim=2) * tgt).sum() / count).reshape(1)
-        return loss, att2_loss, ground_loss
+        return att2_loss, ground_loss
 
 
 class LanguageCriterion(nn.Module):
@@ -79,6 +98,9 @@ class LanguageCriterion(nn.Module):
 
     def forward(self, txt_input, target):
         return _masked_nll_mean(txt_input, target)
+
+    def from_logits(self, logits, target):
+        return _masked_nll_mean_from_logits(logits, target)[0]
 
 
 def bbox_overlaps(rois, gt_box, frm_mask):

@@ -112,7 +112,11 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
 
     def _logprobs(self, output):
         """F.log_softmax(self.logit(output), dim=1) (reference :266, :361, :437)"""
-        return F_.log_softmax(F_.linear(output, self.logit.weight, self.logit.bias))
+        return F_.log_softmax(self._logits(output))
+
+    def _logits(self, output):
+        """self.logit(output); the training pass hands these to the fused criteria, which never write log-probs"""
+        return F_.linear(output, self.logit.weight, self.logit.bias)
 
     def _grounder(self, xt, att_feats, mask, bias=None, min_value=-1e8):
         """reference :132-173, dot-product branch (the captioner owns no alpha_net)."""
@@ -186,7 +190,7 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
             outputs.append(output)
             masked_attn.append(frame_masked_attn)
         att2_weights = torch.stack(masked_attn, dim=1)                               # pre-softmax (:273)
-        lang_outputs = self._logprobs(torch.stack(outputs, 1).view(B * T, -1)).view(B, T, -1)   # all T at once
+        lang_logits = self._logits(torch.stack(outputs, 1).view(B * T, -1))          # all T at once, [B*T, V]
 
         # ---- grounder over all T                                                      reference :282-294
         xt_clamp = torch.clamp(input_seq[:, 1:T + 1, 0].clone() - self.vocab_size, min=0)
@@ -199,14 +203,13 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         ground_weights = self._grounder(xt_all, g_pool_feats, frm_mask_output[:, :, 1:], bias + att2_weights)
 
         target = gt_caption[:, 1:T + 1].clone()
+        # criteria fused with log_softmax and the argmax cut of :313 (one pass over the logits, no [B,T,V] log-probs)
+        lm_loss, att2_loss, ground_loss, output_seq = self.critLM.from_logits(
+            lang_logits, att2_weights, ground_weights, target, roi_labels[:, :T, :].clone(), input_seq[:, 1:T + 1, 0].clone())
         if self.opts.train_decoder_only:                                              # reference :297-307
-            lm_loss, att2_loss, ground_loss = self.critLM(lang_outputs.view(-1, lang_outputs.size(2)), att2_weights,
-                                                          ground_weights, target, roi_labels[:, :T, :].clone(),
-                                                          input_seq[:, 1:T + 1, 0].clone())
             return lm_loss.reshape(1), att2_loss.reshape(1), ground_loss.reshape(1), cls_loss.reshape(1)
 
         # ---- argmax cut, Loop B: localize (no recurrence -> all T in one attention call)  :313-338
-        _, output_seq = lang_outputs.max(2)
         loc_emb = self._embed(output_seq)                                            # [B, T, E]
         loc_pool, loc_conv, _prob = self.localizer_core.forward_all_steps(loc_emb, conv_feats, p_conv_feats, pool_feats,
                                                                            p_pool_feats, region_mask)
@@ -219,12 +222,7 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
             output, state = self.attended_roi_decoder_core(emb_all_c[:, t], fc_feats, loc_pool[:, t], loc_conv[:, t],
                                                            state, with_sentinel=False)
             rec_outputs.append(output)
-        consistent_outputs = self._logprobs(torch.stack(rec_outputs, 1).view(B * T, -1))
-
-        lm_loss, att2_loss, ground_loss = self.critLM(lang_outputs.view(-1, lang_outputs.size(2)), att2_weights,
-                                                      ground_weights, target, roi_labels[:, :T, :].clone(),
-                                                      input_seq[:, 1:T + 1, 0].clone())
-        lm_recon_loss = self.xe_criterion(consistent_outputs, target)
+        lm_recon_loss = self.xe_criterion.from_logits(self._logits(torch.stack(rec_outputs, 1).view(B * T, -1)), target)
         return (lm_loss.reshape(1), att2_loss.reshape(1), ground_loss.reshape(1), cls_loss.reshape(1),
                 lm_recon_loss.reshape(1))
 

@@ -209,17 +209,23 @@ int cvc_log_softmax_bwd(const float* logp, const float* d_logp, int M, int V, fl
 int cvc_top2_unk(const float* logits, int M, int V, int unk_idx, int64_t* word, int word_stride,
                  float* logprob, cvc_stream_t stream);
 
-/* Masked NLL over a [M, V] log-prob matrix (misc/utils.py:132-146, 181-192):
- * loss_sum[0] += sum_m w[m] * -logp[m, target[m]];  with d_logits (nullable, [M,V]):
- * d_logits[m, v] = scale * w[m] * (exp(logp[m,v]) - [v == target[m]]) -- the fused
- * log_softmax+NLL backward. */
+/* Masked NLL over a [M, V] log-prob matrix (misc/utils.py:132-146, 181-192), the module-level
+ * criterion API that receives log-probs:  loss_sum[0] += sum_m w[m] * -logp[m, target[m]]. */
 int cvc_nll_fwd(const float* logp, const int64_t* target, const float* w, int M, int V,
                 float* loss_sum, cvc_stream_t stream);
 /* d_logp[m, v] = -w[m] * g[0] at v == target[m], else 0 (g: device scalar upstream gradient) */
 int cvc_nll_bwd(const int64_t* target, const float* w, const float* g, int M, int V, float* d_logp,
                 cvc_stream_t stream);
-int cvc_nll_logsoftmax_bwd(const float* logp, const int64_t* target, const float* w, float scale,
-                           int M, int V, float* d_logits, cvc_stream_t stream);
+
+/* Fused vocabulary criterion (captioner.py:266 + :313 + misc/utils.py:132-146, 181-192) straight from raw
+ * logits [M, V], no log-prob matrix: lse[m] = logsumexp(logits[m]); argmax[m] (nullable; ties -> lowest
+ * index) for the cycle's argmax cut; row_loss[m] = w[m] * (lse[m] - logits[m, target[m]]);
+ * loss_sum[0] = sum_m row_loss[m] in a fixed order.  Backward:
+ * d_logits[m, v] = g[0] * w[m] * (exp(logits[m, v] - lse[m]) - [v == target[m]])  (g: device scalar). */
+int cvc_vocab_nll_fwd(const float* logits, const int64_t* target, const float* w, int M, int V,
+                      float* lse, int64_t* argmax, float* row_loss, float* loss_sum, cvc_stream_t stream);
+int cvc_vocab_nll_bwd(const float* logits, const float* lse, const int64_t* target, const float* w,
+                      const float* g, int M, int V, float* d_logits, cvc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Grounder (captioner.py:132-173, dot-product branch): out[b,t,n] = xt[b,t,:] . feats[b,n,:]

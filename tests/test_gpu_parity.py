@@ -258,6 +258,29 @@ def test_backward_data_gemm_vs_fp64(dev, lib, M, R, widths):
         assert torch.equal(o, o2)                                               # fixed-order K-slice sum
 
 
+@pytest.mark.parametrize("M,V", [(1280, 5000), (7, 50), (1, 3)])
+def test_fused_vocab_criterion_vs_torch(dev, lib, M, V):
+    """cvc_vocab_nll_fwd/bwd == log_softmax -> masked NLL sum -> argmax, and its autograd (fp64 reference)."""
+    from cvc import functional as F_
+    g = torch.Generator(device="cpu").manual_seed(M + V)
+    logits = (torch.randn(M, V, generator=g) * 3).to(dev)
+    logits[0, min(5, V - 1)] = logits[0, 1] = logits[0].max() + 1                  # an exact tie: lowest index wins
+    target = torch.randint(0, V, (M,), generator=g).to(dev)
+    w = (torch.rand(M, generator=g) < 0.7).float().to(dev)
+    x = logits.clone().requires_grad_(True)
+    loss, amax = F_.vocab_nll(x, target, w)
+    (loss * 0.37).sum().backward()
+    xr = logits.double().requires_grad_(True)
+    lp = torch.log_softmax(xr, 1)
+    ref = -(lp.gather(1, target[:, None]).squeeze(1) * w.double()).sum()
+    (ref * 0.37).backward()
+    close(loss, ref.float().reshape(1), rtol=2e-6 * max(M, 8), atol=1e-5)
+    assert torch.equal(amax, lp.max(1)[1]) and int(amax[0]) == 1
+    close(x.grad, xr.grad.float(), rtol=2e-5, atol=2e-6)
+    loss2, amax2 = F_.vocab_nll(logits, target, w)
+    assert torch.equal(loss2, loss.detach()) and torch.equal(amax2, amax)           # fixed-order row sum
+
+
 # ------------------------------------------------------------------ greedy decode (a8)
 def test_a8_greedy_tiny_golden(tiny, g1):
     from helpers import model_call, tie_aware_seq_equal
