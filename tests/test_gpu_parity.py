@@ -496,7 +496,7 @@ def test_dot_product_decoder_variant(g1, dev, lib):
     close(att, att_o, **SEQ_TOL)
 
 
-@pytest.mark.parametrize("B,N,F", [(1, 1, 1), (33, 50, 17), (63, 129, 5), (64, 1000, 64), (5, 3, 300)])
+@pytest.mark.parametrize("B,N,F", [(1, 1, 1), (33, 50, 17), (63, 129, 5), (64, 1000, 64), (5, 3, 300), (65, 9, 4), (150, 20, 7)])
 def test_decode_ragged_batch_and_region_counts(dev, lib, B, N, F):
     """Edge shapes of the packed decode path (M < 64 padding, one / two MFMA row tiles, a single region, N beyond
     one softmax pass per thread) vs the CPU oracle; R = 64, A = E = 32 keep the oracle fast."""
@@ -509,7 +509,7 @@ def test_decode_ragged_batch_and_region_counts(dev, lib, B, N, F):
     with torch.no_grad():
         seq_o, att_o, _, logp_o = O.greedy_sample(O.to_torch(sd), O.to_torch(f_np), d.T, synth.UNK_IDX, return_logprobs=True)
     eng = DecodeEngine(DecodeWeights(to_dev(sd, dev)), to_dev(f_np, dev), d.T, synth.UNK_IDX)
-    assert eng.packed
+    assert eng.packed == (B <= 64)          # more than 64 clips per GPU: the row-major path (any M), same results
     seq, att = eng.run()
     n_exact = tie_aware_seq_equal(seq.cpu().numpy(), seq_o.numpy(), logp_o.numpy())
     assert n_exact >= 0.95 * B * d.T
