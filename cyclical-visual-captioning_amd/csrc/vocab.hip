@@ -377,7 +377,6 @@ __global__ __launch_bounds__(64) void beam_merge_kernel(const float* cand_v, con
             // -inf fillers at distinct low flat indices so that tie-breaking matches a full scan
             cv = r == 0 ? sc : -INFINITY;
             flat = k * V + r;
-            if (r > 0) flat = k * V + (r == 0 ? 0 : r);
         } else {
             const float v = cand_v[row * BEAM_MAX + r];
             const int vi = cand_i[row * BEAM_MAX + r];

@@ -281,6 +281,48 @@ def test_fused_vocab_criterion_vs_torch(dev, lib, M, V):
     assert torch.equal(loss2, loss.detach()) and torch.equal(amax2, amax)           # fixed-order row sum
 
 
+@pytest.mark.parametrize("B,beam,V,first", [(64, 5, 5000, False), (3, 2, 50, True), (7, 8, 97, False), (1, 1, 9, True)])
+def test_beam_bookkeeping_ops_vs_bruteforce(dev, lib, B, beam, V, first):
+    """cvc_beam_select / cvc_gather_rows / cvc_top2_unk against a full scan in torch fp64."""
+    g = torch.Generator(device="cpu").manual_seed(B * 100 + beam)
+    rows, unk = B * beam, 1
+    logits = (torch.randn(rows, V, generator=g) * 2).to(dev)
+    score = torch.randn(rows, generator=g).to(dev)
+    done = (torch.rand(rows, generator=g) < 0.2).to(dev)
+    if first:
+        done[:] = False
+    parent, word, new_score, new_done = lib.beam_select(logits, score, done.to(torch.uint8), B, beam, unk, first)
+    lp = torch.log_softmax(logits.double(), 1)
+    cand = score.double().view(B, beam, 1) + lp.view(B, beam, V)
+    cand[:, :, unk] = -float("inf")
+    frozen = torch.full_like(cand, -float("inf"))
+    frozen[:, :, 0] = score.double().view(B, beam)
+    cand = torch.where(done.view(B, beam, 1), frozen, cand)
+    if first:
+        cand[:, 1:] = -float("inf")
+    top_v, top_i = torch.sort(cand.view(B, beam * V), dim=1, descending=True, stable=True)
+    top_v, top_i = top_v[:, :beam], top_i[:, :beam]
+    live = torch.isfinite(top_v)                       # fewer live candidates than `beam`: the fillers are unspecified
+    assert torch.equal(parent.view(B, beam)[live], (top_i // V)[live])
+    assert torch.equal(word.view(B, beam)[live], (top_i % V)[live])
+    close(new_score.view(B, beam)[live], top_v[live].float(), rtol=1e-5, atol=1e-5)
+    want_done = done.view(B, beam).gather(1, (top_i // V)) | ((top_i % V) == 0)
+    assert torch.equal(new_done.view(B, beam).bool()[live], want_done[live])
+    # reorder the recurrent state by parent
+    state = torch.randn(rows, 64, generator=g).to(dev)
+    moved = lib.gather_rows(state, parent, beam)
+    src = (torch.arange(rows, device=dev) // beam) * beam + parent
+    assert torch.equal(moved, state[src])
+    # greedy top-2 with the UNK rule
+    words = torch.empty(rows, dtype=torch.int64, device=dev)
+    logp = torch.empty(rows, dtype=torch.float32, device=dev)
+    lib.top2_unk(logits, unk, words, 1, logp)
+    masked = lp.clone()
+    masked[:, unk] = -float("inf")
+    assert torch.equal(words, masked.max(1)[1])
+    close(logp, masked.max(1)[0].float(), rtol=1e-5, atol=1e-5)
+
+
 # ------------------------------------------------------------------ greedy decode (a8)
 def test_a8_greedy_tiny_golden(tiny, g1):
     from helpers import model_call, tie_aware_seq_equal
