@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from .distributed import GradReducer
+from .prefetch import DevicePrefetcher
 from .misc import utils
 from .misc.utils import AverageMeter
 
@@ -49,8 +50,8 @@ class Trainer:
             bboxs, box_mask = _trim(bboxs, n_box), _trim(box_mask, n_box, 2)
             frm_mask = _trim(_trim(frm_mask, n_prop), n_box, 2)
         dev = self.device
-        to = lambda x: x.to(dev) if isinstance(x, torch.Tensor) else x
-        seg = {k: to(v) for k, v in seg_feat.items()} if isinstance(seg_feat, dict) else seg_feat.float().to(dev)
+        to = lambda x: x.to(dev, non_blocking=True) if isinstance(x, torch.Tensor) else x   # async from pinned memory
+        seg = {k: to(v) for k, v in seg_feat.items()} if isinstance(seg_feat, dict) else to(seg_feat).float()
         mask_ppls = to(ppl_mask)
         pnt_mask = torch.cat((mask_ppls.new_zeros(mask_ppls.size(0), 1), mask_ppls), dim=1)
         return dict(segs_feat=seg, input_seqs=to(iseq), gt_seqs=to(gts_seq), num=to(num), ppls=to(proposals),
@@ -72,7 +73,10 @@ class Trainer:
         return loss, lm_loss, att2_loss, cls_loss, lm_recon
 
     def train_step(self, batch):
-        b = self._prepare(batch, True)
+        return self.train_step_prepared(self._prepare(batch, True))
+
+    def train_step_prepared(self, b):
+        """One optimisation step on a batch that already is on the device (see cvc.prefetch.DevicePrefetcher)."""
         if self.opts.att_model != 'cyclical':
             raise ValueError('Unknown att_model: {}'.format(self.opts.att_model))
         out = self._call(b)
@@ -131,15 +135,17 @@ class Trainer:
     def train(self, epoch, tb_logger=None):
         meters = {k: AverageMeter() for k in ("batch", "data", "lm", "attn", "cls", "recon")}
         self.model.train()
-        it = iter(self.train_loader)
         end = time.time()
         n_steps = len(self.train_loader) - 1                 # the reference drops the last batch (:55)
-        for step in range(n_steps):
+        # batch k+1 is staged into HBM on a side stream while step k runs
+        batches = DevicePrefetcher(self.train_loader, lambda raw: self._prepare(raw, True), self.device, limit=n_steps)
+        for step, b in enumerate(batches):
             meters["data"].update(time.time() - end)
-            _, lm, att2, cls, rec = self.train_step(next(it))
+            _, lm, att2, cls, rec = self.train_step_prepared(b)
             n = self.opts.batch_size * self.opts.seq_per_img
-            meters["lm"].update(lm.item(), n); meters["attn"].update(att2.item(), n)
-            meters["cls"].update(cls.item(), n); meters["recon"].update(rec.item(), n)
+            lm_v, att2_v, cls_v, rec_v = torch.stack([lm, att2, cls, rec]).tolist()      # one host sync per step
+            meters["lm"].update(lm_v, n); meters["attn"].update(att2_v, n)
+            meters["cls"].update(cls_v, n); meters["recon"].update(rec_v, n)
             meters["batch"].update(time.time() - end)
             end = time.time()
             if step % self.opts.disp_interval == 0:

@@ -97,6 +97,23 @@ def test_main_entry_point_raw_features_through_encoder(tmp_path):
         assert k in sd, k
 
 
+def test_device_prefetcher_preserves_order_and_contents():
+    """cvc.prefetch.DevicePrefetcher: same batches, same order, tensors usable on the current stream."""
+    from cvc.prefetch import DevicePrefetcher
+    dev = torch.device("cuda:0")
+    batches = [({"a": torch.full((256, 1024), float(i)), "ids": ["s%d" % i]}, torch.arange(4) + i, "tag%d" % i) for i in range(5)]
+    seen = []
+
+    def prepare(raw):
+        assert raw[0]["a"].is_pinned() and raw[1].is_pinned()
+        return {"a": raw[0]["a"].to(dev, non_blocking=True), "ids": raw[0]["ids"], "n": raw[1].to(dev, non_blocking=True),
+                "tag": raw[2]}
+    for i, b in enumerate(DevicePrefetcher(batches, prepare, dev, limit=4)):
+        assert b["tag"] == "tag%d" % i and b["ids"] == ["s%d" % i]
+        seen.append((float((b["a"] * 2).sum()), b["n"].tolist()))
+    assert seen == [(2.0 * i * 256 * 1024, [i, i + 1, i + 2, i + 3]) for i in range(4)]
+
+
 def test_graphed_train_step_equals_eager():
     """Trainer.train_step_graphed (whole step in one HIP graph) reproduces the eager step sequence (dropout off so that
     both are deterministic; the graphed path runs 3 warm-up steps before capture)."""
