@@ -558,6 +558,7 @@ int launch(const GemmArgs& a, int blocks, bool fast, hipStream_t st) {
 }
 
 int g_force_generic = 0;   // test hook: cvc_gemm_force_generic(1) routes everything to the direct-load kernel
+int g_packed_split = 1;    // packed path: fp32 products as 3-way bf16 splits on the bf16 MFMA (cvc_gemm_packed_split)
 
 }  // namespace
 
@@ -634,6 +635,12 @@ extern "C" int cvc_lstm_cell_fwd(const cvc_gemm_seg* segs, int nsegs, const floa
     return 0;
 }
 
+extern "C" int cvc_gemm_packed_split(int on) {
+    const int prev = g_packed_split;
+    g_packed_split = on ? 1 : 0;
+    return prev;
+}
+
 extern "C" int cvc_gemm_force_generic(int on) {
     const int prev = g_force_generic;
     g_force_generic = on ? 1 : 0;
@@ -684,7 +691,41 @@ struct PFrag {
     f32x4 x[MT][4];
 };
 
-template <int MT, bool LSTM, int DEPTH>
+// ---- fp32 products on the bf16 matrix pipe (16x the fp32 MFMA rate), without giving up fp32 accuracy:
+// every fp32 operand is split EXACTLY into three bf16 terms, v = hi + mid + lo (8 + 8 + 8 mantissa bits, by
+// truncation, so both remainders are exact fp32 subtractions), and a product w*x is taken as the six leading
+// cross terms  hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid  (each exact in the fp32 accumulator's
+// product width); the three dropped terms are below 2^-23 |w x|, i.e. at the level of one fp32 rounding.
+// 6 bf16 MFMAs (32 cycles each, K = 16) replace 8 fp32 MFMAs (64 cycles each, K = 2): 0.375x the matrix time,
+// paid for with ~4.5 VALU ops per operand element for the split.
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+struct Split3 { u32x4 hi, mid, lo; };       // 8 bf16 each: element e of quad a -> slot e, of quad b -> slot 4 + e
+
+__device__ __forceinline__ Split3 split8(const f32x4 a, const f32x4 b) {
+    Split3 r;
+    const f32x2 v[4] = {{a.x, a.y}, {a.z, a.w}, {b.x, b.y}, {b.z, b.w}};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const u32x2 u0 = __builtin_bit_cast(u32x2, v[p]);
+        const f32x2 r1 = v[p] - __builtin_bit_cast(f32x2, u0 & 0xffff0000u);
+        const u32x2 u1 = __builtin_bit_cast(u32x2, r1);
+        const f32x2 r2 = r1 - __builtin_bit_cast(f32x2, u1 & 0xffff0000u);
+        const u32x2 u2 = __builtin_bit_cast(u32x2, r2);
+        r.hi[p] = __builtin_amdgcn_perm(u0.y, u0.x, 0x07060302u);     // {top 16 bits of .y, top 16 bits of .x}
+        r.mid[p] = __builtin_amdgcn_perm(u1.y, u1.x, 0x07060302u);
+        r.lo[p] = __builtin_amdgcn_perm(u2.y, u2.x, 0x07060302u);
+    }
+    return r;
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int MT, bool LSTM, int DEPTH, bool SPLIT>
 __global__ __launch_bounds__(256) void skinny_gemm_packed_kernel(PackedArgs a) {
     constexpr int NW = 4;
     constexpr int LDM = MT * 32 + 1;
@@ -745,13 +786,31 @@ __global__ __launch_bounds__(256) void skinny_gemm_packed_kernel(PackedArgs a) {
         }
         return;
 #endif
+        if constexpr (SPLIT) {
+            // the lane half's 4 quads = 16 k-slots = two K=16 steps (quads 2s, 2s+1); W and X use the same slot map
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const Split3 W = split8(f.w[2 * s2], f.w[2 * s2 + 1]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int mt = 0; mt < MT; ++mt) {
+                    const Split3 X = split8(f.x[mt][2 * s2], f.x[mt][2 * s2 + 1]);
+                    acc[mt] = mfma_bf16(W.mid, X.mid, acc[mt]);
+                    acc[mt] = mfma_bf16(W.lo, X.hi, acc[mt]);
+                    acc[mt] = mfma_bf16(W.hi, X.lo, acc[mt]);
+                    acc[mt] = mfma_bf16(W.mid, X.hi, acc[mt]);
+                    acc[mt] = mfma_bf16(W.hi, X.mid, acc[mt]);
+                    acc[mt] = mfma_bf16(W.hi, X.hi, acc[mt]);
+                }
+            }
+        } else {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w[q][e], f.x[mt][q][e], acc[mt], 0, 0, 0);
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w[q][e], f.x[mt][q][e], acc[mt], 0, 0, 0);
+        }
     };
 
     // register ring, DEPTH chunks in flight; fully unrolled so that every fragment is statically named.
@@ -770,11 +829,20 @@ __global__ __launch_bounds__(256) void skinny_gemm_packed_kernel(PackedArgs a) {
             for (int s = 0; s < DEPTH; ++s) {
                 load(ring[(s + DEPTH - 1) % DEPTH], j + s + DEPTH - 1);
                 mma(ring[s]);
+                if constexpr (SPLIT) {
 #pragma unroll
-                for (int g = 0; g < 4 + 4 * MT; ++g) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU (addresses)
+                    for (int g = 0; g < 4 + 4 * MT; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x002, 18, 0);  // VALU (operand split + addresses)
+                        __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);  // MFMA (12 * MT per slot)
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4 + 4 * MT; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU (addresses)
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -899,8 +967,13 @@ template <bool LSTM>
 static int launch_packed(const PackedArgs& a, int blocks, hipStream_t st) {
     if (a.M < 1 || a.M > 64 || (a.nquad & 7) || a.nquad < 8) return CVC_E_BADARG;
     const dim3 grid(blocks, LSTM || a.ksplit < 1 ? 1 : a.ksplit);
-    if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_packed_kernel<1, LSTM, CVC_PACKED_DEPTH>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, LSTM, CVC_PACKED_DEPTH>), grid, dim3(256), 0, st, a);
+    if (g_packed_split) {
+        if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_packed_kernel<1, LSTM, CVC_PACKED_DEPTH, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, LSTM, CVC_PACKED_DEPTH, true>), grid, dim3(256), 0, st, a);
+    } else {
+        if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_packed_kernel<1, LSTM, CVC_PACKED_DEPTH, false>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, LSTM, CVC_PACKED_DEPTH, false>), grid, dim3(256), 0, st, a);
+    }
     return cvc_launch_status();
 }
 

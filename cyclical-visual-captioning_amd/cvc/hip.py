@@ -50,6 +50,7 @@ SIGNATURES = {
     "cvc_attn_bwd": [_I, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "cvc_linear_fwd": [C.POINTER(GemmSeg), _I, _P, _P, _I, _I, _P, _I, _P],
     "cvc_gemm_force_generic": [_I],
+    "cvc_gemm_packed_split": [_I],
     "cvc_lstm_cell_fwd": [C.POINTER(GemmSeg), _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "cvc_lstm_pointwise_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "cvc_linear_nn_fwd": [_P, _I, _I, C.POINTER(NNSeg), _I, _I, _P, _P],
@@ -204,6 +205,11 @@ def linear_fwd(segs: Sequence[dict], bias: Optional[torch.Tensor], M: int, Nout:
     _check(lib().cvc_linear_fwd(arr, len(segs), _dev(bias), _dev(bias2), M, Nout, _dev(y), y.stride(0), _stream()),
            "cvc_linear_fwd")
     return y
+
+
+def gemm_packed_split(on: bool) -> bool:
+    """Packed decode GEMMs: bf16x3-split products on the bf16 MFMA (default) vs plain fp32 MFMA.  -> previous setting"""
+    return bool(lib().cvc_gemm_packed_split(1 if on else 0))
 
 
 def gemm_force_generic(on: bool) -> bool:

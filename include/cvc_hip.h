@@ -145,6 +145,11 @@ int cvc_packed_lstm_fwd(const float* wp, const float* xq, int K, const float* b_
 int cvc_packed_linear_fwd(const float* wp, const float* xq, int K, const float* bias, int M, int Nout,
                           int ksplit, float* y, int ldy, float* top2_part, cvc_stream_t stream);
 
+/* Packed path arithmetic: 1 (default) = every fp32 operand split exactly into three bf16 terms and each
+ * product taken as its six leading cross terms on the bf16 MFMA (fp32 accumulate; dropped terms < 2^-23
+ * relative, the level of one fp32 rounding), 0 = plain fp32 MFMA.  Returns the previous setting. */
+int cvc_gemm_packed_split(int on);
+
 /* Test hook: route every concat-GEMM to the generic direct-load kernel (on != 0) instead of the
  * LDS-DMA fast path that is taken when all segment widths are multiples of 128.  Returns the
  * previous setting.  Both kernels compute the same sums in different k-orders. */
