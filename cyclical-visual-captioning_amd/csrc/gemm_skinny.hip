@@ -558,7 +558,7 @@ int launch(const GemmArgs& a, int blocks, bool fast, hipStream_t st) {
 }
 
 int g_force_generic = 0;   // test hook: cvc_gemm_force_generic(1) routes everything to the direct-load kernel
-int g_packed_split = 1;    // packed path: fp32 products as 3-way bf16 splits on the bf16 MFMA (cvc_gemm_packed_split)
+int g_packed_split = 2;    // packed path: 0 fp32 MFMA, 1 / 2 = products as 3-way bf16 splits on the bf16 MFMA with 4 / 8 waves
 
 }  // namespace
 
@@ -637,7 +637,7 @@ extern "C" int cvc_lstm_cell_fwd(const cvc_gemm_seg* segs, int nsegs, const floa
 
 extern "C" int cvc_gemm_packed_split(int on) {
     const int prev = g_packed_split;
-    g_packed_split = on ? 1 : 0;
+    g_packed_split = on < 0 ? 0 : (on > 2 ? 2 : on);
     return prev;
 }
 
@@ -725,11 +725,24 @@ __device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const 
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-template <int MT, bool LSTM, int DEPTH, bool SPLIT>
-__global__ __launch_bounds__(256) void skinny_gemm_packed_kernel(PackedArgs a) {
-    constexpr int NW = 4;
+// NW waves split K (chunk c goes to wave c % NW).  NW = 8 puts two waves on every SIMD, each with a shallower
+// ring: while one waits on HBM the other multiplies -- the split-product variant needs that, its compute per
+// chunk being too short for one wave's ring to cover the memory latency.
+template <int NW>
+__device__ __forceinline__ float sum_partials(const float* red, int row, int ldm, int m) {
+    float v = (red[(0 * 32 + row) * ldm + m] + red[(1 * 32 + row) * ldm + m]) +
+              (red[(2 * 32 + row) * ldm + m] + red[(3 * 32 + row) * ldm + m]);
+    if constexpr (NW == 8)
+        v += (red[(4 * 32 + row) * ldm + m] + red[(5 * 32 + row) * ldm + m]) +
+             (red[(6 * 32 + row) * ldm + m] + red[(7 * 32 + row) * ldm + m]);
+    return v;
+}
+
+template <int MT, bool LSTM, int DEPTH, bool SPLIT, int NW>
+__global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs a) {
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     constexpr int LDM = MT * 32 + 1;
-    __shared__ float red[NW * 32 * LDM + 4 * 64 * 6];
+    __shared__ float red[NW * 32 * LDM + NW * 64 * 6];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, kh = lane >> 5;
@@ -889,8 +902,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_packed_kernel(PackedArgs a) {
                 float pre[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    float v = (red[(0 * 32 + g * 8 + jj) * LDM + m] + red[(1 * 32 + g * 8 + jj) * LDM + m]) +
-                              (red[(2 * 32 + g * 8 + jj) * LDM + m] + red[(3 * 32 + g * 8 + jj) * LDM + m]);
+                    float v = sum_partials<NW>(red, g * 8 + jj, LDM, m);
                     if (a.bias != nullptr) v += a.bias[g * R + j];
                     if (a.bias2 != nullptr) v += a.bias2[g * R + j];
                     if (a.gate_bias != nullptr) v += a.gate_bias[(size_t)m * 4 * R + g * R + j];
@@ -915,8 +927,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_packed_kernel(PackedArgs a) {
                 const int nl = u & 31, m = u >> 5;
                 const int n = n0 + nl;
                 if (m >= M || n >= a.Nout) continue;
-                float v = (red[(0 * 32 + nl) * LDM + m] + red[(1 * 32 + nl) * LDM + m]) +
-                          (red[(2 * 32 + nl) * LDM + m] + red[(3 * 32 + nl) * LDM + m]);
+                float v = sum_partials<NW>(red, nl, LDM, m);
                 if (lead && a.bias != nullptr) v += a.bias[n];
                 y[(size_t)m * a.ldy + n] = v;
             }
@@ -926,11 +937,11 @@ __global__ __launch_bounds__(256) void skinny_gemm_packed_kernel(PackedArgs a) {
             float v1 = -__builtin_inff(), v2 = -__builtin_inff(), mx = -__builtin_inff(), se = 0.f;
             int i1 = 0x7fffffff, i2 = 0x7fffffff;
             const int m = lane < MT * 32 ? lane : MT * 32 - 1;
-            for (int nl = wave * 8; nl < wave * 8 + 8; ++nl) {
+            constexpr int CPW = 32 / NW;                          // columns scanned per wave
+            for (int nl = wave * CPW; nl < wave * CPW + CPW; ++nl) {
                 const int n = n0 + nl;
                 if (n >= a.Nout) break;
-                float v = (red[(0 * 32 + nl) * LDM + m] + red[(1 * 32 + nl) * LDM + m]) +
-                          (red[(2 * 32 + nl) * LDM + m] + red[(3 * 32 + nl) * LDM + m]);
+                float v = sum_partials<NW>(red, nl, LDM, m);
                 if (a.bias != nullptr) v += a.bias[n];
                 if (v > v1) { v2 = v1; i2 = i1; v1 = v; i1 = n; }
                 else if (v > v2) { v2 = v; i2 = n; }
@@ -942,7 +953,7 @@ __global__ __launch_bounds__(256) void skinny_gemm_packed_kernel(PackedArgs a) {
             r4[0] = v1; r4[1] = __int_as_float(i1); r4[2] = v2; r4[3] = __int_as_float(i2); r4[4] = mx; r4[5] = se;
             __syncthreads();
             if (wave == 0 && lane < M) {
-                for (int w = 1; w < 4; ++w) {
+                for (int w = 1; w < NW; ++w) {
                     const float* q4 = scratch + ((size_t)w * 64 + lane) * 6;
                     const float u1 = q4[0], u2 = q4[2];
                     const int k1 = __float_as_int(q4[1]), k2 = __float_as_int(q4[3]);
@@ -962,17 +973,23 @@ __global__ __launch_bounds__(256) void skinny_gemm_packed_kernel(PackedArgs a) {
 #ifndef CVC_PACKED_DEPTH
 #define CVC_PACKED_DEPTH 4
 #endif
+#ifndef CVC_PACKED_DEPTH8
+#define CVC_PACKED_DEPTH8 3
+#endif
 
 template <bool LSTM>
 static int launch_packed(const PackedArgs& a, int blocks, hipStream_t st) {
     if (a.M < 1 || a.M > 64 || (a.nquad & 7) || a.nquad < 8) return CVC_E_BADARG;
     const dim3 grid(blocks, LSTM || a.ksplit < 1 ? 1 : a.ksplit);
-    if (g_packed_split) {
-        if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_packed_kernel<1, LSTM, CVC_PACKED_DEPTH, true>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, LSTM, CVC_PACKED_DEPTH, true>), grid, dim3(256), 0, st, a);
+    if (g_packed_split == 2) {            // split products, 8 waves (2 per SIMD), ring depth CVC_PACKED_DEPTH8
+        if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_packed_kernel<1, LSTM, CVC_PACKED_DEPTH8, true, 8>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, LSTM, CVC_PACKED_DEPTH8, true, 8>), grid, dim3(512), 0, st, a);
+    } else if (g_packed_split) {
+        if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_packed_kernel<1, LSTM, CVC_PACKED_DEPTH, true, 4>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, LSTM, CVC_PACKED_DEPTH, true, 4>), grid, dim3(256), 0, st, a);
     } else {
-        if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_packed_kernel<1, LSTM, CVC_PACKED_DEPTH, false>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, LSTM, CVC_PACKED_DEPTH, false>), grid, dim3(256), 0, st, a);
+        if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_packed_kernel<1, LSTM, CVC_PACKED_DEPTH, false, 4>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, LSTM, CVC_PACKED_DEPTH, false, 4>), grid, dim3(256), 0, st, a);
     }
     return cvc_launch_status();
 }

@@ -207,9 +207,10 @@ def linear_fwd(segs: Sequence[dict], bias: Optional[torch.Tensor], M: int, Nout:
     return y
 
 
-def gemm_packed_split(on: bool) -> bool:
-    """Packed decode GEMMs: bf16x3-split products on the bf16 MFMA (default) vs plain fp32 MFMA.  -> previous setting"""
-    return bool(lib().cvc_gemm_packed_split(1 if on else 0))
+def gemm_packed_split(mode: int) -> int:
+    """Packed decode GEMMs: 0 = plain fp32 MFMA, 1 = bf16x3-split products on the bf16 MFMA with 4 waves per
+    workgroup, 2 = the same with 8 waves (two per SIMD).  -> previous setting"""
+    return int(lib().cvc_gemm_packed_split(int(mode)))
 
 
 def gemm_force_generic(on: bool) -> bool:

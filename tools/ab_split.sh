@@ -5,7 +5,7 @@ for flags in "$@"; do
   export CVC_EXTRA_HIPCC_FLAGS="$flags"
   python cyclical-visual-captioning_amd/build_hip.py --force > /dev/null 2>&1
   echo "== flags='$flags'"
-  python tools/bench_split.py 2>/dev/null | cut -c1-200
+  python tools/bench_split.py 2>/dev/null | cut -c1-260
 done
 export CVC_EXTRA_HIPCC_FLAGS=""
 python cyclical-visual-captioning_amd/build_hip.py --force > /dev/null 2>&1

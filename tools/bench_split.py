@@ -39,7 +39,7 @@ def main():
         y = torch.empty(M, N, device=dev)
         ref = x.double() @ w.double().t() + b.double()
         line = "%-16s M=%d K=%d N=%d:" % (name, M, K, N)
-        for mode, label in ((0, "fp32"), (3, "bf16x6"), (1, "bf16x6+msplit")):
+        for mode, label in ((0, "fp32"), (1, "bf16x6/4w"), (2, "bf16x6/8w")):
             hip.lib().cvc_gemm_packed_split(mode)
             run = lambda: L.cvc_packed_linear_fwd(wp.data_ptr(), xq.data_ptr(), K, b.data_ptr(), M, N, 1, y.data_ptr(), N, None, st)
             run()
