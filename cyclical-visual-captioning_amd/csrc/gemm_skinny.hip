@@ -637,7 +637,7 @@ extern "C" int cvc_lstm_cell_fwd(const cvc_gemm_seg* segs, int nsegs, const floa
 
 extern "C" int cvc_gemm_packed_split(int on) {
     const int prev = g_packed_split;
-    g_packed_split = on < 0 ? 0 : (on > 2 ? 2 : on);
+    if (on >= 0) g_packed_split = on > 2 ? 2 : on;       // negative: query only
     return prev;
 }
 
@@ -778,6 +778,9 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f.w[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + q * 128));
+#if defined(CVC_PABL) && CVC_PABL == 3
+            if (j > 0) continue;                                     // ablation: stream the weights only
+#endif
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) f.x[mt][q] = ld4(x + q * 256 + mt * 128);
         }
@@ -790,7 +793,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
     auto mma = [&](const PFrag<MT>& f) __attribute__((always_inline)) {
-#if defined(CVC_PABL) && CVC_PABL == 2
+#if defined(CVC_PABL) && CVC_PABL >= 2
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                               // ablation: memory side only, keep the loads live
             asm volatile("" ::"v"(f.w[q]));

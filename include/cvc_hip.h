@@ -145,10 +145,12 @@ int cvc_packed_lstm_fwd(const float* wp, const float* xq, int K, const float* b_
 int cvc_packed_linear_fwd(const float* wp, const float* xq, int K, const float* bias, int M, int Nout,
                           int ksplit, float* y, int ldy, float* top2_part, cvc_stream_t stream);
 
-/* Packed path arithmetic: 1 (default) = every fp32 operand split exactly into three bf16 terms and each
- * product taken as its six leading cross terms on the bf16 MFMA (fp32 accumulate; dropped terms < 2^-23
- * relative, the level of one fp32 rounding), 0 = plain fp32 MFMA.  Returns the previous setting. */
-int cvc_gemm_packed_split(int on);
+/* Packed path arithmetic.  mode 2 (default) / 1: every fp32 operand is split exactly into three bf16 terms
+ * (v = hi + mid + lo) and each product taken as its six leading cross terms on the bf16 MFMA, fp32
+ * accumulate -- the dropped terms are < 2^-23 relative, the level of one fp32 rounding (measured error
+ * against fp64 is slightly BELOW the fp32-MFMA path's); 8 (mode 2) or 4 (mode 1) waves per workgroup.
+ * mode 0: plain fp32 MFMA.  A negative mode only queries.  Returns the previous mode. */
+int cvc_gemm_packed_split(int mode);
 
 /* Test hook: route every concat-GEMM to the generic direct-load kernel (on != 0) instead of the
  * LDS-DMA fast path that is taken when all segment widths are multiples of 128.  Returns the

@@ -323,6 +323,37 @@ def test_beam_bookkeeping_ops_vs_bruteforce(dev, lib, B, beam, V, first):
     close(logp, masked.max(1)[0].float(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("M,K,N", [(64, 6144, 8192), (64, 2048, 5000), (17, 256, 96)])
+def test_split_product_gemm_is_fp32_grade(dev, lib, M, K, N):
+    """The packed GEMM's default arithmetic (every fp32 operand split exactly into three bf16 terms, six cross
+    products on the bf16 MFMA, fp32 accumulate) must be as close to the fp64 result as the plain fp32-MFMA path:
+    rms and max error no worse than 1.25x, on operands with mixed magnitudes."""
+    from cvc.decode import pack_weights, to_quad
+    g = torch.Generator(device="cpu").manual_seed(K + N)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    x = torch.randn(M, K, generator=g).to(dev)
+    x[:, ::7] *= 1e-3
+    x[:, 3::11] *= 64.0
+    b = torch.randn(N, generator=g).to(dev)
+    wp, xq = pack_weights(w), to_quad(x)
+    ref = x.double() @ w.double().t() + b.double()
+    st = torch.cuda.current_stream().cuda_stream
+    err = {}
+    prev = lib.gemm_packed_split(-1)
+    try:
+        for mode in (0, 1, 2):
+            lib.gemm_packed_split(mode)
+            y = torch.empty(M, N, device=dev)
+            assert lib.lib().cvc_packed_linear_fwd(wp.data_ptr(), xq.data_ptr(), K, b.data_ptr(), M, N, 1, y.data_ptr(), N, None, st) == 0
+            e = (y.double() - ref).abs()
+            err[mode] = (e.pow(2).mean().sqrt().item(), e.max().item())
+            assert err[mode][0] <= 1e-6 * ref.pow(2).mean().sqrt().item(), (mode, err[mode])   # ~1e-7 relative rms in practice
+    finally:
+        lib.gemm_packed_split(prev)
+    for mode in (1, 2):
+        assert err[mode][0] <= 1.25 * err[0][0] and err[mode][1] <= 1.25 * err[0][1], err
+
+
 # ------------------------------------------------------------------ greedy decode (a8)
 def test_a8_greedy_tiny_golden(tiny, g1):
     from helpers import model_call, tie_aware_seq_equal
