@@ -326,7 +326,41 @@ struct RFrag {
     f32x4 x[MT][2];
 };
 
-template <int MT, bool LSTM>
+// ---- fp32 products on the bf16 matrix pipe (16x the fp32 MFMA rate), without giving up fp32 accuracy:
+// every fp32 operand is split EXACTLY into three bf16 terms, v = hi + mid + lo (8 + 8 + 8 mantissa bits, by
+// truncation, so both remainders are exact fp32 subtractions), and a product w*x is taken as the six leading
+// cross terms  hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid  (each exact in the fp32 accumulator's
+// product width); the three dropped terms are below 2^-23 |w x|, i.e. at the level of one fp32 rounding.
+// 6 bf16 MFMAs (32 cycles each, K = 16) replace 8 fp32 MFMAs (64 cycles each, K = 2): 0.375x the matrix time,
+// paid for with ~4.5 VALU ops per operand element for the split.
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+struct Split3 { u32x4 hi, mid, lo; };       // 8 bf16 each: element e of quad a -> slot e, of quad b -> slot 4 + e
+
+__device__ __forceinline__ Split3 split8(const f32x4 a, const f32x4 b) {
+    Split3 r;
+    const f32x2 v[4] = {{a.x, a.y}, {a.z, a.w}, {b.x, b.y}, {b.z, b.w}};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const u32x2 u0 = __builtin_bit_cast(u32x2, v[p]);
+        const f32x2 r1 = v[p] - __builtin_bit_cast(f32x2, u0 & 0xffff0000u);
+        const u32x2 u1 = __builtin_bit_cast(u32x2, r1);
+        const f32x2 r2 = r1 - __builtin_bit_cast(f32x2, u1 & 0xffff0000u);
+        const u32x2 u2 = __builtin_bit_cast(u32x2, r2);
+        r.hi[p] = __builtin_amdgcn_perm(u0.y, u0.x, 0x07060302u);     // {top 16 bits of .y, top 16 bits of .x}
+        r.mid[p] = __builtin_amdgcn_perm(u1.y, u1.x, 0x07060302u);
+        r.lo[p] = __builtin_amdgcn_perm(u2.y, u2.x, 0x07060302u);
+    }
+    return r;
+}
+
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int MT, bool LSTM, bool SPLIT>
 __global__ __launch_bounds__(256) void skinny_gemm_ring_kernel(GemmArgs a) {
     constexpr int NW = 4;
     constexpr int ROWS = 32 + MT * 32;
@@ -389,16 +423,39 @@ __global__ __launch_bounds__(256) void skinny_gemm_ring_kernel(GemmArgs a) {
             }
         return;
 #endif
+        if constexpr (SPLIT) {
+            // products as exact 3-way bf16 splits on the bf16 MFMA (see split8): quads (h, 0), (h, 1) = one K=16 step
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h) {
+                const Split3 W = split8(f[h].w[0], f[h].w[1]);
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
+                for (int mt = 0; mt < MT; ++mt) {
+                    f32x4 x0 = f[h].x[mt][0], x1 = f[h].x[mt][1];
+                    if (RELU) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                        for (int e = 0; e < 4; ++e) { x0[e] = fmaxf(x0[e], 0.f); x1[e] = fmaxf(x1[e], 0.f); }
+                    }
+                    const Split3 X = split8(x0, x1);
+                    acc[mt] = mfma_bf16(W.mid, X.mid, acc[mt]);
+                    acc[mt] = mfma_bf16(W.lo, X.hi, acc[mt]);
+                    acc[mt] = mfma_bf16(W.hi, X.lo, acc[mt]);
+                    acc[mt] = mfma_bf16(W.mid, X.hi, acc[mt]);
+                    acc[mt] = mfma_bf16(W.hi, X.mid, acc[mt]);
+                    acc[mt] = mfma_bf16(W.hi, X.hi, acc[mt]);
+                }
+            }
+        } else {
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[h].w[p][e], RELU ? fmaxf(f[h].x[mt][p][e], 0.f) : f[h].x[mt][p][e],
-                                                                       acc[mt], 0, 0, 0);
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[h].w[p][e], RELU ? fmaxf(f[h].x[mt][p][e], 0.f) : f[h].x[mt][p][e],
+                                                                           acc[mt], 0, 0, 0);
+        }
     };
 
     // ---- K loop: segment by segment (the decode engine passes ONE pre-concatenated segment, so the
@@ -457,17 +514,32 @@ __global__ __launch_bounds__(256) void skinny_gemm_ring_kernel(GemmArgs a) {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
                 read_frags(nxt, (c + 1) % RING);
                 mma(cur, relu_tag);
+                if constexpr (SPLIT) {                                   // 12 MT MFMAs, ~108 MT split VALU ops, 2 NLOAD memory ops
     #pragma unroll
-                for (int q = 0; q < NLOAD; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
-                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (LDS-DMA)
-                }
+                    for (int q = 0; q < NLOAD; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);   // VALU (operand split)
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (LDS-DMA)
+                    }
     #pragma unroll
-                for (int q = 0; q < NLOAD; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
+                    for (int q = 0; q < NLOAD; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);   // VALU
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                    }
+                } else {
+    #pragma unroll
+                    for (int q = 0; q < NLOAD; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (LDS-DMA)
+                    }
+    #pragma unroll
+                    for (int q = 0; q < NLOAD; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU
+                    }
                 }
             };
 
@@ -543,13 +615,20 @@ bool fast_ok(const cvc_gemm_seg* segs, int nsegs, int Nout_rows) {
     return gathers <= 1;
 }
 
+// 0 = fp32 MFMA; 1 / 2 = products as exact 3-way bf16 splits on the bf16 MFMA (cvc_gemm_packed_split), the packed
+// kernel then running 4 / 8 waves per workgroup; the row-major ring kernel uses the split for any non-zero mode
+int g_packed_split = 2;
+
 template <bool LSTM>
 int launch(const GemmArgs& a, int blocks, bool fast, hipStream_t st) {
     if (a.M > 64) return CVC_E_TOOBIG;
     const dim3 grid(blocks, LSTM || a.ksplit < 1 ? 1 : a.ksplit);
-    if (fast) {
-        if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_ring_kernel<1, LSTM>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((skinny_gemm_ring_kernel<2, LSTM>), grid, dim3(256), 0, st, a);
+    if (fast && g_packed_split) {
+        if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_ring_kernel<1, LSTM, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((skinny_gemm_ring_kernel<2, LSTM, true>), grid, dim3(256), 0, st, a);
+    } else if (fast) {
+        if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_ring_kernel<1, LSTM, false>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((skinny_gemm_ring_kernel<2, LSTM, false>), grid, dim3(256), 0, st, a);
     } else {
         if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_kernel<1, 8, LSTM>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((skinny_gemm_kernel<2, 8, LSTM>), grid, dim3(512), 0, st, a);
@@ -558,7 +637,6 @@ int launch(const GemmArgs& a, int blocks, bool fast, hipStream_t st) {
 }
 
 int g_force_generic = 0;   // test hook: cvc_gemm_force_generic(1) routes everything to the direct-load kernel
-int g_packed_split = 2;    // packed path: 0 fp32 MFMA, 1 / 2 = products as 3-way bf16 splits on the bf16 MFMA with 4 / 8 waves
 
 }  // namespace
 
@@ -690,40 +768,6 @@ struct PFrag {
     f32x4 w[4];
     f32x4 x[MT][4];
 };
-
-// ---- fp32 products on the bf16 matrix pipe (16x the fp32 MFMA rate), without giving up fp32 accuracy:
-// every fp32 operand is split EXACTLY into three bf16 terms, v = hi + mid + lo (8 + 8 + 8 mantissa bits, by
-// truncation, so both remainders are exact fp32 subtractions), and a product w*x is taken as the six leading
-// cross terms  hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid  (each exact in the fp32 accumulator's
-// product width); the three dropped terms are below 2^-23 |w x|, i.e. at the level of one fp32 rounding.
-// 6 bf16 MFMAs (32 cycles each, K = 16) replace 8 fp32 MFMAs (64 cycles each, K = 2): 0.375x the matrix time,
-// paid for with ~4.5 VALU ops per operand element for the split.
-using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-using f32x2 = __attribute__((ext_vector_type(2))) float;
-using u32x2 = __attribute__((ext_vector_type(2))) unsigned;
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-struct Split3 { u32x4 hi, mid, lo; };       // 8 bf16 each: element e of quad a -> slot e, of quad b -> slot 4 + e
-
-__device__ __forceinline__ Split3 split8(const f32x4 a, const f32x4 b) {
-    Split3 r;
-    const f32x2 v[4] = {{a.x, a.y}, {a.z, a.w}, {b.x, b.y}, {b.z, b.w}};
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const u32x2 u0 = __builtin_bit_cast(u32x2, v[p]);
-        const f32x2 r1 = v[p] - __builtin_bit_cast(f32x2, u0 & 0xffff0000u);
-        const u32x2 u1 = __builtin_bit_cast(u32x2, r1);
-        const f32x2 r2 = r1 - __builtin_bit_cast(f32x2, u1 & 0xffff0000u);
-        const u32x2 u2 = __builtin_bit_cast(u32x2, r2);
-        r.hi[p] = __builtin_amdgcn_perm(u0.y, u0.x, 0x07060302u);     // {top 16 bits of .y, top 16 bits of .x}
-        r.mid[p] = __builtin_amdgcn_perm(u1.y, u1.x, 0x07060302u);
-        r.lo[p] = __builtin_amdgcn_perm(u2.y, u2.x, 0x07060302u);
-    }
-    return r;
-}
-
-__device__ __forceinline__ f32x16 mfma_bf16(const u32x4 a, const u32x4 b, const f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
 
 // NW waves split K (chunk c goes to wave c % NW).  NW = 8 puts two waves on every SIMD, each with a shallower
 // ring: while one waits on HBM the other multiplies -- the split-product variant needs that, its compute per
