@@ -818,7 +818,11 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
         int jr = j + rot;
         jr = jr >= n_my ? jr - n_my : jr;
         const float* w = wl + (size_t)jr * WSTEP;
+#if defined(CVC_PABL) && CVC_PABL == 4
+        const float* x = a.xq + (size_t)i * 4 + kh * 4 * 256;     // ablation: every wave re-reads ONE activation chunk (L1 hits)
+#else
         const float* x = xl + (size_t)jr * XSTEP;
+#endif
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f.w[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + q * 128));
