@@ -78,17 +78,24 @@ __global__ __launch_bounds__(WG) void attn_wsum_kernel(WsumArgs a) {
 
         const float* C = S.ctx + (size_t)clip * n * R + col;
         f32x4 acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-        if (col_ok) {
+        // the large set (frames) is streamed non-temporally, the small one (regions) may stay in the Infinity Cache
+        auto accumulate = [&](auto stream_tag) __attribute__((always_inline)) {
+            constexpr bool STREAM = decltype(stream_tag)::value;
+#define LDF(ptr) (STREAM ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ptr)) : ld4(ptr))
             int i = wave;
             for (; i + 12 < n; i += 16) {
-                f32x4 c0 = ld4(C + (size_t)i * R), c1 = ld4(C + (size_t)(i + 4) * R);
-                f32x4 c2 = ld4(C + (size_t)(i + 8) * R), c3 = ld4(C + (size_t)(i + 12) * R);
+                f32x4 c0 = LDF(C + (size_t)i * R), c1 = LDF(C + (size_t)(i + 4) * R);
+                f32x4 c2 = LDF(C + (size_t)(i + 8) * R), c3 = LDF(C + (size_t)(i + 12) * R);
                 acc0 += a_s[i] * c0;
                 acc1 += a_s[i + 4] * c1;
                 acc2 += a_s[i + 8] * c2;
                 acc3 += a_s[i + 12] * c3;
             }
-            for (; i < n; i += 4) acc0 += a_s[i] * ld4(C + (size_t)i * R);
+            for (; i < n; i += 4) acc0 += a_s[i] * LDF(C + (size_t)i * R);
+#undef LDF
+        };
+        if (col_ok) {
+            if (n >= CVC_FEAT_STREAM_MIN_N) accumulate(std::true_type{}); else accumulate(std::false_type{});
         }
         part[wave * 64 + lane] = (acc0 + acc1) + (acc2 + acc3);
         __syncthreads();

@@ -2,6 +2,11 @@
 // the same streaming dot product) and the grounder (captioner.py:154-158).  See attn_fwd.hip.
 #pragma once
 #include "cvc_common.h"
+#include <type_traits>
+
+#ifndef CVC_FEAT_STREAM_MIN_N
+#define CVC_FEAT_STREAM_MIN_N 256   // feature sets with at least this many rows per clip are streamed (nt)
+#endif
 
 namespace {
 
@@ -52,13 +57,18 @@ __global__ __launch_bounds__(SCORE_WG) void attn_scores_kernel(ScoreArgs a) {
     const int row_end = min(n, row0 + ROWS_PER_WG);
     const float* P = S.proj + (size_t)clip * n * A;
 
+    // feature rows of the LARGE set (frames) are streamed with the non-temporal policy; the small set (regions) keeps
+    // the default one so that it can stay in the 256 MB Infinity Cache from one decode step to the next
+    auto rows = [&](auto stream_tag) __attribute__((always_inline)) {
+        constexpr bool STREAM = decltype(stream_tag)::value;
+#define LDF(ptr) (STREAM ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ptr)) : ld4(ptr))
     f32x4 cur[NCH], nxt[NCH];
     int r = row0 + wave;
     if (r < row_end) {
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             int col = (j * 64 + lane) * 4;
-            cur[j] = col < A ? ld4(P + (size_t)r * A + col) : f32x4{0, 0, 0, 0};
+            cur[j] = col < A ? LDF(P + (size_t)r * A + col) : f32x4{0, 0, 0, 0};
         }
     }
     for (; r < row_end; r += 4) {
@@ -67,7 +77,7 @@ __global__ __launch_bounds__(SCORE_WG) void attn_scores_kernel(ScoreArgs a) {
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
                 int col = (j * 64 + lane) * 4;
-                nxt[j] = col < A ? ld4(P + (size_t)rn * A + col) : f32x4{0, 0, 0, 0};
+                nxt[j] = col < A ? LDF(P + (size_t)rn * A + col) : f32x4{0, 0, 0, 0};
             }
         }
         const bool masked = S.mask != nullptr && S.mask[(size_t)clip * n + r] != 0;
@@ -103,6 +113,9 @@ __global__ __launch_bounds__(SCORE_WG) void attn_scores_kernel(ScoreArgs a) {
 #pragma unroll
         for (int j = 0; j < NCH; ++j) cur[j] = nxt[j];
     }
+#undef LDF
+    };
+    if (n >= CVC_FEAT_STREAM_MIN_N) rows(std::true_type{}); else rows(std::false_type{});
 }
 
 template <int KIND>
