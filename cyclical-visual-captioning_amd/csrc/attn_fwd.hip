@@ -78,7 +78,7 @@ __global__ __launch_bounds__(WG) void attn_wsum_kernel(WsumArgs a) {
 
         const float* C = S.ctx + (size_t)clip * n * R + col;
         f32x4 acc0 = {0, 0, 0, 0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-        // the large set (frames) is streamed non-temporally, the small one (regions) may stay in the Infinity Cache
+        // a set marked `stream` (bit 1) is read non-temporally, see attn_scores.h
         auto accumulate = [&](auto stream_tag) __attribute__((always_inline)) {
             constexpr bool STREAM = decltype(stream_tag)::value;
 #define LDF(ptr) (STREAM ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ptr)) : ld4(ptr))
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(WG) void attn_wsum_kernel(WsumArgs a) {
 #undef LDF
         };
         if (col_ok) {
-            if (n >= CVC_FEAT_STREAM_MIN_N) accumulate(std::true_type{}); else accumulate(std::false_type{});
+            if (S.stream & 2) accumulate(std::true_type{}); else accumulate(std::false_type{});
         }
         part[wave * 64 + lane] = (acc0 + acc1) + (acc2 + acc3);
         __syncthreads();

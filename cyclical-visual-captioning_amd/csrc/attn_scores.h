@@ -4,10 +4,6 @@
 #include "cvc_common.h"
 #include <type_traits>
 
-#ifndef CVC_FEAT_STREAM_MIN_N
-#define CVC_FEAT_STREAM_MIN_N 256   // feature sets with at least this many rows per clip are streamed (nt)
-#endif
-
 namespace {
 
 #ifndef CVC_SCORE_ROWS
@@ -57,8 +53,8 @@ __global__ __launch_bounds__(SCORE_WG) void attn_scores_kernel(ScoreArgs a) {
     const int row_end = min(n, row0 + ROWS_PER_WG);
     const float* P = S.proj + (size_t)clip * n * A;
 
-    // feature rows of the LARGE set (frames) are streamed with the non-temporal policy; the small set (regions) keeps
-    // the default one so that it can stay in the 256 MB Infinity Cache from one decode step to the next
+    // a set marked `stream` is read with the non-temporal policy so that it does not displace what the decode loop
+    // re-reads every step from the 256 MB Infinity Cache (the caller budgets that: cvc/decode.py)
     auto rows = [&](auto stream_tag) __attribute__((always_inline)) {
         constexpr bool STREAM = decltype(stream_tag)::value;
 #define LDF(ptr) (STREAM ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ptr)) : ld4(ptr))
@@ -115,7 +111,7 @@ __global__ __launch_bounds__(SCORE_WG) void attn_scores_kernel(ScoreArgs a) {
     }
 #undef LDF
     };
-    if (n >= CVC_FEAT_STREAM_MIN_N) rows(std::true_type{}); else rows(std::false_type{});
+    if (S.stream & 1) rows(std::true_type{}); else rows(std::false_type{});
 }
 
 template <int KIND>

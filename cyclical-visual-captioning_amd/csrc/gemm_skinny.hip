@@ -763,6 +763,10 @@ struct PackedArgs {
     float* top2_part;
 };
 
+#ifndef CVC_LIN_W_NT
+#define CVC_LIN_W_NT 0      // 1: also stream the linear layers' weights non-temporally (A/B switch)
+#endif
+
 template <int MT>
 struct PFrag {
     f32x4 w[4];
@@ -827,7 +831,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
         for (int q = 0; q < 4; ++q) {
             // gate weights (369 MB per step) are streamed; the small linear layers' weights (vocabulary head, h2attn:
             // 49 MB) keep the default policy so that they can stay in the Infinity Cache between steps
-            if constexpr (LSTM) f.w[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + q * 128));
+            if constexpr (LSTM || CVC_LIN_W_NT) f.w[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + q * 128));
             else f.w[q] = ld4(w + q * 128);
 #if defined(CVC_PABL) && CVC_PABL == 3
             if (j > 0) continue;                                     // ablation: stream the weights only

@@ -22,7 +22,7 @@ ATTN_ADDITIVE, ATTN_DOT = 0, 1
 class AttnSet(C.Structure):
     _fields_ = [("proj", C.c_void_p), ("ctx", C.c_void_p), ("mask", C.c_void_p), ("frame_mask", C.c_void_p),
                 ("scores", C.c_void_p), ("frame_masked", C.c_void_p), ("attn", C.c_void_p), ("ctx_out", C.c_void_p),
-                ("n", C.c_int)]
+                ("n", C.c_int), ("stream", C.c_int)]
 
 
 class GemmSeg(C.Structure):

@@ -51,6 +51,9 @@ typedef struct {
     float* attn;                /* [rows, n]  out: softmax over n                                */
     float* ctx_out;             /* [rows, R]  out: sum_n attn * ctx, or NULL                     */
     int n;
+    int stream;                 /* cache policy of the feature reads: bit 0 = proj, bit 1 = ctx read with
+                                 * non-temporal loads (a stream that should not displace what is re-read
+                                 * every step from the 256 MB Infinity Cache); 0 = default, cacheable      */
 } cvc_attn_set;
 
 /* q [rows, A] is h2attn(h) (bias included).  kind ADDITIVE: s = w_a . tanh(proj_n + q) + b_a[0]

@@ -92,3 +92,15 @@ def test_yaml_overlay_semantics():
     got = copy.deepcopy(base)
     update_values(over, got)
     assert got == {"a": 1, "b": {"c": 7, "d": 3}, "e": 0}           # None keeps the old value, nested dicts recurse
+
+
+def test_cache_plan_keeps_the_largest_subset_that_fits():
+    """cvc.decode.cache_plan: which per-step feature streams stay cacheable in the 256 MiB Infinity Cache."""
+    from cvc.decode import cache_plan
+    cfg2 = {"ppool": 26214400, "pconv": 125829120, "pool": 52428800, "conv": 251658240}
+    assert cache_plan(int(49.2e6), cfg2) == {"ppool": True, "pconv": True, "pool": False, "conv": False}
+    cfg5 = {"ppool": 157286400, "pconv": 251658240, "pool": 314572800, "conv": 503316480}
+    assert not any(cache_plan(int(116e6), cfg5).values())                      # nothing fits: everything streams
+    assert all(cache_plan(1000, {"ppool": 100, "pconv": 100, "pool": 100, "conv": 100}).values())
+    plan = cache_plan(0, cfg2, budget=100 << 20)
+    assert sum(cfg2[k] for k, v in plan.items() if v) == 26214400 + 52428800   # best fit under 100 MiB
