@@ -99,6 +99,11 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         z = torch.zeros(num_layers, batch_size, self.rnn_size, device=self.device)
         return (z, z.clone())
 
+    def _init_step_state(self, batch_size):
+        """init_hidden() as the unstacked (h_att, c_att, h_lang, c_lang) the cores' step() takes"""
+        z = torch.zeros(4, batch_size, self.rnn_size, device=self.device)
+        return tuple(z.unbind(0))
+
     def _embed(self, word):
         """embed = Embedding -> ReLU -> Dropout (reference :53-68); lookup+ReLU(+mask) is one kernel."""
         drop_p = self.embed[2].p if (self.training and len(self.embed) > 2) else 0.0
@@ -180,13 +185,16 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         step_fmask = frm_mask_output[:, :, 1:].permute(1, 0, 2).contiguous()           # [T, B, N]
 
         # ---- Loop A: teacher-forced decode (sequential: LSTM recurrence)            reference :242-270
-        state = self.init_hidden(B, self.decoder_num_layers)
+        state = self._init_step_state(B)
         emb_all = self._embed(gt_caption[:, :T])                                     # [B, T, E], one launch
         outputs, masked_attn = [], []
+        # one unbind per tensor instead of T selects: a select's backward is a zero-filled [B, T, E] tensor plus an
+        # accumulation per step, unbind's is a single stack
+        emb_steps = emb_all.unbind(1)
         for t in range(T):
-            output, state, _roi_attn, frame_masked_attn, _wp = self.decoder_core(
-                emb_all[:, t], fc_feats, conv_feats, p_conv_feats, pool_feats, p_pool_feats, region_mask, state,
-                proposal_frame_mask=step_fmask[t], with_sentinel=False)
+            output, state, _roi_attn, frame_masked_attn, _wp = self.decoder_core.step(
+                emb_steps[t], fc_feats, conv_feats, p_conv_feats, pool_feats, p_pool_feats, region_mask, state,
+                proposal_frame_mask=step_fmask[t])
             outputs.append(output)
             masked_attn.append(frame_masked_attn)
         att2_weights = torch.stack(masked_attn, dim=1)                               # pre-softmax (:273)
@@ -215,12 +223,12 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
                                                                            p_pool_feats, region_mask)
 
         # ---- Loop C: reconstruct from the localized regions (sequential)             reference :348-362
-        state = self.init_hidden(B, self.decoder_num_layers)
+        state = self._init_step_state(B)
         emb_all_c = self._embed(gt_caption[:, :T]) if self.training else emb_all      # fresh dropout mask in training
         rec_outputs = []
+        emb_steps_c, pool_steps, conv_steps = emb_all_c.unbind(1), loc_pool.unbind(1), loc_conv.unbind(1)
         for t in range(T):
-            output, state = self.attended_roi_decoder_core(emb_all_c[:, t], fc_feats, loc_pool[:, t], loc_conv[:, t],
-                                                           state, with_sentinel=False)
+            output, state = self.attended_roi_decoder_core.step(emb_steps_c[t], fc_feats, pool_steps[t], conv_steps[t], state)
             rec_outputs.append(output)
         lm_recon_loss = self.xe_criterion.from_logits(self._logits(torch.stack(rec_outputs, 1).view(B * T, -1)), target)
         return (lm_loss.reshape(1), att2_loss.reshape(1), ground_loss.reshape(1), cls_loss.reshape(1),

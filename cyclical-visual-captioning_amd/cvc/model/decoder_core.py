@@ -34,19 +34,29 @@ class TopDownDecoderCore(nn.Module):
 
     def forward(self, embedded_word, fc_feats, conv_feats, p_conv_feats, pool_feats, p_pool_feats, pnt_mask,
                 state, proposal_frame_mask=None, with_sentinel=False):
+        """The reference's call: state = (h [2, B, R], c [2, B, R]) in and out (layer 0 = attention LSTM, 1 = language LSTM)."""
         if with_sentinel:
             raise NotImplementedError("with_sentinel=True is not part of the caption-decode hot path")
-        prev_h = state[0][-1]                      # the language LSTM's h (:43)
-        xs = [prev_h, fc_feats, embedded_word] if self.opts.global_img_in_attn_lstm else [prev_h, embedded_word]
-        h_attn, c_attn = F_.lstm_cell(xs, state[0][0], state[1][0], *_cell(self.att_lstm))
+        (h_att, h_lang), (c_att, c_lang) = state[0].unbind(0), state[1].unbind(0)
+        output, (h_att, c_att, h_lang, c_lang), roi_attn, frame_masked_attn, weighted_pool_feat = self.step(
+            embedded_word, fc_feats, conv_feats, p_conv_feats, pool_feats, p_pool_feats, pnt_mask, (h_att, c_att, h_lang, c_lang),
+            proposal_frame_mask)
+        return output, (torch.stack([h_att, h_lang]), torch.stack([c_att, c_lang])), roi_attn, frame_masked_attn, weighted_pool_feat
+
+    def step(self, embedded_word, fc_feats, conv_feats, p_conv_feats, pool_feats, p_pool_feats, pnt_mask, state,
+             proposal_frame_mask=None):
+        """forward() on an unstacked state (h_att, c_att, h_lang, c_lang): what the captioner's T-step loops call --
+        stacking the state every step costs ~17 small kernels per step in the backward pass (the selects' zero-filled
+        gradients, their accumulation, the stack / unbind pairs)."""
+        h_att, c_att, h_lang, c_lang = state
+        xs = [h_lang, fc_feats, embedded_word] if self.opts.global_img_in_attn_lstm else [h_lang, embedded_word]
+        h_attn, c_attn = F_.lstm_cell(xs, h_att, c_att, *_cell(self.att_lstm))
         # regions (masked, optional frame-masked copy) and frames share the query: one launch
         ctx_sum, ((weighted_pool_feat, roi_attn, frame_masked_attn), _frames) = _soft_attn_pair(
             self.soft_attn, h_attn,
             [(p_pool_feats, pool_feats, pnt_mask, proposal_frame_mask), (p_conv_feats, conv_feats, None, None)])
-        h_lang, c_lang = F_.lstm_cell([ctx_sum, h_attn], state[0][1], state[1][1], *_cell(self.lang_lstm))
-        output = self.dropout(h_lang)
-        state = (torch.stack([h_attn, h_lang]), torch.stack([c_attn, c_lang]))
-        return output, state, roi_attn, frame_masked_attn, weighted_pool_feat
+        h_lang, c_lang = F_.lstm_cell([ctx_sum, h_attn], h_lang, c_lang, *_cell(self.lang_lstm))
+        return self.dropout(h_lang), (h_attn, c_attn, h_lang, c_lang), roi_attn, frame_masked_attn, weighted_pool_feat
 
 
 class AttenedDecoderCore(nn.Module):
@@ -64,11 +74,15 @@ class AttenedDecoderCore(nn.Module):
         self.dropout = nn.Dropout(opts.drop_prob_lm)
 
     def forward(self, embedded_word, fc_feats, weighted_pool_feat, attn_conv, state, with_sentinel=False):
-        prev_h = state[0][-1]
-        xs = [prev_h, fc_feats, embedded_word] if self.opts.global_img_in_attn_lstm else [prev_h, embedded_word]
-        h_attn, c_attn = F_.lstm_cell(xs, state[0][0], state[1][0], *_cell(self.att_lstm))
-        h_lang, c_lang = F_.lstm_cell([weighted_pool_feat + attn_conv, h_attn], state[0][1], state[1][1],
-                                      *_cell(self.lang_lstm))
-        output = self.dropout(h_lang)
-        state = (torch.stack([h_attn, h_lang]), torch.stack([c_attn, c_lang]))
-        return output, state
+        (h_att, h_lang), (c_att, c_lang) = state[0].unbind(0), state[1].unbind(0)
+        output, (h_att, c_att, h_lang, c_lang) = self.step(embedded_word, fc_feats, weighted_pool_feat, attn_conv,
+                                                           (h_att, c_att, h_lang, c_lang))
+        return output, (torch.stack([h_att, h_lang]), torch.stack([c_att, c_lang]))
+
+    def step(self, embedded_word, fc_feats, weighted_pool_feat, attn_conv, state):
+        """forward() on an unstacked state (h_att, c_att, h_lang, c_lang), see TopDownDecoderCore.step"""
+        h_att, c_att, h_lang, c_lang = state
+        xs = [h_lang, fc_feats, embedded_word] if self.opts.global_img_in_attn_lstm else [h_lang, embedded_word]
+        h_attn, c_attn = F_.lstm_cell(xs, h_att, c_att, *_cell(self.att_lstm))
+        h_lang, c_lang = F_.lstm_cell([weighted_pool_feat + attn_conv, h_attn], h_lang, c_lang, *_cell(self.lang_lstm))
+        return self.dropout(h_lang), (h_attn, c_attn, h_lang, c_lang)

@@ -37,7 +37,10 @@ def main():
         part = torch.empty((V + 31) // 32, 64, 6, device=dev)
         t_y = timeit(lambda: L.cvc_packed_linear_fwd(wp.data_ptr(), xq.data_ptr(), K, b.data_ptr(), M, V, 1, y.data_ptr(), V, None, st))
         t_p = timeit(lambda: L.cvc_packed_linear_fwd(wp.data_ptr(), xq.data_ptr(), K, b.data_ptr(), M, V, 1, None, V, part.data_ptr(), st))
-        t_mm = timeit(lambda: torch.addmm(b, from_q, w.t())) if False else 0
+        y2 = torch.empty(4, M, V, device=dev)
+        t_k = [timeit(lambda ks=ks: L.cvc_packed_linear_fwd(wp.data_ptr(), xq.data_ptr(), K, b.data_ptr(), M, V, ks, y2.data_ptr(), V, None, st))
+               for ks in (2, 3, 4)]
+        print("   split-K logits (slices summed by the consumer): ksplit 2 / 3 / 4 = %.1f / %.1f / %.1f us" % tuple(t_k))
         print("M=%d K=%d V=%d: logits only %.1f us, fused top-2 partials %.1f us  (weights %.0f MB -> %.2f TB/s)" % (
             M, K, V, t_y, t_p, V * K * 4 / 1e6, V * K * 4 / t_p / 1e6))
 
