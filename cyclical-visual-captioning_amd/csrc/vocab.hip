@@ -41,24 +41,49 @@ __global__ __launch_bounds__(WG) void embed_relu_fwd_kernel(const float* table, 
 }
 
 // Deterministic scatter-add without atomics and without a host round trip: the host passes a stable argsort
-// of the word indices, so the rows of one word are contiguous in `order`; workgroup r does nothing unless
-// row r starts a run, in which case it sums the run in (original) order and writes that word's gradient row.
-__global__ __launch_bounds__(WG) void embed_relu_bwd_kernel(const float* table, const int64_t* idx, const int64_t* order,
-                                                            const float* drop, const float* d_out, int M, int E,
-                                                            float* d_table) {
+// of the word indices, so the rows of one word are contiguous in `order` (a "run").  Two passes, both in a fixed
+// order: (1) the sorted positions are cut into chunks of EMB_CHUNK; a workgroup walks its chunk and writes one
+// partial sum per (word, chunk) piece to part[first sorted position of the piece]; (2) the workgroup of a run's
+// first position adds the run's pieces (its own, then the ones starting at the following chunk boundaries) and
+// writes that word's gradient row.  A long run -- the BOS / padding word owns about a third of the B*T rows --
+// is thereby summed by run/EMB_CHUNK workgroups in parallel instead of one workgroup walking it row by row.
+constexpr int EMB_CHUNK = 16;
+
+__global__ __launch_bounds__(WG) void embed_bwd_pieces_kernel(const int64_t* idx, const int64_t* order, const float* drop,
+                                                              const float* d_out, int M, int E, float* part) {
+    const int r0 = blockIdx.y * EMB_CHUNK;
+    const int e = (blockIdx.x * WG + threadIdx.x) * 4;
+    if (e >= E) return;
+    const int r1 = min(M, r0 + EMB_CHUNK);
+    int start = r0;
+    int64_t w = idx[order[r0]];
+    f32x4 acc = {0, 0, 0, 0};
+    for (int r = r0; r < r1; ++r) {
+        const int64_t m = order[r];
+        const int64_t wr = idx[m];
+        if (wr != w) {                                         // the piece ends: flush it, open the next one
+            st4(part + (size_t)start * E + e, acc);
+            acc = f32x4{0, 0, 0, 0};
+            start = r;
+            w = wr;
+        }
+        f32x4 g = ld4(d_out + (size_t)m * E + e);
+        if (drop != nullptr) g *= ld4(drop + (size_t)m * E + e);
+        acc += g;
+    }
+    st4(part + (size_t)start * E + e, acc);
+}
+
+__global__ __launch_bounds__(WG) void embed_bwd_runs_kernel(const float* table, const int64_t* idx, const int64_t* order,
+                                                            const float* part, int M, int E, float* d_table) {
     const int r0 = blockIdx.y;
     const int64_t w = idx[order[r0]];
     if (r0 > 0 && idx[order[r0 - 1]] == w) return;            // not the first row of its word
     const int e = (blockIdx.x * WG + threadIdx.x) * 4;
     if (e >= E) return;
-    f32x4 acc = {0, 0, 0, 0};
-    for (int r = r0; r < M; ++r) {
-        const int64_t m = order[r];
-        if (idx[m] != w) break;
-        f32x4 g = ld4(d_out + (size_t)m * E + e);
-        if (drop != nullptr) g *= ld4(drop + (size_t)m * E + e);
-        acc += g;
-    }
+    f32x4 acc = ld4(part + (size_t)r0 * E + e);               // the piece that starts the run
+    for (int r = (r0 / EMB_CHUNK + 1) * EMB_CHUNK; r < M && idx[order[r]] == w; r += EMB_CHUNK)
+        acc += ld4(part + (size_t)r * E + e);                 // pieces that start at the following chunk boundaries
     const f32x4 t = ld4(table + (size_t)w * E + e);
     acc.x = t.x > 0.f ? acc.x : 0.f; acc.y = t.y > 0.f ? acc.y : 0.f;
     acc.z = t.z > 0.f ? acc.z : 0.f; acc.w = t.w > 0.f ? acc.w : 0.f;
@@ -426,10 +451,13 @@ extern "C" int cvc_embed_relu_fwd(const float* table, const int64_t* idx, const 
 }
 
 extern "C" int cvc_embed_relu_bwd(const float* table, const int64_t* idx, const int64_t* order, const float* drop,
-                                  const float* d_out, int M, int E, float* d_table, cvc_stream_t stream) {
-    if (!table || !idx || !order || !d_out || !d_table || M < 1 || E < 4 || (E & 3)) return CVC_E_BADARG;
-    hipLaunchKernelGGL(embed_relu_bwd_kernel, dim3((E / 4 + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, table, idx, order,
-                       drop, d_out, M, E, d_table);
+                                  const float* d_out, int M, int E, float* d_table, float* workspace, cvc_stream_t stream) {
+    if (!table || !idx || !order || !d_out || !d_table || !workspace || M < 1 || E < 4 || (E & 3)) return CVC_E_BADARG;
+    const int gx = (E / 4 + WG - 1) / WG;
+    hipLaunchKernelGGL(embed_bwd_pieces_kernel, dim3(gx, (M + EMB_CHUNK - 1) / EMB_CHUNK), dim3(WG), 0, (hipStream_t)stream, idx,
+                       order, drop, d_out, M, E, workspace);
+    hipLaunchKernelGGL(embed_bwd_runs_kernel, dim3(gx, M), dim3(WG), 0, (hipStream_t)stream, table, idx, order, workspace, M, E,
+                       d_table);
     return cvc_launch_status();
 }
 

@@ -55,7 +55,7 @@ SIGNATURES = {
     "cvc_lstm_pointwise_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "cvc_linear_nn_fwd": [_P, _I, _I, C.POINTER(NNSeg), _I, _I, _P, _P],
     "cvc_embed_relu_fwd": [_P, _P, _P, _I, _I, _P, _P],
-    "cvc_embed_relu_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P],
+    "cvc_embed_relu_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     "cvc_log_softmax_fwd": [_P, _I, _I, _P, _P],
     "cvc_log_softmax_bwd": [_P, _P, _I, _I, _P, _P],
     "cvc_nll_bwd": [_P, _P, _P, _I, _I, _P, _P],
@@ -280,8 +280,9 @@ def embed_relu_fwd(table, idx, drop=None):
 def embed_relu_bwd(table, idx, drop, d_out):
     d_table = torch.zeros_like(table)
     order = torch.argsort(idx, stable=True)                      # rows grouped by word, original order inside a group
+    ws = torch.empty(idx.shape[0], table.shape[1], device=table.device, dtype=torch.float32)
     _check(lib().cvc_embed_relu_bwd(_dev(table), _dev(idx, torch.int64), _dev(order, torch.int64), _dev(drop), _dev(d_out),
-                                    idx.shape[0], table.shape[1], _dev(d_table), _stream()), "cvc_embed_relu_bwd")
+                                    idx.shape[0], table.shape[1], _dev(d_table), _dev(ws), _stream()), "cvc_embed_relu_bwd")
     return d_table
 
 

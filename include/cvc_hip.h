@@ -201,10 +201,12 @@ int cvc_embed_relu_fwd(const float* table, const int64_t* idx, const float* drop
                        float* out, cvc_stream_t stream);
 /* d_table[w, :] = (table[w, :] > 0) * sum_{m: idx[m] == w} drop[m, :] * d_out[m, :] for every word w that
  * occurs; no atomics and no host round trip: `order` [M] is a stable argsort of idx, so the rows of a word
- * are contiguous in it and the workgroup of a run's first row sums the run in order.  Rows of d_table for
- * words that do not occur are left untouched (caller zero-fills). */
+ * are contiguous in it; they are summed in a fixed two-level order (16-row pieces, then the pieces of a
+ * word), so a word that owns many rows (BOS / padding) does not serialise.  workspace: M * E floats.
+ * Rows of d_table for words that do not occur are left untouched (caller zero-fills). */
 int cvc_embed_relu_bwd(const float* table, const int64_t* idx, const int64_t* order, const float* drop,
-                       const float* d_out, int M, int E, float* d_table, cvc_stream_t stream);
+                       const float* d_out, int M, int E, float* d_table, float* workspace,
+                       cvc_stream_t stream);
 
 /* In-place-capable row log-softmax: logp[m, :] = logits[m, :] - logsumexp(logits[m, :]) */
 int cvc_log_softmax_fwd(const float* logits, int M, int V, float* logp, cvc_stream_t stream);

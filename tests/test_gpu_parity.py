@@ -354,6 +354,26 @@ def test_split_product_gemm_is_fp32_grade(dev, lib, M, K, N):
         assert err[mode][0] <= 1.25 * err[0][0] and err[mode][1] <= 1.25 * err[0][1], err
 
 
+@pytest.mark.parametrize("M,V,E,pad", [(1280, 5000, 1024, 0.35), (37, 11, 16, 0.5), (1, 3, 4, 0.0), (64, 2, 8, 0.9)])
+def test_embedding_backward_long_runs(dev, lib, M, V, E, pad):
+    """cvc_embed_relu_bwd (sorted runs summed as 16-row pieces) vs index_add in fp64; a third of the rows share
+    word 0 (BOS / padding), as in a teacher-forced batch."""
+    g = torch.Generator(device="cpu").manual_seed(M + V)
+    table = torch.randn(V, E, generator=g).to(dev)
+    idx = torch.randint(0, V, (M,), generator=g)
+    idx[torch.rand(M, generator=g) < pad] = 0
+    idx = idx.to(dev)
+    drop = ((torch.rand(M, E, generator=g) > 0.5).float() * 2).to(dev)
+    d_out = torch.randn(M, E, generator=g).to(dev)
+    for dm in (drop, None):
+        got = lib.embed_relu_bwd(table, idx, dm, d_out)
+        ref = torch.zeros(V, E, dtype=torch.float64, device=dev)
+        ref.index_add_(0, idx, (d_out if dm is None else d_out * dm).double())
+        ref = ref * (table > 0)
+        close(got, ref.float(), rtol=2e-5, atol=2e-5)
+        assert torch.equal(got, lib.embed_relu_bwd(table, idx, dm, d_out))       # fixed summation order
+
+
 # ------------------------------------------------------------------ greedy decode (a8)
 def test_a8_greedy_tiny_golden(tiny, g1):
     from helpers import model_call, tie_aware_seq_equal
