@@ -1,0 +1,351 @@
+// Packed GEMM of the decode engine (split out of gemm_skinny.hip; the row-major kernels live there).
+#include "cvc_common.h"
+#include "gemm_split.h"
+
+// ==========================================================================================
+// Packed path for the decode engine: both MFMA operands are stored fragment-native in HBM, so a
+// wave loads them straight into VGPRs with fully coalesced dwordx4 loads -- no LDS, no DMA, no
+// swizzle -- and the prefetch depth is bounded by the 512-entry register file (one wave per SIMD)
+// instead of LDS: DEPTH chunks (DEPTH x 4 KB of weights per wave) in flight.
+//
+// Measured motivation (cfg2 lang-LSTM): with the LDS ring of gemm_skinny.hip, the memory side alone needs 53 us
+// (3.8 TB/s: only 2 x 4 KB of weights in flight per wave, because activations take 2/3 of the
+// ring and vmcnt retires in order), the MFMA side alone 57 us, together 71 us.
+//
+// Layouts ("quad" = 4 consecutive k):
+//   weights  Wp[blk][quad][32][4]   blk = 32 output rows (LSTM: the 4 gates x 8 hidden units of
+//            workgroup blk, i.e. row (i>>3)*R + blk*8 + (i&7)), packed once when the engine binds
+//            the checkpoint (cvc/decode.py::pack_weights); the concat over K segments is baked in.
+//   activations XQ[quad][64][4]     written in this form by the producers (this kernel's own
+//            epilogue, attn_wsum, top2_final), 64 = padded batch rows.
+// Lane l (i = l & 31, kh = l >> 5) of a wave handling chunk c (32 k = 8 quads) loads quads
+// 8c + 4kh + {0..3}: each half-wave reads 512 contiguous bytes per instruction.
+// ==========================================================================================
+struct PackedArgs {
+    const float* wp;          // packed weights of this GEMM
+    const float* xq;          // packed activations, first quad of this GEMM's K range
+    int nquad;                // K / 4 (multiple of 8)
+    int M, Nout, R;
+    const float* bias;        // linear: [Nout]; lstm: b_ih [4R] (nullable)
+    const float* bias2;       // lstm: b_hh (nullable)
+    const float* gate_bias;   // lstm: [M, 4R] row-major (nullable)
+    const float* c_prev_q;    // lstm: cell state, quad layout [R/4][64][4]
+    float* c_out_q;
+    float* h_dst1_q;          // lstm: h' in quad layout at (quad offset baked into the pointer); nullable
+    float* h_dst2_q;
+    float* y;                 // linear: row-major [M, ldy] (+ split slices), nullable
+    int ldy;
+    int ksplit;
+    long long split_stride;
+    float* top2_part;
+};
+
+#ifndef CVC_LIN_W_NT
+#define CVC_LIN_W_NT 0      // 1: also stream the linear layers' weights non-temporally (A/B switch)
+#endif
+
+template <int MT>
+struct PFrag {
+    f32x4 w[4];
+    f32x4 x[MT][4];
+};
+
+// NW waves split K (chunk c goes to wave c % NW).  NW = 8 puts two waves on every SIMD, each with a shallower
+// ring: while one waits on HBM the other multiplies -- the split-product variant needs that, its compute per
+// chunk being too short for one wave's ring to cover the memory latency.
+template <int NW>
+__device__ __forceinline__ float sum_partials(const float* red, int row, int ldm, int m) {
+    float v = (red[(0 * 32 + row) * ldm + m] + red[(1 * 32 + row) * ldm + m]) +
+              (red[(2 * 32 + row) * ldm + m] + red[(3 * 32 + row) * ldm + m]);
+    if constexpr (NW == 8)
+        v += (red[(4 * 32 + row) * ldm + m] + red[(5 * 32 + row) * ldm + m]) +
+             (red[(6 * 32 + row) * ldm + m] + red[(7 * 32 + row) * ldm + m]);
+    return v;
+}
+
+template <int MT, bool LSTM, int DEPTH, bool SPLIT, int NW>
+__global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs a) {
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
+    constexpr int LDM = MT * 32 + 1;
+    __shared__ float red[NW * 32 * LDM + NW * 64 * 6];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, kh = lane >> 5;
+    const int M = a.M, R = a.R;
+
+    int nchunk = a.nquad >> 3, c0 = 0;
+    if (!LSTM && a.ksplit > 1) {                              // K slice of this workgroup (whole chunks)
+        const int lo = nchunk * (int)blockIdx.y / a.ksplit, hi = nchunk * ((int)blockIdx.y + 1) / a.ksplit;
+        c0 = lo;
+        nchunk = hi - lo;
+    }
+    const int n_my = nchunk > wave ? (nchunk - wave + NW - 1) / NW : 0;   // chunks c0 + wave + 4*j
+    // per-lane bases: quad q of this block lives at wp + ((blk * nquad + q) * 32 + i) * 4
+    const float* wl = a.wp + ((size_t)blockIdx.x * a.nquad * 32 + i) * 4 + (size_t)(c0 + wave) * 8 * 128 + kh * 4 * 128;
+    const float* xl = a.xq + (size_t)i * 4 + (size_t)(c0 + wave) * 8 * 256 + kh * 4 * 256;
+    constexpr size_t WSTEP = (size_t)NW * 8 * 128, XSTEP = (size_t)NW * 8 * 256;   // floats per wave-chunk step
+#ifndef CVC_ROT_MUL
+#define CVC_ROT_MUL 5
+#endif
+    const int rot = n_my > 0 ? (int)((blockIdx.x * CVC_ROT_MUL) % (unsigned)n_my) : 0;
+
+    auto load = [&](PFrag<MT>& f, int j) __attribute__((always_inline)) {
+#if defined(CVC_PABL) && CVC_PABL == 1
+        if (j > 0) { asm volatile("" : "+v"(f.w[0])); return; }     // ablation: only the first chunk is ever loaded (MFMA side only)
+#endif
+        // every workgroup walks K from a different starting chunk: all 256 of them read the SAME activation lines,
+        // and in lock step they would queue on the same L2 channels (the order of a wave's partial sums changes
+        // with the block index, the result of a given block is still deterministic)
+        int jr = j + rot;
+        jr = jr >= n_my ? jr - n_my : jr;
+        const float* w = wl + (size_t)jr * WSTEP;
+#if defined(CVC_PABL) && CVC_PABL == 4
+        const float* x = a.xq + (size_t)i * 4 + kh * 4 * 256;     // ablation: every wave re-reads ONE activation chunk (L1 hits)
+#else
+        const float* x = xl + (size_t)jr * XSTEP;
+#endif
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // gate weights (369 MB per step) are streamed; the small linear layers' weights (vocabulary head, h2attn:
+            // 49 MB) keep the default policy so that they can stay in the Infinity Cache between steps
+            if constexpr (LSTM || CVC_LIN_W_NT) f.w[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + q * 128));
+            else f.w[q] = ld4(w + q * 128);
+#if defined(CVC_PABL) && CVC_PABL == 3
+            if (j > 0) continue;                                     // ablation: stream the weights only
+#endif
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) f.x[mt][q] = ld4(x + q * 256 + mt * 128);
+        }
+    };
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+    auto mma = [&](const PFrag<MT>& f) __attribute__((always_inline)) {
+#if defined(CVC_PABL) && CVC_PABL >= 2
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                               // ablation: memory side only, keep the loads live
+            asm volatile("" ::"v"(f.w[q]));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(f.x[mt][q]));
+        }
+        return;
+#endif
+        if constexpr (SPLIT) {
+            // the lane half's 4 quads = 16 k-slots = two K=16 steps (quads 2s, 2s+1); W and X use the same slot map
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const Split3 W = split8(f.w[2 * s2], f.w[2 * s2 + 1]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const Split3 X = split8(f.x[mt][2 * s2], f.x[mt][2 * s2 + 1]);
+                    acc[mt] = mfma_bf16(W.mid, X.mid, acc[mt]);
+                    acc[mt] = mfma_bf16(W.lo, X.hi, acc[mt]);
+                    acc[mt] = mfma_bf16(W.hi, X.lo, acc[mt]);
+                    acc[mt] = mfma_bf16(W.mid, X.hi, acc[mt]);
+                    acc[mt] = mfma_bf16(W.hi, X.mid, acc[mt]);
+                    acc[mt] = mfma_bf16(W.hi, X.hi, acc[mt]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w[q][e], f.x[mt][q][e], acc[mt], 0, 0, 0);
+        }
+    };
+
+    // register ring, DEPTH chunks in flight; fully unrolled so that every fragment is statically named.
+    // The steady-state loop issues its loads UNCONDITIONALLY: with a conditional load on any path the
+    // compiler's s_waitcnt insertion has to assume the fewest loads outstanding and degrades the
+    // counted vmcnt(N) of the oldest slot to a near-full drain.
+    PFrag<MT> ring[DEPTH];
+    if (n_my >= DEPTH) {
+        // slots 0 .. DEPTH-2 are filled up front; every step multiplies slot s while it (re)fills the slot
+        // consumed one step earlier, the 12 loads spread between the 32 MFMAs of the step
+#pragma unroll
+        for (int s = 0; s < DEPTH - 1; ++s) load(ring[s], s);
+        int j = 0;
+        for (; j + 2 * DEPTH - 1 <= n_my; j += DEPTH) {
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) {
+                load(ring[(s + DEPTH - 1) % DEPTH], j + s + DEPTH - 1);
+                mma(ring[s]);
+                if constexpr (SPLIT) {
+#pragma unroll
+                    for (int g = 0; g < 4 + 4 * MT; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x002, 18, 0);  // VALU (operand split + addresses)
+                        __builtin_amdgcn_sched_group_barrier(0x008, MT, 0);  // MFMA (12 * MT per slot)
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                    }
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4 + 4 * MT; ++g) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);   // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // VALU (addresses)
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // drain: chunks j .. n_my-1 (fewer than 2*DEPTH-1 left); slots 0..DEPTH-2 hold chunks j..j+DEPTH-2
+#pragma unroll
+        for (int s = 0; s < DEPTH; ++s) {
+            if (j + s + DEPTH - 1 < n_my) load(ring[(s + DEPTH - 1) % DEPTH], j + s + DEPTH - 1);
+            if (j + s < n_my) mma(ring[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < DEPTH - 1; ++s)
+            if (j + DEPTH + s < n_my) mma(ring[s]);
+    } else {
+        for (int j = 0; j < n_my; ++j) {                       // short K: no pipeline
+            load(ring[0], j);
+            mma(ring[0]);
+        }
+    }
+
+    // ---- ordered cross-wave reduction (same scheme as combine_and_store)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            red[(wave * 32 + row) * LDM + mt * 32 + i] = acc[mt][r];
+        }
+    __syncthreads();
+
+    if (LSTM) {
+        // unit u -> (batch row m fastest, quad-of-hidden qd in 0..1): a thread finishes 4 hidden units
+        // and stores them as one float4 in quad layout (64 rows x 16 B contiguous per quad)
+        const int j0 = blockIdx.x * 8;
+        for (int u = tid; u < 2 * 64; u += NW * 64) {
+            const int m = u & 63, qd = u >> 6;
+            if (m >= M || m >= MT * 32) continue;
+            f32x4 hv, cv;
+            const size_t qoff = ((size_t)(j0 / 4 + qd) * 64 + m) * 4;
+            const f32x4 cp = ld4(a.c_prev_q + qoff);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int jj = qd * 4 + e, j = j0 + jj;
+                float pre[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v = sum_partials<NW>(red, g * 8 + jj, LDM, m);
+                    if (a.bias != nullptr) v += a.bias[g * R + j];
+                    if (a.bias2 != nullptr) v += a.bias2[g * R + j];
+                    if (a.gate_bias != nullptr) v += a.gate_bias[(size_t)m * 4 * R + g * R + j];
+                    pre[g] = v;
+                }
+                const float ig = fast_sigmoid(pre[0]), fg = fast_sigmoid(pre[1]);
+                const float gg = fast_tanh(pre[2]), og = fast_sigmoid(pre[3]);
+                const float c2 = fg * cp[e] + ig * gg;
+                cv[e] = c2;
+                hv[e] = og * fast_tanh(c2);
+            }
+            st4(a.c_out_q + qoff, cv);
+            if (a.h_dst1_q != nullptr) st4(a.h_dst1_q + qoff, hv);
+            if (a.h_dst2_q != nullptr) st4(a.h_dst2_q + qoff, hv);
+        }
+    } else {
+        const int n0 = blockIdx.x * 32;
+        const bool lead = blockIdx.y == 0;
+        float* y = a.y != nullptr ? a.y + (long long)blockIdx.y * a.split_stride : nullptr;
+        if (y != nullptr) {
+            for (int u = tid; u < 32 * MT * 32; u += NW * 64) {
+                const int nl = u & 31, m = u >> 5;
+                const int n = n0 + nl;
+                if (m >= M || n >= a.Nout) continue;
+                float v = sum_partials<NW>(red, nl, LDM, m);
+                if (lead && a.bias != nullptr) v += a.bias[n];
+                y[(size_t)m * a.ldy + n] = v;
+            }
+        }
+        if (a.top2_part != nullptr) {
+            float* scratch = red + NW * 32 * LDM;
+            float v1 = -__builtin_inff(), v2 = -__builtin_inff(), mx = -__builtin_inff(), se = 0.f;
+            int i1 = 0x7fffffff, i2 = 0x7fffffff;
+            const int m = lane < MT * 32 ? lane : MT * 32 - 1;
+            constexpr int CPW = 32 / NW;                          // columns scanned per wave
+            for (int nl = wave * CPW; nl < wave * CPW + CPW; ++nl) {
+                const int n = n0 + nl;
+                if (n >= a.Nout) break;
+                float v = sum_partials<NW>(red, nl, LDM, m);
+                if (a.bias != nullptr) v += a.bias[n];
+                if (v > v1) { v2 = v1; i2 = i1; v1 = v; i1 = n; }
+                else if (v > v2) { v2 = v; i2 = n; }
+                const float nm = fmaxf(mx, v);
+                se = se * __expf(mx - nm) + __expf(v - nm);
+                mx = nm;
+            }
+            float* r4 = scratch + ((size_t)wave * 64 + lane) * 6;
+            r4[0] = v1; r4[1] = __int_as_float(i1); r4[2] = v2; r4[3] = __int_as_float(i2); r4[4] = mx; r4[5] = se;
+            __syncthreads();
+            if (wave == 0 && lane < M) {
+                for (int w = 1; w < NW; ++w) {
+                    const float* q4 = scratch + ((size_t)w * 64 + lane) * 6;
+                    const float u1 = q4[0], u2 = q4[2];
+                    const int k1 = __float_as_int(q4[1]), k2 = __float_as_int(q4[3]);
+                    if (u1 > v1) { if (v1 >= u2) { v2 = v1; i2 = i1; } else { v2 = u2; i2 = k2; } v1 = u1; i1 = k1; }
+                    else if (u1 > v2) { v2 = u1; i2 = k1; }
+                    const float nm = fmaxf(mx, q4[4]);
+                    se = (nm == -__builtin_inff()) ? 0.f : se * __expf(mx - nm) + q4[5] * __expf(q4[4] - nm);
+                    mx = nm;
+                }
+                float* rec = a.top2_part + ((size_t)blockIdx.x * 64 + lane) * 6;
+                rec[0] = v1; rec[1] = __int_as_float(i1); rec[2] = v2; rec[3] = __int_as_float(i2); rec[4] = mx; rec[5] = se;
+            }
+        }
+    }
+}
+
+#ifndef CVC_PACKED_DEPTH
+#define CVC_PACKED_DEPTH 4
+#endif
+#ifndef CVC_PACKED_DEPTH8
+#define CVC_PACKED_DEPTH8 3
+#endif
+
+template <bool LSTM>
+static int launch_packed(const PackedArgs& a, int blocks, hipStream_t st) {
+    if (a.M < 1 || a.M > 64 || (a.nquad & 7) || a.nquad < 8) return CVC_E_BADARG;
+    const dim3 grid(blocks, LSTM || a.ksplit < 1 ? 1 : a.ksplit);
+    if (cvc_gemm_split_mode == 2) {            // split products, 8 waves (2 per SIMD), ring depth CVC_PACKED_DEPTH8
+        if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_packed_kernel<1, LSTM, CVC_PACKED_DEPTH8, true, 8>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, LSTM, CVC_PACKED_DEPTH8, true, 8>), grid, dim3(512), 0, st, a);
+    } else if (cvc_gemm_split_mode) {
+        if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_packed_kernel<1, LSTM, CVC_PACKED_DEPTH, true, 4>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, LSTM, CVC_PACKED_DEPTH, true, 4>), grid, dim3(256), 0, st, a);
+    } else {
+        if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_packed_kernel<1, LSTM, CVC_PACKED_DEPTH, false, 4>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, LSTM, CVC_PACKED_DEPTH, false, 4>), grid, dim3(256), 0, st, a);
+    }
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_packed_lstm_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
+                                   const float* gate_bias, const float* c_prev_q, int M, int R, float* h_dst1_q,
+                                   float* h_dst2_q, float* c_out_q, cvc_stream_t stream) {
+    if (!wp || !xq || !c_prev_q || !c_out_q || (K & 31) || R < 8 || (R & 7)) return CVC_E_BADARG;
+    PackedArgs a{};
+    a.wp = wp; a.xq = xq; a.nquad = K / 4; a.M = M; a.Nout = 4 * R; a.R = R;
+    a.bias = b_ih; a.bias2 = b_hh; a.gate_bias = gate_bias; a.c_prev_q = c_prev_q; a.c_out_q = c_out_q;
+    a.h_dst1_q = h_dst1_q; a.h_dst2_q = h_dst2_q; a.ksplit = 1;
+    return launch_packed<true>(a, R / 8, (hipStream_t)stream);
+}
+
+extern "C" int cvc_packed_linear_fwd(const float* wp, const float* xq, int K, const float* bias, int M, int Nout,
+                                     int ksplit, float* y, int ldy, float* top2_part, cvc_stream_t stream) {
+    if (!wp || !xq || (K & 31) || Nout < 1 || ksplit < 1 || (!y && !top2_part)) return CVC_E_BADARG;
+    if (ksplit > 1 && top2_part != nullptr) return CVC_E_BADARG;
+    PackedArgs a{};
+    a.wp = wp; a.xq = xq; a.nquad = K / 4; a.M = M; a.Nout = Nout; a.R = 0;
+    a.bias = bias; a.y = y; a.ldy = ldy; a.ksplit = ksplit; a.split_stride = (long long)M * ldy; a.top2_part = top2_part;
+    return launch_packed<false>(a, (Nout + 31) / 32, (hipStream_t)stream);
+}
