@@ -248,6 +248,11 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
             self._decode_cache = cached
         return cached[1]
 
+    def invalidate_decode_cache(self):
+        """Drop the cached decode binding.  Needed after parameter updates that bypass the tensors' version counters:
+        a HIP-graph replay of the training step, or a fused optimizer kernel (Trainer calls this after every step)."""
+        self._decode_cache = None
+
     @torch.no_grad()
     def _sample(self, segs_feat, seq, proposals, gt_caption, num, mask_boxes, gt_boxes, region_feats, frm_mask, sample_idx,
                 pnt_mask, beam_size: Optional[int] = None):

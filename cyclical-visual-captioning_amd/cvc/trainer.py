@@ -87,7 +87,15 @@ class Trainer:
             self.grad_reducer.finalize()                     # the one exchange step of the path
         nn.utils.clip_grad_norm_(self.model.parameters(), self.opts.grad_clip)
         self.optimizer.step()
+        self._weights_changed()
         return loss.detach(), lm.detach(), att2.detach(), cls.detach(), rec.detach()
+
+    def _weights_changed(self):
+        """The fused Adam kernel and HIP-graph replays update parameters without touching their version counters,
+        which is what the captioner's cached decode binding watches: drop it explicitly."""
+        inval = getattr(self.model, "invalidate_decode_cache", None)
+        if inval is not None:
+            inval()
 
     # ------------------------------------------------------------------ HIP-graph training step
     def _core_step(self, b):
@@ -129,6 +137,7 @@ class Trainer:
                 for kk, vv in v.items():
                     static[k][kk].copy_(vv)
         g.replay()
+        self._weights_changed()
         return res
 
     # ------------------------------------------------------------------ epoch loops
@@ -256,7 +265,9 @@ def build_optimizer(model, opt, capturable: bool = False):
     if opt.optim == 'sgd':
         return torch.optim.SGD([{k: v for k, v in p.items() if k != 'betas'} for p in params], lr=opt.learning_rate, momentum=0.9)
     if opt.optim == 'adam':
-        return torch.optim.Adam(params, capturable=capturable)
+        # fused = one pass over (p, g, m, v) per tensor instead of the foreach path's ~9 passes (Adam was 8 % of the step)
+        fused = all(p['params'][0].is_cuda for p in params)
+        return torch.optim.Adam(params, capturable=capturable, fused=fused)
     if opt.optim == 'adamax':
         return torch.optim.Adamax(params)
     raise ValueError('Unknown optimizer: {}'.format(opt.optim))

@@ -136,18 +136,21 @@ def test_graphed_train_step_equals_eager():
     np.testing.assert_allclose(losses["graph"], losses["eager"], rtol=1e-5, atol=1e-6)
 
 
-def test_decode_weights_cache_follows_parameter_updates():
+@pytest.mark.parametrize("graphed", [False, True])
+def test_decode_weights_cache_follows_parameter_updates(graphed):
+    """The cached decode binding (packed weight copies) must not survive a training step -- neither an eager one
+    (fused Adam does not bump version counters) nor a HIP-graph replay (no Python-side trace of the update at all)."""
     dev = torch.device("cuda:0")
     d = synth.CONFIGS["tiny"]
     o, model, batch, Trainer, build_optimizer = _setup(dev, d)
-    tr = Trainer(o, None, model, build_optimizer(model, o), None, None)
+    tr = Trainer(o, None, model, build_optimizer(model, o, capturable=graphed), None, None)
     model.eval()
     w1 = model.decode_weights()
     assert model.decode_weights() is w1                                   # unchanged parameters: same binding
     b = tr._prepare(batch, False)
     seq1, att1, _ = tr._call(b, True)
     model.train()
-    tr.train_step(batch)                                                  # optimizer step bumps the version counters
+    (tr.train_step_graphed if graphed else tr.train_step)(batch)
     model.eval()
     w2 = model.decode_weights()
     assert w2 is not w1
