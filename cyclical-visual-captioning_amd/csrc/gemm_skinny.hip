@@ -1,4 +1,5 @@
-// Weight-streaming skinny GEMM (M <= 64 rows) on fp32 MFMA, with the nn.LSTMCell pointwise
+// Weight-streaming skinny GEMM (M <= 64 rows) on the matrix cores (fp32 MFMA, or -- default -- fp32 products taken as
+// exact bf16 splits on the bf16 MFMA, gemm_split.h), with the nn.LSTMCell pointwise
 // update fused into its epilogue.  Reference call sites: model/decoder_core.py:45-50 (att-LSTM
 // over cat[h_lang, fc, emb] + h_att), :59-61 (lang-LSTM over cat[ctx, h_att] + h_lang),
 // model/modules.py:109 (h2attn), model/captioner.py:266 (logit).

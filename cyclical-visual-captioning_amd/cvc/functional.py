@@ -1,7 +1,8 @@
 """Autograd-aware ops of the caption-decode hot path, each backed by the HIP kernels in
 libcvc_hip.so (cvc.hip).  Forward passes and the fused / recomputing backward passes are
-hand-written kernels; the backward's plain dense GEMMs (dX = dY W, dW = dY^T X) go to the
-vendor library through torch.mm (rocBLAS/hipBLASLt), which is what those are for.
+hand-written kernels (including the LSTM cells' backward-data product dX = dY W, csrc/gemm_nn.hip); the
+remaining plain dense GEMMs of the backward (dW = dY^T X batched over all T steps, the M = B*T dX of the
+vocabulary head) go to the vendor library through torch.mm (hipBLASLt), which is what those are for.
 
 No CPU path: every op raises if handed CPU tensors (cvc.hip._dev).
 """

@@ -98,8 +98,9 @@ int cvc_attn_bwd(int kind, const float* q, const float* w_a, float inv_temp,
 /* ---------------------------------------------------------------------------------------
  * Skinny GEMM over a virtual concat of K-segments:  Y[m, n] = sum_s X_s[m, :] . W_s[n, :]
  * (torch.cat + nn.Linear / nn.LSTMCell input GEMMs, decoder_core.py:45-50,59-61,
- * captioner.py:266).  Weights stream once from HBM through fp32 MFMA
- * (v_mfma_f32_32x32x2_f32, exact fp32 fma chain); M <= 64.
+ * captioner.py:266).  Weights stream once from HBM through the matrix cores: fp32 in, fp32
+ * accumulate, products either on the fp32 MFMA or (default) as exact three-way bf16 splits on the
+ * bf16 MFMA with fp32-grade error -- see cvc_gemm_packed_split; M <= 64.
  */
 typedef struct {
     const float* x;      /* [M, k] leading dim ldx; with idx: table [*, k] read at row idx[m] */
