@@ -252,6 +252,7 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         """Drop the cached decode binding.  Needed after parameter updates that bypass the tensors' version counters:
         a HIP-graph replay of the training step, or a fused optimizer kernel (Trainer calls this after every step)."""
         self._decode_cache = None
+        self._engine_cache = None
 
     @torch.no_grad()
     def _sample(self, segs_feat, seq, proposals, gt_caption, num, mask_boxes, gt_boxes, region_feats, frm_mask, sample_idx,
@@ -264,8 +265,18 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
                      pool_feats=pool_feats.contiguous(), p_pool_feats=p_pool_feats.contiguous(), pnt_mask=pnt_mask)
         beam = self.beam_size if beam_size is None else int(beam_size)
         temp = float(getattr(self.opts, "softmax_temp", 1.0))
-        engine = DecodeEngine(self.decode_weights(), feats, self.seq_length, self.unk_idx, beam=beam, inv_temp=1.0 / temp)
-        if self.use_hip_graph:
-            engine.capture()
+        weights = self.decode_weights()
+        # one engine (bound launch list + captured graph) per batch shape, reused across the batches of an evaluation
+        # loop: the next batch is copied into the engine's own feature buffers instead of re-binding and re-capturing
+        key = (id(weights), tuple(fc_feats.shape), tuple(conv_feats.shape), tuple(pool_feats.shape), beam, temp, self.seq_length,
+               self.use_hip_graph)
+        cached = getattr(self, "_engine_cache", None)
+        if cached is not None and cached[0] == key:
+            engine = cached[1].load_features(feats)
+        else:
+            engine = DecodeEngine(weights, feats, self.seq_length, self.unk_idx, beam=beam, inv_temp=1.0 / temp, own_features=True)
+            if self.use_hip_graph:
+                engine.capture()
+            self._engine_cache = (key, engine)
         res = engine.run()
         return res[0].clone(), res[1].clone(), None

@@ -374,6 +374,33 @@ def test_embedding_backward_long_runs(dev, lib, M, V, E, pad):
         assert torch.equal(got, lib.embed_relu_bwd(table, idx, dm, d_out))       # fixed summation order
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_module_decode_reuses_engine_across_batches(dev, lib, graph):
+    """captioner._sample keeps one bound engine (+ captured graph) per batch shape and copies the next batch's features
+    into it: the results must be those of a fresh binding, batch after batch, and a new shape must re-bind."""
+    import dataclasses
+    from helpers import build_model, to_dev, model_call
+    d = dataclasses.replace(synth.CONFIGS["tiny"], B=5, R=64, A=32, E=32, V=97, T=6)
+    sd = synth.hot_path_state_dict(d, 3)
+    model = build_model(d, sd, dev, hip_graph=graph)
+    outs = []
+    with torch.no_grad():
+        for seed in (21, 22, 21):
+            f, b = to_dev(synth.clip_features(d, seed), dev), to_dev(synth.label_glue_batch(d, seed), dev)
+            seq, att, _ = model_call(model, f, b, True)
+            outs.append((seq.clone(), att.clone()))
+            fresh = build_model(d, sd, dev, hip_graph=False)
+            seq_f, att_f, _ = model_call(fresh, f, b, True)
+            assert torch.equal(seq, seq_f) and torch.equal(att, att_f)
+        engine = model._engine_cache[1]
+        d2 = dataclasses.replace(d, B=3)
+        f, b = to_dev(synth.clip_features(d2, 5), dev), to_dev(synth.label_glue_batch(d2, 5), dev)
+        seq, att, _ = model_call(model, f, b, True)
+        assert seq.shape[0] == 3 and model._engine_cache[1] is not engine
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+    assert not torch.equal(outs[0][1], outs[1][1])
+
+
 # ------------------------------------------------------------------ greedy decode (a8)
 def test_a8_greedy_tiny_golden(tiny, g1):
     from helpers import model_call, tie_aware_seq_equal
