@@ -179,8 +179,7 @@ class Trainer:
         o = self.opts
         ds = self.dataset
         with torch.no_grad():
-            for batch in self.val_loader:
-                b = self._prepare(batch, False)
+            for b in DevicePrefetcher(self.val_loader, lambda raw: self._prepare(raw, False), self.device):
                 seq, att2_weights, _ = self._call(b, True)
                 if getattr(o, "eval_obj_grounding", False):
                     assert o.beam_size == 1, 'only support beam_size is 1'
@@ -213,16 +212,17 @@ class Trainer:
         boxes = torch.gather(ppls.view(-1, o.num_sampled_frm, o.num_prop_per_frm, 7).permute(0, 2, 1, 3).contiguous(), 1,
                              att2_ind.unsqueeze(-1).expand(B, att2_ind.size(1), o.num_sampled_frm, ppls.size(-1)))
         lemma_det = {o.wtol[k]: i for k, i in o.wtod.items() if k in o.wtol}
+        words = seq.tolist()                                   # one device -> host copy each, not one per word
+        boxes_l = boxes[..., :4].tolist()
         for i in range(B):
             vid_id, seg_idx = b["seg_id"][i].split('_segment_')
             res = {'clss': [], 'idx_in_sent': [], 'bbox_for_all_frames': []}
-            for j in range(seq.size(1)):
-                w = seq[i, j].item()
+            for j, w in enumerate(words[i]):
                 if w == 0:
                     break
                 lemma = o.wtol[o.itow[str(w)]]
                 if lemma in lemma_det:
-                    res['bbox_for_all_frames'].append(boxes[i, j, :, :4].tolist())
+                    res['bbox_for_all_frames'].append(boxes_l[i][j])
                     res['clss'].append(o.itod[lemma_det[lemma]])
                     res['idx_in_sent'].append(j)
             grd_output[vid_id][str(int(seg_idx))] = res

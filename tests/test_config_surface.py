@@ -152,3 +152,33 @@ def test_eval_output_files_follow_the_reference_layout(tmp_path):
     assert p.endswith("results/attn-gen-sent-results-validation-x1.json")
     d = json.load(open(p))
     assert d["eval_mode"] == "gen" and d["results"] == grd and d["external_data"]["used"] is True
+
+
+def test_grounding_box_gather_matches_reference_logic():
+    """Trainer._collect_grounding (reference trainer.py:217-248): for every generated word whose lemma is a detection
+    class, the most attended proposal of each sampled frame."""
+    import argparse
+    from collections import defaultdict
+    import torch
+    from cvc.trainer import Trainer
+    torch.manual_seed(0)
+    B, T, nf, npf = 2, 4, 3, 5
+    o = argparse.Namespace(num_sampled_frm=nf, num_prop_per_frm=npf, itow={"1": "dog", "2": "runs", "3": "ball"},
+                           wtol={"dog": "dog", "runs": "run", "ball": "ball"}, wtod={"dog": 1, "ball": 2}, itod={1: "dog", 2: "ball"})
+    tr = Trainer(o, None, torch.nn.Linear(1, 1), None, None, None)
+    ppls = torch.rand(B, nf * npf, 7) * 100
+    att = torch.rand(B, T, nf * npf)
+    seq = torch.tensor([[1, 2, 3, 0], [2, 0, 1, 3]])
+    b = {"ppls": ppls, "seg_id": ["v_a_segment_02", "v_b_segment_10"]}
+    out = defaultdict(dict)
+    tr._collect_grounding(b, seq, att, out)
+    assert set(out) == {"v_a", "v_b"} and set(out["v_a"]) == {"2"} and set(out["v_b"]) == {"10"}
+    ra, rb = out["v_a"]["2"], out["v_b"]["10"]
+    assert ra["clss"] == ["dog", "ball"] and ra["idx_in_sent"] == [0, 2]
+    assert rb["clss"] == [] and rb["idx_in_sent"] == []                    # the sentence ends at the first 0
+    # reference: proposals are frame-major after the permute, i.e. proposal p of frame f sits at index p * nf + f
+    per = ppls.view(B, nf, npf, 7).permute(0, 2, 1, 3)
+    for k, j in enumerate(ra["idx_in_sent"]):
+        ind = att[0, j].view(nf, npf).argmax(-1)
+        want = torch.gather(per[0], 0, ind.view(1, nf, 1).expand(1, nf, 7))[0, :, :4]
+        assert torch.allclose(torch.tensor(ra["bbox_for_all_frames"][k]), want)
