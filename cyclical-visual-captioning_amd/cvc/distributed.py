@@ -61,6 +61,23 @@ def shard_batch(batch, rank: int, world: int):
     return type(batch)(cut(v, sl) for v in batch)
 
 
+def gather_eval_outputs(predictions: dict, grd_output: dict):
+    """Inference has no collective in its data path (clips are sharded); the per-rank outputs are merged host-side:
+    every rank contributes its {video: [segment predictions]} / {video: {segment: grounding}} dicts, all ranks receive
+    the union (rank order, so the result is deterministic).  No-op without an initialised process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return predictions, grd_output
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, (dict(predictions), dict(grd_output)))
+    preds, grd = {}, {}
+    for p, g in parts:
+        for vid, items in p.items():
+            preds.setdefault(vid, []).extend(items)
+        for vid, segs in g.items():
+            grd.setdefault(vid, {}).update(segs)
+    return preds, grd
+
+
 class GradReducer:
     """Bucketed, hook-driven gradient averaging across ranks."""
 

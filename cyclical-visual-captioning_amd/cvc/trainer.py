@@ -17,7 +17,7 @@ from collections import defaultdict
 import torch
 import torch.nn as nn
 
-from .distributed import GradReducer
+from .distributed import GradReducer, gather_eval_outputs
 from .prefetch import DevicePrefetcher
 from .misc import utils
 from .misc.utils import AverageMeter
@@ -189,8 +189,13 @@ class Trainer:
                 for k, sent in enumerate(sents):
                     vid_idx, seg_idx = b["seg_id"][k].split('_segment_')
                     predictions[vid_idx].append({'sentence': sent, 'segment': str(int(seg_idx))})
+        # every rank decoded its shard of the clips; merge host-side, rank 0 writes the files and scores
+        predictions, grd_output = gather_eval_outputs(predictions, grd_output)
         lang_stats = {}
         self.submission_file = self.attn_file = None
+        self.predictions = predictions
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_rank() != 0:
+            return lang_stats
         if getattr(o, "language_eval", False) and o.val_split != 'hidden_test':
             self.submission_file = write_densecap_json(predictions, o)
         if getattr(o, "eval_obj_grounding", False):

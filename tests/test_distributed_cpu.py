@@ -60,6 +60,14 @@ def _worker(rank, world, port, q):
         p1.grad = torch.ones(4) if rank == 0 else None
         red.finalize()
         np.testing.assert_allclose(p1.grad.numpy(), np.full(4, 0.5))
+        # inference outputs of the clip shards are merged host-side, identically on every rank
+        from cvc.distributed import gather_eval_outputs
+        preds = {"v_%d" % rank: [{"sentence": "s%d" % rank, "segment": "0"}], "v_shared": [{"sentence": "r%d" % rank, "segment": str(rank)}]}
+        grd = {"v_shared": {str(rank): {"clss": ["c%d" % rank]}}}
+        all_p, all_g = gather_eval_outputs(preds, grd)
+        assert set(all_p) == {"v_0", "v_1", "v_shared"}
+        assert [x["sentence"] for x in all_p["v_shared"]] == ["r0", "r1"]      # rank order
+        assert all_g == {"v_shared": {"0": {"clss": ["c0"]}, "1": {"clss": ["c1"]}}}
         # clip sharding covers the batch exactly once
         cover = [shard_range(7, r_, 2) for r_ in range(2)]
         assert cover[0].start == 0 and cover[0].stop == cover[1].start and cover[1].stop == 7
