@@ -75,6 +75,10 @@ def main(argv=None):
             trainer.train(epoch, tb)
         stats = trainer.eval(epoch, tb) if (epoch % max(opt.val_every_epoch, 1) == 0) else {}
         score = stats.get("CIDEr", 0.0)
+        if world > 1:                                   # only rank 0 scores: every rank must step its LR schedule on the same value
+            box = [score]
+            torch.distributed.broadcast_object_list(box, src=0)
+            score = box[0]
         scheduler.step(score)
         if rank == 0 and not opt.inference_only:
             os.makedirs(save_dir, exist_ok=True)
