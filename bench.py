@@ -290,7 +290,7 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "caption decode-steps/sec (BxT) at N=100,D=2048", "value": round(value, 1), "unit": "decode-steps/s",
+            "metric": f"caption decode-steps/sec (BxT) at N={d.N},D={d.R}", "value": round(value, 1), "unit": "decode-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: greedy caption decode" if args.beam == 1 else f"{args.config}: beam={args.beam} caption decode",
