@@ -16,7 +16,8 @@ namespace {
 // cross terms  hi*hi + hi*mid + mid*hi + hi*lo + lo*hi + mid*mid  (each exact in the fp32 accumulator's
 // product width); the three dropped terms are below 2^-23 |w x|, i.e. at the level of one fp32 rounding.
 // 6 bf16 MFMAs (32 cycles each, K = 16) replace 8 fp32 MFMAs (64 cycles each, K = 2): 0.375x the matrix time,
-// paid for with ~4.5 VALU ops per operand element for the split.
+// paid for with ~4.5 VALU ops per operand element for the split.  Finite operands only: an infinite input splits
+// into (inf, nan, nan) and yields NaN where the fp32 MFMA would return inf.
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned;

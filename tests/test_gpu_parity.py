@@ -334,6 +334,9 @@ def test_split_product_gemm_is_fp32_grade(dev, lib, M, K, N):
     x = torch.randn(M, K, generator=g).to(dev)
     x[:, ::7] *= 1e-3
     x[:, 3::11] *= 64.0
+    x[:, 5::13] *= 1e18                       # wide exponent range: the split terms must not over- / underflow
+    w[:, 5::13] *= 1e-18
+    x[0, :4] = torch.tensor([0.0, -0.0, 1.0, -2.0 ** -100])
     b = torch.randn(N, generator=g).to(dev)
     wp, xq = pack_weights(w), to_quad(x)
     ref = x.double() @ w.double().t() + b.double()
