@@ -156,3 +156,39 @@ def test_decode_weights_cache_follows_parameter_updates(graphed):
     assert w2 is not w1
     seq2, att2, _ = tr._call(b, True)
     assert not torch.equal(att1, att2)                                    # the decode sees the updated weights
+
+
+@pytest.mark.parametrize("B,N,F,R,A,E,V,T", [(33, 20, 16, 256, 64, 32, 50, 2), (64, 3, 5, 128, 16, 16, 50, 4),
+                                             (1, 3, 1, 256, 16, 16, 50, 4), (8, 7, 1, 128, 32, 16, 97, 2)])
+def test_cyclical_gradients_vs_oracle_on_other_shapes(B, N, F, R, A, E, V, T):
+    """Losses and every parameter gradient of the cyclical pass (eval-mode dropout) against the CPU oracle's autograd on
+    shapes the golden fixtures do not cover: two MFMA row tiles / ragged M, a single clip, one frame, widths that take the
+    backward-data GEMM's partial slabs."""
+    import dataclasses
+    from helpers import build_model, to_dev, model_call
+    from oracle import ref_cpu as O
+    dev = torch.device("cuda:0")
+    d = dataclasses.replace(synth.CONFIGS["tiny"], B=B, N=N, F=F, R=R, A=A, E=E, V=V, T=T, K=min(3, N))
+    seed = B + R
+    sd, f, b = synth.hot_path_state_dict(d, seed), synth.clip_features(d, seed), synth.label_glue_batch(d, seed)
+    P = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in O.to_torch(sd).items()}
+    for k in list(P):                                           # the reconstructor shares the decoder's LSTM cells
+        if k.startswith("attended_roi_decoder_core.") and "lstm" in k:
+            P[k] = P[k.replace("attended_roi_decoder_core.", "decoder_core.")]
+    ref = O.cyclical_forward(P, O.to_torch(f), O.to_torch(b), T=T, vocab_size=V)
+    O.training_loss(ref, xe_loss_weight=0.5, w_att2=0.05, w_cls=0.0, caption_consistency_loss_weight=0.5).backward()
+    model = build_model(d, sd, dev)
+    out = model_call(model, to_dev(f, dev), to_dev(b, dev), False)
+    for got, want in zip(out, ref):
+        assert float(got.detach().mean()) == pytest.approx(float(want.detach().mean()), rel=2e-5, abs=2e-6)
+    lm, a2, _g, _cls, rec = [x.mean() for x in out]
+    (0.5 * lm + 0.05 * a2 + 0.5 * rec).backward()
+    checked = 0
+    for n, p in model.named_parameters():
+        if n.startswith("roi_feat_extractor") or n not in P or P[n].grad is None:
+            continue
+        want = P[n].grad.double()
+        err = float((p.grad.cpu().double() - want).norm())
+        assert err <= 5e-4 * float(want.norm()) + 1e-6, (n, err, float(want.norm()))   # alpha_net.bias: true gradient ~0
+        checked += 1
+    assert checked >= 15
