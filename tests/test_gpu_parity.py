@@ -404,6 +404,28 @@ def test_module_decode_reuses_engine_across_batches(dev, lib, graph):
     assert not torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("B,N,F,R,A,E,V,T", [(33, 3, 5, 160, 128, 96, 50, 1), (2, 257, 64, 128, 64, 16, 513, 6),
+                                             (31, 257, 130, 64, 64, 32, 513, 6), (7, 1, 5, 256, 32, 32, 1000, 6),
+                                             (100, 100, 130, 160, 16, 96, 1000, 3), (64, 3, 64, 32, 16, 32, 513, 6)])
+def test_decode_other_widths_vs_oracle(dev, lib, B, N, F, R, A, E, V, T):
+    """Greedy decode vs the CPU oracle on widths the fixtures do not use (R, A, E not powers of two / not multiples of
+    32, vocabularies that end inside a 32-column block): whichever GEMM path the engine picks must agree."""
+    import dataclasses
+    from helpers import to_dev, tie_aware_seq_equal
+    from oracle import ref_cpu as O
+    from cvc.decode import DecodeEngine, DecodeWeights
+    d = dataclasses.replace(synth.CONFIGS["tiny"], B=B, N=N, F=F, R=R, A=A, E=E, V=V, T=T)
+    sd, f_np = synth.hot_path_state_dict(d, R + A), synth.clip_features(d, R + A)
+    with torch.no_grad():
+        seq_o, att_o, _, logp_o = O.greedy_sample(O.to_torch(sd), O.to_torch(f_np), T, synth.UNK_IDX, return_logprobs=True)
+    eng = DecodeEngine(DecodeWeights(to_dev(sd, dev)), to_dev(f_np, dev), T, synth.UNK_IDX)
+    seq, att = eng.run()
+    n_exact = tie_aware_seq_equal(seq.cpu().numpy(), seq_o.numpy(), logp_o.numpy())
+    assert n_exact >= 0.95 * B * T
+    if n_exact == B * T:
+        close(att, att_o, **SEQ_TOL)
+
+
 # ------------------------------------------------------------------ greedy decode (a8)
 def test_a8_greedy_tiny_golden(tiny, g1):
     from helpers import model_call, tie_aware_seq_equal
