@@ -228,21 +228,25 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
         for (int u = tid; u < 2 * 64; u += NW * 64) {
             const int m = u & 63, qd = u >> 6;
             if (m >= M || m >= MT * 32) continue;
-            f32x4 hv, cv;
-            const size_t qoff = ((size_t)(j0 / 4 + qd) * 64 + m) * 4;
+            const int jq = j0 + qd * 4;                                // first of this thread's 4 hidden units
+            const size_t qoff = ((size_t)(jq / 4) * 64 + m) * 4;
+            // every global operand of the cell update as ONE 16-byte load per gate, all issued before the first use
+            const f32x4 zero = {0, 0, 0, 0};
             const f32x4 cp = ld4(a.c_prev_q + qoff);
+            f32x4 add[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                add[g] = a.bias != nullptr ? ld4(a.bias + g * R + jq) : zero;
+                if (a.bias2 != nullptr) add[g] += ld4(a.bias2 + g * R + jq);
+                if (a.gate_bias != nullptr) add[g] += ld4(a.gate_bias + (size_t)m * 4 * R + g * R + jq);
+            }
+            f32x4 hv, cv;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int jj = qd * 4 + e, j = j0 + jj;
+                const int jj = qd * 4 + e;
                 float pre[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float v = sum_partials<NW>(red, g * 8 + jj, LDM, m);
-                    if (a.bias != nullptr) v += a.bias[g * R + j];
-                    if (a.bias2 != nullptr) v += a.bias2[g * R + j];
-                    if (a.gate_bias != nullptr) v += a.gate_bias[(size_t)m * 4 * R + g * R + j];
-                    pre[g] = v;
-                }
+                for (int g = 0; g < 4; ++g) pre[g] = sum_partials<NW>(red, g * 8 + jj, LDM, m) + add[g][e];
                 const float ig = fast_sigmoid(pre[0]), fg = fast_sigmoid(pre[1]);
                 const float gg = fast_tanh(pre[2]), og = fast_sigmoid(pre[3]);
                 const float c2 = fg * cp[e] + ig * gg;
