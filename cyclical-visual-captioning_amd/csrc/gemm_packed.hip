@@ -211,6 +211,23 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
         }
     }
 
+    // LSTM: the cell update's global operands (one work item per thread: batch row m, 4 hidden units) are requested
+    // BEFORE the cross-wave LDS stage, so that their latency runs under it
+    const int em = tid & 63, eqd = tid >> 6;
+    const bool ework = LSTM && tid < 2 * 64 && em < M && em < MT * 32;
+    const int ejq = (int)blockIdx.x * 8 + eqd * 4;                     // first of this thread's 4 hidden units
+    const size_t eqoff = ((size_t)(ejq / 4) * 64 + em) * 4;
+    f32x4 ecp = {0, 0, 0, 0}, eadd[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    if (ework) {
+        ecp = ld4(a.c_prev_q + eqoff);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (a.bias != nullptr) eadd[g] = ld4(a.bias + g * R + ejq);
+            if (a.bias2 != nullptr) eadd[g] += ld4(a.bias2 + g * R + ejq);
+            if (a.gate_bias != nullptr) eadd[g] += ld4(a.gate_bias + (size_t)em * 4 * R + g * R + ejq);
+        }
+    }
+
     // ---- ordered cross-wave reduction (same scheme as combine_and_store)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -224,38 +241,23 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
     if (LSTM) {
         // unit u -> (batch row m fastest, quad-of-hidden qd in 0..1): a thread finishes 4 hidden units
         // and stores them as one float4 in quad layout (64 rows x 16 B contiguous per quad)
-        const int j0 = blockIdx.x * 8;
-        for (int u = tid; u < 2 * 64; u += NW * 64) {
-            const int m = u & 63, qd = u >> 6;
-            if (m >= M || m >= MT * 32) continue;
-            const int jq = j0 + qd * 4;                                // first of this thread's 4 hidden units
-            const size_t qoff = ((size_t)(jq / 4) * 64 + m) * 4;
-            // every global operand of the cell update as ONE 16-byte load per gate, all issued before the first use
-            const f32x4 zero = {0, 0, 0, 0};
-            const f32x4 cp = ld4(a.c_prev_q + qoff);
-            f32x4 add[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                add[g] = a.bias != nullptr ? ld4(a.bias + g * R + jq) : zero;
-                if (a.bias2 != nullptr) add[g] += ld4(a.bias2 + g * R + jq);
-                if (a.gate_bias != nullptr) add[g] += ld4(a.gate_bias + (size_t)m * 4 * R + g * R + jq);
-            }
+        if (ework) {
             f32x4 hv, cv;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int jj = qd * 4 + e;
+                const int jj = eqd * 4 + e;
                 float pre[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) pre[g] = sum_partials<NW>(red, g * 8 + jj, LDM, m) + add[g][e];
+                for (int g = 0; g < 4; ++g) pre[g] = sum_partials<NW>(red, g * 8 + jj, LDM, em) + eadd[g][e];
                 const float ig = fast_sigmoid(pre[0]), fg = fast_sigmoid(pre[1]);
                 const float gg = fast_tanh(pre[2]), og = fast_sigmoid(pre[3]);
-                const float c2 = fg * cp[e] + ig * gg;
+                const float c2 = fg * ecp[e] + ig * gg;
                 cv[e] = c2;
                 hv[e] = og * fast_tanh(c2);
             }
-            st4(a.c_out_q + qoff, cv);
-            if (a.h_dst1_q != nullptr) st4(a.h_dst1_q + qoff, hv);
-            if (a.h_dst2_q != nullptr) st4(a.h_dst2_q + qoff, hv);
+            st4(a.c_out_q + eqoff, cv);
+            if (a.h_dst1_q != nullptr) st4(a.h_dst1_q + eqoff, hv);
+            if (a.h_dst2_q != nullptr) st4(a.h_dst2_q + eqoff, hv);
         }
     } else {
         const int n0 = blockIdx.x * 32;
