@@ -228,6 +228,15 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
         }
     }
 
+    // linear variant with the fused top-2 epilogue: the biases of the columns this wave scans, requested here too
+    constexpr int ECPW = 32 / NW;
+    float ebias[ECPW];
+#pragma unroll
+    for (int c = 0; c < ECPW; ++c) {
+        const int n = (int)blockIdx.x * 32 + wave * ECPW + c;
+        ebias[c] = (!LSTM && a.top2_part != nullptr && a.bias != nullptr) ? a.bias[n < a.Nout ? n : a.Nout - 1] : 0.f;
+    }
+
     // ---- ordered cross-wave reduction (same scheme as combine_and_store)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -279,11 +288,11 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
             int i1 = 0x7fffffff, i2 = 0x7fffffff;
             const int m = lane < MT * 32 ? lane : MT * 32 - 1;
             constexpr int CPW = 32 / NW;                          // columns scanned per wave
-            for (int nl = wave * CPW; nl < wave * CPW + CPW; ++nl) {
-                const int n = n0 + nl;
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) {
+                const int nl = wave * CPW + c, n = n0 + nl;
                 if (n >= a.Nout) break;
-                float v = sum_partials<NW>(red, nl, LDM, m);
-                if (a.bias != nullptr) v += a.bias[n];
+                const float v = sum_partials<NW>(red, nl, LDM, m) + ebias[c];
                 if (v > v1) { v2 = v1; i2 = i1; v1 = v; i1 = n; }
                 else if (v > v2) { v2 = v; i2 = n; }
                 const float nm = fmaxf(mx, v);
