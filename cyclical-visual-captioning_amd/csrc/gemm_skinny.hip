@@ -134,10 +134,11 @@ __device__ __forceinline__ void combine_and_store(f32x16 (&acc)[MT], float* red,
     __syncthreads();
 
     if (LSTM) {
-        // unit u -> (hidden jj in 0..7, batch row m); reads along m are conflict-free
+        // unit u -> (batch row m, hidden jj in 0..7 fastest): 8 lanes share a 32-byte piece of a row-major state row
+        // (with m fastest every lane touched its own line); LDS reads stay conflict-free (LDM is odd)
         const int j0 = blockIdx.x * 8;
         for (int u = tid; u < 8 * MT * 32; u += NW * 64) {
-            const int m = u % (MT * 32), jj = u / (MT * 32);
+            const int jj = u & 7, m = u >> 3;
             if (m >= M) continue;
             const int j = j0 + jj;
             float pre[4];
