@@ -167,7 +167,9 @@ __global__ __launch_bounds__(WG) void top2_unk_kernel(const float* logits, int V
     s = block_sum(s, red);
     if (threadIdx.x == 0) {
         const bool use2 = (t.i1 == unk) && V > 1;        // captioner.py:417-421
-        word[(size_t)row * wstride] = use2 ? t.i2 : t.i1;
+        int w = use2 ? t.i2 : t.i1;
+        if ((unsigned)w >= (unsigned)V) w = 0;             // all-NaN row (diverged checkpoint): nothing compares greater; stay in range
+        word[(size_t)row * wstride] = w;
         if (logprob != nullptr) logprob[row] = (use2 ? t.v2 : t.v1) - (m + logf(s));
     }
 }
@@ -208,7 +210,9 @@ __global__ __launch_bounds__(WG) void top2_final_kernel(const float* part, int n
     se = block_sum(se, red);
     if (threadIdx.x == 0) {
         const bool use2 = (t.i1 == unk) && t.i2 != 0x7fffffff;          // captioner.py:417-421
-        const int w = use2 ? t.i2 : t.i1;
+        int w = use2 ? t.i2 : t.i1;
+        if (w == 0x7fffffff || w < 0) w = 0;               // all-NaN logits: no record ever compared greater; the word is
+                                                           // also a gather address (table + w * E) here and next step
         word[(size_t)row * wstride] = w;
         if (logprob != nullptr) logprob[row] = (use2 ? t.v2 : t.v1) - (mx + logf(se));
         chosen = w;
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(WG) void vocab_nll_fwd_kernel(const float* logits, 
     if (threadIdx.x == 0) {
         const float lse = bm + logf(s);
         lse_out[row] = lse;
-        if (argmax != nullptr) argmax[row] = best;
+        if (argmax != nullptr) argmax[row] = best == 0x7fffffff ? 0 : best;      // all-NaN row: keep the index in range
         const float wm = w[row];
         row_loss[row] = wm != 0.f ? wm * (lse - x[target[row]]) : 0.f;
     }
@@ -419,7 +423,8 @@ __global__ __launch_bounds__(64) void beam_merge_kernel(const float* cand_v, con
             if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
         }
         if (lane == 0) {
-            const int kk = bi / V, vv = bi - kk * V;
+            int kk = bi / V, vv = bi - kk * V;
+            if (bi == 0x7fffffff) { kk = 0; vv = 0; }      // every candidate NaN: parent / word feed gathers, keep them in range
             parent[b * beam + sel] = kk;
             word[b * beam + sel] = vv;
             score_out[b * beam + sel] = bv;

@@ -35,6 +35,11 @@ class SyntheticCaptionDataset(Dataset):
         self.itod = {i: "cls%d" % i for i in range(1, dims.DET + 1)}
         self.ltow, self.itoc, self.wtod = {}, {}, {}
         self.vocab_size = dims.V
+        # segment timestamps in the layout of the ANet-Entities annotation file the reference's eval reads
+        # (opts.grd_reference -> ['annotations'][video]['segments'][segment]['timestamps'], trainer.py:162, 259-260)
+        self.grd_reference = {"annotations": {
+            "v_synth%05d" % i: {"segments": {"0": {"timestamps": [round(1.5 * i, 3), round(1.5 * i + 7.25, 3)]}}}
+            for i in range(n_clips)}}
 
     def __len__(self):
         return self.d.B

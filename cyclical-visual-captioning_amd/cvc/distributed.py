@@ -39,9 +39,12 @@ def init_from_env(backend: str = "nccl") -> Tuple[int, int, int]:
     return rank, world, local_rank
 
 
-def shard_range(n: int, rank: int, world: int) -> slice:
-    """Contiguous split of n clips; the first n % world ranks get one extra clip."""
+def shard_range(n: int, rank: int, world: int, equal: bool = False) -> slice:
+    """Contiguous split of n clips; the first n % world ranks get one extra clip.  equal=True drops the remainder
+    instead, so that every rank holds exactly n // world clips (same number of steps and collectives on every rank)."""
     base, extra = divmod(n, world)
+    if equal:
+        return slice(rank * base, (rank + 1) * base)
     start = rank * base + min(rank, extra)
     return slice(start, start + base + (1 if rank < extra else 0))
 

@@ -48,7 +48,9 @@ def main(argv=None):
     dims = synth.Dims(B=opt.batch_size, N=opt.num_prop_per_frm, F=opt.t_attn_size, R=opt.rnn_size, A=opt.att_hid_size,
                       E=opt.input_encoding_size, T=opt.seq_length, G=opt.vis_encoding_size, K=min(8, opt.num_prop_per_frm))
     full = SyntheticCaptionDataset(dims, opt.synthetic_clips, opt.seed, opt.train_split, raw=opt.synthetic_raw)
-    sl = shard_range(len(full), rank, world)                                          # clips are sharded across ranks
+    # clips are sharded across ranks; every rank gets the SAME number of clips (the remainder is dropped) so that all
+    # ranks run the same number of steps and issue the same collectives
+    sl = shard_range(len(full), rank, world, equal=True)
     train_set = torch.utils.data.Subset(full, range(sl.start, sl.stop))
     per_rank_bs = max(1, opt.batch_size // world)
     loader = DataLoader(train_set, batch_size=per_rank_bs, shuffle=True, num_workers=0, collate_fn=collate, drop_last=True)
@@ -62,37 +64,75 @@ def main(argv=None):
         opt.vg_cls, opt.detectron_tables = full.vg_cls, full.tables
 
     model = build_model(opt, device)
+    save_dir = os.path.join(opt.checkpoint_path, opt.exp_name)
+
+    # ---- resume (reference main.py:119-163): state_dict + infos (+ histories) of `model.pth` or `model-best.pth`
+    infos, histories = {}, {}
+    if opt.resume:
+        suffix = "-best" if opt.load_best_score else ""
+        model_path = os.path.join(save_dir, "model%s.pth" % suffix)
+        info_path = os.path.join(save_dir, "infos_" + opt.id + suffix + ".pkl")
+        with open(info_path, "rb") as f:
+            infos = pickle.load(f)
+        model.load_state_dict(torch.load(model_path, map_location=device))
+        hist_path = os.path.join(save_dir, "histories_" + opt.id + ".pkl")
+        if os.path.isfile(hist_path):
+            with open(hist_path, "rb") as f:
+                histories = pickle.load(f)
+        if rank == 0:
+            print("resumed %s (epoch %s, best CIDEr %s)" % (model_path, infos.get("epoch"), infos.get("best_val_score")))
+    elif opt.inference_only:
+        raise SystemExit("--inference_only needs --resume True (a checkpoint under %s): refusing to evaluate randomly "
+                         "initialised weights" % save_dir)
+    best = infos.get("best_val_score", None)
+    if opt.resume_decoder_exp_name != "" and not opt.resume:                           # reference main.py:156-160
+        start_epoch = getattr(opt, "start_epoch", 0)
+    else:
+        start_epoch = infos.get("epoch", 0)
+    val_result_history = histories.get("val_result_history", {})
+    lr_history = histories.get("lr_history", {})
+
     optimizer = build_optimizer(model, opt)
     reducer = GradReducer(model.named_parameters()) if world > 1 else None
     trainer = Trainer(opt, full, model, optimizer, loader, val_loader, grad_reducer=reducer)
     scheduler = ReduceLROnPlateau(optimizer, 'max', patience=opt.patience, min_lr=opt.min_lr)
     tb = utils.set_tb_logger(opt.tb_log_dir, opt.exp_name, opt.resume) if (rank == 0 and opt.tensorboard and not opt.inference_only) else None
 
-    save_dir = os.path.join(opt.checkpoint_path, opt.exp_name)
-    best = None
-    for epoch in range(getattr(opt, "start_epoch", 0), opt.max_epochs):
+    for epoch in range(start_epoch, opt.max_epochs):
         if not opt.inference_only:
             trainer.train(epoch, tb)
-        stats = trainer.eval(epoch, tb) if (epoch % max(opt.val_every_epoch, 1) == 0) else {}
-        score = stats.get("CIDEr", 0.0)
-        if world > 1:                                   # only rank 0 scores: every rank must step its LR schedule on the same value
+        if epoch % max(opt.val_every_epoch, 1) != 0:        # reference main.py:221: scheduler + checkpoints only with an eval
+            continue
+        stats = trainer.eval(epoch, tb)
+        if opt.inference_only:
+            break
+        score = stats.get("CIDEr")                            # None without an external scorer
+        if world > 1:                                         # only rank 0 scores: every rank must step its LR schedule alike
             box = [score]
             torch.distributed.broadcast_object_list(box, src=0)
             score = box[0]
-        scheduler.step(score)
-        if rank == 0 and not opt.inference_only:
+        if score is not None:                                 # no score -> no plateau evidence: leave the LR alone
+            scheduler.step(score)
+        if rank == 0:
             os.makedirs(save_dir, exist_ok=True)
+            best_flag = score is not None and (best is None or score > best)
+            if best_flag:
+                best = score
             torch.save(model.state_dict(), os.path.join(save_dir, "model.pth"))
-            infos = {"epoch": epoch, "best_val_score": best, "opt": {k: v for k, v in vars(opt).items() if _picklable(v)}}
+            val_result_history[epoch] = dict(stats)
+            lr_history[epoch] = optimizer.param_groups[0]["lr"]
+            infos = {"iter": (epoch + 1) * max(len(loader) - 1, 0), "epoch": epoch, "best_val_score": best, "vocab": full.itow,
+                     "opt": {k: v for k, v in vars(opt).items() if _picklable(v)}}
+            histories = {"val_result_history": val_result_history, "loss_history": {}, "lr_history": lr_history,
+                         "ss_prob_history": {}}
             with open(os.path.join(save_dir, "infos_" + opt.id + ".pkl"), "wb") as f:
                 pickle.dump(infos, f)
-            if best is None or score > best:
-                best = score
+            with open(os.path.join(save_dir, "histories_" + opt.id + ".pkl"), "wb") as f:
+                pickle.dump(histories, f)
+            if best_flag or not os.path.isfile(os.path.join(save_dir, "model-best.pth")):
                 torch.save(model.state_dict(), os.path.join(save_dir, "model-best.pth"))
                 with open(os.path.join(save_dir, "infos_" + opt.id + "-best.pkl"), "wb") as f:
                     pickle.dump(infos, f)
-        if opt.inference_only:
-            break
     return 0
 
 

@@ -88,6 +88,9 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         self.xe_criterion = utils.LanguageCriterion()
         self.beam_size = int(getattr(opts, "beam_size", 1))
         self.use_hip_graph = bool(getattr(opts, "hip_graph", False))
+        # test hook: set to a dict to receive the training pass's intermediate tensors (ground_weights, att2_weights,
+        # output_seq) that the reference computes as locals of _forward_3_loops and never returns
+        self.debug_collect: Optional[dict] = None
 
     # ------------------------------------------------------------------ small pieces
     @property
@@ -210,6 +213,9 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
             bias = 0
         ground_weights = self._grounder(xt_all, g_pool_feats, frm_mask_output[:, :, 1:], bias + att2_weights)
 
+        if self.debug_collect is not None:
+            self.debug_collect.update(ground_weights=ground_weights, att2_weights=att2_weights, roi_labels=roi_labels,
+                                      frm_mask_output=frm_mask_output)
         target = gt_caption[:, 1:T + 1].clone()
         # criteria fused with log_softmax and the argmax cut of :313 (one pass over the logits, no [B,T,V] log-probs)
         lm_loss, att2_loss, ground_loss, output_seq = self.critLM.from_logits(

@@ -33,26 +33,56 @@ def _stream_key(seed: int, stream: str) -> np.uint64:
     return np.uint64((int(seed) * 0x100000001B3 + zlib.crc32(stream.encode())) & 0xFFFFFFFFFFFFFFFF)
 
 
-def _u01(n: int, seed: int, stream: str, lane: int = 0) -> np.ndarray:
-    """n doubles in (0, 1), 53-bit mantissa, from counters [0, n)."""
-    key = _splitmix64(np.asarray([_stream_key(seed, stream) + np.uint64(lane)], dtype=np.uint64))[0]
+def _u01_range(key: np.uint64, lo: int, hi: int) -> np.ndarray:
     with np.errstate(over="ignore"):
-        ctr = (np.arange(n, dtype=np.uint64) * np.uint64(2) + np.uint64(1)) * np.uint64(0x2545F4914F6CDD1D)
+        ctr = (np.arange(lo, hi, dtype=np.uint64) * np.uint64(2) + np.uint64(1)) * np.uint64(0x2545F4914F6CDD1D)
         bits = _splitmix64((ctr ^ key) & _MASK64)
     return ((bits >> np.uint64(11)).astype(np.float64) + 0.5) * (1.0 / 9007199254740992.0)
 
 
+_CHUNK = 1 << 22
+
+
+def _chunked(n: int, fn, dtype) -> np.ndarray:
+    """fn(lo, hi) -> values of counters [lo, hi); large arrays are filled chunk by chunk on a few threads (numpy releases
+    the GIL inside its loops).  The values depend on the counter only, so the result is identical for any chunking."""
+    if n <= _CHUNK:
+        return fn(0, n).astype(dtype, copy=False)
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    out = np.empty(n, dtype=dtype)
+
+    def work(lo):
+        out[lo:min(lo + _CHUNK, n)] = fn(lo, min(lo + _CHUNK, n))
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        list(ex.map(work, range(0, n, _CHUNK)))
+    return out
+
+
+def _key(seed: int, stream: str, lane: int = 0) -> np.uint64:
+    return _splitmix64(np.asarray([_stream_key(seed, stream) + np.uint64(lane)], dtype=np.uint64))[0]
+
+
+def _u01(n: int, seed: int, stream: str, lane: int = 0) -> np.ndarray:
+    """n doubles in (0, 1), 53-bit mantissa, from counters [0, n)."""
+    key = _key(seed, stream, lane)
+    return _chunked(n, lambda lo, hi: _u01_range(key, lo, hi), np.float64)
+
+
 def uniform(shape, seed: int, stream: str, lo: float = 0.0, hi: float = 1.0) -> np.ndarray:
     n = int(np.prod(shape)) if len(shape) else 1
-    return (lo + (hi - lo) * _u01(n, seed, stream)).astype(np.float32).reshape(shape)
+    key = _key(seed, stream)
+    return _chunked(n, lambda a, b: (lo + (hi - lo) * _u01_range(key, a, b)).astype(np.float32), np.float32).reshape(shape)
 
 
 def normal(shape, seed: int, stream: str) -> np.ndarray:
     n = int(np.prod(shape)) if len(shape) else 1
-    u1 = _u01(n, seed, stream, 0)
-    u2 = _u01(n, seed, stream, 1)
-    z = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
-    return z.astype(np.float32).reshape(shape)
+    k0, k1 = _key(seed, stream, 0), _key(seed, stream, 1)
+
+    def box_muller(a, b):
+        u1, u2 = _u01_range(k0, a, b), _u01_range(k1, a, b)
+        return (np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)).astype(np.float32)
+    return _chunked(n, box_muller, np.float32).reshape(shape)
 
 
 def randint(shape, seed: int, stream: str, lo: int, hi: int) -> np.ndarray:

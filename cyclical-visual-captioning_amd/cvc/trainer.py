@@ -170,14 +170,32 @@ class Trainer:
             tb_logger.add_scalar('train/cls_loss', meters["cls"].avg, epoch)
             tb_logger.add_scalar('train/lm_recon_loss', meters["recon"].avg, epoch)
 
+    def _segment_timestamps(self):
+        """{video: {segment: [start, end]}} of the validation segments: the reference reads them from the ANet-Entities
+        annotation file `opts.grd_reference` (trainer.py:162) as ['annotations'][vid]['segments'][seg]['timestamps']; a
+        dataset object may carry the same structure as `dataset.grd_reference` (the synthetic stand-in does)."""
+        if getattr(self, "_timestamps", None) is None:
+            src = getattr(self.dataset, "grd_reference", None)
+            if src is None:
+                path = getattr(self.opts, "grd_reference", None)
+                if not path or not os.path.isfile(path):
+                    raise FileNotFoundError(
+                        f"eval needs the segment timestamps (opts.grd_reference = {path!r}, reference trainer.py:162): the "
+                        "densecap file the ANETcaptions evaluator reads carries a 'timestamp' per predicted segment")
+                with open(path) as f:
+                    src = json.load(f)
+            self._timestamps = src['annotations']
+        return self._timestamps
+
     def eval(self, epoch, tb_logger=None):
         """Greedy (or beam) decode of the validation split -> predictions in the densecap JSON
-        layout (trainer.py:276-286) -> optional external scorer."""
+        layout (trainer.py:254-286: {'sentence', 'timestamp': [start, end]} per segment) -> optional external scorer."""
         self.model.eval()
         predictions = defaultdict(list)
         grd_output = defaultdict(dict)
         o = self.opts
         ds = self.dataset
+        timestamps = self._segment_timestamps()
         with torch.no_grad():
             for b in DevicePrefetcher(self.val_loader, lambda raw: self._prepare(raw, False), self.device):
                 seq, att2_weights, _ = self._call(b, True)
@@ -187,8 +205,8 @@ class Trainer:
                 sents = utils.decode_sequence(ds.itow, getattr(ds, "itod", None), getattr(ds, "ltow", None),
                                               getattr(ds, "itoc", None), getattr(ds, "wtod", None), seq.data, o.vocab_size, o)
                 for k, sent in enumerate(sents):
-                    vid_idx, seg_idx = b["seg_id"][k].split('_segment_')
-                    predictions[vid_idx].append({'sentence': sent, 'segment': str(int(seg_idx))})
+                    vid_idx, entry = densecap_entry(sent, b["seg_id"][k], timestamps)
+                    predictions[vid_idx].append(entry)
         # every rank decoded its shard of the clips; merge host-side, rank 0 writes the files and scores
         predictions, grd_output = gather_eval_outputs(predictions, grd_output)
         lang_stats = {}
@@ -231,6 +249,16 @@ class Trainer:
                     res['clss'].append(o.itod[lemma_det[lemma]])
                     res['idx_in_sent'].append(j)
             grd_output[vid_id][str(int(seg_idx))] = res
+
+
+def densecap_entry(sentence, seg_id, timestamps):
+    """One element of predictions[video] as the reference builds it (trainer.py:253-261): the sentence plus the segment's
+    [start, end] from the annotation file, rounded to 2 decimals -- what the ANETcaptions evaluator matches on.
+    `segment` (the segment index as a string) is an extra key for the multi-rank merge and debugging."""
+    vid_idx, seg_idx = seg_id.split('_segment_')
+    seg_idx = str(int(seg_idx))
+    stamps = timestamps[vid_idx]['segments'][seg_idx]['timestamps']
+    return vid_idx, {'sentence': sentence, 'timestamp': [round(ts, 2) for ts in stamps], 'segment': seg_idx}
 
 
 def _results_path(o, stem):

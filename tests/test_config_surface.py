@@ -141,6 +141,15 @@ def test_eval_output_files_follow_the_reference_layout(tmp_path):
     from cvc.trainer import write_densecap_json, write_grounding_json
     o = argparse.Namespace(results_dir=str(tmp_path / "results"), val_split="validation", id="x1")
     pred = defaultdict(list)
+    from cvc.trainer import densecap_entry
+    # reference trainer.py:253-261: {'sentence', 'timestamp': [round(t, 2) ...]} looked up in opts.grd_reference's
+    # ['annotations'][video]['segments'][segment]['timestamps'] -- the key the ANETcaptions evaluator reads
+    stamps = {"v_abc": {"segments": {"3": {"timestamps": [12.3456, 20.0049]}}}}
+    vid, entry = densecap_entry("a man rides", "v_abc_segment_03", stamps)
+    assert vid == "v_abc" and entry["sentence"] == "a man rides" and entry["timestamp"] == [12.35, 20.0]
+    assert set(entry) >= {"sentence", "timestamp"}
+    with pytest.raises(KeyError):
+        densecap_entry("x", "v_abc_segment_04", stamps)
     pred["v_abc"].append({"sentence": "a man rides", "segment": "3"})
     p = write_densecap_json(pred, o)
     assert p.endswith("results/densecap-validation-x1.json")

@@ -65,18 +65,36 @@ def test_main_entry_point_one_epoch(tmp_path):
     import os
     from cvc import main as cvc_main
     from conftest import GOLDEN
-    rc = cvc_main.main(["--no_cfg", "--max_epochs", "1", "--batch_size", "4", "--synthetic_clips", "12", "--num_prop_per_frm", "7",
-                        "--t_attn_size", "5", "--rnn_size", "32", "--att_hid_size", "16", "--input_encoding_size", "16",
-                        "--seq_length", "4", "--vis_encoding_size", "24", "--tensorboard", "0", "--disp_interval", "100",
-                        "--checkpoint_path", str(tmp_path) + "/", "--exp_name", "t", "--learning_rate", "0.001",
-                        "--language_eval", "--results_dir", str(tmp_path / "results"), "--id", "t1"])
+    common = ["--no_cfg", "--max_epochs", "1", "--batch_size", "4", "--synthetic_clips", "12", "--num_prop_per_frm", "7",
+              "--t_attn_size", "5", "--rnn_size", "32", "--att_hid_size", "16", "--input_encoding_size", "16",
+              "--seq_length", "4", "--vis_encoding_size", "24", "--tensorboard", "0", "--disp_interval", "100",
+              "--exp_name", "t", "--learning_rate", "0.001", "--language_eval", "--results_dir", str(tmp_path / "results")]
+    rc = cvc_main.main(common + ["--checkpoint_path", str(tmp_path) + "/", "--id", "t1"])
     assert rc == 0
     dense = json.load(open(tmp_path / "results" / "densecap-validation-t1.json"))
     assert len(dense["results"]) == 12 and all("sentence" in r[0] for r in dense["results"].values())
+    # reference trainer.py:256-260: every predicted segment carries its [start, end] timestamp, rounded to 2 decimals
+    for vid, segs in dense["results"].items():
+        i = int(vid[len("v_synth"):])
+        assert segs[0]["timestamp"] == [round(1.5 * i, 2), round(1.5 * i + 7.25, 2)]
     sd = torch.load(os.path.join(tmp_path, "t", "model-best.pth"), map_location="cpu")
     ref_keys = set(json.load(open(os.path.join(GOLDEN, "config_surface.json")))["state_dict"])
     assert set(sd.keys()) == ref_keys
     assert os.path.exists(os.path.join(tmp_path, "t", "infos_t1-best.pkl"))
+    import pickle
+    infos = pickle.load(open(os.path.join(tmp_path, "t", "infos_t1.pkl"), "rb"))
+    hist = pickle.load(open(os.path.join(tmp_path, "t", "histories_t1.pkl"), "rb"))
+    assert infos["epoch"] == 0 and "best_val_score" in infos and set(hist) >= {"val_result_history", "lr_history"}
+    lr0 = hist["lr_history"][0]
+    assert lr0 == pytest.approx(0.001)                    # no scorer -> no CIDEr -> the plateau scheduler is not stepped
+    # --inference_only without a checkpoint must refuse (the reference loads model.pth first, main.py:121-147)
+    with pytest.raises(SystemExit):
+        cvc_main.main(common + ["--inference_only", "--checkpoint_path", str(tmp_path / "nowhere") + "/", "--id", "t1"])
+    # --resume restores the saved weights: inference on the resumed model reproduces the first run's sentences
+    rc = cvc_main.main(common + ["--inference_only", "--resume", "True", "--checkpoint_path", str(tmp_path) + "/", "--id", "t1"])
+    assert rc == 0
+    dense2 = json.load(open(tmp_path / "results" / "densecap-validation-t1.json"))
+    assert dense2["results"] == dense["results"]
 
 
 def test_main_entry_point_raw_features_through_encoder(tmp_path):

@@ -104,3 +104,17 @@ def test_cache_plan_keeps_the_largest_subset_that_fits():
     assert all(cache_plan(1000, {"ppool": 100, "pconv": 100, "pool": 100, "conv": 100}).values())
     plan = cache_plan(0, cfg2, budget=100 << 20)
     assert sum(cfg2[k] for k, v in plan.items() if v) == 26214400 + 52428800   # best fit under 100 MiB
+
+
+def test_equal_clip_shards_give_every_rank_the_same_step_count():
+    """cvc.distributed.shard_range(equal=True): 127 clips on 2 ranks with per-rank batch 32 and drop_last must not leave one
+    rank with 1 step and the other with 0 (mismatched collectives hang RCCL)."""
+    from cvc.distributed import shard_range
+    for n, world in ((127, 2), (12, 8), (256, 8), (5, 3), (3, 4)):
+        sizes = [len(range(*shard_range(n, r, world, equal=True).indices(n))) for r in range(world)]
+        assert len(set(sizes)) == 1 and sizes[0] == n // world
+        spans = [shard_range(n, r, world, equal=True) for r in range(world)]
+        assert all(spans[r].stop == spans[r + 1].start for r in range(world - 1))       # contiguous, disjoint
+    # the ragged default still covers every clip exactly once (inference sharding)
+    cover = [i for r in range(3) for i in range(*shard_range(10, r, 3).indices(10))]
+    assert cover == list(range(10))
