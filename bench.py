@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: caption decode-steps/sec (B x T per full greedy decode) on MI355X.
 
-  python bench.py --gpus 1 --steps 20 --warmup 3                      # BASELINE config 2
+  python bench.py                                                     # BASELINE config 2, 300 timed decodes (>= 1 s)
+  python bench.py --gpus 1 --steps 20 --warmup 5                      # what the driver runs
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one batch: the full T-step greedy decode of B clips
@@ -40,8 +41,11 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 32x32x16 (same guide); the packed 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--steps", type=int, default=300, help="timed steps (default: >= 1 s of decodes at cfg2)")
+    p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--min-warm-seconds", type=float, default=0.5,
+                   help="untimed: keep replaying after the W warm-up steps until this much wall time has passed, so that the "
+                        "timed K steps start at settled clocks (a 20-step region is 80 ms)")
     p.add_argument("--config", default="cfg2", help="cvc.synth.CONFIGS key (cfg2 = B=64,N=100,D=2048,T=20 greedy)")
     for k in ("B", "N", "F", "R", "A", "E", "V", "T"):
         p.add_argument("--" + k, type=int, default=None)
@@ -73,6 +77,32 @@ def usable_cores() -> int:
         except Exception:
             pass
     return max(1, n)
+
+
+def pmc_traffic(kernel, args, over, mode="decode"):
+    """HBM bytes per launch of `kernel` from the tracked PMC collection (profiles/traffic.json, written by
+    tools/collect_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very command).
+    The file records the hash of the kernel sources it was collected on; numbers from any other build are REFUSED
+    (traffic = null plus the reason) instead of printed as if they were current."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None, "profiles/traffic.json absent"
+    try:
+        tf = json.load(open(path))
+    except Exception as e:
+        return None, f"profiles/traffic.json unreadable: {e}"
+    import build_hip
+    have = build_hip.source_hash()
+    if tf.get("source_hash") != have:
+        return None, f"stale: collected on kernel sources {tf.get('source_hash')}, this build is {have}"
+    want = dict(config=args.config, beam=args.beam, mode=mode)
+    got = {k: tf.get("workload", {}).get(k) for k in want}
+    if over or got != want:
+        return None, f"collected for {tf.get('workload')}, not for this workload"
+    ent = tf.get("kernels", {}).get(kernel)
+    if not ent:
+        return None, f"no PMC entry for {kernel}"
+    return int(ent["hbm_bytes"]), f"{ent['symbol']} ({ent['dispatches']} dispatches; 2 x FETCH_SIZE + WRITE_SIZE, KiB units)"
 
 
 def algorithmic_work(d, beam):
@@ -121,11 +151,16 @@ def run_train(args, d, dev, rank, world):
     import torch.distributed as dist
     dist_on = dist.is_available() and dist.is_initialized()
     step = tr.train_step_graphed if args.train_graph else tr.train_step
+    w0 = time.perf_counter()
     for _ in range(args.warmup):
         step(batch)
     torch.cuda.synchronize()
+    while time.perf_counter() - w0 < args.min_warm_seconds:
+        step(batch)
+        torch.cuda.synchronize()
     if dist_on:
         dist.barrier()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step(batch)[0]
@@ -135,15 +170,112 @@ def run_train(args, d, dev, rank, world):
         dist.barrier()
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     el = float(el.item())
+    ms_step = el / args.steps * 1e3
+
+    # ---- per-entry-point GPU time of one step: HIP events around every C-ABI launch (eager steps, launch stream)
+    roof, kernels, cpu = None, [], None
     if rank == 0:
-        print(json.dumps({
+        from cvc import hip
+        work = train_work(d)
+        timers = hip.enable_timers()
+        nprobe = 2
+        tr.train_step(batch)
+        torch.cuda.synchronize()
+        timers.clear()
+        for _ in range(nprobe):
+            tr.train_step(batch)
+        torch.cuda.synchronize()
+        hip.disable_timers()
+        tot = {k: sum(a.elapsed_time(b) for a, b in v) / nprobe for k, v in timers.items()}      # ms per step
+        cnt = {k: len(v) // nprobe for k, v in timers.items()}
+        ours = sum(tot.values())
+        for name in sorted(tot, key=lambda k: -tot[k]):
+            ent = dict(kernel=name, launches_per_step=cnt[name], ms_per_step=round(tot[name], 3), avg_us=round(tot[name] / cnt[name] * 1e3, 2),
+                       share=round(tot[name] / ms_step, 4))
+            wk = work.get(name)
+            if wk:
+                # work totals are per STEP (all launches of the entry point); per launch = total / launches
+                per_b, per_f = wk["bytes"] / cnt[name], wk["flops"] / cnt[name]
+                avg_s = tot[name] / cnt[name] * 1e-3
+                gbs, tf = per_b / avg_s / 1e9, per_f / avg_s / 1e12
+                peak_tf = MFMA_BF16_PEAK_TFLOPS / 6 if wk["mfma"] == "split" else MFMA_F32_PEAK_TFLOPS
+                bound = "mfma" if per_f / (peak_tf * 1e12) > per_b / (HBM_PEAK_GBS * 1e9) else "hbm"
+                ent.update(algorithmic_bytes=int(per_b), algorithmic_flops=int(per_f), achieved_GBs=round(gbs, 1),
+                           frac_hbm=round(gbs / HBM_PEAK_GBS, 4), achieved_TFLOPs=round(tf, 2), mfma_peak_TFLOPs=round(peak_tf, 1),
+                           frac_mfma=round(tf / peak_tf, 4), bound=bound, mfma=wk["mfma"])
+            kernels.append(ent)
+        kernels.append(dict(kernel="(library / ATen kernels and gaps: Adam, clip, autograd glue)", ms_per_step=round(ms_step - ours, 3),
+                            share=round((ms_step - ours) / ms_step, 4)))
+        dom = next((e for e in kernels if "bound" in e), None)
+        if dom is not None:
+            traffic, note = pmc_traffic(dom["kernel"], args, None, mode="train")
+            if dom["bound"] == "mfma":
+                roof = dict(kernel=dom["kernel"], bound="mfma", achieved=dom["achieved_TFLOPs"], peak=dom["mfma_peak_TFLOPs"],
+                            unit="TFLOP/s", frac=dom["frac_mfma"], traffic=traffic, traffic_source=note, avg_us=dom["avg_us"],
+                            peak_note="fp32-equivalent flops; split-product kernels issue 6 bf16 MFMAs per fp32 product, so their "
+                                      "roof is the dense bf16 peak / 6" if dom["mfma"] == "split" else "f32 MFMA 32x32x2")
+            else:
+                roof = dict(kernel=dom["kernel"], bound="hbm", achieved=dom["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=dom["frac_hbm"], traffic=traffic, traffic_source=note, avg_us=dom["avg_us"],
+                            algorithmic_bytes=dom["algorithmic_bytes"])
+        # ---- CPU baseline: the oracle's cyclical forward + autograd backward on this box's host cores, one step of the
+        # same workload (eval-mode dropout: the reference's train-mode backward does not run on torch 2.x)
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import ref_cpu as O
+            ncores = usable_cores()
+            torch.set_num_threads(ncores)
+            f_np, b_np = synth.clip_features(d, args.seed), synth.label_glue_batch(d, args.seed)
+            sd_np = synth.hot_path_state_dict(d, args.seed)
+            best = None
+            for rep in range(1 + max(1, args.cpu_repeats - 1)):
+                P = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in O.to_torch(sd_np).items()}
+                for k in list(P):
+                    if k.startswith("attended_roi_decoder_core.") and "lstm" in k:
+                        P[k] = P[k.replace("attended_roi_decoder_core.", "decoder_core.")]
+                c0 = time.perf_counter()
+                ls = O.cyclical_forward(P, O.to_torch(f_np), O.to_torch(b_np), T=d.T, vocab_size=d.V)
+                O.training_loss(ls, xe_loss_weight=0.5, w_att2=0.0, w_cls=0.0, caption_consistency_loss_weight=0.5).backward()
+                dt = time.perf_counter() - c0
+                if rep > 0 or args.cpu_repeats == 1:
+                    best = dt if best is None else min(best, dt)
+                del P, ls
+            cpu = dict(value=round(d.B * d.T / best, 1), unit="decode-steps/s", cores=torch.get_num_threads(), kind="port",
+                       sample=f"one cyclical forward + backward of the same workload (B={d.B}, T={d.T}; no optimizer step), warm-up 1, "
+                              f"best of {max(1, args.cpu_repeats - 1)}; torch {torch.__version__} CPU autograd, {ncores} host cores",
+                       seconds=round(best, 3))
+    if rank == 0:
+        line = {
             "metric": "cyclical train decode-steps/sec (BxT per fwd+bwd+update)", "value": round(d.B * d.T * world * args.steps / el, 1),
             "unit": "decode-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "samples_per_s": round(d.B * world * args.steps / el, 2), "loss": float(loss),
-            "config": {"workload": f"{args.config}: cyclical train step (decode+localize+reconstruct fwd, bwd, Adam)",
-                       "B_per_gpu": d.B, "N": d.N, "F": d.F, "D": d.R, "T": d.T,
-                       "parallelism": f"dp{world}: clips sharded, one RCCL gradient all-reduce per step"}}), flush=True)
+            "config": {"workload": f"{args.config}: cyclical train step (decode+localize+reconstruct fwd, bwd, clip, Adam), train-mode dropout",
+                       "B_per_gpu": d.B, "N": d.N, "F": d.F, "D": d.R, "T": d.T, "hip_graph": bool(args.train_graph),
+                       "parallelism": f"dp{world}: clips sharded, one RCCL gradient all-reduce per step"},
+            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels}
+        if cpu:
+            line["gpu_over_cpu"] = round(line["value"] / cpu["value"], 1)
+        print(json.dumps(line), flush=True)
+
+
+def train_work(d):
+    """Algorithmic bytes / flops per training STEP of the C-ABI entry points that carry the dense work (cyclical pass,
+    train_decoder_only = False; SURVEY.md section 8(d) training formulas).  Weights stream once per launch; M = B rows per
+    step-wise launch, M = B*T for the T-batched ones.  `mfma`: which matrix instruction executes the products."""
+    B, N, F, R, A, E, V, T = d.B, d.N, d.F, d.R, d.A, d.E, d.V, d.T
+    w = {}
+    k_att, k_lang = E + 3 * R, 3 * R                       # K of the two cells (fc segment included in training)
+    # forward cells: Loop A + Loop C, T launches each per cell
+    w["cvc_lstm_cell_fwd"] = dict(bytes=2 * T * 4 * (4 * R * (k_att + k_lang)) + 2 * T * 4 * B * (k_att + k_lang + 12 * R),
+                                  flops=2 * T * 2 * B * 4 * R * (k_att + k_lang), mfma="split")
+    # backward-data of the cells: every input range except fc_feats (features carry no gradient in the bench)
+    kx = (E + 2 * R) + 3 * R
+    w["cvc_linear_nn_fwd"] = dict(bytes=2 * T * 4 * 4 * R * kx + 2 * T * 4 * B * (8 * R + kx), flops=2 * T * 2 * B * 4 * R * kx, mfma="f32")
+    # attention: Loop A (T launches, nq = 1) + Loop B (1 launch, nq = T): each streams proj + ctx of both sets once
+    att_bytes = 4 * B * (N + F) * (A + R)
+    w["cvc_attn_fwd"] = dict(bytes=(T + 1) * att_bytes, flops=(T + T) * B * (N + F) * (4 * A + 2 * R), mfma="none")
+    w["cvc_attn_bwd"] = dict(bytes=2 * (T + 1) * att_bytes, flops=2 * (T + T) * B * (N + F) * (4 * A + 2 * R), mfma="none")
+    return w
 
 
 def main():
@@ -199,8 +331,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    w0 = time.perf_counter()
     for _ in range(args.warmup):
         eng.run()
+    torch.cuda.synchronize()
+    while time.perf_counter() - w0 < args.min_warm_seconds:      # untimed: DVFS / cache warm-up beyond the W steps
+        eng.run()
+        torch.cuda.synchronize()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -252,20 +389,15 @@ def main():
             kernels.append(ent)
         kernels.sort(key=lambda e: -(e["share"] or 0))
         dom = next(e for e in kernels if "achieved_GBs" in e)
-        traffic = None
-        tf_path = os.path.join(ROOT, "profiles", "traffic.json")      # PMC-derived HBM bytes per launch (cfg2), if collected
-        if os.path.exists(tf_path) and args.config == "cfg2" and not over and args.beam == 1:
-            try:
-                traffic = json.load(open(tf_path)).get(dom["kernel"])
-            except Exception:
-                traffic = None
+        traffic, traffic_note = pmc_traffic(dom["kernel"], args, over)
         if dom["bound"] == "mfma":
             roof = dict(kernel=dom["kernel"], bound="mfma", achieved=dom["achieved_TFLOPs"], peak=dom["mfma_peak_TFLOPs"],
-                        unit="TFLOP/s", frac=dom["frac_mfma"], traffic=traffic, avg_us=dom["avg_us"],
-                        hbm_frac=dom["frac_hbm"])
+                        unit="TFLOP/s", frac=dom["frac_mfma"], traffic=traffic, traffic_source=traffic_note,
+                        avg_us=dom["avg_us"], hbm_frac=dom["frac_hbm"])
         else:
             roof = dict(kernel=dom["kernel"], bound="hbm", achieved=dom["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=dom["frac_hbm"], traffic=traffic, avg_us=dom["avg_us"])
+                        frac=dom["frac_hbm"], traffic=traffic, traffic_source=traffic_note, avg_us=dom["avg_us"],
+                        algorithmic_bytes=dom["algorithmic_bytes"])
 
     # ---- CPU baseline: the oracle on this box's host cores, same workload (rank 0, N=1 only)
     cpu = None

@@ -26,6 +26,17 @@ def deps():
         [os.path.join(os.path.dirname(HERE), "include", "cvc_hip.h")]
 
 
+def source_hash() -> str:
+    """sha256 over the kernel sources + the C-ABI header (sorted by name): identifies the build that a PMC collection
+    (profiles/traffic.json) belongs to; bench.py refuses byte counts collected on other sources."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(deps(), key=os.path.basename):
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def up_to_date() -> bool:
     if not os.path.exists(OUT):
         return False

@@ -94,6 +94,40 @@ def version() -> str:
     return lib().cvc_version().decode()
 
 
+# --------------------------------------------------------------------------- per-entry-point HIP-event timing (bench.py)
+_raw_fns = {}
+
+
+def enable_timers() -> dict:
+    """Bracket every C-ABI launch with a HIP-event pair on the launch stream (torch's current stream, which is the stream
+    handed to the entry point).  Returns the dict that fills up: entry-point name -> [(start_event, end_event)].
+    Measurement aid for bench.py (--mode train); the product path never enables it."""
+    l = lib()
+    timers: dict = {}
+    if _raw_fns:
+        disable_timers()
+    for name in SIGNATURES:
+        raw = getattr(l, name)
+        _raw_fns[name] = raw
+
+        def timed(*args, _raw=raw, _name=name):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = _raw(*args)
+            e1.record()
+            timers.setdefault(_name, []).append((e0, e1))
+            return rc
+        setattr(l, name, timed)
+    return timers
+
+
+def disable_timers():
+    l = lib()
+    for name, raw in _raw_fns.items():
+        setattr(l, name, raw)
+    _raw_fns.clear()
+
+
 def _check(rc: int, name: str):
     if rc != 0:
         kind = {-1: "bad argument (size/alignment precondition)", -2: "dimension not covered by the kernel templates"}.get(
