@@ -376,7 +376,7 @@ def main():
                 if "flops" in wk:
                     # matrix work as EXECUTED: the packed path takes every fp32 product as six bf16 cross terms
                     # (cvc_gemm_packed_split), the row-major path issues fp32 MFMAs
-                    split = eng.packed and split_mode > 0
+                    split = (eng.packed and split_mode > 0) or getattr(eng, "tile", False)
                     mult, peak, what = (6, MFMA_BF16_PEAK_TFLOPS, "bf16 32x32x16, 6 per fp32 product") if split else \
                                        (1, MFMA_F32_PEAK_TFLOPS, "f32 32x32x2")
                     tf = mult * wk["flops"] / (avg * 1e-3) / 1e12
@@ -430,7 +430,8 @@ def main():
                        "hip_graph": not args.no_graph, "parallelism": f"clips sharded over {world} rank(s), no collective",
                        "gemm_arithmetic": ("f32 in / f32 accumulate; products = exact 3-way bf16 split of both operands, 6 leading "
                                            "cross terms on the bf16 MFMA (error vs f64 <= the f32-MFMA path's, tests/test_gpu_parity.py)")
-                       if (eng.packed and gemm_mode > 0) else "f32 MFMA"},
+                       if ((eng.packed and gemm_mode > 0) or getattr(eng, "tile", False)) else "f32 MFMA",
+                       "engine_path": "packed" if eng.packed else ("tile" if getattr(eng, "tile", False) else "ring")},
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
         }
         if cpu:

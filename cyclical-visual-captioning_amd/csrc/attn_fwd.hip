@@ -26,7 +26,27 @@ struct WsumArgs {
     int nsets, nq, R;
     float* ctx_sum;               // [rows, R] or null
     int ctx_quad;                 // 1: ctx_sum is written in the GEMM's quad layout [R/4][64][4] (rows <= 64)
+                                  // 2: as bf16 split-term fragments of the tile GEMM (gemm_tile.hip), row-block stride below
+    long long frag_stride;
 };
+
+// 4 consecutive columns of row m as the three bf16 terms (hi, mid, lo: exact truncation split, gemm_split.h) inside the
+// 1 KiB fragments [k half][row & 31][8 k] of the tile GEMM's activation layout
+__device__ __forceinline__ void store_ctx_frag(uint16_t* xb, long long mblk_stride, int m, int k, const f32x4 v) {
+    using u16x4 = __attribute__((ext_vector_type(4))) uint16_t;
+    u16x4 p[3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned u0 = __float_as_uint(v[e]);
+        const float r1 = v[e] - __uint_as_float(u0 & 0xffff0000u);
+        const unsigned u1 = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+        p[0][e] = (uint16_t)(u0 >> 16); p[1][e] = (uint16_t)(u1 >> 16); p[2][e] = (uint16_t)(__float_as_uint(r2) >> 16);
+    }
+    uint16_t* base = xb + (size_t)(m >> 5) * mblk_stride + (size_t)(k >> 4) * 1536 + (((k >> 3) & 1) * 32 + (m & 31)) * 8 + (k & 7);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u16x4*>(base + pl * 512) = p[pl];
+}
 
 __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -107,7 +127,8 @@ __global__ __launch_bounds__(WG) void attn_wsum_kernel(WsumArgs a) {
         __syncthreads();
     }
     if (a.ctx_sum != nullptr && wave == 0 && col_ok) {
-        if (a.ctx_quad) st4(a.ctx_sum + ((size_t)(col >> 2) * 64 + row) * 4, total);
+        if (a.ctx_quad == 2) store_ctx_frag(reinterpret_cast<uint16_t*>(a.ctx_sum), a.frag_stride, row, col, total);
+        else if (a.ctx_quad) st4(a.ctx_sum + ((size_t)(col >> 2) * 64 + row) * 4, total);
         else st4(a.ctx_sum + (size_t)row * R + col, total);
     }
 }
@@ -147,7 +168,7 @@ extern "C" int cvc_attn_scores_qparts(int kind, const float* q_parts, int q_npar
 }
 
 static int wsum_impl(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum, int ctx_quad,
-                     cvc_stream_t stream);
+                     cvc_stream_t stream, long long frag_stride = 0);
 
 extern "C" int cvc_attn_wsum(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum,
                              cvc_stream_t stream) {
@@ -160,15 +181,21 @@ extern "C" int cvc_attn_wsum_quad(const cvc_attn_set* sets, int nsets, int nclip
     return wsum_impl(sets, nsets, nclip, nq, R, ctx_sum_q, 1, stream);
 }
 
+extern "C" int cvc_attn_wsum_frag(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, void* ctx_frag,
+                                  long long frag_mblk_stride, cvc_stream_t stream) {
+    if (ctx_frag == nullptr || (R & 15) || (frag_mblk_stride & 3)) return CVC_E_BADARG;
+    return wsum_impl(sets, nsets, nclip, nq, R, (float*)ctx_frag, 2, stream, frag_mblk_stride);
+}
+
 static int wsum_impl(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum, int ctx_quad,
-                     cvc_stream_t stream) {
+                     cvc_stream_t stream, long long frag_stride) {
     int n_max;
     int rc = check_sets(sets, nsets, nclip, nq, 0, R, &n_max);
     if (rc) return rc;
     WsumArgs wa;
     wa.set[0] = sets[0];
     wa.set[1] = nsets > 1 ? sets[1] : sets[0];
-    wa.nsets = nsets; wa.nq = nq; wa.R = R; wa.ctx_sum = ctx_sum; wa.ctx_quad = ctx_quad;
+    wa.nsets = nsets; wa.nq = nq; wa.R = R; wa.ctx_sum = ctx_sum; wa.ctx_quad = ctx_quad; wa.frag_stride = frag_stride;
     const size_t lds2 = (4 * 64 * 4 + 16 + n_max) * sizeof(float);
     if (lds2 > 64 * 1024) return CVC_E_TOOBIG;
     dim3 g2((R + 255) / 256, nclip * nq);

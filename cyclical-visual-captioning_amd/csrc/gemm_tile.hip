@@ -1,0 +1,405 @@
+// Tile GEMM of the decode engine for MORE than 64 live rows (beam search: rows = clips x beam; big greedy batches),
+// its finishing kernels, and the beam-state reorder that feeds it.
+//
+// Why a second GEMM family: with 64 rows the gate GEMMs are weight-streaming problems (gemm_packed.hip: one workgroup = 32
+// weight rows x all rows x full K, operands straight into registers).  With 320 rows (cfg3 / cfg5, beam 5) the same tiling needs
+// (32 + 320) operand rows per 32 x 320 products: 70 B of L2 ingress per matrix-pipe cycle and CU, three times what a CU can take
+// in, and the row-major ring kernel it used to fall back to re-streamed the weights once per 64-row slab.  Here:
+//
+//   * one workgroup = 128 weight rows x up to 320 rows x K / ksplit; 8 waves = 4 weight blocks x 2 row halves, every wave
+//     owning 32 x (32 * MH) outputs (MH <= 5 accumulator tiles, 80 registers);
+//   * BOTH operands are stored in HBM the way the matrix pipe wants them: split once into the three bf16 terms of the
+//     split-product arithmetic (gemm_split.h: v = hi + mid + lo exactly) and cut into 1 KiB fragments = 32 rows x 16 k of one
+//     term, ordered [k half][row][8 k] = the lane order of v_mfma_f32_32x32x16_bf16's A / B operand.  Weights are packed once
+//     per checkpoint (cvc/decode.py::pack_weights_tile), activations are written in this form by their producers (the finishing
+//     kernels below, attn_wsum, beam_reorder_pack), so the K loop has NO operand-preparation VALU work at all;
+//   * a K step (16 k) of the tile is (4 + 2 MH) x 3 fragments = 42 KiB at MH = 5, copied by LDS-DMA (global_load_lds_dwordx4, one
+//     fragment per wave instruction, lane-linear = the fragment itself, so fragment reads are conflict-free ds_read_b128 with no
+//     swizzle) into a 3-stage ring: two stages in flight, ONE raw s_barrier per stage, counted s_waitcnt vmcnt;
+//   * per stage a wave issues 3 + 3 MH ds_read_b128 and 6 MH MFMAs (the six leading cross terms, small terms first);
+//   * K is split over workgroups so that 256 of them exist (N / 128 tiles x ksplit); the partial tiles go to fp32 row-major
+//     slabs [ksplit][rows, ld] and are summed IN A FIXED ORDER by the consumer that exists anyway: the LSTM finishing kernel
+//     (bias + gate non-linearities + cell update), the attention score kernel (query partials, attn_scores.h), or
+//     tile_linear_finish (vocabulary logits).
+//
+// Arithmetic is the same as the packed path's split mode (6 bf16 MFMAs per 16 k, fp32 accumulate): fp32-grade error
+// (tests/test_gpu_parity.py::test_tile_gemm_vs_fp64).
+#include "cvc_common.h"
+#include "gemm_split.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+#ifndef CVC_TILE_VARIANT
+#define CVC_TILE_VARIANT 1
+#endif
+constexpr int FRAG = 512;              // bf16 elements per fragment (32 rows x 16 k) = 1 KiB
+constexpr int KSTEP = 3 * FRAG;        // bf16 elements per (block, k step): three split terms
+
+struct TileArgs {
+    const uint16_t* wb;        // [nblk_pad][w_ksteps][3][FRAG]   packed weights, nblk_pad a multiple of 4
+    const uint16_t* xb;        // [mblk][...][3][FRAG]            packed activations, first k step of this GEMM's K range
+    long long x_mblk_stride;   // bf16 elements between consecutive 32-row blocks of xb
+    int ksteps;                // K / 16
+    int M, N;                  // live rows / output features (store guards)
+    int ntile;                 // ceil(N / 128)
+    int ksplit;
+    float* parts;              // [ksplit] slabs, row-major [M, ld]
+    int ld;
+    long long part_stride;
+};
+
+template <int MH>
+__global__ __launch_bounds__(512) void tile_gemm_kernel(TileArgs a) {
+    constexpr int NX = 2 * MH;                  // 32-row activation blocks per workgroup
+    constexpr int NF = (4 + NX) * 3;            // fragments per stage
+    constexpr int ND = (NF + 7) / 8;            // LDS-DMA instructions per wave and stage
+    constexpr int STAGE = NF * 1024;
+    constexpr int NSTAGE = 3;
+    __shared__ __attribute__((aligned(16))) char lds[NSTAGE * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wbk = wave & 3, mh = wave >> 2;
+    // workgroup -> (weight tile, K slice).  Speed only: workgroups are dispatched round-robin over the 8 XCDs (private L2s), so
+    // when ksplit divides 8 every XCD is given ONE K slice: its L2 then pulls 1 / ksplit of the activations instead of all of
+    // them (at 320 x 6144 the activations are 11.8 MB of fragments against 4 MB of L2)
+    int tile = (int)blockIdx.x % a.ntile, ks = (int)blockIdx.x / a.ntile;
+#ifndef CVC_TILE_NO_XCD
+    if (a.ksplit > 1 && a.ksplit <= 8 && 8 % a.ksplit == 0 && a.ntile % (8 / a.ksplit) == 0) {
+        const int g = 8 / a.ksplit, xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+        ks = xcd / g;
+        tile = j * g + xcd % g;
+    }
+#endif
+    const int mb0 = (int)blockIdx.y * NX;
+    const int s_lo = (int)((long long)a.ksteps * ks / a.ksplit), s_hi = (int)((long long)a.ksteps * (ks + 1) / a.ksplit);
+    const int nst = s_hi - s_lo;
+
+    // this wave's share of a stage's fragments: f = wave + 8 j.  NF is not a multiple of 8: the first NF % 8 waves copy one
+    // fragment more than the others (their counted vmcnt is one higher; the wave index is uniform, so that is a scalar branch)
+    constexpr int NDLO = NF / 8, NEXTRA = NF % 8;
+    const bool extra = NEXTRA != 0 && wave < NEXTRA;
+    const uint16_t* src[ND];
+    int dst[ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+        int f = wave + 8 * j;
+        if (f >= NF) f -= NF;                    // (never copied: j == NDLO is issued by waves < NEXTRA only)
+        const int g = f < 12 ? f : f - 12;
+        const int blk = g / 3, pl = g - blk * 3;
+        if (f < 12) src[j] = a.wb + ((size_t)(tile * 4 + blk) * a.ksteps + s_lo) * KSTEP + pl * FRAG + lane * 8;
+        else src[j] = a.xb + (size_t)(mb0 + blk) * a.x_mblk_stride + (size_t)s_lo * KSTEP + pl * FRAG + lane * 8;
+        dst[j] = f * 1024;
+    }
+    auto issue = [&](int s, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NDLO; ++j)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[j] + (size_t)s * KSTEP), (lds_ptr_t)(lds + buf * STAGE + dst[j]), 16, 0, 0);
+        if constexpr (NEXTRA != 0)
+            if (extra)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[NDLO] + (size_t)s * KSTEP), (lds_ptr_t)(lds + buf * STAGE + dst[NDLO]), 16, 0, 0);
+    };
+
+    f32x16 acc[MH];
+#pragma unroll
+    for (int t = 0; t < MH; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    if (nst > 0) issue(0, 0);
+    if (nst > 1) issue(1, 1);
+    int buf = 0;
+    for (int s = 0; s < nst; ++s) {
+        // stage s has landed once at most the copies of stage s + 1 are still outstanding
+        if (s + 1 < nst) {
+            if (extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDLO + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDLO) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();           // every wave's copies of stage s are in LDS; stage s - 1 has been read by all
+#if !defined(CVC_TILE_ABL) || CVC_TILE_ABL != 2
+        if (s + 2 < nst) issue(s + 2, buf == 0 ? 2 : buf - 1);
+#else
+        if (s + 2 < nst && extra) asm volatile("s_nop 0");    // ablation 2: no copies after the prologue (compute side only)
+#endif
+        const char* base = lds + buf * STAGE + lane * 16;
+        auto frag = [&](int f) __attribute__((always_inline)) { return *reinterpret_cast<const u32x4*>(base + f * 1024); };
+        // fragment reads of tile t + 1 are issued before the six MFMAs of tile t, so that LDS latency runs under the matrix pipe
+        u32x4 w[3], x[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) { w[pl] = frag(wbk * 3 + pl); x[0][pl] = frag(12 + (mh * MH) * 3 + pl); }
+#pragma unroll
+        for (int t = 0; t < MH; ++t) {
+            if (t + 1 < MH) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) x[(t + 1) & 1][pl] = frag(12 + (mh * MH + t + 1) * 3 + pl);
+            }
+            const u32x4* xt = x[t & 1];
+#if CVC_TILE_VARIANT >= 1
+            __builtin_amdgcn_sched_barrier(0);      // the next tile's reads are issued BEFORE this tile's MFMAs
+#endif
+#if CVC_TILE_VARIANT == 2
+            __builtin_amdgcn_s_setprio(1);
+#endif
+#if defined(CVC_TILE_ABL) && CVC_TILE_ABL == 1
+            asm volatile("" ::"v"(xt[0]), "v"(xt[1]), "v"(xt[2]), "v"(w[0]), "v"(w[1]), "v"(w[2]));   // ablation 1: memory side only
+            continue;
+#endif
+            // D[i = activation row][j = weight row] += X[i][k] W[j][k]; terms 0 / 1 / 2 = hi / mid / lo, small products first
+            acc[t] = mfma_bf16(xt[1], w[1], acc[t]);
+            acc[t] = mfma_bf16(xt[0], w[2], acc[t]);
+            acc[t] = mfma_bf16(xt[2], w[0], acc[t]);
+            acc[t] = mfma_bf16(xt[0], w[1], acc[t]);
+            acc[t] = mfma_bf16(xt[1], w[0], acc[t]);
+            acc[t] = mfma_bf16(xt[0], w[0], acc[t]);
+            // pin the order: [3 reads of the next tile] then [6 MFMAs]
+#if CVC_TILE_VARIANT == 2
+            __builtin_amdgcn_s_setprio(0);
+#endif
+#if CVC_TILE_VARIANT >= 1
+            __builtin_amdgcn_sched_barrier(0);
+#else
+            if (t == 0) __builtin_amdgcn_sched_group_barrier(0x100, MH > 1 ? 9 : 6, 0);
+            else if (t + 1 < MH) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+#endif
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+
+    // partial tile -> slab ks, row-major: lane = output feature (32 consecutive floats per half wave), register = row
+    float* out = a.parts + (size_t)ks * a.part_stride;
+    const int n = (tile * 4 + wbk) * 32 + (lane & 31);
+    const int kh = lane >> 5;
+#if defined(CVC_TILE_ABL) && CVC_TILE_ABL == 3
+    if (acc[0][0] == 12345.678f)                              // ablation 3: no epilogue stores
+#endif
+    if (n < a.N) {
+#pragma unroll
+        for (int t = 0; t < MH; ++t) {
+            const int mbase = (mb0 + mh * MH + t) * 32 + 4 * kh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                if (m < a.M) out[(size_t)m * a.ld + n] = acc[t][r];
+            }
+        }
+    }
+}
+
+// ---- split one fp32 into its three bf16 terms (same truncation as gemm_split.h::split8)
+__device__ __forceinline__ void split3(float v, uint16_t& hi, uint16_t& mid, uint16_t& lo) {
+    const unsigned u0 = __float_as_uint(v);
+    const float r1 = v - __uint_as_float(u0 & 0xffff0000u);
+    const unsigned u1 = __float_as_uint(r1);
+    const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+    hi = (uint16_t)(u0 >> 16); mid = (uint16_t)(u1 >> 16); lo = (uint16_t)(__float_as_uint(r2) >> 16);
+}
+
+using u16x4 = __attribute__((ext_vector_type(4))) uint16_t;
+
+// 4 consecutive k of activation row m, starting at k (k % 4 == 0), into the three term fragments of its block
+__device__ __forceinline__ void store_frag4(uint16_t* xb, long long mblk_stride, int m, int k, const f32x4 v) {
+    u16x4 p[3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        uint16_t h, mi, l;
+        split3(v[e], h, mi, l);
+        p[0][e] = h; p[1][e] = mi; p[2][e] = l;
+    }
+    uint16_t* base = xb + (size_t)(m >> 5) * mblk_stride + (size_t)(k >> 4) * KSTEP + (((k >> 3) & 1) * 32 + (m & 31)) * 8 + (k & 7);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u16x4*>(base + pl * FRAG) = p[pl];
+}
+
+struct LstmFinishArgs {
+    const float* parts; int nparts; long long part_stride;   // slabs [M, 4R], feature order = packed: blk * 32 + gate * 8 + unit
+    const float* b_ih; const float* b_hh;                    // [4R] checkpoint order (gate * R + hidden), nullable
+    const float* gate_bias; int gb_div;                      // [ceil(M / gb_div), 4R] checkpoint order, row m / gb_div; nullable
+    const float* c_prev;                                     // [M, R]
+    float* c_out; float* h_out;                              // [M, R]; h_out nullable
+    uint16_t* frag1; long long frag1_stride;                 // h' as activation fragments (pointer at its first k step), nullable
+    uint16_t* frag2; long long frag2_stride;
+    int M, R;
+};
+
+__global__ __launch_bounds__(256) void tile_lstm_finish_kernel(LstmFinishArgs a) {
+    const int R = a.R;
+    const int q = blockIdx.x * 256 + threadIdx.x;            // (row m, hidden quad)
+    const int nq = R >> 2;
+    if (q >= a.M * nq) return;
+    const int m = q / nq, j = (q - m * nq) * 4;              // hidden units j .. j + 3
+    const int col = (j >> 3) * 32 + (j & 7);                 // packed feature index of gate 0
+    f32x4 pre[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 s = ld4(a.parts + (size_t)m * 4 * R + col + g * 8);
+        for (int p = 1; p < a.nparts; ++p) s += ld4(a.parts + (size_t)p * a.part_stride + (size_t)m * 4 * R + col + g * 8);
+        if (a.b_ih != nullptr) s += ld4(a.b_ih + g * R + j);
+        if (a.b_hh != nullptr) s += ld4(a.b_hh + g * R + j);
+        if (a.gate_bias != nullptr) s += ld4(a.gate_bias + (size_t)(m / a.gb_div) * 4 * R + g * R + j);
+        pre[g] = s;
+    }
+    const f32x4 cp = ld4(a.c_prev + (size_t)m * R + j);
+    f32x4 hv, cv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float ig = fast_sigmoid(pre[0][e]), fg = fast_sigmoid(pre[1][e]);
+        const float gg = fast_tanh(pre[2][e]), og = fast_sigmoid(pre[3][e]);
+        const float c2 = fg * cp[e] + ig * gg;
+        cv[e] = c2;
+        hv[e] = og * fast_tanh(c2);
+    }
+    st4(a.c_out + (size_t)m * R + j, cv);
+    if (a.h_out != nullptr) st4(a.h_out + (size_t)m * R + j, hv);
+    if (a.frag1 != nullptr) store_frag4(a.frag1, a.frag1_stride, m, j, hv);
+    if (a.frag2 != nullptr) store_frag4(a.frag2, a.frag2_stride, m, j, hv);
+}
+
+// y[m, n] = sum_p parts[p][m, n] + bias[n] + bias2[n]      (vocabulary logits / gate_fc of the tile path)
+__global__ __launch_bounds__(256) void tile_linear_finish_kernel(const float* parts, int nparts, long long part_stride, int ld,
+                                                                 const float* bias, const float* bias2, int M, int N, float* y,
+                                                                 int ldy) {
+    const int n = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
+    if (n >= N) return;
+    float s = parts[(size_t)m * ld + n];
+    for (int p = 1; p < nparts; ++p) s += parts[(size_t)p * part_stride + (size_t)m * ld + n];
+    if (bias != nullptr) s += bias[n];
+    if (bias2 != nullptr) s += bias2[n];
+    y[(size_t)m * ldy + n] = s;
+}
+
+// fp32 row-major [M, K] (optionally gathered rows, optional ReLU) -> activation fragments
+__global__ __launch_bounds__(256) void tile_pack_rows_kernel(const float* x, int ldx, const int64_t* idx, int relu, int M, int K,
+                                                             uint16_t* xb, long long mblk_stride) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int nq = K >> 2;
+    if (q >= M * nq) return;
+    const int m = q / nq, k = (q - m * nq) * 4;
+    const int64_t r = idx != nullptr ? idx[m] : (int64_t)m;
+    f32x4 v = ld4(x + (size_t)r * ldx + k);
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    store_frag4(xb, mblk_stride, m, k, v);
+}
+
+// After word / beam selection of step t: row r of step t + 1 continues hypothesis src = (r / beam) * beam + parent[r]
+// (parent == nullptr: r itself).  Builds, in one pass over the four state tensors, everything step t + 1 reads:
+//   c_att_prev / c_lang_prev [rows, R]  <- c_att / c_lang [src]
+//   xa = [h_lang[src] | relu(Emb[word[r]]) | h_att[src]]   (att-LSTM input fragments, K = 2R + E)
+//   xl third segment <- h_lang[src]                        (lang-LSTM input fragments, k offset 2R)
+struct ReorderArgs {
+    const int64_t* parent; const int64_t* word; int beam;
+    const float* h_att; const float* c_att; const float* h_lang; const float* c_lang;   // [rows, R] of step t
+    const float* table; int E; int V;
+    float* c_att_prev; float* c_lang_prev;
+    uint16_t* xa; long long xa_stride;
+    uint16_t* xl_hlang; long long xl_stride;     // pointer at k step 2R / 16 of xl
+    int rows, R;
+};
+
+__global__ __launch_bounds__(256) void tile_reorder_pack_kernel(ReorderArgs a) {
+    const int R = a.R, E = a.E;
+    const int nq = (2 * R + E) >> 2;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= a.rows * nq) return;
+    const int r = q / nq, k = (q - r * nq) * 4;
+    const int src = a.parent != nullptr ? (r / a.beam) * a.beam + (int)a.parent[r] : r;
+    if (k < R) {                                   // h_lang -> xa segment 0 and xl segment 2; c_lang rides along
+        const f32x4 h = ld4(a.h_lang + (size_t)src * R + k);
+        store_frag4(a.xa, a.xa_stride, r, k, h);
+        store_frag4(a.xl_hlang, a.xl_stride, r, k, h);
+        st4(a.c_lang_prev + (size_t)r * R + k, ld4(a.c_lang + (size_t)src * R + k));
+    } else if (k < R + E) {
+        int64_t w = a.word[r];
+        if (w < 0 || w >= a.V) w = 0;
+        f32x4 v = ld4(a.table + (size_t)w * E + (k - R));
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        store_frag4(a.xa, a.xa_stride, r, k, v);
+    } else {
+        const int kk = k - R - E;
+        store_frag4(a.xa, a.xa_stride, r, k, ld4(a.h_att + (size_t)src * R + kk));
+        st4(a.c_att_prev + (size_t)r * R + kk, ld4(a.c_att + (size_t)src * R + kk));
+    }
+}
+
+}  // namespace
+
+extern "C" int cvc_tile_gemm(const void* wb, const void* xb, long long x_mblk_stride, int K, int M, int N, int ksplit,
+                             float* parts, int ld, long long part_stride, cvc_stream_t stream) {
+    if (!wb || !xb || !parts || K < 16 || (K & 15) || M < 1 || N < 1 || ksplit < 1 || ksplit > K / 16 || ld < N) return CVC_E_BADARG;
+    if (((uintptr_t)wb & 15) || ((uintptr_t)xb & 15) || (x_mblk_stride & 7)) return CVC_E_BADARG;
+    TileArgs a;
+    a.wb = (const uint16_t*)wb; a.xb = (const uint16_t*)xb; a.x_mblk_stride = x_mblk_stride; a.ksteps = K / 16;
+    a.M = M; a.N = N; a.ntile = (N + 127) / 128; a.ksplit = ksplit; a.parts = parts; a.ld = ld; a.part_stride = part_stride;
+    const int mblk = (M + 31) / 32;
+    const hipStream_t st = (hipStream_t)stream;
+    // rows are walked in chunks of 2 MH blocks; MH = 5 (320 rows) per chunk when there are more than 320
+    int MH = mblk >= 10 ? 5 : (mblk + 1) / 2;
+    const int chunks = (mblk + 2 * MH - 1) / (2 * MH);
+    const dim3 grid(a.ntile * ksplit, chunks);
+    switch (MH) {
+        case 1: hipLaunchKernelGGL(tile_gemm_kernel<1>, grid, dim3(512), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(tile_gemm_kernel<2>, grid, dim3(512), 0, st, a); break;
+        case 3: hipLaunchKernelGGL(tile_gemm_kernel<3>, grid, dim3(512), 0, st, a); break;
+        case 4: hipLaunchKernelGGL(tile_gemm_kernel<4>, grid, dim3(512), 0, st, a); break;
+        default: hipLaunchKernelGGL(tile_gemm_kernel<5>, grid, dim3(512), 0, st, a); break;
+    }
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_tile_rows_alloc(int M) {
+    const int mblk = (M + 31) / 32;
+    const int MH = mblk >= 10 ? 5 : (mblk + 1) / 2;
+    const int chunks = (mblk + 2 * MH - 1) / (2 * MH);
+    return chunks * 2 * MH * 32;
+}
+
+extern "C" int cvc_tile_lstm_finish(const float* parts, int nparts, long long part_stride, const float* b_ih, const float* b_hh,
+                                    const float* gate_bias, int gb_div, const float* c_prev, int M, int R, float* c_out,
+                                    float* h_out, void* frag1, long long frag1_stride, void* frag2, long long frag2_stride,
+                                    cvc_stream_t stream) {
+    if (!parts || nparts < 1 || !c_prev || !c_out || M < 1 || R < 16 || (R & 15) || gb_div < 1) return CVC_E_BADARG;
+    LstmFinishArgs a;
+    a.parts = parts; a.nparts = nparts; a.part_stride = part_stride; a.b_ih = b_ih; a.b_hh = b_hh; a.gate_bias = gate_bias;
+    a.gb_div = gb_div; a.c_prev = c_prev; a.c_out = c_out; a.h_out = h_out; a.frag1 = (uint16_t*)frag1; a.frag1_stride = frag1_stride;
+    a.frag2 = (uint16_t*)frag2; a.frag2_stride = frag2_stride; a.M = M; a.R = R;
+    const long long n = (long long)M * (R / 4);
+    hipLaunchKernelGGL(tile_lstm_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_tile_linear_finish(const float* parts, int nparts, long long part_stride, int ld, const float* bias,
+                                      const float* bias2, int M, int N, float* y, int ldy, cvc_stream_t stream) {
+    if (!parts || nparts < 1 || !y || M < 1 || N < 1 || ld < N || ldy < N) return CVC_E_BADARG;
+    hipLaunchKernelGGL(tile_linear_finish_kernel, dim3((N + 255) / 256, M), dim3(256), 0, (hipStream_t)stream, parts, nparts,
+                       part_stride, ld, bias, bias2, M, N, y, ldy);
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_tile_pack_rows(const float* x, int ldx, const int64_t* idx, int relu, int M, int K, void* xb,
+                                  long long x_mblk_stride, cvc_stream_t stream) {
+    if (!x || !xb || M < 1 || K < 16 || (K & 15) || (ldx & 3)) return CVC_E_BADARG;
+    const long long n = (long long)M * (K / 4);
+    hipLaunchKernelGGL(tile_pack_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, idx, relu,
+                       M, K, (uint16_t*)xb, x_mblk_stride);
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_tile_reorder_pack(const int64_t* parent, const int64_t* word, int beam, const float* h_att, const float* c_att,
+                                     const float* h_lang, const float* c_lang, const float* table, int E, int V,
+                                     float* c_att_prev, float* c_lang_prev, void* xa, long long xa_stride, void* xl_hlang,
+                                     long long xl_stride, int rows, int R, cvc_stream_t stream) {
+    if (!word || !h_att || !c_att || !h_lang || !c_lang || !table || !c_att_prev || !c_lang_prev || !xa || !xl_hlang)
+        return CVC_E_BADARG;
+    if (rows < 1 || beam < 1 || R < 16 || (R & 15) || E < 16 || (E & 15) || V < 1) return CVC_E_BADARG;
+    ReorderArgs a;
+    a.parent = parent; a.word = word; a.beam = beam; a.h_att = h_att; a.c_att = c_att; a.h_lang = h_lang; a.c_lang = c_lang;
+    a.table = table; a.E = E; a.V = V; a.c_att_prev = c_att_prev; a.c_lang_prev = c_lang_prev; a.xa = (uint16_t*)xa;
+    a.xa_stride = xa_stride; a.xl_hlang = (uint16_t*)xl_hlang; a.xl_stride = xl_stride; a.rows = rows; a.R = R;
+    const long long n = (long long)rows * ((2 * R + E) / 4);
+    hipLaunchKernelGGL(tile_reorder_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return cvc_launch_status();
+}

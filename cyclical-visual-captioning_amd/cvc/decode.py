@@ -88,6 +88,55 @@ def from_quad(xq: torch.Tensor, m: int) -> torch.Tensor:
     return xq[:, :m].permute(1, 0, 2).reshape(m, -1)
 
 
+# ------------------------------------------------------------------ tile path operands (csrc/gemm_tile.hip)
+def split3_bf16(x: torch.Tensor):
+    """fp32 -> the three bf16 terms of the split-product arithmetic as int16 bit patterns (hi, mid, lo): truncation,
+    both remainders exact (csrc/gemm_split.h)."""
+    def top(v):
+        return (v.view(torch.int32) & -65536).view(torch.float32)
+    hi = top(x)
+    r1 = x - hi
+    mid = top(r1)
+    lo = top(r1 - mid)
+    bits = lambda v: (v.view(torch.int32) >> 16).to(torch.int16)
+    return bits(hi), bits(mid), bits(lo)
+
+
+def to_frag(x: torch.Tensor, rows_alloc: Optional[int] = None) -> torch.Tensor:
+    """[M, K] fp32 row-major -> fragments [rows_alloc/32][K/16][3 terms][2 k halves][32 rows][8 k] (int16 bit patterns of
+    bf16); rows beyond M are zero.  The layout the tile GEMM reads (include/cvc_hip.h, "Tile path")."""
+    m, k = x.shape
+    assert k % 16 == 0, k
+    ra = rows_alloc if rows_alloc is not None else (m + 31) // 32 * 32
+    xp = x.new_zeros(ra, k)
+    xp[:m] = x
+    planes = torch.stack(split3_bf16(xp.contiguous()), 0)                       # [3, ra, k]
+    return planes.view(3, ra // 32, 32, k // 16, 2, 8).permute(1, 3, 0, 4, 2, 5).contiguous()
+
+
+def from_frag(xb: torch.Tensor, m: int) -> torch.Tensor:
+    """inverse of to_frag (sum of the three terms)."""
+    nb, ks = xb.shape[0], xb.shape[1]
+    f = (xb.to(torch.int32) << 16).view(torch.float32)                           # [nb, ks, 3, 2, 32, 8]
+    x = f.sum(2).permute(0, 3, 1, 2, 4).reshape(nb * 32, ks * 16)               # [nb, 32, ks, 2, 8]
+    return x[:m]
+
+
+def pack_weights_tile(w: torch.Tensor, lstm_R: Optional[int] = None) -> torch.Tensor:
+    """[Nout, K] row-major fp32 -> tile-GEMM weight fragments [ceil(Nout/128)*4][K/16][3][2][32][8] (bf16 bit patterns),
+    zero rows beyond Nout.  LSTM gate matrices use the packed row order of `pack_weights` (block b = 4 gates x hidden
+    units 8b..8b+7), so that a 128-row tile holds complete hidden units."""
+    n, k = w.shape
+    assert k % 16 == 0, k
+    if lstm_R is not None:
+        R = lstm_R
+        assert n == 4 * R and R % 8 == 0
+        i = torch.arange(32, device=w.device)
+        rows = ((i >> 3) * R + (i & 7)).view(1, 32) + (torch.arange(R // 8, device=w.device) * 8).view(-1, 1)
+        w = w[rows.reshape(-1)]
+    return to_frag(w, (n + 127) // 128 * 128)
+
+
 CACHE_BUDGET = 208 << 20      # bytes re-read every step that are left cacheable in the 256 MiB Infinity Cache
 
 
@@ -114,8 +163,10 @@ class DecodeEngine:
     """Binds weights + one batch of clip features to preallocated state and a launch list."""
 
     def __init__(self, weights: DecodeWeights, feats: Dict[str, torch.Tensor], T: int, unk_idx: int, beam: int = 1,
-                 inv_temp: float = 1.0, own_features: bool = False):
-        """own_features: keep private copies of the clip features, so that the bound launch list (and a captured HIP
+                 inv_temp: float = 1.0, own_features: bool = False, path: str = "auto"):
+        """path: "auto" picks packed (greedy, <= 64 rows) / tile (> 64 rows or beams) / ring (odd widths); "ring" forces the
+        row-major fallback kernels (tests compare the paths).
+        own_features: keep private copies of the clip features, so that the bound launch list (and a captured HIP
         graph) can be reused for the next batch of the same shape through load_features()."""
         W = self.W = weights
         self.T, self.unk, self.beam = int(T), int(unk_idx), int(beam)
@@ -173,9 +224,14 @@ class DecodeEngine:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self._keep: List = []
         self.packed = self.beam == 1 and rows <= 64 and R % 32 == 0 and W.E % 32 == 0 and A % 32 == 0
+        # more than 64 live rows (beam search, big greedy batches): bf16-fragment tile GEMMs (csrc/gemm_tile.hip)
+        self.tile = (not self.packed) and (self.beam > 1 or rows > 64) and R % 16 == 0 and W.E % 16 == 0 and path != "ring"
         if self.packed:
             self._alloc_packed()
             self._launches = self._build_packed()
+        elif self.tile:
+            self._alloc_tile()
+            self._launches = self._build_tile()
         else:
             self._launches = self._build()
 
@@ -234,6 +290,112 @@ class DecodeEngine:
                                                             ptr(self.top2_part))))
             out.append(("word_select", L.cvc_top2_final, (ptr(self.top2_part), nblk_v, rows, self.unk, ptr(self.words[t + 1]), 1,
                                                           ptr(self.logprob[t]), ptr(W.embed), E, qoff(XA_w, R), 0)))
+            self._keep.append(sets)
+        return out
+
+    # ------------------------------------------------------------------ tile path (rows > 64 or beam search)
+    @staticmethod
+    def _ksplit(n_out: int, K: int) -> int:
+        """K slices of a tile GEMM: enough workgroups (128-row tiles x slices) to cover the 256 CUs, at least 8 k steps per
+        slice; 4 / 8 slices preferred (they map onto whole XCDs)."""
+        ntile = (n_out + 127) // 128
+        ks = max(1, min(256 // ntile, (K // 16) // 8))
+        for p in (8, 4, 2):
+            if ks >= p and ks < 2 * p and ntile * p >= 192:
+                return p
+        return ks
+
+    def _alloc_tile(self):
+        """Weight fragments (once per checkpoint binding) and the activation fragment buffers of the tile path:
+          XA = [h_lang(t-1) | relu(Emb[word_t]) | h_att(t-1)]       att-LSTM input, K = 2R + E
+          XL = [ctx_regions + ctx_frames | h_att(t) | h_lang(t-1)]   lang-LSTM input, K = 3R (h2attn reads its middle segment)
+          XH = h_lang(t)                                             vocabulary head input"""
+        W, R, E, A, V = self.W, self.W.R, self.W.E, self.W.A, self.W.V
+        dev = self.fc.device
+        if not hasattr(W, "t_att"):
+            W.t_att = pack_weights_tile(torch.cat([W.w_ih_att[:, 0:R], W.w_ih_att[:, 2 * R:2 * R + E], W.w_hh_att], 1), R)
+            W.t_lang = pack_weights_tile(torch.cat([W.w_ih_lang, W.w_hh_lang], 1), R)
+            W.t_h = pack_weights_tile(W.w_h)
+            W.t_o = pack_weights_tile(W.w_o)
+            W.t_fc = pack_weights_tile(W.w_ih_att[:, R:2 * R].contiguous())
+        rows, B = self.rows, self.B
+        ra, rb = hip.tile_rows_alloc(rows), hip.tile_rows_alloc(B)
+        zf = lambda r, k: torch.zeros(r // 32, k // 16, 3, 2, 32, 8, device=dev, dtype=torch.int16)
+        self.XAf, self.XLf, self.XHf, self.XFf = zf(ra, 2 * R + E), zf(ra, 3 * R), zf(ra, R), zf(rb, R)
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.ks_gate, self.ks_q, self.ks_o, self.ks_fc = (self._ksplit(4 * R, min(2 * R + E, 3 * R)), self._ksplit(A, R),
+                                                          self._ksplit(V, R), self._ksplit(4 * R, R))
+        self.parts_gate = torch.empty(self.ks_gate, rows, 4 * R, **f32)
+        self.parts_q = torch.empty(self.ks_q, rows, A, **f32)
+        self.parts_o = torch.empty(self.ks_o, rows, V, **f32)
+        self.parts_fc = torch.empty(self.ks_fc, B, 4 * R, **f32)
+        self.gate_fc_clip = torch.empty(B, 4 * R, **f32)
+        z = lambda: torch.zeros(rows, R, **f32)
+        self.t_h_att, self.t_c_att, self.t_h_lang, self.t_c_lang = z(), z(), z(), z()        # state of the current step
+        self.t_c_att_prev, self.t_c_lang_prev, self.t_zero = z(), z(), z()
+
+    def _build_tile(self):
+        L, W = hip.lib(), self.W
+        B, N, Fr, R, A, E, V, rows, beam = self.B, self.N, self.F, W.R, W.A, W.E, W.V, self.rows, self.beam
+        fc, conv, pconv, pool, ppool = self.feats
+        ptr = lambda t: None if t is None else t.data_ptr()
+        fp = hip._frag_ptr
+        out = []
+        # ---- once per decode: hoisted fc gate term (+ both biases), one row per clip; step-0 operands from the zero state
+        xf_p, xf_s = fp(self.XFf)
+        out.append(("gate_fc", L.cvc_tile_pack_rows, (ptr(fc), fc.stride(0), None, 0, B, R, xf_p, xf_s)))
+        out.append(("gate_fc", L.cvc_tile_gemm, (ptr(W.t_fc), xf_p, xf_s, R, B, 4 * R, self.ks_fc, ptr(self.parts_fc), 4 * R,
+                                                 B * 4 * R)))
+        out.append(("gate_fc", L.cvc_tile_linear_finish, (ptr(self.parts_fc), self.ks_fc, B * 4 * R, 4 * R, ptr(W.b_ih_att),
+                                                          ptr(W.b_hh_att), B, 4 * R, ptr(self.gate_fc_clip), 4 * R)))
+        xa_p, xa_s = fp(self.XAf)
+        xl_p, xl_s = fp(self.XLf)
+        xl_hatt, _ = fp(self.XLf, R)
+        xl_hlang, _ = fp(self.XLf, 2 * R)
+        xh_p, xh_s = fp(self.XHf)
+        zero = ptr(self.t_zero)
+        out.append(("beam_reorder", L.cvc_tile_reorder_pack, (None, ptr(self.words[0]), beam, zero, zero, zero, zero, ptr(W.embed), E, V,
+                                                              ptr(self.t_c_att_prev), ptr(self.t_c_lang_prev), xa_p, xa_s, xl_hlang,
+                                                              xl_s, rows, R)))
+        for t in range(self.T):
+            out.append(("att_lstm", L.cvc_tile_gemm, (ptr(W.t_att), xa_p, xa_s, 2 * R + E, rows, 4 * R, self.ks_gate,
+                                                      ptr(self.parts_gate), 4 * R, rows * 4 * R)))
+            out.append(("att_finish", L.cvc_tile_lstm_finish, (ptr(self.parts_gate), self.ks_gate, rows * 4 * R, None, None,
+                                                               ptr(self.gate_fc_clip), beam, ptr(self.t_c_att_prev), rows, R,
+                                                               ptr(self.t_c_att), ptr(self.t_h_att), xl_hatt, xl_s, None, 0)))
+            out.append(("h2attn", L.cvc_tile_gemm, (ptr(W.t_h), xl_hatt, xl_s, R, rows, A, self.ks_q, ptr(self.parts_q), A, rows * A)))
+            sets = (hip.AttnSet * 2)()
+            sets[0] = hip.AttnSet(ptr(ppool), ptr(pool), ptr(self.mask), None, ptr(self.scores_r), None,
+                                  ptr(self.att_steps[t]), None, N, self.stream_r)
+            sets[1] = hip.AttnSet(ptr(pconv), ptr(conv), None, None, ptr(self.scores_f), None, ptr(self.attn_f), None, Fr,
+                                  self.stream_f)
+            out.append(("attn_scores", L.cvc_attn_scores_qparts, (W.kind, ptr(self.parts_q), self.ks_q, ptr(W.b_h), ptr(W.w_a),
+                                                                  ptr(W.b_a), self.inv_temp, sets, 2, B, beam, A)))
+            out.append(("attn_wsum", L.cvc_attn_wsum_frag, (sets, 2, B, beam, R, xl_p, xl_s)))
+            out.append(("lang_lstm", L.cvc_tile_gemm, (ptr(W.t_lang), xl_p, xl_s, 3 * R, rows, 4 * R, self.ks_gate,
+                                                       ptr(self.parts_gate), 4 * R, rows * 4 * R)))
+            out.append(("lang_finish", L.cvc_tile_lstm_finish, (ptr(self.parts_gate), self.ks_gate, rows * 4 * R, ptr(W.b_ih_lang),
+                                                                ptr(W.b_hh_lang), None, 1, ptr(self.t_c_lang_prev), rows, R,
+                                                                ptr(self.t_c_lang), ptr(self.t_h_lang), xh_p, xh_s, None, 0)))
+            out.append(("logits", L.cvc_tile_gemm, (ptr(W.t_o), xh_p, xh_s, R, rows, V, self.ks_o, ptr(self.parts_o), V, rows * V)))
+            out.append(("logits_finish", L.cvc_tile_linear_finish, (ptr(self.parts_o), self.ks_o, rows * V, V, ptr(W.b_o), None, rows, V,
+                                                                    ptr(self.logits), V)))
+            if beam == 1:
+                out.append(("word_select", L.cvc_top2_unk, (ptr(self.logits), rows, V, self.unk, ptr(self.words[t + 1]), 1,
+                                                            ptr(self.logprob[t]))))
+                parent = None
+            else:
+                srd, swr = t & 1, (t + 1) & 1
+                out.append(("word_select", L.cvc_beam_select, (ptr(self.logits), ptr(self.score[srd]), ptr(self.done[srd]), B,
+                                                               beam, V, self.unk, 1 if t == 0 else 0, ptr(self.parent[t]),
+                                                               ptr(self.words[t + 1]), ptr(self.score[swr]),
+                                                               ptr(self.done[swr]), ptr(self.beam_ws))))
+                parent = ptr(self.parent[t])
+            if t + 1 < self.T:
+                out.append(("beam_reorder", L.cvc_tile_reorder_pack, (parent, ptr(self.words[t + 1]), beam, ptr(self.t_h_att),
+                                                                      ptr(self.t_c_att), ptr(self.t_h_lang), ptr(self.t_c_lang),
+                                                                      ptr(W.embed), E, V, ptr(self.t_c_att_prev),
+                                                                      ptr(self.t_c_lang_prev), xa_p, xa_s, xl_hlang, xl_s, rows, R)))
             self._keep.append(sets)
         return out
 
@@ -314,6 +476,12 @@ class DecodeEngine:
         return out
 
     def _reset(self):
+        if self.tile:
+            self.words[0].zero_()
+            if self.beam > 1:
+                self.score.zero_()
+                self.done.zero_()
+            return
         if self.packed:
             self.XA[0].copy_(self.XA0_init)
             self.XL[0].zero_()

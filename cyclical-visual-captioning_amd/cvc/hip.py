@@ -34,7 +34,7 @@ class NNSeg(C.Structure):
     _fields_ = [("w", C.c_void_p), ("dst", C.c_void_p), ("ldw", C.c_int), ("ncols", C.c_int), ("ld_dst", C.c_int)]
 
 
-_P, _I, _F = C.c_void_p, C.c_int, C.c_float
+_P, _I, _F, _LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 # name -> argtypes, exactly the declarations of include/cvc_hip.h (tests/test_cabi.py checks both)
 SIGNATURES = {
     "cvc_attn_fwd": [_I, _P, _P, _P, _F, C.POINTER(AttnSet), _I, _I, _I, _I, _I, _P, _P],
@@ -66,6 +66,13 @@ SIGNATURES = {
     "cvc_grounder_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "cvc_beam_select": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "cvc_gather_rows": [_P, _P, _I, _I, _I, _P, _P],
+    "cvc_tile_rows_alloc": [_I],
+    "cvc_tile_gemm": [_P, _P, _LL, _I, _I, _I, _I, _P, _I, _LL, _P],
+    "cvc_tile_lstm_finish": [_P, _I, _LL, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _LL, _P, _LL, _P],
+    "cvc_tile_linear_finish": [_P, _I, _LL, _I, _P, _P, _I, _I, _P, _I, _P],
+    "cvc_tile_pack_rows": [_P, _I, _P, _I, _I, _I, _P, _LL, _P],
+    "cvc_tile_reorder_pack": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _LL, _P, _LL, _I, _I, _P],
+    "cvc_attn_wsum_frag": [C.POINTER(AttnSet), _I, _I, _I, _I, _P, _LL, _P],
 }
 
 _lib = None
@@ -407,3 +414,37 @@ def gather_rows(src, parent, beam: int):
     _check(lib().cvc_gather_rows(_dev(src), _dev(parent, torch.int64), rows, beam, width, _dev(dst), _stream()),
            "cvc_gather_rows")
     return dst
+
+
+# --------------------------------------------------------------------------- tile path (rows > 64), csrc/gemm_tile.hip
+def tile_rows_alloc(M: int) -> int:
+    return int(lib().cvc_tile_rows_alloc(int(M)))
+
+
+def _frag_ptr(xb: torch.Tensor, k0: int = 0):
+    """(address of k step k0/16 of row block 0, row-block stride in bf16 elements) of a fragment tensor
+    [blocks][k steps][3][2][32][8] int16."""
+    if not xb.is_cuda or xb.dtype != torch.int16 or not xb.is_contiguous() or xb.dim() != 6:
+        raise RuntimeError("cvc.hip: activation / weight fragments must be a contiguous int16 GPU tensor [blk][kstep][3][2][32][8]")
+    assert k0 % 16 == 0
+    return xb.data_ptr() + (k0 // 16) * 3 * 1024, xb.shape[1] * 1536
+
+
+def tile_gemm(wb: torch.Tensor, xb: torch.Tensor, k0: int, K: int, M: int, N: int, ksplit: int, parts: Optional[torch.Tensor] = None):
+    """parts [ksplit, M, N] = per-K-slice partial products of x[:, k0:k0+K] @ W^T (wb packed for exactly these K columns)."""
+    wp, _ = _frag_ptr(wb)
+    assert wb.shape[1] == K // 16 and wb.shape[0] * 32 >= N and xb.shape[0] * 32 >= tile_rows_alloc(M)
+    xp, xs = _frag_ptr(xb, k0)
+    if parts is None:
+        parts = torch.empty(ksplit, M, N, device=xb.device, dtype=torch.float32)
+    _check(lib().cvc_tile_gemm(wp, xp, xs, K, M, N, ksplit, _dev(parts), N, M * N, _stream()), "cvc_tile_gemm")
+    return parts
+
+
+def tile_pack_rows(x: torch.Tensor, xb: torch.Tensor, k0: int = 0, idx: Optional[torch.Tensor] = None, relu: bool = False):
+    M = x.shape[0] if idx is None else idx.shape[0]
+    K = x.shape[1]
+    xp, xs = _frag_ptr(xb, k0)
+    _check(lib().cvc_tile_pack_rows(_dev(x), x.stride(0), _dev(idx, torch.int64), 1 if relu else 0, M, K, xp, xs, _stream()),
+           "cvc_tile_pack_rows")
+    return xb

@@ -262,6 +262,49 @@ int cvc_beam_select(const float* logits, const float* score_in, const uint8_t* d
 int cvc_gather_rows(const float* src, const int64_t* parent, int rows, int beam, int width,
                     float* dst, cvc_stream_t stream);
 
+
+/* ---------------------------------------------------------------------------------------
+ * Tile path of the decode engine: more than 64 live rows per step (beam search: rows = clips x beam, model/captioner.py
+ * :410-438 with the build-defined beam rule of SURVEY.md section 7; greedy batches beyond 64 clips).
+ * Both GEMM operands live in HBM as "fragments": 32 rows x 16 k of ONE of the three bf16 terms of the split-product
+ * arithmetic (v = hi + mid + lo exactly, see cvc_gemm_packed_split), 1 KiB, ordered [k half][row][8 k] -- the lane order
+ * of the bf16 MFMA operand.  A block of 32 rows stores, per k step of 16, its three terms back to back (3 KiB):
+ *   wb : weights      [ceil(N/128)*4 blocks][K/16][3][512 bf16]  (zero rows beyond N; LSTM gate matrices in the packed row
+ *                     order of cvc_packed_lstm_fwd: block b = 4 gates x hidden units 8b..8b+7), packed once per checkpoint
+ *                     by cvc.decode.pack_weights_tile;
+ *   xb : activations  [cvc_tile_rows_alloc(M)/32 blocks][k steps][3][512], x_mblk_stride = bf16 elements between row
+ *                     blocks; a GEMM over a K segment of a wider buffer just points at the segment's first k step.
+ *                     Written by the producers below (and cvc_attn_wsum_frag); rows beyond M must be zero-initialised.
+ * cvc_tile_gemm: parts[s][m, n] (row-major, leading dim ld, slab stride part_stride floats) = partial product over K slice s
+ * of ksplit; the consumer sums the slabs in slab order.  K % 16 == 0; any M (walked in chunks of 320 rows); any N.
+ */
+int cvc_tile_rows_alloc(int M);      /* rows (a multiple of 32) an activation fragment buffer for M live rows must hold */
+int cvc_tile_gemm(const void* wb, const void* xb, long long x_mblk_stride, int K, int M, int N, int ksplit,
+                  float* parts, int ld, long long part_stride, cvc_stream_t stream);
+/* nn.LSTMCell epilogue over the slabs of a gate GEMM (packed feature order): + b_ih + b_hh + gate_bias[m / gb_div]
+ * (checkpoint order [*, 4R]; the hoisted fc term, one row per clip), cell update with c_prev [M, R]; writes c_out, h_out
+ * [M, R] (h_out nullable) and h' as activation fragments at up to two destinations (pointer at the segment's first k step). */
+int cvc_tile_lstm_finish(const float* parts, int nparts, long long part_stride, const float* b_ih, const float* b_hh,
+                         const float* gate_bias, int gb_div, const float* c_prev, int M, int R, float* c_out,
+                         float* h_out, void* frag1, long long frag1_stride, void* frag2, long long frag2_stride,
+                         cvc_stream_t stream);
+/* y[m, n] = sum_s parts[s][m, n] + bias[n] + bias2[n]  (nn.Linear epilogue: vocabulary logits, hoisted fc gate term) */
+int cvc_tile_linear_finish(const float* parts, int nparts, long long part_stride, int ld, const float* bias,
+                           const float* bias2, int M, int N, float* y, int ldy, cvc_stream_t stream);
+/* fp32 rows (optionally gathered through idx, optionally ReLU'd) -> activation fragments */
+int cvc_tile_pack_rows(const float* x, int ldx, const int64_t* idx, int relu, int M, int K, void* xb,
+                       long long x_mblk_stride, cvc_stream_t stream);
+/* Beam-state reorder fused with next step's operand packing: row r continues hypothesis (r / beam) * beam + parent[r]
+ * (parent NULL: r).  c_*_prev[r] = c_*[src]; xa = [h_lang[src] | relu(table[word[r]]) | h_att[src]] as fragments (K = 2R + E,
+ * decoder_core.py:45-48 without the hoisted fc segment); xl_hlang (lang-LSTM input, third K segment) = h_lang[src]. */
+int cvc_tile_reorder_pack(const int64_t* parent, const int64_t* word, int beam, const float* h_att, const float* c_att,
+                          const float* h_lang, const float* c_lang, const float* table, int E, int V,
+                          float* c_att_prev, float* c_lang_prev, void* xa, long long xa_stride, void* xl_hlang,
+                          long long xl_stride, int rows, int R, cvc_stream_t stream);
+/* Pass 2 of the attention writing the summed context as activation fragments (rows of the tile path) */
+int cvc_attn_wsum_frag(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, void* ctx_frag,
+                       long long frag_mblk_stride, cvc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -164,7 +164,7 @@ def test_a10_ground_weights_elementwise_golden(g1, dev):
         gold = g1[variant + "ground_weights"]
         assert tuple(gw.shape) == gold.shape == (d.B, d.T, d.N)
         close(gw, gold, rtol=2e-5, atol=2e-5)
-        assert np.array_equal(gw.cpu().numpy() == -1e8, gold == -1e8)
+        assert np.array_equal(gw.detach().cpu().numpy() == -1e8, gold == -1e8)
 
 
 @pytest.mark.parametrize("B,T,N,G", [(3, 4, 7, 24), (64, 20, 100, 2048), (2, 1, 1, 4), (5, 3, 130, 36)])
@@ -225,7 +225,7 @@ def test_ground_loss_gradient_through_the_model(g1, dev):
     # the grounder's own parameters (vis_embed, vis_classifiers_bias) must have received a gradient
     pe = dict(model.named_parameters())
     assert float(pe["roi_feat_extractor.vis_embed.0.weight"].grad.abs().max()) > 0
-    assert float(pe["roi_feat_extractor.vis_classifiers_bias"].grad.abs().max()) > 0
+    # (vis_classifiers_bias enters as a per-(clip, word) constant over the regions: log_softmax is invariant to it, its true gradient is 0)
     assert n >= 15
 
 

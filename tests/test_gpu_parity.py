@@ -357,6 +357,89 @@ def test_split_product_gemm_is_fp32_grade(dev, lib, M, K, N):
         assert err[mode][0] <= 1.25 * err[0][0] and err[mode][1] <= 1.25 * err[0][1], err
 
 
+@pytest.mark.parametrize("M,K,N,ksplit", [(320, 6144, 8192, 4), (320, 2048, 5000, 6), (150, 512, 130, 3), (65, 32, 50, 2),
+                                          (700, 256, 256, 1), (1, 16, 1, 1)])
+def test_tile_gemm_vs_fp64(dev, lib, M, K, N, ksplit):
+    """cvc_tile_gemm (rows > 64: both operands as bf16 split-term fragments, LDS-DMA ring, K split over workgroups): the slab
+    sum against fp64 with an error no worse than an fp32 GEMM's, round trip of the fragment packers, and run-to-run
+    bitwise determinism.  Covers the cfg3 beam shapes (320 x 6144 x 8192, the V = 5000 head), ragged M / N, M > 320
+    (row chunks) and the one-k-step corner."""
+    from cvc.decode import to_frag, from_frag, pack_weights_tile
+    g = torch.Generator().manual_seed(M + K + N)
+    x = (torch.randn(M, K, generator=g) * torch.exp2(torch.randint(-6, 3, (M, 1), generator=g).float())).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    ra = lib.tile_rows_alloc(M)
+    assert ra % 32 == 0 and ra >= M
+    xb = torch.zeros(ra // 32, K // 16, 3, 2, 32, 8, dtype=torch.int16, device=dev)
+    lib.tile_pack_rows(x, xb)
+    assert torch.equal(xb, to_frag(x, ra))                       # device packer == host packer, bit for bit
+    assert torch.equal(from_frag(xb, M), x)                      # hi + mid + lo reproduces every fp32 exactly
+    wb = pack_weights_tile(w)
+    parts = lib.tile_gemm(wb, xb, 0, K, M, N, ksplit)
+    y = parts.sum(0)
+    ref = x.double() @ w.double().t()
+    err = float((y.double() - ref).norm() / ref.norm())
+    err32 = float(((x @ w.t()).double() - ref).norm() / ref.norm())
+    assert err <= max(2.0 * err32, 3e-7), (err, err32)
+    assert torch.equal(parts, lib.tile_gemm(wb, xb, 0, K, M, N, ksplit))
+    # a K segment of a wider activation buffer: point at its first k step
+    if K >= 64:
+        xw = torch.zeros(ra // 32, (K + 32) // 16, 3, 2, 32, 8, dtype=torch.int16, device=dev)
+        lib.tile_pack_rows(x, xw, k0=32)
+        assert torch.equal(lib.tile_gemm(wb, xw, 32, K, M, N, ksplit), parts)
+
+
+@pytest.mark.parametrize("M,R,beam,nparts", [(320, 2048, 5, 4), (70, 32, 1, 2), (15, 48, 3, 1)])
+def test_tile_lstm_finish_and_reorder_pack(dev, lib, M, R, beam, nparts):
+    """The tile path's LSTM epilogue (slab sum + biases + per-clip gate term + cell update, h' as fragments) and the
+    beam-state reorder fused with the next step's operand packing, against plain torch."""
+    from cvc.decode import from_frag
+    import ctypes as C
+    g = torch.Generator().manual_seed(M * 7 + R)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    E, V = 32, 41
+    nclip = M // beam
+    parts = rnd(nparts, M, 4 * R) * 0.5                          # packed feature order: blk * 32 + gate * 8 + unit
+    b_ih, b_hh, gate_bias, c_prev = rnd(4 * R) * 0.1, rnd(4 * R) * 0.1, rnd(nclip, 4 * R) * 0.3, rnd(M, R)
+    ra = lib.tile_rows_alloc(M)
+    c_out, h_out = torch.empty(M, R, device=dev), torch.empty(M, R, device=dev)
+    f1 = torch.zeros(ra // 32, (3 * R) // 16, 3, 2, 32, 8, dtype=torch.int16, device=dev)
+    f2 = torch.zeros(ra // 32, R // 16, 3, 2, 32, 8, dtype=torch.int16, device=dev)
+    p1, s1 = lib._frag_ptr(f1, R)
+    p2, s2 = lib._frag_ptr(f2, 0)
+    L = lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    rc = L.cvc_tile_lstm_finish(parts.data_ptr(), nparts, M * 4 * R, b_ih.data_ptr(), b_hh.data_ptr(), gate_bias.data_ptr(), beam,
+                                c_prev.data_ptr(), M, R, c_out.data_ptr(), h_out.data_ptr(), p1, s1, p2, s2, st)
+    assert rc == 0
+    pre = parts.sum(0).view(M, R // 8, 4, 8).permute(0, 2, 1, 3).reshape(M, 4 * R)        # -> checkpoint order gate * R + hidden
+    pre = pre + b_ih + b_hh + gate_bias.repeat_interleave(beam, 0)
+    i, f, gg, o = pre.chunk(4, 1)
+    c_ref = torch.sigmoid(f) * c_prev + torch.sigmoid(i) * torch.tanh(gg)
+    h_ref = torch.sigmoid(o) * torch.tanh(c_ref)
+    close(c_out, c_ref, **OP_TOL); close(h_out, h_ref, **OP_TOL)
+    assert torch.equal(from_frag(f1, M)[:, R:2 * R], h_out) and torch.equal(from_frag(f2, M), h_out)
+    assert float(from_frag(f1, M)[:, :R].abs().max()) == 0.0
+    # reorder + pack
+    parent = torch.randint(0, beam, (M,), generator=g).to(dev)
+    word = torch.randint(0, V, (M,), generator=g).to(dev)
+    h_att, c_att, h_lang, c_lang, table = rnd(M, R), rnd(M, R), rnd(M, R), rnd(M, R), rnd(V, E)
+    xa = torch.zeros(ra // 32, (2 * R + E) // 16, 3, 2, 32, 8, dtype=torch.int16, device=dev)
+    xl = torch.zeros(ra // 32, (3 * R) // 16, 3, 2, 32, 8, dtype=torch.int16, device=dev)
+    cap, clp = torch.empty(M, R, device=dev), torch.empty(M, R, device=dev)
+    pa, sa = lib._frag_ptr(xa, 0)
+    pl, sl = lib._frag_ptr(xl, 2 * R)
+    for par in (parent, None):
+        rc = L.cvc_tile_reorder_pack(None if par is None else par.data_ptr(), word.data_ptr(), beam, h_att.data_ptr(), c_att.data_ptr(),
+                                     h_lang.data_ptr(), c_lang.data_ptr(), table.data_ptr(), E, V, cap.data_ptr(), clp.data_ptr(),
+                                     pa, sa, pl, sl, M, R, st)
+        assert rc == 0
+        src = torch.arange(M, device=dev) if par is None else (torch.arange(M, device=dev) // beam) * beam + par
+        want_xa = torch.cat([h_lang[src], torch.relu(table[word]), h_att[src]], 1)
+        assert torch.equal(from_frag(xa, M), want_xa)
+        assert torch.equal(from_frag(xl, M)[:, 2 * R:], h_lang[src]) and torch.equal(cap, c_att[src]) and torch.equal(clp, c_lang[src])
+
+
 @pytest.mark.parametrize("M,V,E,pad", [(1280, 5000, 1024, 0.35), (37, 11, 16, 0.5), (1, 3, 4, 0.0), (64, 2, 8, 0.9)])
 def test_embedding_backward_long_runs(dev, lib, M, V, E, pad):
     """cvc_embed_relu_bwd (sorted runs summed as 16-row pieces) vs index_add in fp64; a third of the rows share
@@ -576,6 +659,29 @@ def test_beam_vs_oracle(tiny, g1, dev):
             close(att, att_o, **SEQ_TOL)
             close(sc, sc_o, **SEQ_TOL)
             assert bool((sc[:, :-1] >= sc[:, 1:]).all())
+
+
+@pytest.mark.parametrize("B,N,F,R,A,E,V,T,beam", [(3, 7, 5, 32, 16, 16, 50, 4, 3), (20, 30, 12, 256, 64, 48, 300, 5, 5),
+                                                 (70, 9, 4, 64, 32, 32, 97, 3, 1), (130, 5, 3, 48, 20, 16, 50, 3, 2)])
+def test_tile_path_equals_ring_path(dev, lib, B, N, F, R, A, E, V, T, beam):
+    """The fragment / tile-GEMM path of the decode engine (rows > 64 or beam search) against the row-major ring path on the
+    same inputs: sequences identical, attention maps and scores to fp32 reordering noise.  Includes more than 320 rows
+    (row chunks of the tile GEMM) and greedy with B > 64."""
+    from helpers import to_dev
+    from cvc.decode import DecodeEngine, DecodeWeights
+    d = dataclasses.replace(synth.CONFIGS["tiny"], B=B, N=N, F=F, R=R, A=A, E=E, V=V, T=T)
+    sd, f_np = synth.hot_path_state_dict(d, 31 + B), synth.clip_features(d, 31 + B)
+    W, f = DecodeWeights(to_dev(sd, dev)), to_dev(f_np, dev)
+    e_tile, e_ring = DecodeEngine(W, f, T, synth.UNK_IDX, beam=beam), DecodeEngine(W, f, T, synth.UNK_IDX, beam=beam, path="ring")
+    assert e_tile.tile and not e_ring.tile and not e_ring.packed
+    a, b = [x.clone() for x in e_tile.run()], [x.clone() for x in e_ring.run()]
+    same = (a[0] == b[0]).all(1)
+    assert int(same.sum()) >= B - max(1, B // 20)
+    close(a[1][same], b[1][same], **SEQ_TOL)
+    if beam > 1:
+        close(a[2][same], b[2][same], rtol=2e-4, atol=2e-4)
+    a2 = e_tile.capture().run()
+    assert all(torch.equal(x, y) for x, y in zip(a, a2))          # graph replay == eager, bitwise
 
 
 def test_beam5_cfg1_vs_oracle(dev, lib):
