@@ -133,6 +133,113 @@ __global__ __launch_bounds__(WG) void attn_wsum_kernel(WsumArgs a) {
     }
 }
 
+// Several queries per clip (beams of a clip, the T localizer queries of a clip): one workgroup = (clip, 256-column block,
+// group of up to QB queries).  The clip's context rows are streamed ONCE for the whole group and accumulated into QB register
+// accumulators; the one-query kernel above would re-read them per query (5 x the bytes at beam 5).
+template <int QB>
+__global__ __launch_bounds__(WG) void attn_wsum_mq_kernel(WsumArgs a, int n_max) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4* part = reinterpret_cast<f32x4*>(smem);      // [4 waves][QB][64 lanes]
+    float* red = smem + 4 * QB * 64 * 4;               // [16]
+    float* a_s = red + 16;                             // [QB][n_max]
+    const int clip = blockIdx.y, cb = blockIdx.x;
+    const int qbase = blockIdx.z * QB;
+    const int nqb = min(QB, a.nq - qbase);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int R = a.R;
+    const int col = cb * 256 + lane * 4;
+    const bool col_ok = col < R;
+    f32x4 total[QB];
+#pragma unroll
+    for (int u = 0; u < QB; ++u) total[u] = f32x4{0, 0, 0, 0};
+
+    for (int s = 0; s < a.nsets; ++s) {
+        const cvc_attn_set& S = a.set[s];
+        const int n = S.n;
+        for (int u = nqb; u < QB; ++u)                  // unused slots of the group weigh nothing: the FMA loop has no branches
+            for (int i = tid; i < n; i += WG) a_s[(size_t)u * n_max + i] = 0.f;
+        for (int u = 0; u < nqb; ++u) {                 // softmax over n per query (torch.softmax: exp(x - max) / sum)
+            const int row = clip * a.nq + qbase + u;
+            const float* sc = S.scores + (size_t)row * n;
+            float* as = a_s + (size_t)u * n_max;
+            float m = -INFINITY;
+            for (int i = tid; i < n; i += WG) m = fmaxf(m, sc[i]);
+            m = block_reduce(m, red, true);
+            float sum = 0.f;
+            for (int i = tid; i < n; i += WG) {
+                float e = expf(sc[i] - m);
+                as[i] = e;
+                sum += e;
+            }
+            sum = block_reduce(sum, red, false);
+            for (int i = tid; i < n; i += WG) {
+                float p = as[i] / sum;
+                as[i] = p;
+                if (cb == 0) S.attn[(size_t)row * n + i] = p;
+            }
+        }
+        __syncthreads();
+        if (S.ctx_out == nullptr && a.ctx_sum == nullptr) continue;
+
+        const float* C = S.ctx + (size_t)clip * n * R + col;
+        f32x4 acc[QB];
+#pragma unroll
+        for (int u = 0; u < QB; ++u) acc[u] = f32x4{0, 0, 0, 0};
+        auto accumulate = [&](auto stream_tag) __attribute__((always_inline)) {
+            constexpr bool STREAM = decltype(stream_tag)::value;
+#define LDF(ptr) (STREAM ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ptr)) : ld4(ptr))
+            int i = wave;
+            for (; i + 12 < n; i += 16) {
+                const f32x4 c0 = LDF(C + (size_t)i * R), c1 = LDF(C + (size_t)(i + 4) * R);
+                const f32x4 c2 = LDF(C + (size_t)(i + 8) * R), c3 = LDF(C + (size_t)(i + 12) * R);
+#pragma unroll
+                for (int u = 0; u < QB; ++u) {
+                    const float* as = a_s + (size_t)u * n_max;
+                    acc[u] += as[i] * c0;
+                    acc[u] += as[i + 4] * c1;
+                    acc[u] += as[i + 8] * c2;
+                    acc[u] += as[i + 12] * c3;
+                }
+            }
+            for (; i < n; i += 4) {
+                const f32x4 c0 = LDF(C + (size_t)i * R);
+#pragma unroll
+                for (int u = 0; u < QB; ++u) acc[u] += a_s[(size_t)u * n_max + i] * c0;
+            }
+#undef LDF
+        };
+        if (col_ok) {
+            if (S.stream & 2) accumulate(std::true_type{}); else accumulate(std::false_type{});
+        }
+#pragma unroll
+        for (int u = 0; u < QB; ++u) part[(wave * QB + u) * 64 + lane] = acc[u];
+        __syncthreads();
+        if (wave == 0 && col_ok) {
+#pragma unroll
+            for (int u = 0; u < QB; ++u) {
+                if (u < nqb) {
+                    const f32x4 v = (part[(0 * QB + u) * 64 + lane] + part[(1 * QB + u) * 64 + lane]) +
+                                    (part[(2 * QB + u) * 64 + lane] + part[(3 * QB + u) * 64 + lane]);
+                    if (S.ctx_out != nullptr) st4(S.ctx_out + (size_t)(clip * a.nq + qbase + u) * R + col, v);
+                    total[u] += v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (a.ctx_sum != nullptr && wave == 0 && col_ok) {
+#pragma unroll
+        for (int u = 0; u < QB; ++u) {
+            if (u < nqb) {
+                const int row = clip * a.nq + qbase + u;
+                if (a.ctx_quad == 2) store_ctx_frag(reinterpret_cast<uint16_t*>(a.ctx_sum), a.frag_stride, row, col, total[u]);
+                else if (a.ctx_quad) st4(a.ctx_sum + ((size_t)(col >> 2) * 64 + row) * 4, total[u]);
+                else st4(a.ctx_sum + (size_t)row * R + col, total[u]);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 static int check_sets(const cvc_attn_set* sets, int nsets, int nclip, int nq, int A, int R, int* n_max) {
@@ -196,6 +303,24 @@ static int wsum_impl(const cvc_attn_set* sets, int nsets, int nclip, int nq, int
     wa.set[0] = sets[0];
     wa.set[1] = nsets > 1 ? sets[1] : sets[0];
     wa.nsets = nsets; wa.nq = nq; wa.R = R; wa.ctx_sum = ctx_sum; wa.ctx_quad = ctx_quad; wa.frag_stride = frag_stride;
+    if (nq > 1) {
+        // queries of a clip in groups of QB (the largest group whose softmax rows + partials fit 64 KB of LDS): the clip's
+        // context rows are read once per group; if not even 2 fit, the one-query kernel below takes every row on its own
+        int QB = nq <= 2 ? 2 : (nq <= 4 ? 4 : (nq <= 5 ? 5 : 8));
+        auto lds_of = [&](int qb) { return ((size_t)4 * qb * 64 * 4 + 16 + (size_t)qb * n_max) * sizeof(float); };
+        while (QB > 1 && lds_of(QB) > 64 * 1024) QB = QB == 8 ? 5 : (QB == 5 ? 4 : (QB == 4 ? 2 : 1));
+        if (QB > 1) {
+            const size_t lds = lds_of(QB);
+            dim3 g((R + 255) / 256, nclip, (nq + QB - 1) / QB);
+            switch (QB) {
+                case 2: hipLaunchKernelGGL(attn_wsum_mq_kernel<2>, g, dim3(WG), lds, (hipStream_t)stream, wa, n_max); break;
+                case 4: hipLaunchKernelGGL(attn_wsum_mq_kernel<4>, g, dim3(WG), lds, (hipStream_t)stream, wa, n_max); break;
+                case 5: hipLaunchKernelGGL(attn_wsum_mq_kernel<5>, g, dim3(WG), lds, (hipStream_t)stream, wa, n_max); break;
+                default: hipLaunchKernelGGL(attn_wsum_mq_kernel<8>, g, dim3(WG), lds, (hipStream_t)stream, wa, n_max); break;
+            }
+            return cvc_launch_status();
+        }
+    }
     const size_t lds2 = (4 * 64 * 4 + 16 + n_max) * sizeof(float);
     if (lds2 > 64 * 1024) return CVC_E_TOOBIG;
     dim3 g2((R + 255) / 256, nclip * nq);

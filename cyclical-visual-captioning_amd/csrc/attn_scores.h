@@ -26,11 +26,15 @@ struct ScoreArgs {
     int nq_total, q0;              // row = clip * nq_total + q0 + qi
 };
 
-template <int KIND, int NCH>
+// QG = queries per group: the group's accumulators are independent chains for the VALU and its LDS reads / wave reductions are
+// issued back to back.  The query list is padded to a multiple of QG in LDS (zero rows), so the group body has NO branches:
+// with a per-query `if` the compiler fences every 16-byte query read behind its own s_waitcnt (measured at beam 5: 87 us).
+template <int KIND, int NCH, int QG>
 __global__ __launch_bounds__(SCORE_WG) void attn_scores_kernel(ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* q_s = smem;                         // [nq][A]
-    float* w_s = smem + (size_t)a.nq * a.A;    // [A]
+    const int nq_pad = (a.nq + QG - 1) / QG * QG;
+    float* q_s = smem;                         // [nq_pad][A]
+    float* w_s = smem + (size_t)nq_pad * a.A;  // [A]
     const int clip = blockIdx.y;
     const int s = (int)blockIdx.x < a.chunks0 ? 0 : 1;
     const int chunk = s == 0 ? blockIdx.x : blockIdx.x - a.chunks0;
@@ -38,11 +42,14 @@ __global__ __launch_bounds__(SCORE_WG) void attn_scores_kernel(ScoreArgs a) {
     const int A = a.A, nq = a.nq, n = S.n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    for (int i = tid * 4; i < nq * A; i += SCORE_WG * 4) {
-        const float* src = a.q + ((size_t)clip * a.nq_total + a.q0) * A + i;
-        f32x4 v = ld4(src);
-        for (int p = 1; p < a.q_nparts; ++p) v += ld4(src + (size_t)p * a.q_part_stride);
-        if (a.q_bias != nullptr) v += ld4(a.q_bias + (i % A));
+    for (int i = tid * 4; i < nq_pad * A; i += SCORE_WG * 4) {
+        f32x4 v = {0, 0, 0, 0};
+        if (i < nq * A) {
+            const float* src = a.q + ((size_t)clip * a.nq_total + a.q0) * A + i;
+            v = ld4(src);
+            for (int p = 1; p < a.q_nparts; ++p) v += ld4(src + (size_t)p * a.q_part_stride);
+            if (a.q_bias != nullptr) v += ld4(a.q_bias + (i % A));
+        }
         st4(q_s + i, v);
     }
     if (KIND == CVC_ATTN_ADDITIVE)
@@ -58,52 +65,80 @@ __global__ __launch_bounds__(SCORE_WG) void attn_scores_kernel(ScoreArgs a) {
     auto rows = [&](auto stream_tag) __attribute__((always_inline)) {
         constexpr bool STREAM = decltype(stream_tag)::value;
 #define LDF(ptr) (STREAM ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ptr)) : ld4(ptr))
+    // Every load of the row loop is issued UNCONDITIONALLY (clamped addresses instead of guards): with a load under a
+    // divergent `col < A` or a `next row exists` branch, hipcc's s_waitcnt insertion gives up counting and waits vmcnt(0)
+    // right after the prefetch is issued -- the prefetch then overlaps nothing (the score pass sat at 31 us / 87 us for
+    // 1 / 5 queries with most wave cycles in s_waitcnt).  Columns beyond A load a valid address and are zeroed by select.
     f32x4 cur[NCH], nxt[NCH];
-    int r = row0 + wave;
-    if (r < row_end) {
+    int colc[NCH];
+    bool cok[NCH];
 #pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            int col = (j * 64 + lane) * 4;
-            cur[j] = col < A ? LDF(P + (size_t)r * A + col) : f32x4{0, 0, 0, 0};
-        }
+    for (int j = 0; j < NCH; ++j) {
+        const int col = (j * 64 + lane) * 4;
+        cok[j] = col < A;
+        colc[j] = cok[j] ? col : A - 4;
     }
-    for (; r < row_end; r += 4) {
-        const int rn = r + 4;
-        if (rn < row_end) {
+    int r = row0 + wave;
+    if (r >= row_end) return;
+    // region mask bits of this wave's rows (rows r, r + 4, ...), fetched before the pipelined loop
+    unsigned mbits = 0;
+    if (S.mask != nullptr)
+        for (int k = 0, rr = r; rr < row_end; ++k, rr += 4) mbits |= (S.mask[(size_t)clip * n + rr] != 0 ? 1u : 0u) << k;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) cur[j] = LDF(P + (size_t)r * A + colc[j]);
+    for (int k = 0; r < row_end; r += 4, ++k) {
+#if defined(CVC_SC_ABL) && CVC_SC_ABL == 2
+        const int rn = r;
+#else
+        const int rn = min(r + 4, row_end - 1);          // past the end: re-read the last row (unused)
+#endif
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) nxt[j] = LDF(P + (size_t)rn * A + colc[j]);
+        const bool masked = (mbits >> k) & 1u;
+        // queries in groups of QG: their accumulators are independent chains for the VALU, and the wave reductions of a group
+        // are issued back to back (beams of a clip / the T localizer queries of a clip share this row's registers)
+        for (int q0 = 0; q0 < nq; q0 += QG) {
+            float acc[QG];
+#pragma unroll
+            for (int u = 0; u < QG; ++u) acc[u] = 0.f;
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
-                int col = (j * 64 + lane) * 4;
-                nxt[j] = col < A ? LDF(P + (size_t)rn * A + col) : f32x4{0, 0, 0, 0};
-            }
-        }
-        const bool masked = S.mask != nullptr && S.mask[(size_t)clip * n + r] != 0;
-        for (int qi = 0; qi < nq; ++qi) {
-            float acc = 0.f;
+                const f32x4 p = cok[j] ? cur[j] : f32x4{0, 0, 0, 0};
+                f32x4 w4 = {0, 0, 0, 0};
+                if (KIND == CVC_ATTN_ADDITIVE) {
+                    w4 = ld4(w_s + colc[j]);
+                    if (!cok[j]) w4 = f32x4{0, 0, 0, 0};
+                }
 #pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                int col = (j * 64 + lane) * 4;
-                if (col < A) {
-                    f32x4 q4 = ld4(q_s + qi * A + col);
-                    f32x4 p = cur[j];
+                for (int u = 0; u < QG; ++u) {
+                    const f32x4 q4 = ld4(q_s + (q0 + u) * A + colc[j]);
+#if defined(CVC_SC_ABL) && CVC_SC_ABL == 1
+                    if (KIND == CVC_ATTN_ADDITIVE) {                       // ablation: no transcendental work
+                        acc[u] += w4.x * (p.x + q4.x) + w4.y * (p.y + q4.y) + w4.z * (p.z + q4.z) + w4.w * (p.w + q4.w);
+                    } else
+#endif
                     if (KIND == CVC_ATTN_ADDITIVE) {
-                        f32x4 w4 = ld4(w_s + col);
-                        acc += w4.x * fast_tanh(p.x + q4.x);
-                        acc += w4.y * fast_tanh(p.y + q4.y);
-                        acc += w4.z * fast_tanh(p.z + q4.z);
-                        acc += w4.w * fast_tanh(p.w + q4.w);
+                        acc[u] += w4.x * fast_tanh(p.x + q4.x);
+                        acc[u] += w4.y * fast_tanh(p.y + q4.y);
+                        acc[u] += w4.z * fast_tanh(p.z + q4.z);
+                        acc[u] += w4.w * fast_tanh(p.w + q4.w);
                     } else {
-                        acc += p.x * q4.x + p.y * q4.y + p.z * q4.z + p.w * q4.w;
+                        acc[u] += p.x * q4.x + p.y * q4.y + p.z * q4.z + p.w * q4.w;
                     }
                 }
             }
-            acc = wave_sum(acc);
-            if (lane == 0) {
-                float sc = KIND == CVC_ATTN_ADDITIVE ? acc + (a.b_a != nullptr ? a.b_a[0] : 0.f) : acc * a.inv_temp;
-                if (masked) sc = CVC_MIN_VALUE;
-                const size_t o = ((size_t)clip * a.nq_total + a.q0 + qi) * n + r;
-                S.scores[o] = sc;
-                if (S.frame_masked != nullptr)
-                    S.frame_masked[o] = S.frame_mask[o] != 0 ? CVC_MIN_VALUE : sc;
+#pragma unroll
+            for (int u = 0; u < QG; ++u) acc[u] = wave_sum(acc[u]);
+#pragma unroll
+            for (int u = 0; u < QG; ++u) {
+                if (q0 + u < nq && lane == 0) {
+                    float sc = KIND == CVC_ATTN_ADDITIVE ? acc[u] + (a.b_a != nullptr ? a.b_a[0] : 0.f) : acc[u] * a.inv_temp;
+                    if (masked) sc = CVC_MIN_VALUE;
+                    const size_t o = ((size_t)clip * a.nq_total + a.q0 + q0 + u) * n + r;
+                    S.scores[o] = sc;
+                    if (S.frame_masked != nullptr)
+                        S.frame_masked[o] = S.frame_mask[o] != 0 ? CVC_MIN_VALUE : sc;
+                }
             }
         }
 #pragma unroll
@@ -114,10 +149,10 @@ __global__ __launch_bounds__(SCORE_WG) void attn_scores_kernel(ScoreArgs a) {
     if (S.stream & 1) rows(std::true_type{}); else rows(std::false_type{});
 }
 
-template <int KIND>
-int launch_scores(const ScoreArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+template <int KIND, int QG>
+int launch_scores_q(const ScoreArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     const int nch = (a.A + 255) / 256;
-#define CVC_SC(N) hipLaunchKernelGGL((attn_scores_kernel<KIND, N>), grid, dim3(SCORE_WG), lds, st, a)
+#define CVC_SC(N) hipLaunchKernelGGL((attn_scores_kernel<KIND, N, QG>), grid, dim3(SCORE_WG), lds, st, a)
     if (nch <= 1) CVC_SC(1);
     else if (nch <= 2) CVC_SC(2);
     else if (nch <= 4) CVC_SC(4);
@@ -126,6 +161,23 @@ int launch_scores(const ScoreArgs& a, dim3 grid, size_t lds, hipStream_t st) {
     else return CVC_E_TOOBIG;
 #undef CVC_SC
     return cvc_launch_status();
+}
+
+// queries per group for nq queries: 1 / 4 / 5 are compiled; the list is padded to a multiple (5 beams -> 5, 20 localizer
+// queries -> 5, 2 or 3 -> 4 with a little padding)
+inline int score_group(int nq) {
+    if (nq <= 1) return 1;
+    const int p4 = (nq + 3) / 4 * 4, p5 = (nq + 4) / 5 * 5;
+    return p5 <= p4 ? 5 : 4;
+}
+
+template <int KIND>
+int launch_scores(const ScoreArgs& a, dim3 grid, size_t lds, hipStream_t st) {
+    switch (score_group(a.nq)) {
+        case 1: return launch_scores_q<KIND, 1>(a, grid, lds, st);
+        case 4: return launch_scores_q<KIND, 4>(a, grid, lds, st);
+        default: return launch_scores_q<KIND, 5>(a, grid, lds, st);
+    }
 }
 
 
@@ -137,6 +189,10 @@ inline int run_scores(int kind, const float* q, const float* w_a, const float* b
     int q_per_launch = (int)((64 * 1024) / ((size_t)A * 4)) - 1;
     if (q_per_launch < 1) return CVC_E_TOOBIG;
     if (q_per_launch > nq) q_per_launch = nq;
+    // the padded query list of a launch must fit too: keep whole groups of 5 (or 4) per launch
+    if (q_per_launch < nq && q_per_launch >= 5) q_per_launch = q_per_launch / 5 * 5;
+    while (q_per_launch > 1 && (size_t)((q_per_launch + score_group(q_per_launch) - 1) / score_group(q_per_launch) *
+                                        score_group(q_per_launch) + 1) * A * 4 > 64 * 1024) --q_per_launch;
     ScoreArgs sa;
     sa.set[0] = sets[0];
     sa.set[1] = nsets > 1 ? sets[1] : sets[0];
@@ -148,7 +204,8 @@ inline int run_scores(int kind, const float* q, const float* w_a, const float* b
     for (int q0 = 0; q0 < nq; q0 += q_per_launch) {
         sa.q0 = q0;
         sa.nq = nq - q0 < q_per_launch ? nq - q0 : q_per_launch;
-        const size_t lds1 = (size_t)(sa.nq + 1) * A * sizeof(float);
+        const int qg = score_group(sa.nq);
+        const size_t lds1 = (size_t)((sa.nq + qg - 1) / qg * qg + 1) * A * sizeof(float);
         int rc = kind == CVC_ATTN_ADDITIVE ? launch_scores<CVC_ATTN_ADDITIVE>(sa, g1, lds1, st)
                                            : launch_scores<CVC_ATTN_DOT>(sa, g1, lds1, st);
         if (rc != 0) return rc;

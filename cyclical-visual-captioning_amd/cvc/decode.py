@@ -369,8 +369,12 @@ class DecodeEngine:
                                   ptr(self.att_steps[t]), None, N, self.stream_r)
             sets[1] = hip.AttnSet(ptr(pconv), ptr(conv), None, None, ptr(self.scores_f), None, ptr(self.attn_f), None, Fr,
                                   self.stream_f)
-            out.append(("attn_scores", L.cvc_attn_scores_qparts, (W.kind, ptr(self.parts_q), self.ks_q, ptr(W.b_h), ptr(W.w_a),
-                                                                  ptr(W.b_a), self.inv_temp, sets, 2, B, beam, A)))
+            # the query slabs are summed ONCE here: every one of a clip's ~19 score workgroups would otherwise re-sum
+            # ks_q x beam x A partials on its own (measured: 106 -> us of the score pass were that)
+            out.append(("h2attn_finish", L.cvc_tile_linear_finish, (ptr(self.parts_q), self.ks_q, rows * A, A, ptr(W.b_h), None, rows, A,
+                                                                    ptr(self.q), A)))
+            out.append(("attn_scores", L.cvc_attn_scores, (W.kind, ptr(self.q), ptr(W.w_a), ptr(W.b_a), self.inv_temp, sets, 2, B,
+                                                           beam, A)))
             out.append(("attn_wsum", L.cvc_attn_wsum_frag, (sets, 2, B, beam, R, xl_p, xl_s)))
             out.append(("lang_lstm", L.cvc_tile_gemm, (ptr(W.t_lang), xl_p, xl_s, 3 * R, rows, 4 * R, self.ks_gate,
                                                        ptr(self.parts_gate), 4 * R, rows * 4 * R)))
