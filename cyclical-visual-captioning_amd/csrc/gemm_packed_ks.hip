@@ -1,0 +1,230 @@
+// K-split gate GEMM of the decode engine (<= 64 rows) and its finishing kernel.
+//
+// What it fixes: in gemm_packed.hip one workgroup = 32 gate rows x all 64 batch rows x FULL K, so each of the 256 workgroups
+// reads the whole activation block: 402 MB of L2 reads per lang-LSTM GEMM next to the 201 MB of weights that come from HBM
+// (profiles/r01: loads-only 45 us, weights-only 31 us).  The activations cannot be shared below L2 there -- the waves of a
+// workgroup split K, so no two of them want the same chunk.
+//
+// Here one workgroup = 256 gate rows (8 packed blocks, one per wave) x 64 batch rows x K / S, S = 8 K slices for R = 2048:
+//   * weights: unchanged -- every wave streams ITS 32 rows straight into a register ring with non-temporal dwordx4 loads;
+//   * activations: all 8 waves want the SAME 32-k chunk, so it is fetched ONCE per workgroup (each wave loads one quad = 1 KB),
+//     split ONCE into the three bf16 terms (the per-wave split of X was 2/3 of the kernel's VALU work) and parked in LDS as
+//     MFMA-ready fragments; the waves read them back with conflict-free ds_read_b128.  L2 activation reads: 402 -> 50 MB;
+//   * the 32 x 64 partial tiles of the S slices go to fp32 slabs (16.8 MB, L2 / MALL resident) and a small finishing kernel
+//     adds them in slice order, applies biases + cell update and writes h' / c' in the quad layout of the next GEMMs.
+//     S maps onto the XCDs (slice = workgroup index mod 8), so an XCD's L2 holds one K slice of the activations.
+// Arithmetic: identical products to the full-K kernel's split mode (6 bf16 MFMAs per 16 k); the summation order over K differs
+// (fixed, deterministic).
+#include "cvc_common.h"
+#include "gemm_split.h"
+
+namespace {
+
+struct KsArgs {
+    const float* wp;     // packed weights [nblk][nquad][32][4]
+    const float* xq;     // packed activations [nquad][64][4]
+    int nquad;           // K / 4 (multiple of 8)
+    long long wstride;   // floats between consecutive 32-row blocks of wp (>= nquad * 128)
+    int nblk;            // R / 8 (multiple of 8)
+    int ksplit;
+    float* slab;         // [ksplit][nblk][64][32]
+};
+
+using u16x4 = __attribute__((ext_vector_type(4))) uint16_t;
+
+#ifndef CVC_KS_DEPTH
+#define CVC_KS_DEPTH 4
+#endif
+constexpr int XSTAGE = 12 * 1024;          // one 32-k activation chunk as fragments: [k16 step][row tile][term] x 1 KiB
+
+__device__ __forceinline__ void stage_x(char* stage, const f32x4 v, int wave, int lane) {
+    // this wave's quad of the chunk (k = 4 wave + e) for batch row `lane`: split, store 4 bf16 per term
+    u16x4 p[3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned u0 = __float_as_uint(v[e]);
+        const float r1 = v[e] - __uint_as_float(u0 & 0xffff0000u);
+        const unsigned u1 = __float_as_uint(r1);
+        const float r2 = r1 - __uint_as_float(u1 & 0xffff0000u);
+        p[0][e] = (uint16_t)(u0 >> 16); p[1][e] = (uint16_t)(u1 >> 16); p[2][e] = (uint16_t)(__float_as_uint(r2) >> 16);
+    }
+    // slot map shared with the weight fragments (gemm_packed.hip): lane half kh holds k = 16 kh + 8 s2 + slot
+    const int kh = wave >> 2, s2 = (wave & 3) >> 1, slot0 = 4 * (wave & 1);
+    const int mt = lane >> 5, i = lane & 31;
+    char* base = stage + ((s2 * 2 + mt) * 3) * 1024 + ((kh * 32 + i) * 8 + slot0) * 2;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u16x4*>(base + pl * 1024) = p[pl];
+}
+
+__global__ __launch_bounds__(512) void packed_ks_kernel(KsArgs a) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * XSTAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, kh = lane >> 5;
+    const int S = a.ksplit;
+    const int ks = (int)blockIdx.x % S, tile = (int)blockIdx.x / S;
+    const int blk = tile * 8 + wave;
+    const int nchunk_all = a.nquad >> 3;
+    const int c_lo = nchunk_all * ks / S, c_hi = nchunk_all * (ks + 1) / S;
+    const int n = c_hi - c_lo;
+    // weights: quad q of block blk at wp + ((blk * nquad + q) * 32 + i) * 4; this lane takes quads 8c + 4kh + {0..3}
+    const float* wl = a.wp + (size_t)blk * a.wstride + (size_t)i * 4 + (size_t)c_lo * 8 * 128 + kh * 4 * 128;
+    // activations: this wave's quad of chunk c, one row per lane
+    const float* xl = a.xq + ((size_t)(c_lo * 8 + wave) * 64 + lane) * 4;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+    if (n > 0) {
+        // every load below is unconditional (clamped chunk index): a load under a branch makes hipcc's s_waitcnt insertion
+        // fall back to vmcnt(0) and the ring stops overlapping anything
+        auto cl = [&](int c) { return c < n ? c : n - 1; };
+        auto ldw = [&](f32x4 (&w)[4], int c) __attribute__((always_inline)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                w[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wl + (size_t)cl(c) * 8 * 128 + q * 128));
+        };
+        auto ldx = [&](int c) __attribute__((always_inline)) { return ld4(xl + (size_t)cl(c) * 8 * 256); };
+        auto compute = [&](const f32x4 (&w)[4], const char* stage) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const Split3 W = split8(w[2 * s2], w[2 * s2 + 1]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const char* f = stage + ((s2 * 2 + mt) * 3) * 1024 + lane * 16;
+                    const u32x4 xh = *reinterpret_cast<const u32x4*>(f);
+                    const u32x4 xm = *reinterpret_cast<const u32x4*>(f + 1024);
+                    const u32x4 xo = *reinterpret_cast<const u32x4*>(f + 2048);
+                    acc[mt] = mfma_bf16(W.mid, xm, acc[mt]);
+                    acc[mt] = mfma_bf16(W.lo, xh, acc[mt]);
+                    acc[mt] = mfma_bf16(W.hi, xo, acc[mt]);
+                    acc[mt] = mfma_bf16(W.mid, xh, acc[mt]);
+                    acc[mt] = mfma_bf16(W.hi, xm, acc[mt]);
+                    acc[mt] = mfma_bf16(W.hi, xh, acc[mt]);
+                }
+            }
+        };
+
+        // Register rings of D chunks (weights: 4 KB per wave and chunk; activations: this wave's 1 KB quad), statically indexed
+        // by full unrolling.  Per chunk c: request activations then weights of chunk c + D - 1 (unconditional, clamped index);
+        // stage chunk c + 1's quad (requested D - 2 chunks ago) into the other LDS slot; multiply chunk c; barrier (publishes
+        // c + 1, everyone is done reading c).  D - 1 chunks of weights (16 KB per wave at D = 5) stay in flight under the MFMAs.
+        constexpr int D = CVC_KS_DEPTH;
+        f32x4 wr[D][4], xr[D];
+#pragma unroll
+        for (int s = 0; s < D - 1; ++s) { xr[s] = ldx(s); ldw(wr[s], s); }
+        stage_x(lds, xr[0], wave, lane);
+        __syncthreads();
+        for (int j = 0; j < n; j += D) {
+#pragma unroll
+            for (int s = 0; s < D; ++s) {
+                const int c = j + s;                                  // wave-uniform; slots past the end only re-request
+                xr[(s + D - 1) % D] = ldx(c + D - 1);
+                ldw(wr[(s + D - 1) % D], c + D - 1);
+                __builtin_amdgcn_sched_barrier(0);                    // requests first: the scheduler would sink them behind the MFMAs
+                stage_x(lds + ((c + 1) & 1) * XSTAGE, xr[(s + 1) % D], wave, lane);
+                if (c < n) compute(wr[s], lds + (c & 1) * XSTAGE);
+                __syncthreads();
+            }
+        }
+    }
+
+    // partial tile -> slab[ks][blk][m][row]: row = e + 8 rq + 4 kh for register 4 rq + e, so a lane stores float4s
+    float* out = a.slab + (((size_t)ks * a.nblk + blk) * 64) * 32;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = mt * 32 + i;
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const f32x4 v = {acc[mt][4 * rq], acc[mt][4 * rq + 1], acc[mt][4 * rq + 2], acc[mt][4 * rq + 3]};
+            st4(out + (size_t)m * 32 + 8 * rq + 4 * kh, v);
+        }
+    }
+}
+
+struct KsFinishArgs {
+    const float* slab; int ksplit; int nblk;
+    const float* b_ih; const float* b_hh;     // [4R], nullable
+    const float* gate_bias;                   // [M, 4R] row-major, nullable
+    const float* c_prev_q;                    // quad layout [R/4][64][4]
+    float* c_out_q; float* h_dst1_q; float* h_dst2_q;
+    int M, R;
+};
+
+// NS = number of slabs (compile time: the slab reads of a gate are then issued together instead of one L2 round trip after
+// the other)
+template <int NS>
+__global__ __launch_bounds__(128) void packed_ks_finish_kernel(KsFinishArgs a) {
+    const int t = blockIdx.x * 128 + threadIdx.x;
+    const int hq = t & 1, m = (t >> 1) & 63, blk = t >> 7;
+    if (blk >= a.nblk || m >= a.M) return;
+    const int R = a.R;
+    const int j = blk * 8 + hq * 4;                            // first of this thread's 4 hidden units
+    f32x4 pre[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float* p = a.slab + (((size_t)blk * 64 + m) * 32) + g * 8 + hq * 4;
+        f32x4 v[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) v[k] = ld4(p + (size_t)k * a.nblk * 64 * 32);
+        f32x4 s = v[0];
+#pragma unroll
+        for (int k = 1; k < NS; ++k) s += v[k];
+        if (a.b_ih != nullptr) s += ld4(a.b_ih + g * R + j);
+        if (a.b_hh != nullptr) s += ld4(a.b_hh + g * R + j);
+        if (a.gate_bias != nullptr) s += ld4(a.gate_bias + (size_t)m * 4 * R + g * R + j);
+        pre[g] = s;
+    }
+    const size_t qoff = ((size_t)(j >> 2) * 64 + m) * 4;
+    const f32x4 cp = ld4(a.c_prev_q + qoff);
+    f32x4 hv, cv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float ig = fast_sigmoid(pre[0][e]), fg = fast_sigmoid(pre[1][e]);
+        const float gg = fast_tanh(pre[2][e]), og = fast_sigmoid(pre[3][e]);
+        const float c2 = fg * cp[e] + ig * gg;
+        cv[e] = c2;
+        hv[e] = og * fast_tanh(c2);
+    }
+    st4(a.c_out_q + qoff, cv);
+    if (a.h_dst1_q != nullptr) st4(a.h_dst1_q + qoff, hv);
+    if (a.h_dst2_q != nullptr) st4(a.h_dst2_q + qoff, hv);
+}
+
+}  // namespace
+
+extern "C" int cvc_packed_lstm_ks_slices(int K, int R) {
+    if (R < 64 || (R & 63) || (K & 31)) return 0;           // not covered: use cvc_packed_lstm_fwd
+    const int ntile = R / 64, nchunk = K / 32;
+    int s = 8;                                               // a power of two: 8, 4, 2 or 1 slices
+    while (s > 1 && (ntile * s > 256 || nchunk / s < 6)) s >>= 1;     // <= 256 workgroups, at least a few chunks per slice
+    return s;
+}
+
+extern "C" int cvc_packed_lstm_ks_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
+                                      const float* gate_bias, const float* c_prev_q, int M, int R, float* h_dst1_q,
+                                      float* h_dst2_q, float* c_out_q, float* slab, long long w_blk_stride, cvc_stream_t stream) {
+    if (!wp || !xq || !c_prev_q || !c_out_q || !slab || M < 1 || M > 64) return CVC_E_BADARG;
+    const int S = cvc_packed_lstm_ks_slices(K, R);
+    if (S < 1) return CVC_E_BADARG;
+    KsArgs a;
+    a.wp = wp; a.xq = xq; a.nquad = K / 4; a.nblk = R / 8; a.ksplit = S; a.slab = slab;
+    a.wstride = w_blk_stride > 0 ? w_blk_stride : (long long)(K / 4) * 128;
+    if (a.wstride < (long long)(K / 4) * 128 || (a.wstride & 3)) return CVC_E_BADARG;
+    hipLaunchKernelGGL(packed_ks_kernel, dim3((R / 64) * S), dim3(512), 0, (hipStream_t)stream, a);
+    int rc = cvc_launch_status();
+    if (rc) return rc;
+    KsFinishArgs f;
+    f.slab = slab; f.ksplit = S; f.nblk = R / 8; f.b_ih = b_ih; f.b_hh = b_hh; f.gate_bias = gate_bias; f.c_prev_q = c_prev_q;
+    f.c_out_q = c_out_q; f.h_dst1_q = h_dst1_q; f.h_dst2_q = h_dst2_q; f.M = M; f.R = R;
+    const dim3 g(R / 8);                                     // one 128-thread workgroup per packed block: (64 rows) x (2 hidden quads)
+    switch (S) {
+        case 8: hipLaunchKernelGGL(packed_ks_finish_kernel<8>, g, dim3(128), 0, (hipStream_t)stream, f); break;
+        case 4: hipLaunchKernelGGL(packed_ks_finish_kernel<4>, g, dim3(128), 0, (hipStream_t)stream, f); break;
+        case 2: hipLaunchKernelGGL(packed_ks_finish_kernel<2>, g, dim3(128), 0, (hipStream_t)stream, f); break;
+        default: hipLaunchKernelGGL(packed_ks_finish_kernel<1>, g, dim3(128), 0, (hipStream_t)stream, f); break;
+    }
+    return cvc_launch_status();
+}

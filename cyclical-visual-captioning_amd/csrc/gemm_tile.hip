@@ -226,6 +226,8 @@ struct LstmFinishArgs {
     int M, R;
 };
 
+// NP = number of slabs when it is 1 / 2 / 4 / 8 (their reads are then issued together), 0 = any number (one after the other)
+template <int NP>
 __global__ __launch_bounds__(256) void tile_lstm_finish_kernel(LstmFinishArgs a) {
     const int R = a.R;
     const int q = blockIdx.x * 256 + threadIdx.x;            // (row m, hidden quad)
@@ -236,8 +238,19 @@ __global__ __launch_bounds__(256) void tile_lstm_finish_kernel(LstmFinishArgs a)
     f32x4 pre[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        f32x4 s = ld4(a.parts + (size_t)m * 4 * R + col + g * 8);
-        for (int p = 1; p < a.nparts; ++p) s += ld4(a.parts + (size_t)p * a.part_stride + (size_t)m * 4 * R + col + g * 8);
+        const float* src = a.parts + (size_t)m * 4 * R + col + g * 8;
+        f32x4 s;
+        if constexpr (NP > 0) {
+            f32x4 v[NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) v[p] = ld4(src + (size_t)p * a.part_stride);
+            s = v[0];
+#pragma unroll
+            for (int p = 1; p < NP; ++p) s += v[p];
+        } else {
+            s = ld4(src);
+            for (int p = 1; p < a.nparts; ++p) s += ld4(src + (size_t)p * a.part_stride);
+        }
         if (a.b_ih != nullptr) s += ld4(a.b_ih + g * R + j);
         if (a.b_hh != nullptr) s += ld4(a.b_hh + g * R + j);
         if (a.gate_bias != nullptr) s += ld4(a.gate_bias + (size_t)(m / a.gb_div) * 4 * R + g * R + j);
@@ -260,13 +273,25 @@ __global__ __launch_bounds__(256) void tile_lstm_finish_kernel(LstmFinishArgs a)
 }
 
 // y[m, n] = sum_p parts[p][m, n] + bias[n] + bias2[n]      (vocabulary logits / gate_fc of the tile path)
+template <int NP>
 __global__ __launch_bounds__(256) void tile_linear_finish_kernel(const float* parts, int nparts, long long part_stride, int ld,
                                                                  const float* bias, const float* bias2, int M, int N, float* y,
                                                                  int ldy) {
     const int n = blockIdx.x * 256 + threadIdx.x, m = blockIdx.y;
     if (n >= N) return;
-    float s = parts[(size_t)m * ld + n];
-    for (int p = 1; p < nparts; ++p) s += parts[(size_t)p * part_stride + (size_t)m * ld + n];
+    const float* src = parts + (size_t)m * ld + n;
+    float s;
+    if constexpr (NP > 0) {
+        float v[NP];
+#pragma unroll
+        for (int p = 0; p < NP; ++p) v[p] = src[(size_t)p * part_stride];
+        s = v[0];
+#pragma unroll
+        for (int p = 1; p < NP; ++p) s += v[p];
+    } else {
+        s = src[0];
+        for (int p = 1; p < nparts; ++p) s += src[(size_t)p * part_stride];
+    }
     if (bias != nullptr) s += bias[n];
     if (bias2 != nullptr) s += bias2[n];
     y[(size_t)m * ldy + n] = s;
@@ -367,15 +392,33 @@ extern "C" int cvc_tile_lstm_finish(const float* parts, int nparts, long long pa
     a.gb_div = gb_div; a.c_prev = c_prev; a.c_out = c_out; a.h_out = h_out; a.frag1 = (uint16_t*)frag1; a.frag1_stride = frag1_stride;
     a.frag2 = (uint16_t*)frag2; a.frag2_stride = frag2_stride; a.M = M; a.R = R;
     const long long n = (long long)M * (R / 4);
-    hipLaunchKernelGGL(tile_lstm_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
+    const dim3 g((unsigned)((n + 255) / 256));
+    switch (nparts) {
+        case 1: hipLaunchKernelGGL(tile_lstm_finish_kernel<1>, g, dim3(256), 0, (hipStream_t)stream, a); break;
+        case 2: hipLaunchKernelGGL(tile_lstm_finish_kernel<2>, g, dim3(256), 0, (hipStream_t)stream, a); break;
+        case 4: hipLaunchKernelGGL(tile_lstm_finish_kernel<4>, g, dim3(256), 0, (hipStream_t)stream, a); break;
+        case 8: hipLaunchKernelGGL(tile_lstm_finish_kernel<8>, g, dim3(256), 0, (hipStream_t)stream, a); break;
+        default: hipLaunchKernelGGL(tile_lstm_finish_kernel<0>, g, dim3(256), 0, (hipStream_t)stream, a); break;
+    }
     return cvc_launch_status();
 }
 
 extern "C" int cvc_tile_linear_finish(const float* parts, int nparts, long long part_stride, int ld, const float* bias,
                                       const float* bias2, int M, int N, float* y, int ldy, cvc_stream_t stream) {
     if (!parts || nparts < 1 || !y || M < 1 || N < 1 || ld < N || ldy < N) return CVC_E_BADARG;
-    hipLaunchKernelGGL(tile_linear_finish_kernel, dim3((N + 255) / 256, M), dim3(256), 0, (hipStream_t)stream, parts, nparts,
-                       part_stride, ld, bias, bias2, M, N, y, ldy);
+    const dim3 g((N + 255) / 256, M);
+#define CVC_LF(NP) hipLaunchKernelGGL(tile_linear_finish_kernel<NP>, g, dim3(256), 0, (hipStream_t)stream, parts, nparts, \
+                                      part_stride, ld, bias, bias2, M, N, y, ldy)
+    switch (nparts) {
+        case 1: CVC_LF(1); break;
+        case 2: CVC_LF(2); break;
+        case 4: CVC_LF(4); break;
+        case 6: CVC_LF(6); break;
+        case 8: CVC_LF(8); break;
+        case 16: CVC_LF(16); break;
+        default: CVC_LF(0); break;
+    }
+#undef CVC_LF
     return cvc_launch_status();
 }
 

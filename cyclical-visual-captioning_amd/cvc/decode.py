@@ -57,9 +57,10 @@ def _segs(items):
     return arr
 
 
-def pack_weights(w: torch.Tensor, lstm_R: Optional[int] = None) -> torch.Tensor:
-    """[Nout, K] row-major -> MFMA-fragment-native [ceil(Nout/32)][K/4][32][4] (include/cvc_hip.h, "Packed
-    path").  For an LSTM gate matrix (Nout = 4R) block b holds the 4 gates of hidden units 8b..8b+7."""
+def pack_weights(w: torch.Tensor, lstm_R: Optional[int] = None, pad_quads: int = 0) -> torch.Tensor:
+    """[Nout, K] row-major -> MFMA-fragment-native [ceil(Nout/32)][K/4 (+ pad_quads)][32][4] (include/cvc_hip.h, "Packed
+    path").  For an LSTM gate matrix (Nout = 4R) block b holds the 4 gates of hidden units 8b..8b+7.  pad_quads unused
+    quads per block stagger the blocks in HBM (cvc_packed_lstm_ks_fwd's w_blk_stride)."""
     n, k = w.shape
     assert k % 32 == 0, k
     if lstm_R is not None:
@@ -73,7 +74,12 @@ def pack_weights(w: torch.Tensor, lstm_R: Optional[int] = None) -> torch.Tensor:
         nb = (n + 31) // 32
         if nb * 32 != n:
             w = torch.cat([w, w.new_zeros(nb * 32 - n, k)], 0)
-    return w.view(nb, 32, k // 4, 4).permute(0, 2, 1, 3).contiguous()
+    out = w.view(nb, 32, k // 4, 4).permute(0, 2, 1, 3)
+    if pad_quads:
+        padded = w.new_zeros(nb, k // 4 + pad_quads, 32, 4)
+        padded[:, :k // 4] = out
+        return padded
+    return out.contiguous()
 
 
 def to_quad(x: torch.Tensor) -> torch.Tensor:
@@ -137,6 +143,9 @@ def pack_weights_tile(w: torch.Tensor, lstm_R: Optional[int] = None) -> torch.Te
     return to_frag(w, (n + 127) // 128 * 128)
 
 
+GATE_KSPLIT_DEFAULT = False   # measured (profiles/README.md, r02): the K-split kernel itself is 8-9 us faster per GEMM, its finishing launch costs the same
+KS_PAD_QUADS = 0          # extra quads between the 32-row weight blocks of the K-split gate GEMM (measured: no effect; 0 = share the dense pack)
+
 CACHE_BUDGET = 208 << 20      # bytes re-read every step that are left cacheable in the 256 MiB Infinity Cache
 
 
@@ -163,7 +172,7 @@ class DecodeEngine:
     """Binds weights + one batch of clip features to preallocated state and a launch list."""
 
     def __init__(self, weights: DecodeWeights, feats: Dict[str, torch.Tensor], T: int, unk_idx: int, beam: int = 1,
-                 inv_temp: float = 1.0, own_features: bool = False, path: str = "auto"):
+                 inv_temp: float = 1.0, own_features: bool = False, path: str = "auto", gate_ksplit: Optional[bool] = None):
         """path: "auto" picks packed (greedy, <= 64 rows) / tile (> 64 rows or beams) / ring (odd widths); "ring" forces the
         row-major fallback kernels (tests compare the paths).
         own_features: keep private copies of the clip features, so that the bound launch list (and a captured HIP
@@ -224,6 +233,8 @@ class DecodeEngine:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self._keep: List = []
         self.packed = self.beam == 1 and rows <= 64 and R % 32 == 0 and W.E % 32 == 0 and A % 32 == 0
+        # packed path: K-split gate GEMMs (activations shared through LDS, csrc/gemm_packed_ks.hip) where the shape allows
+        self.gate_ksplit = GATE_KSPLIT_DEFAULT if gate_ksplit is None else bool(gate_ksplit)
         # more than 64 live rows (beam search, big greedy batches): bf16-fragment tile GEMMs (csrc/gemm_tile.hip)
         self.tile = (not self.packed) and (self.beam > 1 or rows > 64) and R % 16 == 0 and W.E % 16 == 0 and path != "ring"
         if self.packed:
@@ -254,6 +265,15 @@ class DecodeEngine:
         bos = torch.relu(W.embed[0]).view(1, E).expand(self.rows, E).contiguous()
         self.XA0_init = zq(2 * R + E)
         self.XA0_init[R // 4:(R + E) // 4] = to_quad(bos)
+        L = hip.lib()
+        self.ks_att = int(L.cvc_packed_lstm_ks_slices(2 * R + E, R)) if self.gate_ksplit else 0
+        self.ks_lang = int(L.cvc_packed_lstm_ks_slices(3 * R, R)) if self.gate_ksplit else 0
+        self.ks_pad = KS_PAD_QUADS if (self.ks_att or self.ks_lang) else 0
+        if self.ks_pad and not hasattr(W, "p_att_ks"):
+            W.p_att_ks = pack_weights(torch.cat([W.w_ih_att[:, 0:R], W.w_ih_att[:, 2 * R:2 * R + E], W.w_hh_att], 1), R, self.ks_pad)
+            W.p_lang_ks = pack_weights(torch.cat([W.w_ih_lang, W.w_hh_lang], 1), R, self.ks_pad)
+        if self.ks_att or self.ks_lang:
+            self.gate_slab = torch.empty(max(self.ks_att, self.ks_lang) * (R // 8) * 2048, device=dev, dtype=torch.float32)
 
     def _build_packed(self):
         L, W = hip.lib(), self.W
@@ -270,9 +290,15 @@ class DecodeEngine:
         for t in range(self.T):
             rd, wr = t & 1, (t + 1) & 1
             XA_r, XA_w, XL_r, XL_w = self.XA[rd], self.XA[wr], self.XL[rd], self.XL[wr]
-            out.append(("att_lstm", L.cvc_packed_lstm_fwd, (ptr(W.p_att), ptr(XA_r), 2 * R + E, None, None, ptr(self.gate_fc),
-                                                            ptr(self.cA[rd]), rows, R, qoff(XL_r, R), qoff(XA_w, R + E),
-                                                            ptr(self.cA[wr]))))
+            if self.ks_att:
+                wp_att = W.p_att_ks if self.ks_pad else W.p_att
+                out.append(("att_lstm", L.cvc_packed_lstm_ks_fwd, (ptr(wp_att), ptr(XA_r), 2 * R + E, None, None, ptr(self.gate_fc),
+                                                                   ptr(self.cA[rd]), rows, R, qoff(XL_r, R), qoff(XA_w, R + E),
+                                                                   ptr(self.cA[wr]), ptr(self.gate_slab), wp_att.stride(0))))
+            else:
+                out.append(("att_lstm", L.cvc_packed_lstm_fwd, (ptr(W.p_att), ptr(XA_r), 2 * R + E, None, None, ptr(self.gate_fc),
+                                                                ptr(self.cA[rd]), rows, R, qoff(XL_r, R), qoff(XA_w, R + E),
+                                                                ptr(self.cA[wr]))))
             out.append(("h2attn", L.cvc_packed_linear_fwd, (ptr(W.p_h), qoff(XL_r, R), R, None, rows, A, self.QSPLIT,
                                                             ptr(self.q_parts), A, None)))
             sets = (hip.AttnSet * 2)()
@@ -283,9 +309,16 @@ class DecodeEngine:
             out.append(("attn_scores", L.cvc_attn_scores_qparts, (W.kind, ptr(self.q_parts), self.QSPLIT, ptr(W.b_h), ptr(W.w_a),
                                                                   ptr(W.b_a), self.inv_temp, sets, 2, B, 1, A)))
             out.append(("attn_wsum", L.cvc_attn_wsum_quad, (sets, 2, B, 1, R, ptr(XL_r))))
-            out.append(("lang_lstm", L.cvc_packed_lstm_fwd, (ptr(W.p_lang), ptr(XL_r), 3 * R, ptr(W.b_ih_lang), ptr(W.b_hh_lang),
-                                                             None, ptr(self.cL[rd]), rows, R, ptr(XA_w), qoff(XL_w, 2 * R),
-                                                             ptr(self.cL[wr]))))
+            if self.ks_lang:
+                wp_lang = W.p_lang_ks if self.ks_pad else W.p_lang
+                out.append(("lang_lstm", L.cvc_packed_lstm_ks_fwd, (ptr(wp_lang), ptr(XL_r), 3 * R, ptr(W.b_ih_lang),
+                                                                    ptr(W.b_hh_lang), None, ptr(self.cL[rd]), rows, R, ptr(XA_w),
+                                                                    qoff(XL_w, 2 * R), ptr(self.cL[wr]), ptr(self.gate_slab),
+                                                                    wp_lang.stride(0))))
+            else:
+                out.append(("lang_lstm", L.cvc_packed_lstm_fwd, (ptr(W.p_lang), ptr(XL_r), 3 * R, ptr(W.b_ih_lang), ptr(W.b_hh_lang),
+                                                                 None, ptr(self.cL[rd]), rows, R, ptr(XA_w), qoff(XL_w, 2 * R),
+                                                                 ptr(self.cL[wr]))))
             out.append(("logits", L.cvc_packed_linear_fwd, (ptr(W.p_o), ptr(XA_w), R, ptr(W.b_o), rows, V, 1, None, V,
                                                             ptr(self.top2_part))))
             out.append(("word_select", L.cvc_top2_final, (ptr(self.top2_part), nblk_v, rows, self.unk, ptr(self.words[t + 1]), 1,

@@ -149,6 +149,19 @@ int cvc_packed_lstm_fwd(const float* wp, const float* xq, int K, const float* b_
 int cvc_packed_linear_fwd(const float* wp, const float* xq, int K, const float* bias, int M, int Nout,
                           int ksplit, float* y, int ldy, float* top2_part, cvc_stream_t stream);
 
+/* K-split variant of cvc_packed_lstm_fwd (same operands, same arithmetic): one workgroup = 256 gate rows x K / S, the 32-k
+ * activation chunks fetched and split once per workgroup and shared through LDS (cuts the L2 activation reads of the full-K
+ * kernel from 2 x the weight bytes to 1/4 of them); partial tiles go to `slab` (>= S * (R/8) * 2048 floats, S =
+ * cvc_packed_lstm_ks_slices(K, R)) and a finishing launch sums them in slice order, adds the biases and does the cell update.
+ * w_blk_stride: floats between consecutive 32-row blocks of wp (0 = dense, K/4 * 128): a pack whose blocks are 4 KB further
+ * apart than dense keeps the 8 waves of a workgroup, which stream the same chunk index of 8 different blocks, off the same
+ * HBM channels.
+ * cvc_packed_lstm_ks_slices returns 0 when the shape is not covered (R % 64 != 0): use cvc_packed_lstm_fwd then. */
+int cvc_packed_lstm_ks_slices(int K, int R);
+int cvc_packed_lstm_ks_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
+                           const float* gate_bias, const float* c_prev_q, int M, int R, float* h_dst1_q,
+                           float* h_dst2_q, float* c_out_q, float* slab, long long w_blk_stride, cvc_stream_t stream);
+
 /* Packed path arithmetic.  mode 2 (default) / 1: every fp32 operand is split exactly into three bf16 terms
  * (v = hi + mid + lo) and each product taken as its six leading cross terms on the bf16 MFMA, fp32
  * accumulate -- the dropped terms are < 2^-23 relative, the level of one fp32 rounding (measured error

@@ -357,6 +357,47 @@ def test_split_product_gemm_is_fp32_grade(dev, lib, M, K, N):
         assert err[mode][0] <= 1.25 * err[0][0] and err[mode][1] <= 1.25 * err[0][1], err
 
 
+@pytest.mark.parametrize("M,R,E", [(64, 2048, 1024), (37, 256, 96), (1, 64, 32), (64, 4096, 2048)])
+def test_packed_lstm_ksplit_equals_full_k_kernel(dev, lib, M, R, E):
+    """cvc_packed_lstm_ks_fwd (256 gate rows x K / S per workgroup, activations shared through LDS, slabs + finishing kernel)
+    against cvc_packed_lstm_fwd on the same packed operands: same products, different K summation order -> fp32 noise; and
+    against fp64; bitwise run-to-run determinism."""
+    from cvc.decode import pack_weights, to_quad, from_quad
+    g = torch.Generator().manual_seed(M + R)
+    K = 2 * R + E
+    w = (torch.randn(4 * R, K, generator=g) / K ** 0.5).to(dev)
+    x = torch.randn(M, K, generator=g).to(dev)
+    b1, b2 = (torch.randn(4 * R, generator=g) * 0.1).to(dev), (torch.randn(4 * R, generator=g) * 0.1).to(dev)
+    gb = (torch.randn(M, 4 * R, generator=g) * 0.2).to(dev)
+    c_prev = torch.randn(M, R, generator=g).to(dev)
+    wp, xq, cq = pack_weights(w, R), to_quad(x), to_quad(c_prev)
+    L = lib.lib()
+    S = L.cvc_packed_lstm_ks_slices(K, R)
+    assert S in (1, 2, 4, 8)
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for mode in ("full", "ks", "ks"):
+        h1, h2, c2 = torch.zeros(R // 4, 64, 4, device=dev), torch.zeros(R // 4, 64, 4, device=dev), torch.zeros(R // 4, 64, 4, device=dev)
+        if mode == "full":
+            rc = L.cvc_packed_lstm_fwd(wp.data_ptr(), xq.data_ptr(), K, b1.data_ptr(), b2.data_ptr(), gb.data_ptr(), cq.data_ptr(), M, R,
+                                       h1.data_ptr(), h2.data_ptr(), c2.data_ptr(), st)
+        else:
+            slab = torch.empty(S * (R // 8) * 2048, device=dev)
+            wpk = pack_weights(w, R, pad_quads=8 if len(outs) == 1 else 0)           # staggered and dense block strides
+            rc = L.cvc_packed_lstm_ks_fwd(wpk.data_ptr(), xq.data_ptr(), K, b1.data_ptr(), b2.data_ptr(), gb.data_ptr(), cq.data_ptr(), M, R,
+                                          h1.data_ptr(), h2.data_ptr(), c2.data_ptr(), slab.data_ptr(), wpk.stride(0), st)
+        assert rc == 0
+        outs.append((from_quad(h1, M), from_quad(h2, M), from_quad(c2, M)))
+    (hf, _, cf), (hk, hk2, ck), (hk_b, _, ck_b) = outs
+    assert torch.equal(hk, hk2) and torch.equal(hk, hk_b) and torch.equal(ck, ck_b)
+    close(hk, hf, rtol=2e-5, atol=2e-5); close(ck, cf, rtol=2e-5, atol=2e-5)
+    pre = x.double() @ w.double().t() + b1.double() + b2.double() + gb.double()
+    i, f, gg, o = pre.chunk(4, 1)
+    c_ref = torch.sigmoid(f) * c_prev.double() + torch.sigmoid(i) * torch.tanh(gg)
+    h_ref = torch.sigmoid(o) * torch.tanh(c_ref)
+    close(hk, h_ref.float(), rtol=2e-5, atol=2e-5); close(ck, c_ref.float(), rtol=2e-5, atol=2e-5)
+
+
 @pytest.mark.parametrize("M,K,N,ksplit", [(320, 6144, 8192, 4), (320, 2048, 5000, 6), (150, 512, 130, 3), (65, 32, 50, 2),
                                           (700, 256, 256, 1), (1, 16, 1, 1)])
 def test_tile_gemm_vs_fp64(dev, lib, M, K, N, ksplit):

@@ -1,9 +1,13 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/r02e
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_ACTIVE_INST_LDS -d $R/gpurun_out/r02e/pmc_sq -o sq -- python3 $R/bench.py --beam 5 --steps 2 --warmup 1 --no-graph --no-cpu-baseline > $R/gpurun_out/r02e/pmc_sq.log 2>&1
-ls -R $R/gpurun_out/r02e/pmc_sq | head
-DB=$(find $R/gpurun_out/r02e/pmc_sq -name "*.db" | head -1)
-python3 $R/tools/rocpd_pmc.py $DB > $R/gpurun_out/r02e/pmc_sq.md 2>&1
-grep -E "attn_scores|attn_wsum|tile_gemm" $R/gpurun_out/r02e/pmc_sq.md | head -40
-rm -rf $R/gpurun_out/r02e/pmc_sq
+cd $R && timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "ksplit" 2>&1 | tail -2; cd /tmp
+for PAD in 8 0 24; do
+sed -i "s/^KS_PAD_QUADS = .*/KS_PAD_QUADS = $PAD/" $R/cyclical-visual-captioning_amd/cvc/decode.py
+echo "== pad quads $PAD"
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/r02e/kt -o kt -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $R/gpurun_out/r02e/kt.log 2>&1
+DB=$(find $R/gpurun_out/r02e/kt -name "*.db" | head -1)
+python3 $R/tools/rocpd_summary.py $DB | grep -E "packed_ks" | cut -c1-150
+grep -o '"value": [0-9.]*' $R/gpurun_out/r02e/kt.log | head -1
+rm -rf $R/gpurun_out/r02e/kt
+done
