@@ -1,0 +1,197 @@
+// Host-side decode drivers: cvc_decode_greedy / cvc_decode_beam enqueue the whole T-step caption decode
+// (model/captioner.py:384-443) on the caller's stream from a bound descriptor -- the launch list that cvc/decode.py used to walk
+// in Python (one ctypes call per kernel), now one call per decode.  Nothing here touches the device except through the C-ABI
+// entry points of this library and stream-ordered memcpy / memset, so the call is capturable into a HIP graph.
+#include <hip/hip_runtime.h>
+#include <new>
+#include <stdint.h>
+#include "../../include/cvc_hip.h"
+
+struct cvc_decode_plan {
+    cvc_decode_desc d;
+    int launches;
+};
+
+namespace {
+
+#define CVC_TRY(expr)            \
+    do {                         \
+        int rc_ = (expr);        \
+        ++n;                     \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+inline float* quad_off(float* buf, int k0) { return buf + (size_t)(k0 / 4) * 64 * 4; }
+inline void* frag_off(void* xb, int k0) { return (char*)xb + (size_t)(k0 / 16) * 3 * 1024; }
+
+int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
+
+// State reset as ordinary kernel launches (16-byte granules): inside a captured graph they are plain kernel nodes, ordered like
+// every other launch of the decode (memcpy / memset nodes may be served by a copy engine).
+__global__ __launch_bounds__(256) void reset_kernel(uint4* dst, const uint4* src, size_t n16) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src != nullptr ? src[i] : uint4{0, 0, 0, 0};
+}
+int reset(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if ((bytes & 15) || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) {       // odd sizes (the BOS row of a ragged batch)
+        return hip_rc(src ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st) : hipMemsetAsync(dst, 0, bytes, st));
+    }
+    const size_t n16 = bytes / 16;
+    hipLaunchKernelGGL(reset_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (uint4*)dst, (const uint4*)src, n16);
+    return hip_rc(hipGetLastError());
+}
+
+void attn_sets(const cvc_decode_desc& d, int t, int rows, cvc_attn_set* sets) {
+    sets[0] = cvc_attn_set{d.ppool, d.pool, d.mask, nullptr, d.scores_r, nullptr, d.att_steps + (size_t)t * rows * d.N, nullptr,
+                           d.N, d.stream_r};
+    sets[1] = cvc_attn_set{d.pconv, d.conv, nullptr, nullptr, d.scores_f, nullptr, d.attn_f, nullptr, d.F, d.stream_f};
+}
+
+// ---- packed path: greedy, <= 64 rows (7 launches per step)
+int run_packed(cvc_decode_plan* p, hipStream_t st) {
+    const cvc_decode_desc& d = p->d;
+    const int rows = d.B, R = d.R, E = d.E, A = d.A, V = d.V, N = d.N;
+    const size_t qbytes = (size_t)64 * 4 * sizeof(float);          // one quad of the activation layout
+    int n = 0;
+    // reset: XA of step 0, zero XL / cell states / BOS words
+    CVC_TRY(reset(d.xa[0], d.xa0_init, (size_t)((2 * R + E) / 4) * qbytes, st));
+    CVC_TRY(reset(d.xl[0], nullptr, (size_t)(3 * R / 4) * qbytes, st));
+    CVC_TRY(reset(d.ca[0], nullptr, (size_t)(R / 4) * qbytes, st));
+    CVC_TRY(reset(d.cl[0], nullptr, (size_t)(R / 4) * qbytes, st));
+    CVC_TRY(reset(d.words, nullptr, (size_t)rows * sizeof(int64_t), st));
+    // hoisted fc gate term + both biases (decoder_core.py:46)
+    cvc_gemm_seg seg{d.fc, nullptr, d.w_fc, R, R, d.ld_w_fc, 0};
+    CVC_TRY(cvc_linear_fwd(&seg, 1, d.b_ih_att, d.b_hh_att, rows, 4 * R, d.gate_fc, 4 * R, st));
+    const int nblk_v = (V + 31) / 32;
+    for (int t = 0; t < d.T; ++t) {
+        const int rd = t & 1, wr = (t + 1) & 1;
+        float *XA_r = d.xa[rd], *XA_w = d.xa[wr], *XL_r = d.xl[rd], *XL_w = d.xl[wr];
+        CVC_TRY(cvc_packed_lstm_fwd((const float*)d.w_att, XA_r, 2 * R + E, nullptr, nullptr, d.gate_fc, d.ca[rd], rows, R,
+                                    quad_off(XL_r, R), quad_off(XA_w, R + E), d.ca[wr], st));
+        CVC_TRY(cvc_packed_linear_fwd((const float*)d.w_h, quad_off(XL_r, R), R, nullptr, rows, A, d.qsplit, d.q_parts, A, nullptr, st));
+        cvc_attn_set sets[2];
+        attn_sets(d, t, rows, sets);
+        CVC_TRY(cvc_attn_scores_qparts(d.attn_kind, d.q_parts, d.qsplit, d.b_h, d.w_a, d.b_a, d.inv_temp, sets, 2, d.B, 1, A, st));
+        CVC_TRY(cvc_attn_wsum_quad(sets, 2, d.B, 1, R, XL_r, st));
+        CVC_TRY(cvc_packed_lstm_fwd((const float*)d.w_lang, XL_r, 3 * R, d.b_ih_lang, d.b_hh_lang, nullptr, d.cl[rd], rows, R, XA_w,
+                                    quad_off(XL_w, 2 * R), d.cl[wr], st));
+        CVC_TRY(cvc_packed_linear_fwd((const float*)d.w_o, XA_w, R, d.b_o, rows, V, 1, nullptr, V, d.top2_part, st));
+        CVC_TRY(cvc_top2_final(d.top2_part, nblk_v, rows, d.unk_idx, d.words + (size_t)(t + 1) * rows, 1,
+                               d.logprob ? d.logprob + (size_t)t * rows : nullptr, d.embed, E, quad_off(XA_w, R), 0, st));
+    }
+    p->launches = n;
+    return 0;
+}
+
+// ---- tile path: beam search or more than 64 rows (12 launches per step)
+int run_tile(cvc_decode_plan* p, hipStream_t st) {
+    const cvc_decode_desc& d = p->d;
+    const int B = d.B, beam = d.beam, rows = B * beam, R = d.R, E = d.E, A = d.A, V = d.V;
+    int n = 0;
+    CVC_TRY(reset(d.words, nullptr, (size_t)rows * sizeof(int64_t), st));
+    if (beam > 1) {
+        CVC_TRY(reset(d.score, nullptr, (size_t)2 * rows * sizeof(float), st));
+        CVC_TRY(reset(d.done, nullptr, (size_t)2 * rows, st));
+    }
+    // once per decode: hoisted fc gate term (+ both biases), one row per clip; step-0 operands from the zero state
+    CVC_TRY(cvc_tile_pack_rows(d.fc, R, nullptr, 0, B, R, d.xff, d.xff_stride, st));
+    CVC_TRY(cvc_tile_gemm(d.w_fc_frag, d.xff, d.xff_stride, R, B, 4 * R, d.ks_fc, d.parts_fc, 4 * R, (long long)B * 4 * R, st));
+    CVC_TRY(cvc_tile_linear_finish(d.parts_fc, d.ks_fc, (long long)B * 4 * R, 4 * R, d.b_ih_att, d.b_hh_att, B, 4 * R, d.gate_fc,
+                                   4 * R, st));
+    void* xl_hatt = frag_off(d.xlf, R);
+    void* xl_hlang = frag_off(d.xlf, 2 * R);
+    CVC_TRY(cvc_tile_reorder_pack(nullptr, d.words, beam, d.zero_state, d.zero_state, d.zero_state, d.zero_state, d.embed, E, V,
+                                  d.c_att_prev, d.c_lang_prev, d.xaf, d.xaf_stride, xl_hlang, d.xlf_stride, rows, R, st));
+    const long long gs = (long long)rows * 4 * R;
+    for (int t = 0; t < d.T; ++t) {
+        CVC_TRY(cvc_tile_gemm(d.w_att, d.xaf, d.xaf_stride, 2 * R + E, rows, 4 * R, d.ks_gate, d.parts_gate, 4 * R, gs, st));
+        CVC_TRY(cvc_tile_lstm_finish(d.parts_gate, d.ks_gate, gs, nullptr, nullptr, d.gate_fc, beam, d.c_att_prev, rows, R, d.c_att,
+                                     d.h_att, xl_hatt, d.xlf_stride, nullptr, 0, st));
+        CVC_TRY(cvc_tile_gemm(d.w_h, xl_hatt, d.xlf_stride, R, rows, A, d.ks_q, d.q_parts, A, (long long)rows * A, st));
+        CVC_TRY(cvc_tile_linear_finish(d.q_parts, d.ks_q, (long long)rows * A, A, d.b_h, nullptr, rows, A, d.q, A, st));
+        cvc_attn_set sets[2];
+        attn_sets(d, t, rows, sets);
+        CVC_TRY(cvc_attn_scores(d.attn_kind, d.q, d.w_a, d.b_a, d.inv_temp, sets, 2, B, beam, A, st));
+        CVC_TRY(cvc_attn_wsum_frag(sets, 2, B, beam, R, d.xlf, d.xlf_stride, st));
+        CVC_TRY(cvc_tile_gemm(d.w_lang, d.xlf, d.xlf_stride, 3 * R, rows, 4 * R, d.ks_gate, d.parts_gate, 4 * R, gs, st));
+        CVC_TRY(cvc_tile_lstm_finish(d.parts_gate, d.ks_gate, gs, d.b_ih_lang, d.b_hh_lang, nullptr, 1, d.c_lang_prev, rows, R,
+                                     d.c_lang, d.h_lang, d.xhf, d.xhf_stride, nullptr, 0, st));
+        CVC_TRY(cvc_tile_gemm(d.w_o, d.xhf, d.xhf_stride, R, rows, V, d.ks_o, d.parts_o, V, (long long)rows * V, st));
+        CVC_TRY(cvc_tile_linear_finish(d.parts_o, d.ks_o, (long long)rows * V, V, d.b_o, nullptr, rows, V, d.logits, V, st));
+        int64_t* word_next = d.words + (size_t)(t + 1) * rows;
+        const int64_t* parent = nullptr;
+        if (beam == 1) {
+            CVC_TRY(cvc_top2_unk(d.logits, rows, V, d.unk_idx, word_next, 1, d.logprob ? d.logprob + (size_t)t * rows : nullptr, st));
+        } else {
+            const int srd = t & 1, swr = (t + 1) & 1;
+            int64_t* par = d.parent + (size_t)t * rows;
+            CVC_TRY(cvc_beam_select(d.logits, d.score + (size_t)srd * rows, d.done + (size_t)srd * rows, B, beam, V, d.unk_idx,
+                                    t == 0 ? 1 : 0, par, word_next, d.score + (size_t)swr * rows, d.done + (size_t)swr * rows,
+                                    d.beam_ws, st));
+            parent = par;
+        }
+        if (t + 1 < d.T)
+            CVC_TRY(cvc_tile_reorder_pack(parent, word_next, beam, d.h_att, d.c_att, d.h_lang, d.c_lang, d.embed, E, V, d.c_att_prev,
+                                          d.c_lang_prev, d.xaf, d.xaf_stride, xl_hlang, d.xlf_stride, rows, R, st));
+    }
+    p->launches = n;
+    return 0;
+}
+
+int validate(const cvc_decode_desc& d) {
+    if (d.B < 1 || d.beam < 1 || d.beam > 8 || d.T < 1 || d.N < 1 || d.F < 1 || d.V < 2) return CVC_E_BADARG;
+    if (d.attn_kind != CVC_ATTN_ADDITIVE && d.attn_kind != CVC_ATTN_DOT) return CVC_E_BADARG;
+    if (!d.fc || !d.conv || !d.pconv || !d.pool || !d.ppool || !d.words || !d.att_steps || !d.embed || !d.b_o || !d.b_h) return CVC_E_BADARG;
+    if (d.attn_kind == CVC_ATTN_ADDITIVE && !d.w_a) return CVC_E_BADARG;
+    if (!d.w_att || !d.w_lang || !d.w_h || !d.w_o || !d.gate_fc || !d.scores_r || !d.scores_f || !d.attn_f || !d.q_parts) return CVC_E_BADARG;
+    if (d.path == 0) {
+        if (d.beam != 1 || d.B > 64 || (d.R & 31) || (d.E & 31) || (d.A & 31) || d.qsplit < 1) return CVC_E_BADARG;
+        if (!d.w_fc || !d.top2_part || !d.xa[0] || !d.xa[1] || !d.xl[0] || !d.xl[1] || !d.ca[0] || !d.ca[1] || !d.cl[0] || !d.cl[1] ||
+            !d.xa0_init)
+            return CVC_E_BADARG;
+    } else if (d.path == 1) {
+        if ((d.R & 15) || (d.E & 15) || d.ks_gate < 1 || d.ks_q < 1 || d.ks_o < 1 || d.ks_fc < 1) return CVC_E_BADARG;
+        if (!d.w_fc_frag || !d.xaf || !d.xlf || !d.xhf || !d.xff || !d.parts_gate || !d.parts_o || !d.parts_fc || !d.logits || !d.q ||
+            !d.h_att || !d.c_att || !d.h_lang || !d.c_lang || !d.c_att_prev || !d.c_lang_prev || !d.zero_state)
+            return CVC_E_BADARG;
+        if (d.beam > 1 && (!d.score || !d.done || !d.parent || !d.beam_ws)) return CVC_E_BADARG;
+    } else {
+        return CVC_E_BADARG;
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int cvc_decode_plan_create(const cvc_decode_desc* desc, cvc_decode_plan** plan) {
+    if (!desc || !plan) return CVC_E_BADARG;
+    int rc = validate(*desc);
+    if (rc) return rc;
+    cvc_decode_plan* p = new (std::nothrow) cvc_decode_plan;
+    if (!p) return CVC_E_BADARG;
+    p->d = *desc;
+    p->launches = 0;
+    *plan = p;
+    return 0;
+}
+
+extern "C" int cvc_decode_plan_set_features(cvc_decode_plan* plan, const float* fc, const float* conv, const float* pconv,
+                                            const float* pool, const float* ppool, const uint8_t* mask) {
+    if (!plan || !fc || !conv || !pconv || !pool || !ppool) return CVC_E_BADARG;
+    plan->d.fc = fc; plan->d.conv = conv; plan->d.pconv = pconv; plan->d.pool = pool; plan->d.ppool = ppool; plan->d.mask = mask;
+    return 0;
+}
+
+extern "C" void cvc_decode_plan_destroy(cvc_decode_plan* plan) { delete plan; }
+
+extern "C" int cvc_decode_num_launches(const cvc_decode_plan* plan) { return plan ? plan->launches : 0; }
+
+extern "C" int cvc_decode_greedy(cvc_decode_plan* plan, cvc_stream_t stream) {
+    if (!plan || plan->d.beam != 1) return CVC_E_BADARG;
+    return plan->d.path == 0 ? run_packed(plan, (hipStream_t)stream) : run_tile(plan, (hipStream_t)stream);
+}
+
+extern "C" int cvc_decode_beam(cvc_decode_plan* plan, cvc_stream_t stream) {
+    if (!plan || plan->d.beam < 2 || plan->d.path != 1) return CVC_E_BADARG;
+    return run_tile(plan, (hipStream_t)stream);
+}

@@ -170,10 +170,14 @@ def cache_plan(linear_weight_bytes: int, feature_bytes: Dict[str, int], budget: 
 
 class DecodeEngine:
     """Binds weights + one batch of clip features to preallocated state and a launch list."""
+    _warm = set()
 
     def __init__(self, weights: DecodeWeights, feats: Dict[str, torch.Tensor], T: int, unk_idx: int, beam: int = 1,
-                 inv_temp: float = 1.0, own_features: bool = False, path: str = "auto", gate_ksplit: Optional[bool] = None):
-        """path: "auto" picks packed (greedy, <= 64 rows) / tile (> 64 rows or beams) / ring (odd widths); "ring" forces the
+                 inv_temp: float = 1.0, own_features: bool = False, path: str = "auto", gate_ksplit: Optional[bool] = None,
+                 driver: bool = True):
+        """driver: enqueue the decode through the C-ABI drivers cvc_decode_greedy / cvc_decode_beam (one host call per decode);
+        False walks the launch list in Python (one ctypes call per kernel; tests compare the two).
+        path: "auto" picks packed (greedy, <= 64 rows) / tile (> 64 rows or beams) / ring (odd widths); "ring" forces the
         row-major fallback kernels (tests compare the paths).
         own_features: keep private copies of the clip features, so that the bound launch list (and a captured HIP
         graph) can be reused for the next batch of the same shape through load_features()."""
@@ -237,6 +241,7 @@ class DecodeEngine:
         self.gate_ksplit = GATE_KSPLIT_DEFAULT if gate_ksplit is None else bool(gate_ksplit)
         # more than 64 live rows (beam search, big greedy batches): bf16-fragment tile GEMMs (csrc/gemm_tile.hip)
         self.tile = (not self.packed) and (self.beam > 1 or rows > 64) and R % 16 == 0 and W.E % 16 == 0 and path != "ring"
+        self._plan = None
         if self.packed:
             self._alloc_packed()
             self._launches = self._build_packed()
@@ -245,6 +250,67 @@ class DecodeEngine:
             self._launches = self._build_tile()
         else:
             self._launches = self._build()
+        if driver and (self.tile or (self.packed and not (self.ks_att or self.ks_lang))):
+            self._bind_driver()
+
+    # ------------------------------------------------------------------ C-ABI decode driver (csrc/decode_driver.hip)
+    def _bind_driver(self):
+        """Bind every buffer of this engine into a cvc_decode_desc and create the plan: run() / capture() then enqueue the
+        whole decode with ONE call (cvc_decode_greedy / cvc_decode_beam) instead of walking the launch list in Python.  The
+        Python launch list stays for run_timed() (per-launch HIP events) and as the reference the driver is tested against."""
+        W, L = self.W, hip.lib()
+        ptr = lambda t: None if t is None else t.data_ptr()
+        d = hip.DecodeDesc()
+        d.B, d.beam, d.T, d.N, d.F, d.R, d.A, d.E, d.V = self.B, self.beam, self.T, self.N, self.F, W.R, W.A, W.E, W.V
+        d.unk_idx, d.attn_kind, d.inv_temp = self.unk, W.kind, self.inv_temp
+        d.stream_r, d.stream_f = self.stream_r, self.stream_f
+        for k in ("b_ih_att", "b_hh_att", "b_ih_lang", "b_hh_lang", "b_h", "w_a", "b_a", "b_o", "embed"):
+            setattr(d, k, ptr(getattr(W, k)))
+        fc, conv, pconv, pool, ppool = self.feats
+        d.fc, d.conv, d.pconv, d.pool, d.ppool, d.mask = ptr(fc), ptr(conv), ptr(pconv), ptr(pool), ptr(ppool), ptr(self.mask)
+        d.words, d.att_steps, d.logprob = ptr(self.words), ptr(self.att_steps), ptr(self.logprob)
+        d.scores_r, d.scores_f, d.attn_f = ptr(self.scores_r), ptr(self.scores_f), ptr(self.attn_f)
+        if self.packed:
+            R = W.R
+            d.path, d.qsplit = 0, self.QSPLIT
+            d.w_att, d.w_lang, d.w_h, d.w_o = ptr(W.p_att), ptr(W.p_lang), ptr(W.p_h), ptr(W.p_o)
+            w_fc = W.w_ih_att[:, R:2 * R]
+            d.w_fc, d.ld_w_fc = w_fc.data_ptr(), w_fc.stride(0)
+            d.gate_fc, d.q_parts, d.top2_part = ptr(self.gate_fc), ptr(self.q_parts), ptr(self.top2_part)
+            for name, bufs in (("xa", self.XA), ("xl", self.XL), ("ca", self.cA), ("cl", self.cL)):
+                arr = getattr(d, name)
+                arr[0], arr[1] = ptr(bufs[0]), ptr(bufs[1])
+            d.xa0_init = ptr(self.XA0_init)
+        else:
+            d.path = 1
+            d.ks_gate, d.ks_q, d.ks_o, d.ks_fc = self.ks_gate, self.ks_q, self.ks_o, self.ks_fc
+            d.w_att, d.w_lang, d.w_h, d.w_o, d.w_fc_frag = ptr(W.t_att), ptr(W.t_lang), ptr(W.t_h), ptr(W.t_o), ptr(W.t_fc)
+            d.gate_fc, d.q, d.q_parts, d.logits = ptr(self.gate_fc_clip), ptr(self.q), ptr(self.parts_q), ptr(self.logits)
+            for name, t in (("xaf", self.XAf), ("xlf", self.XLf), ("xhf", self.XHf), ("xff", self.XFf)):
+                p_, s_ = hip._frag_ptr(t)
+                setattr(d, name, p_)
+                setattr(d, name + "_stride", s_)
+            d.parts_gate, d.parts_o, d.parts_fc = ptr(self.parts_gate), ptr(self.parts_o), ptr(self.parts_fc)
+            d.h_att, d.c_att, d.h_lang, d.c_lang = ptr(self.t_h_att), ptr(self.t_c_att), ptr(self.t_h_lang), ptr(self.t_c_lang)
+            d.c_att_prev, d.c_lang_prev, d.zero_state = ptr(self.t_c_att_prev), ptr(self.t_c_lang_prev), ptr(self.t_zero)
+            if self.beam > 1:
+                d.score, d.done, d.parent, d.beam_ws = ptr(self.score), ptr(self.done), ptr(self.parent), ptr(self.beam_ws)
+        plan = C.c_void_p()
+        hip._check(L.cvc_decode_plan_create(C.byref(d), C.byref(plan)), "cvc_decode_plan_create")
+        self._desc, self._plan = d, plan
+        self._plan_call = L.cvc_decode_beam if self.beam > 1 else L.cvc_decode_greedy
+
+    def __del__(self):
+        plan = getattr(self, "_plan", None)
+        if plan is not None and plan.value:
+            try:
+                hip.lib().cvc_decode_plan_destroy(plan)
+            except Exception:
+                pass
+            self._plan = None
+
+    def _run_driver(self):
+        hip._check(self._plan_call(self._plan, torch.cuda.current_stream().cuda_stream), "cvc_decode_greedy/beam")
 
     # ------------------------------------------------------------------ packed path (greedy, rows <= 64)
     def _alloc_packed(self):
@@ -537,7 +603,7 @@ class DecodeEngine:
         """timers: optional dict name -> list of (start_event, end_event), filled per launch
         (HIP events on the launch stream; used by bench.py for per-kernel durations)."""
         stream = torch.cuda.current_stream().cuda_stream
-        for name, fn, args in self._launches:
+        for name, fn, args in self._python_launches():
             if timers is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -565,6 +631,33 @@ class DecodeEngine:
         self.mask.copy_(hip._mask(mask))
         return self
 
+    def bind_features(self, feats: Dict[str, torch.Tensor]):
+        """Next batch of the same shape WITHOUT copying it: the C-ABI plan (and this engine) is pointed at the caller's
+        feature tensors.  Only for engines that run through the driver without a captured graph (a graph keeps the pointers it
+        was captured with: use load_features there)."""
+        if self._plan is None or self.graph is not None:
+            raise RuntimeError("DecodeEngine.bind_features needs a driver-bound engine without a captured graph")
+        pool = feats["pool_feats"]
+        mask = feats["pnt_mask"][:, 1:] if feats["pnt_mask"].shape[1] == pool.shape[1] + 1 else feats["pnt_mask"]
+        new = (feats["fc_feats"], feats["conv_feats"], feats["p_conv_feats"], pool, feats["p_pool_feats"])
+        for dst, src, name in zip(self.feats, new, ("fc_feats", "conv_feats", "p_conv_feats", "pool_feats", "p_pool_feats")):
+            if dst.shape != src.shape:
+                raise RuntimeError(f"DecodeEngine.bind_features: shape {tuple(src.shape)} != bound {tuple(dst.shape)}")
+            hip._dev(src, name=name)
+        self.mask = hip._mask(mask)
+        self.feats = new
+        self.fc = new[0]
+        hip._check(hip.lib().cvc_decode_plan_set_features(self._plan, *(t.data_ptr() for t in new), self.mask.data_ptr()),
+                   "cvc_decode_plan_set_features")
+        self._launches = None                       # the Python launch list holds the old pointers: rebuilt on demand
+        return self
+
+    def _python_launches(self):
+        if self._launches is None:
+            self._keep = []
+            self._launches = self._build_packed() if self.packed else (self._build_tile() if self.tile else self._build())
+        return self._launches
+
     def run_timed(self):
         """One eager decode with a HIP-event pair around every launch.  Returns name -> list of ms."""
         timers = {}
@@ -573,18 +666,28 @@ class DecodeEngine:
         torch.cuda.synchronize()
         return {k: [a.elapsed_time(b) for a, b in v] for k, v in timers.items()}
 
-    def capture(self):
-        """Capture the T-step loop into a HIP graph (launch-bound inner loop -> one replay)."""
-        self._reset()
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            self._run_launches()          # warm-up outside capture (module load, lazy init)
-        torch.cuda.current_stream().wait_stream(s)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+    def _run_once(self):
+        """One decode on the current stream: through the C-ABI driver when bound (it resets its state itself), else the
+        Python launch list."""
+        if self._plan is not None:
+            self._run_driver()
+        else:
             self._reset()
             self._run_launches()
+
+    def capture(self):
+        """Capture the T-step loop into a HIP graph (launch-bound inner loop -> one replay)."""
+        key = (self.packed, self.tile, self.beam > 1)
+        if key not in DecodeEngine._warm:                 # first capture of this path in the process: run once outside capture
+            s = torch.cuda.Stream()                       # (module load, lazy init); later engines skip the extra decode
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._run_once()
+            torch.cuda.current_stream().wait_stream(s)
+            DecodeEngine._warm.add(key)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._run_once()
         self.graph = g
         return self
 
@@ -594,8 +697,7 @@ class DecodeEngine:
         if self.graph is not None:
             self.graph.replay()
         else:
-            self._reset()
-            self._run_launches()
+            self._run_once()
         if self.beam == 1:
             return self.words[1:].t(), self.att_steps.permute(1, 0, 2)
         return self._backtrack()

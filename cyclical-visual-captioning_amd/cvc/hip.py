@@ -35,6 +35,27 @@ class NNSeg(C.Structure):
 
 
 _P, _I, _F, _LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+
+class DecodeDesc(C.Structure):
+    """cvc_decode_desc of include/cvc_hip.h, field for field (tests/test_cabi.py compares the size with the C compiler's)."""
+    _fields_ = (
+        [(n, C.c_int) for n in ("B", "beam", "T", "N", "F", "R", "A", "E", "V", "unk_idx", "attn_kind")] +
+        [("inv_temp", C.c_float)] +
+        [(n, C.c_int) for n in ("stream_r", "stream_f", "path", "qsplit", "ks_gate", "ks_q", "ks_o", "ks_fc")] +
+        [(n, C.c_void_p) for n in ("b_ih_att", "b_hh_att", "b_ih_lang", "b_hh_lang", "b_h", "w_a", "b_a", "b_o", "embed")] +
+        [("w_fc", C.c_void_p), ("ld_w_fc", C.c_int)] +
+        [(n, C.c_void_p) for n in ("w_att", "w_lang", "w_h", "w_o", "w_fc_frag")] +
+        [(n, C.c_void_p) for n in ("fc", "conv", "pconv", "pool", "ppool", "mask")] +
+        [(n, C.c_void_p) for n in ("words", "att_steps", "logprob", "score", "done", "parent")] +
+        [(n, C.c_void_p) for n in ("gate_fc", "scores_r", "scores_f", "attn_f", "q", "q_parts", "top2_part")] +
+        [("xa", C.c_void_p * 2), ("xl", C.c_void_p * 2), ("ca", C.c_void_p * 2), ("cl", C.c_void_p * 2), ("xa0_init", C.c_void_p)] +
+        [(n, C.c_void_p) for n in ("xaf", "xlf", "xhf", "xff")] +
+        [(n, C.c_longlong) for n in ("xaf_stride", "xlf_stride", "xhf_stride", "xff_stride")] +
+        [(n, C.c_void_p) for n in ("parts_gate", "parts_o", "parts_fc", "logits")] +
+        [(n, C.c_void_p) for n in ("h_att", "c_att", "h_lang", "c_lang", "c_att_prev", "c_lang_prev", "zero_state")] +
+        [("beam_ws", C.c_void_p)])
+
 # name -> argtypes, exactly the declarations of include/cvc_hip.h (tests/test_cabi.py checks both)
 SIGNATURES = {
     "cvc_attn_fwd": [_I, _P, _P, _P, _F, C.POINTER(AttnSet), _I, _I, _I, _I, _I, _P, _P],
@@ -75,7 +96,14 @@ SIGNATURES = {
     "cvc_tile_pack_rows": [_P, _I, _P, _I, _I, _I, _P, _LL, _P],
     "cvc_tile_reorder_pack": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _LL, _P, _LL, _I, _I, _P],
     "cvc_attn_wsum_frag": [C.POINTER(AttnSet), _I, _I, _I, _I, _P, _LL, _P],
+    "cvc_decode_plan_create": [C.POINTER(DecodeDesc), C.POINTER(C.c_void_p)],
+    "cvc_decode_plan_destroy": [_P],
+    "cvc_decode_plan_set_features": [_P, _P, _P, _P, _P, _P, _P],
+    "cvc_decode_num_launches": [_P],
+    "cvc_decode_greedy": [_P, _P],
+    "cvc_decode_beam": [_P, _P],
 }
+_VOID_RETURN = {"cvc_decode_plan_destroy"}
 
 _lib = None
 
@@ -92,7 +120,7 @@ def lib() -> C.CDLL:
         for name, argtypes in SIGNATURES.items():
             fn = getattr(l, name)
             fn.argtypes = argtypes
-            fn.restype = C.c_int
+            fn.restype = None if name in _VOID_RETURN else C.c_int
         l.cvc_version.restype = C.c_char_p
         l.cvc_version.argtypes = []
         _lib = l

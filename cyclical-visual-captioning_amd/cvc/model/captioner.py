@@ -278,7 +278,14 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
                self.use_hip_graph)
         cached = getattr(self, "_engine_cache", None)
         if cached is not None and cached[0] == key:
-            engine = cached[1].load_features(feats)
+            engine = cached[1]
+            # next batch of the same shape.  Driver-bound engine without a graph: the C-ABI plan is simply pointed at the new
+            # tensors.  Graph replay (or the ring fallback for odd widths): the batch is copied into the engine's own buffers
+            # (0.2 ms at cfg2) -- a captured graph keeps the pointers it was captured with.
+            if engine._plan is not None and engine.graph is None:
+                engine.bind_features(feats)
+            else:
+                engine.load_features(feats)
         else:
             engine = DecodeEngine(weights, feats, self.seq_length, self.unk_idx, beam=beam, inv_temp=1.0 / temp, own_features=True)
             if self.use_hip_graph:

@@ -318,6 +318,62 @@ int cvc_tile_reorder_pack(const int64_t* parent, const int64_t* word, int beam, 
 int cvc_attn_wsum_frag(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, void* ctx_frag,
                        long long frag_mblk_stride, cvc_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Whole-decode drivers: the T-step sampler of model/captioner.py:384-443 (`_sample`: exactly T decoder steps from BOS,
+ * top-2 with UNK suppression, no EOS early exit) and its beam-search counterpart (build-defined) as ONE
+ * host call that enqueues every launch of the decode on the caller's stream -- no Python in the loop, no allocation, no host
+ * synchronisation, capturable into a HIP graph.  The caller binds device buffers once in a cvc_decode_desc (weights in the
+ * packed / fragment layouts above, the clip features, state and output buffers it allocated) and creates a plan; the plan only
+ * copies the descriptor (host memory).  Greedy with <= 64 rows runs the packed path (cvc_packed_*), everything else the tile
+ * path (cvc_tile_*); which fields a path reads is noted per field.  cvc.decode.DecodeEngine is the reference user.
+ */
+typedef struct cvc_decode_desc {
+    /* dimensions */
+    int B, beam, T, N, F, R, A, E, V;     /* clips, beams per clip (1 = greedy), steps, regions, frames, widths, vocabulary   */
+    int unk_idx, attn_kind;               /* CVC_ATTN_ADDITIVE / CVC_ATTN_DOT                                                */
+    float inv_temp;
+    int stream_r, stream_f;               /* cvc_attn_set.stream of the region / frame feature sets                          */
+    int path;                             /* 0 = packed (beam == 1, B <= 64), 1 = tile                                       */
+    int qsplit;                           /* packed: K slices of the h2attn GEMM                                             */
+    int ks_gate, ks_q, ks_o, ks_fc;       /* tile: K slices of the gate / h2attn / vocabulary / fc GEMMs                     */
+    /* parameters (checkpoint tensors) */
+    const float *b_ih_att, *b_hh_att, *b_ih_lang, *b_hh_lang, *b_h, *w_a, *b_a, *b_o, *embed;
+    const float* w_fc; int ld_w_fc;       /* packed: W_ih_att[:, R:2R] row-major (leading dim E + 2R)                        */
+    /* packed weights: packed path -> [blk][K/4][32][4] fp32; tile path -> bf16 fragments (cvc_tile_gemm's wb)              */
+    const void *w_att, *w_lang, *w_h, *w_o, *w_fc_frag;
+    /* clip features (model/backbone.py:350-351 outputs) */
+    const float *fc, *conv, *pconv, *pool, *ppool; const uint8_t* mask;
+    /* outputs */
+    int64_t* words;                       /* [(T + 1), rows]; words[0] = BOS = 0 is written by the driver                    */
+    float* att_steps;                     /* [T, rows, N] post-softmax region attention of every step                        */
+    float* logprob;                       /* [T, rows] (greedy) or NULL                                                      */
+    float* score; uint8_t* done; int64_t* parent;   /* beam: [2, rows], [2, rows], [T, rows]                                 */
+    /* workspaces, all caller-allocated */
+    float *gate_fc;                       /* packed: [rows, 4R]; tile: [B, 4R]                                               */
+    float *scores_r, *scores_f, *attn_f;  /* [rows, N], [rows, F], [rows, F]                                                 */
+    float *q;                             /* tile: [rows, A]                                                                 */
+    float *q_parts;                       /* packed: [qsplit, rows, A]; tile: [ks_q, rows, A]                                */
+    float *top2_part;                     /* packed: [ceil(V/32), 64, 6]                                                     */
+    float *xa[2], *xl[2], *ca[2], *cl[2]; /* packed: quad-layout activation / cell-state ping-pong buffers                   */
+    const float* xa0_init;                /* packed: XA of step 0 (relu(Emb[BOS]) in its K segment, zeros elsewhere)         */
+    void *xaf, *xlf, *xhf, *xff;          /* tile: activation fragments XA [2R+E], XL [3R], XH [R], fc [R]                   */
+    long long xaf_stride, xlf_stride, xhf_stride, xff_stride;
+    float *parts_gate, *parts_o, *parts_fc, *logits;           /* tile                                                        */
+    float *h_att, *c_att, *h_lang, *c_lang, *c_att_prev, *c_lang_prev; const float* zero_state;   /* tile: [rows, R] each     */
+    float *beam_ws;                       /* beam: >= 17 * rows floats                                                       */
+} cvc_decode_desc;
+typedef struct cvc_decode_plan cvc_decode_plan;
+int cvc_decode_plan_create(const cvc_decode_desc* desc, cvc_decode_plan** plan);   /* validates, copies the descriptor       */
+void cvc_decode_plan_destroy(cvc_decode_plan* plan);
+/* next batch of the SAME shape: point the plan at other feature tensors (no copy, no new plan; a graph captured from the plan
+ * keeps the old pointers -- re-capture or copy into the bound buffers instead when replaying graphs) */
+int cvc_decode_plan_set_features(cvc_decode_plan* plan, const float* fc, const float* conv, const float* pconv,
+                                 const float* pool, const float* ppool, const uint8_t* mask);
+int cvc_decode_num_launches(const cvc_decode_plan* plan);                            /* kernels + copies per decode           */
+/* enqueue one full decode on `stream`; results land in desc.words / att_steps / logprob (greedy), + score / parent (beam) */
+int cvc_decode_greedy(cvc_decode_plan* plan, cvc_stream_t stream);
+int cvc_decode_beam(cvc_decode_plan* plan, cvc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,7 @@ HEADER = os.path.join(ROOT, "include", "cvc_hip.h")
 def declared_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|const char\*)\s+(cvc_\w+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|void|const char\*)\s+(cvc_\w+)\s*\(", src)))
 
 
 def test_library_builds_and_loads():
@@ -50,6 +50,34 @@ def test_struct_layouts_match_header():
     # 8 pointers + int (padded to 8) ; 3 pointers + 4 ints
     assert ctypes.sizeof(hip.AttnSet) == 8 * 8 + 8
     assert ctypes.sizeof(hip.GemmSeg) == 3 * 8 + 4 * 4
+
+
+def test_decode_descriptor_layout_matches_the_c_compiler(tmp_path):
+    """cvc.hip.DecodeDesc (ctypes) must be cvc_decode_desc (include/cvc_hip.h) byte for byte: compile a probe with the host C
+    compiler that prints sizeof and a few offsets."""
+    import subprocess
+    from cvc import hip
+    src = tmp_path / "probe.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(void) { printf("%%zu %%zu %%zu %%zu %%zu %%zu\\n", '
+                   'sizeof(cvc_decode_desc), offsetof(cvc_decode_desc, inv_temp), offsetof(cvc_decode_desc, w_fc), '
+                   'offsetof(cvc_decode_desc, words), offsetof(cvc_decode_desc, xa), offsetof(cvc_decode_desc, beam_ws)); return 0; }\n' % HEADER)
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-o", str(exe), str(src)])
+    got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
+    D = hip.DecodeDesc
+    want = [ctypes.sizeof(D), D.inv_temp.offset, D.w_fc.offset, D.words.offset, D.xa.offset, D.beam_ws.offset]
+    assert got == want, (got, want)
+
+
+def test_decode_plan_rejects_incomplete_descriptors():
+    """cvc_decode_plan_create validates on the host (no GPU needed): NULL buffers / bad dims -> CVC_E_BADARG, no plan."""
+    from cvc import hip
+    lib = hip.lib()
+    d = hip.DecodeDesc()
+    plan = ctypes.c_void_p()
+    assert lib.cvc_decode_plan_create(ctypes.byref(d), ctypes.byref(plan)) == -1 and not plan.value
+    assert lib.cvc_decode_greedy(None, None) == -1 and lib.cvc_decode_beam(None, None) == -1
+    assert lib.cvc_decode_num_launches(None) == 0
 
 
 def test_product_ops_refuse_cpu_tensors():

@@ -725,6 +725,29 @@ def test_tile_path_equals_ring_path(dev, lib, B, N, F, R, A, E, V, T, beam):
     assert all(torch.equal(x, y) for x, y in zip(a, a2))          # graph replay == eager, bitwise
 
 
+@pytest.mark.parametrize("B,beam,dims", [(4, 1, dict(N=20, F=12, R=128, A=64, E=64, V=300, T=6)),        # packed path
+                                         (70, 1, dict(N=9, F=4, R=64, A=32, E=32, V=97, T=3)),          # tile path, greedy
+                                         (5, 3, dict(N=7, F=5, R=32, A=16, E=16, V=50, T=4))])          # tile path, beam
+def test_cabi_decode_driver_equals_python_launch_list(dev, lib, B, beam, dims):
+    """cvc_decode_greedy / cvc_decode_beam (csrc/decode_driver.hip: the whole T-step decode enqueued by one host call from a
+    bound cvc_decode_desc) against the same engine walking its launch list in Python: bitwise identical outputs, eager and
+    from a captured HIP graph; the plan reports its launch count."""
+    from helpers import to_dev
+    from cvc.decode import DecodeEngine, DecodeWeights
+    d = dataclasses.replace(synth.CONFIGS["tiny"], B=B, **dims)
+    sd, f_np = synth.hot_path_state_dict(d, 91 + B), synth.clip_features(d, 91 + B)
+    W, f = DecodeWeights(to_dev(sd, dev)), to_dev(f_np, dev)
+    e_drv, e_py = DecodeEngine(W, f, d.T, synth.UNK_IDX, beam=beam), DecodeEngine(W, f, d.T, synth.UNK_IDX, beam=beam, driver=False)
+    assert e_drv._plan is not None and e_py._plan is None
+    a, b = [x.clone() for x in e_drv.run()], [x.clone() for x in e_py.run()]
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    n = lib.lib().cvc_decode_num_launches(e_drv._plan)
+    assert n >= 7 * d.T
+    a2 = [x.clone() for x in e_drv.capture().run()]
+    assert all(torch.equal(x, y) for x, y in zip(a, a2))
+    assert all(torch.equal(x, y) for x, y in zip(a, e_drv.run()))          # replay again: state is reset inside the driver
+
+
 def test_beam5_cfg1_vs_oracle(dev, lib):
     """beam=5 at config-1 size (rows = 20, V = 5000): sequences/scores vs the CPU beam oracle; where the oracle's
     own candidate margin is inside fp32 noise the comparison stops at that step (tie-aware)."""
