@@ -143,7 +143,7 @@ def run_train(args, d, dev, rank, world):
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.hot_path_state_dict(d, args.seed).items()}, strict=False)
     model = model.to(dev).train()
     optim = build_optimizer(model, o, capturable=args.train_graph)
-    reducer = GradReducer(model.named_parameters()) if torch.distributed.is_initialized() else None
+    reducer = GradReducer(model.named_parameters())        # flat gradient arenas (also for one rank: one fill / one clip multiply)
     tr = Trainer(o, None, model, optim, None, None, grad_reducer=reducer)
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     feats = {k: t(v) for k, v in synth.clip_features(d, args.seed + rank).items()}

@@ -82,102 +82,165 @@ def gather_eval_outputs(predictions: dict, grd_output: dict):
 
 
 class GradReducer:
-    """Bucketed, hook-driven gradient averaging across ranks."""
+    """Flat gradient arenas + hook-driven asynchronous exchange (replaces the reference's nn.DataParallel, main.py:169).
 
-    def __init__(self, named_params: Iterable[Tuple[str, torch.nn.Parameter]], bucket_mb: float = 128.0,
-                 group=None, overlap: bool = True):
+    * Every bucket is ONE flat fp32 tensor and every `param.grad` of the bucket is a view into it, for the whole run: autograd
+      accumulates straight into the arena, so the exchange needs no `cat`, no copy-back and no per-tensor kernels;
+      `zero_grad()` is one fill per bucket, `clip_()` one norm + one multiply per bucket with the 1/G of the averaging folded
+      into the clip coefficient (trainer.py:120-121 semantics: global norm over the AVERAGED gradients).
+    * Buckets follow the order in which backward completes gradients: the vocabulary head is complete
+      before BPTT of the decode loop starts and is exchanged under it; everything that is touched at every time step (LSTM
+      cells, h2attn, alpha_net, embedding) completes at t = 0.  Each LSTM weight matrix is its own bucket (its deferred
+      dW GEMM finishes separately), biases ride with their cell's weight_hh.
+    * With RCCL ("nccl") a bucket goes as in-place reduce_scatter + all_gather over the xGMI mesh, two calls on the
+      communicator's stream issued back to back from the hook; other backends (gloo in the CPU tests) use one all_reduce.
+    * Parameters that never receive a gradient keep an all-zero view: Adam leaves them unchanged,
+      exactly as skipping them does, and no rank-dependent None-ness can desynchronise the message sizes.
+    Expected exposed time at BASELINE config 4 (8 x MI355X, 486 MB of gradients, 7 xGMI links per GPU): the 445 MB that
+    complete at t = 0 cost 2 x 7/8 x 445 MB per GPU over 7 links = 0.7 ms at the 153 GB/s link peak, ~2 ms at a third of it,
+    against a ~29 ms step; the head's 41 MB overlap the decode loop's BPTT.
+    """
+
+    def __init__(self, named_params: Iterable[Tuple[str, torch.nn.Parameter]], bucket_mb: float = 0.0, group=None,
+                 overlap: bool = True, world: Optional[int] = None):
+        """bucket_mb > 0 additionally splits the 'rest' bucket into pieces of at most that size (tests use tiny buckets)."""
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
         seen, params = set(), []
         for name, p in named_params:
             if p.requires_grad and id(p) not in seen:       # shared LSTM cells are listed once
                 seen.add(id(p))
                 params.append((name, p))
-        params.reverse()                                    # backward order
-        cap = int(bucket_mb * (1 << 20) / 4)
-        self.buckets: List[List[Tuple[str, torch.nn.Parameter]]] = [[]]
-        size = 0
+        # ---- bucket plan, in backward-completion order
+        head, rest, cells = [], [], {}
         for name, p in params:
-            if size and size + p.numel() > cap:
-                self.buckets.append([])
-                size = 0
-            self.buckets[-1].append((name, p))
-            size += p.numel()
-        self._bucket_of: Dict[int, int] = {id(p): i for i, b in enumerate(self.buckets) for _, p in b}
-        self._pending: List[int] = []
-        self._ready: List[int] = []
-        self._work = []
-        self._active: Optional[List[bool]] = None           # which params carry gradients (agreed once)
+            if "lstm" in name:
+                cell = name.rsplit(".", 1)[0]
+                kind = name.rsplit(".", 1)[1]
+                key = (cell, "ih") if kind == "weight_ih" else (cell, "hh")
+                cells.setdefault(key, []).append((name, p))
+            elif name.startswith("logit") or ".logit." in name:
+                head.append((name, p))
+            else:
+                rest.append((name, p))
+        groups: List[List[Tuple[str, torch.nn.Parameter]]] = []
+        if head:
+            groups.append(head)
+        if rest:
+            if bucket_mb > 0:
+                cap, cur, size = int(bucket_mb * (1 << 20) / 4), [], 0
+                for item in reversed(rest):
+                    if cur and size + item[1].numel() > cap:
+                        groups.append(cur)
+                        cur, size = [], 0
+                    cur.append(item)
+                    size += item[1].numel()
+                if cur:
+                    groups.append(cur)
+            else:
+                groups.append(list(reversed(rest)))
+        groups += [cells[k] for k in sorted(cells, reverse=True)]
+        self.buckets = groups
+        self.arenas: List[torch.Tensor] = []
+        self._views: Dict[int, torch.Tensor] = {}
+        align = 64 * max(self.world, 1)                       # floats: equal, 256-byte aligned shards for reduce_scatter
+        for b in groups:
+            n = sum((p.numel() + 63) // 64 * 64 for _, p in b)
+            n = (n + align - 1) // align * align
+            p0 = b[0][1]
+            arena = torch.zeros(n, device=p0.device, dtype=p0.dtype)
+            off = 0
+            for _, p in b:
+                v = arena[off:off + p.numel()].view_as(p)
+                self._views[id(p)] = v
+                p.grad = v
+                off += (p.numel() + 63) // 64 * 64
+            self.arenas.append(arena)
+        self._bucket_of: Dict[int, int] = {id(p): i for i, b in enumerate(groups) for _, p in b}
+        self._ready = [0] * len(groups)
+        self._launched = [False] * len(groups)
+        self._expected: Optional[List[int]] = None           # gradient arrivals per bucket, learned on the first step
+        self._seen_first: List[set] = [set() for _ in groups]
+        self._work: List = []
         self.overlap = overlap and self.world > 1
-        self._hooks = []
-        if self.overlap:
-            for _, p in params:
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
-        self._reset_counts()
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for b in groups for _, p in b] if self.world > 1 else []
 
-    # ------------------------------------------------------------------
-    def _reset_counts(self):
+    # ------------------------------------------------------------------ gradient bookkeeping
+    def zero_grad(self):
+        """One fill per bucket; re-attaches a view if something replaced a .grad (optimizer.zero_grad(set_to_none=True))."""
+        for a in self.arenas:
+            a.zero_()
+        for b in self.buckets:
+            for _, p in b:
+                v = self._views[id(p)]
+                if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                    p.grad = v
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
 
-    def _expected(self, i: int) -> int:
-        if self._active is None:
-            return 1 << 30                                   # first step: no early launches
-        return sum(1 for _, p in self.buckets[i] if self._active_by_id[id(p)])
-
     def _on_grad(self, p):
         i = self._bucket_of[id(p)]
+        v = self._views[id(p)]
+        if p.grad is not v and p.grad.data_ptr() != v.data_ptr():      # autograd installed its own tensor: move it into the arena
+            v.copy_(p.grad)
+            p.grad = v
         self._ready[i] += 1
-        if self._active is not None and not self._launched[i] and self._ready[i] >= self._expected(i):
+        if self._expected is None:
+            self._seen_first[i].add(id(p))
+        elif self.overlap and not self._launched[i] and self._ready[i] >= self._expected[i]:
             self._launch(i)
 
     def _launch(self, i: int):
-        grads = [p.grad for _, p in self.buckets[i] if p.grad is not None]
         self._launched[i] = True
-        if not grads:
-            return
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._work.append((work, flat, grads))
-
-    def _agree_on_active(self):
-        """All ranks must skip the same None-grad parameters; agree once (MAX over a 0/1 mask)."""
-        flags = [0 if p.grad is None else 1 for b in self.buckets for _, p in b]
-        dev = next((p.grad.device for b in self.buckets for _, p in b if p.grad is not None), torch.device("cpu"))
-        mask = torch.tensor(flags, dtype=torch.int32, device=dev)
-        if self.world > 1:
-            dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)
-        agreed = mask.tolist()
-        k = 0
-        self._active_by_id = {}
-        for b in self.buckets:
-            for _, p in b:
-                if agreed[k] and p.grad is None:
-                    p.grad = torch.zeros_like(p)             # another rank has a gradient here
-                self._active_by_id[id(p)] = bool(agreed[k])
-                k += 1
-        self._active = [bool(a) for a in agreed]
-
-    def finalize(self):
-        """Call after backward(): launches what the hooks did not, waits, writes back averages."""
         if self.world == 1:
-            self._reset_counts()
             return
-        if self._active is None:
-            self._agree_on_active()
-        for i in range(len(self.buckets)):
-            if not self._launched[i]:
-                self._launch(i)
-        inv = 1.0 / self.world
-        for work, flat, grads in self._work:
-            work.wait()
-            off = 0
-            for g in grads:
-                n = g.numel()
-                g.copy_(flat[off:off + n].view_as(g)).mul_(inv)
-                off += n
-        self._work.clear()
-        self._reset_counts()
+        a = self.arenas[i]
+        if self.backend == "nccl":
+            n = a.numel() // self.world
+            r = dist.get_rank(self.group)
+            shard = a[r * n:(r + 1) * n]
+            w1 = dist.reduce_scatter_tensor(shard, a, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w2 = dist.all_gather_into_tensor(a, shard, group=self.group, async_op=True)
+            self._work += [w1, w2]
+        else:
+            self._work.append(dist.all_reduce(a, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finalize(self, average: bool = True):
+        """Call after backward(): exchanges what the hooks did not, waits.  average=True leaves every gradient divided by
+        the world size; average=False leaves SUMS for clip_() to fold the 1/G into its single multiply."""
+        if self.world > 1:
+            if self._expected is None:
+                # first step: every rank must expect the same arrivals per bucket (same model, same graph) -- checked once
+                counts = torch.tensor([len(s) for s in self._seen_first], dtype=torch.int64, device=self.arenas[0].device)
+                lo, hi = counts.clone(), counts.clone()
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+                dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+                if not torch.equal(lo, hi):
+                    raise RuntimeError("GradReducer: ranks disagree on which parameters receive gradients: "
+                                       f"{lo.tolist()} vs {hi.tolist()}")
+                self._expected = [int(c) for c in counts.tolist()]
+            for i in range(len(self.buckets)):
+                if not self._launched[i]:
+                    self._launch(i)
+            for w in self._work:
+                w.wait()
+            self._work.clear()
+            if average:
+                for a in self.arenas:
+                    a.mul_(1.0 / self.world)
+        self._ready = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
+
+    def clip_(self, max_norm: float, summed: bool = True) -> torch.Tensor:
+        """clip_grad_norm_(parameters, max_norm) over the arenas (trainer.py:120-121): global L2 norm of the averaged
+        gradients, one multiply per bucket.  summed=True: the arenas hold sums over ranks (finalize(average=False))."""
+        inv = 1.0 / self.world if summed else 1.0
+        total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(a) for a in self.arenas])) * inv
+        coef = torch.clamp(max_norm / (total + 1e-6), max=1.0) * inv
+        for a in self.arenas:
+            a.mul_(coef)
+        return total
 
     def remove_hooks(self):
         for h in self._hooks:

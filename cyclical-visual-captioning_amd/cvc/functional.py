@@ -64,7 +64,10 @@ class _WeightGradBatcher:
             grads = flush_fn(items)
             for w, g in zip(owner, grads):
                 if w is not None and g is not None and w.requires_grad:
-                    w.grad = g if w.grad is None else w.grad + g
+                    if w.grad is None:
+                        w.grad = g
+                    else:
+                        w.grad.add_(g.view_as(w.grad))       # in place: .grad may be a view into a gradient arena
         self.uses.clear()
 
 

@@ -93,7 +93,7 @@ def main(argv=None):
     lr_history = histories.get("lr_history", {})
 
     optimizer = build_optimizer(model, opt)
-    reducer = GradReducer(model.named_parameters()) if world > 1 else None
+    reducer = GradReducer(model.named_parameters())        # flat gradient arenas; exchanges only when world > 1
     trainer = Trainer(opt, full, model, optimizer, loader, val_loader, grad_reducer=reducer)
     scheduler = ReduceLROnPlateau(optimizer, 'max', patience=opt.patience, min_lr=opt.min_lr)
     tb = utils.set_tb_logger(opt.tb_log_dir, opt.exp_name, opt.resume) if (rank == 0 and opt.tensorboard and not opt.inference_only) else None

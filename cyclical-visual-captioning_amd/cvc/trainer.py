@@ -81,14 +81,24 @@ class Trainer:
             raise ValueError('Unknown att_model: {}'.format(self.opts.att_model))
         out = self._call(b)
         loss, lm, att2, cls, rec = self.loss_mix(out)
-        self.optimizer.zero_grad()
-        loss.backward()
-        if self.grad_reducer is not None:
-            self.grad_reducer.finalize()                     # the one exchange step of the path
-        nn.utils.clip_grad_norm_(self.model.parameters(), self.opts.grad_clip)
-        self.optimizer.step()
+        self._backward_and_update(loss)
         self._weights_changed()
         return loss.detach(), lm.detach(), att2.detach(), cls.detach(), rec.detach()
+
+    def _backward_and_update(self, loss, set_to_none=True):
+        """zero_grad -> backward -> [gradient exchange] -> clip_grad_norm_ -> step (trainer.py:116-122).  With a GradReducer
+        the gradients live in flat arenas: one fill to zero them, the exchange in place, one multiply to clip (1/G folded in)."""
+        red = self.grad_reducer
+        if red is None:
+            self.optimizer.zero_grad(set_to_none=set_to_none)
+            loss.backward()
+            nn.utils.clip_grad_norm_(self.model.parameters(), self.opts.grad_clip)
+        else:
+            red.zero_grad()
+            loss.backward()
+            red.finalize(average=False)                      # the one exchange step of the path
+            red.clip_(self.opts.grad_clip, summed=True)
+        self.optimizer.step()
 
     def _weights_changed(self):
         """The fused Adam kernel and HIP-graph replays update parameters without touching their version counters,
@@ -101,12 +111,7 @@ class Trainer:
     def _core_step(self, b):
         out = self._call(b)
         loss, lm, att2, cls, rec = self.loss_mix(out)
-        self.optimizer.zero_grad(set_to_none=False)
-        loss.backward()
-        if self.grad_reducer is not None:
-            self.grad_reducer.finalize()
-        nn.utils.clip_grad_norm_(self.model.parameters(), self.opts.grad_clip)
-        self.optimizer.step()
+        self._backward_and_update(loss, set_to_none=False)
         return torch.stack([loss.detach().reshape(()), lm.detach().reshape(()), att2.detach().reshape(()),
                             cls.detach().reshape(()), rec.detach().reshape(())])
 
@@ -115,6 +120,9 @@ class Trainer:
         (~7k launches) disappears.  Requirements: constant batch shapes (inputs are copied into static buffers), an
         optimizer built with capturable=True (build_optimizer(..., capturable=True)), single rank or a reducer without
         hooks.  Returns a static tensor [loss, lm, att2, cls, recon] (clone to keep)."""
+        if self.grad_reducer is not None and self.grad_reducer.world > 1:
+            raise RuntimeError("train_step_graphed with a multi-rank GradReducer is not supported: the RCCL exchange is issued "
+                               "from autograd hooks on the communicator's stream and is not captured; use train_step")
         b = self._prepare(batch, True)
         if self._graph is None:
             static = {k: (v.clone() if isinstance(v, torch.Tensor) else ({kk: vv.clone() for kk, vv in v.items()} if isinstance(v, dict) else v))

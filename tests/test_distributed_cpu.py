@@ -1,7 +1,8 @@
 """The N>1 path on CPU: world_size-2 gloo processes.  Compute is out of reach without a GPU, so
 the gradients come from the golden fixture G3 (per-shard reference gradients) and the test checks
-the exchange itself: bucketed all-reduce + 1/G == the fixture's shard mean, None-grad parameters are
-skipped consistently, a rank-divergent None is healed, results are bitwise equal across ranks."""
+the exchange itself: flat gradient arenas (every .grad a view), hook-driven bucket exchange + 1/G == the
+fixture's shard mean over several steps, never-used parameters keep all-zero views, the clip with the 1/G
+folded in == clip_grad_norm_ over averaged gradients, results are bitwise equal across ranks."""
 import os
 import sys
 
@@ -31,35 +32,45 @@ def _worker(rank, world, port, q):
         for overlap in (False, True):
             red = GradReducer(params, bucket_mb=0.01, overlap=overlap)          # tiny buckets -> several messages
             assert len(red.buckets) > 2
-            for step in range(2):                                                # step 0 agrees on active set; step 1 uses hooks
-                for n, p in params:
-                    p.grad = None
+            for n, p in params:                                                 # every .grad is a view into a flat arena
+                assert p.grad is not None and p.grad.data_ptr() == red._views[id(p)].data_ptr()
+            for step in range(3):                                               # step 0 learns the arrivals; 1, 2 launch from hooks
+                red.zero_grad()
                 for n, p in params:
                     if n in dead:
                         continue
                     g = torch.from_numpy(z["shard%d.grad.%s" % (rank, n)]).clone()
-                    if overlap:
-                        (p * g).sum().backward()                                  # drives the post-accumulate hooks
-                    else:
-                        p.grad = g
+                    (p * g).sum().backward()                                      # accumulates in place, drives the hooks
+                if step == 2 and overlap:
+                    assert any(red._launched)                                     # buckets left from inside backward
                 red.finalize()
                 for n, p in params:
+                    assert p.grad.data_ptr() == red._views[id(p)].data_ptr(), n  # still the arena view
                     if n in dead:
-                        assert p.grad is None, n
+                        assert float(p.grad.abs().max()) == 0.0, n               # never-used parameters: all-zero view
                     else:
                         np.testing.assert_allclose(p.grad.numpy(), z["mean.grad." + n], rtol=1e-6, atol=1e-8)
                 # bitwise equal across ranks
-                flat = torch.cat([p.grad.reshape(-1) for n, p in params if n not in dead])
+                flat = torch.cat([a for a in red.arenas])
                 both = [torch.zeros_like(flat) for _ in range(world)]
                 dist.all_gather(both, flat)
                 assert torch.equal(both[0], both[1])
+            # sums + clip with the 1/G folded in == clip_grad_norm_ over the averaged gradients (trainer.py:120-121)
+            red.zero_grad()
+            for n, p in params:
+                if n not in dead:
+                    (p * torch.from_numpy(z["shard%d.grad.%s" % (rank, n)])).sum().backward()
+            red.finalize(average=False)
+            total = red.clip_(0.1, summed=True)
+            ref = [torch.from_numpy(z["mean.grad." + n]).clone() for n, p in params if n not in dead]
+            ref_norm = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g) for g in ref]))
+            np.testing.assert_allclose(float(total), float(ref_norm), rtol=1e-5)
+            coef = min(1.0, 0.1 / (float(ref_norm) + 1e-6))
+            for (n, p), g in zip([(n, p) for n, p in params if n not in dead], ref):
+                np.testing.assert_allclose(p.grad.numpy(), (g * coef).numpy(), rtol=1e-5, atol=1e-9)
             red.remove_hooks()
-        # a gradient present on one rank only is healed with zeros on the other
-        p1 = torch.nn.Parameter(torch.zeros(4))
-        red = GradReducer([("only_rank0", p1)], overlap=False)
-        p1.grad = torch.ones(4) if rank == 0 else None
-        red.finalize()
-        np.testing.assert_allclose(p1.grad.numpy(), np.full(4, 0.5))
+            for n, p in params:
+                p.grad = None
         # inference outputs of the clip shards are merged host-side, identically on every rank
         from cvc.distributed import gather_eval_outputs
         preds = {"v_%d" % rank: [{"sentence": "s%d" % rank, "segment": "0"}], "v_shared": [{"sentence": "r%d" % rank, "segment": str(rank)}]}
