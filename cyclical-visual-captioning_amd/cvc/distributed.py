@@ -102,8 +102,9 @@ class GradReducer:
     """
 
     def __init__(self, named_params: Iterable[Tuple[str, torch.nn.Parameter]], bucket_mb: float = 0.0, group=None,
-                 overlap: bool = True, world: Optional[int] = None):
-        """bucket_mb > 0 additionally splits the 'rest' bucket into pieces of at most that size (tests use tiny buckets)."""
+                 overlap: bool = True, world: Optional[int] = None, always_exchange: bool = False):
+        """always_exchange: issue the collectives even in a one-rank group (tests: the RCCL path on a single GPU).
+        bucket_mb > 0 additionally splits the 'rest' bucket into pieces of at most that size (tests use tiny buckets)."""
         self.group = group
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
@@ -163,8 +164,9 @@ class GradReducer:
         self._expected: Optional[List[int]] = None           # gradient arrivals per bucket, learned on the first step
         self._seen_first: List[set] = [set() for _ in groups]
         self._work: List = []
-        self.overlap = overlap and self.world > 1
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for b in groups for _, p in b] if self.world > 1 else []
+        self.exchange = self.world > 1 or (always_exchange and dist.is_initialized())
+        self.overlap = overlap and self.exchange
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for b in groups for _, p in b] if self.exchange else []
 
     # ------------------------------------------------------------------ gradient bookkeeping
     def zero_grad(self):
@@ -193,7 +195,7 @@ class GradReducer:
 
     def _launch(self, i: int):
         self._launched[i] = True
-        if self.world == 1:
+        if not self.exchange:
             return
         a = self.arenas[i]
         if self.backend == "nccl":
@@ -209,7 +211,7 @@ class GradReducer:
     def finalize(self, average: bool = True):
         """Call after backward(): exchanges what the hooks did not, waits.  average=True leaves every gradient divided by
         the world size; average=False leaves SUMS for clip_() to fold the 1/G into its single multiply."""
-        if self.world > 1:
+        if self.exchange:
             if self._expected is None:
                 # first step: every rank must expect the same arrivals per bucket (same model, same graph) -- checked once
                 counts = torch.tensor([len(s) for s in self._seen_first], dtype=torch.int64, device=self.arenas[0].device)

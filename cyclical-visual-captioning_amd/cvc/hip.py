@@ -102,6 +102,10 @@ SIGNATURES = {
     "cvc_decode_num_launches": [_P],
     "cvc_decode_greedy": [_P, _P],
     "cvc_decode_beam": [_P, _P],
+    "cvc_comm_unique_id": [_P],
+    "cvc_comm_init": [_I, _I, _P, C.POINTER(C.c_void_p)],
+    "cvc_allreduce_grads": [_P, _P, _LL, _P],
+    "cvc_comm_destroy": [_P],
 }
 _VOID_RETURN = {"cvc_decode_plan_destroy"}
 
@@ -167,7 +171,8 @@ def disable_timers():
 
 def _check(rc: int, name: str):
     if rc != 0:
-        kind = {-1: "bad argument (size/alignment precondition)", -2: "dimension not covered by the kernel templates"}.get(
+        kind = {-1: "bad argument (size/alignment precondition)", -2: "dimension not covered by the kernel templates",
+                -3: "librccl.so could not be opened"}.get(
             rc, f"hipError_t {rc}")
         raise RuntimeError(f"{name} failed: {kind}")
 

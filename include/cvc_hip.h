@@ -28,6 +28,7 @@ typedef void* cvc_stream_t; /* hipStream_t */
 
 #define CVC_E_BADARG (-1)   /* a size/alignment precondition is violated            */
 #define CVC_E_TOOBIG (-2)   /* a dimension exceeds what the kernel templates cover  */
+#define CVC_E_NORCCL (-3)   /* librccl.so could not be opened (cvc_comm_* / cvc_allreduce_grads only) */
 
 #define CVC_ATTN_ADDITIVE 0 /* model/modules.py:100-159 AdditiveSoftAttention.forward */
 #define CVC_ATTN_DOT 1      /* model/modules.py:24-76   SoftAttention.forward         */
@@ -373,6 +374,19 @@ int cvc_decode_num_launches(const cvc_decode_plan* plan);                       
 /* enqueue one full decode on `stream`; results land in desc.words / att_steps / logprob (greedy), + score / parent (beam) */
 int cvc_decode_greedy(cvc_decode_plan* plan, cvc_stream_t stream);
 int cvc_decode_beam(cvc_decode_plan* plan, cvc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Multi-GPU training: the one exchange step of the path.  The reference reduces gradients inside nn.DataParallel
+ * (main.py:169; per-replica token-mean losses, unweighted mean over replicas, trainer.py:101-122); with one process per GPU
+ * that is a SUM all-reduce of the gradients over RCCL / xGMI followed by 1/G, which the caller folds into its clip multiply
+ * (cvc.distributed.GradReducer.clip_).  cvc_comm_unique_id (rank 0) -> share the 128 bytes with every rank by any means ->
+ * cvc_comm_init on every rank -> cvc_allreduce_grads(comm, flat gradient arena, floats, stream) per bucket, in place, stream
+ * ordered, no host synchronisation.  Return codes: 0, CVC_E_*, or 1000 + ncclResult_t.  librccl is dlopen'ed on first use.
+ */
+int cvc_comm_unique_id(void* out128);
+int cvc_comm_init(int world, int rank, const void* id128, void** comm);
+int cvc_allreduce_grads(void* comm, float* grads, long long count, cvc_stream_t stream);
+int cvc_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

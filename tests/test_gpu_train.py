@@ -210,3 +210,63 @@ def test_cyclical_gradients_vs_oracle_on_other_shapes(B, N, F, R, A, E, V, T):
         assert err <= 5e-4 * float(want.norm()) + 1e-6, (n, err, float(want.norm()))   # alpha_net.bias: true gradient ~0
         checked += 1
     assert checked >= 15
+
+
+def test_rccl_allreduce_cabi_one_rank():
+    """cvc_comm_unique_id -> cvc_comm_init -> cvc_allreduce_grads -> cvc_comm_destroy straight onto librccl (dlopen): a one-rank
+    communicator on the single GPU of the box; the SUM over one rank must return the arena bit for bit."""
+    import ctypes as C
+    from cvc import hip
+    L = hip.lib()
+    dev = torch.device("cuda:0")
+    uid = (C.c_char * 128)()
+    hip._check(L.cvc_comm_unique_id(uid), "cvc_comm_unique_id")
+    comm = C.c_void_p()
+    hip._check(L.cvc_comm_init(1, 0, uid, C.byref(comm)), "cvc_comm_init")
+    assert comm.value
+    arena = torch.randn(1 << 20, device=dev)
+    want = arena.clone()
+    s = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        hip._check(L.cvc_allreduce_grads(comm, arena.data_ptr(), arena.numel(), s), "cvc_allreduce_grads")
+    torch.cuda.synchronize()
+    assert torch.equal(arena, want)
+    assert L.cvc_allreduce_grads(None, arena.data_ptr(), 4, s) == -1          # bad arguments are rejected, not executed
+    hip._check(L.cvc_comm_destroy(comm), "cvc_comm_destroy")
+
+
+def test_gradient_exchange_on_rccl_one_rank_equals_no_exchange():
+    """torch.distributed "nccl" (= RCCL) process group of one rank, no torchrun: a training step whose GradReducer issues the
+    in-place reduce_scatter + all_gather from the autograd hooks must leave bit-identical parameters to the same step without
+    any exchange; and the graphed step refuses a multi-rank reducer loudly."""
+    import torch.distributed as dist
+    from cvc.distributed import GradReducer
+    dev = torch.device("cuda:0")
+    d = synth.CONFIGS["tiny"]
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29653", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        finals = []
+        for exch in (False, True):
+            o, model, batch, Trainer, build_optimizer = _setup(dev, d, train_decoder_only=False)
+            model.eval()                                                  # no dropout: both runs are deterministic
+            red = GradReducer(model.named_parameters(), always_exchange=exch)
+            assert red.exchange == exch and (red.backend == "nccl")
+            tr = Trainer(o, None, model, build_optimizer(model, o), None, None, grad_reducer=red)
+            for _ in range(3):                                             # step 0 learns the arrivals, 1-2 launch from hooks
+                tr.train_step(batch)
+            torch.cuda.synchronize()
+            finals.append({k: v.detach().clone() for k, v in model.state_dict().items()})
+            red.remove_hooks()
+        for k in finals[0]:
+            assert torch.equal(finals[0][k], finals[1][k]), k
+        o, model, batch, Trainer, build_optimizer = _setup(dev, d)
+        red = GradReducer(model.named_parameters(), world=2)
+        tr = Trainer(o, None, model, build_optimizer(model, o, capturable=True), None, None, grad_reducer=red)
+        with pytest.raises(RuntimeError, match="multi-rank"):
+            tr.train_step_graphed(batch)
+    finally:
+        if created:
+            dist.destroy_process_group()
