@@ -45,23 +45,42 @@ def main(argv=None):
     torch.cuda.set_device(device)
     random.seed(opt.seed); np.random.seed(opt.seed); torch.manual_seed(opt.seed)     # reference main.py:63-67
 
-    dims = synth.Dims(B=opt.batch_size, N=opt.num_prop_per_frm, F=opt.t_attn_size, R=opt.rnn_size, A=opt.att_hid_size,
-                      E=opt.input_encoding_size, T=opt.seq_length, G=opt.vis_encoding_size, K=min(8, opt.num_prop_per_frm))
-    full = SyntheticCaptionDataset(dims, opt.synthetic_clips, opt.seed, opt.train_split, raw=opt.synthetic_raw)
-    # clips are sharded across ranks; every rank gets the SAME number of clips (the remainder is dropped) so that all
-    # ranks run the same number of steps and issue the same collectives
-    sl = shard_range(len(full), rank, world, equal=True)
-    train_set = torch.utils.data.Subset(full, range(sl.start, sl.stop))
     per_rank_bs = max(1, opt.batch_size // world)
-    loader = DataLoader(train_set, batch_size=per_rank_bs, shuffle=True, num_workers=0, collate_fn=collate, drop_last=True)
-    val_loader = DataLoader(train_set, batch_size=per_rank_bs, shuffle=False, num_workers=0, collate_fn=collate)
-    # fields the reference injects into opt from the dataset (main.py:100-114)
-    opt.vocab_size, opt.itow, opt.wtoi, opt.itod, opt.detect_size = full.vocab_size, full.itow, full.wtoi, full.itod, dims.DET
-    if opt.synthetic_raw:
-        if opt.att_feat_size != opt.vis_encoding_size:
-            raise SystemExit("--synthetic_raw needs att_feat_size == vis_encoding_size (fc7 is square, backbone.py:115)")
-        opt.glove_clss, opt.glove_vg_cls = torch.from_numpy(full.glove_clss), torch.from_numpy(full.glove_vg_cls)
-        opt.vg_cls, opt.detectron_tables = full.vg_cls, full.tables
+    if opt.input_dic:
+        # ---- the reference's on-disk dataset (misc/dataloader_anet.py; main.py:78-114): .npy features, proposal arrays,
+        # annotation JSONs -> 12-tuples -> raw features through the once-per-clip encoder
+        from .misc.dataloader_anet import ANetEntitiesDataset, collate as anet_collate
+        full = ANetEntitiesDataset(opt, split=opt.train_split, seq_per_img=opt.seq_per_img)
+        val_full = ANetEntitiesDataset(opt, split=opt.val_split, seq_per_img=opt.seq_per_img, num_proposals=full.num_proposals,
+                                       label_proposals=full.label_proposals)
+        sl = shard_range(len(full), rank, world, equal=True)
+        vsl = shard_range(len(val_full), rank, world)
+        loader = DataLoader(torch.utils.data.Subset(full, range(sl.start, sl.stop)), batch_size=per_rank_bs, shuffle=True,
+                            num_workers=opt.num_workers, collate_fn=anet_collate, drop_last=True)
+        val_loader = DataLoader(torch.utils.data.Subset(val_full, range(vsl.start, vsl.stop)), batch_size=per_rank_bs, shuffle=False,
+                                num_workers=opt.num_workers, collate_fn=anet_collate)
+        opt.vocab_size, opt.detect_size = full.vocab_size, full.detect_size                # reference main.py:100-114
+        opt.glove_w, opt.glove_vg_cls, opt.glove_clss = (torch.from_numpy(getattr(full, k)).float()
+                                                         for k in ("glove_w", "glove_vg_cls", "glove_clss"))
+        for k in ("wtoi", "itow", "itod", "ltow", "itoc", "wtol", "wtod", "vg_cls"):
+            setattr(opt, k, getattr(full, k))
+    else:
+        dims = synth.Dims(B=opt.batch_size, N=opt.num_prop_per_frm, F=opt.t_attn_size, R=opt.rnn_size, A=opt.att_hid_size,
+                          E=opt.input_encoding_size, T=opt.seq_length, G=opt.vis_encoding_size, K=min(8, opt.num_prop_per_frm))
+        full = SyntheticCaptionDataset(dims, opt.synthetic_clips, opt.seed, opt.train_split, raw=opt.synthetic_raw)
+        # clips are sharded across ranks; every rank gets the SAME number of clips (the remainder is dropped) so that all
+        # ranks run the same number of steps and issue the same collectives
+        sl = shard_range(len(full), rank, world, equal=True)
+        train_set = torch.utils.data.Subset(full, range(sl.start, sl.stop))
+        loader = DataLoader(train_set, batch_size=per_rank_bs, shuffle=True, num_workers=0, collate_fn=collate, drop_last=True)
+        val_loader = DataLoader(train_set, batch_size=per_rank_bs, shuffle=False, num_workers=0, collate_fn=collate)
+        # fields the reference injects into opt from the dataset (main.py:100-114)
+        opt.vocab_size, opt.itow, opt.wtoi, opt.itod, opt.detect_size = full.vocab_size, full.itow, full.wtoi, full.itod, dims.DET
+        if opt.synthetic_raw:
+            if opt.att_feat_size != opt.vis_encoding_size:
+                raise SystemExit("--synthetic_raw needs att_feat_size == vis_encoding_size (fc7 is square, backbone.py:115)")
+            opt.glove_clss, opt.glove_vg_cls = torch.from_numpy(full.glove_clss), torch.from_numpy(full.glove_vg_cls)
+            opt.vg_cls, opt.detectron_tables = full.vg_cls, full.tables
 
     model = build_model(opt, device)
     save_dir = os.path.join(opt.checkpoint_path, opt.exp_name)

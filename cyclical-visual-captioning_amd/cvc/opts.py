@@ -121,6 +121,8 @@ _BUILD = [
     ("--warm_start_mode", dict(type=str, default="reference")),  # "reference" = suffix/last-wins, "corrected"
     ("--results_dir", dict(type=str, default="results")),   # where eval writes the densecap / grounding JSON
     ("--detectron_weights_dir", dict(type=str, default="data/detectron_weights")),  # fc7 / cls_score pickles
+    ("--glove_path", dict(type=str, default="data/glove.6B.300d.npz")),     # GloVe as .npz (words, vectors): no torchtext here
+    ("--vg_vocab_file", dict(type=str, default="data/vg_object_vocab.txt")),  # Visual Genome classes (reference: hard-coded)
 ]
 
 

@@ -12,7 +12,7 @@ from cvc import opts as cvc_opts
 from cvc import synth
 from conftest import GOLDEN
 
-BUILD_ONLY = {"hip_graph", "dist_backend", "warm_start_mode", "results_dir", "detectron_weights_dir"}
+BUILD_ONLY = {"hip_graph", "dist_backend", "warm_start_mode", "results_dir", "detectron_weights_dir", "glove_path", "vg_vocab_file"}
 
 
 @pytest.fixture(scope="module")

@@ -441,6 +441,71 @@ def g5_encoder(path):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+def g6_dataloader(path):
+    """The reference's misc/dataloader_anet.py::DataLoader itself, run over the tiny synthetic dataset of
+    cvc.data_fixture (written in the reference's own file formats), with stand-ins ONLY for the third-party modules this
+    image lacks: h5py (File -> the two proposal arrays from the .npz twin), torchtext.vocab.GloVe (-> the dataset's GloVe
+    table) and torchvision (imported by the reference, never used on this path).  Captures every 12-tuple of two splits,
+    the test-mode tuples, and the constructor's GloVe tables."""
+    import importlib
+    import random
+    import tempfile
+    from cvc.data_fixture import write_tiny_anet_dataset
+    root = tempfile.mkdtemp(prefix="g6_")
+    o = write_tiny_anet_dataset(root, seed=7)
+
+    class _H5File(dict):
+        def __init__(self, p, mode="r", driver=None):
+            with np.load(p) as z:
+                super().__init__({k: z[k] for k in z.files})
+
+        def close(self):
+            pass
+    h5 = types.ModuleType("h5py"); h5.File = _H5File
+    tt, ttv = types.ModuleType("torchtext"), types.ModuleType("torchtext.vocab")
+
+    class _GloVe:
+        def __init__(self, name=None, dim=300):
+            z = np.load(o.glove_path)
+            self.stoi = {str(w): i for i, w in enumerate(z["words"])}
+            self.vectors = torch.from_numpy(z["vectors"]).float()
+    ttv.GloVe = _GloVe; tt.vocab = ttv
+    tv, tvd, tvf, tvt = (types.ModuleType(n) for n in ("torchvision", "torchvision.datasets", "torchvision.datasets.folder",
+                                                      "torchvision.transforms"))
+    tvf.default_loader = None; tvd.folder = tvf; tv.datasets = tvd; tv.transforms = tvt
+    sys.modules.update({"h5py": h5, "torchtext": tt, "torchtext.vocab": ttv, "torchvision": tv, "torchvision.datasets": tvd,
+                        "torchvision.datasets.folder": tvf, "torchvision.transforms": tvt})
+    ref = importlib.import_module("misc.dataloader_anet")
+    out = OrderedDict()
+    cwd = os.getcwd()
+    os.chdir(root)                                   # the reference opens 'data/vg_object_vocab.txt' relative to the CWD
+    try:
+        for tag, split, test_mode in (("train", "training", False), ("val", "validation", False), ("test", "training", True)):
+            ro = argparse.Namespace(**{k: getattr(o, k) for k in (
+                "batch_size", "seq_per_img", "seq_length", "att_feat_size", "feature_root", "seg_feature_root", "num_sampled_frm",
+                "num_prop_per_frm", "exclude_bgd_det", "prop_thresh", "t_attn_size", "input_dic", "input_json", "grd_reference",
+                "proposal_h5")}, test_mode=test_mode)
+            np.random.seed(3); random.seed(3)
+            ds = ref.DataLoader(ro, split=split, seq_per_img=o.seq_per_img)
+            out[tag + ".len"] = np.asarray(len(ds))
+            if tag == "train":
+                for k in ("glove_vg_cls", "glove_clss", "glove_w"):
+                    out["tables." + k] = np.asarray(getattr(ds, k))
+                out["tables.vocab_size"], out["tables.detect_size"] = np.asarray(ds.vocab_size), np.asarray(ds.detect_size)
+                out["tables.split_ix"] = np.asarray(ds.split_ix)
+            for i in range(len(ds)):
+                item = ds[i]
+                for j, x in enumerate(item):
+                    if isinstance(x, str):
+                        out["%s.%d.%d" % (tag, i, j)] = np.asarray(x)
+                    else:
+                        out["%s.%d.%d" % (tag, i, j)] = x.numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
     gdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gdir, exist_ok=True)
@@ -449,7 +514,8 @@ if __name__ == "__main__":
             "g2": lambda: g2_cfg1(os.path.join(gdir, "g2_cfg1.npz")),
             "g3": lambda: g3_shards(os.path.join(gdir, "g3_shards.npz")),
             "g4": lambda: g4_config_surface(os.path.join(gdir, "config_surface.json")),
-            "g5": lambda: g5_encoder(os.path.join(gdir, "g5_encoder.npz"))}
+            "g5": lambda: g5_encoder(os.path.join(gdir, "g5_encoder.npz")),
+            "g6": lambda: g6_dataloader(os.path.join(gdir, "g6_dataloader.npz"))}
     for name, job in jobs.items():
         if not only or name in only:
             job()
