@@ -29,12 +29,18 @@ struct ScoreArgs {
 // QG = queries per group: the group's accumulators are independent chains for the VALU and its LDS reads / wave reductions are
 // issued back to back.  The query list is padded to a multiple of QG in LDS (zero rows), so the group body has NO branches:
 // with a per-query `if` the compiler fences every 16-byte query read behind its own s_waitcnt (measured at beam 5: 87 us).
+//
+// Additive form, instruction count per (row, query, element) -- the pass is VALU-issue-bound with several queries per clip (PMC at
+// beam 5: the vector ALU busy 68 of 80 us, ~4.8 cycles per instruction whatever its kind): tanh(p + q) = 1 - 2 / (1 + 2^(C (p + q))),
+// C = 2 log2 e, with C q stored in LDS (scaled once per workgroup) and C p formed once per row element for all of its queries:
+// add, exp2, add, rcp, fma, fma = 6 instructions (the expf(2x) form compiled to 8).
 template <int KIND, int NCH, int QG>
 __global__ __launch_bounds__(SCORE_WG) void attn_scores_kernel(ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nq_pad = (a.nq + QG - 1) / QG * QG;
     float* q_s = smem;                         // [nq_pad][A]
     float* w_s = smem + (size_t)nq_pad * a.A;  // [A]
+    constexpr float EXP_C = 2.8853900817779268f;          // 2 log2(e)
     const int clip = blockIdx.y;
     const int s = (int)blockIdx.x < a.chunks0 ? 0 : 1;
     const int chunk = s == 0 ? blockIdx.x : blockIdx.x - a.chunks0;
@@ -50,6 +56,7 @@ __global__ __launch_bounds__(SCORE_WG) void attn_scores_kernel(ScoreArgs a) {
             for (int p = 1; p < a.q_nparts; ++p) v += ld4(src + (size_t)p * a.q_part_stride);
             if (a.q_bias != nullptr) v += ld4(a.q_bias + (i % A));
         }
+        if (KIND == CVC_ATTN_ADDITIVE) v *= EXP_C;
         st4(q_s + i, v);
     }
     if (KIND == CVC_ATTN_ADDITIVE)
@@ -103,25 +110,22 @@ __global__ __launch_bounds__(SCORE_WG) void attn_scores_kernel(ScoreArgs a) {
             for (int u = 0; u < QG; ++u) acc[u] = 0.f;
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
-                const f32x4 p = cok[j] ? cur[j] : f32x4{0, 0, 0, 0};
+                f32x4 p = cok[j] ? cur[j] : f32x4{0, 0, 0, 0};
                 f32x4 w4 = {0, 0, 0, 0};
                 if (KIND == CVC_ATTN_ADDITIVE) {
                     w4 = ld4(w_s + colc[j]);
                     if (!cok[j]) w4 = f32x4{0, 0, 0, 0};
+                    p *= EXP_C;
                 }
 #pragma unroll
                 for (int u = 0; u < QG; ++u) {
                     const f32x4 q4 = ld4(q_s + (q0 + u) * A + colc[j]);
-#if defined(CVC_SC_ABL) && CVC_SC_ABL == 1
-                    if (KIND == CVC_ATTN_ADDITIVE) {                       // ablation: no transcendental work
-                        acc[u] += w4.x * (p.x + q4.x) + w4.y * (p.y + q4.y) + w4.z * (p.z + q4.z) + w4.w * (p.w + q4.w);
-                    } else
-#endif
                     if (KIND == CVC_ATTN_ADDITIVE) {
-                        acc[u] += w4.x * fast_tanh(p.x + q4.x);
-                        acc[u] += w4.y * fast_tanh(p.y + q4.y);
-                        acc[u] += w4.z * fast_tanh(p.z + q4.z);
-                        acc[u] += w4.w * fast_tanh(p.w + q4.w);
+                        const f32x4 x = p + q4;                    // C (p + q)
+                        acc[u] = fmaf(w4.x, fmaf(-2.0f, fast_rcp(1.0f + __builtin_amdgcn_exp2f(x.x)), 1.0f), acc[u]);
+                        acc[u] = fmaf(w4.y, fmaf(-2.0f, fast_rcp(1.0f + __builtin_amdgcn_exp2f(x.y)), 1.0f), acc[u]);
+                        acc[u] = fmaf(w4.z, fmaf(-2.0f, fast_rcp(1.0f + __builtin_amdgcn_exp2f(x.z)), 1.0f), acc[u]);
+                        acc[u] = fmaf(w4.w, fmaf(-2.0f, fast_rcp(1.0f + __builtin_amdgcn_exp2f(x.w)), 1.0f), acc[u]);
                     } else {
                         acc[u] += p.x * q4.x + p.y * q4.y + p.z * q4.z + p.w * q4.w;
                     }

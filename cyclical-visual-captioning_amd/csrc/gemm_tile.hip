@@ -230,11 +230,18 @@ struct LstmFinishArgs {
 template <int NP>
 __global__ __launch_bounds__(256) void tile_lstm_finish_kernel(LstmFinishArgs a) {
     const int R = a.R;
-    const int q = blockIdx.x * 256 + threadIdx.x;            // (row m, hidden quad)
-    const int nq = R >> 2;
-    if (q >= a.M * nq) return;
-    const int m = q / nq, j = (q - m * nq) * 4;              // hidden units j .. j + 3
-    const int col = (j >> 3) * 32 + (j & 7);                 // packed feature index of gate 0
+    // A wave = 32 rows x the 2 hidden quads of ONE packed block (8 hidden units, 32 slab columns): its slab reads are 32-byte
+    // runs that together use every fetched line, and its fragment writes are 512 contiguous bytes per term (row stride 16 B,
+    // the two quads side by side) -- with the hidden quad fastest across a wave the fragment stores were 8-byte scatters.
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int hq = (int)(q & 1), i = (int)((q >> 1) & 31);
+    const long long unit = q >> 6;                           // (row block, packed block), packed block fastest
+    const int nblk = R >> 3;
+    const int blk = (int)(unit % nblk), mb = (int)(unit / nblk);
+    const int m = mb * 32 + i;
+    if (m >= a.M) return;
+    const int j = blk * 8 + hq * 4;                          // hidden units j .. j + 3
+    const int col = blk * 32 + hq * 4;                       // packed feature index of gate 0
     f32x4 pre[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -391,7 +398,7 @@ extern "C" int cvc_tile_lstm_finish(const float* parts, int nparts, long long pa
     a.parts = parts; a.nparts = nparts; a.part_stride = part_stride; a.b_ih = b_ih; a.b_hh = b_hh; a.gate_bias = gate_bias;
     a.gb_div = gb_div; a.c_prev = c_prev; a.c_out = c_out; a.h_out = h_out; a.frag1 = (uint16_t*)frag1; a.frag1_stride = frag1_stride;
     a.frag2 = (uint16_t*)frag2; a.frag2_stride = frag2_stride; a.M = M; a.R = R;
-    const long long n = (long long)M * (R / 4);
+    const long long n = (long long)((M + 31) / 32) * 32 * (R / 4);       // whole 32-row blocks (threads past M exit)
     const dim3 g((unsigned)((n + 255) / 256));
     switch (nparts) {
         case 1: hipLaunchKernelGGL(tile_lstm_finish_kernel<1>, g, dim3(256), 0, (hipStream_t)stream, a); break;

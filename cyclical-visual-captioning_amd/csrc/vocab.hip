@@ -330,8 +330,10 @@ __global__ __launch_bounds__(WG) void lstm_pointwise_bwd_kernel(const float* d_h
 constexpr int BEAM_MAX = 8;
 constexpr int ROW_CACHE = 32;        // values per thread kept in registers: V <= 256 * 32
 
-__global__ __launch_bounds__(WG) void beam_rowtop_kernel(const float* logits, int beam, int V, int unk, float* cand_v,
-                                                         int* cand_i, float* lse_out) {
+// logits: [rows, V], or -- nparts > 1 / bias given -- the K-slice slabs of the vocabulary GEMM [nparts][rows, V] (+ bias [V]),
+// summed in slab order while the row is loaded (the tile path's logits never exist as one matrix)
+__global__ __launch_bounds__(WG) void beam_rowtop_kernel(const float* logits, int nparts, long long part_stride, const float* bias,
+                                                         int beam, int V, int unk, float* cand_v, int* cand_i, float* lse_out) {
     __shared__ float red[4];
     __shared__ float bestv[4];
     __shared__ int besti[4];
@@ -343,7 +345,13 @@ __global__ __launch_bounds__(WG) void beam_rowtop_kernel(const float* logits, in
 #pragma unroll
     for (int u = 0; u < ROW_CACHE; ++u) {
         const int v = threadIdx.x + u * WG;
-        vals[u] = v < V ? x[v] : -INFINITY;
+        float xv = -INFINITY;
+        if (v < V) {
+            xv = x[v];
+            for (int p = 1; p < nparts; ++p) xv += x[(size_t)p * part_stride + v];
+            if (bias != nullptr) xv += bias[v];
+        }
+        vals[u] = xv;
         m = fmaxf(m, vals[u]);
     }
     m = block_max(m, red);
@@ -538,9 +546,23 @@ extern "C" int cvc_lstm_pointwise_bwd(const float* d_h, const float* d_c, const 
     return cvc_launch_status();
 }
 
+extern "C" int cvc_beam_select_parts(const float* parts, int nparts, long long part_stride, const float* bias,
+                                     const float* score_in, const uint8_t* done_in, int B, int beam, int V, int unk_idx,
+                                     int first_step, int64_t* parent, int64_t* word, float* score_out, uint8_t* done_out,
+                                     float* workspace, cvc_stream_t stream);
+
 extern "C" int cvc_beam_select(const float* logits, const float* score_in, const uint8_t* done_in, int B, int beam, int V,
                                int unk_idx, int first_step, int64_t* parent, int64_t* word, float* score_out,
                                uint8_t* done_out, float* workspace, cvc_stream_t stream) {
+    return cvc_beam_select_parts(logits, 1, 0, nullptr, score_in, done_in, B, beam, V, unk_idx, first_step, parent, word, score_out,
+                                 done_out, workspace, stream);
+}
+
+extern "C" int cvc_beam_select_parts(const float* logits, int nparts, long long part_stride, const float* bias,
+                                     const float* score_in, const uint8_t* done_in, int B, int beam, int V, int unk_idx,
+                                     int first_step, int64_t* parent, int64_t* word, float* score_out, uint8_t* done_out,
+                                     float* workspace, cvc_stream_t stream) {
+    if (nparts < 1) return CVC_E_BADARG;
     if (!logits || !score_in || !done_in || !parent || !word || !score_out || !done_out || !workspace) return CVC_E_BADARG;
     if (B < 1 || beam < 1 || beam > BEAM_MAX || V < beam + 1 || V > WG * ROW_CACHE) return CVC_E_BADARG;
     // workspace: [rows*8] candidate values, [rows*8] candidate indices, [rows] lse   (rows = B*beam)
@@ -548,8 +570,8 @@ extern "C" int cvc_beam_select(const float* logits, const float* score_in, const
     float* cand_v = workspace;
     int* cand_i = reinterpret_cast<int*>(workspace + (size_t)rows * BEAM_MAX);
     float* lse = workspace + (size_t)rows * BEAM_MAX * 2;
-    hipLaunchKernelGGL(beam_rowtop_kernel, dim3(rows), dim3(WG), 0, (hipStream_t)stream, logits, beam, V, unk_idx, cand_v,
-                       cand_i, lse);
+    hipLaunchKernelGGL(beam_rowtop_kernel, dim3(rows), dim3(WG), 0, (hipStream_t)stream, logits, nparts, part_stride, bias, beam, V,
+                       unk_idx, cand_v, cand_i, lse);
     hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, cand_v, cand_i, lse, score_in, done_in,
                        beam, V, first_step, parent, word, score_out, done_out);
     return cvc_launch_status();

@@ -88,6 +88,7 @@ SIGNATURES = {
     "cvc_vocab_nll_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P],
     "cvc_grounder_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "cvc_beam_select": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "cvc_beam_select_parts": [_P, _I, _LL, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "cvc_gather_rows": [_P, _P, _I, _I, _I, _P, _P],
     "cvc_tile_rows_alloc": [_I],
     "cvc_tile_gemm": [_P, _P, _LL, _I, _I, _I, _I, _P, _I, _LL, _P],

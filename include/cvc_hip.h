@@ -272,6 +272,12 @@ int cvc_beam_select(const float* logits, const float* score_in, const uint8_t* d
                     int B, int beam, int V, int unk_idx, int first_step,
                     int64_t* parent, int64_t* word, float* score_out, uint8_t* done_out,
                     float* workspace /* >= 17 * B * beam floats */, cvc_stream_t stream);
+/* the same with the logits given as the K-slice slabs of the vocabulary GEMM, parts[s][rows, V] (slab stride part_stride floats)
+ * plus bias[V] (nullable): summed in slab order while a row is loaded, so the tile path never writes the logits matrix */
+int cvc_beam_select_parts(const float* parts, int nparts, long long part_stride, const float* bias,
+                          const float* score_in, const uint8_t* done_in, int B, int beam, int V, int unk_idx,
+                          int first_step, int64_t* parent, int64_t* word, float* score_out, uint8_t* done_out,
+                          float* workspace, cvc_stream_t stream);
 /* dst[r, :] = src[(r / beam) * beam + parent[r], :] for r in [0, rows)  (state reorder) */
 int cvc_gather_rows(const float* src, const int64_t* parent, int rows, int beam, int width,
                     float* dst, cvc_stream_t stream);

@@ -357,6 +357,29 @@ def test_split_product_gemm_is_fp32_grade(dev, lib, M, K, N):
         assert err[mode][0] <= 1.25 * err[0][0] and err[mode][1] <= 1.25 * err[0][1], err
 
 
+@pytest.mark.parametrize("nq", [2, 5, 7])
+def test_multi_query_additive_scores_large_values_take_the_direct_form(dev, lib, nq):
+    """Several additive queries per clip use tanh(p + q) = 1 - 2 / (1 + 2^(Cp) 2^(Cq)) with the two factors computed separately
+    (one transcendental per element instead of two); values beyond |20| must fall back to the direct form -- per feature row
+    for p, per workgroup for q -- or the product would overflow / flush.  Checked against fp64 with planted large entries of
+    both signs (p = 45 with q = -44 is tanh(1), not tanh(inf))."""
+    g = torch.Generator().manual_seed(nq)
+    nclip, N, A, R = 3, 70, 256, 64
+    P = torch.randn(nclip, N, A, generator=g)
+    q = torch.randn(nclip * nq, A, generator=g)
+    P[0, 3, 5], P[0, 3, 6], P[1, 40, 0] = 45.0, -60.0, 21.0             # rows 3 / 40 of clips 0 / 1: direct form for the row
+    q[nq * 2 + 1, 7] = -44.0                                                # clip 2: direct form for the whole workgroup
+    q[0, 5] = -44.0                                                         # clip 0, query 0: p + q = 1 at [3, 5]
+    w = torch.randn(A, generator=g) * 0.2
+    b = torch.randn(1, generator=g)
+    ctx = torch.randn(nclip, N, R, generator=g)
+    outs, _ = lib.attn_fwd(lib.ATTN_ADDITIVE, q.to(dev), w.to(dev), b.to(dev), 1.0, [dict(proj=P.to(dev), ctx=ctx.to(dev))], nclip, nq)
+    scores = outs[0][0].cpu()
+    ref = (torch.tanh(P.double().repeat_interleave(nq, 0) + q.double().unsqueeze(1)) * w.double()).sum(2) + b.double()
+    close(scores, ref.float(), rtol=2e-5, atol=2e-5)
+    assert bool(torch.isfinite(scores).all())
+
+
 @pytest.mark.parametrize("M,R,E", [(64, 2048, 1024), (37, 256, 96), (1, 64, 32), (64, 4096, 2048)])
 def test_packed_lstm_ksplit_equals_full_k_kernel(dev, lib, M, R, E):
     """cvc_packed_lstm_ks_fwd (256 gate rows x K / S per workgroup, activations shared through LDS, slabs + finishing kernel)
