@@ -50,8 +50,9 @@ def parse():
     for k in ("B", "N", "F", "R", "A", "E", "V", "T"):
         p.add_argument("--" + k, type=int, default=None)
     p.add_argument("--beam", type=int, default=1)
-    p.add_argument("--mode", default="decode", choices=["decode", "train"],
-                   help="decode = headline metric (default); train = cyclical fwd+bwd+all-reduce+Adam step (configs 3-ii / 4)")
+    p.add_argument("--mode", default="decode", choices=["decode", "train", "encoder"],
+                   help="decode = headline metric (default); train = cyclical fwd+bwd+all-reduce+Adam step (configs 3-ii / 4); "
+                        "encoder = the once-per-clip region / frame encoder (SURVEY 8(f) rank 1, library ops) per piece")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--gate-ksplit", type=int, default=None, choices=[0, 1],
                    help="packed path: 1 = K-split gate GEMMs (activations shared through LDS + finishing kernel), 0 = full-K "
@@ -261,6 +262,69 @@ def run_train(args, d, dev, rank, world):
         print(json.dumps(line), flush=True)
 
 
+def run_encoder(args, d, dev):
+    """Once-per-clip encoder (cvc/model/backbone.py, mirror of the reference's RegionalFeatureExtractorGVD, backbone.py:189-351)
+    at the hot path's dimensions: raw frame features [B, F, 3072] and region features [B, N, G] -> the tensors the decoder reads.
+    It is library work (hipBLASLt GEMMs, MIOpen GRU); this mode times its pieces so that the next round can decide which
+    deserve kernels.  clips/s, not decode-steps/s: the encoder runs once per clip, the decoder T times."""
+    import argparse as ap
+    from cvc import synth
+    from cvc.model.backbone import RegionalFeatureExtractorGVD
+    tables = synth.detectron_tables(d, args.seed)
+    o = ap.Namespace(
+        vocab_size=d.V, seq_length=d.T, seq_per_img=1, rnn_size=d.R, input_encoding_size=d.E, att_hid_size=d.A, drop_prob_lm=0.5,
+        detect_size=d.DET, vis_encoding_size=d.G, enable_BUTD=False, att_input_mode="both", num_sampled_frm=10, finetune_cnn=False,
+        att_feat_size=d.G, fc_feat_size=synth.SEG_FEAT_DIM, t_attn_size=d.F, second_drop_prob=0.3, att_model="topdown",
+        t_attn_mode="bigru", test_mode=False, itod={i + 1: "d%d" % i for i in range(d.DET)},
+        vg_cls=["vg%d" % i for i in range(tables["glove_vg_cls"].shape[0])], glove_clss=torch.from_numpy(tables["glove_clss"]),
+        glove_vg_cls=torch.from_numpy(tables["glove_vg_cls"]), detectron_tables=tables)
+    enc = RegionalFeatureExtractorGVD(o).to(dev).eval()
+    inp = {k: (torch.from_numpy(np.ascontiguousarray(v)).to(dev) if isinstance(v, np.ndarray) else v)
+           for k, v in synth.encoder_inputs(d, args.seed).items()}
+    from cvc.misc import utils
+    overlaps = utils.bbox_overlaps(inp["proposals"], inp["gt_bboxs"], inp["frm_mask"] | inp["pnt_mask_in"][:, 1:].unsqueeze(-1))
+
+    def fwd():
+        return enc(inp["segs_feat"], inp["proposals"], inp["num"], inp["box_mask"], inp["region_feats"], inp["gt_bboxs"], overlaps,
+                   inp["sample_idx"])
+
+    def timed(fn, n):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            fwd()
+        ms = timed(fwd, max(3, min(args.steps, 30)))
+        # pieces (same tensors, eval mode)
+        B, N, F = d.B, d.N, d.F
+        regions = inp["region_feats"]
+        seg = inp["segs_feat"].float()
+        x_rnn = torch.randn(B, F, d.R, device=dev)
+        pieces = {
+            "ctx2pool_grd  [B*N, G] x [G, G] + ReLU (backbone.py:206-210)": lambda: enc.ctx2pool_grd(regions),
+            "class similarity softmax [B, DET+1, N] (backbone.py:216-235)": lambda: enc.class_similarity(regions, inp["pnt_mask_in"][:, 1:]),
+            "frame embeddings 2 x Linear + BatchNorm (backbone.py:325-333)": lambda: enc.att_embed_aux(
+                torch.cat((enc.att_embed[0](seg[..., :2048]), enc.att_embed[1](seg[..., 2048:3072])), 2).transpose(1, 2)),
+            "2-layer BiGRU over F frames (backbone.py:335-338)": lambda: enc.context_enc(x_rnn),
+            "ctx2att_fc [B*F, R] x [R, A] (backbone.py:343)": lambda: enc.ctx2att_fc(x_rnn),
+        }
+        piece_ms = {k: round(timed(fn, 10), 3) for k, fn in pieces.items()}
+    print(json.dumps({
+        "metric": "once-per-clip encoder clips/sec (library ops; not the headline metric)", "value": round(d.B / (ms * 1e-3), 1),
+        "unit": "clips/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}: RegionalFeatureExtractorGVD forward (eval), raw frame features [B,{d.F},3072] + region "
+                               f"features [B,{d.N},{d.G}]", "B_per_gpu": d.B, "N": d.N, "F": d.F, "D": d.R, "G": d.G},
+        "decode_ms_for_comparison": "T-step greedy decode of the same B clips: see the default mode (4.1 ms at cfg2)",
+        "pieces_ms": piece_ms, "roofline": None, "cpu_baseline": None}), flush=True)
+
+
 def train_work(d):
     """Algorithmic bytes / flops per training STEP of the C-ABI entry points that carry the dense work (cyclical pass,
     train_decoder_only = False; SURVEY.md section 8(d) training formulas).  Weights stream once per launch; M = B rows per
@@ -310,6 +374,13 @@ def main():
     over = {k: getattr(args, k) for k in ("B", "N", "F", "R", "A", "E", "V", "T") if getattr(args, k) is not None}
     if over:
         d = dataclasses.replace(d, **over)
+    if args.mode == "encoder":
+        if rank == 0:
+            run_encoder(args, d, dev)
+        if dist_on:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
     if args.mode == "train":
         run_train(args, d, dev, rank, world)
         if dist_on:

@@ -14,6 +14,7 @@
 //   ordered cross-wave sum in LDS, K slices written as partial planes, summed in a fixed order by
 //   nn_reduce_kernel (bitwise reproducible).
 #include "cvc_common.h"
+#include "gemm_split.h"
 
 namespace {
 
@@ -210,6 +211,195 @@ __global__ __launch_bounds__(256, CVC_NN_WGS) void skinny_gemm_nn_kernel(NNArgs 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Split-product variant (cvc_gemm_packed_split != 0, the default): the same tiling, but two consecutive 8-row groups of a wave
+// are taken together as one K = 16 step of v_mfma_f32_32x32x16_bf16 -- each fp32 operand split exactly into three bf16 terms,
+// six cross terms per product (gemm_split.h) -- 48 bf16 MFMAs (1536 matrix cycles) instead of 128 fp32 MFMAs (8192) per 16 rows
+// at MT = 2.  The fp32 kernel above is matrix-bound (MFMA-only 66 us of its 75 us at the cfg3 lang cell); this one is bound by
+// the weight stream.  Register budget: 128 accumulators + a ring of 16-row groups (48 registers each) -> one workgroup per CU
+// (4 waves, up to 512 registers each), ring depth 4 to cover HBM latency with a single wave per SIMD.
+// k-slot map of a double group (groups ga, gb of this wave): slot s < 4 <-> row 8 ga + 4 kh + s, slot 4 + s <-> row 8 gb + 4 kh + s,
+// the same for the weight rows and for the dY quads, so any permutation of k is harmless.
+#ifndef CVC_NNS_DEPTH
+#define CVC_NNS_DEPTH 4
+#endif
+
+template <int MT>
+struct NNFrag2 {
+    f32x4 w[8];
+    f32x4 x[MT][2];
+};
+
+template <int MT>
+__global__ __launch_bounds__(256, 1) void skinny_gemm_nn_split_kernel(NNArgs a) {
+    constexpr int NW = 4;
+    constexpr int LDM = MT * 32 + 1;
+    constexpr int D = CVC_NNS_DEPTH;
+    __shared__ float red[2 * 128 * LDM];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, kh = lane >> 5;
+    const int kslice = (int)blockIdx.x % a.ksplit, slab = (int)blockIdx.x / a.ksplit;
+    int s = 0;
+    for (int t = 1; t < a.nseg; ++t)
+        if (slab >= a.seg[t].slab0) s = t;
+    const NNSeg sg = a.seg[s];
+    const int n0 = (slab - sg.slab0) * 128;
+    int col = n0 + 4 * i;
+    col = col + 4 <= sg.ncols ? col : sg.ncols - 4;
+
+    const int ngroup = a.K >> 3;
+    const int g_lo = ngroup * kslice / a.ksplit, g_hi = ngroup * (kslice + 1) / a.ksplit;
+    const int ng = g_hi - g_lo;
+    const int n_my = ng > wave ? (ng - wave + NW - 1) / NW : 0;      // groups g_lo + wave + 4*j
+    const int n2 = n_my >> 1;                                         // double groups; an odd last group runs on the fp32 MFMA
+    const size_t ldw = (size_t)sg.ldw;
+    const float* wp[4];
+    wp[0] = sg.w + (size_t)((g_lo + wave) * 8 + kh * 4) * ldw + col;
+#pragma unroll
+    for (int e = 1; e < 4; ++e) wp[e] = wp[e - 1] + ldw;
+    const float* xp = a.xq + ((size_t)((g_lo + wave) * 2 + kh) * 64 + i) * 4;
+    const size_t WSTEP = (size_t)NW * 8 * ldw;
+    constexpr size_t XSTEP = (size_t)NW * 2 * 256;
+
+    auto load2 = [&](NNFrag2<MT>& f) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f.w[h * 4 + e] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(wp[e]));
+                wp[e] += WSTEP;
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) f.x[mt][h] = ld4(xp + mt * 128);
+            xp += XSTEP;
+        }
+    };
+
+    f32x16 acc[4][MT];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][mt][r] = 0.f;
+
+    auto mma2 = [&](const NNFrag2<MT>& f) __attribute__((always_inline)) {
+        Split3 X[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) X[mt] = split8(f.x[mt][0], f.x[mt][1]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 wa = {f.w[0][c], f.w[1][c], f.w[2][c], f.w[3][c]};
+            const f32x4 wb = {f.w[4][c], f.w[5][c], f.w[6][c], f.w[7][c]};
+            const Split3 W = split8(wa, wb);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                acc[c][mt] = mfma_bf16(W.mid, X[mt].mid, acc[c][mt]);
+                acc[c][mt] = mfma_bf16(W.lo, X[mt].hi, acc[c][mt]);
+                acc[c][mt] = mfma_bf16(W.hi, X[mt].lo, acc[c][mt]);
+                acc[c][mt] = mfma_bf16(W.mid, X[mt].hi, acc[c][mt]);
+                acc[c][mt] = mfma_bf16(W.hi, X[mt].mid, acc[c][mt]);
+                acc[c][mt] = mfma_bf16(W.hi, X[mt].hi, acc[c][mt]);
+            }
+        }
+    };
+
+    NNFrag2<MT> ring[D];
+    if (n2 >= D) {
+#pragma unroll
+        for (int t = 0; t < D - 1; ++t) load2(ring[t]);
+        int j = 0;
+        for (; j + 2 * D - 1 <= n2; j += D) {
+#pragma unroll
+            for (int t = 0; t < D; ++t) {
+                load2(ring[(t + D - 1) % D]);
+                __builtin_amdgcn_sched_barrier(0);            // requests first (the scheduler would sink them behind the MFMAs)
+                mma2(ring[t]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < D; ++t) {
+            if (j + t + D - 1 < n2) load2(ring[(t + D - 1) % D]);
+            if (j + t < n2) mma2(ring[t]);
+        }
+#pragma unroll
+        for (int t = 0; t < D - 1; ++t)
+            if (j + D + t < n2) mma2(ring[t]);
+    } else {
+        for (int j = 0; j < n2; ++j) {
+            load2(ring[0]);
+            mma2(ring[0]);
+        }
+    }
+    if (n_my & 1) {                                           // odd last group: exact fp32 products on the fp32 MFMA
+        f32x4 w[4], x[MT];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = ld4(wp[e]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) x[mt] = ld4(xp + mt * 128);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[c][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e][c], x[mt][e], acc[c][mt], 0, 0, 0);
+    }
+
+    // ---- cross-wave sum and store: identical to skinny_gemm_nn_kernel
+    float* const planeA = red;
+    float* const planeB = red + 128 * LDM;
+    auto put = [&](float* plane) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    plane[(4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + c) * LDM + mt * 32 + i] = acc[c][mt][r];
+    };
+    auto add = [&](const float* plane) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x16 t;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[r] = plane[(4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + c) * LDM + mt * 32 + i];
+                acc[c][mt] += t;
+            }
+    };
+    if (wave == 2) put(planeA);
+    if (wave == 3) put(planeB);
+    __syncthreads();
+    if (wave == 0) add(planeA);
+    if (wave == 1) { add(planeB); put(planeB); }
+    __syncthreads();
+    if (wave == 0) { add(planeB); put(planeA); }
+    __syncthreads();
+
+    const int M = a.M;
+    float* out;
+    size_t ld;
+    int cbase;
+    if (a.ksplit > 1) {
+        out = a.part + (size_t)kslice * M * a.ntot;
+        ld = (size_t)a.ntot;
+        cbase = sg.slab0 * 128 + n0;
+    } else {
+        out = sg.dst;
+        ld = (size_t)sg.ld_dst;
+        cbase = n0;
+    }
+    const int nvalid = sg.ncols - n0 < 128 ? sg.ncols - n0 : 128;
+    for (int u = tid; u < 128 * MT * 32; u += NW * 64) {
+        const int nl = u & 127, m = u >> 7;
+        if (m >= M || nl >= nvalid) continue;
+        out[(size_t)m * ld + cbase + nl] = red[nl * LDM + m];
+    }
+}
+
 // dst[seg][m][n] = sum over planes, fixed order
 __global__ __launch_bounds__(256) void nn_reduce_kernel(NNArgs a) {
     const int m = blockIdx.y;
@@ -251,7 +441,10 @@ extern "C" int cvc_linear_nn_fwd(const float* dy_q, int K, int M, const cvc_nn_s
     a.ntot = slab * 128;
     if (ksplit > 1 && !workspace) return CVC_E_BADARG;
     const dim3 grid(slab * ksplit);
-    if (M <= 32) hipLaunchKernelGGL((skinny_gemm_nn_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (cvc_gemm_split_mode != 0) {
+        if (M <= 32) hipLaunchKernelGGL((skinny_gemm_nn_split_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((skinny_gemm_nn_split_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    } else if (M <= 32) hipLaunchKernelGGL((skinny_gemm_nn_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((skinny_gemm_nn_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, a);
     if (ksplit > 1)
         hipLaunchKernelGGL(nn_reduce_kernel, dim3((a.ntot / 4 + 255) / 256, M), dim3(256), 0, (hipStream_t)stream, a);

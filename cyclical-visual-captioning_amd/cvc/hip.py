@@ -284,10 +284,19 @@ def linear_fwd(segs: Sequence[dict], bias: Optional[torch.Tensor], M: int, Nout:
     return y
 
 
+_split_mode_cache = None
+
+
 def gemm_packed_split(mode: int) -> int:
     """Packed decode GEMMs: 0 = plain fp32 MFMA, 1 = bf16x3-split products on the bf16 MFMA with 4 waves per
-    workgroup, 2 = the same with 8 waves (two per SIMD).  -> previous setting"""
-    return int(lib().cvc_gemm_packed_split(int(mode)))
+    workgroup, 2 = the same with 8 waves (two per SIMD).  -> previous setting.  A negative mode only queries (cached on the
+    host: the backward pass asks once per LSTM step)."""
+    global _split_mode_cache
+    if mode < 0 and _split_mode_cache is not None:
+        return _split_mode_cache
+    prev = int(lib().cvc_gemm_packed_split(int(mode)))
+    _split_mode_cache = prev if mode < 0 else (2 if mode > 2 else int(mode))
+    return prev
 
 
 def gemm_force_generic(on: bool) -> bool:
@@ -339,7 +348,9 @@ def linear_nn(dy_q, M, K, ranges, ksplit=None):
     # K slices: one resident round of workgroups (the kernel fits two per CU = 512 on the chip) and >= 16 8-row
     # groups per wave in every slice
     if ksplit is None:
-        ksplit = max(1, min(K // 8 // 64, 512 // slabs))
+        # the split-product kernel holds one workgroup per CU (256 on the chip), the fp32-MFMA kernel two
+        resident = 256 if gemm_packed_split(-1) != 0 else 512
+        ksplit = max(1, min(K // 8 // 64, resident // slabs))
     ws = torch.empty(ksplit * M * slabs * 128, device=dy_q.device, dtype=torch.float32) if ksplit > 1 else None
     _check(lib().cvc_linear_nn_fwd(_dev(dy_q), K, M, arr, len(ranges), ksplit, _dev(ws), _stream()), "cvc_linear_nn_fwd")
     return outs
