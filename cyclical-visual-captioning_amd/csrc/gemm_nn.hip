@@ -418,7 +418,24 @@ __global__ __launch_bounds__(256) void nn_reduce_kernel(NNArgs a) {
     st4(sg.dst + (size_t)m * sg.ld_dst + n, v);
 }
 
+// row-major [M <= 64, K] -> quad layout [K/4][64][4] (rows beyond M zero): the dY operand of cvc_linear_nn_fwd for layers whose
+// upstream gradient arrives row-major (nn.Linear backward; the LSTM cells get theirs from cvc_lstm_pointwise_bwd)
+__global__ __launch_bounds__(256) void pack_quad_kernel(const float* x, long long ldx, int M, int K, float* xq) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int m = t & 63, q = t >> 6;
+    if (q >= (K >> 2)) return;
+    f32x4 v = {0, 0, 0, 0};
+    if (m < M) v = ld4(x + (size_t)m * ldx + q * 4);
+    st4(xq + ((size_t)q * 64 + m) * 4, v);
+}
+
 }  // namespace
+
+extern "C" int cvc_pack_quad(const float* x, long long ldx, int M, int K, float* xq, cvc_stream_t stream) {
+    if (!x || !xq || M < 1 || M > 64 || K < 4 || (K & 3) || (ldx & 3) || ((uintptr_t)x & 15)) return CVC_E_BADARG;
+    hipLaunchKernelGGL(pack_quad_kernel, dim3((K / 4 * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, ldx, M, K, xq);
+    return cvc_launch_status();
+}
 
 extern "C" int cvc_linear_nn_fwd(const float* dy_q, int K, int M, const cvc_nn_seg* segs, int nsegs, int ksplit,
                                  float* workspace, cvc_stream_t stream) {

@@ -317,6 +317,57 @@ __global__ __launch_bounds__(256) void tile_pack_rows_kernel(const float* x, int
     store_frag4(xb, mblk_stride, m, k, v);
 }
 
+
+// fp32 row-major [M, K], ANY K (scalar, bounds-checked loads; the k tail of the last 16-step is zero) -> activation fragments
+__global__ __launch_bounds__(256) void tile_pack_rows_any_kernel(const float* x, long long ldx, int M, int K, uint16_t* xb,
+                                                                 long long mblk_stride) {
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int nq = (K + 3) >> 2;
+    if (q >= (long long)M * nq) return;
+    const int m = (int)(q / nq), k = (int)(q - (long long)m * nq) * 4;
+    f32x4 v = {0, 0, 0, 0};
+    const float* src = x + (size_t)m * ldx + k;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (k + e < K) v[e] = src[e];
+    store_frag4(xb, mblk_stride, m, k, v);
+}
+
+// fp32 row-major [S, C] read as its transpose: fragment rows = the C columns, contraction index = the S rows (dW = dY^T X and
+// dX = dY W need one operand this way).  One wave per 32 columns x 16 rows: coalesced 128-byte row reads into a padded LDS
+// tile, then lane (k half, column) gathers its 8 rows and writes 16 bytes per term.  Any S, C (zero fill).
+__global__ __launch_bounds__(256) void tile_pack_cols_kernel(const float* x, long long ldx, int S, int C, uint16_t* xb,
+                                                             long long mblk_stride) {
+    __shared__ float tile[4][16][33];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cb = blockIdx.x;                                   // 32-column block
+    const int ks = blockIdx.y * 4 + wave;                        // k step of 16 rows
+    const int nks = (S + 15) >> 4;
+    if (ks < nks) {
+        const int c = lane & 31;
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            const int r = (lane >> 5) + 2 * h;
+            const int s = ks * 16 + r, col = cb * 32 + c;
+            tile[wave][r][c] = (s < S && col < C) ? x[(size_t)s * ldx + col] : 0.f;
+        }
+    }
+    __syncthreads();
+    if (ks >= nks) return;
+    const int kh = lane >> 5, i = lane & 31;
+    using u16x8 = __attribute__((ext_vector_type(8))) uint16_t;
+    u16x8 p[3];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        uint16_t h, mi, l;
+        split3(tile[wave][kh * 8 + e][i], h, mi, l);
+        p[0][e] = h; p[1][e] = mi; p[2][e] = l;
+    }
+    uint16_t* base = xb + (size_t)cb * mblk_stride + (size_t)ks * KSTEP + (kh * 32 + i) * 8;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u16x8*>(base + pl * FRAG) = p[pl];
+}
+
 // After word / beam selection of step t: row r of step t + 1 continues hypothesis src = (r / beam) * beam + parent[r]
 // (parent == nullptr: r itself).  Builds, in one pass over the four state tensors, everything step t + 1 reads:
 //   c_att_prev / c_lang_prev [rows, R]  <- c_att / c_lang [src]
@@ -435,6 +486,23 @@ extern "C" int cvc_tile_pack_rows(const float* x, int ldx, const int64_t* idx, i
     const long long n = (long long)M * (K / 4);
     hipLaunchKernelGGL(tile_pack_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, idx, relu,
                        M, K, (uint16_t*)xb, x_mblk_stride);
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_tile_pack_rows_any(const float* x, long long ldx, int M, int K, void* xb, long long x_mblk_stride,
+                                      cvc_stream_t stream) {
+    if (!x || !xb || M < 1 || K < 1 || ldx < K || (x_mblk_stride & 7)) return CVC_E_BADARG;
+    const long long n = (long long)M * ((K + 3) / 4);
+    hipLaunchKernelGGL(tile_pack_rows_any_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, M, K,
+                       (uint16_t*)xb, x_mblk_stride);
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_tile_pack_cols(const float* x, long long ldx, int S, int C, void* xb, long long x_mblk_stride,
+                                  cvc_stream_t stream) {
+    if (!x || !xb || S < 1 || C < 1 || ldx < C || (x_mblk_stride & 7)) return CVC_E_BADARG;
+    const dim3 g((C + 31) / 32, ((S + 15) / 16 + 3) / 4);
+    hipLaunchKernelGGL(tile_pack_cols_kernel, g, dim3(256), 0, (hipStream_t)stream, x, ldx, S, C, (uint16_t*)xb, x_mblk_stride);
     return cvc_launch_status();
 }
 

@@ -1,8 +1,8 @@
 """Autograd-aware ops of the caption-decode hot path, each backed by the HIP kernels in
-libcvc_hip.so (cvc.hip).  Forward passes and the fused / recomputing backward passes are
-hand-written kernels (including the LSTM cells' backward-data product dX = dY W, csrc/gemm_nn.hip); the
-remaining plain dense GEMMs of the backward (dW = dY^T X batched over all T steps, the M = B*T dX of the
-vocabulary head) go to the vendor library through torch.mm (hipBLASLt), which is what those are for.
+libcvc_hip.so (cvc.hip).  Forward passes, the fused / recomputing backward passes, the LSTM cells' backward-data
+product dX = dY W (csrc/gemm_nn.hip) and the dense products of the backward (dW = dY^T X batched over all T steps,
+the M = B*T dX of the vocabulary head: cvc.hip.tile_mm on csrc/gemm_tile.hip) are hand-written kernels; no library
+GEMM is on the training path (the grounder's backward, which the reference's objective never reaches, is the exception).
 
 No CPU path: every op raises if handed CPU tensors (cvc.hip._dev).
 """
@@ -74,6 +74,23 @@ class _WeightGradBatcher:
 _BATCHER = _WeightGradBatcher()
 
 
+def _mm_tn(d: Tensor, x: Tensor) -> Tensor:
+    """dW = d^T x  ([S, N]^T [S, K] -> [N, K]): contraction over the S = T*B sample rows, on the tile GEMM."""
+    return hip.tile_mm(d, x, a_kmajor=True, b_kmajor=True)
+
+
+def _mm_nn(dy: Tensor, w: Tensor) -> Tensor:
+    """dX = dy w  ([M, N] [N, K] -> [M, K]; w may be a column slice of a wider matrix).  Up to 64 rows: the weight-streaming
+    backward-data kernel (csrc/gemm_nn.hip, weights read in place, dY repacked into its quad layout by one small launch);
+    more rows, or shapes that kernel does not take: the tile GEMM."""
+    M, N = dy.shape
+    if M <= 64 and dy.stride(1) == 1 and dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0 and N % 8 == 0:
+        seg = (w, 0, w.shape[1])
+        if hip.linear_nn_ok(M, N, [seg]):
+            return hip.linear_nn(hip.pack_quad(dy), M, N, [seg])[0]
+    return hip.tile_mm(dy, w, b_kmajor=True)
+
+
 # ------------------------------------------------------------------------------- linear
 class _Linear(torch.autograd.Function):
     """y = cat(xs) W^T + b with the concat virtual (nn.Linear over torch.cat)."""
@@ -106,7 +123,7 @@ class _Linear(torch.autograd.Function):
             def flush(items):
                 D = torch.cat([i[0] for i in items], 0) if len(items) > 1 else items[0][0]
                 X = torch.cat([i[1] for i in items], 0) if len(items) > 1 else items[0][1]
-                return torch.mm(D.t(), X), (D.sum(0) if ctx.has_bias else None)
+                return _mm_tn(D, X), (D.sum(0) if ctx.has_bias else None)
 
             res = _BATCHER.add(ctx.key, (dy, x), (weight, bias), flush)
             if res is not None:
@@ -118,7 +135,7 @@ class _Linear(torch.autograd.Function):
         d_xs, k0 = [], 0
         for i, x in enumerate(xs):
             k = x.shape[1]
-            d_xs.append(torch.mm(dy, weight[:, k0:k0 + k]) if ctx.needs_input_grad[2 + i] else None)
+            d_xs.append(_mm_nn(dy, weight[:, k0:k0 + k]) if ctx.needs_input_grad[2 + i] else None)
             k0 += k
         return (d_w, d_b, *d_xs)
 
@@ -184,25 +201,26 @@ class _LstmCell(torch.autograd.Function):
                 cols = [torch.cat([i[2 + k] for i in items], 0) if len(items) > 1 else items[0][2 + k] for k in range(nseg)]
                 X = torch.cat(cols, 1) if nseg > 1 else cols[0]
                 db = D.sum(0)
-                return torch.mm(D.t(), X), torch.mm(D.t(), Hp), db, db
+                Dp = hip.TileOperand(D, kmajor=True)                    # dY^T packed once for both weight matrices
+                return hip.tile_mm(Dp, X, b_kmajor=True), hip.tile_mm(Dp, Hp, b_kmajor=True), db, db
 
             res = _BATCHER.add(ctx.key, (d_gates, h_prev, *xs), (w_ih, w_hh, b_ih, b_hh), flush)
             if res is not None:
                 d_w_ih, d_w_hh, d_b, _ = res
         else:
-            d_w_ih = torch.mm(d_gates.t(), torch.cat(xs, 1) if len(xs) > 1 else xs[0]) if ni[0] else None
-            d_w_hh = torch.mm(d_gates.t(), h_prev) if ni[1] else None
+            d_w_ih = _mm_tn(d_gates, torch.cat(xs, 1) if len(xs) > 1 else xs[0]) if ni[0] else None
+            d_w_hh = _mm_tn(d_gates, h_prev) if ni[1] else None
             d_b = d_gates.sum(0) if (ni[2] or ni[3]) else None
         if use_nn:                      # every needed dX from one pass over the weights (csrc/gemm_nn.hip)
             got = iter(hip.linear_nn(pw[2], M, K, ranges))
             d_h_prev = next(got) if ni[4] else None
             d_xs = [next(got) if ni[6 + i] else None for i in range(len(xs))]
         else:                           # widths the kernel does not take (not multiples of 4): library GEMM
-            d_h_prev = torch.mm(d_gates, w_hh) if ni[4] else None
+            d_h_prev = _mm_nn(d_gates, w_hh) if ni[4] else None
             d_xs, k0 = [], 0
             for i, x in enumerate(xs):
                 k = x.shape[1]
-                d_xs.append(torch.mm(d_gates, w_ih[:, k0:k0 + k]) if ni[6 + i] else None)
+                d_xs.append(_mm_nn(d_gates, w_ih[:, k0:k0 + k]) if ni[6 + i] else None)
                 k0 += k
         return (d_w_ih, d_w_hh, d_b if ni[2] else None, d_b if ni[3] else None, d_h_prev,
                 d_c_prev if ni[5] else None, *d_xs)

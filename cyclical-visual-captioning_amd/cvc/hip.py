@@ -77,6 +77,7 @@ SIGNATURES = {
     "cvc_lstm_cell_fwd": [C.POINTER(GemmSeg), _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "cvc_lstm_pointwise_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "cvc_linear_nn_fwd": [_P, _I, _I, C.POINTER(NNSeg), _I, _I, _P, _P],
+    "cvc_pack_quad": [_P, _LL, _I, _I, _P, _P],
     "cvc_embed_relu_fwd": [_P, _P, _P, _I, _I, _P, _P],
     "cvc_embed_relu_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     "cvc_log_softmax_fwd": [_P, _I, _I, _P, _P],
@@ -95,6 +96,8 @@ SIGNATURES = {
     "cvc_tile_lstm_finish": [_P, _I, _LL, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _LL, _P, _LL, _P],
     "cvc_tile_linear_finish": [_P, _I, _LL, _I, _P, _P, _I, _I, _P, _I, _P],
     "cvc_tile_pack_rows": [_P, _I, _P, _I, _I, _I, _P, _LL, _P],
+    "cvc_tile_pack_rows_any": [_P, _LL, _I, _I, _P, _LL, _P],
+    "cvc_tile_pack_cols": [_P, _LL, _I, _I, _P, _LL, _P],
     "cvc_tile_reorder_pack": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _LL, _P, _LL, _I, _I, _P],
     "cvc_attn_wsum_frag": [C.POINTER(AttnSet), _I, _I, _I, _I, _P, _LL, _P],
     "cvc_decode_plan_create": [C.POINTER(DecodeDesc), C.POINTER(C.c_void_p)],
@@ -333,6 +336,14 @@ def linear_nn_ok(M, K, ranges):
         for (w, c0, n) in ranges)
 
 
+def pack_quad(x: torch.Tensor) -> torch.Tensor:
+    """[M <= 64, K] row-major -> [K/4][64][4] (linear_nn's dY layout)."""
+    M, K = x.shape
+    xq = torch.empty(K // 4, 64, 4, device=x.device, dtype=torch.float32)
+    _check(lib().cvc_pack_quad(_dev(x), x.stride(0), M, K, _dev(xq), _stream()), "cvc_pack_quad")
+    return xq
+
+
 def linear_nn(dy_q, M, K, ranges, ksplit=None):
     """dX_s[M, n_s] = dY[M, K] @ W_s[:, c0_s : c0_s + n_s] for every (W_s, c0_s, n_s) in `ranges`, one launch.
     dy_q: dY in the quad layout [K/4][64][4] (lstm_pointwise_bwd(want_quad=True))."""
@@ -495,3 +506,47 @@ def tile_pack_rows(x: torch.Tensor, xb: torch.Tensor, k0: int = 0, idx: Optional
     _check(lib().cvc_tile_pack_rows(_dev(x), x.stride(0), _dev(idx, torch.int64), 1 if relu else 0, M, K, xp, xs, _stream()),
            "cvc_tile_pack_rows")
     return xb
+
+
+class TileOperand:
+    """One operand of tile_mm, packed once into bf16 split-term fragments (reusable as either side of several products)."""
+
+    def __init__(self, t: torch.Tensor, kmajor: bool = False):
+        """t is [rows, K], or [K, rows] with kmajor (read as its transpose).  Unit inner stride; any sizes."""
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise RuntimeError("cvc.hip: tile_mm operands must be fp32 GPU tensors (no CPU fallback)")
+        if t.dim() != 2:
+            raise RuntimeError("cvc.hip: tile_mm operands are matrices")
+        if t.stride(1) != 1:
+            t = t.contiguous()
+        self.rows, self.K = (t.shape[1], t.shape[0]) if kmajor else (t.shape[0], t.shape[1])
+        rows_alloc = max(tile_rows_alloc(self.rows), (self.rows + 127) // 128 * 128)
+        self.frags = torch.zeros(rows_alloc // 32, (self.K + 15) // 16, 3, 2, 32, 8, dtype=torch.int16, device=t.device)
+        self.ptr, self.stride = _frag_ptr(self.frags)
+        L = lib()
+        if kmajor:
+            _check(L.cvc_tile_pack_cols(t.data_ptr(), t.stride(0), self.K, self.rows, self.ptr, self.stride, _stream()), "cvc_tile_pack_cols")
+        else:
+            _check(L.cvc_tile_pack_rows_any(t.data_ptr(), t.stride(0), self.rows, self.K, self.ptr, self.stride, _stream()),
+                   "cvc_tile_pack_rows_any")
+
+
+def tile_mm(a, b, a_kmajor: bool = False, b_kmajor: bool = False) -> torch.Tensor:
+    """C[M, N] = sum_k A[m, k] B[n, k] on the tile GEMM (split products on the bf16 MFMA, fp32 accumulate, fp32-grade error):
+    the dense products of the backward pass -- no library GEMM.  `a` is [M, K], or [K, M] with a_kmajor (read as its transpose);
+    `b` is [N, K], or [K, N] with b_kmajor; either may be a TileOperand packed earlier (shared operands are packed once)."""
+    A = a if isinstance(a, TileOperand) else TileOperand(a, a_kmajor)
+    B = b if isinstance(b, TileOperand) else TileOperand(b, b_kmajor)
+    assert A.K == B.K, (A.rows, A.K, B.rows, B.K)
+    M, N, L, st = A.rows, B.rows, lib(), _stream()
+    Kp = (A.K + 15) // 16 * 16
+    ntile, chunks = (N + 127) // 128, (tile_rows_alloc(M) + 319) // 320
+    ks = max(1, min(256 // max(1, ntile * chunks), (Kp // 16) // 8))
+    out = torch.empty(M, N, device=A.frags.device, dtype=torch.float32)
+    if ks == 1:
+        _check(L.cvc_tile_gemm(B.ptr, A.ptr, A.stride, Kp, M, N, 1, out.data_ptr(), N, M * N, st), "cvc_tile_gemm")
+        return out
+    parts = torch.empty(ks, M, N, device=out.device, dtype=torch.float32)
+    _check(L.cvc_tile_gemm(B.ptr, A.ptr, A.stride, Kp, M, N, ks, parts.data_ptr(), N, M * N, st), "cvc_tile_gemm")
+    _check(L.cvc_tile_linear_finish(parts.data_ptr(), ks, M * N, N, None, None, M, N, out.data_ptr(), N, st), "cvc_tile_linear_finish")
+    return out

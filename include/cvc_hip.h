@@ -207,6 +207,8 @@ typedef struct cvc_nn_seg {
 } cvc_nn_seg;
 int cvc_linear_nn_fwd(const float* dy_q, int K, int M, const cvc_nn_seg* segs, int nsegs, int ksplit,
                       float* workspace, cvc_stream_t stream);
+/* x [M <= 64, K] row-major (leading dim ldx) -> the quad layout [K/4][64][4] cvc_linear_nn_fwd reads (rows beyond M zero) */
+int cvc_pack_quad(const float* x, long long ldx, int M, int K, float* xq, cvc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Word embedding and vocabulary head (captioner.py:53-68, 72-76, 266, 415-422).
@@ -314,6 +316,12 @@ int cvc_tile_linear_finish(const float* parts, int nparts, long long part_stride
 /* fp32 rows (optionally gathered through idx, optionally ReLU'd) -> activation fragments */
 int cvc_tile_pack_rows(const float* x, int ldx, const int64_t* idx, int relu, int M, int K, void* xb,
                        long long x_mblk_stride, cvc_stream_t stream);
+/* Operand packers for the dense backward products (autograd of nn.Linear / nn.LSTMCell: dW = dY^T X batched over all T steps,
+ * dX = dY W of the vocabulary head; reference decoder_core.py:50,61, captioner.py:266,361): any sizes, zero fill.
+ * cvc_tile_pack_rows_any: x [M, K] row-major -> fragments with rows m, contraction k (k padded to a multiple of 16).
+ * cvc_tile_pack_cols:     x [S, C] row-major read as its transpose -> fragments with rows c, contraction s. */
+int cvc_tile_pack_rows_any(const float* x, long long ldx, int M, int K, void* xb, long long x_mblk_stride, cvc_stream_t stream);
+int cvc_tile_pack_cols(const float* x, long long ldx, int S, int C, void* xb, long long x_mblk_stride, cvc_stream_t stream);
 /* Beam-state reorder fused with next step's operand packing: row r continues hypothesis (r / beam) * beam + parent[r]
  * (parent NULL: r).  c_*_prev[r] = c_*[src]; xa = [h_lang[src] | relu(table[word[r]]) | h_att[src]] as fragments (K = 2R + E,
  * decoder_core.py:45-48 without the hoisted fc segment); xl_hlang (lang-LSTM input, third K segment) = h_lang[src]. */

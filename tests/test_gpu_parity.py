@@ -453,6 +453,30 @@ def test_tile_gemm_vs_fp64(dev, lib, M, K, N, ksplit):
         assert torch.equal(lib.tile_gemm(wb, xw, 32, K, M, N, ksplit), parts)
 
 
+@pytest.mark.parametrize("M,N,K,ak,bk", [(8192, 5120, 2560, True, True), (1280, 2048, 5000, False, True), (50, 16, 12, True, True),
+                                          (3, 70, 37, False, False), (1280, 1024, 2048, False, True), (200, 130, 1, True, False)])
+def test_tile_mm_backward_products_vs_fp64(dev, lib, M, N, K, ak, bk):
+    """cvc.hip.tile_mm: C = A B^T with either operand given transposed (the training pass's dW = dY^T X over T*B rows, the
+    vocabulary head's dX over V = 5000 columns, odd little shapes): operands packed by the transposing / any-size packers,
+    product on the tile GEMM, error against fp64 no worse than an fp32 GEMM's."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(*((K, M) if ak else (M, K)), generator=g).to(dev)
+    b = torch.randn(*((K, N) if bk else (N, K)), generator=g).to(dev)
+    c = lib.tile_mm(a, b, a_kmajor=ak, b_kmajor=bk)
+    A, B = (a.t() if ak else a), (b.t() if bk else b)
+    ref = A.double() @ B.double().t()
+    err = float((c.double() - ref).norm() / ref.norm())
+    err32 = float(((A @ B.t()).double() - ref).norm() / ref.norm())
+    assert c.shape == (M, N) and err <= max(2.0 * err32, 4e-7), (err, err32)
+    # operands that are column slices of wider matrices (a weight's K segment) and a packed operand used twice
+    if N >= 64:
+        wide = torch.randn(b.shape[0], b.shape[1] + 24, generator=g).to(dev)
+        sl = wide[:, 8:8 + b.shape[1]]
+        close(lib.tile_mm(a, sl, a_kmajor=ak, b_kmajor=bk), (A.double() @ (sl.t() if bk else sl).double().t()).float(), rtol=1e-4, atol=1e-4 * K ** 0.5)
+        Ap = lib.TileOperand(a, kmajor=ak)
+        assert torch.equal(lib.tile_mm(Ap, b, b_kmajor=bk), c) and torch.equal(lib.tile_mm(Ap, b, b_kmajor=bk), c)
+
+
 @pytest.mark.parametrize("M,R,beam,nparts", [(320, 2048, 5, 4), (70, 32, 1, 2), (15, 48, 3, 1)])
 def test_tile_lstm_finish_and_reorder_pack(dev, lib, M, R, beam, nparts):
     """The tile path's LSTM epilogue (slab sum + biases + per-clip gate term + cell update, h' as fragments) and the
