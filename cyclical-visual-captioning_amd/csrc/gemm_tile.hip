@@ -119,8 +119,10 @@ __global__ __launch_bounds__(512) void tile_gemm_kernel(TileArgs a) {
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+#if !defined(CVC_TILE_ABL) || (CVC_TILE_ABL != 5 && CVC_TILE_ABL < 6)
         __builtin_amdgcn_s_barrier();           // every wave's copies of stage s are in LDS; stage s - 1 has been read by all
-#if !defined(CVC_TILE_ABL) || CVC_TILE_ABL != 2
+#endif
+#if !defined(CVC_TILE_ABL) || CVC_TILE_ABL < 2 || CVC_TILE_ABL == 3
         if (s + 2 < nst) issue(s + 2, buf == 0 ? 2 : buf - 1);
 #else
         if (s + 2 < nst && extra) asm volatile("s_nop 0");    // ablation 2: no copies after the prologue (compute side only)
@@ -129,6 +131,42 @@ __global__ __launch_bounds__(512) void tile_gemm_kernel(TileArgs a) {
         auto frag = [&](int f) __attribute__((always_inline)) { return *reinterpret_cast<const u32x4*>(base + f * 1024); };
         // fragment reads of tile t + 1 are issued before the six MFMAs of tile t, so that LDS latency runs under the matrix pipe
         u32x4 w[3], x[2][3];
+#if defined(CVC_TILE_ABL) && (CVC_TILE_ABL == 4 || CVC_TILE_ABL >= 6)
+        // ablation 4 / 6: fragment reads only in the first stage (matrix pipe + barrier only)
+        const char* base0 = lds + lane * 16;
+        auto frag0 = [&](int f) __attribute__((always_inline)) { return *reinterpret_cast<const u32x4*>(base0 + (s == 0 ? f : 0) * 1024); };
+        if (s == 0) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) { w[pl] = frag0(wbk * 3 + pl); x[0][pl] = frag0(12 + pl); x[1][pl] = frag0(15 + pl); }
+        }
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) { asm volatile("" : "+v"(w[pl]), "+v"(x[0][pl]), "+v"(x[1][pl])); }
+#if CVC_TILE_ABL == 8
+        // ablation 8: the six terms outermost -> consecutive MFMAs hit different accumulators
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+            for (int t = 0; t < MH; ++t) {
+                const u32x4* xt = x[t & 1];
+                const int xi = term == 0 ? 1 : (term == 2 ? 2 : (term == 4 ? 1 : 0));
+                const int wi = term == 0 ? 1 : (term == 1 ? 2 : (term == 3 ? 1 : 0));
+                acc[t] = mfma_bf16(xt[xi], w[wi], acc[t]);
+            }
+#else
+#pragma unroll
+        for (int t = 0; t < MH; ++t) {
+            const u32x4* xt = x[t & 1];
+            acc[t] = mfma_bf16(xt[1], w[1], acc[t]);
+            acc[t] = mfma_bf16(xt[0], w[2], acc[t]);
+            acc[t] = mfma_bf16(xt[2], w[0], acc[t]);
+            acc[t] = mfma_bf16(xt[0], w[1], acc[t]);
+            acc[t] = mfma_bf16(xt[1], w[0], acc[t]);
+            acc[t] = mfma_bf16(xt[0], w[0], acc[t]);
+        }
+#endif
+        buf = buf == 2 ? 0 : buf + 1;
+        continue;
+#endif
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) { w[pl] = frag(wbk * 3 + pl); x[0][pl] = frag(12 + (mh * MH) * 3 + pl); }
 #pragma unroll
@@ -174,9 +212,126 @@ __global__ __launch_bounds__(512) void tile_gemm_kernel(TileArgs a) {
     float* out = a.parts + (size_t)ks * a.part_stride;
     const int n = (tile * 4 + wbk) * 32 + (lane & 31);
     const int kh = lane >> 5;
-#if defined(CVC_TILE_ABL) && CVC_TILE_ABL == 3
-    if (acc[0][0] == 12345.678f)                              // ablation 3: no epilogue stores
+#if defined(CVC_TILE_ABL) && (CVC_TILE_ABL == 3 || CVC_TILE_ABL == 7)
+    if (acc[0][0] == 12345.678f)                              // ablation 3 / 7: no epilogue stores
 #endif
+    if (n < a.N) {
+#pragma unroll
+        for (int t = 0; t < MH; ++t) {
+            const int mbase = (mb0 + mh * MH + t) * 32 + 4 * kh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                if (m < a.M) out[(size_t)m * a.ld + n] = acc[t][r];
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Loader / consumer variant: the LDS-DMA copies are issued by NL extra waves that do nothing else, the eight computing waves
+// only read fragments and issue MFMAs.  Why: ablations of tile_gemm_kernel at 320 x 6144 x 8192 -- compute side alone (no
+// copies) 143 us, memory side alone 92 us, together 190 us: the sides do not overlap because a wave that issues its share of
+// the copies (6 x global_load_lds, ~100-180 issue cycles each next to LDS reads) cannot issue MFMAs meanwhile, and that is as
+// long as the stage's matrix work (960 cycles per wave).  Same ring, same one barrier per k step, counted vmcnt in the loaders.
+template <int MH, int NL>
+__global__ __launch_bounds__((8 + NL) * 64) void tile_gemm_ld_kernel(TileArgs a) {
+    constexpr int NX = 2 * MH;
+    constexpr int NF = (4 + NX) * 3;
+    constexpr int STAGE = NF * 1024;
+    constexpr int NSTAGE = 3;
+    __shared__ __attribute__((aligned(16))) char lds[NSTAGE * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile = (int)blockIdx.x % a.ntile, ks = (int)blockIdx.x / a.ntile;
+    if (a.ksplit > 1 && a.ksplit <= 8 && 8 % a.ksplit == 0 && a.ntile % (8 / a.ksplit) == 0) {
+        const int g = 8 / a.ksplit, xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+        ks = xcd / g;
+        tile = j * g + xcd % g;
+    }
+    const int mb0 = (int)blockIdx.y * NX;
+    const int s_lo = (int)((long long)a.ksteps * ks / a.ksplit), s_hi = (int)((long long)a.ksteps * (ks + 1) / a.ksplit);
+    const int nst = s_hi - s_lo;
+
+    if (wave >= 8) {
+        // ---------------- loader wave: fragments f = lw + NL j of every stage
+        const int lw = wave - 8;
+        constexpr int NDLO = NF / NL, NEXTRA = NF % NL, ND = NDLO + (NEXTRA ? 1 : 0);
+        const bool extra = NEXTRA != 0 && lw < NEXTRA;
+        const uint16_t* src[ND];
+        int dst[ND];
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            int f = lw + NL * j;
+            if (f >= NF) f -= NF;
+            const int g = f < 12 ? f : f - 12;
+            const int blk = g / 3, pl = g - blk * 3;
+            if (f < 12) src[j] = a.wb + ((size_t)(tile * 4 + blk) * a.ksteps + s_lo) * KSTEP + pl * FRAG + lane * 8;
+            else src[j] = a.xb + (size_t)(mb0 + blk) * a.x_mblk_stride + (size_t)s_lo * KSTEP + pl * FRAG + lane * 8;
+            dst[j] = f * 1024;
+        }
+        auto issue = [&](int s, int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < NDLO; ++j)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[j] + (size_t)s * KSTEP), (lds_ptr_t)(lds + buf * STAGE + dst[j]), 16, 0, 0);
+            if constexpr (NEXTRA != 0)
+                if (extra)
+                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[NDLO] + (size_t)s * KSTEP), (lds_ptr_t)(lds + buf * STAGE + dst[NDLO]), 16, 0, 0);
+        };
+        if (nst > 0) issue(0, 0);
+        if (nst > 1) issue(1, 1);
+        int buf = 0;
+        for (int s = 0; s < nst; ++s) {
+            if (s + 1 < nst) {
+                if (extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDLO + 1) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDLO) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();       // stage s is in LDS (all loaders waited); stage s - 1 has been read by all
+            if (s + 2 < nst) issue(s + 2, buf == 0 ? 2 : buf - 1);
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+        return;
+    }
+
+    // ---------------- computing wave
+    const int wbk = wave & 3, mh = wave >> 2;
+    f32x16 acc[MH];
+#pragma unroll
+    for (int t = 0; t < MH; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    int buf = 0;
+    for (int s = 0; s < nst; ++s) {
+        __builtin_amdgcn_s_barrier();
+        const char* base = lds + buf * STAGE + lane * 16;
+        auto frag = [&](int f) __attribute__((always_inline)) { return *reinterpret_cast<const u32x4*>(base + f * 1024); };
+        u32x4 w[3], x[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) { w[pl] = frag(wbk * 3 + pl); x[0][pl] = frag(12 + (mh * MH) * 3 + pl); }
+#pragma unroll
+        for (int t = 0; t < MH; ++t) {
+            if (t + 1 < MH) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) x[(t + 1) & 1][pl] = frag(12 + (mh * MH + t + 1) * 3 + pl);
+            }
+            const u32x4* xt = x[t & 1];
+            __builtin_amdgcn_sched_barrier(0);
+            acc[t] = mfma_bf16(xt[1], w[1], acc[t]);
+            acc[t] = mfma_bf16(xt[0], w[2], acc[t]);
+            acc[t] = mfma_bf16(xt[2], w[0], acc[t]);
+            acc[t] = mfma_bf16(xt[0], w[1], acc[t]);
+            acc[t] = mfma_bf16(xt[1], w[0], acc[t]);
+            acc[t] = mfma_bf16(xt[0], w[0], acc[t]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        buf = buf == 2 ? 0 : buf + 1;
+    }
+    float* out = a.parts + (size_t)ks * a.part_stride;
+    const int n = (tile * 4 + wbk) * 32 + (lane & 31);
+    const int kh = lane >> 5;
     if (n < a.N) {
 #pragma unroll
         for (int t = 0; t < MH; ++t) {
@@ -410,6 +565,14 @@ __global__ __launch_bounds__(256) void tile_reorder_pack_kernel(ReorderArgs a) {
 
 }  // namespace
 
+static int cvc_tile_loader_waves = 1;
+// test / A-B hook: 0 = every wave copies its share of a stage (tile_gemm_kernel), 1 = dedicated loader waves (default)
+extern "C" int cvc_tile_gemm_loaders(int on) {
+    const int prev = cvc_tile_loader_waves;
+    if (on >= 0) cvc_tile_loader_waves = on ? 1 : 0;
+    return prev;
+}
+
 extern "C" int cvc_tile_gemm(const void* wb, const void* xb, long long x_mblk_stride, int K, int M, int N, int ksplit,
                              float* parts, int ld, long long part_stride, cvc_stream_t stream) {
     if (!wb || !xb || !parts || K < 16 || (K & 15) || M < 1 || N < 1 || ksplit < 1 || ksplit > K / 16 || ld < N) return CVC_E_BADARG;
@@ -423,6 +586,21 @@ extern "C" int cvc_tile_gemm(const void* wb, const void* xb, long long x_mblk_st
     int MH = mblk >= 10 ? 5 : (mblk + 1) / 2;
     const int chunks = (mblk + 2 * MH - 1) / (2 * MH);
     const dim3 grid(a.ntile * ksplit, chunks);
+#ifndef CVC_TILE_LOADERS
+#define CVC_TILE_LOADERS 4
+#endif
+    if (CVC_TILE_LOADERS > 0 && cvc_tile_loader_waves != 0) {
+        constexpr int NL = CVC_TILE_LOADERS > 0 ? CVC_TILE_LOADERS : 1;
+        const dim3 blk((8 + NL) * 64);
+        switch (MH) {
+            case 1: hipLaunchKernelGGL((tile_gemm_ld_kernel<1, NL>), grid, blk, 0, st, a); break;
+            case 2: hipLaunchKernelGGL((tile_gemm_ld_kernel<2, NL>), grid, blk, 0, st, a); break;
+            case 3: hipLaunchKernelGGL((tile_gemm_ld_kernel<3, NL>), grid, blk, 0, st, a); break;
+            case 4: hipLaunchKernelGGL((tile_gemm_ld_kernel<4, NL>), grid, blk, 0, st, a); break;
+            default: hipLaunchKernelGGL((tile_gemm_ld_kernel<5, NL>), grid, blk, 0, st, a); break;
+        }
+        return cvc_launch_status();
+    }
     switch (MH) {
         case 1: hipLaunchKernelGGL(tile_gemm_kernel<1>, grid, dim3(512), 0, st, a); break;
         case 2: hipLaunchKernelGGL(tile_gemm_kernel<2>, grid, dim3(512), 0, st, a); break;

@@ -92,6 +92,7 @@ SIGNATURES = {
     "cvc_beam_select_parts": [_P, _I, _LL, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "cvc_gather_rows": [_P, _P, _I, _I, _I, _P, _P],
     "cvc_tile_rows_alloc": [_I],
+    "cvc_tile_gemm_loaders": [_I],
     "cvc_tile_gemm": [_P, _P, _LL, _I, _I, _I, _I, _P, _I, _LL, _P],
     "cvc_tile_lstm_finish": [_P, _I, _LL, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _LL, _P, _LL, _P],
     "cvc_tile_linear_finish": [_P, _I, _LL, _I, _P, _P, _I, _I, _P, _I, _P],

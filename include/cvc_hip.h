@@ -300,6 +300,7 @@ int cvc_gather_rows(const float* src, const int64_t* parent, int rows, int beam,
  * cvc_tile_gemm: parts[s][m, n] (row-major, leading dim ld, slab stride part_stride floats) = partial product over K slice s
  * of ksplit; the consumer sums the slabs in slab order.  K % 16 == 0; any M (walked in chunks of 320 rows); any N.
  */
+int cvc_tile_gemm_loaders(int on);   /* A/B + test hook: 1 (default) = dedicated LDS-DMA loader waves, 0 = every wave copies; <0 queries */
 int cvc_tile_rows_alloc(int M);      /* rows (a multiple of 32) an activation fragment buffer for M live rows must hold */
 int cvc_tile_gemm(const void* wb, const void* xb, long long x_mblk_stride, int K, int M, int N, int ksplit,
                   float* parts, int ld, long long part_stride, cvc_stream_t stream);

@@ -1,9 +1,9 @@
 export TMPDIR=/tmp
 mkdir -p gpurun_out/r02c
-for v in "-DCVC_TILE_NO_XCD=1" ""; do
-  CVC_EXTRA_HIPCC_FLAGS="$v" python cyclical-visual-captioning_amd/build_hip.py --force > /dev/null 2>&1
-  echo "== flags $v" | tee -a gpurun_out/r02c/tile_xcd.log
-  timeout 300 python tools/bench_tile.py 2>/dev/null | tee -a gpurun_out/r02c/tile_xcd.log
-  timeout 300 python tools/bench_tile.py 2>/dev/null | tee -a gpurun_out/r02c/tile_xcd.log
-done
 timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "tile" 2>&1 | tail -3
+timeout 300 python tools/bench_tile.py "" 0 1 0 1 2>/dev/null | tee gpurun_out/r02c/tile_loaders.log
+timeout 600 python bench.py --beam 5 --steps 20 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print(d['value'], d['ms_per_step'])
+print([ (k['kernel'],k.get('avg_us')) for k in d['kernels']][:14])"
