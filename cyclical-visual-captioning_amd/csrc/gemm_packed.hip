@@ -38,6 +38,11 @@ struct PackedArgs {
     int ksplit;
     long long split_stride;
     float* top2_part;
+    // lstm, training form (cvc_packed_lstm_train_fwd): row-major state and the activated gates autograd keeps
+    const float* c_prev_rm;   // [M, R]; used instead of c_prev_q when set
+    float* h_rm;              // [M, R]
+    float* c_rm;              // [M, R]
+    float* gates_rm;          // [M, 4R] activated (i, f, g, o)
 };
 
 #ifndef CVC_LIN_W_NT
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
     const size_t eqoff = ((size_t)(ejq / 4) * 64 + em) * 4;
     f32x4 ecp = {0, 0, 0, 0}, eadd[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     if (ework) {
-        ecp = ld4(a.c_prev_q + eqoff);
+        ecp = a.c_prev_rm != nullptr ? ld4(a.c_prev_rm + (size_t)em * R + ejq) : ld4(a.c_prev_q + eqoff);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (a.bias != nullptr) eadd[g] = ld4(a.bias + g * R + ejq);
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
         // unit u -> (batch row m fastest, quad-of-hidden qd in 0..1): a thread finishes 4 hidden units
         // and stores them as one float4 in quad layout (64 rows x 16 B contiguous per quad)
         if (ework) {
-            f32x4 hv, cv;
+            f32x4 hv, cv, gv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int jj = eqd * 4 + e;
@@ -263,10 +268,17 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
                 const float c2 = fg * ecp[e] + ig * gg;
                 cv[e] = c2;
                 hv[e] = og * fast_tanh(c2);
+                gv[0][e] = ig; gv[1][e] = fg; gv[2][e] = gg; gv[3][e] = og;
             }
-            st4(a.c_out_q + eqoff, cv);
+            if (a.c_out_q != nullptr) st4(a.c_out_q + eqoff, cv);
             if (a.h_dst1_q != nullptr) st4(a.h_dst1_q + eqoff, hv);
             if (a.h_dst2_q != nullptr) st4(a.h_dst2_q + eqoff, hv);
+            if (a.h_rm != nullptr) st4(a.h_rm + (size_t)em * R + ejq, hv);
+            if (a.c_rm != nullptr) st4(a.c_rm + (size_t)em * R + ejq, cv);
+            if (a.gates_rm != nullptr) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) st4(a.gates_rm + (size_t)em * 4 * R + g * R + ejq, gv[g]);
+            }
         }
     } else {
         const int n0 = blockIdx.x * 32;
@@ -353,6 +365,100 @@ extern "C" int cvc_packed_lstm_fwd(const float* wp, const float* xq, int K, cons
     a.bias = b_ih; a.bias2 = b_hh; a.gate_bias = gate_bias; a.c_prev_q = c_prev_q; a.c_out_q = c_out_q;
     a.h_dst1_q = h_dst1_q; a.h_dst2_q = h_dst2_q; a.ksplit = 1;
     return launch_packed<true>(a, R / 8, (hipStream_t)stream);
+}
+
+extern "C" int cvc_packed_lstm_train_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
+                                         const float* c_prev, int M, int R, float* h_out, float* c_out, float* gates_out,
+                                         cvc_stream_t stream) {
+    if (!wp || !xq || !c_prev || !h_out || !c_out || (K & 31) || R < 8 || (R & 7)) return CVC_E_BADARG;
+    PackedArgs a{};
+    a.wp = wp; a.xq = xq; a.nquad = K / 4; a.M = M; a.Nout = 4 * R; a.R = R;
+    a.bias = b_ih; a.bias2 = b_hh; a.c_prev_rm = c_prev; a.h_rm = h_out; a.c_rm = c_out; a.gates_rm = gates_out; a.ksplit = 1;
+    return launch_packed<true>(a, R / 8, (hipStream_t)stream);
+}
+
+// ---- operands of the training form: both are rebuilt from the row-major tensors autograd and the optimizer own
+namespace {
+
+struct PackWArgs {
+    const float* w_ih; const float* w_hh;   // [4R, K_ih], [4R, K_hh] row-major (the checkpoint layout)
+    int K_ih, K_hh, R;
+    float* wp;                              // [R/8][(K_ih + K_hh)/4][32][4]
+};
+
+// one workgroup: the 32 gate rows of one block x 64 quads, transposed through LDS so that both the reads (1 KB runs of a
+// weight row) and the writes (one 32 KB run of the packed block) are contiguous
+__global__ __launch_bounds__(256) void pack_lstm_w_kernel(PackWArgs a) {
+    __shared__ f32x4 tile[64][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int blk = blockIdx.x, q0 = blockIdx.y * 64;
+    const int nquad = (a.K_ih + a.K_hh) >> 2, q = q0 + lane;
+#pragma unroll
+    for (int r = wave; r < 32; r += 4) {
+        const size_t n = (size_t)(r >> 3) * a.R + blk * 8 + (r & 7);
+        f32x4 v = {0, 0, 0, 0};
+        if (q < nquad) {
+            const int k = q * 4;
+            v = k < a.K_ih ? ld4(a.w_ih + n * a.K_ih + k) : ld4(a.w_hh + n * a.K_hh + (k - a.K_ih));
+        }
+        tile[lane][r] = v;
+    }
+    __syncthreads();
+    float* out = a.wp + ((size_t)blk * nquad + q0) * 128;
+#pragma unroll
+    for (int e = tid; e < 64 * 32; e += 256) {
+        const int qq = e >> 5, r = e & 31;
+        if (q0 + qq < nquad) st4(out + (size_t)e * 4, tile[qq][r]);
+    }
+}
+
+struct PackXArgs {
+    const float* x[6];
+    int q_end[6];          // running quad count after each segment
+    long long ldx[6];
+    int nseg, M;
+    float* xq;
+};
+
+// up to 6 row-major segments [M <= 64, k_s] -> one quad-layout operand [sum k_s / 4][64][4] (rows beyond M zero)
+__global__ __launch_bounds__(256) void pack_quad_segs_kernel(PackXArgs a) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int m = t & 63, q = t >> 6;
+    if (q >= a.q_end[a.nseg - 1]) return;
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) s += (i < a.nseg - 1 && q >= a.q_end[i]) ? 1 : 0;
+    const int qs = q - (s ? a.q_end[s - 1] : 0);
+    f32x4 v = {0, 0, 0, 0};
+    if (m < a.M) v = ld4(a.x[s] + (size_t)m * a.ldx[s] + qs * 4);
+    st4(a.xq + ((size_t)q * 64 + m) * 4, v);
+}
+
+}  // namespace
+
+extern "C" int cvc_pack_lstm_weights(const float* w_ih, int K_ih, const float* w_hh, int K_hh, int R, float* wp,
+                                     cvc_stream_t stream) {
+    if (!w_ih || !w_hh || !wp || K_ih < 4 || K_hh < 4 || (K_ih & 3) || (K_hh & 3) || ((K_ih + K_hh) & 31) || R < 8 || (R & 7))
+        return CVC_E_BADARG;
+    PackWArgs a{w_ih, w_hh, K_ih, K_hh, R, wp};
+    const int nquad = (K_ih + K_hh) / 4;
+    hipLaunchKernelGGL(pack_lstm_w_kernel, dim3(R / 8, (nquad + 63) / 64), dim3(256), 0, (hipStream_t)stream, a);
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_pack_quad_segs(const float* const* xs, const long long* ldx, const int* widths, int nseg, int M, float* xq,
+                                  cvc_stream_t stream) {
+    if (!xs || !ldx || !widths || !xq || nseg < 1 || nseg > 6 || M < 1 || M > 64) return CVC_E_BADARG;
+    PackXArgs a{};
+    int q = 0;
+    for (int s = 0; s < nseg; ++s) {
+        if (!xs[s] || widths[s] < 4 || (widths[s] & 3) || (ldx[s] & 3) || ((uintptr_t)xs[s] & 15)) return CVC_E_BADARG;
+        q += widths[s] / 4;
+        a.x[s] = xs[s]; a.ldx[s] = ldx[s]; a.q_end[s] = q;
+    }
+    a.nseg = nseg; a.M = M; a.xq = xq;
+    hipLaunchKernelGGL(pack_quad_segs_kernel, dim3((q * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    return cvc_launch_status();
 }
 
 extern "C" int cvc_packed_linear_fwd(const float* wp, const float* xq, int K, const float* bias, int M, int Nout,

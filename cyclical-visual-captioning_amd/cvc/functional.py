@@ -151,6 +151,14 @@ def linear(xs, weight: Tensor, bias: Optional[Tensor] = None) -> Tensor:
 
 
 # ------------------------------------------------------------------------------- LSTM cell
+PACKED_LSTM_FORWARD = True     # False: the in-place (row-major weights) ring kernel for every forward (A/B switch)
+
+
+def new_step() -> None:
+    """Start of a training forward: weight packs derived from the parameters are rebuilt at their next use."""
+    hip.lstm_train_new_step()
+
+
 class _LstmCell(torch.autograd.Function):
     """nn.LSTMCell over a virtual concat of input segments (decoder_core.py:45-50, 59-61)."""
 
@@ -158,14 +166,21 @@ class _LstmCell(torch.autograd.Function):
     def forward(ctx, w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, *xs):
         xs = [_c(x) for x in xs]
         h_prev, c_prev = _c(h_prev), _c(c_prev)
-        segs, k0 = [], 0
-        for x in xs:
-            segs.append({"x": x, "w": w_ih[:, k0:k0 + x.shape[1]]})
-            k0 += x.shape[1]
+        k0 = sum(x.shape[1] for x in xs)
         assert k0 == w_ih.shape[1], ("LSTM input width mismatch", k0, tuple(w_ih.shape))
-        segs.append({"x": h_prev, "w": w_hh})
         need_bwd = any(ctx.needs_input_grad)
-        h, c, gates = hip.lstm_cell_fwd(segs, b_ih, b_hh, c_prev, want_gates=need_bwd)
+        M, R = c_prev.shape
+        if PACKED_LSTM_FORWARD and w_ih.is_contiguous() and w_hh.is_contiguous() and hip.lstm_train_ok(
+                M, R, [x.shape[1] for x in xs] + [h_prev.shape[1]]) and all(x.data_ptr() % 16 == 0 for x in (*xs, h_prev)):
+            # the decode engine's packed gate GEMM; its weight pack is rebuilt once per optimizer step
+            h, c, gates = hip.lstm_cell_train_fwd(xs, h_prev, c_prev, w_ih, w_hh, b_ih, b_hh, want_gates=need_bwd)
+        else:
+            segs, k0 = [], 0
+            for x in xs:
+                segs.append({"x": x, "w": w_ih[:, k0:k0 + x.shape[1]]})
+                k0 += x.shape[1]
+            segs.append({"x": h_prev, "w": w_hh})
+            h, c, gates = hip.lstm_cell_fwd(segs, b_ih, b_hh, c_prev, want_gates=need_bwd)
         ctx.set_materialize_grads(False)          # an unused h or c arrives as None, not as a zero-filled tensor
         if need_bwd:
             ctx.save_for_backward(w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, c, gates, *xs)

@@ -67,6 +67,9 @@ SIGNATURES = {
     "cvc_attn_wsum_quad": [C.POINTER(AttnSet), _I, _I, _I, _I, _P, _P],
     "cvc_packed_lstm_fwd": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "cvc_packed_linear_fwd": [_P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P],
+    "cvc_packed_lstm_train_fwd": [_P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "cvc_pack_lstm_weights": [_P, _I, _P, _I, _I, _P, _P],
+    "cvc_pack_quad_segs": [C.POINTER(_P), C.POINTER(_LL), C.POINTER(_I), _I, _I, _P, _P],
     "cvc_packed_lstm_ks_slices": [_I, _I],
     "cvc_packed_lstm_ks_fwd": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _LL, _P],
     "cvc_attn_wsum": [C.POINTER(AttnSet), _I, _I, _I, _I, _P, _P],
@@ -316,6 +319,60 @@ def lstm_cell_fwd(segs: Sequence[dict], b_ih, b_hh, c_prev, want_gates: bool = F
     arr = _segs(segs, M)
     _check(lib().cvc_lstm_cell_fwd(arr, len(segs), _dev(b_ih), _dev(b_hh), _dev(gate_bias), _dev(c_prev), M, R, _dev(h),
                                    _dev(c), _dev(gates), _stream()), "cvc_lstm_cell_fwd")
+    return h, c, gates
+
+
+# ---- training form of the packed gate GEMM: the weights are re-packed once per optimizer step, the cell's inputs per call
+_train_packs: dict = {}     # (w_ih ptr, w_hh ptr) -> [packed tensor, generation, w_ih version, w_hh version]
+_train_generation = 0
+
+
+def lstm_train_new_step() -> None:
+    """Called by the model at the start of every training forward: the packed LSTM weights are rebuilt at their first use of
+    the step whatever their autograd version says (a captured training step must contain the re-pack launch)."""
+    global _train_generation
+    _train_generation += 1
+
+
+def lstm_train_ok(M: int, R: int, widths: Sequence[int]) -> bool:
+    return 1 <= M <= 64 and R % 8 == 0 and all(w % 4 == 0 and w >= 4 for w in widths) and sum(widths) % 32 == 0
+
+
+def _train_pack(w_ih, w_hh, R):
+    key = (w_ih.data_ptr(), w_hh.data_ptr())
+    ent = _train_packs.get(key)
+    stamp = (_train_generation, w_ih._version, w_hh._version)
+    if ent is not None and ent[1] == stamp:
+        return ent[0]
+    K_ih, K_hh = w_ih.shape[1], w_hh.shape[1]
+    wp = ent[0] if ent is not None else torch.empty(R // 8, (K_ih + K_hh) // 4, 32, 4, device=w_ih.device, dtype=torch.float32)
+    _check(lib().cvc_pack_lstm_weights(_dev(w_ih), K_ih, _dev(w_hh), K_hh, R, _dev(wp), _stream()), "cvc_pack_lstm_weights")
+    if len(_train_packs) > 16 and ent is None:
+        _train_packs.clear()
+    _train_packs[key] = [wp, stamp]
+    return wp
+
+
+def pack_quad_segs(xs: Sequence[torch.Tensor]) -> torch.Tensor:
+    """Row-major segments [M <= 64, k_s] -> one quad-layout operand [sum k_s / 4][64][4]."""
+    n, M = len(xs), xs[0].shape[0]
+    ptrs = (_P * n)(*[x.data_ptr() for x in xs])
+    lds = (_LL * n)(*[x.stride(0) for x in xs])
+    ws = (_I * n)(*[x.shape[1] for x in xs])
+    xq = torch.empty(sum(x.shape[1] for x in xs) // 4, 64, 4, device=xs[0].device, dtype=torch.float32)
+    _check(lib().cvc_pack_quad_segs(ptrs, lds, ws, n, M, _dev(xq), _stream()), "cvc_pack_quad_segs")
+    return xq
+
+
+def lstm_cell_train_fwd(xs: Sequence[torch.Tensor], h_prev, c_prev, w_ih, w_hh, b_ih, b_hh, want_gates: bool = True):
+    """nn.LSTMCell forward on the packed gate GEMM (cvc_packed_lstm_train_fwd): -> h, c, activated gates (or None)."""
+    M, R = c_prev.shape
+    wp = _train_pack(w_ih, w_hh, R)
+    xq = pack_quad_segs([*xs, h_prev])
+    h, c = torch.empty_like(c_prev), torch.empty_like(c_prev)
+    gates = torch.empty(M, 4 * R, device=c_prev.device, dtype=torch.float32) if want_gates else None
+    _check(lib().cvc_packed_lstm_train_fwd(_dev(wp), _dev(xq), xq.shape[0] * 4, _dev(b_ih), _dev(b_hh), _dev(c_prev), M, R,
+                                           _dev(h), _dev(c), _dev(gates), _stream()), "cvc_packed_lstm_train_fwd")
     return h, c, gates
 
 

@@ -143,6 +143,7 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
     def forward(self, segs_feat, input_seq, gt_caption, num, proposals, gt_boxes, mask_boxes, region_feats, frm_mask,
                 sample_idx, pnt_mask, lang_eval=False, teacher_forcing=False):
         """reference :175-194"""
+        F_.new_step()
         if lang_eval is False or teacher_forcing:
             return self._forward_3_loops(segs_feat, input_seq, proposals, gt_caption, num, mask_boxes, gt_boxes,
                                          region_feats, frm_mask, sample_idx, pnt_mask)

@@ -150,6 +150,21 @@ int cvc_packed_lstm_fwd(const float* wp, const float* xq, int K, const float* b_
 int cvc_packed_linear_fwd(const float* wp, const float* xq, int K, const float* bias, int M, int Nout,
                           int ksplit, float* y, int ldy, float* top2_part, cvc_stream_t stream);
 
+/* Training form of cvc_packed_lstm_fwd (nn.LSTMCell forward under autograd, decoder_core.py:45-50, 59-61): the same GEMM
+ * kernel with row-major state -- c_prev / h_out / c_out [M, R] and the activated gates [M, 4R] (i, f, g, o; nullable) that
+ * cvc_lstm_pointwise_bwd reads.  Its two operands are rebuilt from the tensors autograd and the optimizer own:
+ *   cvc_pack_lstm_weights : w_ih [4R, K_ih], w_hh [4R, K_hh] row-major (the checkpoint layout) -> wp of K = K_ih + K_hh
+ *                           (once per optimizer step; K_ih, K_hh % 4 == 0, K % 32 == 0, R % 8 == 0);
+ *   cvc_pack_quad_segs    : up to 6 row-major segments [M <= 64, width_s] (the virtual concat of the cell's inputs followed
+ *                           by h_prev; widths % 4 == 0, 16-byte aligned) -> xq [K/4][64][4], rows beyond M zero. */
+int cvc_packed_lstm_train_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
+                              const float* c_prev, int M, int R, float* h_out, float* c_out, float* gates_out,
+                              cvc_stream_t stream);
+int cvc_pack_lstm_weights(const float* w_ih, int K_ih, const float* w_hh, int K_hh, int R, float* wp,
+                          cvc_stream_t stream);
+int cvc_pack_quad_segs(const float* const* xs, const long long* ldx, const int* widths, int nseg, int M, float* xq,
+                       cvc_stream_t stream);
+
 /* K-split variant of cvc_packed_lstm_fwd (same operands, same arithmetic): one workgroup = 256 gate rows x K / S, the 32-k
  * activation chunks fetched and split once per workgroup and shared through LDS (cuts the L2 activation reads of the full-K
  * kernel from 2 x the weight bytes to 1/4 of them); partial tiles go to `slab` (>= S * (R/8) * 2048 floats, S =

@@ -897,4 +897,61 @@ def test_product_path_has_no_cpu_fallback(lib):
     x = torch.zeros(4, 8)
     w = torch.zeros(8, 8)
     with pytest.raises(RuntimeError, match="GPU"):
-        F_.linear(x, w, None)
+        F_.linear(x, w, None)@pytest.mark.gpu
+@pytest.mark.parametrize("M,R,widths", [(64, 64, (32, 64, 32)), (20, 128, (64, 128, 96)), (3, 40, (20, 36)), (64, 1024, (512, 1024, 512))])
+def test_lstm_train_form_of_packed_gemm(dev, lib, M, R, widths):
+    """Training forward of nn.LSTMCell on the decode engine's packed gate GEMM (cvc_pack_lstm_weights + cvc_pack_quad_segs +
+    cvc_packed_lstm_train_fwd, decoder_core.py:45-50): the weight pack equals the host-side pack bit for bit, h / c / gates
+    match fp64 and the ring kernel, the autograd function gives the same gradients on either forward, and a pack is rebuilt
+    after an in-place weight update."""
+    import cvc.functional as F_
+    from cvc.decode import pack_weights, to_quad
+    g = torch.Generator().manual_seed(M * 13 + R)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    K_ih = sum(widths)
+    w_ih, w_hh = rnd(4 * R, K_ih) / (K_ih + R) ** 0.5, rnd(4 * R, R) / (K_ih + R) ** 0.5
+    b_ih, b_hh = rnd(4 * R) * 0.1, rnd(4 * R) * 0.1
+    xs, h_prev, c_prev = [rnd(M, w) for w in widths], rnd(M, R), rnd(M, R)
+    assert lib.lstm_train_ok(M, R, list(widths) + [R])
+    # operands
+    wp = lib._train_pack(w_ih, w_hh, R)
+    assert torch.equal(wp, pack_weights(torch.cat([w_ih, w_hh], 1), R))
+    assert torch.equal(lib.pack_quad_segs([*xs, h_prev]), to_quad(torch.cat([*xs, h_prev], 1)))
+    # forward
+    h, c, gates = lib.lstm_cell_train_fwd(xs, h_prev, c_prev, w_ih, w_hh, b_ih, b_hh)
+    segs, k0 = [], 0
+    for x in xs:
+        segs.append({"x": x, "w": w_ih[:, k0:k0 + x.shape[1]]}); k0 += x.shape[1]
+    segs.append({"x": h_prev, "w": w_hh})
+    h_r, c_r, g_r = lib.lstm_cell_fwd(segs, b_ih, b_hh, c_prev, want_gates=True)
+    X = torch.cat([*xs, h_prev], 1).double()
+    pre = X @ torch.cat([w_ih, w_hh], 1).double().t() + b_ih.double() + b_hh.double()
+    i, f, gg, o = pre.chunk(4, 1)
+    c64 = torch.sigmoid(f) * c_prev.double() + torch.sigmoid(i) * torch.tanh(gg)
+    h64 = torch.sigmoid(o) * torch.tanh(c64)
+    g64 = torch.cat([torch.sigmoid(i), torch.sigmoid(f), torch.tanh(gg), torch.sigmoid(o)], 1)
+    for got, ring, ref in ((h, h_r, h64), (c, c_r, c64), (gates, g_r, g64)):
+        close(got, ref.float(), **OP_TOL); close(got, ring, **OP_TOL)
+    # autograd: same gradients whichever forward ran
+    grads = {}
+    for packed in (True, False):
+        F_.PACKED_LSTM_FORWARD = packed
+        try:
+            leaves = [t.clone().requires_grad_(True) for t in (w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, *xs)]
+            h2, c2 = F_.lstm_cell(leaves[6:], leaves[4], leaves[5], *leaves[:4])
+            ((h2 * h64.float()).sum() + (c2 * c64.float()).sum() * 0.5).backward()
+            grads[packed] = [t.grad for t in leaves]
+        finally:
+            F_.PACKED_LSTM_FORWARD = True
+    for a, b in zip(grads[True], grads[False]):
+        close(a, b, rtol=1e-4, atol=1e-4)
+    # an in-place update of the weights invalidates the pack
+    w_ih.mul_(0.5)
+    h3, _, _ = lib.lstm_cell_train_fwd(xs, h_prev, c_prev, w_ih, w_hh, b_ih, b_hh)
+    pre = X @ torch.cat([w_ih, w_hh], 1).double().t() + b_ih.double() + b_hh.double()
+    i, f, gg, o = pre.chunk(4, 1)
+    h64b = torch.sigmoid(o) * torch.tanh(torch.sigmoid(f) * c_prev.double() + torch.sigmoid(i) * torch.tanh(gg))
+    close(h3, h64b.float(), **OP_TOL)
+
+
+
