@@ -43,6 +43,13 @@ struct PackedArgs {
     float* h_rm;              // [M, R]
     float* c_rm;              // [M, R]
     float* gates_rm;          // [M, 4R] activated (i, f, g, o)
+    // GRU step (cvc_gru_seq_fwd): blockIdx.y = direction d; R = hidden size H; block rows = (r, z, n, zero) x 8 hidden units
+    long long gru_w_stride;   // floats between the directions' weight packs
+    long long gru_h_stride;   // floats between the directions' hidden states (quad layout)
+    const float* gru_gi[2];   // this step's input projections of direction d: row m at + m * gru_gi_ld, columns [3H] (r, z, n)
+    long long gru_gi_ld;
+    float* gru_y[2];          // this step's output rows of direction d: row m at + m * gru_y_ld, H columns
+    long long gru_y_ld;
 };
 
 #ifndef CVC_LIN_W_NT
@@ -68,8 +75,16 @@ __device__ __forceinline__ float sum_partials(const float* red, int row, int ldm
     return v;
 }
 
-template <int MT, bool LSTM, int DEPTH, bool SPLIT, int NW>
+template <int MT, bool LSTM, int DEPTH, bool SPLIT, int NW, bool GRU = false>
 __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs a) {
+    static_assert(!GRU || LSTM, "the GRU step shares the LSTM form's work split");
+    if constexpr (GRU) {                                       // direction of this workgroup
+        a.wp += (size_t)blockIdx.y * a.gru_w_stride;
+        a.xq += (size_t)blockIdx.y * a.gru_h_stride;
+        a.h_dst1_q += (size_t)blockIdx.y * a.gru_h_stride;
+        a.bias += (size_t)blockIdx.y * 3 * a.R;
+        a.bias2 += (size_t)blockIdx.y * 3 * a.R;
+    }
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     constexpr int LDM = MT * 32 + 1;
     __shared__ float red[NW * 32 * LDM + NW * 64 * 6];
@@ -113,7 +128,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
         for (int q = 0; q < 4; ++q) {
             // gate weights (369 MB per step) are streamed; the small linear layers' weights (vocabulary head, h2attn:
             // 49 MB) keep the default policy so that they can stay in the Infinity Cache between steps
-            if constexpr (LSTM || CVC_LIN_W_NT) f.w[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + q * 128));
+            if constexpr ((LSTM && !GRU) || CVC_LIN_W_NT) f.w[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + q * 128));
             else f.w[q] = ld4(w + q * 128);
 #if defined(CVC_PABL) && CVC_PABL == 3
             if (j > 0) continue;                                     // ablation: stream the weights only
@@ -223,7 +238,17 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
     const int ejq = (int)blockIdx.x * 8 + eqd * 4;                     // first of this thread's 4 hidden units
     const size_t eqoff = ((size_t)(ejq / 4) * 64 + em) * 4;
     f32x4 ecp = {0, 0, 0, 0}, eadd[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    if (ework) {
+    if (GRU && ework) {
+        // eadd: r, z: x-projection + both biases; n: x-projection + b_in; [3]: b_hn (multiplied by r with the h-projection)
+        const float* gi = a.gru_gi[blockIdx.y] + (size_t)em * a.gru_gi_ld + ejq;
+        ecp = ld4(a.xq + eqoff);                                      // h_prev of these 4 hidden units
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            eadd[g] = ld4(gi + g * R) + ld4(a.bias + g * R + ejq);
+            if (g < 2) eadd[g] += ld4(a.bias2 + g * R + ejq);
+        }
+        eadd[3] = ld4(a.bias2 + 2 * R + ejq);
+    } else if (ework) {
         ecp = a.c_prev_rm != nullptr ? ld4(a.c_prev_rm + (size_t)em * R + ejq) : ld4(a.c_prev_q + eqoff);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -252,7 +277,23 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
         }
     __syncthreads();
 
-    if (LSTM) {
+    if constexpr (GRU) {
+        if (ework) {
+            f32x4 hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int jj = eqd * 4 + e;
+                float pre[3];
+#pragma unroll
+                for (int g = 0; g < 3; ++g) pre[g] = sum_partials<NW>(red, g * 8 + jj, LDM, em);
+                const float rg = fast_sigmoid(pre[0] + eadd[0][e]), zg = fast_sigmoid(pre[1] + eadd[1][e]);
+                const float ng = fast_tanh(eadd[2][e] + rg * (pre[2] + eadd[3][e]));
+                hv[e] = ng + zg * (ecp[e] - ng);                       // (1 - z) n + z h
+            }
+            st4(a.h_dst1_q + eqoff, hv);
+            st4(a.gru_y[blockIdx.y] + (size_t)em * a.gru_y_ld + ejq, hv);
+        }
+    } else if (LSTM) {
         // unit u -> (batch row m fastest, quad-of-hidden qd in 0..1): a thread finishes 4 hidden units
         // and stores them as one float4 in quad layout (64 rows x 16 B contiguous per quad)
         if (ework) {
@@ -375,6 +416,52 @@ extern "C" int cvc_packed_lstm_train_fwd(const float* wp, const float* xq, int K
     a.wp = wp; a.xq = xq; a.nquad = K / 4; a.M = M; a.Nout = 4 * R; a.R = R;
     a.bias = b_ih; a.bias2 = b_hh; a.c_prev_rm = c_prev; a.h_rm = h_out; a.c_rm = c_out; a.gates_rm = gates_out; a.ksplit = 1;
     return launch_packed<true>(a, R / 8, (hipStream_t)stream);
+}
+
+// ---- GRU over a whole sequence (the encoder's frame context, backbone.py:335-338): one launch per time step, both directions
+namespace {
+__global__ __launch_bounds__(256) void zero_kernel(float* p, long long n) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t < n) p[t] = 0.f;
+}
+}  // namespace
+
+extern "C" int cvc_gru_seq_fwd(const float* wp, const float* gi, long long gi_ld_m, long long gi_ld_t, const float* b_ih,
+                               const float* b_hh, int M, int F, int H, int ndir, float* hq, float* y, long long y_ld_m,
+                               long long y_ld_t, cvc_stream_t stream) {
+    if (!wp || !gi || !b_ih || !b_hh || !hq || !y || M < 1 || M > 64 || F < 1 || H < 8 || (H & 7) || ndir < 1 || ndir > 2 ||
+        (gi_ld_m & 3) || (gi_ld_t & 3) || (y_ld_m & 3) || (y_ld_t & 3))
+        return CVC_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int Kp = (H + 31) / 32 * 32;                             // contraction length, zero-padded to whole 32-k chunks
+    const long long hsz = (long long)Kp * 64;                      // one direction's state in quad layout
+    // h0 = 0, and the padding quads of both parities stay zero
+    hipLaunchKernelGGL(zero_kernel, dim3((unsigned)((2 * hsz * ndir + 255) / 256)), dim3(256), 0, st, hq, 2 * hsz * ndir);
+    PackedArgs a{};
+    a.nquad = Kp / 4; a.M = M; a.Nout = 4 * H; a.R = H; a.bias = b_ih; a.bias2 = b_hh; a.ksplit = 1;
+    a.wp = wp; a.gru_w_stride = (long long)(H / 8) * (Kp / 4) * 128; a.gru_h_stride = hsz;
+    a.gru_gi_ld = gi_ld_m; a.gru_y_ld = y_ld_m;
+    const dim3 grid(H / 8, ndir);
+    for (int s = 0; s < F; ++s) {
+        a.xq = hq + (size_t)(s & 1) * hsz * ndir;
+        a.h_dst1_q = hq + (size_t)((s + 1) & 1) * hsz * ndir;
+        for (int d = 0; d < ndir; ++d) {
+            const long long t = d == 0 ? s : F - 1 - s;
+            a.gru_gi[d] = gi + t * gi_ld_t + (long long)d * 3 * H;
+            a.gru_y[d] = y + t * y_ld_t + (long long)d * H;
+        }
+        if (cvc_gemm_split_mode == 2) {
+            if (M <= 32) hipLaunchKernelGGL((skinny_gemm_packed_kernel<1, true, CVC_PACKED_DEPTH8, true, 8, true>), grid, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, true, CVC_PACKED_DEPTH8, true, 8, true>), grid, dim3(512), 0, st, a);
+        } else if (cvc_gemm_split_mode) {
+            if (M <= 32) hipLaunchKernelGGL((skinny_gemm_packed_kernel<1, true, CVC_PACKED_DEPTH, true, 4, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, true, CVC_PACKED_DEPTH, true, 4, true>), grid, dim3(256), 0, st, a);
+        } else {
+            if (M <= 32) hipLaunchKernelGGL((skinny_gemm_packed_kernel<1, true, CVC_PACKED_DEPTH, false, 4, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, true, CVC_PACKED_DEPTH, false, 4, true>), grid, dim3(256), 0, st, a);
+        }
+    }
+    return cvc_launch_status();
 }
 
 // ---- operands of the training form: both are rebuilt from the row-major tensors autograd and the optimizer own

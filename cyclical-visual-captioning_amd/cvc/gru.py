@@ -1,0 +1,86 @@
+"""Frame-context GRU of the once-per-clip encoder on the HIP kernels (reference backbone.py:103-106 builds
+`nn.GRU(R, R/2, 2, dropout=0.2, bidirectional=True, batch_first=True)`, :335-338 runs it over the F sampled frames).
+
+The reference hands the whole recurrence to cuDNN; on ROCm the same module runs in MIOpen (79 of the encoder's 84 ms at
+config 2).  Here a layer is
+  1. ONE dense GEMM for the input projections of all F steps and both directions (the tile GEMM, csrc/gemm_tile.hip), and
+  2. F launches of the packed gate-GEMM kernel in its GRU form (cvc_gru_seq_fwd, csrc/gemm_packed.hip): W_hh of both
+     directions (25 MB at H = 1024) stays in the Infinity Cache between steps, the state ping-pongs in the quad layout.
+Inference only (eval mode, h0 = 0, no inter-layer dropout): the training pass keeps the library module, whose backward
+autograd needs."""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import hip
+from .decode import pack_weights
+
+_packs: Dict[int, Tuple[tuple, list]] = {}
+
+
+def pack_gru_weights(w_hh: torch.Tensor, H: int) -> torch.Tensor:
+    """[3H, H] (r, z, n) -> the packed-LSTM block order with a zero fourth gate, columns zero-padded to a multiple of 32:
+    [H/8][Kp/4][32][4]."""
+    assert w_hh.shape == (3 * H, H) and H % 8 == 0
+    Kp = (H + 31) // 32 * 32
+    w = w_hh.new_zeros(4 * H, Kp)
+    w[:3 * H, :H] = w_hh
+    return pack_weights(w, lstm_R=H)
+
+
+def supported(gru: nn.Module, x: torch.Tensor) -> bool:
+    return (isinstance(gru, nn.GRU) and gru.batch_first and gru.bias and gru.hidden_size % 8 == 0 and x.dim() == 3
+            and x.is_cuda and x.dtype == torch.float32 and not (gru.training and gru.dropout > 0
+                                                                                          and gru.num_layers > 1))
+
+
+def _layer_operands(gru: nn.GRU):
+    """Per layer: (W_ih of both directions as a tile operand, packed W_hh [ndir][...], b_ih [ndir, 3H], b_hh [ndir, 3H]);
+    rebuilt when any parameter changed."""
+    params = list(gru.parameters())
+    stamp = tuple((p.data_ptr(), p._version) for p in params)
+    ent = _packs.get(id(gru))
+    if ent is not None and ent[0] == stamp:
+        return ent[1]
+    H, sfx = gru.hidden_size, ([""] if not gru.bidirectional else ["", "_reverse"])
+    layers = []
+    with torch.no_grad():
+        for l in range(gru.num_layers):
+            g = lambda n: [getattr(gru, f"{n}_l{l}{s}").detach().float() for s in sfx]
+            w_ih = torch.cat(g("weight_ih"), 0).contiguous()
+            layers.append((hip.TileOperand(w_ih, kmajor=False), torch.stack([pack_gru_weights(w, H) for w in g("weight_hh")]),
+                           torch.stack(g("bias_ih")).contiguous(), torch.stack(g("bias_hh")).contiguous()))
+    if len(_packs) > 8:
+        _packs.clear()
+    _packs[id(gru)] = (stamp, layers)
+    return layers
+
+
+def gru_forward(gru: nn.GRU, x: torch.Tensor) -> torch.Tensor:
+    """x [B, F, in] -> [B, F, ndir * H], the first output of `gru(x)` (h0 = 0)."""
+    assert supported(gru, x), "shape / module outside the HIP GRU's range"
+    B, F, _ = x.shape
+    H, ndir = gru.hidden_size, 2 if gru.bidirectional else 1
+    layers = _layer_operands(gru)
+    out = torch.empty(B, F, ndir * H, device=x.device, dtype=torch.float32)
+    L, st = hip.lib(), hip._stream()
+    for b0 in range(0, B, 64):
+        m = min(64, B - b0)
+        cur = x[b0:b0 + m].transpose(0, 1).contiguous().view(F * m, -1)            # time-major rows (t, clip)
+        hq = torch.empty(2 * ndir * ((H + 31) // 32 * 32) * 64, device=x.device, dtype=torch.float32)
+        for l, (w_ih, wp, b_ih, b_hh) in enumerate(layers):
+            gi = hip.tile_mm(cur, w_ih)                                              # [F*m, ndir*3H], no bias
+            last = l == len(layers) - 1
+            if last:
+                y, ld_m, ld_t = out[b0:b0 + m], F * ndir * H, ndir * H
+            else:
+                y = torch.empty(F * m, ndir * H, device=x.device, dtype=torch.float32)
+                ld_m, ld_t = ndir * H, m * ndir * H
+            hip._check(L.cvc_gru_seq_fwd(wp.data_ptr(), gi.data_ptr(), ndir * 3 * H, m * ndir * 3 * H, b_ih.data_ptr(),
+                                         b_hh.data_ptr(), m, F, H, ndir, hq.data_ptr(), y.data_ptr(), ld_m, ld_t, st),
+                       "cvc_gru_seq_fwd")
+            cur = y
+    return out

@@ -24,6 +24,10 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import gru as gru_hip
+
+HIP_GRU = True     # inference: frame-context GRU on the HIP kernels (cvc/gru.py); False = the library module everywhere
+
 GLOVE_DIM = 300          # backbone.py:43,46
 SEG_INFO_SIZE = 50       # backbone.py:29
 RGB_DIM, MOTION_DIM = 2048, 1024   # backbone.py:68,73,328
@@ -197,8 +201,12 @@ class RegionalFeatureExtractorGVD(nn.Module):
             rgb, motion = conv_feats[..., :RGB_DIM], conv_feats[..., RGB_DIM:RGB_DIM + MOTION_DIM]
             x = torch.cat((self.att_embed[0](rgb), self.att_embed[1](motion)), dim=2)
             x = self.att_embed_aux(x.transpose(1, 2)).transpose(1, 2).contiguous()      # BatchNorm1d over channels
-            self.context_enc.flatten_parameters()
-            x = self.context_enc(x)[0].masked_fill(sample_idx_mask, 0)
+            if HIP_GRU and not torch.is_grad_enabled() and gru_hip.supported(self.context_enc, x):
+                x = gru_hip.gru_forward(self.context_enc, x)          # inference: csrc/gemm_packed.hip GRU steps + tile GEMM
+            else:
+                self.context_enc.flatten_parameters()                 # training (autograd) and CPU: the library module
+                x = self.context_enc(x)[0]
+            x = x.masked_fill(sample_idx_mask, 0)
             conv_feats = x if self.seq_per_img == 1 else x.repeat_interleave(self.seq_per_img, dim=0)
             p_conv_feats = self.ctx2att_fc(conv_feats)
         else:

@@ -165,6 +165,20 @@ int cvc_pack_lstm_weights(const float* w_ih, int K_ih, const float* w_hh, int K_
 int cvc_pack_quad_segs(const float* const* xs, const long long* ldx, const int* widths, int nseg, int M, float* xq,
                        cvc_stream_t stream);
 
+/* GRU over a whole sequence, one or both directions: the recurrent half of nn.GRU(batch_first, h0 = 0) as the encoder's frame
+ * context uses it (backbone.py:103-106, 335-338; gate order r, z, n; n = tanh(W_in x + b_in + r * (W_hn h + b_hn)),
+ * h' = (1 - z) n + z h).  One launch of the packed GEMM kernel per time step serves both directions (direction 1 walks the
+ * sequence backwards); the input projections of ALL steps come from one dense GEMM beforehand (cvc_tile_gemm):
+ *   wp : [ndir][H/8][Kp/4][32][4]  W_hh packed like an LSTM gate matrix whose 4th gate is zero (block b = (r, z, n, 0) x
+ *        hidden units 8b..8b+7), columns zero-padded to Kp = H rounded up to a multiple of 32;
+ *   gi : x W_ih^T WITHOUT bias; row of (clip m, step t) at gi + m * gi_ld_m + t * gi_ld_t, columns [ndir][3H];
+ *   b_ih, b_hh : [ndir][3H];  hq : workspace of 2 * ndir * Kp * 64 floats (the two parities of the state, quad layout);
+ *   y  : h_t of direction d at y + m * y_ld_m + t * y_ld_t + d * H.
+ * M <= 64 clips, H % 8 == 0, strides multiples of 4 floats. */
+int cvc_gru_seq_fwd(const float* wp, const float* gi, long long gi_ld_m, long long gi_ld_t, const float* b_ih,
+                    const float* b_hh, int M, int F, int H, int ndir, float* hq, float* y, long long y_ld_m,
+                    long long y_ld_t, cvc_stream_t stream);
+
 /* K-split variant of cvc_packed_lstm_fwd (same operands, same arithmetic): one workgroup = 256 gate rows x K / S, the 32-k
  * activation chunks fetched and split once per workgroup and shared through LDS (cuts the L2 activation reads of the full-K
  * kernel from 2 x the weight bytes to 1/4 of them); partial tiles go to `slab` (>= S * (R/8) * 2048 floats, S =

@@ -85,6 +85,34 @@ def lstm_cell_explicit(x, h, c, w_ih, w_hh, b_ih, b_hh):
     return torch.sigmoid(o) * torch.tanh(c2), c2
 
 
+def gru_sequence(x: Tensor, P: Dict[str, Tensor], num_layers: int = 2, bidirectional: bool = True) -> Tensor:
+    """nn.GRU(batch_first=True, h0 = 0) in eval mode, spelled out step by step: the frame-context encoder built at
+    model/backbone.py:103-106 and run at :335-338.  P holds the module's own parameter names (weight_ih_l0,
+    weight_hh_l0_reverse, ...); gate order r, z, n; n = tanh(W_in x + b_in + r * (W_hn h + b_hn)); h' = (1-z) n + z h."""
+    cur = x
+    for l in range(num_layers):
+        outs = []
+        for sfx in ([""] + (["_reverse"] if bidirectional else [])):
+            w_ih, w_hh = P[f"weight_ih_l{l}{sfx}"], P[f"weight_hh_l{l}{sfx}"]
+            b_ih, b_hh = P[f"bias_ih_l{l}{sfx}"], P[f"bias_hh_l{l}{sfx}"]
+            H = w_hh.shape[1]
+            h = cur.new_zeros(cur.shape[0], H)
+            gi_all = F.linear(cur, w_ih, b_ih)
+            ys = [None] * cur.shape[1]
+            order = range(cur.shape[1]) if sfx == "" else range(cur.shape[1] - 1, -1, -1)
+            for t in order:
+                gh = F.linear(h, w_hh, b_hh)
+                i_r, i_z, i_n = gi_all[:, t].chunk(3, 1)
+                h_r, h_z, h_n = gh.chunk(3, 1)
+                r, z = torch.sigmoid(i_r + h_r), torch.sigmoid(i_z + h_z)
+                n = torch.tanh(i_n + r * h_n)
+                h = (1 - z) * n + z * h
+                ys[t] = h
+            outs.append(torch.stack(ys, 1))
+        cur = torch.cat(outs, 2)
+    return cur
+
+
 def _cell(P: Dict[str, Tensor], prefix: str):
     return (P[prefix + ".weight_ih"], P[prefix + ".weight_hh"], P[prefix + ".bias_ih"], P[prefix + ".bias_hh"])
 

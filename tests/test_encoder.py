@@ -158,3 +158,73 @@ def test_encoder_plus_hot_path_end_to_end(g5, tmp_path):
         else:
             got = params[k[:-len(".norm")]].grad.double().norm().item()
             assert got == pytest.approx(float(v), rel=2e-4, abs=1e-6), k
+
+
+# ------------------------------------------------------------------ frame-context GRU (cvc/gru.py, cvc_gru_seq_fwd)
+def _gru(inp, H, layers, bidir, seed):
+    torch.manual_seed(seed)
+    g = torch.nn.GRU(inp, H, layers, dropout=0.2 if layers > 1 else 0.0, bidirectional=bidir, batch_first=True).eval()
+    with torch.no_grad():
+        for p in g.parameters():
+            p.mul_(1.5)                      # wider gate pre-activations than the default init gives
+    return g
+
+
+@pytest.mark.parametrize("B,F,inp,H,layers,bidir", [(3, 5, 32, 16, 2, True), (5, 9, 24, 40, 1, False), (4, 6, 64, 32, 3, True)])
+def test_oracle_gru_restatement_matches_the_library_module(B, F, inp, H, layers, bidir):
+    """oracle.gru_sequence (the step-by-step restatement the GPU kernel is checked against) == nn.GRU, the module the
+    reference calls (backbone.py:103-106, 335-338)."""
+    from oracle import ref_cpu as O
+    g = _gru(inp, H, layers, bidir, 3)
+    x = torch.randn(B, F, inp)
+    with torch.no_grad():
+        want = g(x)[0]
+        got = O.gru_sequence(x, dict(g.named_parameters()), layers, bidir)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_gru_weight_pack_layout():
+    from cvc.gru import pack_gru_weights
+    H = 40
+    w = torch.arange(3 * H * H, dtype=torch.float32).view(3 * H, H)
+    p = pack_gru_weights(w, H)                                   # [H/8][Kp/4][32][4]
+    assert p.shape == (H // 8, 64 // 4, 32, 4)
+    for blk, q, i, e in ((0, 0, 0, 0), (2, 3, 9, 1), (4, 9, 23, 3), (1, 5, 17, 2)):
+        gate, unit, k = i >> 3, blk * 8 + (i & 7), 4 * q + e
+        assert float(p[blk, q, i, e]) == float(w[gate * H + unit, k])
+    assert float(p[:, :, 24:].abs().max()) == 0 and float(p[:, H // 4:].abs().max()) == 0      # zero fourth gate, zero K padding
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,F,inp,H,layers,bidir", [(3, 5, 32, 16, 2, True), (64, 20, 256, 128, 2, True), (70, 7, 48, 40, 1, False),
+                                                    (33, 11, 100, 72, 2, True)])
+def test_gru_hip_vs_oracle(B, F, inp, H, layers, bidir):
+    """cvc.gru.gru_forward (tile GEMM input projections + one packed-GEMM GRU launch per step, both directions) against the
+    CPU oracle; more than 64 clips run in chunks; bitwise run-to-run determinism."""
+    from oracle import ref_cpu as O
+    from cvc import gru as G
+    g = _gru(inp, H, layers, bidir, 5)
+    x = torch.randn(B, F, inp)
+    with torch.no_grad():
+        want = O.gru_sequence(x, dict(g.named_parameters()), layers, bidir)
+        gd = g.to("cuda:0")
+        assert G.supported(gd, x.cuda())
+        got = G.gru_forward(gd, x.cuda())
+        again = G.gru_forward(gd, x.cuda())
+    assert torch.equal(got, again)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.gpu
+def test_gru_hip_full_size_vs_library_cpu():
+    """Config-2 encoder size (B=64 clips, F=480 frames, R=2048 -> H=1024, 2 layers, bidirectional): HIP path against nn.GRU
+    on the host CPU (the module the reference calls)."""
+    from cvc import gru as G
+    g = _gru(2048, 1024, 2, True, 7)
+    x = torch.randn(64, 480, 2048)
+    with torch.no_grad():
+        want = g(x)[0]
+        got = G.gru_forward(g.to("cuda:0"), x.cuda()).cpu()
+    err = (got - want).abs().max().item()
+    assert err < 5e-5, err
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=5e-5)
