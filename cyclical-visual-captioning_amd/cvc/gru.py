@@ -4,8 +4,12 @@
 The reference hands the whole recurrence to cuDNN; on ROCm the same module runs in MIOpen (79 of the encoder's 84 ms at
 config 2).  Here a layer is
   1. ONE dense GEMM for the input projections of all F steps and both directions (the tile GEMM, csrc/gemm_tile.hip), and
-  2. F launches of the packed gate-GEMM kernel in its GRU form (cvc_gru_seq_fwd, csrc/gemm_packed.hip): W_hh of both
-     directions (25 MB at H = 1024) stays in the Infinity Cache between steps, the state ping-pongs in the quad layout.
+  2. the recurrence, in one of two forms with identical results:
+     - persistent (cvc_gru_seq_persistent_fwd, csrc/gru_persistent.hip; H % 128 == 0, H <= 1024): one cooperative launch
+       for the whole sequence, W_hh held in registers, steps separated by a barrier in device memory;
+     - per step (cvc_gru_seq_fwd, csrc/gemm_packed.hip): F launches of the packed gate-GEMM kernel in its GRU form, W_hh of
+       both directions (25 MB at H = 1024) re-read from the Infinity Cache every step -- any H % 8 == 0, and the fallback
+       when the persistent form cannot run or reports a barrier time-out.
 Inference only (eval mode, h0 = 0, no inter-layer dropout): the training pass keeps the library module, whose backward
 autograd needs."""
 from __future__ import annotations
@@ -19,6 +23,9 @@ from . import hip
 from .decode import pack_weights
 
 _packs: Dict[int, Tuple[tuple, list]] = {}
+
+PERSISTENT = True       # False: always the per-step form (A/B switch)
+last_form = None        # "persistent" / "steps": which form produced the last layer (tests, bench)
 
 
 def pack_gru_weights(w_hh: torch.Tensor, H: int) -> torch.Tensor:
@@ -79,8 +86,18 @@ def gru_forward(gru: nn.GRU, x: torch.Tensor) -> torch.Tensor:
             else:
                 y = torch.empty(F * m, ndir * H, device=x.device, dtype=torch.float32)
                 ld_m, ld_t = ndir * H, m * ndir * H
-            hip._check(L.cvc_gru_seq_fwd(wp.data_ptr(), gi.data_ptr(), ndir * 3 * H, m * ndir * 3 * H, b_ih.data_ptr(),
-                                         b_hh.data_ptr(), m, F, H, ndir, hq.data_ptr(), y.data_ptr(), ld_m, ld_t, st),
-                       "cvc_gru_seq_fwd")
+            args = (wp.data_ptr(), gi.data_ptr(), ndir * 3 * H, m * ndir * 3 * H, b_ih.data_ptr(), b_hh.data_ptr(), m, F, H, ndir,
+                    hq.data_ptr(), y.data_ptr(), ld_m, ld_t)
+            done = False
+            if PERSISTENT and H % 128 == 0 and H <= 1024:
+                sync = torch.zeros(4, device=x.device, dtype=torch.int32)
+                slots = torch.empty((F + 1) * ndir * H * 64, device=x.device, dtype=torch.float32)     # one state slot per step
+                pargs = args[:10] + (slots.data_ptr(),) + args[11:]
+                if L.cvc_gru_seq_persistent_fwd(*pargs, sync.data_ptr(), st) == 0:
+                    done = int(sync[2]) == 0          # (host sync) a barrier time-out leaves the error word set: redo per step
+            if not done:
+                hip._check(L.cvc_gru_seq_fwd(*args, st), "cvc_gru_seq_fwd")
+            global last_form
+            last_form = "persistent" if done else "steps"
             cur = y
     return out

@@ -197,10 +197,11 @@ def test_gru_weight_pack_layout():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,F,inp,H,layers,bidir", [(3, 5, 32, 16, 2, True), (64, 20, 256, 128, 2, True), (70, 7, 48, 40, 1, False),
-                                                    (33, 11, 100, 72, 2, True)])
+                                                    (33, 11, 100, 72, 2, True), (20, 33, 64, 384, 2, True), (64, 17, 96, 256, 1, False)])
 def test_gru_hip_vs_oracle(B, F, inp, H, layers, bidir):
-    """cvc.gru.gru_forward (tile GEMM input projections + one packed-GEMM GRU launch per step, both directions) against the
-    CPU oracle; more than 64 clips run in chunks; bitwise run-to-run determinism."""
+    """cvc.gru.gru_forward (tile GEMM input projections + the recurrence in its persistent and its per-step form) against the
+    CPU oracle and against each other; more than 64 clips run in chunks;
+    bitwise run-to-run determinism."""
     from oracle import ref_cpu as O
     from cvc import gru as G
     g = _gru(inp, H, layers, bidir, 5)
@@ -210,9 +211,19 @@ def test_gru_hip_vs_oracle(B, F, inp, H, layers, bidir):
         gd = g.to("cuda:0")
         assert G.supported(gd, x.cuda())
         got = G.gru_forward(gd, x.cuda())
+        assert G.last_form == ("persistent" if H % 128 == 0 else "steps")
         again = G.gru_forward(gd, x.cuda())
+        G.PERSISTENT = False
+        try:
+            steps = G.gru_forward(gd, x.cuda())
+            assert G.last_form == "steps"
+        finally:
+            G.PERSISTENT = True
     assert torch.equal(got, again)
     np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(steps.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
+    # (the two forms split K over 4 and 8 waves: same products, different fp32 summation order)
+    np.testing.assert_allclose(got.cpu().numpy(), steps.cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
 @pytest.mark.gpu

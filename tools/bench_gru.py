@@ -1,0 +1,52 @@
+"""Per-step time of cvc_gru_seq_fwd (the recurrent half of the encoder's GRU) over shapes / split modes."""
+import sys, torch
+sys.path.insert(0, "cyclical-visual-captioning_amd")
+from cvc import hip
+from cvc.gru import pack_gru_weights
+
+dev = torch.device("cuda:0")
+L = hip.lib()
+st = torch.cuda.current_stream().cuda_stream
+
+
+def run(M, H, ndir, F=240, mode=2):
+    hip.gemm_packed_split(mode)
+    wp = torch.stack([pack_gru_weights(torch.randn(3 * H, H, device=dev) / H ** 0.5, H) for _ in range(ndir)])
+    gi = torch.randn(F * M, ndir * 3 * H, device=dev)
+    b1, b2 = torch.randn(ndir, 3 * H, device=dev) * 0.1, torch.randn(ndir, 3 * H, device=dev) * 0.1
+    Kp = (H + 31) // 32 * 32
+    hq = torch.empty(2 * ndir * Kp * 64, device=dev)
+    y = torch.empty(F * M, ndir * H, device=dev)
+    sync = torch.zeros(4, device=dev, dtype=torch.int32)
+    slots = torch.empty((F + 1) * ndir * Kp * 64, device=dev)
+    def go_p():
+        rc = L.cvc_gru_seq_persistent_fwd(wp.data_ptr(), gi.data_ptr(), ndir * 3 * H, M * ndir * 3 * H, b1.data_ptr(), b2.data_ptr(), M, F, H, ndir,
+                               slots.data_ptr(), y.data_ptr(), ndir * H, M * ndir * H, sync.data_ptr(), st)
+        return rc
+    if H % 128 == 0 and H <= 1024 and mode == 2:
+        rc = go_p(); torch.cuda.synchronize()
+        if rc == 0 and int(sync[2]) == 0:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); go_p(); go_p(); e1.record(); torch.cuda.synchronize()
+            print(f"M={M:3d} H={H:5d} ndir={ndir} persistent: {e0.elapsed_time(e1) * 1e3 / (2 * F):6.2f} us/step  err={int(sync[2])}", flush=True)
+        else:
+            print("persistent form unavailable", rc, int(sync[2]))
+    def go():
+        rc = L.cvc_gru_seq_fwd(wp.data_ptr(), gi.data_ptr(), ndir * 3 * H, M * ndir * 3 * H, b1.data_ptr(), b2.data_ptr(), M, F, H, ndir,
+                               hq.data_ptr(), y.data_ptr(), ndir * H, M * ndir * H, st)
+        assert rc == 0
+    go(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); go(); go(); e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / (2 * F)
+    print(f"M={M:3d} H={H:5d} ndir={ndir} mode={mode}: {us:6.2f} us/step", flush=True)
+    hip.gemm_packed_split(2)
+
+
+for mode in (2, 1, 0):
+    run(64, 1024, 2, mode=mode)
+run(32, 1024, 2)
+run(64, 1024, 1)
+run(64, 512, 2)
+run(64, 2048, 2)
+run(16, 1024, 2)
