@@ -1,5 +1,5 @@
 # Collects the round's measured evidence into gpurun_out/prof/ (copy the summaries into profiles/ afterwards):
-#   bench lines (greedy default, driver-style 20 steps, beam 5, cfg5 greedy, train), rocprofv3 kernel-trace summaries of the same
+#   bench lines (greedy default, driver-style 20 steps, beam 5, cfg5 greedy, train, encoder), rocprofv3 kernel-trace summaries of the same
 #   commands, and the FETCH_SIZE / WRITE_SIZE PMC passes (separate runs, --kernel-trace only) that tools/collect_traffic.py
 #   turns into profiles/traffic.json.
 TAG=${1:-r02}
@@ -7,23 +7,6 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof
 mkdir -p $O
-python3 $R/bench.py > $O/bench_${TAG}_greedy.json 2> $O/bench_greedy.err
-python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_${TAG}_greedy_20steps.json 2>> $O/bench_greedy.err
-python3 $R/bench.py --beam 5 --steps 50 --warmup 3 > $O/bench_${TAG}_beam5.json 2> $O/bench_beam.err
-python3 $R/bench.py --config cfg5 --steps 50 --warmup 3 --no-cpu-baseline > $O/bench_${TAG}_cfg5_greedy.json 2> $O/bench_cfg5.err
-python3 $R/bench.py --config cfg5 --beam 5 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_${TAG}_cfg5_beam5.json 2>> $O/bench_cfg5.err
-python3 $R/bench.py --mode train --config cfg3 --steps 30 --warmup 3 > $O/bench_${TAG}_train.json 2> $O/bench_train.err
-for what in greedy beam5 train; do
-  case $what in
-    greedy) ARGS="--steps 20 --warmup 3 --no-cpu-baseline";;
-    beam5) ARGS="--beam 5 --steps 6 --warmup 2 --no-cpu-baseline";;
-    train) ARGS="--mode train --config cfg3 --steps 8 --warmup 2 --no-cpu-baseline";;
-  esac
-  rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python3 $R/bench.py $ARGS > $O/kt_$what.log 2>&1
-  DB=$(find $O/kt -name "*.db" | head -1)
-  python3 $R/tools/rocpd_summary.py $DB > $O/${TAG}_${what}_kernel_stats.md 2>&1
-  rm -rf $O/kt
-done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_f -o f -- python3 $R/bench.py --no-graph --steps 4 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_w -o w -- python3 $R/bench.py --no-graph --steps 4 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1
 FDB=$(find $O/pmc_f -name "*.db" | head -1); WDB=$(find $O/pmc_w -name "*.db" | head -1)
@@ -32,6 +15,27 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_
 MDB=$(find $O/pmc_m -name "*.db" | head -1)
 python3 $R/tools/rocpd_pmc.py $MDB > $O/${TAG}_pmc_mfma_busy.md 2>&1
 rm -rf $O/pmc_f $O/pmc_w $O/pmc_m
+# the bench lines below read this build's traffic (bench.py refuses a traffic.json whose kernel-source hash is not the build's)
+cp $O/traffic.json $R/profiles/traffic.json
+python3 $R/bench.py > $O/bench_${TAG}_greedy.json 2> $O/bench_greedy.err
+python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_${TAG}_greedy_20steps.json 2>> $O/bench_greedy.err
+python3 $R/bench.py --beam 5 --steps 50 --warmup 3 > $O/bench_${TAG}_beam5.json 2> $O/bench_beam.err
+python3 $R/bench.py --config cfg5 --steps 50 --warmup 3 --no-cpu-baseline > $O/bench_${TAG}_cfg5_greedy.json 2> $O/bench_cfg5.err
+python3 $R/bench.py --config cfg5 --beam 5 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_${TAG}_cfg5_beam5.json 2>> $O/bench_cfg5.err
+python3 $R/bench.py --mode train --config cfg3 --steps 30 --warmup 3 > $O/bench_${TAG}_train.json 2> $O/bench_train.err
+python3 $R/bench.py --mode encoder --steps 10 --warmup 2 > $O/bench_${TAG}_encoder.json 2> $O/bench_encoder.err
+for what in greedy beam5 train encoder; do
+  case $what in
+    greedy) ARGS="--steps 20 --warmup 3 --no-cpu-baseline";;
+    beam5) ARGS="--beam 5 --steps 6 --warmup 2 --no-cpu-baseline";;
+    train) ARGS="--mode train --config cfg3 --steps 8 --warmup 2 --no-cpu-baseline";;
+    encoder) ARGS="--mode encoder --steps 3 --warmup 1";;
+  esac
+  rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python3 $R/bench.py $ARGS > $O/kt_$what.log 2>&1
+  DB=$(find $O/kt -name "*.db" | head -1)
+  python3 $R/tools/rocpd_summary.py $DB > $O/${TAG}_${what}_kernel_stats.md 2>&1
+  rm -rf $O/kt
+done
 ls -la $O | head -40
 head -c 700 $O/bench_${TAG}_greedy.json; echo
 for f in beam5 cfg5_greedy cfg5_beam5 train; do python3 -c "
