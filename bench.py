@@ -54,7 +54,7 @@ def parse():
                    help="decode = headline metric (default); train = cyclical fwd+bwd+all-reduce+Adam step (configs 3-ii / 4); "
                         "encoder = the once-per-clip region / frame encoder (SURVEY 8(f) rank 1, library ops) per piece")
     p.add_argument("--no-graph", action="store_true")
-    p.add_argument("--gate-ksplit", type=int, default=None, choices=[0, 1],
+    p.add_argument("--gate-ksplit", type=int, default=None, choices=[0, 1, 2],
                    help="packed path: 1 = K-split gate GEMMs (activations shared through LDS + finishing kernel), 0 = full-K "
                         "kernel; default = cvc.decode.GATE_KSPLIT_DEFAULT")
     p.add_argument("--train-graph", action="store_true", help="--mode train: capture the whole training step in a HIP graph")
@@ -400,7 +400,7 @@ def main():
     W = DecodeWeights({k: torch.from_numpy(v).to(dev) for k, v in sd_np.items()})
     feats = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in feats_np.items()}
     eng = DecodeEngine(W, feats, d.T, synth.UNK_IDX, beam=args.beam,
-                       gate_ksplit=None if args.gate_ksplit is None else bool(args.gate_ksplit))
+                       gate_ksplit=None if args.gate_ksplit is None else (bool(args.gate_ksplit) if args.gate_ksplit < 2 else "fused"))
     from cvc import hip as _hip
     gemm_mode = _hip.gemm_packed_split(-1)
     if not args.no_graph:

@@ -28,6 +28,12 @@ struct KsArgs {
     int nblk;            // R / 8 (multiple of 8)
     int ksplit;
     float* slab;         // [ksplit][nblk][64][32]
+    // fused finish (cvc_packed_lstm_ksf_fwd): the last K slice of a 256-row tile to arrive sums the tile's slabs and does the
+    // cell update in place of a finishing launch
+    unsigned* counters;  // [R / 64] arrival counters, zero between launches (the last arriver resets its tile's)
+    const float* b_ih; const float* b_hh; const float* gate_bias; const float* c_prev_q;
+    float* c_out_q; float* h_dst1_q; float* h_dst2_q;
+    int M, R;
 };
 
 using u16x4 = __attribute__((ext_vector_type(4))) uint16_t;
@@ -56,13 +62,25 @@ __device__ __forceinline__ void stage_x(char* stage, const f32x4 v, int wave, in
     for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u16x4*>(base + pl * 1024) = p[pl];
 }
 
+template <int NS> __device__ __forceinline__ void ks_finish_item(const KsArgs& a, int blk, int m, int hq);
+
+// FUSED_NS = 0: partial tiles only (a finishing launch follows); > 0: that many K slices, fused finish
+template <int FUSED_NS>
 __global__ __launch_bounds__(512) void packed_ks_kernel(KsArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[2 * XSTAGE];
+    __shared__ int last_arrival;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, kh = lane >> 5;
     const int S = a.ksplit;
-    const int ks = (int)blockIdx.x % S, tile = (int)blockIdx.x / S;
+    int ks = (int)blockIdx.x % S, tile = (int)blockIdx.x / S;
+    if (FUSED_NS > 0 && ((a.nblk >> 3) & 7) == 0) {
+        // all K slices of a tile on ONE XCD (workgroup x runs on XCD x % 8): the slabs the last arriver sums are then in its
+        // own L2.  Only a placement hint -- correctness rests on the write-through stores and the arrival counter below.
+        const int x = (int)blockIdx.x, l = x >> 3;
+        ks = l % S;
+        tile = (l / S) * 8 + (x & 7);
+    }
     const int blk = tile * 8 + wave;
     const int nchunk_all = a.nquad >> 3;
     const int c_lo = nchunk_all * ks / S, c_hi = nchunk_all * (ks + 1) / S;
@@ -133,15 +151,82 @@ __global__ __launch_bounds__(512) void packed_ks_kernel(KsArgs a) {
 
     // partial tile -> slab[ks][blk][m][row]: row = e + 8 rq + 4 kh for register 4 rq + e, so a lane stores float4s
     float* out = a.slab + (((size_t)ks * a.nblk + blk) * 64) * 32;
+    if constexpr (FUSED_NS > 0) {
+        // the stores below are inline assembly and the compiler's hazard recognizer does not look inside: the wait for the
+        // last MFMAs' results is spelled out here, and every store carries its own "s_nop 1" (a store of more than 8 bytes
+        // followed by a write to its data registers needs wait states -- without them some lanes stored address bits)
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int m = mt * 32 + i;
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
             const f32x4 v = {acc[mt][4 * rq], acc[mt][4 * rq + 1], acc[mt][4 * rq + 2], acc[mt][4 * rq + 3]};
-            st4(out + (size_t)m * 32 + 8 * rq + 4 * kh, v);
+            if constexpr (FUSED_NS > 0) {
+                // straight through L2 to memory: visible to whichever workgroup arrives last, without a write-back fence
+                // (buffer_wbl2 walks the whole L2: measured 30 us per use in csrc/gru_persistent.hip)
+                float* pp = out + (size_t)m * 32 + 8 * rq + 4 * kh;
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(pp), "v"(v) : "memory");
+            } else {
+                st4(out + (size_t)m * 32 + 8 * rq + 4 * kh, v);
+            }
         }
     }
+    if constexpr (FUSED_NS > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                                  // every wave's slab rows are acknowledged
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(a.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last_arrival = old == (unsigned)(S - 1);
+            if (old == (unsigned)(S - 1)) __hip_atomic_store(a.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!last_arrival) return;
+        // the tile's 8 blocks x 64 batch rows x 2 hidden quads: wave = block, two items per lane; slabs summed in slice order
+        // whichever slice arrived last (these addresses were last read before this kernel started: no stale cache lines)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int t = lane + 64 * it;
+            ks_finish_item<FUSED_NS>(a, blk, t >> 1, t & 1);
+        }
+    }
+}
+
+template <int NS>
+__device__ __forceinline__ void ks_finish_item(const KsArgs& a, int blk, int m, int hq) {
+    if (m >= a.M) return;
+    const int R = a.R;
+    const int j = blk * 8 + hq * 4;
+    f32x4 pre[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float* p = a.slab + (((size_t)blk * 64 + m) * 32) + g * 8 + hq * 4;
+        f32x4 v[NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) v[k] = ld4(p + (size_t)k * a.nblk * 64 * 32);
+        f32x4 s = v[0];
+#pragma unroll
+        for (int k = 1; k < NS; ++k) s += v[k];
+        if (a.b_ih != nullptr) s += ld4(a.b_ih + g * R + j);
+        if (a.b_hh != nullptr) s += ld4(a.b_hh + g * R + j);
+        if (a.gate_bias != nullptr) s += ld4(a.gate_bias + (size_t)m * 4 * R + g * R + j);
+        pre[g] = s;
+    }
+    const size_t qoff = ((size_t)(j >> 2) * 64 + m) * 4;
+    const f32x4 cp = ld4(a.c_prev_q + qoff);
+    f32x4 hv, cv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float ig = fast_sigmoid(pre[0][e]), fg = fast_sigmoid(pre[1][e]);
+        const float gg = fast_tanh(pre[2][e]), og = fast_sigmoid(pre[3][e]);
+        const float c2 = fg * cp[e] + ig * gg;
+        cv[e] = c2;
+        hv[e] = og * fast_tanh(c2);
+    }
+    st4(a.c_out_q + qoff, cv);
+    if (a.h_dst1_q != nullptr) st4(a.h_dst1_q + qoff, hv);
+    if (a.h_dst2_q != nullptr) st4(a.h_dst2_q + qoff, hv);
 }
 
 struct KsFinishArgs {
@@ -209,11 +294,11 @@ extern "C" int cvc_packed_lstm_ks_fwd(const float* wp, const float* xq, int K, c
     if (!wp || !xq || !c_prev_q || !c_out_q || !slab || M < 1 || M > 64) return CVC_E_BADARG;
     const int S = cvc_packed_lstm_ks_slices(K, R);
     if (S < 1) return CVC_E_BADARG;
-    KsArgs a;
+    KsArgs a{};
     a.wp = wp; a.xq = xq; a.nquad = K / 4; a.nblk = R / 8; a.ksplit = S; a.slab = slab;
     a.wstride = w_blk_stride > 0 ? w_blk_stride : (long long)(K / 4) * 128;
     if (a.wstride < (long long)(K / 4) * 128 || (a.wstride & 3)) return CVC_E_BADARG;
-    hipLaunchKernelGGL(packed_ks_kernel, dim3((R / 64) * S), dim3(512), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(packed_ks_kernel<0>, dim3((R / 64) * S), dim3(512), 0, (hipStream_t)stream, a);
     int rc = cvc_launch_status();
     if (rc) return rc;
     KsFinishArgs f;
@@ -225,6 +310,33 @@ extern "C" int cvc_packed_lstm_ks_fwd(const float* wp, const float* xq, int K, c
         case 4: hipLaunchKernelGGL(packed_ks_finish_kernel<4>, g, dim3(128), 0, (hipStream_t)stream, f); break;
         case 2: hipLaunchKernelGGL(packed_ks_finish_kernel<2>, g, dim3(128), 0, (hipStream_t)stream, f); break;
         default: hipLaunchKernelGGL(packed_ks_finish_kernel<1>, g, dim3(128), 0, (hipStream_t)stream, f); break;
+    }
+    return cvc_launch_status();
+}
+
+// K-split gate GEMM with the finish fused into its last-arriving slice: same operands and results as cvc_packed_lstm_ks_fwd, one
+// launch.  counters: R / 64 words of device memory, zero before the first use (every launch leaves them zero).
+// Measured (cfg2, in the decode graph): lang / att 62.9 / 57.5 us against 53.1 / 46.0 for the two-launch form and 52.0 / 43.9
+// for the full-K kernel -- the finish of a tile is 14 us when ONE workgroup (the last arriver) does it (32 workgroups busy, 224
+// idle, 64 dependent-latency loads per thread) against 7.4 us for the chip-wide finishing launch; placing a tile's slices on one
+// XCD matters (without it 33 us: the slabs then come over the fabric), write-through vs ordinary stores is 3 us.  Kept
+// selectable (DecodeEngine(gate_ksplit="fused")) and tested; not the default.
+extern "C" int cvc_packed_lstm_ksf_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
+                                       const float* gate_bias, const float* c_prev_q, int M, int R, float* h_dst1_q,
+                                       float* h_dst2_q, float* c_out_q, float* slab, unsigned* counters, cvc_stream_t stream) {
+    if (!wp || !xq || !c_prev_q || !c_out_q || !slab || !counters || M < 1 || M > 64) return CVC_E_BADARG;
+    const int S = cvc_packed_lstm_ks_slices(K, R);
+    if (S < 1) return CVC_E_BADARG;
+    KsArgs a{};
+    a.wp = wp; a.xq = xq; a.nquad = K / 4; a.nblk = R / 8; a.ksplit = S; a.slab = slab; a.wstride = (long long)(K / 4) * 128;
+    a.counters = counters; a.b_ih = b_ih; a.b_hh = b_hh; a.gate_bias = gate_bias; a.c_prev_q = c_prev_q;
+    a.c_out_q = c_out_q; a.h_dst1_q = h_dst1_q; a.h_dst2_q = h_dst2_q; a.M = M; a.R = R;
+    const dim3 g((R / 64) * S);
+    switch (S) {
+        case 8: hipLaunchKernelGGL(packed_ks_kernel<8>, g, dim3(512), 0, (hipStream_t)stream, a); break;
+        case 4: hipLaunchKernelGGL(packed_ks_kernel<4>, g, dim3(512), 0, (hipStream_t)stream, a); break;
+        case 2: hipLaunchKernelGGL(packed_ks_kernel<2>, g, dim3(512), 0, (hipStream_t)stream, a); break;
+        default: hipLaunchKernelGGL(packed_ks_kernel<1>, g, dim3(512), 0, (hipStream_t)stream, a); break;
     }
     return cvc_launch_status();
 }

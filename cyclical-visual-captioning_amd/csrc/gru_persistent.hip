@@ -201,9 +201,10 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruPArgs a) {
                 hv[e] = ng + zg * (ehp[e] - ng);
             }
             // the state goes straight through this XCD's L2 to memory (sc0 sc1): a release fence would instead walk the whole
-            // L2 for dirty lines (buffer_wbl2) once per workgroup and step
+            // L2 for dirty lines (buffer_wbl2) once per workgroup and step.  (Inline assembly is invisible to the compiler's
+            // hazard recognizer: the s_nop covers "wide store followed by a write to its data registers".)
             float* hp = hnext + eqoff;
-            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(hp), "v"(hv) : "memory");
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(hp), "v"(hv) : "memory");
             st4(a.y + (size_t)em * a.y_ld_m + t * a.y_ld_t + (size_t)dir * H + ejq, hv);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }

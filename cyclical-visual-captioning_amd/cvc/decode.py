@@ -238,7 +238,10 @@ class DecodeEngine:
         self._keep: List = []
         self.packed = self.beam == 1 and rows <= 64 and R % 32 == 0 and W.E % 32 == 0 and A % 32 == 0
         # packed path: K-split gate GEMMs (activations shared through LDS, csrc/gemm_packed_ks.hip) where the shape allows
-        self.gate_ksplit = GATE_KSPLIT_DEFAULT if gate_ksplit is None else bool(gate_ksplit)
+        # (True: partial tiles + a finishing launch; "fused": the last-arriving K slice of a tile finishes it in the same launch)
+        self.gate_ksplit = GATE_KSPLIT_DEFAULT if gate_ksplit is None else gate_ksplit
+        self.gate_fused = self.gate_ksplit == "fused"
+        self.gate_ksplit = bool(self.gate_ksplit)
         # more than 64 live rows (beam search, big greedy batches): bf16-fragment tile GEMMs (csrc/gemm_tile.hip)
         self.tile = (not self.packed) and (self.beam > 1 or rows > 64) and R % 16 == 0 and W.E % 16 == 0 and path != "ring"
         self._plan = None
@@ -340,6 +343,7 @@ class DecodeEngine:
             W.p_lang_ks = pack_weights(torch.cat([W.w_ih_lang, W.w_hh_lang], 1), R, self.ks_pad)
         if self.ks_att or self.ks_lang:
             self.gate_slab = torch.empty(max(self.ks_att, self.ks_lang) * (R // 8) * 2048, device=dev, dtype=torch.float32)
+            self.gate_counters = torch.zeros(R // 64, device=dev, dtype=torch.int32)
 
     def _build_packed(self):
         L, W = hip.lib(), self.W
@@ -356,7 +360,11 @@ class DecodeEngine:
         for t in range(self.T):
             rd, wr = t & 1, (t + 1) & 1
             XA_r, XA_w, XL_r, XL_w = self.XA[rd], self.XA[wr], self.XL[rd], self.XL[wr]
-            if self.ks_att:
+            if self.ks_att and self.gate_fused:
+                out.append(("att_lstm", L.cvc_packed_lstm_ksf_fwd, (ptr(W.p_att), ptr(XA_r), 2 * R + E, None, None, ptr(self.gate_fc),
+                                                                    ptr(self.cA[rd]), rows, R, qoff(XL_r, R), qoff(XA_w, R + E),
+                                                                    ptr(self.cA[wr]), ptr(self.gate_slab), ptr(self.gate_counters))))
+            elif self.ks_att:
                 wp_att = W.p_att_ks if self.ks_pad else W.p_att
                 out.append(("att_lstm", L.cvc_packed_lstm_ks_fwd, (ptr(wp_att), ptr(XA_r), 2 * R + E, None, None, ptr(self.gate_fc),
                                                                    ptr(self.cA[rd]), rows, R, qoff(XL_r, R), qoff(XA_w, R + E),
@@ -375,7 +383,12 @@ class DecodeEngine:
             out.append(("attn_scores", L.cvc_attn_scores_qparts, (W.kind, ptr(self.q_parts), self.QSPLIT, ptr(W.b_h), ptr(W.w_a),
                                                                   ptr(W.b_a), self.inv_temp, sets, 2, B, 1, A)))
             out.append(("attn_wsum", L.cvc_attn_wsum_quad, (sets, 2, B, 1, R, ptr(XL_r))))
-            if self.ks_lang:
+            if self.ks_lang and self.gate_fused:
+                out.append(("lang_lstm", L.cvc_packed_lstm_ksf_fwd, (ptr(W.p_lang), ptr(XL_r), 3 * R, ptr(W.b_ih_lang),
+                                                                     ptr(W.b_hh_lang), None, ptr(self.cL[rd]), rows, R, ptr(XA_w),
+                                                                     qoff(XL_w, 2 * R), ptr(self.cL[wr]), ptr(self.gate_slab),
+                                                                     ptr(self.gate_counters))))
+            elif self.ks_lang:
                 wp_lang = W.p_lang_ks if self.ks_pad else W.p_lang
                 out.append(("lang_lstm", L.cvc_packed_lstm_ks_fwd, (ptr(wp_lang), ptr(XL_r), 3 * R, ptr(W.b_ih_lang),
                                                                     ptr(W.b_hh_lang), None, ptr(self.cL[rd]), rows, R, ptr(XA_w),

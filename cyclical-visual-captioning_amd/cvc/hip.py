@@ -74,6 +74,7 @@ SIGNATURES = {
     "cvc_gru_seq_persistent_fwd": [_P, _P, _LL, _LL, _P, _P, _I, _I, _I, _I, _P, _P, _LL, _LL, _P, _P],
     "cvc_packed_lstm_ks_slices": [_I, _I],
     "cvc_packed_lstm_ks_fwd": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _LL, _P],
+    "cvc_packed_lstm_ksf_fwd": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     "cvc_attn_wsum": [C.POINTER(AttnSet), _I, _I, _I, _I, _P, _P],
     "cvc_attn_bwd": [_I, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "cvc_linear_fwd": [C.POINTER(GemmSeg), _I, _P, _P, _I, _I, _P, _I, _P],

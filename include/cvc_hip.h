@@ -201,6 +201,13 @@ int cvc_packed_lstm_ks_slices(int K, int R);
 int cvc_packed_lstm_ks_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
                            const float* gate_bias, const float* c_prev_q, int M, int R, float* h_dst1_q,
                            float* h_dst2_q, float* c_out_q, float* slab, long long w_blk_stride, cvc_stream_t stream);
+/* The same with the finish fused into the GEMM launch: partial tiles are stored write-through, the K slices of a 256-row tile
+ * count their arrivals in counters[tile] and the LAST one sums the tile's slabs in slice order and does the cell update
+ * (deterministic: the order of the sum does not depend on who arrives last).  counters: R / 64 words of device memory, zero
+ * before the first use; every launch leaves them zero.  Dense weight pack (no block stagger). */
+int cvc_packed_lstm_ksf_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
+                            const float* gate_bias, const float* c_prev_q, int M, int R, float* h_dst1_q,
+                            float* h_dst2_q, float* c_out_q, float* slab, unsigned* counters, cvc_stream_t stream);
 
 /* Packed path arithmetic.  mode 2 (default) / 1: every fp32 operand is split exactly into three bf16 terms
  * (v = hi + mid + lo) and each product taken as its six leading cross terms on the bf16 MFMA, fp32

@@ -413,6 +413,23 @@ def test_packed_lstm_ksplit_equals_full_k_kernel(dev, lib, M, R, E):
         outs.append((from_quad(h1, M), from_quad(h2, M), from_quad(c2, M)))
     (hf, _, cf), (hk, hk2, ck), (hk_b, _, ck_b) = outs
     assert torch.equal(hk, hk2) and torch.equal(hk, hk_b) and torch.equal(ck, ck_b)
+    # finish fused into the GEMM launch (last-arriving K slice sums the slabs in slice order): the two-launch form's result up
+    # to the contraction of the cell arithmetic (1 ulp), the same bits launch after launch whichever slice arrives last, and
+    # the arrival counters back at zero
+    counters = torch.zeros(R // 64, dtype=torch.int32, device=dev)
+    slab = torch.empty(S * (R // 8) * 2048, device=dev)
+    for _ in range(5):
+        h1, h2, c2 = torch.zeros(R // 4, 64, 4, device=dev), torch.zeros(R // 4, 64, 4, device=dev), torch.zeros(R // 4, 64, 4, device=dev)
+        rc = L.cvc_packed_lstm_ksf_fwd(wp.data_ptr(), xq.data_ptr(), K, b1.data_ptr(), b2.data_ptr(), gb.data_ptr(), cq.data_ptr(), M, R,
+                                       h1.data_ptr(), h2.data_ptr(), c2.data_ptr(), slab.data_ptr(), counters.data_ptr(), st)
+        assert rc == 0
+        got = (from_quad(h1, M), from_quad(h2, M), from_quad(c2, M))
+        close(got[0], hk, rtol=1e-6, atol=1e-6); close(got[2], ck, rtol=1e-6, atol=1e-6)
+        assert torch.equal(got[0], got[1])
+        if _ > 0:
+            assert torch.equal(got[0], first[0]) and torch.equal(got[2], first[2])
+        first = got
+        assert int(counters.abs().sum()) == 0
     close(hk, hf, rtol=2e-5, atol=2e-5); close(ck, cf, rtol=2e-5, atol=2e-5)
     pre = x.double() @ w.double().t() + b1.double() + b2.double() + gb.double()
     i, f, gg, o = pre.chunk(4, 1)
@@ -793,6 +810,28 @@ def test_cabi_decode_driver_equals_python_launch_list(dev, lib, B, beam, dims):
     a2 = [x.clone() for x in e_drv.capture().run()]
     assert all(torch.equal(x, y) for x, y in zip(a, a2))
     assert all(torch.equal(x, y) for x, y in zip(a, e_drv.run()))          # replay again: state is reset inside the driver
+
+
+@pytest.mark.parametrize("form", [True, "fused"])
+def test_decode_with_ksplit_gate_gemms_equals_default_engine(dev, lib, form):
+    """Greedy decode with the K-split gate GEMMs (two-launch form and finish fused into the last-arriving slice,
+    csrc/gemm_packed_ks.hip) against the default full-K engine: same word sequences, attention within the recurrent
+    tolerance, eager == captured graph replayed twice (the fused form's arrival counters come back to zero)."""
+    from helpers import to_dev
+    from cvc.decode import DecodeEngine, DecodeWeights
+    d = dataclasses.replace(synth.CONFIGS["tiny"], B=64, N=20, F=12, R=256, A=64, E=64, V=300, T=6)
+    sd, f_np = synth.hot_path_state_dict(d, 55), synth.clip_features(d, 55)
+    W, f = DecodeWeights(to_dev(sd, dev)), to_dev(f_np, dev)
+    ref = [x.clone() for x in DecodeEngine(W, f, d.T, synth.UNK_IDX).run()]
+    e = DecodeEngine(W, f, d.T, synth.UNK_IDX, gate_ksplit=form)
+    assert e.ks_att > 0 and e.ks_lang > 0 and e.gate_fused == (form == "fused")
+    a = [x.clone() for x in e.run()]
+    same = (a[0] == ref[0]).all(1)
+    assert int(same.sum()) >= d.B - 1
+    close(a[1][same], ref[1][same], **SEQ_TOL)
+    e.capture()
+    for _ in range(2):
+        assert all(torch.equal(x, y) for x, y in zip(a, e.run()))
 
 
 def test_beam5_cfg1_vs_oracle(dev, lib):
