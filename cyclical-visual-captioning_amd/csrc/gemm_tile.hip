@@ -397,28 +397,48 @@ __global__ __launch_bounds__(256) void tile_lstm_finish_kernel(LstmFinishArgs a)
     if (m >= a.M) return;
     const int j = blk * 8 + hq * 4;                          // hidden units j .. j + 3
     const int col = blk * 32 + hq * 4;                       // packed feature index of gate 0
+    // every read -- the slabs of the four gates, the cell state, the optional bias terms (behind uniform branches) -- is
+    // requested before the first sum: with a gate's slab sum and its bias branches inside one loop body the compiler ran four
+    // dependent rounds of loads (23 us per launch at 320 rows)
     f32x4 pre[4];
+    const float* src = a.parts + (size_t)m * 4 * R + col;
+    constexpr int NV = NP > 0 ? NP : 1;
+    f32x4 v[4][NV];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int p = 0; p < NV; ++p) v[g][p] = ld4(src + g * 8 + (size_t)p * a.part_stride);
+    const f32x4 cp0 = ld4(a.c_prev + (size_t)m * R + j);
+    f32x4 bi[4], bh[4], gbv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bi[g] = bh[g] = gbv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.b_ih != nullptr) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bi[g] = ld4(a.b_ih + g * R + j);
+    }
+    if (a.b_hh != nullptr) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bh[g] = ld4(a.b_hh + g * R + j);
+    }
+    if (a.gate_bias != nullptr) {
+        const float* gb = a.gate_bias + (size_t)(m / a.gb_div) * 4 * R + j;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gbv[g] = ld4(gb + g * R);
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const float* src = a.parts + (size_t)m * 4 * R + col + g * 8;
-        f32x4 s;
-        if constexpr (NP > 0) {
-            f32x4 v[NP];
+        pre[g] = v[g][0];
 #pragma unroll
-            for (int p = 0; p < NP; ++p) v[p] = ld4(src + (size_t)p * a.part_stride);
-            s = v[0];
-#pragma unroll
-            for (int p = 1; p < NP; ++p) s += v[p];
-        } else {
-            s = ld4(src);
-            for (int p = 1; p < a.nparts; ++p) s += ld4(src + (size_t)p * a.part_stride);
-        }
-        if (a.b_ih != nullptr) s += ld4(a.b_ih + g * R + j);
-        if (a.b_hh != nullptr) s += ld4(a.b_hh + g * R + j);
-        if (a.gate_bias != nullptr) s += ld4(a.gate_bias + (size_t)(m / a.gb_div) * 4 * R + g * R + j);
-        pre[g] = s;
+        for (int p = 1; p < NV; ++p) pre[g] += v[g][p];
     }
-    const f32x4 cp = ld4(a.c_prev + (size_t)m * R + j);
+    if constexpr (NP == 0) {
+        for (int p = 1; p < a.nparts; ++p)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[g] += ld4(src + g * 8 + (size_t)p * a.part_stride);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pre[g] = ((pre[g] + bi[g]) + bh[g]) + gbv[g];      // (an absent term adds an exact zero)
+    const f32x4 cp = cp0;
     f32x4 hv, cv;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -539,17 +559,23 @@ struct ReorderArgs {
 };
 
 __global__ __launch_bounds__(256) void tile_reorder_pack_kernel(ReorderArgs a) {
+    // A wave = 32 rows x the two quads of one 8-k group (as in tile_lstm_finish_kernel): its fragment stores are 512 contiguous
+    // bytes per term.  With k fastest across the wave they were 8-byte scatters over 96 lines per instruction (16.8 us).
     const int R = a.R, E = a.E;
-    const int nq = (2 * R + E) >> 2;
-    const int q = blockIdx.x * 256 + threadIdx.x;
-    if (q >= a.rows * nq) return;
-    const int r = q / nq, k = (q - r * nq) * 4;
+    const int noct = (2 * R + E) >> 3;                               // 8-k groups per row (R, E multiples of 16)
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int hq = (int)(q & 1), i = (int)((q >> 1) & 31);
+    const long long unit = q >> 6;                                    // (row block, 8-k group), group fastest
+    const int oct = (int)(unit % noct), mb = (int)(unit / noct);
+    const int r = mb * 32 + i, k = oct * 8 + hq * 4;
+    if (r >= a.rows) return;
     const int src = a.parent != nullptr ? (r / a.beam) * a.beam + (int)a.parent[r] : r;
     if (k < R) {                                   // h_lang -> xa segment 0 and xl segment 2; c_lang rides along
         const f32x4 h = ld4(a.h_lang + (size_t)src * R + k);
+        const f32x4 c = ld4(a.c_lang + (size_t)src * R + k);
         store_frag4(a.xa, a.xa_stride, r, k, h);
         store_frag4(a.xl_hlang, a.xl_stride, r, k, h);
-        st4(a.c_lang_prev + (size_t)r * R + k, ld4(a.c_lang + (size_t)src * R + k));
+        st4(a.c_lang_prev + (size_t)r * R + k, c);
     } else if (k < R + E) {
         int64_t w = a.word[r];
         if (w < 0 || w >= a.V) w = 0;
@@ -558,8 +584,10 @@ __global__ __launch_bounds__(256) void tile_reorder_pack_kernel(ReorderArgs a) {
         store_frag4(a.xa, a.xa_stride, r, k, v);
     } else {
         const int kk = k - R - E;
-        store_frag4(a.xa, a.xa_stride, r, k, ld4(a.h_att + (size_t)src * R + kk));
-        st4(a.c_att_prev + (size_t)r * R + kk, ld4(a.c_att + (size_t)src * R + kk));
+        const f32x4 h = ld4(a.h_att + (size_t)src * R + kk);
+        const f32x4 c = ld4(a.c_att + (size_t)src * R + kk);
+        store_frag4(a.xa, a.xa_stride, r, k, h);
+        st4(a.c_att_prev + (size_t)r * R + kk, c);
     }
 }
 
@@ -695,7 +723,7 @@ extern "C" int cvc_tile_reorder_pack(const int64_t* parent, const int64_t* word,
     a.parent = parent; a.word = word; a.beam = beam; a.h_att = h_att; a.c_att = c_att; a.h_lang = h_lang; a.c_lang = c_lang;
     a.table = table; a.E = E; a.V = V; a.c_att_prev = c_att_prev; a.c_lang_prev = c_lang_prev; a.xa = (uint16_t*)xa;
     a.xa_stride = xa_stride; a.xl_hlang = (uint16_t*)xl_hlang; a.xl_stride = xl_stride; a.rows = rows; a.R = R;
-    const long long n = (long long)rows * ((2 * R + E) / 4);
+    const long long n = (long long)((rows + 31) / 32) * 32 * ((2 * R + E) / 4);      // whole 32-row blocks (threads past `rows` exit)
     hipLaunchKernelGGL(tile_reorder_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return cvc_launch_status();
 }

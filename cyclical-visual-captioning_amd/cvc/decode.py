@@ -231,6 +231,8 @@ class DecodeEngine:
             self.score = z(2, rows)
             self.done = torch.zeros(2, rows, dtype=torch.uint8, device=dev)
             self.parent = torch.zeros(self.T, rows, dtype=torch.int64, device=dev)
+            self.bt_seq = torch.zeros(self.B, self.T, dtype=torch.int64, device=dev)      # rank-0 hypothesis (cvc_beam_backtrack)
+            self.bt_att = z(self.B, self.T, N)
             self.gather_tmp = [z(rows, R) for _ in range(4)]
             self.beam_ws = z(17 * rows)
         self.inv_temp = float(inv_temp)
@@ -687,6 +689,10 @@ class DecodeEngine:
         else:
             self._reset()
             self._run_launches()
+        if self.beam > 1:                                  # rank-0 hypothesis: one launch (was ~60 indexing launches per decode)
+            hip._check(hip.lib().cvc_beam_backtrack(self.words[1:].data_ptr(), self.parent.data_ptr(), self.att_steps.data_ptr(),
+                                                    self.B, self.beam, self.T, self.N, self.bt_seq.data_ptr(),
+                                                    self.bt_att.data_ptr(), hip._stream()), "cvc_beam_backtrack")
 
     def capture(self):
         """Capture the T-step loop into a HIP graph (launch-bound inner loop -> one replay)."""
@@ -716,7 +722,11 @@ class DecodeEngine:
         return self._backtrack()
 
     def _backtrack(self):
-        """Rank-0 hypothesis of every clip: follow parent pointers from the last step."""
+        """Rank-0 hypothesis of every clip (cvc_beam_backtrack, enqueued with the decode) and the final beam scores."""
+        return self.bt_seq, self.bt_att, self.score[self.T & 1].view(self.B, self.beam)
+
+    def _backtrack_host(self):
+        """The same by indexing on the host side of torch (kept as the cross-check of the kernel in the tests)."""
         B, beam, T, N = self.B, self.beam, self.T, self.N
         words = self.words[1:].view(T, B, beam)
         parent = self.parent.view(T, B, beam)

@@ -326,6 +326,12 @@ int cvc_beam_select_parts(const float* parts, int nparts, long long part_stride,
                           const float* score_in, const uint8_t* done_in, int B, int beam, int V, int unk_idx,
                           int first_step, int64_t* parent, int64_t* word, float* score_out, uint8_t* done_out,
                           float* workspace, cvc_stream_t stream);
+/* Best hypothesis of every clip after a beam decode: words [T, B*beam] (the word chosen for row r at step t), parent
+ * [T, B*beam] (its parent beam slot), att [T, B*beam, N] (region attention of the step, computed for the parent row) ->
+ * seq [B, T], att_out [B, T, N] of the rank-0 hypothesis (build-defined beam rule).  T <= 256. */
+int cvc_beam_backtrack(const int64_t* words, const int64_t* parent, const float* att, int B, int beam, int T, int N,
+                       int64_t* seq, float* att_out, cvc_stream_t stream);
+
 /* dst[r, :] = src[(r / beam) * beam + parent[r], :] for r in [0, rows)  (state reorder) */
 int cvc_gather_rows(const float* src, const int64_t* parent, int rows, int beam, int width,
                     float* dst, cvc_stream_t stream);

@@ -785,6 +785,9 @@ def test_tile_path_equals_ring_path(dev, lib, B, N, F, R, A, E, V, T, beam):
     close(a[1][same], b[1][same], **SEQ_TOL)
     if beam > 1:
         close(a[2][same], b[2][same], rtol=2e-4, atol=2e-4)
+    if beam > 1:                                                   # the backtrack kernel against host-side indexing
+        h = e_tile._backtrack_host()
+        assert torch.equal(a[0], h[0]) and torch.equal(a[1], h[1]) and torch.equal(a[2], h[2])
     a2 = e_tile.capture().run()
     assert all(torch.equal(x, y) for x, y in zip(a, a2))          # graph replay == eager, bitwise
 
