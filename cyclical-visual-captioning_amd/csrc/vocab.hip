@@ -400,6 +400,7 @@ __global__ __launch_bounds__(WG) void beam_rowtop_kernel(const float* logits, in
 // loop and bias branch serialised its 20 loads per thread), log-sum-exp from per-wave (max, sum) pairs, and the `beam` best
 // found per WAVE without a barrier (shuffles only), then merged by wave 0 -- the row's top `beam` are among the 4 x beam wave
 // winners, so the result is the general kernel's (ties broken towards the lower index in both).  3 barriers instead of 19.
+template <int NG>      // float4 groups per thread: V <= NG * 1024
 __global__ __launch_bounds__(WG) void beam_rowtop4_kernel(const float* logits, int beam, int V, int unk, float* cand_v, int* cand_i,
                                                           float* lse_out) {
     __shared__ float wm[4], ws[4];
@@ -407,7 +408,6 @@ __global__ __launch_bounds__(WG) void beam_rowtop4_kernel(const float* logits, i
     __shared__ int wi[4 * BEAM_MAX];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* x = logits + (size_t)row * V;
-    constexpr int NG = ROW_CACHE / 4;
     f32x4 v4[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -659,10 +659,21 @@ extern "C" int cvc_beam_select_parts(const float* logits, int nparts, long long 
     float* cand_v = workspace;
     int* cand_i = reinterpret_cast<int*>(workspace + (size_t)rows * BEAM_MAX);
     float* lse = workspace + (size_t)rows * BEAM_MAX * 2;
-    if (nparts == 1 && bias == nullptr && (V & 3) == 0 && ((uintptr_t)logits & 15) == 0 && 4 * BEAM_MAX <= 64)
-        hipLaunchKernelGGL(beam_rowtop4_kernel, dim3(rows), dim3(WG), 0, (hipStream_t)stream, logits, beam, V, unk_idx, cand_v,
-                           cand_i, lse);
-    else
+    if (nparts == 1 && bias == nullptr && (V & 3) == 0 && ((uintptr_t)logits & 15) == 0 && 4 * BEAM_MAX <= 64) {
+#define CVC_RT4(NG_) hipLaunchKernelGGL(beam_rowtop4_kernel<NG_>, dim3(rows), dim3(WG), 0, (hipStream_t)stream, logits, beam, V, \
+                                        unk_idx, cand_v, cand_i, lse)
+        switch ((V + 4 * WG - 1) / (4 * WG)) {
+            case 1: CVC_RT4(1); break;
+            case 2: CVC_RT4(2); break;
+            case 3: CVC_RT4(3); break;
+            case 4: CVC_RT4(4); break;
+            case 5: CVC_RT4(5); break;
+            case 6: CVC_RT4(6); break;
+            case 7: CVC_RT4(7); break;
+            default: CVC_RT4(8); break;
+        }
+#undef CVC_RT4
+    } else
         hipLaunchKernelGGL(beam_rowtop_kernel, dim3(rows), dim3(WG), 0, (hipStream_t)stream, logits, nparts, part_stride, bias, beam,
                            V, unk_idx, cand_v, cand_i, lse);
     hipLaunchKernelGGL(beam_merge_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, cand_v, cand_i, lse, score_in, done_in,
