@@ -238,6 +238,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
     const int ejq = (int)blockIdx.x * 8 + eqd * 4;                     // first of this thread's 4 hidden units
     const size_t eqoff = ((size_t)(ejq / 4) * 64 + em) * 4;
     f32x4 ecp = {0, 0, 0, 0}, eadd[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    f32x4 eadd2[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, eadd3[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     if (GRU && ework) {
         // eadd: r, z: x-projection + both biases; n: x-projection + b_in; [3]: b_hn (multiplied by r with the h-projection)
         const float* gi = a.gru_gi[blockIdx.y] + (size_t)em * a.gru_gi_ld + ejq;
@@ -249,12 +250,20 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
         }
         eadd[3] = ld4(a.bias2 + 2 * R + ejq);
     } else if (ework) {
+        // Requests only -- the sums are taken after the cross-wave stage.  With "eadd[g] += load" under each (uniform) branch
+        // every addition waited for its load: up to eight dependent L2 round trips on the critical path of waves 0 and 1.
         ecp = a.c_prev_rm != nullptr ? ld4(a.c_prev_rm + (size_t)em * R + ejq) : ld4(a.c_prev_q + eqoff);
+        if (a.bias != nullptr) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (a.bias != nullptr) eadd[g] = ld4(a.bias + g * R + ejq);
-            if (a.bias2 != nullptr) eadd[g] += ld4(a.bias2 + g * R + ejq);
-            if (a.gate_bias != nullptr) eadd[g] += ld4(a.gate_bias + (size_t)em * 4 * R + g * R + ejq);
+            for (int g = 0; g < 4; ++g) eadd[g] = ld4(a.bias + g * R + ejq);
+        }
+        if (a.bias2 != nullptr) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) eadd2[g] = ld4(a.bias2 + g * R + ejq);
+        }
+        if (a.gate_bias != nullptr) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) eadd3[g] = ld4(a.gate_bias + (size_t)em * 4 * R + g * R + ejq);
         }
     }
 
@@ -298,6 +307,8 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
         // and stores them as one float4 in quad layout (64 rows x 16 B contiguous per quad)
         if (ework) {
             f32x4 hv, cv, gv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) eadd[g] = (eadd[g] + eadd2[g]) + eadd3[g];      // (an absent term is an exact zero)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int jj = eqd * 4 + e;

@@ -198,23 +198,36 @@ __device__ __forceinline__ void ks_finish_item(const KsArgs& a, int blk, int m, 
     if (m >= a.M) return;
     const int R = a.R;
     const int j = blk * 8 + hq * 4;
-    f32x4 pre[4];
+    // every read is requested before the first sum (bias terms behind uniform branches: see tile_lstm_finish_kernel)
+    f32x4 pre[4], v[4][NS], bi[4], bh[4], gb[4];
+    const float* p0 = a.slab + (((size_t)blk * 64 + m) * 32) + hq * 4;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const float* p = a.slab + (((size_t)blk * 64 + m) * 32) + g * 8 + hq * 4;
-        f32x4 v[NS];
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int k = 0; k < NS; ++k) v[k] = ld4(p + (size_t)k * a.nblk * 64 * 32);
-        f32x4 s = v[0];
-#pragma unroll
-        for (int k = 1; k < NS; ++k) s += v[k];
-        if (a.b_ih != nullptr) s += ld4(a.b_ih + g * R + j);
-        if (a.b_hh != nullptr) s += ld4(a.b_hh + g * R + j);
-        if (a.gate_bias != nullptr) s += ld4(a.gate_bias + (size_t)m * 4 * R + g * R + j);
-        pre[g] = s;
-    }
+        for (int k = 0; k < NS; ++k) v[g][k] = ld4(p0 + g * 8 + (size_t)k * a.nblk * 64 * 32);
     const size_t qoff = ((size_t)(j >> 2) * 64 + m) * 4;
     const f32x4 cp = ld4(a.c_prev_q + qoff);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bi[g] = bh[g] = gb[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.b_ih != nullptr) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bi[g] = ld4(a.b_ih + g * R + j);
+    }
+    if (a.b_hh != nullptr) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bh[g] = ld4(a.b_hh + g * R + j);
+    }
+    if (a.gate_bias != nullptr) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gb[g] = ld4(a.gate_bias + (size_t)m * 4 * R + g * R + j);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 s = v[g][0];
+#pragma unroll
+        for (int k = 1; k < NS; ++k) s += v[g][k];
+        pre[g] = ((s + bi[g]) + bh[g]) + gb[g];
+    }
     f32x4 hv, cv;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -247,23 +260,36 @@ __global__ __launch_bounds__(128) void packed_ks_finish_kernel(KsFinishArgs a) {
     if (blk >= a.nblk || m >= a.M) return;
     const int R = a.R;
     const int j = blk * 8 + hq * 4;                            // first of this thread's 4 hidden units
-    f32x4 pre[4];
+    // every read is requested before the first sum (bias terms behind uniform branches: see tile_lstm_finish_kernel)
+    f32x4 pre[4], v[4][NS], bi[4], bh[4], gb[4];
+    const float* p0 = a.slab + (((size_t)blk * 64 + m) * 32) + hq * 4;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const float* p = a.slab + (((size_t)blk * 64 + m) * 32) + g * 8 + hq * 4;
-        f32x4 v[NS];
+    for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int k = 0; k < NS; ++k) v[k] = ld4(p + (size_t)k * a.nblk * 64 * 32);
-        f32x4 s = v[0];
-#pragma unroll
-        for (int k = 1; k < NS; ++k) s += v[k];
-        if (a.b_ih != nullptr) s += ld4(a.b_ih + g * R + j);
-        if (a.b_hh != nullptr) s += ld4(a.b_hh + g * R + j);
-        if (a.gate_bias != nullptr) s += ld4(a.gate_bias + (size_t)m * 4 * R + g * R + j);
-        pre[g] = s;
-    }
+        for (int k = 0; k < NS; ++k) v[g][k] = ld4(p0 + g * 8 + (size_t)k * a.nblk * 64 * 32);
     const size_t qoff = ((size_t)(j >> 2) * 64 + m) * 4;
     const f32x4 cp = ld4(a.c_prev_q + qoff);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bi[g] = bh[g] = gb[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.b_ih != nullptr) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bi[g] = ld4(a.b_ih + g * R + j);
+    }
+    if (a.b_hh != nullptr) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bh[g] = ld4(a.b_hh + g * R + j);
+    }
+    if (a.gate_bias != nullptr) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gb[g] = ld4(a.gate_bias + (size_t)m * 4 * R + g * R + j);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 s = v[g][0];
+#pragma unroll
+        for (int k = 1; k < NS; ++k) s += v[g][k];
+        pre[g] = ((s + bi[g]) + bh[g]) + gb[g];
+    }
     f32x4 hv, cv;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
