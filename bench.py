@@ -57,6 +57,9 @@ def parse():
     p.add_argument("--gate-ksplit", type=int, default=None, choices=[0, 1, 2],
                    help="packed path: 1 = K-split gate GEMMs (activations shared through LDS + finishing kernel), 0 = full-K "
                         "kernel; default = cvc.decode.GATE_KSPLIT_DEFAULT")
+    p.add_argument("--tile-loaders", type=int, default=None, choices=[0, 1, 2, 3],
+                   help="tile GEMM form (A/B): 0 = every wave copies, 1 = loader waves + 8 computing waves, 2 = loader waves + 4 wide "
+                        "computing waves (default of the library)")
     p.add_argument("--train-graph", action="store_true", help="--mode train: capture the whole training step in a HIP graph")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-repeats", type=int, default=3)
@@ -361,6 +364,9 @@ def main():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.tile_loaders is not None:
+        from cvc import hip as _hip
+        _hip.lib().cvc_tile_gemm_loaders(int(args.tile_loaders))
     # under torchrun (RANK set) the process group is always initialised, also for a single rank, so that the
     # barrier / max-over-ranks path is the same code at every N
     dist_on = "RANK" in os.environ and "WORLD_SIZE" in os.environ

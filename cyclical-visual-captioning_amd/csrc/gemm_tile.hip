@@ -381,6 +381,157 @@ struct LstmFinishArgs {
     int M, R;
 };
 
+// Wide-wave form of tile_gemm_ld_kernel: 4 computing waves, each 2 weight blocks x MH row tiles (2 x MH accumulator tiles),
+// NL loader waves.  Against the 8-wave form: a row-tile fragment read from LDS feeds 12 MFMAs instead of 6 (LDS read traffic
+// per k step 144 -> 84 KB at MH = 5; the LDS was busy ~78 % of the MFMA time), and the k step's barrier sits BEFORE the last row
+// tile's MFMAs -- its fragments are in registers by then -- so that the next stage's first fragments are read under those
+// MFMAs instead of in a bubble at the top of every stage.
+template <int MH, int NL>
+__global__ __launch_bounds__((4 + NL) * 64) void tile_gemm_ld2_kernel(TileArgs a) {
+    constexpr int NX = 2 * MH;
+    constexpr int NF = (4 + NX) * 3;
+    constexpr int STAGE = NF * 1024;
+    constexpr int NSTAGE = 3;
+    __shared__ __attribute__((aligned(16))) char lds[NSTAGE * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile = (int)blockIdx.x % a.ntile, ks = (int)blockIdx.x / a.ntile;
+    if (a.ksplit > 1 && a.ksplit <= 8 && 8 % a.ksplit == 0 && a.ntile % (8 / a.ksplit) == 0) {
+        const int g = 8 / a.ksplit, xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+        ks = xcd / g;
+        tile = j * g + xcd % g;
+    }
+    const int mb0 = (int)blockIdx.y * NX;
+    const int s_lo = (int)((long long)a.ksteps * ks / a.ksplit), s_hi = (int)((long long)a.ksteps * (ks + 1) / a.ksplit);
+    const int nst = s_hi - s_lo;
+
+    if (wave >= 4) {
+        // ---------------- loader wave (as in tile_gemm_ld_kernel); one barrier per stage, in step with the computing waves
+        const int lw = wave - 4;
+        constexpr int NDLO = NF / NL, NEXTRA = NF % NL, ND = NDLO + (NEXTRA ? 1 : 0);
+        const bool extra = NEXTRA != 0 && lw < NEXTRA;
+        const uint16_t* src[ND];
+        int dst[ND];
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            int f = lw + NL * j;
+            if (f >= NF) f -= NF;
+            const int g = f < 12 ? f : f - 12;
+            const int blk = g / 3, pl = g - blk * 3;
+            if (f < 12) src[j] = a.wb + ((size_t)(tile * 4 + blk) * a.ksteps + s_lo) * KSTEP + pl * FRAG + lane * 8;
+            else src[j] = a.xb + (size_t)(mb0 + blk) * a.x_mblk_stride + (size_t)s_lo * KSTEP + pl * FRAG + lane * 8;
+            dst[j] = f * 1024;
+        }
+        auto issue = [&](int s, int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < NDLO; ++j)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[j] + (size_t)s * KSTEP), (lds_ptr_t)(lds + buf * STAGE + dst[j]), 16, 0, 0);
+            if constexpr (NEXTRA != 0)
+                if (extra)
+                    __builtin_amdgcn_global_load_lds((glb_ptr_t)(src[NDLO] + (size_t)s * KSTEP), (lds_ptr_t)(lds + buf * STAGE + dst[NDLO]), 16, 0, 0);
+        };
+        if (nst > 0) issue(0, 0);
+        if (nst > 1) issue(1, 1);
+        int buf = 0;
+        // barrier k (k = 0 .. nst - 1) publishes stage k; the computing waves pass it when every fragment of stage k - 1 they
+        // will ever read is in their registers, so stage k + 2 may overwrite the buffer of stage k - 1
+        for (int s = 0; s < nst; ++s) {
+            if (s + 1 < nst) {
+                if (extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDLO + 1) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDLO) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (s + 2 < nst) issue(s + 2, buf == 0 ? 2 : buf - 1);
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+        return;
+    }
+
+    // ---------------- computing wave: weight blocks 2 wp, 2 wp + 1; row tiles mh * MH .. + MH - 1
+    const int wp = wave & 1, mh = wave >> 1;
+    f32x16 acc[2][MH];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int t = 0; t < MH; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][t][r] = 0.f;
+    u32x4 w[2][3], x[2][3];
+    auto frag = [&](int buf, int f) __attribute__((always_inline)) {
+        return *reinterpret_cast<const u32x4*>(lds + buf * STAGE + lane * 16 + f * 1024);
+    };
+    auto first_frags = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            w[0][pl] = frag(buf, (2 * wp) * 3 + pl);
+            w[1][pl] = frag(buf, (2 * wp + 1) * 3 + pl);
+            x[0][pl] = frag(buf, 12 + (mh * MH) * 3 + pl);
+        }
+    };
+    auto mma = [&](const u32x4* xt, const int t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            acc[b][t] = mfma_bf16(xt[1], w[b][1], acc[b][t]);
+            acc[b][t] = mfma_bf16(xt[0], w[b][2], acc[b][t]);
+            acc[b][t] = mfma_bf16(xt[2], w[b][0], acc[b][t]);
+            acc[b][t] = mfma_bf16(xt[0], w[b][1], acc[b][t]);
+            acc[b][t] = mfma_bf16(xt[1], w[b][0], acc[b][t]);
+            acc[b][t] = mfma_bf16(xt[0], w[b][0], acc[b][t]);
+        }
+    };
+    if (nst > 0) {
+        __builtin_amdgcn_s_barrier();                               // barrier 0: stage 0 is in LDS
+        first_frags(0);
+    }
+    int buf = 0;
+    for (int s = 0; s < nst; ++s) {
+        const int nbuf = buf == 2 ? 0 : buf + 1;
+        // row tiles 0 .. MH - 2 of this stage, the next tile's fragments read under the current tile's MFMAs
+#pragma unroll
+        for (int t = 0; t + 1 < MH; ++t) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) x[(t + 1) & 1][pl] = frag(buf, 12 + (mh * MH + t + 1) * 3 + pl);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(x[t & 1], t);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the last tile's fragments are in registers: this wave is done with the stage's LDS.  Its MFMAs are issued FIRST (they
+        // still use this stage's weight registers), then the barrier that publishes the next stage and that stage's first reads,
+        // which land while those MFMAs execute
+        u32x4 xl[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) xl[pl] = x[(MH - 1) & 1][pl];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        mma(xl, MH - 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < nst) {
+            __builtin_amdgcn_s_barrier();                           // barrier s + 1
+            first_frags(nbuf);
+        }
+        buf = nbuf;
+    }
+    float* out = a.parts + (size_t)ks * a.part_stride;
+    const int kh = lane >> 5;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int n = (tile * 4 + 2 * wp + b) * 32 + (lane & 31);
+        if (n < a.N) {
+#pragma unroll
+            for (int t = 0; t < MH; ++t) {
+                const int mbase = (mb0 + mh * MH + t) * 32 + 4 * kh;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mbase + (r & 3) + 8 * (r >> 2);
+                    if (m < a.M) out[(size_t)m * a.ld + n] = acc[b][t][r];
+                }
+            }
+        }
+    }
+}
+
 // NP = number of slabs when it is 1 / 2 / 4 / 8 (their reads are then issued together), 0 = any number (one after the other)
 template <int NP>
 __global__ __launch_bounds__(256) void tile_lstm_finish_kernel(LstmFinishArgs a) {
@@ -593,11 +744,12 @@ __global__ __launch_bounds__(256) void tile_reorder_pack_kernel(ReorderArgs a) {
 
 }  // namespace
 
-static int cvc_tile_loader_waves = 1;
-// test / A-B hook: 0 = every wave copies its share of a stage (tile_gemm_kernel), 1 = dedicated loader waves (default)
+static int cvc_tile_loader_waves = 3;
+// test / A-B hook: 0 = every wave copies its share of a stage (tile_gemm_kernel), 1 = dedicated loader waves + 8 computing waves,
+// 2 = dedicated loader waves + 4 wide computing waves (tile_gemm_ld2_kernel), 3 = 2 for long K loops, 1 otherwise (default)
 extern "C" int cvc_tile_gemm_loaders(int on) {
     const int prev = cvc_tile_loader_waves;
-    if (on >= 0) cvc_tile_loader_waves = on ? 1 : 0;
+    if (on >= 0) cvc_tile_loader_waves = on > 3 ? 3 : on;
     return prev;
 }
 
@@ -617,6 +769,21 @@ extern "C" int cvc_tile_gemm(const void* wb, const void* xb, long long x_mblk_st
 #ifndef CVC_TILE_LOADERS
 #define CVC_TILE_LOADERS 4
 #endif
+    // form 2 (4 wide computing waves) pays on long K loops (measured: lang / att gate GEMMs -2..3 us, the short-K vocabulary
+    // head and h2attn +2 us each); the default picks per launch
+    const bool wide = cvc_tile_loader_waves == 2 || (cvc_tile_loader_waves == 3 && a.ksteps / ksplit >= 64);
+    if (CVC_TILE_LOADERS > 0 && wide) {
+        constexpr int NL = CVC_TILE_LOADERS > 0 ? CVC_TILE_LOADERS : 1;
+        const dim3 blk((4 + NL) * 64);
+        switch (MH) {
+            case 1: hipLaunchKernelGGL((tile_gemm_ld2_kernel<1, NL>), grid, blk, 0, st, a); break;
+            case 2: hipLaunchKernelGGL((tile_gemm_ld2_kernel<2, NL>), grid, blk, 0, st, a); break;
+            case 3: hipLaunchKernelGGL((tile_gemm_ld2_kernel<3, NL>), grid, blk, 0, st, a); break;
+            case 4: hipLaunchKernelGGL((tile_gemm_ld2_kernel<4, NL>), grid, blk, 0, st, a); break;
+            default: hipLaunchKernelGGL((tile_gemm_ld2_kernel<5, NL>), grid, blk, 0, st, a); break;
+        }
+        return cvc_launch_status();
+    }
     if (CVC_TILE_LOADERS > 0 && cvc_tile_loader_waves != 0) {
         constexpr int NL = CVC_TILE_LOADERS > 0 ? CVC_TILE_LOADERS : 1;
         const dim3 blk((8 + NL) * 64);

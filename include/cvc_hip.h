@@ -352,7 +352,10 @@ int cvc_gather_rows(const float* src, const int64_t* parent, int rows, int beam,
  * cvc_tile_gemm: parts[s][m, n] (row-major, leading dim ld, slab stride part_stride floats) = partial product over K slice s
  * of ksplit; the consumer sums the slabs in slab order.  K % 16 == 0; any M (walked in chunks of 320 rows); any N.
  */
-int cvc_tile_gemm_loaders(int on);   /* A/B + test hook: 1 (default) = dedicated LDS-DMA loader waves, 0 = every wave copies; <0 queries */
+/* A/B + test hook, returns the previous setting (< 0 only queries): 0 = every wave issues its share of the LDS-DMA copies,
+ * 1 = dedicated loader waves + 8 computing waves, 2 = dedicated loader waves + 4 wide computing waves (2 weight blocks each),
+ * 3 (default) = form 2 for long K loops (>= 64 k steps per workgroup), form 1 otherwise.  All forms: identical results. */
+int cvc_tile_gemm_loaders(int on);
 int cvc_tile_rows_alloc(int M);      /* rows (a multiple of 32) an activation fragment buffer for M live rows must hold */
 int cvc_tile_gemm(const void* wb, const void* xb, long long x_mblk_stride, int K, int M, int N, int ksplit,
                   float* parts, int ld, long long part_stride, cvc_stream_t stream);
