@@ -1,0 +1,53 @@
+"""Inference-time dense layers of the once-per-clip encoder on the tile GEMM (csrc/gemm_tile.hip): `nn.Linear`, or the
+reference's Linear -> ReLU -> Dropout blocks (backbone.py:55-79), applied to thousands of rows at a time (B*F frame rows,
+B*N region rows).  Split products on the bf16 MFMA with fp32 accumulation: fp32-grade results (tests/test_encoder.py) at
+about twice the rate of the library's fp32 GEMM.  Autograd, CPU tensors and small row counts keep the module itself."""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import hip
+
+ENABLED = True
+MIN_ROWS = 1024          # below this the launch-bound library kernel is as good
+
+_packs: Dict[int, Tuple[tuple, "hip.TileOperand"]] = {}
+
+
+def _weight_operand(lin: nn.Linear):
+    w = lin.weight
+    stamp = (w.data_ptr(), w._version)
+    ent = _packs.get(id(lin))
+    if ent is not None and ent[0] == stamp:
+        return ent[1]
+    op = hip.TileOperand(w.detach().float().contiguous())
+    if len(_packs) > 32:
+        _packs.clear()
+    _packs[id(lin)] = (stamp, op)
+    return op
+
+
+def usable(x: torch.Tensor) -> bool:
+    return (ENABLED and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+            and x.numel() // max(1, x.shape[-1]) >= MIN_ROWS)
+
+
+def apply(layer: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """layer(x) for `nn.Linear` or `nn.Sequential(nn.Linear, nn.ReLU[, nn.Dropout])` in eval mode."""
+    lin = layer if isinstance(layer, nn.Linear) else (layer[0] if isinstance(layer, nn.Sequential) and len(layer) > 0 else None)
+    if not isinstance(lin, nn.Linear) or not usable(x) or layer.training:
+        return layer(x)
+    rest = [] if layer is lin else list(layer)[1:]
+    if not all(isinstance(m, (nn.ReLU, nn.Dropout)) for m in rest):
+        return layer(x)
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1])
+    y = hip.tile_mm(x2, _weight_operand(lin))
+    if lin.bias is not None:
+        y += lin.bias
+    if any(isinstance(m, nn.ReLU) for m in rest):
+        y.relu_()
+    return y.view(*lead, -1)

@@ -583,7 +583,9 @@ class TileOperand:
             t = t.contiguous()
         self.rows, self.K = (t.shape[1], t.shape[0]) if kmajor else (t.shape[0], t.shape[1])
         rows_alloc = max(tile_rows_alloc(self.rows), (self.rows + 127) // 128 * 128)
-        self.frags = torch.zeros(rows_alloc // 32, (self.K + 15) // 16, 3, 2, 32, 8, dtype=torch.int16, device=t.device)
+        # (padding rows / k must read as zero; a shape without padding is written completely by the packer)
+        alloc = torch.empty if (rows_alloc == self.rows and self.K % 16 == 0) else torch.zeros
+        self.frags = alloc(rows_alloc // 32, (self.K + 15) // 16, 3, 2, 32, 8, dtype=torch.int16, device=t.device)
         self.ptr, self.stride = _frag_ptr(self.frags)
         L = lib()
         if kmajor:

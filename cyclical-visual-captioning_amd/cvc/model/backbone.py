@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import gru as gru_hip
+from .. import dense, gru as gru_hip
 
 HIP_GRU = True     # inference: frame-context GRU on the HIP kernels (cvc/gru.py); False = the library module everywhere
 
@@ -55,7 +55,7 @@ def _relu_drop(layer, p):
 
 def project_and_mask(feat, projector, keep):
     """reference model/modules.py:162-176 (`proj_masking`) without its host-side assert."""
-    out = projector(feat)
+    out = dense.apply(projector, feat)
     return out * keep.unsqueeze(-1).to(out.dtype)
 
 
@@ -199,7 +199,7 @@ class RegionalFeatureExtractorGVD(nn.Module):
 
         if self.att_input_mode in ('both', 'featmap'):
             rgb, motion = conv_feats[..., :RGB_DIM], conv_feats[..., RGB_DIM:RGB_DIM + MOTION_DIM]
-            x = torch.cat((self.att_embed[0](rgb), self.att_embed[1](motion)), dim=2)
+            x = torch.cat((dense.apply(self.att_embed[0], rgb), dense.apply(self.att_embed[1], motion)), dim=2)
             x = self.att_embed_aux(x.transpose(1, 2)).transpose(1, 2).contiguous()      # BatchNorm1d over channels
             if HIP_GRU and not torch.is_grad_enabled() and gru_hip.supported(self.context_enc, x):
                 x = gru_hip.gru_forward(self.context_enc, x)          # inference: csrc/gemm_packed.hip GRU steps + tile GEMM
@@ -208,7 +208,7 @@ class RegionalFeatureExtractorGVD(nn.Module):
                 x = self.context_enc(x)[0]
             x = x.masked_fill(sample_idx_mask, 0)
             conv_feats = x if self.seq_per_img == 1 else x.repeat_interleave(self.seq_per_img, dim=0)
-            p_conv_feats = self.ctx2att_fc(conv_feats)
+            p_conv_feats = dense.apply(self.ctx2att_fc, conv_feats)
         else:
             conv_feats = pool_feats.new_zeros(1, 1)
             p_conv_feats = pool_feats.new_zeros(1, 1)

@@ -239,3 +239,28 @@ def test_gru_hip_full_size_vs_library_cpu():
     err = (got - want).abs().max().item()
     assert err < 5e-5, err
     np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=5e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,K,N,block", [(2000, 300, 200, False), (1500, 2780, 256, True), (4096, 1024, 512, True)])
+def test_dense_layers_on_the_tile_gemm(rows, K, N, block):
+    """cvc.dense.apply (inference-time nn.Linear / Linear-ReLU-Dropout blocks of the encoder on the tile GEMM) against the module
+    in fp64: an error no worse than the library's fp32 result; grad mode and small inputs keep the module itself."""
+    from cvc import dense
+    torch.manual_seed(rows + K)
+    lin = torch.nn.Linear(K, N)
+    layer = (torch.nn.Sequential(lin, torch.nn.ReLU(), torch.nn.Dropout(0.5)) if block else lin).cuda().eval()
+    x = torch.randn(3, rows // 3 + 1, K, device="cuda")
+    with torch.no_grad():
+        assert dense.usable(x)
+        got = dense.apply(layer, x)
+        lib32 = layer(x)
+        ref = layer.double()(x.double())
+        layer.float()
+    e_got = float((got.double() - ref).norm() / ref.norm())
+    e_lib = float((lib32.double() - ref).norm() / ref.norm())
+    assert got.shape == lib32.shape and e_got <= max(2.0 * e_lib, 3e-7), (e_got, e_lib)
+    assert not dense.usable(x[:, :4])                        # few rows: library kernel
+    with torch.enable_grad():
+        y = dense.apply(layer, x.requires_grad_(True))       # autograd: the module itself
+        assert y.requires_grad
