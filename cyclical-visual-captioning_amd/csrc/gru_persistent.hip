@@ -27,12 +27,15 @@ struct GruPArgs {
     int M, F, H, Kp;
     float* hq; long long h_stride;                // state slots, quad layout: [F + 1][ndir][Kp/4][64][4], slot 0 = h0
     float* y; long long y_ld_m, y_ld_t;
-    unsigned* sync;                               // [0..1] arrival counters per direction, [2] error word
+    unsigned* sync;                               // [dir * 2 + group] arrival counters, [4] error word (8 words)
     unsigned spin_limit;
 };
 
-// NC = 32-k chunks per wave (K = 128 * NC), MT = 32-clip tiles
-template <int MT, int NC>
+// NC = 32-k chunks per wave (K = 128 * NC).  The batch is processed as NH independent groups of MT 32-clip tiles
+// (NH x MT = 1 or 2): with NH = 2 the two halves of a 64-clip batch are separate recurrences with their own arrival counters,
+// walked alternately -- while the other workgroups' states of one half are still in flight, this workgroup computes the other
+// half, so that a barrier's latency hides behind useful work.
+template <int NH, int MT, int NC>
 __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruPArgs a) {
     constexpr int LDM = MT * 32 + 1;
     __shared__ float red[4 * 32 * LDM];
@@ -43,7 +46,6 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruPArgs a) {
     const int dir = blockIdx.y, blk = blockIdx.x, H = a.H, M = a.M;
     const int nquad = a.Kp >> 2;
     const unsigned nblk = gridDim.x;
-    unsigned* counter = a.sync + dir;
 
     // ---- this wave's share of the weights, split once.  Register slot c holds chunk wave + 4 * ((c + rot) % NC).  (Measured:
     // starting every workgroup at a different chunk, which helps the per-step kernel, is 10 % SLOWER here -- 18.5 vs 16.7 us
@@ -67,13 +69,12 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruPArgs a) {
         }
     }
 
-    // ---- epilogue role: thread (em = clip, eqd = which 4 of the 8 hidden units)
-    const int em = tid & 63, eqd = tid >> 6;
-    const bool ework = tid < 128 && em < M && em < MT * 32;
+    // ---- epilogue role: thread (em = clip within the group, eqd = which 4 of the 8 hidden units)
+    constexpr int ET = MT * 32;
+    const int em = tid % ET, eqd = tid / ET;
     const int ejq = blk * 8 + (eqd & 1) * 4;
-    const size_t eqoff = ((size_t)(ejq / 4) * 64 + em) * 4;
     f32x4 ebias[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    if (ework) {
+    if (eqd < 2) {
         const float* bi = a.b_ih + (size_t)dir * 3 * H + ejq;
         const float* bh = a.b_hh + (size_t)dir * 3 * H + ejq;
         ebias[0] = ld4(bi) + ld4(bh);
@@ -88,144 +89,153 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruPArgs a) {
         const long long t = dir == 0 ? s : a.F - 1 - s;
         const float* hprev = a.hq + ((size_t)s * gridDim.y + dir) * a.h_stride;
         float* hnext = a.hq + ((size_t)(s + 1) * gridDim.y + dir) * a.h_stride;
-
-        // x-projections of this step: independent of the other workgroups, requested before the wait
-        f32x4 egi[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-        if (ework) {
-            const float* gi = a.gi + (size_t)em * a.gi_ld_m + t * a.gi_ld_t + (size_t)dir * 3 * H + ejq;
 #pragma unroll
-            for (int g = 0; g < 3; ++g) egi[g] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gi + g * H));
-        }
+        for (int hf = 0; hf < NH; ++hf) {
+            const int m = hf * ET + em;                                // clip row of the epilogue role
+            const bool ework = eqd < 2 && m < M;
+            const size_t eqoff = ((size_t)(ejq / 4) * 64 + (m < 64 ? m : 63)) * 4;
+            unsigned* counter = a.sync + dir * 2 + hf;
 
-        // ---- wait until every workgroup of this direction has published step s - 1
-        if (s > 0) {
-            if (tid == 0) {
-                const unsigned target = nblk * (unsigned)s;
-                unsigned it = 0;
-                while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                    if (++it > a.spin_limit || __hip_atomic_load(a.sync + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                        __hip_atomic_store(a.sync + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        gave_up = 1;                                   // tell the workgroup
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                }
+            // x-projections of this step: independent of the other workgroups, requested before the wait
+            f32x4 egi[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            if (ework) {
+                const float* gi = a.gi + (size_t)m * a.gi_ld_m + t * a.gi_ld_t + (size_t)dir * 3 * H + ejq;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) egi[g] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(gi + g * H));
             }
-            __syncthreads();                                           // (also: the previous step's readers of `red` are done)
-            if (gave_up) break;                                        // no invalidate: slot s has never been read before
-        }
 
-        // ---- partial tiles: this wave's K slice (chunks wave, wave + 4, ...)
-        f32x16 acc[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
-        // The activations are requested in phases of (half of the wave's chunks) x (one 32-clip tile), two phases in flight
-        // (128 registers next to the 192 of the weights); the schedule is pinned, otherwise the compiler requests the later
-        // phases one load at a time with a full wait behind each
-        constexpr int HC = (NC + 1) / 2;                              // chunks per phase
-        const float* xl = hprev + (size_t)i * 4 + kh * 4 * 256;
-        f32x4 xb[2][HC][4];
-        auto load_phase = [&](f32x4 (&buf)[HC][4], const int half, const int mt) __attribute__((always_inline)) {
-#pragma unroll
-            for (int j = 0; j < HC; ++j) {
-                const int c = half * HC + j;
-                if (c < NC) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) buf[j][q] = ld4(xl + (size_t)chunk_of[c] * 8 * 256 + q * 256 + mt * 128);
-                }
-            }
-        };
-        auto mma_phase = [&](const f32x4 (&buf)[HC][4], const int half, f32x16& d) __attribute__((always_inline)) {
-#pragma unroll
-            for (int j = 0; j < HC; ++j) {
-                const int c = half * HC + j;
-                if (c < NC) {
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        const Split3 X = split8(buf[j][2 * s2], buf[j][2 * s2 + 1]);
-                        const Split3& Wc = W[c][s2];
-                        d = mfma_bf16(Wc.mid, X.mid, d);
-                        d = mfma_bf16(Wc.lo, X.hi, d);
-                        d = mfma_bf16(Wc.hi, X.lo, d);
-                        d = mfma_bf16(Wc.mid, X.hi, d);
-                        d = mfma_bf16(Wc.hi, X.mid, d);
-                        d = mfma_bf16(Wc.hi, X.hi, d);
+            // ---- wait until every workgroup of this direction has published step s - 1 of this group
+            if (s > 0) {
+                if (tid == 0) {
+                    const unsigned target = nblk * (unsigned)s;
+                    unsigned it = 0;
+                    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                        if (++it > a.spin_limit || __hip_atomic_load(a.sync + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                            __hip_atomic_store(a.sync + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            gave_up = 1;                               // tell the workgroup
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
                     }
                 }
+                __syncthreads();                                       // (also: the previous group's readers of `red` are done)
+                if (gave_up) return;                                   // no invalidate: slot s has never been read before
+            } else if (hf > 0) {
+                __syncthreads();
             }
-        };
-        load_phase(xb[0], 0, 0);
-        load_phase(xb[1], 1, 0);
-        const f32x4 ehp = ld4(hprev + eqoff);                         // (every thread: an unconditional load keeps the waits counted)
-        __builtin_amdgcn_sched_barrier(0);
-        mma_phase(xb[0], 0, acc[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MT == 2) load_phase(xb[0], 0, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_phase(xb[1], 1, acc[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MT == 2) {
-            load_phase(xb[1], 1, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_phase(xb[0], 0, acc[1]);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_phase(xb[1], 1, acc[1]);
-        }
 
-        // ---- ordered cross-wave sum, gate arithmetic
+            // ---- partial tiles: this wave's K slice (chunks wave, wave + 4, ...) of this group's clip tiles
+            f32x16 acc[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                red[(wave * 32 + row) * LDM + mt * 32 + i] = acc[mt][r];
-            }
-        __syncthreads();
-        if (ework) {
-            f32x4 hv;
+                for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+            // The activations are requested in phases of (half of the wave's chunks) x (one 32-clip tile), two phases in
+            // flight (128 registers next to the 192 of the weights); the schedule is pinned, otherwise the compiler requests
+            // the later phases one load at a time with a full wait behind each
+            constexpr int HC = (NC + 1) / 2;                          // chunks per phase
+            const float* xl = hprev + (size_t)i * 4 + kh * 4 * 256 + hf * ET * 4;
+            f32x4 xb[2][HC][4];
+            auto load_phase = [&](f32x4 (&buf)[HC][4], const int half, const int mt) __attribute__((always_inline)) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int jj = eqd * 4 + e;
-                float pre[3];
+                for (int j = 0; j < HC; ++j) {
+                    const int c = half * HC + j;
+                    if (c < NC) {
 #pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    const int row = g * 8 + jj;
-                    pre[g] = (red[(0 * 32 + row) * LDM + em] + red[(1 * 32 + row) * LDM + em]) +
-                             (red[(2 * 32 + row) * LDM + em] + red[(3 * 32 + row) * LDM + em]);
+                        for (int q = 0; q < 4; ++q) buf[j][q] = ld4(xl + (size_t)chunk_of[c] * 8 * 256 + q * 256 + mt * 128);
+                    }
                 }
-                const float rg = fast_sigmoid(pre[0] + egi[0][e] + ebias[0][e]);
-                const float zg = fast_sigmoid(pre[1] + egi[1][e] + ebias[1][e]);
-                const float ng = fast_tanh(egi[2][e] + ebias[2][e] + rg * (pre[2] + ebias[3][e]));
-                hv[e] = ng + zg * (ehp[e] - ng);
+            };
+            auto mma_phase = [&](const f32x4 (&buf)[HC][4], const int half, f32x16& d) __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < HC; ++j) {
+                    const int c = half * HC + j;
+                    if (c < NC) {
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            const Split3 X = split8(buf[j][2 * s2], buf[j][2 * s2 + 1]);
+                            const Split3& Wc = W[c][s2];
+                            d = mfma_bf16(Wc.mid, X.mid, d);
+                            d = mfma_bf16(Wc.lo, X.hi, d);
+                            d = mfma_bf16(Wc.hi, X.lo, d);
+                            d = mfma_bf16(Wc.mid, X.hi, d);
+                            d = mfma_bf16(Wc.hi, X.mid, d);
+                            d = mfma_bf16(Wc.hi, X.hi, d);
+                        }
+                    }
+                }
+            };
+            load_phase(xb[0], 0, 0);
+            load_phase(xb[1], 1, 0);
+            const f32x4 ehp = ld4(hprev + eqoff);                     // (every thread: an unconditional load keeps the waits counted)
+            __builtin_amdgcn_sched_barrier(0);
+            mma_phase(xb[0], 0, acc[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MT == 2) load_phase(xb[0], 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_phase(xb[1], 1, acc[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MT == 2) {
+                load_phase(xb[1], 1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_phase(xb[0], 0, acc[1]);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_phase(xb[1], 1, acc[1]);
             }
-            // the state goes straight through this XCD's L2 to memory (sc0 sc1): a release fence would instead walk the whole
-            // L2 for dirty lines (buffer_wbl2) once per workgroup and step.  (Inline assembly is invisible to the compiler's
-            // hazard recognizer: the s_nop covers "wide store followed by a write to its data registers".)
-            float* hp = hnext + eqoff;
-            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(hp), "v"(hv) : "memory");
-            st4(a.y + (size_t)em * a.y_ld_m + t * a.y_ld_t + (size_t)dir * H + ejq, hv);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+            // ---- ordered cross-wave sum, gate arithmetic
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    red[(wave * 32 + row) * LDM + mt * 32 + i] = acc[mt][r];
+                }
+            __syncthreads();
+            if (ework) {
+                f32x4 hv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int jj = eqd * 4 + e;
+                    float pre[3];
+#pragma unroll
+                    for (int g = 0; g < 3; ++g) {
+                        const int row = g * 8 + jj;
+                        pre[g] = (red[(0 * 32 + row) * LDM + em] + red[(1 * 32 + row) * LDM + em]) +
+                                 (red[(2 * 32 + row) * LDM + em] + red[(3 * 32 + row) * LDM + em]);
+                    }
+                    const float rg = fast_sigmoid(pre[0] + egi[0][e] + ebias[0][e]);
+                    const float zg = fast_sigmoid(pre[1] + egi[1][e] + ebias[1][e]);
+                    const float ng = fast_tanh(egi[2][e] + ebias[2][e] + rg * (pre[2] + ebias[3][e]));
+                    hv[e] = ng + zg * (ehp[e] - ng);
+                }
+                // the state goes straight through this XCD's L2 to memory (sc0 sc1): a release fence would instead walk the
+                // whole L2 for dirty lines (buffer_wbl2) once per workgroup and step.  (Inline assembly is invisible to the
+                // compiler's hazard recognizer: the s_nop covers "wide store followed by a write to its data registers".)
+                float* hp = hnext + eqoff;
+                asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(hp), "v"(hv) : "memory");
+                st4(a.y + (size_t)m * a.y_ld_m + t * a.y_ld_t + (size_t)dir * H + ejq, hv);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            // ---- publish: one arrival per workgroup, after all of its state stores have been acknowledged
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // ---- publish: one arrival per workgroup, after all of its state stores have been acknowledged
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 __global__ __launch_bounds__(256) void gru_zero_kernel(float* p, long long n, unsigned* sync) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t < n) p[t] = 0.f;
-    if (t < 3) sync[t] = 0u;
+    if (t < 8) sync[t] = 0u;
 }
 
-template <int MT, int NC>
+template <int NH, int MT, int NC>
 int launch_persistent(GruPArgs& a, int ndir, hipStream_t st) {
     void* params[] = {&a};
     const dim3 grid(a.H / 8, ndir);
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)gru_persistent_kernel<MT, NC>, 256, 0) != hipSuccess) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)gru_persistent_kernel<NH, MT, NC>, 256, 0) != hipSuccess) {
         (void)hipGetLastError();
         return CVC_E_BADARG;
     }
@@ -233,7 +243,7 @@ int launch_persistent(GruPArgs& a, int ndir, hipStream_t st) {
     if (hipGetDevice(&devid) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid) != hipSuccess)
         return CVC_E_BADARG;
     if ((long long)per_cu * cus < (long long)grid.x * grid.y) return CVC_E_BADARG;     // would not be co-resident
-    if (hipLaunchCooperativeKernel((const void*)gru_persistent_kernel<MT, NC>, grid, dim3(256), params, 0, st) != hipSuccess) {
+    if (hipLaunchCooperativeKernel((const void*)gru_persistent_kernel<NH, MT, NC>, grid, dim3(256), params, 0, st) != hipSuccess) {
         (void)hipGetLastError();
         return CVC_E_BADARG;
     }
@@ -242,8 +252,21 @@ int launch_persistent(GruPArgs& a, int ndir, hipStream_t st) {
 
 }  // namespace
 
-// Same operands and results as cvc_gru_seq_fwd (include/cvc_hip.h) except hq: (F + 1) * ndir * H * 64 floats; `sync` = 3 words of device memory (two arrival counters
-// and an error word that is non-zero afterwards when the barrier timed out -- the outputs are then invalid).  Returns
+static int cvc_gru_halves = 0;
+// A/B + test hook: 1 = a batch of more than 32 clips runs as two interleaved 32-clip recurrences with their own counters,
+// 0 (default) = all clips in one recurrence.  Returns the previous setting; < 0 queries.
+// Measured: the interleaved form is SLOWER (18.6 vs 14.9 us per step at 64 clips, H = 1024, both directions): a step is not
+// waiting for the other workgroups but walking its own chain of dependent latencies (counter poll -> state loads from L2 ->
+// MFMAs -> LDS sum -> write-through store acknowledged -> arrival), about 9.5 us for 32 clips whatever else is going on, and
+// a workgroup executes its two halves one after the other.
+extern "C" int cvc_gru_persistent_halves(int on) {
+    const int prev = cvc_gru_halves;
+    if (on >= 0) cvc_gru_halves = on ? 1 : 0;
+    return prev;
+}
+
+// Same operands and results as cvc_gru_seq_fwd (include/cvc_hip.h) except hq: (F + 1) * ndir * H * 64 floats; `sync` = 8 words of device memory (four arrival counters
+// and, at word 4, an error word that is non-zero afterwards when the barrier timed out -- the outputs are then invalid).  Returns
 // CVC_E_BADARG for shapes outside the persistent form (H % 128 != 0, H > 1024, more workgroups than can be resident): use
 // cvc_gru_seq_fwd then.
 extern "C" int cvc_gru_seq_persistent_fwd(const float* wp, const float* gi, long long gi_ld_m, long long gi_ld_t, const float* b_ih,
@@ -261,12 +284,14 @@ extern "C" int cvc_gru_seq_persistent_fwd(const float* wp, const float* gi, long
     const long long n = a.h_stride * ndir;                          // slot 0 = h0 = 0
     hipLaunchKernelGGL(gru_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, hq, n, sync);
     const int NC = H / 128;
-#define CVC_GRU_P(MT_, NC_) return launch_persistent<MT_, NC_>(a, ndir, st)
-    if (M <= 32) {
-        switch (NC) { case 1: CVC_GRU_P(1, 1); case 2: CVC_GRU_P(1, 2); case 3: CVC_GRU_P(1, 3); case 4: CVC_GRU_P(1, 4);
-                      case 5: CVC_GRU_P(1, 5); case 6: CVC_GRU_P(1, 6); case 7: CVC_GRU_P(1, 7); default: CVC_GRU_P(1, 8); }
-    }
-    switch (NC) { case 1: CVC_GRU_P(2, 1); case 2: CVC_GRU_P(2, 2); case 3: CVC_GRU_P(2, 3); case 4: CVC_GRU_P(2, 4);
-                  case 5: CVC_GRU_P(2, 5); case 6: CVC_GRU_P(2, 6); case 7: CVC_GRU_P(2, 7); default: CVC_GRU_P(2, 8); }
+#define CVC_GRU_P(NH_, MT_, NC_) return launch_persistent<NH_, MT_, NC_>(a, ndir, st)
+#define CVC_GRU_NC(NH_, MT_)                                                                                          \
+    switch (NC) { case 1: CVC_GRU_P(NH_, MT_, 1); case 2: CVC_GRU_P(NH_, MT_, 2); case 3: CVC_GRU_P(NH_, MT_, 3);      \
+                  case 4: CVC_GRU_P(NH_, MT_, 4); case 5: CVC_GRU_P(NH_, MT_, 5); case 6: CVC_GRU_P(NH_, MT_, 6);      \
+                  case 7: CVC_GRU_P(NH_, MT_, 7); default: CVC_GRU_P(NH_, MT_, 8); }
+    if (M <= 32) { CVC_GRU_NC(1, 1) }
+    if (cvc_gru_halves) { CVC_GRU_NC(2, 1) }        // two interleaved 32-clip recurrences
+    CVC_GRU_NC(1, 2)
+#undef CVC_GRU_NC
 #undef CVC_GRU_P
 }

@@ -90,11 +90,11 @@ def gru_forward(gru: nn.GRU, x: torch.Tensor) -> torch.Tensor:
                     hq.data_ptr(), y.data_ptr(), ld_m, ld_t)
             done = False
             if PERSISTENT and H % 128 == 0 and H <= 1024:
-                sync = torch.zeros(4, device=x.device, dtype=torch.int32)
+                sync = torch.zeros(8, device=x.device, dtype=torch.int32)
                 slots = torch.empty((F + 1) * ndir * H * 64, device=x.device, dtype=torch.float32)     # one state slot per step
                 pargs = args[:10] + (slots.data_ptr(),) + args[11:]
                 if L.cvc_gru_seq_persistent_fwd(*pargs, sync.data_ptr(), st) == 0:
-                    done = int(sync[2]) == 0          # (host sync) a barrier time-out leaves the error word set: redo per step
+                    done = int(sync[4]) == 0          # (host sync) a barrier time-out leaves the error word set: redo per step
             if not done:
                 hip._check(L.cvc_gru_seq_fwd(*args, st), "cvc_gru_seq_fwd")
             global last_form

@@ -222,6 +222,15 @@ def test_gru_hip_vs_oracle(B, F, inp, H, layers, bidir):
     assert torch.equal(got, again)
     np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(steps.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
+    if H % 128 == 0 and B > 32:        # the interleaved-halves form of the persistent kernel: same per-clip arithmetic, same bits
+        from cvc import hip
+        prev = hip.lib().cvc_gru_persistent_halves(1)
+        try:
+            with torch.no_grad():
+                halves = G.gru_forward(gd, x.cuda())
+            assert G.last_form == "persistent" and torch.equal(halves, got)
+        finally:
+            hip.lib().cvc_gru_persistent_halves(prev)
     # (the two forms split K over 4 and 8 waves: same products, different fp32 summation order)
     np.testing.assert_allclose(got.cpu().numpy(), steps.cpu().numpy(), rtol=1e-5, atol=1e-5)
 
