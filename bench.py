@@ -60,6 +60,8 @@ def parse():
     p.add_argument("--tile-loaders", type=int, default=None, choices=[0, 1, 2, 3],
                    help="tile GEMM form (A/B): 0 = every wave copies, 1 = loader waves + 8 computing waves, 2 = loader waves + 4 wide "
                         "computing waves (default of the library)")
+    p.add_argument("--lstm-blocks", type=int, default=None, choices=[1, 2],
+                   help="packed decode LSTM gate GEMM (A/B): 32-row weight blocks per workgroup (library default 1)")
     p.add_argument("--train-graph", action="store_true", help="--mode train: capture the whole training step in a HIP graph")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-repeats", type=int, default=3)
@@ -367,6 +369,9 @@ def main():
     if args.tile_loaders is not None:
         from cvc import hip as _hip
         _hip.lib().cvc_tile_gemm_loaders(int(args.tile_loaders))
+    if args.lstm_blocks is not None:
+        from cvc import hip as _hip
+        _hip.lib().cvc_packed_lstm_wg_blocks(int(args.lstm_blocks))
     # under torchrun (RANK set) the process group is always initialised, also for a single rank, so that the
     # barrier / max-over-ranks path is the same code at every N
     dist_on = "RANK" in os.environ and "WORLD_SIZE" in os.environ

@@ -75,9 +75,15 @@ __device__ __forceinline__ float sum_partials(const float* red, int row, int ldm
     return v;
 }
 
-template <int MT, bool LSTM, int DEPTH, bool SPLIT, int NW, bool GRU = false>
+// NB = 32-row weight blocks per workgroup (LSTM decode form only; selectable experiment, see cvc_packed_lstm_wg_blocks).
+// NB = 2: waves w and w + NW/2 take the SAME K chunks for two different blocks, on the same SIMD and in lock step, so the
+// second request for an activation line is served by the CU's L1 (or merged with the pending miss): L2 activation reads per
+// launch halve (402 -> 201 MB for the lang cell), with half as many workgroups.
+template <int MT, bool LSTM, int DEPTH, bool SPLIT, int NW, bool GRU = false, int NB = 1>
 __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs a) {
     static_assert(!GRU || LSTM, "the GRU step shares the LSTM form's work split");
+    static_assert(NB == 1 || (LSTM && !GRU && NW == 8 && NB == 2), "two blocks per workgroup: LSTM form, 8 waves");
+    constexpr int NWK = NW / NB;                               // waves that split K for one block
     if constexpr (GRU) {                                       // direction of this workgroup
         a.wp += (size_t)blockIdx.y * a.gru_w_stride;
         a.xq += (size_t)blockIdx.y * a.gru_h_stride;
@@ -99,11 +105,12 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
         c0 = lo;
         nchunk = hi - lo;
     }
-    const int n_my = nchunk > wave ? (nchunk - wave + NW - 1) / NW : 0;   // chunks c0 + wave + 4*j
+    const int wblk = NB == 1 ? 0 : wave / NWK, kw = NB == 1 ? wave : wave % NWK;       // this wave's block and K slot
+    const int n_my = nchunk > kw ? (nchunk - kw + NWK - 1) / NWK : 0;     // chunks c0 + kw + NWK*j
     // per-lane bases: quad q of this block lives at wp + ((blk * nquad + q) * 32 + i) * 4
-    const float* wl = a.wp + ((size_t)blockIdx.x * a.nquad * 32 + i) * 4 + (size_t)(c0 + wave) * 8 * 128 + kh * 4 * 128;
-    const float* xl = a.xq + (size_t)i * 4 + (size_t)(c0 + wave) * 8 * 256 + kh * 4 * 256;
-    constexpr size_t WSTEP = (size_t)NW * 8 * 128, XSTEP = (size_t)NW * 8 * 256;   // floats per wave-chunk step
+    const float* wl = a.wp + ((size_t)((int)blockIdx.x * NB + wblk) * a.nquad * 32 + i) * 4 + (size_t)(c0 + kw) * 8 * 128 + kh * 4 * 128;
+    const float* xl = a.xq + (size_t)i * 4 + (size_t)(c0 + kw) * 8 * 256 + kh * 4 * 256;
+    constexpr size_t WSTEP = (size_t)NWK * 8 * 128, XSTEP = (size_t)NWK * 8 * 256;   // floats per wave-chunk step
 #ifndef CVC_ROT_MUL
 #define CVC_ROT_MUL 5
 #endif
@@ -233,9 +240,10 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
 
     // LSTM: the cell update's global operands (one work item per thread: batch row m, 4 hidden units) are requested
     // BEFORE the cross-wave LDS stage, so that their latency runs under it
-    const int em = tid & 63, eqd = tid >> 6;
-    const bool ework = LSTM && tid < 2 * 64 && em < M && em < MT * 32;
-    const int ejq = (int)blockIdx.x * 8 + eqd * 4;                     // first of this thread's 4 hidden units
+    const int em = tid & 63, eqd = (tid >> 6) & 1, eb = tid >> 7;       // (batch row, hidden quad, block of the workgroup)
+    const bool ework = LSTM && tid < NB * 2 * 64 && em < M && em < MT * 32;
+    const int ejq = ((int)blockIdx.x * NB + eb) * 8 + eqd * 4;         // first of this thread's 4 hidden units
+    const float* ered = red + (NB == 1 ? 0 : eb * NWK * 32 * LDM);     // the partial tiles of this thread's block
     const size_t eqoff = ((size_t)(ejq / 4) * 64 + em) * 4;
     f32x4 ecp = {0, 0, 0, 0}, eadd[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     f32x4 eadd2[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, eadd3[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
                 const int jj = eqd * 4 + e;
                 float pre[3];
 #pragma unroll
-                for (int g = 0; g < 3; ++g) pre[g] = sum_partials<NW>(red, g * 8 + jj, LDM, em);
+                for (int g = 0; g < 3; ++g) pre[g] = sum_partials<NWK>(ered, g * 8 + jj, LDM, em);
                 const float rg = fast_sigmoid(pre[0] + eadd[0][e]), zg = fast_sigmoid(pre[1] + eadd[1][e]);
                 const float ng = fast_tanh(eadd[2][e] + rg * (pre[2] + eadd[3][e]));
                 hv[e] = ng + zg * (ecp[e] - ng);                       // (1 - z) n + z h
@@ -314,7 +322,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
                 const int jj = eqd * 4 + e;
                 float pre[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) pre[g] = sum_partials<NW>(red, g * 8 + jj, LDM, em) + eadd[g][e];
+                for (int g = 0; g < 4; ++g) pre[g] = sum_partials<NWK>(ered, g * 8 + jj, LDM, em) + eadd[g][e];
                 const float ig = fast_sigmoid(pre[0]), fg = fast_sigmoid(pre[1]);
                 const float gg = fast_tanh(pre[2]), og = fast_sigmoid(pre[3]);
                 const float c2 = fg * ecp[e] + ig * gg;
@@ -391,10 +399,28 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
 #define CVC_PACKED_DEPTH8 3
 #endif
 
+static int cvc_packed_lstm_blocks = 1;
+// A/B + test hook: weight blocks per workgroup of the decode LSTM gate GEMM (1 = default, or 2); returns the previous setting,
+// < 1 queries.  Measured at cfg2: two blocks per workgroup 85.6 / 74.1 us (lang / att) against 53.3 / 45.8 -- the L2 activation
+// reads do halve, but with 128 workgroups every CU does twice the operand splitting (44 us of VALU work per SIMD) and twice the
+// MFMAs (35 us) while half the chip idles: compute-bound.
+extern "C" int cvc_packed_lstm_wg_blocks(int n) {
+    const int prev = cvc_packed_lstm_blocks;
+    if (n >= 1) cvc_packed_lstm_blocks = n >= 2 ? 2 : 1;
+    return prev;
+}
+
 template <bool LSTM>
 static int launch_packed(const PackedArgs& a, int blocks, hipStream_t st) {
     if (a.M < 1 || a.M > 64 || (a.nquad & 7) || a.nquad < 8) return CVC_E_BADARG;
     const dim3 grid(blocks, LSTM || a.ksplit < 1 ? 1 : a.ksplit);
+    if constexpr (LSTM) {
+        // decode form, 64-row workgroups (two blocks each): halves the L2 activation reads
+        if (cvc_gemm_split_mode == 2 && cvc_packed_lstm_blocks == 2 && (blocks & 1) == 0 && a.M > 32 && a.h_rm == nullptr) {
+            hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, true, CVC_PACKED_DEPTH8, true, 8, false, 2>), dim3(blocks / 2), dim3(512), 0, st, a);
+            return cvc_launch_status();
+        }
+    }
     if (cvc_gemm_split_mode == 2) {            // split products, 8 waves (2 per SIMD), ring depth CVC_PACKED_DEPTH8
         if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_packed_kernel<1, LSTM, CVC_PACKED_DEPTH8, true, 8>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, LSTM, CVC_PACKED_DEPTH8, true, 8>), grid, dim3(512), 0, st, a);

@@ -67,6 +67,7 @@ SIGNATURES = {
     "cvc_attn_wsum_quad": [C.POINTER(AttnSet), _I, _I, _I, _I, _P, _P],
     "cvc_packed_lstm_fwd": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "cvc_packed_linear_fwd": [_P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P],
+    "cvc_packed_lstm_wg_blocks": [_I],
     "cvc_packed_lstm_train_fwd": [_P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "cvc_pack_lstm_weights": [_P, _I, _P, _I, _I, _P, _P],
     "cvc_pack_quad_segs": [C.POINTER(_P), C.POINTER(_LL), C.POINTER(_I), _I, _I, _P, _P],

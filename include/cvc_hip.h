@@ -149,6 +149,10 @@ int cvc_packed_lstm_fwd(const float* wp, const float* xq, int K, const float* b_
                         float* h_dst2_q, float* c_out_q, cvc_stream_t stream);
 int cvc_packed_linear_fwd(const float* wp, const float* xq, int K, const float* bias, int M, int Nout,
                           int ksplit, float* y, int ldy, float* top2_part, cvc_stream_t stream);
+/* A/B + test hook: 32-row weight blocks per workgroup of cvc_packed_lstm_fwd (1 = default; 2: two blocks share every
+ * activation line through the CU's L1 -- halves the L2 reads, measured 60 % slower because half the CUs then do all the
+ * operand splitting; same results up to the fp32 summation order over K).  Returns the previous setting; n < 1 only queries. */
+int cvc_packed_lstm_wg_blocks(int n);
 
 /* Training form of cvc_packed_lstm_fwd (nn.LSTMCell forward under autograd, decoder_core.py:45-50, 59-61): the same GEMM
  * kernel with row-major state -- c_prev / h_out / c_out [M, R] and the activated gates [M, 4R] (i, f, g, o; nullable) that

@@ -847,6 +847,27 @@ def test_decode_with_ksplit_gate_gemms_equals_default_engine(dev, lib, form):
         assert all(torch.equal(x, y) for x, y in zip(a, e.run()))
 
 
+def test_decode_with_two_block_gate_gemm_workgroups(dev, lib):
+    """The selectable 64-row-workgroup form of the packed gate GEMM (cvc_packed_lstm_wg_blocks(2): two weight blocks share
+    every activation line through the L1) against the default: same sequences, attention within the recurrent tolerance."""
+    from helpers import to_dev
+    from cvc.decode import DecodeEngine, DecodeWeights
+    d = dataclasses.replace(synth.CONFIGS["tiny"], B=64, N=20, F=12, R=256, A=64, E=64, V=300, T=6)
+    sd, f_np = synth.hot_path_state_dict(d, 56), synth.clip_features(d, 56)
+    W, f = DecodeWeights(to_dev(sd, dev)), to_dev(f_np, dev)
+    ref = [x.clone() for x in DecodeEngine(W, f, d.T, synth.UNK_IDX).run()]
+    prev = lib.lib().cvc_packed_lstm_wg_blocks(2)
+    try:
+        e = DecodeEngine(W, f, d.T, synth.UNK_IDX)
+        a = [x.clone() for x in e.run()]
+        assert all(torch.equal(x, y) for x, y in zip(a, e.run()))
+    finally:
+        lib.lib().cvc_packed_lstm_wg_blocks(prev)
+    same = (a[0] == ref[0]).all(1)
+    assert int(same.sum()) >= d.B - 1
+    close(a[1][same], ref[1][same], **SEQ_TOL)
+
+
 def test_beam5_cfg1_vs_oracle(dev, lib):
     """beam=5 at config-1 size (rows = 20, V = 5000): sequences/scores vs the CPU beam oracle; where the oracle's
     own candidate margin is inside fp32 noise the comparison stops at that step (tie-aware)."""
