@@ -14,19 +14,15 @@ from . import hip
 ENABLED = True
 MIN_ROWS = 1024          # below this the launch-bound library kernel is as good
 
-_packs: Dict[int, Tuple[tuple, "hip.TileOperand"]] = {}
-
 
 def _weight_operand(lin: nn.Linear):
     w = lin.weight
     stamp = (w.data_ptr(), w._version)
-    ent = _packs.get(id(lin))
+    ent = getattr(lin, "_cvc_tile_operand", None)      # lives on the module
     if ent is not None and ent[0] == stamp:
         return ent[1]
     op = hip.TileOperand(w.detach().float().contiguous())
-    if len(_packs) > 32:
-        _packs.clear()
-    _packs[id(lin)] = (stamp, op)
+    lin._cvc_tile_operand = (stamp, op)
     return op
 
 

@@ -163,17 +163,16 @@ class _LstmCell(torch.autograd.Function):
     """nn.LSTMCell over a virtual concat of input segments (decoder_core.py:45-50, 59-61)."""
 
     @staticmethod
-    def forward(ctx, w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, *xs):
+    def forward(ctx, w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, wp, *xs):
         xs = [_c(x) for x in xs]
         h_prev, c_prev = _c(h_prev), _c(c_prev)
         k0 = sum(x.shape[1] for x in xs)
         assert k0 == w_ih.shape[1], ("LSTM input width mismatch", k0, tuple(w_ih.shape))
         need_bwd = any(ctx.needs_input_grad)
         M, R = c_prev.shape
-        if PACKED_LSTM_FORWARD and w_ih.is_contiguous() and w_hh.is_contiguous() and hip.lstm_train_ok(
-                M, R, [x.shape[1] for x in xs] + [h_prev.shape[1]]) and all(x.data_ptr() % 16 == 0 for x in (*xs, h_prev)):
-            # the decode engine's packed gate GEMM; its weight pack is rebuilt once per optimizer step
-            h, c, gates = hip.lstm_cell_train_fwd(xs, h_prev, c_prev, w_ih, w_hh, b_ih, b_hh, want_gates=need_bwd)
+        if wp is not None and all(x.data_ptr() % 16 == 0 for x in (*xs, h_prev)):
+            # the decode engine's packed gate GEMM; `wp` is the pack lstm_cell() found on (or built for) the weight tensors
+            h, c, gates = hip.lstm_cell_train_fwd(xs, h_prev, c_prev, wp, b_ih, b_hh, want_gates=need_bwd)
         else:
             segs, k0 = [], 0
             for x in xs:
@@ -200,7 +199,7 @@ class _LstmCell(torch.autograd.Function):
         # dX ranges that need a gradient: (weight, first column, width) in the order h_prev, xs...
         ranges, k0 = ([(w_hh, 0, w_hh.shape[1])] if ni[4] else []), 0
         for i, x in enumerate(xs):
-            if ni[6 + i]:
+            if ni[7 + i]:
                 ranges.append((w_ih, k0, x.shape[1]))
             k0 += x.shape[1]
         use_nn = bool(ranges) and hip.linear_nn_ok(M, K, ranges)
@@ -229,20 +228,25 @@ class _LstmCell(torch.autograd.Function):
         if use_nn:                      # every needed dX from one pass over the weights (csrc/gemm_nn.hip)
             got = iter(hip.linear_nn(pw[2], M, K, ranges))
             d_h_prev = next(got) if ni[4] else None
-            d_xs = [next(got) if ni[6 + i] else None for i in range(len(xs))]
+            d_xs = [next(got) if ni[7 + i] else None for i in range(len(xs))]
         else:                           # widths the kernel does not take (not multiples of 4): library GEMM
             d_h_prev = _mm_nn(d_gates, w_hh) if ni[4] else None
             d_xs, k0 = [], 0
             for i, x in enumerate(xs):
                 k = x.shape[1]
-                d_xs.append(_mm_nn(d_gates, w_ih[:, k0:k0 + k]) if ni[6 + i] else None)
+                d_xs.append(_mm_nn(d_gates, w_ih[:, k0:k0 + k]) if ni[7 + i] else None)
                 k0 += k
         return (d_w_ih, d_w_hh, d_b if ni[2] else None, d_b if ni[3] else None, d_h_prev,
-                d_c_prev if ni[5] else None, *d_xs)
+                d_c_prev if ni[5] else None, None, *d_xs)
 
 
 def lstm_cell(xs: Sequence[Tensor], h_prev: Tensor, c_prev: Tensor, w_ih, w_hh, b_ih, b_hh) -> Tuple[Tensor, Tensor]:
-    return _LstmCell.apply(w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, *xs)
+    wp = None
+    M, R = c_prev.shape
+    if (PACKED_LSTM_FORWARD and w_ih.is_cuda and w_ih.is_contiguous() and w_hh.is_contiguous()
+            and hip.lstm_train_ok(M, R, [x.shape[1] for x in xs] + [h_prev.shape[1]])):
+        wp = hip.lstm_train_pack(w_ih, w_hh)          # lives on the parameter object; rebuilt once per optimizer step
+    return _LstmCell.apply(w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, wp, *xs)
 
 
 # ------------------------------------------------------------------------------- attention

@@ -22,8 +22,6 @@ import torch.nn as nn
 from . import hip
 from .decode import pack_weights
 
-_packs: Dict[int, Tuple[tuple, list]] = {}
-
 PERSISTENT = True       # False: always the per-step form (A/B switch)
 last_form = None        # "persistent" / "steps": which form produced the last layer (tests, bench)
 
@@ -49,7 +47,7 @@ def _layer_operands(gru: nn.GRU):
     rebuilt when any parameter changed."""
     params = list(gru.parameters())
     stamp = tuple((p.data_ptr(), p._version) for p in params)
-    ent = _packs.get(id(gru))
+    ent = getattr(gru, "_cvc_gru_pack", None)          # lives on the module (no table keyed by ids / addresses)
     if ent is not None and ent[0] == stamp:
         return ent[1]
     H, sfx = gru.hidden_size, ([""] if not gru.bidirectional else ["", "_reverse"])
@@ -60,9 +58,7 @@ def _layer_operands(gru: nn.GRU):
             w_ih = torch.cat(g("weight_ih"), 0).contiguous()
             layers.append((hip.TileOperand(w_ih, kmajor=False), torch.stack([pack_gru_weights(w, H) for w in g("weight_hh")]),
                            torch.stack(g("bias_ih")).contiguous(), torch.stack(g("bias_hh")).contiguous()))
-    if len(_packs) > 8:
-        _packs.clear()
-    _packs[id(gru)] = (stamp, layers)
+    gru._cvc_gru_pack = (stamp, layers)
     return layers
 
 

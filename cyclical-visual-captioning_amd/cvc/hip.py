@@ -329,7 +329,6 @@ def lstm_cell_fwd(segs: Sequence[dict], b_ih, b_hh, c_prev, want_gates: bool = F
 
 
 # ---- training form of the packed gate GEMM: the weights are re-packed once per optimizer step, the cell's inputs per call
-_train_packs: dict = {}     # (w_ih ptr, w_hh ptr) -> [packed tensor, generation, w_ih version, w_hh version]
 _train_generation = 0
 
 
@@ -344,18 +343,21 @@ def lstm_train_ok(M: int, R: int, widths: Sequence[int]) -> bool:
     return 1 <= M <= 64 and R % 8 == 0 and all(w % 4 == 0 and w >= 4 for w in widths) and sum(widths) % 32 == 0
 
 
-def _train_pack(w_ih, w_hh, R):
-    key = (w_ih.data_ptr(), w_hh.data_ptr())
-    ent = _train_packs.get(key)
-    stamp = (_train_generation, w_ih._version, w_hh._version)
+def lstm_train_pack(w_ih: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
+    """Packed copy [R/8][(K_ih + K_hh)/4][32][4] of an LSTM cell's weights for cvc_packed_lstm_train_fwd.  The pack lives ON
+    the weight tensor object (it dies with it: no table keyed by addresses that a later tensor could reuse) and is rebuilt
+    when the step generation, either tensor's version counter or either address changed."""
+    R = w_hh.shape[1]
+    stamp = (_train_generation, w_ih._version, w_hh._version, w_ih.data_ptr(), w_hh.data_ptr(), tuple(w_ih.shape))
+    ent = getattr(w_ih, "_cvc_train_pack", None)
     if ent is not None and ent[1] == stamp:
         return ent[0]
     K_ih, K_hh = w_ih.shape[1], w_hh.shape[1]
-    wp = ent[0] if ent is not None else torch.empty(R // 8, (K_ih + K_hh) // 4, 32, 4, device=w_ih.device, dtype=torch.float32)
+    shape = (R // 8, (K_ih + K_hh) // 4, 32, 4)
+    wp = ent[0] if (ent is not None and tuple(ent[0].shape) == shape and ent[0].device == w_ih.device) else \
+        torch.empty(*shape, device=w_ih.device, dtype=torch.float32)
     _check(lib().cvc_pack_lstm_weights(_dev(w_ih), K_ih, _dev(w_hh), K_hh, R, _dev(wp), _stream()), "cvc_pack_lstm_weights")
-    if len(_train_packs) > 16 and ent is None:
-        _train_packs.clear()
-    _train_packs[key] = [wp, stamp]
+    w_ih._cvc_train_pack = (wp, stamp)
     return wp
 
 
@@ -370,10 +372,10 @@ def pack_quad_segs(xs: Sequence[torch.Tensor]) -> torch.Tensor:
     return xq
 
 
-def lstm_cell_train_fwd(xs: Sequence[torch.Tensor], h_prev, c_prev, w_ih, w_hh, b_ih, b_hh, want_gates: bool = True):
-    """nn.LSTMCell forward on the packed gate GEMM (cvc_packed_lstm_train_fwd): -> h, c, activated gates (or None)."""
+def lstm_cell_train_fwd(xs: Sequence[torch.Tensor], h_prev, c_prev, wp, b_ih, b_hh, want_gates: bool = True):
+    """nn.LSTMCell forward on the packed gate GEMM (cvc_packed_lstm_train_fwd) from the pack `lstm_train_pack` built:
+    -> h, c, activated gates (or None)."""
     M, R = c_prev.shape
-    wp = _train_pack(w_ih, w_hh, R)
     xq = pack_quad_segs([*xs, h_prev])
     h, c = torch.empty_like(c_prev), torch.empty_like(c_prev)
     gates = torch.empty(M, 4 * R, device=c_prev.device, dtype=torch.float32) if want_gates else None

@@ -987,11 +987,11 @@ def test_lstm_train_form_of_packed_gemm(dev, lib, M, R, widths):
     xs, h_prev, c_prev = [rnd(M, w) for w in widths], rnd(M, R), rnd(M, R)
     assert lib.lstm_train_ok(M, R, list(widths) + [R])
     # operands
-    wp = lib._train_pack(w_ih, w_hh, R)
+    wp = lib.lstm_train_pack(w_ih, w_hh)
     assert torch.equal(wp, pack_weights(torch.cat([w_ih, w_hh], 1), R))
     assert torch.equal(lib.pack_quad_segs([*xs, h_prev]), to_quad(torch.cat([*xs, h_prev], 1)))
     # forward
-    h, c, gates = lib.lstm_cell_train_fwd(xs, h_prev, c_prev, w_ih, w_hh, b_ih, b_hh)
+    h, c, gates = lib.lstm_cell_train_fwd(xs, h_prev, c_prev, wp, b_ih, b_hh)
     segs, k0 = [], 0
     for x in xs:
         segs.append({"x": x, "w": w_ih[:, k0:k0 + x.shape[1]]}); k0 += x.shape[1]
@@ -1020,7 +1020,8 @@ def test_lstm_train_form_of_packed_gemm(dev, lib, M, R, widths):
         close(a, b, rtol=1e-4, atol=1e-4)
     # an in-place update of the weights invalidates the pack
     w_ih.mul_(0.5)
-    h3, _, _ = lib.lstm_cell_train_fwd(xs, h_prev, c_prev, w_ih, w_hh, b_ih, b_hh)
+    assert lib.lstm_train_pack(w_ih, w_hh) is wp            # same buffer, rebuilt in place
+    h3, _, _ = lib.lstm_cell_train_fwd(xs, h_prev, c_prev, wp, b_ih, b_hh)
     pre = X @ torch.cat([w_ih, w_hh], 1).double().t() + b_ih.double() + b_hh.double()
     i, f, gg, o = pre.chunk(4, 1)
     h64b = torch.sigmoid(o) * torch.tanh(torch.sigmoid(f) * c_prev.double() + torch.sigmoid(i) * torch.tanh(gg))
