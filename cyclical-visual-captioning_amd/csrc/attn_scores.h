@@ -106,8 +106,13 @@ __global__ __launch_bounds__(SCORE_WG) void attn_scores_kernel(ScoreArgs a) {
         // are issued back to back (beams of a clip / the T localizer queries of a clip share this row's registers)
         for (int q0 = 0; q0 < nq; q0 += QG) {
             float acc[QG];
+            // additive form with several queries per row: the pass is bound by its two quarter-rate transcendentals per
+            // element-query (exp2, rcp); the four full-rate operations around them are taken two elements at a time on the
+            // packed-fp32 VALU (v_pk_add_f32 / v_pk_fma_f32), with even / odd partial sums
+            using f32x2 = __attribute__((ext_vector_type(2))) float;
+            f32x2 acc2[QG];
 #pragma unroll
-            for (int u = 0; u < QG; ++u) acc[u] = 0.f;
+            for (int u = 0; u < QG; ++u) { acc[u] = 0.f; acc2[u] = f32x2{0.f, 0.f}; }
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
                 f32x4 p = cok[j] ? cur[j] : f32x4{0, 0, 0, 0};
@@ -122,14 +127,29 @@ __global__ __launch_bounds__(SCORE_WG) void attn_scores_kernel(ScoreArgs a) {
                     const f32x4 q4 = ld4(q_s + (q0 + u) * A + colc[j]);
                     if (KIND == CVC_ATTN_ADDITIVE) {
                         const f32x4 x = p + q4;                    // C (p + q)
-                        acc[u] = fmaf(w4.x, fmaf(-2.0f, fast_rcp(1.0f + __builtin_amdgcn_exp2f(x.x)), 1.0f), acc[u]);
-                        acc[u] = fmaf(w4.y, fmaf(-2.0f, fast_rcp(1.0f + __builtin_amdgcn_exp2f(x.y)), 1.0f), acc[u]);
-                        acc[u] = fmaf(w4.z, fmaf(-2.0f, fast_rcp(1.0f + __builtin_amdgcn_exp2f(x.z)), 1.0f), acc[u]);
-                        acc[u] = fmaf(w4.w, fmaf(-2.0f, fast_rcp(1.0f + __builtin_amdgcn_exp2f(x.w)), 1.0f), acc[u]);
+                        if constexpr (QG > 1) {
+                            const f32x2 e01 = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+                            const f32x2 e23 = {__builtin_amdgcn_exp2f(x.z), __builtin_amdgcn_exp2f(x.w)};
+                            const f32x2 d01 = e01 + 1.0f, d23 = e23 + 1.0f;
+                            const f32x2 r01 = {fast_rcp(d01.x), fast_rcp(d01.y)}, r23 = {fast_rcp(d23.x), fast_rcp(d23.y)};
+                            const f32x2 t01 = __builtin_elementwise_fma(f32x2{-2.0f, -2.0f}, r01, f32x2{1.0f, 1.0f});
+                            const f32x2 t23 = __builtin_elementwise_fma(f32x2{-2.0f, -2.0f}, r23, f32x2{1.0f, 1.0f});
+                            acc2[u] = __builtin_elementwise_fma(f32x2{w4.x, w4.y}, t01, acc2[u]);
+                            acc2[u] = __builtin_elementwise_fma(f32x2{w4.z, w4.w}, t23, acc2[u]);
+                        } else {
+                            acc[u] = fmaf(w4.x, fmaf(-2.0f, fast_rcp(1.0f + __builtin_amdgcn_exp2f(x.x)), 1.0f), acc[u]);
+                            acc[u] = fmaf(w4.y, fmaf(-2.0f, fast_rcp(1.0f + __builtin_amdgcn_exp2f(x.y)), 1.0f), acc[u]);
+                            acc[u] = fmaf(w4.z, fmaf(-2.0f, fast_rcp(1.0f + __builtin_amdgcn_exp2f(x.z)), 1.0f), acc[u]);
+                            acc[u] = fmaf(w4.w, fmaf(-2.0f, fast_rcp(1.0f + __builtin_amdgcn_exp2f(x.w)), 1.0f), acc[u]);
+                        }
                     } else {
                         acc[u] += p.x * q4.x + p.y * q4.y + p.z * q4.z + p.w * q4.w;
                     }
                 }
+            }
+            if constexpr (KIND == CVC_ATTN_ADDITIVE && QG > 1) {
+#pragma unroll
+                for (int u = 0; u < QG; ++u) acc[u] = acc2[u].x + acc2[u].y;
             }
 #pragma unroll
             for (int u = 0; u < QG; ++u) acc[u] = wave_sum(acc[u]);
