@@ -158,21 +158,23 @@ __global__ __launch_bounds__(WG) void attn_wsum_mq_kernel(WsumArgs a, int n_max)
         const int n = S.n;
         for (int u = nqb; u < QB; ++u)                  // unused slots of the group weigh nothing: the FMA loop has no branches
             for (int i = tid; i < n; i += WG) a_s[(size_t)u * n_max + i] = 0.f;
-        for (int u = 0; u < nqb; ++u) {                 // softmax over n per query (torch.softmax: exp(x - max) / sum)
+        // softmax over n per query (torch.softmax: exp(x - max) / sum): one WAVE per query, reductions inside the wave -- the
+        // block-wide form cost 2 reductions x 2 barriers per query and feature set before the first context byte was requested
+        for (int u = wave; u < nqb; u += WG / 64) {
             const int row = clip * a.nq + qbase + u;
             const float* sc = S.scores + (size_t)row * n;
             float* as = a_s + (size_t)u * n_max;
             float m = -INFINITY;
-            for (int i = tid; i < n; i += WG) m = fmaxf(m, sc[i]);
-            m = block_reduce(m, red, true);
+            for (int i = lane; i < n; i += 64) m = fmaxf(m, sc[i]);
+            m = wave_max(m);
             float sum = 0.f;
-            for (int i = tid; i < n; i += WG) {
+            for (int i = lane; i < n; i += 64) {
                 float e = expf(sc[i] - m);
                 as[i] = e;
                 sum += e;
             }
-            sum = block_reduce(sum, red, false);
-            for (int i = tid; i < n; i += WG) {
+            sum = wave_sum(sum);
+            for (int i = lane; i < n; i += 64) {
                 float p = as[i] / sum;
                 as[i] = p;
                 if (cb == 0) S.attn[(size_t)row * n + i] = p;
@@ -189,6 +191,17 @@ __global__ __launch_bounds__(WG) void attn_wsum_mq_kernel(WsumArgs a, int n_max)
             constexpr bool STREAM = decltype(stream_tag)::value;
 #define LDF(ptr) (STREAM ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ptr)) : ld4(ptr))
             int i = wave;
+            for (; i + 28 < n; i += 32) {                  // 8 rows (8 KB per wave) in flight
+                f32x4 c[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) c[k] = LDF(C + (size_t)(i + 4 * k) * R);
+#pragma unroll
+                for (int u = 0; u < QB; ++u) {
+                    const float* as = a_s + (size_t)u * n_max;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[u] += as[i + 4 * k] * c[k];
+                }
+            }
             for (; i + 12 < n; i += 16) {
                 const f32x4 c0 = LDF(C + (size_t)i * R), c1 = LDF(C + (size_t)(i + 4) * R);
                 const f32x4 c2 = LDF(C + (size_t)(i + 8) * R), c3 = LDF(C + (size_t)(i + 12) * R);
