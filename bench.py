@@ -345,15 +345,19 @@ def train_work(d):
     w = {}
     k_att, k_lang = E + 3 * R, 3 * R                       # K of the two cells (fc segment included in training)
     # forward cells: Loop A + Loop C, T launches each per cell
-    w["cvc_lstm_cell_fwd"] = dict(bytes=2 * T * 4 * (4 * R * (k_att + k_lang)) + 2 * T * 4 * B * (k_att + k_lang + 12 * R),
-                                  flops=2 * T * 2 * B * 4 * R * (k_att + k_lang), mfma="split")
+    cells = dict(bytes=2 * T * 4 * (4 * R * (k_att + k_lang)) + 2 * T * 4 * B * (k_att + k_lang + 12 * R),
+                 flops=2 * T * 2 * B * 4 * R * (k_att + k_lang), mfma="split")
+    w["cvc_packed_lstm_train_fwd"] = cells           # the packed gate GEMM in its training form (default)
+    w["cvc_lstm_cell_fwd"] = cells                   # the row-major ring kernel (shapes the packed form does not take)
     # backward-data of the cells: every input range except fc_feats (features carry no gradient in the bench)
     kx = (E + 2 * R) + 3 * R
-    w["cvc_linear_nn_fwd"] = dict(bytes=2 * T * 4 * 4 * R * kx + 2 * T * 4 * B * (8 * R + kx), flops=2 * T * 2 * B * 4 * R * kx, mfma="f32")
+    w["cvc_linear_nn_fwd"] = dict(bytes=2 * T * 4 * 4 * R * kx + 2 * T * 4 * B * (8 * R + kx), flops=2 * T * 2 * B * 4 * R * kx,
+                                  mfma="split")      # skinny_gemm_nn_split_kernel (cvc_gemm_packed_split != 0, the default)
     # attention: Loop A (T launches, nq = 1) + Loop B (1 launch, nq = T): each streams proj + ctx of both sets once
     att_bytes = 4 * B * (N + F) * (A + R)
     w["cvc_attn_fwd"] = dict(bytes=(T + 1) * att_bytes, flops=(T + T) * B * (N + F) * (4 * A + 2 * R), mfma="none")
-    w["cvc_attn_bwd"] = dict(bytes=2 * (T + 1) * att_bytes, flops=2 * (T + T) * B * (N + F) * (4 * A + 2 * R), mfma="none")
+    # backward: the context rows once (d_attn = d_ctx . C), the projected rows once (tanh recomputed) -- one call per feature set
+    w["cvc_attn_bwd"] = dict(bytes=(T + 1) * att_bytes, flops=2 * (T + T) * B * (N + F) * (4 * A + 2 * R), mfma="none")
     return w
 
 

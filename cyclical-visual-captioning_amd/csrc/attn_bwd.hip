@@ -53,7 +53,9 @@ struct ScoreBwdArgs {
     int nq, n, A;
 };
 
-template <int KIND>
+// WANT_DP: also accumulate into d_proj (the features carry gradient: encoder in the loop).  Rows are taken 8 at a time per wave
+// with all 8 loads requested before the first use (the rolled form kept 4 KB per wave in flight: 1.6 TB/s, latency-bound).
+template <int KIND, bool WANT_DP>
 __global__ __launch_bounds__(WG) void attn_score_bwd_kernel(ScoreBwdArgs a) {
     __shared__ f32x4 part[2][4][64];
     const int clip = blockIdx.y, cb = blockIdx.x;
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(WG) void attn_score_bwd_kernel(ScoreBwdArgs a) {
     const int col = cb * 256 + lane * 4;
     const bool ok = col < A;
     const float* P = a.proj + (size_t)clip * n * A + col;
-    float* dP = a.d_proj != nullptr ? a.d_proj + (size_t)clip * n * A + col : nullptr;
+    float* dP = WANT_DP ? a.d_proj + (size_t)clip * n * A + col : nullptr;
     f32x4 w4 = {0, 0, 0, 0};
     if (KIND == CVC_ATTN_ADDITIVE && ok) w4 = ld4(a.w_a + col);
     for (int qi = 0; qi < a.nq; ++qi) {
@@ -70,26 +72,33 @@ __global__ __launch_bounds__(WG) void attn_score_bwd_kernel(ScoreBwdArgs a) {
         f32x4 q4 = ok ? ld4(a.q + row * A + col) : f32x4{0, 0, 0, 0};
         f32x4 dq = {0, 0, 0, 0}, dw = {0, 0, 0, 0};
         const float* ds_row = a.d_scores + row * n;
-        if (ok) {
-#pragma unroll 4
-            for (int i = wave; i < n; i += 4) {
-                const float ds = ds_row[i];
-                const f32x4 p = ld4(P + (size_t)i * A);
-                f32x4 dpre;
-                if (KIND == CVC_ATTN_ADDITIVE) {
-                    f32x4 t;
-                    t.x = fast_tanh(p.x + q4.x); t.y = fast_tanh(p.y + q4.y);
-                    t.z = fast_tanh(p.z + q4.z); t.w = fast_tanh(p.w + q4.w);
-                    dpre = ds * w4 * (1.f - t * t);
-                    dw += ds * t;
-                    dq += dpre;
-                } else {
-                    const float g = ds * a.inv_temp;
-                    dpre = g * q4;
-                    dq += g * p;
-                }
-                if (dP != nullptr) st4(dP + (size_t)i * A, ld4(dP + (size_t)i * A) + dpre);
+        auto one = [&](const float ds, const f32x4 p, const int i) __attribute__((always_inline)) {
+            f32x4 dpre;
+            if (KIND == CVC_ATTN_ADDITIVE) {
+                f32x4 t;
+                t.x = fast_tanh(p.x + q4.x); t.y = fast_tanh(p.y + q4.y);
+                t.z = fast_tanh(p.z + q4.z); t.w = fast_tanh(p.w + q4.w);
+                dpre = ds * w4 * (1.f - t * t);
+                dw += ds * t;
+                dq += dpre;
+            } else {
+                const float g = ds * a.inv_temp;
+                dpre = g * q4;
+                dq += g * p;
             }
+            if constexpr (WANT_DP) st4(dP + (size_t)i * A, ld4(dP + (size_t)i * A) + dpre);
+        };
+        if (ok) {
+            int i = wave;
+            for (; i + 28 < n; i += 32) {
+                f32x4 p[8];
+                float ds[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { p[k] = ld4(P + (size_t)(i + 4 * k) * A); ds[k] = ds_row[i + 4 * k]; }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) one(ds[k], p[k], i + 4 * k);
+            }
+            for (; i < n; i += 4) one(ds_row[i], ld4(P + (size_t)i * A), i);
         }
         __syncthreads();
         part[0][wave][lane] = dq;
@@ -149,8 +158,13 @@ extern "C" int cvc_attn_bwd(int kind, const float* q, const float* w_a, float in
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3(rows), dim3(WG), 0, st, attn, d_fm, n, d_ctx != nullptr ? 1 : 0, d_scores);
     ScoreBwdArgs a{q, w_a, proj, d_scores, d_q, d_w_part, d_proj, inv_temp, nq, n, A};
     dim3 grid((A + 255) / 256, nclip);
-    if (kind == CVC_ATTN_ADDITIVE) hipLaunchKernelGGL(attn_score_bwd_kernel<CVC_ATTN_ADDITIVE>, grid, dim3(WG), 0, st, a);
-    else hipLaunchKernelGGL(attn_score_bwd_kernel<CVC_ATTN_DOT>, grid, dim3(WG), 0, st, a);
+    if (kind == CVC_ATTN_ADDITIVE) {
+        if (d_proj != nullptr) hipLaunchKernelGGL((attn_score_bwd_kernel<CVC_ATTN_ADDITIVE, true>), grid, dim3(WG), 0, st, a);
+        else hipLaunchKernelGGL((attn_score_bwd_kernel<CVC_ATTN_ADDITIVE, false>), grid, dim3(WG), 0, st, a);
+    } else {
+        if (d_proj != nullptr) hipLaunchKernelGGL((attn_score_bwd_kernel<CVC_ATTN_DOT, true>), grid, dim3(WG), 0, st, a);
+        else hipLaunchKernelGGL((attn_score_bwd_kernel<CVC_ATTN_DOT, false>), grid, dim3(WG), 0, st, a);
+    }
     if (d_ctxfeat != nullptr && d_ctx != nullptr)
         hipLaunchKernelGGL(ctxfeat_bwd_kernel, dim3((R + 255) / 256, nclip), dim3(WG), 0, st, attn, d_ctx, nq, n, R,
                            d_ctxfeat);
