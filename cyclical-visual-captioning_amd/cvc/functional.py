@@ -92,6 +92,9 @@ def _mm_nn(dy: Tensor, w: Tensor) -> Tensor:
 
 
 # ------------------------------------------------------------------------------- linear
+TILE_LINEAR_ROWS = 64          # more rows than the skinny kernels take in one launch -> tile GEMM (0 rows = never: A/B switch)
+
+
 class _Linear(torch.autograd.Function):
     """y = cat(xs) W^T + b with the concat virtual (nn.Linear over torch.cat)."""
 
@@ -104,7 +107,15 @@ class _Linear(torch.autograd.Function):
             segs.append({"x": x, "w": weight[:, k0:k0 + x.shape[1]]})
             k0 += x.shape[1]
         assert k0 == weight.shape[1], (k0, weight.shape)
-        y = hip.linear_fwd(segs, bias, M, weight.shape[0])
+        if M > TILE_LINEAR_ROWS and weight.is_contiguous():
+            # many rows (a layer applied to all T steps at once): ONE pass over the weights on the tile GEMM; the skinny
+            # kernel would re-stream them per 64-row slab
+            x = torch.cat(xs, 1) if len(xs) > 1 else xs[0]
+            y = hip.tile_mm(x, weight)
+            if bias is not None:
+                y += bias
+        else:
+            y = hip.linear_fwd(segs, bias, M, weight.shape[0])
         ctx.save_for_backward(weight, bias, *xs)
         ctx.has_bias = bias is not None
         ctx.key = ("linear", weight.data_ptr())
