@@ -587,9 +587,13 @@ class TileOperand:
             t = t.contiguous()
         self.rows, self.K = (t.shape[1], t.shape[0]) if kmajor else (t.shape[0], t.shape[1])
         rows_alloc = max(tile_rows_alloc(self.rows), (self.rows + 127) // 128 * 128)
-        # (padding rows / k must read as zero; a shape without padding is written completely by the packer)
-        alloc = torch.empty if (rows_alloc == self.rows and self.K % 16 == 0) else torch.zeros
-        self.frags = alloc(rows_alloc // 32, (self.K + 15) // 16, 3, 2, 32, 8, dtype=torch.int16, device=t.device)
+        # padding must read as zero: only what the packer does not write completely is cleared -- the row blocks past the last
+        # full one, and the last k step when K is not a multiple of 16 (the row packer writes whole quads, not whole k steps)
+        self.frags = torch.empty(rows_alloc // 32, (self.K + 15) // 16, 3, 2, 32, 8, dtype=torch.int16, device=t.device)
+        if rows_alloc > self.rows:
+            self.frags[self.rows // 32:].zero_()
+        if self.K % 16 != 0:
+            self.frags[:, -1].zero_()
         self.ptr, self.stride = _frag_ptr(self.frags)
         L = lib()
         if kmajor:
