@@ -21,6 +21,14 @@ def _c(t: Optional[Tensor]) -> Optional[Tensor]:
     return None if t is None else t.contiguous()
 
 
+def _rows(t: Tensor) -> Tensor:
+    """A [M, k] GEMM input as the kernels take it: unit inner stride, rows 16-byte aligned (any row stride) -- a step's slice
+    of a [B, T, k] tensor goes in as it is instead of through a copy."""
+    if t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0:
+        return t
+    return t.contiguous()
+
+
 # ------------------------------------------------------------------------------- deferred weight gradients
 class _WeightGradBatcher:
     """A weight used at every time step (LSTM cells, h2attn: 2 x T uses per training step) would
@@ -100,7 +108,7 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, weight: Tensor, bias: Optional[Tensor], *xs: Tensor):
-        xs = [_c(x) for x in xs]
+        xs = [_rows(x) for x in xs]
         M = xs[0].shape[0]
         segs, k0 = [], 0
         for x in xs:
@@ -175,7 +183,7 @@ class _LstmCell(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, wp, *xs):
-        xs = [_c(x) for x in xs]
+        xs = [_rows(x) for x in xs]
         h_prev, c_prev = _c(h_prev), _c(c_prev)
         k0 = sum(x.shape[1] for x in xs)
         assert k0 == w_ih.shape[1], ("LSTM input width mismatch", k0, tuple(w_ih.shape))
@@ -291,7 +299,7 @@ class _Attention(torch.autograd.Function):
         res = [ctx_sum if nsets > 1 else outs[0][3]]
         non_diff = []
         for (scores, fm, attn, ctx_out) in outs:
-            fm_out = fm if fm is not None else q.new_zeros(())
+            fm_out = fm if fm is not None else q.new_empty(())      # placeholder, never read (no fill launch)
             res += [ctx_out, attn, fm_out]
             non_diff.append(attn)
         ctx.mark_non_differentiable(*non_diff)
