@@ -125,7 +125,8 @@ __global__ __launch_bounds__(WG) void nll_bwd_kernel(const int64_t* target, cons
 }
 
 struct Top2 { float v1; int i1; float v2; int i2; };
-__device__ __forceinline__ bool better(float va, int ia, float vb, int ib) { return va > vb || (va == vb && ia < ib); }
+// (bitwise, not short-circuit: three compares and two mask operations instead of branches)
+__device__ __forceinline__ bool better(float va, int ia, float vb, int ib) { return (va > vb) | ((va == vb) & (ia < ib)); }
 __device__ __forceinline__ Top2 merge(Top2 a, Top2 b) {
     Top2 r;
     if (better(a.v1, a.i1, b.v1, b.i1)) {
@@ -432,8 +433,7 @@ __global__ __launch_bounds__(WG) void beam_rowtop4_kernel(const float* logits, i
 #pragma unroll
     for (int g = 0; g < NG; ++g)
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if ((tid + g * WG) * 4 + e == unk) v4[g][e] = -INFINITY;
+        for (int e = 0; e < 4; ++e) v4[g][e] = ((tid + g * WG) * 4 + e == unk) ? -INFINITY : v4[g][e];
     for (int sel = 0; sel < beam; ++sel) {
         float bv = -INFINITY;
         int bi = 0x7fffffff;
@@ -442,20 +442,23 @@ __global__ __launch_bounds__(WG) void beam_rowtop4_kernel(const float* logits, i
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int v = (tid + g * WG) * 4 + e;
-                if (v < V && better(v4[g][e], v, bv, bi)) { bv = v4[g][e]; bi = v; }
+                const bool take = (v < V) & better(v4[g][e], v, bv, bi);
+                bv = take ? v4[g][e] : bv;
+                bi = take ? v : bi;
             }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float ov = __shfl_xor(bv, o, 64);
             const int oi = __shfl_xor(bi, o, 64);
-            if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+            const bool take = better(ov, oi, bv, bi);
+            bv = take ? ov : bv;
+            bi = take ? oi : bi;
         }
         if (lane == 0) { wv[wave * BEAM_MAX + sel] = bv; wi[wave * BEAM_MAX + sel] = bi; }
 #pragma unroll
         for (int g = 0; g < NG; ++g)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if ((tid + g * WG) * 4 + e == bi) v4[g][e] = -INFINITY;   // taken
+            for (int e = 0; e < 4; ++e) v4[g][e] = ((tid + g * WG) * 4 + e == bi) ? -INFINITY : v4[g][e];   // taken
     }
     __syncthreads();
     if (wave == 0) {
@@ -477,7 +480,9 @@ __global__ __launch_bounds__(WG) void beam_rowtop4_kernel(const float* logits, i
             for (int o = 32; o > 0; o >>= 1) {
                 const float ov = __shfl_xor(bv, o, 64);
                 const int oi = __shfl_xor(bi, o, 64);
-                if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+                const bool take = better(ov, oi, bv, bi);
+                bv = take ? ov : bv;
+                bi = take ? oi : bi;
             }
             if (lane == 0) { cand_v[row * BEAM_MAX + sel] = bv; cand_i[row * BEAM_MAX + sel] = bi; }
             if (ci == bi) { cv = -INFINITY; ci = 0x7fffffff; }
