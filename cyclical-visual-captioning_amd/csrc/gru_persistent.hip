@@ -20,6 +20,10 @@
 
 namespace {
 
+// sync buffer: word SYNC_ERR = error flag; then 4 groups (direction x batch half) of CNT arrival counters, CNT_STRIDE words apart
+constexpr int CNT = 32, CNT_STRIDE = 1024, SYNC_ERR = 4;
+constexpr long long SYNC_WORDS = SYNC_ERR + 8 + 4LL * CNT * CNT_STRIDE;
+
 struct GruPArgs {
     const float* wp; long long w_stride;          // packed W_hh [ndir][H/8][Kp/4][32][4]
     const float* gi; long long gi_ld_m, gi_ld_t;  // input projections (no bias), columns [ndir][3H]
@@ -27,7 +31,7 @@ struct GruPArgs {
     int M, F, H, Kp;
     float* hq; long long h_stride;                // state slots, quad layout: [F + 1][ndir][Kp/4][64][4], slot 0 = h0
     float* y; long long y_ld_m, y_ld_t;
-    unsigned* sync;                               // [dir * 2 + group] arrival counters, [4] error word (8 words)
+    unsigned* sync;                               // SYNC_WORDS words: error word + arrival counters (see above)
     unsigned spin_limit;
 };
 
@@ -35,10 +39,12 @@ struct GruPArgs {
 // (NH x MT = 1 or 2): with NH = 2 the two halves of a 64-clip batch are separate recurrences with their own arrival counters,
 // walked alternately -- while the other workgroups' states of one half are still in flight, this workgroup computes the other
 // half, so that a barrier's latency hides behind useful work.
-template <int NH, int MT, int NC>
-__global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruPArgs a) {
+// NW = 4 waves (one per SIMD, K / 4 each) or 8 (two per SIMD, K / 8 each: while one wave of a SIMD splits its activations on
+// the VALU the other's MFMAs run -- measured 7.4 us of a 14 us step are this compute chain with 4 waves).
+template <int NH, int MT, int NC, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void gru_persistent_kernel(GruPArgs a) {
     constexpr int LDM = MT * 32 + 1;
-    __shared__ float red[4 * 32 * LDM];
+    __shared__ float red[NW * 32 * LDM];
     __shared__ int gave_up;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -57,7 +63,7 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruPArgs a) {
     const int rot = CVC_GRU_ROT ? (blk * 5 + dir * 3) % NC : 0;
     int chunk_of[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) chunk_of[c] = wave + 4 * ((c + rot) % NC);
+    for (int c = 0; c < NC; ++c) chunk_of[c] = wave + NW * ((c + rot) % NC);
     {
         const float* wl = a.wp + (size_t)dir * a.w_stride + ((size_t)blk * nquad * 32 + i) * 4 + kh * 4 * 128;
 #pragma unroll
@@ -94,7 +100,9 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruPArgs a) {
             const int m = hf * ET + em;                                // clip row of the epilogue role
             const bool ework = eqd < 2 && m < M;
             const size_t eqoff = ((size_t)(ejq / 4) * 64 + (m < 64 ? m : 63)) * 4;
-            unsigned* counter = a.sync + dir * 2 + hf;
+            // arrivals are spread over CNT counters 4 KB apart (different memory channels): 128 increments of ONE word queue up
+            // behind each other at the memory-side atomic unit, and the last arrival is the one everybody waits for
+            unsigned* counter = a.sync + SYNC_ERR + 8 + (size_t)((dir * 2 + hf) * CNT) * CNT_STRIDE;
 
             // x-projections of this step: independent of the other workgroups, requested before the wait
             f32x4 egi[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -106,13 +114,21 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruPArgs a) {
 
             // ---- wait until every workgroup of this direction has published step s - 1 of this group
             if (s > 0) {
-                if (tid == 0) {
+                if (wave == 0) {                                       // lanes 0 .. CNT-1 read one counter each
                     const unsigned target = nblk * (unsigned)s;
                     unsigned it = 0;
-                    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-                        if (++it > a.spin_limit || __hip_atomic_load(a.sync + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                            __hip_atomic_store(a.sync + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            gave_up = 1;                               // tell the workgroup
+                    for (;;) {
+                        unsigned v = lane < CNT ? __hip_atomic_load(counter + (size_t)lane * CNT_STRIDE, __ATOMIC_RELAXED,
+                                                                    __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+                        for (int o = 1; o < CNT; o <<= 1) v += __shfl_xor(v, o, 64);
+                        v = __builtin_amdgcn_readfirstlane(v);         // lane 0 holds the sum: one decision for the wave
+                        if (v >= target) break;
+                        if (++it > a.spin_limit || __hip_atomic_load(a.sync + SYNC_ERR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                            if (lane == 0) {
+                                __hip_atomic_store(a.sync + SYNC_ERR, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                gave_up = 1;                           // tell the workgroup
+                            }
                             break;
                         }
                         __builtin_amdgcn_s_sleep(2);
@@ -203,6 +219,9 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruPArgs a) {
                         const int row = g * 8 + jj;
                         pre[g] = (red[(0 * 32 + row) * LDM + em] + red[(1 * 32 + row) * LDM + em]) +
                                  (red[(2 * 32 + row) * LDM + em] + red[(3 * 32 + row) * LDM + em]);
+                        if constexpr (NW == 8)
+                            pre[g] += (red[(4 * 32 + row) * LDM + em] + red[(5 * 32 + row) * LDM + em]) +
+                                      (red[(6 * 32 + row) * LDM + em] + red[(7 * 32 + row) * LDM + em]);
                     }
                     const float rg = fast_sigmoid(pre[0] + egi[0][e] + ebias[0][e]);
                     const float zg = fast_sigmoid(pre[1] + egi[1][e] + ebias[1][e]);
@@ -219,7 +238,8 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruPArgs a) {
             }
             // ---- publish: one arrival per workgroup, after all of its state stores have been acknowledged
             __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0)
+                __hip_atomic_fetch_add(counter + (size_t)(blk % CNT) * CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -227,15 +247,15 @@ __global__ __launch_bounds__(256, 1) void gru_persistent_kernel(GruPArgs a) {
 __global__ __launch_bounds__(256) void gru_zero_kernel(float* p, long long n, unsigned* sync) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t < n) p[t] = 0.f;
-    if (t < 8) sync[t] = 0u;
+    if (t < SYNC_WORDS) sync[t] = 0u;
 }
 
-template <int NH, int MT, int NC>
+template <int NH, int MT, int NC, int NW>
 int launch_persistent(GruPArgs& a, int ndir, hipStream_t st) {
     void* params[] = {&a};
     const dim3 grid(a.H / 8, ndir);
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)gru_persistent_kernel<NH, MT, NC>, 256, 0) != hipSuccess) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)gru_persistent_kernel<NH, MT, NC, NW>, NW * 64, 0) != hipSuccess) {
         (void)hipGetLastError();
         return CVC_E_BADARG;
     }
@@ -243,7 +263,7 @@ int launch_persistent(GruPArgs& a, int ndir, hipStream_t st) {
     if (hipGetDevice(&devid) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid) != hipSuccess)
         return CVC_E_BADARG;
     if ((long long)per_cu * cus < (long long)grid.x * grid.y) return CVC_E_BADARG;     // would not be co-resident
-    if (hipLaunchCooperativeKernel((const void*)gru_persistent_kernel<NH, MT, NC>, grid, dim3(256), params, 0, st) != hipSuccess) {
+    if (hipLaunchCooperativeKernel((const void*)gru_persistent_kernel<NH, MT, NC, NW>, grid, dim3(NW * 64), params, 0, st) != hipSuccess) {
         (void)hipGetLastError();
         return CVC_E_BADARG;
     }
@@ -251,6 +271,16 @@ int launch_persistent(GruPArgs& a, int ndir, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" long long cvc_gru_persistent_sync_words(void) { return SYNC_WORDS; }
+
+static int cvc_gru_waves8 = 1;
+// A/B + test hook: 1 (default) = 8 waves per workgroup where K is a multiple of 256, 0 = always 4.  Returns the previous setting.
+extern "C" int cvc_gru_persistent_waves8(int on) {
+    const int prev = cvc_gru_waves8;
+    if (on >= 0) cvc_gru_waves8 = on ? 1 : 0;
+    return prev;
+}
 
 static int cvc_gru_halves = 0;
 // A/B + test hook: 1 = a batch of more than 32 clips runs as two interleaved 32-clip recurrences with their own counters,
@@ -265,7 +295,7 @@ extern "C" int cvc_gru_persistent_halves(int on) {
     return prev;
 }
 
-// Same operands and results as cvc_gru_seq_fwd (include/cvc_hip.h) except hq: (F + 1) * ndir * H * 64 floats; `sync` = 8 words of device memory (four arrival counters
+// Same operands and results as cvc_gru_seq_fwd (include/cvc_hip.h) except hq: (F + 1) * ndir * H * 64 floats; `sync` = cvc_gru_persistent_sync_words() words of device memory (arrival counters
 // and, at word 4, an error word that is non-zero afterwards when the barrier timed out -- the outputs are then invalid).  Returns
 // CVC_E_BADARG for shapes outside the persistent form (H % 128 != 0, H > 1024, more workgroups than can be resident): use
 // cvc_gru_seq_fwd then.
@@ -282,13 +312,20 @@ extern "C" int cvc_gru_seq_persistent_fwd(const float* wp, const float* gi, long
     a.M = M; a.F = F; a.H = H; a.Kp = H; a.hq = hq; a.h_stride = (long long)H * 64;
     a.y = y; a.y_ld_m = y_ld_m; a.y_ld_t = y_ld_t; a.sync = sync; a.spin_limit = 1u << 20;
     const long long n = a.h_stride * ndir;                          // slot 0 = h0 = 0
-    hipLaunchKernelGGL(gru_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, hq, n, sync);
-    const int NC = H / 128;
-#define CVC_GRU_P(NH_, MT_, NC_) return launch_persistent<NH_, MT_, NC_>(a, ndir, st)
-#define CVC_GRU_NC(NH_, MT_)                                                                                          \
-    switch (NC) { case 1: CVC_GRU_P(NH_, MT_, 1); case 2: CVC_GRU_P(NH_, MT_, 2); case 3: CVC_GRU_P(NH_, MT_, 3);      \
-                  case 4: CVC_GRU_P(NH_, MT_, 4); case 5: CVC_GRU_P(NH_, MT_, 5); case 6: CVC_GRU_P(NH_, MT_, 6);      \
-                  case 7: CVC_GRU_P(NH_, MT_, 7); default: CVC_GRU_P(NH_, MT_, 8); }
+    const long long nz = n > SYNC_WORDS ? n : SYNC_WORDS;
+    hipLaunchKernelGGL(gru_zero_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, st, hq, n, sync);
+    // 8 waves (K / 8 per wave) when K is a multiple of 256, else 4 waves (K / 4 per wave)
+    const bool w8 = cvc_gru_waves8 && (H % 256) == 0;
+    const int NC = w8 ? H / 256 : H / 128;
+#define CVC_GRU_P(NH_, MT_, NC_, NW_) return launch_persistent<NH_, MT_, NC_, NW_>(a, ndir, st)
+#define CVC_GRU_NC(NH_, MT_)                                                                                              \
+    if (w8) {                                                                                                             \
+        switch (NC) { case 1: CVC_GRU_P(NH_, MT_, 1, 8); case 2: CVC_GRU_P(NH_, MT_, 2, 8); case 3: CVC_GRU_P(NH_, MT_, 3, 8); \
+                      default: CVC_GRU_P(NH_, MT_, 4, 8); }                                                               \
+    }                                                                                                                     \
+    switch (NC) { case 1: CVC_GRU_P(NH_, MT_, 1, 4); case 2: CVC_GRU_P(NH_, MT_, 2, 4); case 3: CVC_GRU_P(NH_, MT_, 3, 4);     \
+                  case 4: CVC_GRU_P(NH_, MT_, 4, 4); case 5: CVC_GRU_P(NH_, MT_, 5, 4); case 6: CVC_GRU_P(NH_, MT_, 6, 4);     \
+                  case 7: CVC_GRU_P(NH_, MT_, 7, 4); default: CVC_GRU_P(NH_, MT_, 8, 4); }
     if (M <= 32) { CVC_GRU_NC(1, 1) }
     if (cvc_gru_halves) { CVC_GRU_NC(2, 1) }        // two interleaved 32-clip recurrences
     CVC_GRU_NC(1, 2)

@@ -86,7 +86,7 @@ def gru_forward(gru: nn.GRU, x: torch.Tensor) -> torch.Tensor:
                     hq.data_ptr(), y.data_ptr(), ld_m, ld_t)
             done = False
             if PERSISTENT and H % 128 == 0 and H <= 1024:
-                sync = torch.zeros(8, device=x.device, dtype=torch.int32)
+                sync = torch.zeros(int(L.cvc_gru_persistent_sync_words()), device=x.device, dtype=torch.int32)
                 slots = torch.empty((F + 1) * ndir * H * 64, device=x.device, dtype=torch.float32)     # one state slot per step
                 pargs = args[:10] + (slots.data_ptr(),) + args[11:]
                 if L.cvc_gru_seq_persistent_fwd(*pargs, sync.data_ptr(), st) == 0:

@@ -222,6 +222,16 @@ def test_gru_hip_vs_oracle(B, F, inp, H, layers, bidir):
     assert torch.equal(got, again)
     np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(steps.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
+    if H % 256 == 0:                   # 4 waves per workgroup instead of 8: K split four ways instead of eight (fp32 summation order)
+        from cvc import hip
+        prev = hip.lib().cvc_gru_persistent_waves8(0)
+        try:
+            with torch.no_grad():
+                w4 = G.gru_forward(gd, x.cuda())
+            assert G.last_form == "persistent"
+        finally:
+            hip.lib().cvc_gru_persistent_waves8(prev)
+        np.testing.assert_allclose(w4.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-5)
     if H % 128 == 0 and B > 32:        # the interleaved-halves form of the persistent kernel: same per-clip arithmetic, same bits
         from cvc import hip
         prev = hip.lib().cvc_gru_persistent_halves(1)

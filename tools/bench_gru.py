@@ -17,19 +17,19 @@ def run(M, H, ndir, F=240, mode=2):
     Kp = (H + 31) // 32 * 32
     hq = torch.empty(2 * ndir * Kp * 64, device=dev)
     y = torch.empty(F * M, ndir * H, device=dev)
-    sync = torch.zeros(8, device=dev, dtype=torch.int32)
+    sync = torch.zeros(int(L.cvc_gru_persistent_sync_words()), device=dev, dtype=torch.int32)
     slots = torch.empty((F + 1) * ndir * Kp * 64, device=dev)
     def go_p():
         rc = L.cvc_gru_seq_persistent_fwd(wp.data_ptr(), gi.data_ptr(), ndir * 3 * H, M * ndir * 3 * H, b1.data_ptr(), b2.data_ptr(), M, F, H, ndir,
                                slots.data_ptr(), y.data_ptr(), ndir * H, M * ndir * H, sync.data_ptr(), st)
         return rc
-    for halves in ((1, 0) if (H % 128 == 0 and H <= 1024 and mode == 2) else ()):
-        L.cvc_gru_persistent_halves(halves)
+    for halves in ((0, 2) if (H % 128 == 0 and H <= 1024 and mode == 2) else ()):      # 0: 8 waves (default), 2: 4 waves
+        L.cvc_gru_persistent_waves8(0 if halves == 2 else 1)
         rc = go_p(); torch.cuda.synchronize()
         if rc == 0 and int(sync[4]) == 0:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); go_p(); go_p(); e1.record(); torch.cuda.synchronize()
-            print(f"M={M:3d} H={H:5d} ndir={ndir} persistent halves={halves}: {e0.elapsed_time(e1) * 1e3 / (2 * F):6.2f} us/step  err={int(sync[4])}", flush=True)
+            print(f"M={M:3d} H={H:5d} ndir={ndir} persistent waves={4 if halves == 2 else 8}: {e0.elapsed_time(e1) * 1e3 / (2 * F):6.2f} us/step  err={int(sync[4])}", flush=True)
         else:
             print("persistent form unavailable", rc, int(sync[4]))
     def go():
