@@ -272,7 +272,7 @@ int launch_persistent(GruPArgs& a, int ndir, hipStream_t st) {
 
 }  // namespace
 
-extern "C" long long cvc_gru_persistent_sync_words(void) { return SYNC_WORDS; }
+extern "C" int cvc_gru_persistent_sync_words(void) { return (int)SYNC_WORDS; }
 
 static int cvc_gru_waves8 = 1;
 // A/B + test hook: 1 (default) = 8 waves per workgroup where K is a multiple of 256, 0 = always 4.  Returns the previous setting.

@@ -189,7 +189,7 @@ int cvc_gru_seq_fwd(const float* wp, const float* gi, long long gi_ld_m, long lo
  * words of device memory (arrival counters spread over memory channels); word 4 is non-zero afterwards when the (bounded) barrier wait timed out: the outputs are then
  * invalid and the caller repeats the sequence with cvc_gru_seq_fwd.  Returns CVC_E_BADARG without launching for shapes
  * outside its range (H % 128 != 0, H > 1024, or more workgroups than the device keeps resident at once). */
-long long cvc_gru_persistent_sync_words(void);
+int cvc_gru_persistent_sync_words(void);
 int cvc_gru_persistent_waves8(int on);   /* A/B + test hook: 1 (default) = 8 waves per workgroup where H % 256 == 0, 0 = always 4 */
 int cvc_gru_persistent_halves(int on);   /* A/B + test hook: 1 = more than 32 clips run as two interleaved 32-clip recurrences (measured slower), 0 = default */
 int cvc_gru_seq_persistent_fwd(const float* wp, const float* gi, long long gi_ld_m, long long gi_ld_t,
