@@ -127,6 +127,26 @@ __global__ __launch_bounds__(WG) void ctxfeat_bwd_kernel(const float* attn, cons
     }
 }
 
+// out[clip, i, :] = sum_q w[clip][q * ws_q + i * ws_i] * rows[clip, q, :]   (i < ni, q < nq; rows [nclip, nq, R], out [nclip, ni, R])
+// -- the two small per-clip products of the grounder's backward: a workgroup = (256 columns, output row i, clip); waves split q
+__global__ __launch_bounds__(WG) void weighted_rows_kernel(const float* w, long long w_clip, int ws_q, int ws_i, const float* rows,
+                                                           int nq, int ni, int R, float* out) {
+    __shared__ f32x4 part[4][64];
+    const int cb = blockIdx.x, i = blockIdx.y, clip = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = cb * 256 + lane * 4;
+    const bool ok = col < R;
+    const float* W = w + (size_t)clip * w_clip + (size_t)i * ws_i;
+    const float* X = rows + (size_t)clip * nq * R + col;
+    f32x4 acc = {0, 0, 0, 0};
+    if (ok)
+        for (int q = wave; q < nq; q += 4) acc += W[(size_t)q * ws_q] * ld4(X + (size_t)q * R);
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && ok)
+        st4(out + ((size_t)clip * ni + i) * R + col, (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]));
+}
+
 __global__ __launch_bounds__(WG) void grounder_epilogue_kernel(const float* bias, const uint8_t* mask, size_t total,
                                                                float* out) {
     const size_t i = (size_t)blockIdx.x * WG + threadIdx.x;
@@ -168,6 +188,19 @@ extern "C" int cvc_attn_bwd(int kind, const float* q, const float* w_a, float in
     if (d_ctxfeat != nullptr && d_ctx != nullptr)
         hipLaunchKernelGGL(ctxfeat_bwd_kernel, dim3((R + 255) / 256, nclip), dim3(WG), 0, st, attn, d_ctx, nq, n, R,
                            d_ctxfeat);
+    return cvc_launch_status();
+}
+
+// d_xt[b,t,:] = sum_n d[b,t,n] feats[b,n,:],  d_feats[b,n,:] = sum_t d[b,t,n] xt[b,t,:]   (either output may be null)
+extern "C" int cvc_grounder_bwd(const float* d, const float* xt, const float* feats, int B, int T, int N, int G, float* d_xt,
+                                float* d_feats, cvc_stream_t stream) {
+    if (!d || !xt || !feats || B < 1 || T < 1 || N < 1 || (G & 3) || (!d_xt && !d_feats)) return CVC_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const long long dclip = (long long)T * N;
+    if (d_xt != nullptr)         // q = region n (stride 1 in d), i = step t (stride N)
+        hipLaunchKernelGGL(weighted_rows_kernel, dim3((G + 255) / 256, T, B), dim3(WG), 0, st, d, dclip, 1, N, feats, N, T, G, d_xt);
+    if (d_feats != nullptr)      // q = step t (stride N), i = region n (stride 1)
+        hipLaunchKernelGGL(weighted_rows_kernel, dim3((G + 255) / 256, N, B), dim3(WG), 0, st, d, dclip, N, 1, xt, T, N, G, d_feats);
     return cvc_launch_status();
 }
 

@@ -479,10 +479,9 @@ class _Grounder(torch.autograd.Function):
     def backward(ctx, d_out):
         xt, feats, mask = ctx.saved_tensors
         # captioner.py:171 masks with an autograd-visible masked_fill_: no gradient at filled slots
-        d = d_out.masked_fill(mask, 0) if ctx.has_mask else d_out
+        d = (d_out.masked_fill(mask, 0) if ctx.has_mask else d_out).contiguous()
         ni = ctx.needs_input_grad
-        d_xt = torch.bmm(d, feats) if ni[0] else None
-        d_feats = torch.bmm(d.transpose(1, 2), xt) if ni[1] else None
+        d_xt, d_feats = hip.grounder_bwd(d, xt, feats, ni[0], ni[1]) if (ni[0] or ni[1]) else (None, None)
         return d_xt, d_feats, d if (ctx.has_bias and ni[2]) else None, None
 
 

@@ -99,6 +99,7 @@ SIGNATURES = {
     "cvc_vocab_nll_fwd": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P],
     "cvc_vocab_nll_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P],
     "cvc_grounder_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "cvc_grounder_bwd": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "cvc_beam_select": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "cvc_beam_select_parts": [_P, _I, _LL, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "cvc_gather_rows": [_P, _P, _I, _I, _I, _P, _P],
@@ -518,6 +519,15 @@ def grounder_fwd(xt, feats, bias, mask):
     _check(lib().cvc_grounder_fwd(_dev(xt), _dev(feats), _dev(bias), _dev(m, torch.uint8), B, T, N, G, _dev(out), _stream()),
            "cvc_grounder_fwd")
     return out
+
+
+def grounder_bwd(d, xt, feats, want_xt: bool, want_feats: bool):
+    B, T, G = xt.shape
+    N = feats.shape[1]
+    d_xt = torch.empty_like(xt) if want_xt else None
+    d_feats = torch.empty_like(feats) if want_feats else None
+    _check(lib().cvc_grounder_bwd(_dev(d), _dev(xt), _dev(feats), B, T, N, G, _dev(d_xt), _dev(d_feats), _stream()), "cvc_grounder_bwd")
+    return d_xt, d_feats
 
 
 def beam_select(logits, score_in, done_in, B: int, beam: int, unk_idx: int, first_step: bool):

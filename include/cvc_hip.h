@@ -315,6 +315,10 @@ int cvc_vocab_nll_bwd(const float* logits, const float* lse, const int64_t* targ
  */
 int cvc_grounder_fwd(const float* xt, const float* feats, const float* bias, const uint8_t* mask,
                      int B, int T, int N, int G, float* out, cvc_stream_t stream);
+/* its backward (autograd of captioner.py:160-171): d [B,T,N] is the upstream gradient with masked slots already zero;
+ * d_xt[b,t,:] = sum_n d[b,t,n] feats[b,n,:], d_feats[b,n,:] = sum_t d[b,t,n] xt[b,t,:]; either output may be null. */
+int cvc_grounder_bwd(const float* d, const float* xt, const float* feats, int B, int T, int N, int G,
+                     float* d_xt, float* d_feats, cvc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Beam bookkeeping (build-defined, SURVEY.md section 7 "Beam-search specification"):
