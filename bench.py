@@ -93,9 +93,9 @@ def pmc_traffic(kernel, args, over, mode="decode"):
     tools/collect_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very command).
     The file records the hash of the kernel sources it was collected on; numbers from any other build are REFUSED
     (traffic = null plus the reason) instead of printed as if they were current."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
+    path = os.path.join(ROOT, "profiles", "traffic.json" if mode == "decode" else f"traffic_{mode}.json")
     if not os.path.exists(path):
-        return None, "profiles/traffic.json absent"
+        return None, f"profiles/{os.path.basename(path)} absent"
     try:
         tf = json.load(open(path))
     except Exception as e:

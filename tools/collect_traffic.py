@@ -38,6 +38,17 @@ DECODE_ROLES = {
 }
 
 
+# --mode train: C-ABI entry point of bench.py's training table -> kernel symbol; every dispatch of the symbol is averaged (the
+# entry points run the same kernel on a few shapes per step: both cells, both loops), as bench.py averages their durations
+TRAIN_ROLES = {
+    "cvc_linear_nn_fwd": (r"skinny_gemm_nn_split_kernel", 0, 1),
+    "cvc_packed_lstm_train_fwd": (r"skinny_gemm_packed_kernelILi\dELb1E", 0, 1),
+    "cvc_tile_gemm": (r"tile_gemm_ld2?_kernel", 0, 1),
+    "cvc_attn_score_bwd": (r"attn_score_bwd_kernel", 0, 1),
+    "cvc_attn_wsum": (r"attn_wsum_kernel", 0, 1),
+}
+
+
 def per_dispatch(path, counter):
     """[(kernel_name, value)] in dispatch order for one PMC counter."""
     db = sqlite3.connect(path)
@@ -75,7 +86,7 @@ def main():
     except Exception:
         out["git_head"] = None
     rows = []
-    for role, (pat, pos, cyc) in DECODE_ROLES.items():
+    for role, (pat, pos, cyc) in (TRAIN_ROLES if a.mode == "train" else DECODE_ROLES).items():
         rx = re.compile(pat)
         f = [(n, v) for n, v in fetch if rx.search(n)]
         w = [(n, v) for n, v in write if rx.search(n)]

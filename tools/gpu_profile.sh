@@ -15,6 +15,13 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_
 MDB=$(find $O/pmc_m -name "*.db" | head -1)
 python3 $R/tools/rocpd_pmc.py $MDB > $O/${TAG}_pmc_mfma_busy.md 2>&1
 rm -rf $O/pmc_f $O/pmc_w $O/pmc_m
+# the same two passes over the training step (its table averages every dispatch of an entry point's kernel)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_tf -o f -- python3 $R/bench.py --mode train --config cfg3 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_train_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_tw -o w -- python3 $R/bench.py --mode train --config cfg3 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_train_write.log 2>&1
+FDB=$(find $O/pmc_tf -name "*.db" | head -1); WDB=$(find $O/pmc_tw -name "*.db" | head -1)
+python3 $R/tools/collect_traffic.py $FDB $WDB --config cfg3 --beam 1 --mode train --out $O/traffic_train.json --md $O/${TAG}_pmc_traffic_train.md
+rm -rf $O/pmc_tf $O/pmc_tw
+cp $O/traffic_train.json $R/profiles/traffic_train.json
 # the bench lines below read this build's traffic (bench.py refuses a traffic.json whose kernel-source hash is not the build's)
 cp $O/traffic.json $R/profiles/traffic.json
 python3 $R/bench.py > $O/bench_${TAG}_greedy.json 2> $O/bench_greedy.err
