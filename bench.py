@@ -323,6 +323,25 @@ def run_encoder(args, d, dev):
             "ctx2att_fc [B*F, R] x [R, A] (backbone.py:343)": lambda: enc.ctx2att_fc(x_rnn),
         }
         piece_ms = {k: round(timed(fn, 10), 3) for k, fn in pieces.items()}
+    # the GRU under autograd (what end-to-end training through the encoder pays): forward + backward, both implementations
+    gru_mod = enc.context_enc
+    gru_mod.train()
+    xg = x_rnn.clone().requires_grad_(True)
+    probe = torch.randn(d.B, d.F, d.R, device=dev)
+
+    def fb_hip():
+        gru_mod.zero_grad(set_to_none=True); xg.grad = None
+        (gru_hip.gru_forward_train(gru_mod, xg) * probe).sum().backward()
+
+    def fb_lib():
+        gru_mod.zero_grad(set_to_none=True); xg.grad = None
+        gru_mod.flatten_parameters()
+        (gru_mod(xg)[0] * probe).sum().backward()
+
+    piece_ms["2-layer BiGRU forward + backward, HIP path (cvc.gru.gru_forward_train: cvc_gru_seq_bwd + tile GEMM)"] = round(timed(fb_hip, 3), 3)
+    piece_ms["2-layer BiGRU forward + backward, library module (MIOpen)"] = round(timed(fb_lib, 3), 3)
+    gru_mod.eval()
+    with torch.no_grad():
         backbone.HIP_GRU = False
         ms_library = timed(fwd, max(3, min(args.steps, 10)))
         backbone.HIP_GRU = True

@@ -31,6 +31,7 @@ struct GruPArgs {
     int M, F, H, Kp;
     float* hq; long long h_stride;                // state slots, quad layout: [F + 1][ndir][Kp/4][64][4], slot 0 = h0
     float* y; long long y_ld_m, y_ld_t;
+    float* gates; long long g_ld_m, g_ld_t;       // training: (r, z, n, W_hn h + b_hn) of every step, columns [ndir][4][H]; nullable
     unsigned* sync;                               // SYNC_WORDS words: error word + arrival counters (see above)
     unsigned spin_limit;
 };
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gru_persistent_kernel(GruPArgs a) 
                 }
             __syncthreads();
             if (ework) {
-                f32x4 hv;
+                f32x4 hv, gsave[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int jj = eqd * 4 + e;
@@ -227,6 +228,12 @@ __global__ __launch_bounds__(NW * 64, 1) void gru_persistent_kernel(GruPArgs a) 
                     const float zg = fast_sigmoid(pre[1] + egi[1][e] + ebias[1][e]);
                     const float ng = fast_tanh(egi[2][e] + ebias[2][e] + rg * (pre[2] + ebias[3][e]));
                     hv[e] = ng + zg * (ehp[e] - ng);
+                    gsave[0][e] = rg; gsave[1][e] = zg; gsave[2][e] = ng; gsave[3][e] = pre[2] + ebias[3][e];
+                }
+                if (a.gates != nullptr) {
+                    float* gp = a.gates + (size_t)m * a.g_ld_m + t * a.g_ld_t + (size_t)dir * 4 * H + ejq;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) st4(gp + g * H, gsave[g]);
                 }
                 // the state goes straight through this XCD's L2 to memory (sc0 sc1): a release fence would instead walk the
                 // whole L2 for dirty lines (buffer_wbl2) once per workgroup and step.  (Inline assembly is invisible to the
@@ -299,9 +306,32 @@ extern "C" int cvc_gru_persistent_halves(int on) {
 // and, at word 4, an error word that is non-zero afterwards when the barrier timed out -- the outputs are then invalid).  Returns
 // CVC_E_BADARG for shapes outside the persistent form (H % 128 != 0, H > 1024, more workgroups than can be resident): use
 // cvc_gru_seq_fwd then.
+static int gru_persistent_impl(const float* wp, const float* gi, long long gi_ld_m, long long gi_ld_t, const float* b_ih,
+                               const float* b_hh, int M, int F, int H, int ndir, float* hq, float* y, long long y_ld_m,
+                               long long y_ld_t, float* gates, long long g_ld_m, long long g_ld_t, unsigned* sync,
+                               cvc_stream_t stream);
+
 extern "C" int cvc_gru_seq_persistent_fwd(const float* wp, const float* gi, long long gi_ld_m, long long gi_ld_t, const float* b_ih,
                                           const float* b_hh, int M, int F, int H, int ndir, float* hq, float* y,
                                           long long y_ld_m, long long y_ld_t, unsigned* sync, cvc_stream_t stream) {
+    return gru_persistent_impl(wp, gi, gi_ld_m, gi_ld_t, b_ih, b_hh, M, F, H, ndir, hq, y, y_ld_m, y_ld_t, nullptr, 0, 0, sync, stream);
+}
+
+// Training form: additionally writes, for every step and direction, the gates autograd needs -- (r, z, n, W_hn h + b_hn) at
+// gates + m * g_ld_m + t * g_ld_t + d * 4H + {0, H, 2H, 3H}
+extern "C" int cvc_gru_seq_persistent_train_fwd(const float* wp, const float* gi, long long gi_ld_m, long long gi_ld_t,
+                                                const float* b_ih, const float* b_hh, int M, int F, int H, int ndir, float* hq,
+                                                float* y, long long y_ld_m, long long y_ld_t, float* gates, long long g_ld_m,
+                                                long long g_ld_t, unsigned* sync, cvc_stream_t stream) {
+    if (!gates || (g_ld_m & 3) || (g_ld_t & 3)) return CVC_E_BADARG;
+    return gru_persistent_impl(wp, gi, gi_ld_m, gi_ld_t, b_ih, b_hh, M, F, H, ndir, hq, y, y_ld_m, y_ld_t, gates, g_ld_m, g_ld_t, sync,
+                               stream);
+}
+
+static int gru_persistent_impl(const float* wp, const float* gi, long long gi_ld_m, long long gi_ld_t, const float* b_ih,
+                               const float* b_hh, int M, int F, int H, int ndir, float* hq, float* y, long long y_ld_m,
+                               long long y_ld_t, float* gates, long long g_ld_m, long long g_ld_t, unsigned* sync,
+                               cvc_stream_t stream) {
     if (!wp || !gi || !b_ih || !b_hh || !hq || !y || !sync || M < 1 || M > 64 || F < 1 || H < 128 || (H & 127) || H > 1024 ||
         ndir < 1 || ndir > 2 || (gi_ld_m & 3) || (gi_ld_t & 3) || (y_ld_m & 3) || (y_ld_t & 3))
         return CVC_E_BADARG;
@@ -311,6 +341,7 @@ extern "C" int cvc_gru_seq_persistent_fwd(const float* wp, const float* gi, long
     a.gi = gi; a.gi_ld_m = gi_ld_m; a.gi_ld_t = gi_ld_t; a.b_ih = b_ih; a.b_hh = b_hh;
     a.M = M; a.F = F; a.H = H; a.Kp = H; a.hq = hq; a.h_stride = (long long)H * 64;
     a.y = y; a.y_ld_m = y_ld_m; a.y_ld_t = y_ld_t; a.sync = sync; a.spin_limit = 1u << 20;
+    a.gates = gates; a.g_ld_m = g_ld_m; a.g_ld_t = g_ld_t;
     const long long n = a.h_stride * ndir;                          // slot 0 = h0 = 0
     const long long nz = n > SYNC_WORDS ? n : SYNC_WORDS;
     hipLaunchKernelGGL(gru_zero_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, st, hq, n, sync);

@@ -10,8 +10,10 @@ config 2).  Here a layer is
      - per step (cvc_gru_seq_fwd, csrc/gemm_packed.hip): F launches of the packed gate-GEMM kernel in its GRU form, W_hh of
        both directions (25 MB at H = 1024) re-read from the Infinity Cache every step -- any H % 8 == 0, and the fallback
        when the persistent form cannot run or reports a barrier time-out.
-Inference only (eval mode, h0 = 0, no inter-layer dropout): the training pass keeps the library module, whose backward
-autograd needs."""
+`gru_forward` is the inference path (no autograd).  `gru_forward_train` is the same recurrence under autograd (persistent form
+only: H % 128 == 0, H <= 1024): the forward additionally keeps every step's gates, the backward walks the sequence backwards
+on cvc_gru_seq_bwd (gate arithmetic + dgh W_hh per step on the LSTM cells' backward-data kernel) and takes dW_ih, dW_hh, dX and
+the biases from dense products over all steps on the tile GEMM; inter-layer dropout stays a torch op between the layers."""
 from __future__ import annotations
 
 from typing import Dict, List, Tuple
@@ -37,9 +39,14 @@ def pack_gru_weights(w_hh: torch.Tensor, H: int) -> torch.Tensor:
 
 
 def supported(gru: nn.Module, x: torch.Tensor) -> bool:
+    """Shapes / modules the inference path takes."""
     return (isinstance(gru, nn.GRU) and gru.batch_first and gru.bias and gru.hidden_size % 8 == 0 and x.dim() == 3
-            and x.is_cuda and x.dtype == torch.float32 and not (gru.training and gru.dropout > 0
-                                                                                          and gru.num_layers > 1))
+            and x.is_cuda and x.dtype == torch.float32)
+
+
+def supported_train(gru: nn.Module, x: torch.Tensor) -> bool:
+    """... the autograd path takes (it needs the persistent form of the recurrence)."""
+    return supported(gru, x) and gru.hidden_size % 128 == 0 and gru.hidden_size <= 1024
 
 
 def _layer_operands(gru: nn.GRU):
@@ -97,3 +104,79 @@ def gru_forward(gru: nn.GRU, x: torch.Tensor) -> torch.Tensor:
             last_form = "persistent" if done else "steps"
             cur = y
     return out
+
+
+# ------------------------------------------------------------------------------------------------ training (autograd)
+class _GruLayer(torch.autograd.Function):
+    """One GRU layer over time-major rows (t * m + clip): x [F*m, in] -> y [F*m, ndir*H]."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, m, F):
+        # w_ih [ndir*3H, in], w_hh [ndir, 3H, H], b_ih / b_hh [ndir, 3H]
+        ndir, H = w_hh.shape[0], w_hh.shape[2]
+        L, st = hip.lib(), hip._stream()
+        x, w_ih, w_hh = x.contiguous(), w_ih.contiguous(), w_hh.contiguous()
+        gi = hip.tile_mm(x, w_ih)
+        wp = torch.stack([pack_gru_weights(w_hh[d], H) for d in range(ndir)])
+        y = torch.empty(F * m, ndir * H, device=x.device, dtype=torch.float32)
+        gates = torch.empty(F * m, ndir * 4 * H, device=x.device, dtype=torch.float32)
+        sync = torch.zeros(int(L.cvc_gru_persistent_sync_words()), device=x.device, dtype=torch.int32)
+        slots = torch.empty((F + 1) * ndir * H * 64, device=x.device, dtype=torch.float32)
+        rc = L.cvc_gru_seq_persistent_train_fwd(wp.data_ptr(), gi.data_ptr(), ndir * 3 * H, m * ndir * 3 * H, b_ih.contiguous().data_ptr(),
+                                                b_hh.contiguous().data_ptr(), m, F, H, ndir, slots.data_ptr(), y.data_ptr(), ndir * H,
+                                                m * ndir * H, gates.data_ptr(), ndir * 4 * H, m * ndir * 4 * H, sync.data_ptr(), st)
+        if rc != 0 or int(sync[4]) != 0:
+            raise RuntimeError("cvc.gru: the persistent recurrence could not run (rc=%d, barrier word=%d)" % (rc, int(sync[4])))
+        ctx.save_for_backward(x, w_ih, w_hh, gates, y)
+        ctx.dims = (m, F, H, ndir)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w_ih, w_hh, gates, y = ctx.saved_tensors
+        m, F, H, ndir = ctx.dims
+        L, st = hip.lib(), hip._stream()
+        dy = dy.contiguous()
+        dgi = torch.empty(F * m, ndir * 3 * H, device=x.device, dtype=torch.float32)
+        dgh = torch.empty_like(dgi)
+        ks = int(L.cvc_gru_seq_bwd_ksplit(H))
+        work = torch.empty(ndir * (3 * m * H + 3 * H * 64) + ks * m * ((H + 127) // 128) * 128, device=x.device, dtype=torch.float32)
+        hip._check(L.cvc_gru_seq_bwd(dy.data_ptr(), ndir * H, m * ndir * H, gates.data_ptr(), ndir * 4 * H, m * ndir * 4 * H, y.data_ptr(),
+                                     ndir * H, m * ndir * H, w_hh.data_ptr(), m, F, H, ndir, dgi.data_ptr(), dgh.data_ptr(),
+                                     work.data_ptr(), st), "cvc_gru_seq_bwd")
+        ni = ctx.needs_input_grad
+        Gi = hip.TileOperand(dgi, kmajor=True) if (ni[1]) else None           # dG^T packed once
+        d_x = hip.tile_mm(dgi, w_ih, b_kmajor=True) if ni[0] else None          # [F*m, in]
+        d_w_ih = hip.tile_mm(Gi, x, b_kmajor=True) if ni[1] else None           # [ndir*3H, in]
+        d_w_hh = None
+        if ni[2]:
+            zeros = y.new_zeros(m, H)
+            parts = []
+            for d in range(ndir):
+                yd = y[:, d * H:(d + 1) * H]
+                hp = torch.cat((zeros, yd[:-m]), 0) if d == 0 else torch.cat((yd[m:], zeros), 0)     # h_{t-1} of this direction
+                parts.append(hip.tile_mm(dgh[:, d * 3 * H:(d + 1) * 3 * H], hp, a_kmajor=True, b_kmajor=True))
+            d_w_hh = torch.stack(parts)
+        d_b_ih = dgi.sum(0).view(ndir, 3 * H) if ni[3] else None
+        d_b_hh = dgh.sum(0).view(ndir, 3 * H) if ni[4] else None
+        return d_x, d_w_ih, d_w_hh, d_b_ih, d_b_hh, None, None
+
+
+def gru_forward_train(gru: nn.GRU, x: torch.Tensor) -> torch.Tensor:
+    """`gru(x)[0]` under autograd on the HIP kernels (h0 = 0; inter-layer dropout as the module has it)."""
+    assert supported_train(gru, x), "shape / module outside the HIP GRU's autograd range"
+    B, F, _ = x.shape
+    H, ndir = gru.hidden_size, 2 if gru.bidirectional else 1
+    sfx = [""] if not gru.bidirectional else ["", "_reverse"]
+    outs = []
+    for b0 in range(0, B, 64):
+        m = min(64, B - b0)
+        cur = x[b0:b0 + m].transpose(0, 1).reshape(F * m, -1)                       # time-major rows (t, clip)
+        for l in range(gru.num_layers):
+            g = lambda n: [getattr(gru, f"{n}_l{l}{s}") for s in sfx]
+            cur = _GruLayer.apply(cur, torch.cat(g("weight_ih"), 0), torch.stack(g("weight_hh")), torch.stack(g("bias_ih")),
+                                  torch.stack(g("bias_hh")), m, F)
+            if gru.training and gru.dropout > 0 and l + 1 < gru.num_layers:
+                cur = torch.nn.functional.dropout(cur, gru.dropout, True)
+        outs.append(cur.view(F, m, ndir * H).transpose(0, 1))
+    return torch.cat(outs, 0) if len(outs) > 1 else outs[0].contiguous()

@@ -202,9 +202,11 @@ class RegionalFeatureExtractorGVD(nn.Module):
             x = torch.cat((dense.apply(self.att_embed[0], rgb), dense.apply(self.att_embed[1], motion)), dim=2)
             x = self.att_embed_aux(x.transpose(1, 2)).transpose(1, 2).contiguous()      # BatchNorm1d over channels
             if HIP_GRU and not torch.is_grad_enabled() and gru_hip.supported(self.context_enc, x):
-                x = gru_hip.gru_forward(self.context_enc, x)          # inference: csrc/gemm_packed.hip GRU steps + tile GEMM
+                x = gru_hip.gru_forward(self.context_enc, x)          # inference: persistent / per-step recurrence + tile GEMM
+            elif HIP_GRU and torch.is_grad_enabled() and gru_hip.supported_train(self.context_enc, x):
+                x = gru_hip.gru_forward_train(self.context_enc, x)    # autograd on the same kernels (cvc_gru_seq_bwd)
             else:
-                self.context_enc.flatten_parameters()                 # training (autograd) and CPU: the library module
+                self.context_enc.flatten_parameters()                 # CPU, shapes outside the kernels' range: the library module
                 x = self.context_enc(x)[0]
             x = x.masked_fill(sample_idx_mask, 0)
             conv_feats = x if self.seq_per_img == 1 else x.repeat_interleave(self.seq_per_img, dim=0)

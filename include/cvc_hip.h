@@ -190,6 +190,22 @@ int cvc_gru_seq_fwd(const float* wp, const float* gi, long long gi_ld_m, long lo
  * invalid and the caller repeats the sequence with cvc_gru_seq_fwd.  Returns CVC_E_BADARG without launching for shapes
  * outside its range (H % 128 != 0, H > 1024, or more workgroups than the device keeps resident at once). */
 int cvc_gru_persistent_sync_words(void);
+/* Training form of the persistent recurrence: additionally writes, for every step and direction, what autograd needs --
+ * (r, z, n, W_hn h + b_hn) at gates + m * g_ld_m + t * g_ld_t + d * 4H + {0, H, 2H, 3H}. */
+int cvc_gru_seq_persistent_train_fwd(const float* wp, const float* gi, long long gi_ld_m, long long gi_ld_t,
+                                     const float* b_ih, const float* b_hh, int M, int F, int H, int ndir, float* hq,
+                                     float* y, long long y_ld_m, long long y_ld_t, float* gates, long long g_ld_m,
+                                     long long g_ld_t, unsigned* sync, cvc_stream_t stream);
+/* Backward of the recurrence (autograd of nn.GRU, backbone.py:103-106, 335-338), walking the sequence backwards: per step and
+ * direction the gate arithmetic and dgh_t W_hh (cvc_linear_nn_fwd on the checkpoint-layout weights).  dy / y / gates: row of
+ * (clip m, step t) at base + m * ld_m + t * ld_t, columns [ndir][H] / [ndir][4][H]; w_hh [ndir][3H, H] row-major.
+ * Outputs dgi, dgh: [F * M rows (t * M + m), ndir * 3H] -- pre-activation gradients of the input / hidden side, from which the
+ * caller takes dW_ih, dX, dW_hh and the biases in dense GEMMs over all steps.  work: ndir * (3 M H + 192 H) + ksplit * M *
+ * ceil(H/128) * 128 floats, ksplit = cvc_gru_seq_bwd_ksplit(H).  M <= 64, H % 8 == 0. */
+int cvc_gru_seq_bwd_ksplit(int H);
+int cvc_gru_seq_bwd(const float* dy, long long dy_ld_m, long long dy_ld_t, const float* gates, long long g_ld_m,
+                    long long g_ld_t, const float* y, long long y_ld_m, long long y_ld_t, const float* w_hh, int M,
+                    int F, int H, int ndir, float* dgi, float* dgh, float* work, cvc_stream_t stream);
 int cvc_gru_persistent_waves8(int on);   /* A/B + test hook: 1 (default) = 8 waves per workgroup where H % 256 == 0, 0 = always 4 */
 int cvc_gru_persistent_halves(int on);   /* A/B + test hook: 1 = more than 32 clips run as two interleaved 32-clip recurrences (measured slower), 0 = default */
 int cvc_gru_seq_persistent_fwd(const float* wp, const float* gi, long long gi_ld_m, long long gi_ld_t,

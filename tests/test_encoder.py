@@ -283,3 +283,34 @@ def test_dense_layers_on_the_tile_gemm(rows, K, N, block):
     with torch.enable_grad():
         y = dense.apply(layer, x.requires_grad_(True))       # autograd: the module itself
         assert y.requires_grad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,F,inp,H,layers,bidir", [(5, 7, 48, 128, 2, True), (64, 12, 96, 256, 1, False), (70, 5, 64, 128, 2, True)])
+def test_gru_hip_autograd_vs_library_cpu(B, F, inp, H, layers, bidir):
+    """cvc.gru.gru_forward_train (persistent recurrence keeping the gates + cvc_gru_seq_bwd + dense dW / dX products on the tile
+    GEMM) against torch autograd of nn.GRU on the CPU: output, input gradient and every parameter gradient."""
+    from cvc import gru as G
+    g = _gru(inp, H, layers, bidir, 11)
+    x = torch.randn(B, F, inp)
+    probe = torch.randn(B, F, (2 if bidir else 1) * H)
+    xc = x.clone().requires_grad_(True)
+    (g(xc)[0] * probe).sum().backward()
+    want = {k: p.grad.clone() for k, p in g.named_parameters()}
+    want_dx = xc.grad.clone()
+    for p in g.parameters():
+        p.grad = None
+    gd = g.to("cuda:0")
+    xg = x.cuda().requires_grad_(True)
+    assert G.supported_train(gd, xg)
+    y = G.gru_forward_train(gd, xg)
+    with torch.no_grad():
+        ref_y = g.cpu()(x)[0]
+        g.to("cuda:0")
+    np.testing.assert_allclose(y.detach().cpu().numpy(), ref_y.numpy(), rtol=2e-5, atol=2e-5)
+    (y * probe.cuda()).sum().backward()
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    assert rel(xg.grad.cpu(), want_dx) < 5e-5
+    for k, p in gd.named_parameters():
+        assert p.grad is not None and rel(p.grad.cpu(), want[k]) < 5e-5, (k, rel(p.grad.cpu(), want[k]))
