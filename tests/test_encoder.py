@@ -314,3 +314,47 @@ def test_gru_hip_autograd_vs_library_cpu(B, F, inp, H, layers, bidir):
     assert rel(xg.grad.cpu(), want_dx) < 5e-5
     for k, p in gd.named_parameters():
         assert p.grad is not None and rel(p.grad.cpu(), want[k]) < 5e-5, (k, rel(p.grad.cpu(), want[k]))
+
+
+@pytest.mark.gpu
+def test_encoder_with_hip_gru_matches_library_gru_forward_and_backward(tmp_path):
+    """The whole encoder (backbone.py:298-351) with its frame-context GRU on the HIP kernels -- inference path and autograd
+    path -- against the same module with the library GRU, at a width the kernels' persistent form takes (R = 256 -> H = 128)."""
+    import dataclasses
+    from cvc.model import backbone
+    from cvc.model.backbone import RegionalFeatureExtractorGVD
+    Dw = dataclasses.replace(D, R=256, A=64, F=9, B=5)
+    tables = synth.detectron_tables(Dw, 3)
+    o = make_opts(Dw, seq_per_img=1, enable_BUTD=False, att_input_mode="both", num_sampled_frm=4, finetune_cnn=False,
+                  att_feat_size=Dw.G, fc_feat_size=synth.SEG_FEAT_DIM, t_attn_size=Dw.F, second_drop_prob=0.3, att_model="topdown",
+                  t_attn_mode="bigru", itod={i + 1: "d%d" % i for i in range(Dw.DET)},
+                  vg_cls=["vg%d" % i for i in range(tables["glove_vg_cls"].shape[0])],
+                  glove_clss=torch.from_numpy(tables["glove_clss"]), glove_vg_cls=torch.from_numpy(tables["glove_vg_cls"]),
+                  detectron_tables=tables, test_mode=False)
+    torch.manual_seed(0)
+    enc = RegionalFeatureExtractorGVD(o).to("cuda:0").eval()
+    inp = to_dev(synth.encoder_inputs(Dw, 3), torch.device("cuda:0"))
+    from cvc.misc import utils
+    overlaps = utils.bbox_overlaps(inp["proposals"], inp["gt_bboxs"], inp["frm_mask"] | inp["pnt_mask_in"][:, 1:].unsqueeze(-1))
+    res = {}
+    for hip_gru in (True, False):
+        backbone.HIP_GRU = hip_gru
+        try:
+            with torch.no_grad():
+                out_inf = run_encoder(enc, inp, overlaps)
+            enc.zero_grad(set_to_none=True)
+            enc.context_enc.train(); enc.context_enc.dropout = 0.0          # MIOpen's backward needs train mode; no dropout: deterministic
+            out = run_encoder(enc, inp, overlaps)
+            probe_loss(out).backward()
+            enc.context_enc.eval()
+            res[hip_gru] = (out_inf, out, {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None})
+        finally:
+            backbone.HIP_GRU = True
+    for a, b in ((res[True][0], res[False][0]), (res[True][1], res[False][1])):
+        for name, x, y in zip(OUT, a, b):
+            if torch.is_tensor(x) and x.dtype.is_floating_point:
+                np.testing.assert_allclose(x.detach().cpu().numpy(), y.detach().cpu().numpy(), rtol=2e-4, atol=2e-5, err_msg=name)
+    assert set(res[True][2]) == set(res[False][2])
+    for k, g in res[True][2].items():
+        ref = res[False][2][k]
+        assert float((g - ref).norm() / (ref.norm() + 1e-20)) < 2e-4, k
