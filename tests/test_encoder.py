@@ -358,3 +358,30 @@ def test_encoder_with_hip_gru_matches_library_gru_forward_and_backward(tmp_path)
     for k, g in res[True][2].items():
         ref = res[False][2][k]
         assert float((g - ref).norm() / (ref.norm() + 1e-20)) < 2e-4, k
+
+
+@pytest.mark.gpu
+def test_gru_hip_autograd_full_size_vs_library_cpu():
+    """Config-2 encoder size (B=64, F=480, R=2048 -> H=1024, 2 layers, both directions) under autograd: output, input gradient
+    and every parameter gradient of cvc.gru.gru_forward_train against torch autograd of nn.GRU on the host CPU."""
+    from cvc import gru as G
+    g = _gru(2048, 1024, 2, True, 13)
+    x = torch.randn(64, 480, 2048)
+    probe = torch.randn(64, 480, 2048) / 480 ** 0.5
+    xc = x.clone().requires_grad_(True)
+    ref_y = g(xc)[0]
+    (ref_y * probe).sum().backward()
+    want = {k: p.grad.clone() for k, p in g.named_parameters()}
+    want_dx, ref_y = xc.grad.clone(), ref_y.detach()
+    for p in g.parameters():
+        p.grad = None
+    gd = g.to("cuda:0")
+    xg = x.cuda().requires_grad_(True)
+    y = G.gru_forward_train(gd, xg)
+    assert float((y.detach().cpu() - ref_y).abs().max()) < 5e-5
+    (y * probe.cuda()).sum().backward()
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    assert rel(xg.grad.cpu(), want_dx) < 1e-4
+    for k, p in gd.named_parameters():
+        assert rel(p.grad.cpu(), want[k]) < 1e-4, (k, rel(p.grad.cpu(), want[k]))
