@@ -437,8 +437,24 @@ extern "C" int cvc_pack_quad(const float* x, long long ldx, int M, int K, float*
     return cvc_launch_status();
 }
 
+static int linear_nn_impl(const float* dy_q, int K, int M, const cvc_nn_seg* segs, int nsegs, int ksplit, float* workspace,
+                          bool reduce, cvc_stream_t stream);
+
 extern "C" int cvc_linear_nn_fwd(const float* dy_q, int K, int M, const cvc_nn_seg* segs, int nsegs, int ksplit,
                                  float* workspace, cvc_stream_t stream) {
+    return linear_nn_impl(dy_q, K, M, segs, nsegs, ksplit, workspace, true, stream);
+}
+
+// The same without the summing launch: for ksplit > 1 the K-slice partial products stay in `workspace` as planes
+// [ksplit][M][ntot] (ntot = sum over segments of ceil(ncols / 128) * 128, segment s starting at column 128 * (slabs before it))
+// for a consumer that sums them itself (cvc_gru_seq_bwd folds the sum into its next gate-gradient kernel).
+extern "C" int cvc_linear_nn_planes_fwd(const float* dy_q, int K, int M, const cvc_nn_seg* segs, int nsegs, int ksplit,
+                                        float* workspace, cvc_stream_t stream) {
+    return linear_nn_impl(dy_q, K, M, segs, nsegs, ksplit, workspace, false, stream);
+}
+
+static int linear_nn_impl(const float* dy_q, int K, int M, const cvc_nn_seg* segs, int nsegs, int ksplit, float* workspace,
+                          bool reduce, cvc_stream_t stream) {
     if (!dy_q || !segs || nsegs < 1 || nsegs > NN_MAX_SEG || M < 1 || M > 64 || K < 8 || (K & 7) || ksplit < 1)
         return CVC_E_BADARG;
     if (ksplit > K / 8) ksplit = K / 8;
@@ -463,7 +479,7 @@ extern "C" int cvc_linear_nn_fwd(const float* dy_q, int K, int M, const cvc_nn_s
         else hipLaunchKernelGGL((skinny_gemm_nn_split_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, a);
     } else if (M <= 32) hipLaunchKernelGGL((skinny_gemm_nn_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((skinny_gemm_nn_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, a);
-    if (ksplit > 1)
+    if (ksplit > 1 && reduce)
         hipLaunchKernelGGL(nn_reduce_kernel, dim3((a.ntot / 4 + 255) / 256, M), dim3(256), 0, (hipStream_t)stream, a);
     return cvc_launch_status();
 }

@@ -13,7 +13,9 @@ namespace {
 
 struct GruStepBwd {
     const float* dy; long long dy_ld;          // dL/dh_t rows (row m at + m * dy_ld), H columns of this direction
-    const float* dh_a; const float* dh_b;      // carried gradients [M, H] row-major, nullable
+    const float* dh_a;                         // carried gradient dh z of the previous processed step, [M, H] row-major, nullable
+    const float* dh_planes; int nplanes;       // ... and dgh W_hh of that step as K-slice planes [nplanes][M][plane_ld], nullable
+    long long plane_stride, plane_ld;
     const float* gates; long long g_ld;        // (r, z, n, hn) of this step: row m at + m * g_ld, columns [4][H]
     const float* h_prev; long long hp_ld;      // h_{t-1} rows, nullable (= 0)
     float* dgi; long long dgi_ld;              // [M, 3H] at + m * dgi_ld
@@ -23,7 +25,11 @@ struct GruStepBwd {
     int M, H;
 };
 
-__global__ __launch_bounds__(256) void gru_pointwise_bwd_kernel(GruStepBwd a) {
+struct GruStepBwd2 { GruStepBwd d[2]; };
+
+// both directions in one launch (blockIdx.y); the K-slice planes of the previous step's dgh W_hh are summed here, in slice order
+__global__ __launch_bounds__(256) void gru_pointwise_bwd_kernel(GruStepBwd2 both) {
+    const GruStepBwd& a = both.d[blockIdx.y];
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int m = t & 63, jq = t >> 6;                         // batch row fastest: the quad-layout stores are contiguous
     const int j = jq * 4;
@@ -36,7 +42,12 @@ __global__ __launch_bounds__(256) void gru_pointwise_bwd_kernel(GruStepBwd a) {
     }
     f32x4 dh = ld4(a.dy + (size_t)m * a.dy_ld + j);
     if (a.dh_a != nullptr) dh += ld4(a.dh_a + (size_t)m * H + j);
-    if (a.dh_b != nullptr) dh += ld4(a.dh_b + (size_t)m * H + j);
+    if (a.dh_planes != nullptr) {
+        const float* pl = a.dh_planes + (size_t)m * a.plane_ld + j;
+        f32x4 acc = ld4(pl);
+        for (int k = 1; k < a.nplanes; ++k) acc += ld4(pl + (size_t)k * a.plane_stride);
+        dh += acc;
+    }
     const float* gp = a.gates + (size_t)m * a.g_ld + j;
     const f32x4 r = ld4(gp), z = ld4(gp + H), n = ld4(gp + 2 * H), hn = ld4(gp + 3 * H);
     const f32x4 hp = a.h_prev != nullptr ? ld4(a.h_prev + (size_t)m * a.hp_ld + j) : f32x4{0, 0, 0, 0};
@@ -58,8 +69,8 @@ __global__ __launch_bounds__(256) void gru_pointwise_bwd_kernel(GruStepBwd a) {
 
 // dy, gates, y: row of (clip m, step t) at base + m * ld_m + t * ld_t, columns [ndir][H] (dy, y) / [ndir][4][H] (gates).
 // w_hh: [ndir][3H, H] row-major (the checkpoint layout).  dgi, dgh: [F * M rows (t * M + m), ndir * 3H] outputs.
-// work: ndir * (3 * M * H + 3H * 64) + nn_workspace floats, nn_workspace = ksplit * M * ceil(H / 128) * 128 with
-// ksplit = cvc_gru_seq_bwd_ksplit(H).  M <= 64, H % 8 == 0.
+// work: ndir * (2 * M * H + 3H * 64 + ksplit * M * ceil(H / 128) * 128) floats, ksplit = cvc_gru_seq_bwd_ksplit(H).
+// M <= 64, H % 8 == 0.
 extern "C" int cvc_gru_seq_bwd_ksplit(int H) {
     const int slabs = (H + 127) / 128;
     int ks = 256 / slabs;
@@ -75,31 +86,38 @@ extern "C" int cvc_gru_seq_bwd(const float* dy, long long dy_ld_m, long long dy_
         return CVC_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     const int ks = cvc_gru_seq_bwd_ksplit(H);
-    const size_t mh = (size_t)M * H, per_dir = 3 * mh + (size_t)3 * H * 64;
-    float* nn_ws = work + per_dir * ndir;
+    const long long ntot = (long long)((H + 127) / 128) * 128;     // plane row length of the backward-data product
+    const size_t mh = (size_t)M * H, per_dir = 2 * mh + (size_t)3 * H * 64 + (size_t)ks * M * ntot;
     const long long row_ld = (long long)ndir * 3 * H;            // dgi / dgh row stride
     for (int s = 0; s < F; ++s) {
+        GruStepBwd2 both{};
         for (int d = 0; d < ndir; ++d) {
             const long long t = d == 0 ? F - 1 - s : s;           // the forward direction is walked back from the end
             const long long tp = d == 0 ? t - 1 : t + 1;          // where this direction's h_{t-1} lives
             float* base = work + per_dir * d;
             float* dh_part[2] = {base, base + mh};
-            float* dh_mm = base + 2 * mh;
-            float* dgh_q = base + 3 * mh;
-            GruStepBwd a{};
+            float* dgh_q = base + 2 * mh;
+            float* planes = dgh_q + (size_t)3 * H * 64;
+            GruStepBwd& a = both.d[d];
             a.dy = dy + t * dy_ld_t + (long long)d * H; a.dy_ld = dy_ld_m;
             a.dh_a = s > 0 ? dh_part[(s - 1) & 1] : nullptr;
-            a.dh_b = s > 0 ? dh_mm : nullptr;
+            a.dh_planes = s > 0 ? planes : nullptr; a.nplanes = ks; a.plane_stride = (long long)M * ntot; a.plane_ld = ntot;
             a.gates = gates + t * g_ld_t + (long long)d * 4 * H; a.g_ld = g_ld_m;
             const bool has_prev = tp >= 0 && tp < F;
             a.h_prev = has_prev ? y + tp * y_ld_t + (long long)d * H : nullptr; a.hp_ld = y_ld_m;
             a.dgi = dgi + (t * M) * row_ld + (long long)d * 3 * H; a.dgi_ld = row_ld;
             a.dgh = dgh + (t * M) * row_ld + (long long)d * 3 * H; a.dgh_ld = row_ld;
             a.dgh_q = dgh_q; a.dh_part = dh_part[s & 1]; a.M = M; a.H = H;
-            hipLaunchKernelGGL(gru_pointwise_bwd_kernel, dim3((H / 4 * 64 + 255) / 256), dim3(256), 0, st, a);
-            if (s + 1 < F) {                                      // the carry of the last processed step is not needed
-                cvc_nn_seg seg{w_hh + (size_t)d * 3 * H * H, dh_mm, H, H, H};
-                int rc = cvc_linear_nn_fwd(dgh_q, 3 * H, M, &seg, 1, ks, nn_ws, stream);
+        }
+        hipLaunchKernelGGL(gru_pointwise_bwd_kernel, dim3((H / 4 * 64 + 255) / 256, ndir), dim3(256), 0, st, both);
+        if (s + 1 < F) {                                          // the carry of the last processed step is not needed
+            for (int d = 0; d < ndir; ++d) {
+                float* base = work + per_dir * d;
+                float* dgh_q = base + 2 * mh;
+                float* planes = dgh_q + (size_t)3 * H * 64;
+                // one K slice: the product goes straight into "plane 0" (row stride ntot); several: planes, summed by the next step
+                cvc_nn_seg seg{w_hh + (size_t)d * 3 * H * H, planes, H, H, (int)ntot};
+                int rc = cvc_linear_nn_planes_fwd(dgh_q, 3 * H, M, &seg, 1, ks, planes, stream);
                 if (rc) return rc;
             }
         }

@@ -140,7 +140,7 @@ class _GruLayer(torch.autograd.Function):
         dgi = torch.empty(F * m, ndir * 3 * H, device=x.device, dtype=torch.float32)
         dgh = torch.empty_like(dgi)
         ks = int(L.cvc_gru_seq_bwd_ksplit(H))
-        work = torch.empty(ndir * (3 * m * H + 3 * H * 64) + ks * m * ((H + 127) // 128) * 128, device=x.device, dtype=torch.float32)
+        work = torch.empty(ndir * (2 * m * H + 3 * H * 64 + ks * m * ((H + 127) // 128) * 128), device=x.device, dtype=torch.float32)
         hip._check(L.cvc_gru_seq_bwd(dy.data_ptr(), ndir * H, m * ndir * H, gates.data_ptr(), ndir * 4 * H, m * ndir * 4 * H, y.data_ptr(),
                                      ndir * H, m * ndir * H, w_hh.data_ptr(), m, F, H, ndir, dgi.data_ptr(), dgh.data_ptr(),
                                      work.data_ptr(), st), "cvc_gru_seq_bwd")

@@ -200,8 +200,8 @@ int cvc_gru_seq_persistent_train_fwd(const float* wp, const float* gi, long long
  * direction the gate arithmetic and dgh_t W_hh (cvc_linear_nn_fwd on the checkpoint-layout weights).  dy / y / gates: row of
  * (clip m, step t) at base + m * ld_m + t * ld_t, columns [ndir][H] / [ndir][4][H]; w_hh [ndir][3H, H] row-major.
  * Outputs dgi, dgh: [F * M rows (t * M + m), ndir * 3H] -- pre-activation gradients of the input / hidden side, from which the
- * caller takes dW_ih, dX, dW_hh and the biases in dense GEMMs over all steps.  work: ndir * (3 M H + 192 H) + ksplit * M *
- * ceil(H/128) * 128 floats, ksplit = cvc_gru_seq_bwd_ksplit(H).  M <= 64, H % 8 == 0. */
+ * caller takes dW_ih, dX, dW_hh and the biases in dense GEMMs over all steps.  work: ndir * (2 M H + 192 H + ksplit * M *
+ * ceil(H/128) * 128) floats, ksplit = cvc_gru_seq_bwd_ksplit(H).  M <= 64, H % 8 == 0. */
 int cvc_gru_seq_bwd_ksplit(int H);
 int cvc_gru_seq_bwd(const float* dy, long long dy_ld_m, long long dy_ld_t, const float* gates, long long g_ld_m,
                     long long g_ld_t, const float* y, long long y_ld_m, long long y_ld_t, const float* w_hh, int M,
@@ -276,6 +276,10 @@ typedef struct cvc_nn_seg {
 } cvc_nn_seg;
 int cvc_linear_nn_fwd(const float* dy_q, int K, int M, const cvc_nn_seg* segs, int nsegs, int ksplit,
                       float* workspace, cvc_stream_t stream);
+/* the same without the summing launch: for ksplit > 1 the K-slice planes [ksplit][M][ntot] stay in `workspace` for a consumer
+ * that sums them itself (ntot = sum_s ceil(ncols_s / 128) * 128) */
+int cvc_linear_nn_planes_fwd(const float* dy_q, int K, int M, const cvc_nn_seg* segs, int nsegs, int ksplit,
+                             float* workspace, cvc_stream_t stream);
 /* x [M <= 64, K] row-major (leading dim ldx) -> the quad layout [K/4][64][4] cvc_linear_nn_fwd reads (rows beyond M zero) */
 int cvc_pack_quad(const float* x, long long ldx, int M, int K, float* xq, cvc_stream_t stream);
 
