@@ -74,7 +74,8 @@ __global__ __launch_bounds__(256) void gru_pointwise_bwd_kernel(GruStepBwd2 both
 extern "C" int cvc_gru_seq_bwd_ksplit(int H) {
     const int slabs = (H + 127) / 128;
     int ks = 256 / slabs;
-    const int kmax = 3 * H / 8 / 64;
+    const int kmax = 3 * H / 8 / 16;       // >= 16 rows (two double groups) per wave and slice: the weights are only 12 H^2 bytes, the
+                                            // launch is latency-bound and wants the whole chip (measured: 6 slices 22 us, 24 slices below)
     if (ks > kmax) ks = kmax;
     return ks < 1 ? 1 : ks;
 }
