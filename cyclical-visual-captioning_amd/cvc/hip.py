@@ -429,12 +429,12 @@ def linear_nn(dy_q, M, K, ranges, ksplit=None):
         arr[i] = NNSeg(w.data_ptr() + 4 * c0, out.data_ptr(), w.stride(0), n, n)
         outs.append(out)
         slabs += (n + 127) // 128
-    # K slices: one resident round of workgroups (the kernel fits two per CU = 512 on the chip) and >= 16 8-row
-    # groups per wave in every slice
+    # K slices: one resident round of workgroups and >= 16 rows (two double groups) per wave in every slice -- a short K on few
+    # column slabs (h2attn's backward) is a latency-bound launch that wants the whole chip, not long K loops
     if ksplit is None:
         # the split-product kernel holds one workgroup per CU (256 on the chip), the fp32-MFMA kernel two
         resident = 256 if gemm_packed_split(-1) != 0 else 512
-        ksplit = max(1, min(K // 8 // 64, resident // slabs))
+        ksplit = max(1, min(K // 8 // 16, resident // slabs))
     ws = torch.empty(ksplit * M * slabs * 128, device=dy_q.device, dtype=torch.float32) if ksplit > 1 else None
     _check(lib().cvc_linear_nn_fwd(_dev(dy_q), K, M, arr, len(ranges), ksplit, _dev(ws), _stream()), "cvc_linear_nn_fwd")
     return outs
