@@ -43,6 +43,8 @@ struct PackedArgs {
     float* h_rm;              // [M, R]
     float* c_rm;              // [M, R]
     float* gates_rm;          // [M, 4R] activated (i, f, g, o)
+    float* h_rm2;             // further copies of h' [M, R] (one tensor per consumer: autograd then has nothing to accumulate), nullable
+    float* h_rm3;
     // GRU step (cvc_gru_seq_fwd): blockIdx.y = direction d; R = hidden size H; block rows = (r, z, n, zero) x 8 hidden units
     long long gru_w_stride;   // floats between the directions' weight packs
     long long gru_h_stride;   // floats between the directions' hidden states (quad layout)
@@ -334,6 +336,8 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
             if (a.h_dst1_q != nullptr) st4(a.h_dst1_q + eqoff, hv);
             if (a.h_dst2_q != nullptr) st4(a.h_dst2_q + eqoff, hv);
             if (a.h_rm != nullptr) st4(a.h_rm + (size_t)em * R + ejq, hv);
+            if (a.h_rm2 != nullptr) st4(a.h_rm2 + (size_t)em * R + ejq, hv);
+            if (a.h_rm3 != nullptr) st4(a.h_rm3 + (size_t)em * R + ejq, hv);
             if (a.c_rm != nullptr) st4(a.c_rm + (size_t)em * R + ejq, cv);
             if (a.gates_rm != nullptr) {
 #pragma unroll
@@ -447,9 +451,10 @@ extern "C" int cvc_packed_lstm_fwd(const float* wp, const float* xq, int K, cons
 
 extern "C" int cvc_packed_lstm_train_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
                                          const float* c_prev, int M, int R, float* h_out, float* c_out, float* gates_out,
-                                         cvc_stream_t stream) {
+                                         float* h_out2, float* h_out3, cvc_stream_t stream) {
     if (!wp || !xq || !c_prev || !h_out || !c_out || (K & 31) || R < 8 || (R & 7)) return CVC_E_BADARG;
     PackedArgs a{};
+    a.h_rm2 = h_out2; a.h_rm3 = h_out3;
     a.wp = wp; a.xq = xq; a.nquad = K / 4; a.M = M; a.Nout = 4 * R; a.R = R;
     a.bias = b_ih; a.bias2 = b_hh; a.c_prev_rm = c_prev; a.h_rm = h_out; a.c_rm = c_out; a.gates_rm = gates_out; a.ksplit = 1;
     return launch_packed<true>(a, R / 8, (hipStream_t)stream);

@@ -296,16 +296,17 @@ __global__ __launch_bounds__(WG) void vocab_nll_bwd_kernel(const float* logits, 
 }
 
 // ------------------------------------------------------------------ LSTM pointwise backward
-__global__ __launch_bounds__(WG) void lstm_pointwise_bwd_kernel(const float* d_h, const float* d_c, const float* gates,
-                                                                const float* c_prev, const float* c_new, int M, int R,
-                                                                float* d_gates, float* d_c_prev, float* d_gates_q) {
+__global__ __launch_bounds__(WG) void lstm_pointwise_bwd_kernel(const float* d_h, const float* d_h2, const float* d_h3, const float* d_c,
+                                                                const float* gates, const float* c_prev, const float* c_new, int M,
+                                                                int R, float* d_gates, float* d_c_prev, float* d_gates_q) {
     const int j = blockIdx.x * WG + threadIdx.x;
     const int m = blockIdx.y;
     if (j >= R) return;
     const size_t o = (size_t)m * R + j, g0 = (size_t)m * 4 * R + j;
     const float ig = gates[g0], fg = gates[g0 + R], gg = gates[g0 + 2 * R], og = gates[g0 + 3 * R];
     const float tc = tanhf(c_new[o]);
-    const float dh = d_h != nullptr ? d_h[o] : 0.f;
+    // h' may have gone out as up to three tensors (one per consumer): their gradients are summed here, not by autograd
+    const float dh = ((d_h != nullptr ? d_h[o] : 0.f) + (d_h2 != nullptr ? d_h2[o] : 0.f)) + (d_h3 != nullptr ? d_h3[o] : 0.f);
     const float dcn = (d_c != nullptr ? d_c[o] : 0.f) + dh * og * (1.f - tc * tc);
     const float d0 = dcn * gg * ig * (1.f - ig), d1 = dcn * c_prev[o] * fg * (1.f - fg);
     const float d2 = dcn * ig * (1.f - gg * gg), d3 = dh * tc * og * (1.f - og);
@@ -635,7 +636,18 @@ extern "C" int cvc_lstm_pointwise_bwd(const float* d_h, const float* d_c, const 
                                       float* d_gates_q, cvc_stream_t stream) {
     if (!gates || !c_prev || !c_new || !d_gates || !d_c_prev || M < 1 || R < 1) return CVC_E_BADARG;
     if (d_gates_q != nullptr && (M > 64 || (R & 3))) return CVC_E_BADARG;
-    hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3((R + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, d_h, d_c,
+    hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3((R + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, d_h, nullptr, nullptr,
+                       d_c, gates, c_prev, c_new, M, R, d_gates, d_c_prev, d_gates_q);
+    return cvc_launch_status();
+}
+
+// the same with the gradients of up to three copies of h' (cvc_packed_lstm_train_fwd's h_out, h_out2, h_out3), summed in order
+extern "C" int cvc_lstm_pointwise_bwd3(const float* d_h, const float* d_h2, const float* d_h3, const float* d_c, const float* gates,
+                                       const float* c_prev, const float* c_new, int M, int R, float* d_gates, float* d_c_prev,
+                                       float* d_gates_q, cvc_stream_t stream) {
+    if (!gates || !c_prev || !c_new || !d_gates || !d_c_prev || M < 1 || R < 1) return CVC_E_BADARG;
+    if (d_gates_q != nullptr && (M > 64 || (R & 3))) return CVC_E_BADARG;
+    hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3((R + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, d_h, d_h2, d_h3, d_c,
                        gates, c_prev, c_new, M, R, d_gates, d_c_prev, d_gates_q);
     return cvc_launch_status();
 }

@@ -182,7 +182,7 @@ class _LstmCell(torch.autograd.Function):
     """nn.LSTMCell over a virtual concat of input segments (decoder_core.py:45-50, 59-61)."""
 
     @staticmethod
-    def forward(ctx, w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, wp, *xs):
+    def forward(ctx, w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, wp, copies, *xs):
         xs = [_rows(x) for x in xs]
         h_prev, c_prev = _c(h_prev), _c(c_prev)
         k0 = sum(x.shape[1] for x in xs)
@@ -191,7 +191,8 @@ class _LstmCell(torch.autograd.Function):
         M, R = c_prev.shape
         if wp is not None and all(x.data_ptr() % 16 == 0 for x in (*xs, h_prev)):
             # the decode engine's packed gate GEMM; `wp` is the pack lstm_cell() found on (or built for) the weight tensors
-            h, c, gates = hip.lstm_cell_train_fwd(xs, h_prev, c_prev, wp, b_ih, b_hh, want_gates=need_bwd)
+            h, c, gates = hip.lstm_cell_train_fwd(xs, h_prev, c_prev, wp, b_ih, b_hh, want_gates=need_bwd, copies=copies)
+            hs = h if copies > 1 else (h,)
         else:
             segs, k0 = [], 0
             for x in xs:
@@ -199,6 +200,8 @@ class _LstmCell(torch.autograd.Function):
                 k0 += x.shape[1]
             segs.append({"x": h_prev, "w": w_hh})
             h, c, gates = hip.lstm_cell_fwd(segs, b_ih, b_hh, c_prev, want_gates=need_bwd)
+            hs = (h,) + tuple(h.clone() for _ in range(copies - 1))
+        ctx.ncopy = len(hs)
         ctx.set_materialize_grads(False)          # an unused h or c arrives as None, not as a zero-filled tensor
         if need_bwd:
             ctx.save_for_backward(w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, c, gates, *xs)
@@ -206,23 +209,27 @@ class _LstmCell(torch.autograd.Function):
             ctx.defer = bool(ctx.needs_input_grad[0] and ctx.needs_input_grad[1])
             if ctx.defer:
                 _BATCHER.note_use(ctx.key)
-        return h, c
+        return (*hs, c)
 
     @staticmethod
-    def backward(ctx, d_h, d_c):
+    def backward(ctx, *d):
+        # d = (gradients of the `ncopy` copies of h'..., d_c): the copies' gradients are summed inside the gate-gradient kernel
         w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, c_new, gates, *xs = ctx.saved_tensors
         ni = ctx.needs_input_grad
-        if d_h is None and d_c is None:
-            d_h = torch.zeros_like(c_new)         # (keeps the deferred-weight-gradient use count exact)
+        d_hs = [g for g in d[:ctx.ncopy] if g is not None]
+        d_c = d[ctx.ncopy]
+        if not d_hs and d_c is None:
+            d_hs = [torch.zeros_like(c_new)]      # (keeps the deferred-weight-gradient use count exact)
+        d_hs = [_c(g) for g in d_hs] + [None] * (3 - len(d_hs))
         M, K = gates.shape
         # dX ranges that need a gradient: (weight, first column, width) in the order h_prev, xs...
         ranges, k0 = ([(w_hh, 0, w_hh.shape[1])] if ni[4] else []), 0
         for i, x in enumerate(xs):
-            if ni[7 + i]:
+            if ni[8 + i]:
                 ranges.append((w_ih, k0, x.shape[1]))
             k0 += x.shape[1]
         use_nn = bool(ranges) and hip.linear_nn_ok(M, K, ranges)
-        pw = hip.lstm_pointwise_bwd(_c(d_h), _c(d_c), gates, c_prev, c_new, want_quad=use_nn)
+        pw = hip.lstm_pointwise_bwd(d_hs[0], _c(d_c), gates, c_prev, c_new, want_quad=use_nn, d_h2=d_hs[1], d_h3=d_hs[2])
         d_gates, d_c_prev = pw[0], pw[1]
         d_w_ih = d_w_hh = d_b = None
         if ctx.defer:
@@ -247,25 +254,27 @@ class _LstmCell(torch.autograd.Function):
         if use_nn:                      # every needed dX from one pass over the weights (csrc/gemm_nn.hip)
             got = iter(hip.linear_nn(pw[2], M, K, ranges))
             d_h_prev = next(got) if ni[4] else None
-            d_xs = [next(got) if ni[7 + i] else None for i in range(len(xs))]
+            d_xs = [next(got) if ni[8 + i] else None for i in range(len(xs))]
         else:                           # widths the kernel does not take (not multiples of 4): library GEMM
             d_h_prev = _mm_nn(d_gates, w_hh) if ni[4] else None
             d_xs, k0 = [], 0
             for i, x in enumerate(xs):
                 k = x.shape[1]
-                d_xs.append(_mm_nn(d_gates, w_ih[:, k0:k0 + k]) if ni[7 + i] else None)
+                d_xs.append(_mm_nn(d_gates, w_ih[:, k0:k0 + k]) if ni[8 + i] else None)
                 k0 += k
         return (d_w_ih, d_w_hh, d_b if ni[2] else None, d_b if ni[3] else None, d_h_prev,
-                d_c_prev if ni[5] else None, None, *d_xs)
+                d_c_prev if ni[5] else None, None, None, *d_xs)
 
 
-def lstm_cell(xs: Sequence[Tensor], h_prev: Tensor, c_prev: Tensor, w_ih, w_hh, b_ih, b_hh) -> Tuple[Tensor, Tensor]:
+def lstm_cell(xs: Sequence[Tensor], h_prev: Tensor, c_prev: Tensor, w_ih, w_hh, b_ih, b_hh, copies: int = 1):
+    """-> (h', c'), or with copies = k > 1: (h'_1, ..., h'_k, c') -- k tensors holding the same h', one per consumer, so that
+    autograd has no fan-out to accumulate (their gradients are summed inside the cell's backward kernel)."""
     wp = None
     M, R = c_prev.shape
     if (PACKED_LSTM_FORWARD and w_ih.is_cuda and w_ih.is_contiguous() and w_hh.is_contiguous()
             and hip.lstm_train_ok(M, R, [x.shape[1] for x in xs] + [h_prev.shape[1]])):
         wp = hip.lstm_train_pack(w_ih, w_hh)          # lives on the parameter object; rebuilt once per optimizer step
-    return _LstmCell.apply(w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, wp, *xs)
+    return _LstmCell.apply(w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, wp, max(1, min(3, int(copies))), *xs)
 
 
 # ------------------------------------------------------------------------------- attention

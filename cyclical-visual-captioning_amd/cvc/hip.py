@@ -68,7 +68,7 @@ SIGNATURES = {
     "cvc_packed_lstm_fwd": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "cvc_packed_linear_fwd": [_P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P],
     "cvc_packed_lstm_wg_blocks": [_I],
-    "cvc_packed_lstm_train_fwd": [_P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "cvc_packed_lstm_train_fwd": [_P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     "cvc_pack_lstm_weights": [_P, _I, _P, _I, _I, _P, _P],
     "cvc_pack_quad_segs": [C.POINTER(_P), C.POINTER(_LL), C.POINTER(_I), _I, _I, _P, _P],
     "cvc_beam_backtrack": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
@@ -91,6 +91,7 @@ SIGNATURES = {
     "cvc_gemm_packed_split": [_I],
     "cvc_lstm_cell_fwd": [C.POINTER(GemmSeg), _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "cvc_lstm_pointwise_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "cvc_lstm_pointwise_bwd3": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "cvc_linear_nn_fwd": [_P, _I, _I, C.POINTER(NNSeg), _I, _I, _P, _P],
     "cvc_pack_quad": [_P, _LL, _I, _I, _P, _P],
     "cvc_embed_relu_fwd": [_P, _P, _P, _I, _I, _P, _P],
@@ -379,26 +380,29 @@ def pack_quad_segs(xs: Sequence[torch.Tensor]) -> torch.Tensor:
     return xq
 
 
-def lstm_cell_train_fwd(xs: Sequence[torch.Tensor], h_prev, c_prev, wp, b_ih, b_hh, want_gates: bool = True):
+def lstm_cell_train_fwd(xs: Sequence[torch.Tensor], h_prev, c_prev, wp, b_ih, b_hh, want_gates: bool = True, copies: int = 1):
     """nn.LSTMCell forward on the packed gate GEMM (cvc_packed_lstm_train_fwd) from the pack `lstm_train_pack` built:
-    -> h, c, activated gates (or None)."""
+    -> h (a tuple of `copies` identical tensors when copies > 1), c, activated gates (or None)."""
     M, R = c_prev.shape
     xq = pack_quad_segs([*xs, h_prev])
-    h, c = torch.empty_like(c_prev), torch.empty_like(c_prev)
+    hs = [torch.empty_like(c_prev) for _ in range(max(1, min(3, copies)))]
+    c = torch.empty_like(c_prev)
     gates = torch.empty(M, 4 * R, device=c_prev.device, dtype=torch.float32) if want_gates else None
     _check(lib().cvc_packed_lstm_train_fwd(_dev(wp), _dev(xq), xq.shape[0] * 4, _dev(b_ih), _dev(b_hh), _dev(c_prev), M, R,
-                                           _dev(h), _dev(c), _dev(gates), _stream()), "cvc_packed_lstm_train_fwd")
-    return h, c, gates
+                                           _dev(hs[0]), _dev(c), _dev(gates), _dev(hs[1]) if len(hs) > 1 else None,
+                                           _dev(hs[2]) if len(hs) > 2 else None, _stream()), "cvc_packed_lstm_train_fwd")
+    return (hs[0] if copies <= 1 else tuple(hs)), c, gates
 
 
-def lstm_pointwise_bwd(d_h, d_c, gates, c_prev, c_new, want_quad=False):
-    """-> d_gates [M,4R], d_c_prev [M,R] (+ d_gates in the quad layout [R][64][4] for linear_nn when asked)."""
+def lstm_pointwise_bwd(d_h, d_c, gates, c_prev, c_new, want_quad=False, d_h2=None, d_h3=None):
+    """-> d_gates [M,4R], d_c_prev [M,R] (+ d_gates in the quad layout [R][64][4] for linear_nn when asked).  d_h2, d_h3: the
+    gradients of further copies of h' (summed with d_h inside the kernel)."""
     M, R = c_prev.shape
     d_gates = torch.empty_like(gates)
     d_c_prev = torch.empty_like(c_prev)
     d_gates_q = torch.empty(R, 64, 4, device=gates.device, dtype=torch.float32) if want_quad else None
-    _check(lib().cvc_lstm_pointwise_bwd(_dev(d_h), _dev(d_c), _dev(gates), _dev(c_prev), _dev(c_new), M, R, _dev(d_gates),
-                                        _dev(d_c_prev), _dev(d_gates_q), _stream()), "cvc_lstm_pointwise_bwd")
+    _check(lib().cvc_lstm_pointwise_bwd3(_dev(d_h), _dev(d_h2), _dev(d_h3), _dev(d_c), _dev(gates), _dev(c_prev), _dev(c_new), M, R,
+                                         _dev(d_gates), _dev(d_c_prev), _dev(d_gates_q), _stream()), "cvc_lstm_pointwise_bwd3")
     return (d_gates, d_c_prev, d_gates_q) if want_quad else (d_gates, d_c_prev)
 
 

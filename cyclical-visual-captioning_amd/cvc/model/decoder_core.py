@@ -14,6 +14,11 @@ def _cell(mod: nn.LSTMCell):
     return mod.weight_ih, mod.weight_hh, mod.bias_ih, mod.bias_hh
 
 
+import os as _os
+
+H_COPIES = _os.environ.get("CVC_H_COPIES", "1") != "0"   # False: one h' tensor per cell, autograd sums its consumers' gradients (A/B)
+
+
 class TopDownDecoderCore(nn.Module):
     """reference model/decoder_core.py:8-66"""
 
@@ -38,9 +43,10 @@ class TopDownDecoderCore(nn.Module):
         if with_sentinel:
             raise NotImplementedError("with_sentinel=True is not part of the caption-decode hot path")
         (h_att, h_lang), (c_att, c_lang) = state[0].unbind(0), state[1].unbind(0)
-        output, (h_att, c_att, h_lang, c_lang), roi_attn, frame_masked_attn, weighted_pool_feat = self.step(
+        output, st, roi_attn, frame_masked_attn, weighted_pool_feat = self.step(
             embedded_word, fc_feats, conv_feats, p_conv_feats, pool_feats, p_pool_feats, pnt_mask, (h_att, c_att, h_lang, c_lang),
             proposal_frame_mask)
+        h_att, c_att, h_lang, c_lang = st[:4]
         return output, (torch.stack([h_att, h_lang]), torch.stack([c_att, c_lang])), roi_attn, frame_masked_attn, weighted_pool_feat
 
     def step(self, embedded_word, fc_feats, conv_feats, p_conv_feats, pool_feats, p_pool_feats, pnt_mask, state,
@@ -48,15 +54,21 @@ class TopDownDecoderCore(nn.Module):
         """forward() on an unstacked state (h_att, c_att, h_lang, c_lang): what the captioner's T-step loops call --
         stacking the state every step costs ~17 small kernels per step in the backward pass (the selects' zero-filled
         gradients, their accumulation, the stack / unbind pairs)."""
-        h_att, c_att, h_lang, c_lang = state
+        # h' of either cell has three consumers (this step's other cell / attention query / output, and the next step twice): under
+        # autograd every consumer gets its own copy of the tensor (written by the cell's kernel), so that the backward pass
+        # has no fan-out to accumulate; the state then carries h_lang twice (5 entries)
+        h_att, c_att, h_lang, c_lang = state[:4]
+        h_lang_s = state[4] if len(state) > 4 else h_lang
+        k = 3 if (torch.is_grad_enabled() and H_COPIES) else 1
         xs = [h_lang, fc_feats, embedded_word] if self.opts.global_img_in_attn_lstm else [h_lang, embedded_word]
-        h_attn, c_attn = F_.lstm_cell(xs, h_att, c_att, *_cell(self.att_lstm))
+        *h_attn, c_attn = F_.lstm_cell(xs, h_att, c_att, *_cell(self.att_lstm), copies=k)
         # regions (masked, optional frame-masked copy) and frames share the query: one launch
         ctx_sum, ((weighted_pool_feat, roi_attn, frame_masked_attn), _frames) = _soft_attn_pair(
-            self.soft_attn, h_attn,
+            self.soft_attn, h_attn[0],
             [(p_pool_feats, pool_feats, pnt_mask, proposal_frame_mask), (p_conv_feats, conv_feats, None, None)])
-        h_lang, c_lang = F_.lstm_cell([ctx_sum, h_attn], h_lang, c_lang, *_cell(self.lang_lstm))
-        return self.dropout(h_lang), (h_attn, c_attn, h_lang, c_lang), roi_attn, frame_masked_attn, weighted_pool_feat
+        *h_new, c_lang = F_.lstm_cell([ctx_sum, h_attn[1 % k]], h_lang_s, c_lang, *_cell(self.lang_lstm), copies=k)
+        return (self.dropout(h_new[0]), (h_attn[2 % k], c_attn, h_new[1 % k], c_lang, h_new[2 % k]), roi_attn, frame_masked_attn,
+                weighted_pool_feat)
 
 
 class AttenedDecoderCore(nn.Module):
@@ -75,14 +87,17 @@ class AttenedDecoderCore(nn.Module):
 
     def forward(self, embedded_word, fc_feats, weighted_pool_feat, attn_conv, state, with_sentinel=False):
         (h_att, h_lang), (c_att, c_lang) = state[0].unbind(0), state[1].unbind(0)
-        output, (h_att, c_att, h_lang, c_lang) = self.step(embedded_word, fc_feats, weighted_pool_feat, attn_conv,
-                                                           (h_att, c_att, h_lang, c_lang))
+        output, st = self.step(embedded_word, fc_feats, weighted_pool_feat, attn_conv, (h_att, c_att, h_lang, c_lang))
+        h_att, c_att, h_lang, c_lang = st[:4]
         return output, (torch.stack([h_att, h_lang]), torch.stack([c_att, c_lang]))
 
     def step(self, embedded_word, fc_feats, weighted_pool_feat, attn_conv, state):
         """forward() on an unstacked state (h_att, c_att, h_lang, c_lang), see TopDownDecoderCore.step"""
-        h_att, c_att, h_lang, c_lang = state
+        h_att, c_att, h_lang, c_lang = state[:4]
+        h_lang_s = state[4] if len(state) > 4 else h_lang
+        grad = torch.is_grad_enabled() and H_COPIES
         xs = [h_lang, fc_feats, embedded_word] if self.opts.global_img_in_attn_lstm else [h_lang, embedded_word]
-        h_attn, c_attn = F_.lstm_cell(xs, h_att, c_att, *_cell(self.att_lstm))
-        h_lang, c_lang = F_.lstm_cell([weighted_pool_feat + attn_conv, h_attn], h_lang, c_lang, *_cell(self.lang_lstm))
-        return self.dropout(h_lang), (h_attn, c_attn, h_lang, c_lang)
+        *h_attn, c_attn = F_.lstm_cell(xs, h_att, c_att, *_cell(self.att_lstm), copies=2 if grad else 1)
+        *h_new, c_lang = F_.lstm_cell([weighted_pool_feat + attn_conv, h_attn[0]], h_lang_s, c_lang, *_cell(self.lang_lstm),
+                                      copies=3 if grad else 1)
+        return self.dropout(h_new[0]), (h_attn[-1], c_attn, h_new[1 % len(h_new)], c_lang, h_new[2 % len(h_new)])

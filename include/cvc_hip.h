@@ -163,7 +163,7 @@ int cvc_packed_lstm_wg_blocks(int n);
  *                           by h_prev; widths % 4 == 0, 16-byte aligned) -> xq [K/4][64][4], rows beyond M zero. */
 int cvc_packed_lstm_train_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
                               const float* c_prev, int M, int R, float* h_out, float* c_out, float* gates_out,
-                              cvc_stream_t stream);
+                              float* h_out2, float* h_out3, cvc_stream_t stream);   /* h_out2/3: further copies of h', nullable */
 int cvc_pack_lstm_weights(const float* w_ih, int K_ih, const float* w_hh, int K_hh, int R, float* wp,
                           cvc_stream_t stream);
 int cvc_pack_quad_segs(const float* const* xs, const long long* ldx, const int* widths, int nseg, int M, float* xq,
@@ -262,6 +262,11 @@ int cvc_lstm_cell_fwd(const cvc_gemm_seg* segs, int nsegs, const float* b_ih, co
 int cvc_lstm_pointwise_bwd(const float* d_h, const float* d_c, const float* gates,
                            const float* c_prev, const float* c_new, int M, int R,
                            float* d_gates, float* d_c_prev, float* d_gates_q, cvc_stream_t stream);
+/* the same with the gradients of up to three copies of h' (h has several consumers per step -- the other cell, the attention
+ * query, the next step -- and a copy per consumer leaves autograd nothing to accumulate: 160 small launches per training step) */
+int cvc_lstm_pointwise_bwd3(const float* d_h, const float* d_h2, const float* d_h3, const float* d_c,
+                            const float* gates, const float* c_prev, const float* c_new, int M, int R,
+                            float* d_gates, float* d_c_prev, float* d_gates_q, cvc_stream_t stream);
 
 /* Backward-data product of the skinny layers, autograd of nn.LSTMCell / nn.Linear
  * (decoder_core.py:45-50, 59-61, 99-108):  dst_s[M, ncols_s] = dY[M, K] x W_s[K, ncols_s]  for up to 6

@@ -1018,6 +1018,23 @@ def test_lstm_train_form_of_packed_gemm(dev, lib, M, R, widths):
             F_.PACKED_LSTM_FORWARD = True
     for a, b in zip(grads[True], grads[False]):
         close(a, b, rtol=1e-4, atol=1e-4)
+    # one copy of h' per consumer (copies = 3): identical tensors out, and gradients fed through three of them give what the
+    # sum fed through one does (the copies' gradients are summed inside the gate-gradient kernel, not by autograd)
+    for packed in (True, False):
+        F_.PACKED_LSTM_FORWARD = packed
+        try:
+            la = [t.clone().requires_grad_(True) for t in (w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, *xs)]
+            ha, hb, hc, c3 = F_.lstm_cell(la[6:], la[4], la[5], *la[:4], copies=3)
+            assert torch.equal(ha, hb) and torch.equal(ha, hc)
+            g1, g2, g3 = h64.float(), torch.sin(h64.float() * 3), torch.cos(h64.float() * 5)
+            ((ha * g1).sum() + (hb * g2).sum() + (hc * g3).sum() + (c3 * c64.float()).sum() * 0.5).backward()
+            lb = [t.clone().requires_grad_(True) for t in (w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, *xs)]
+            h1, c1 = F_.lstm_cell(lb[6:], lb[4], lb[5], *lb[:4])
+            ((h1 * (g1 + g2 + g3)).sum() + (c1 * c64.float()).sum() * 0.5).backward()
+            for a, b in zip(la, lb):
+                close(a.grad, b.grad, rtol=1e-4, atol=1e-4)
+        finally:
+            F_.PACKED_LSTM_FORWARD = True
     # an in-place update of the weights invalidates the pack
     w_ih.mul_(0.5)
     assert lib.lstm_train_pack(w_ih, w_hh) is wp            # same buffer, rebuilt in place
