@@ -38,6 +38,17 @@ def pack_gru_weights(w_hh: torch.Tensor, H: int) -> torch.Tensor:
     return pack_weights(w, lstm_R=H)
 
 
+def pack_gru_weights_t(w_hh: torch.Tensor, H: int) -> torch.Tensor:
+    """[3H, H] -> W_hh^T for the persistent backward: [H/8 blocks][3H/8 k groups][8 units][8 k] (a workgroup's 8 weight COLUMNS,
+    8 consecutive k per lane)."""
+    assert w_hh.shape == (3 * H, H) and H % 8 == 0
+    return w_hh.reshape(3 * H // 8, 8, H // 8, 8).permute(2, 0, 3, 1).contiguous()
+
+
+BWD_PERSISTENT = True      # False: always the per-step backward (A/B switch)
+last_bwd_form = None
+
+
 def supported(gru: nn.Module, x: torch.Tensor) -> bool:
     """Shapes / modules the inference path takes."""
     return (isinstance(gru, nn.GRU) and gru.batch_first and gru.bias and gru.hidden_size % 8 == 0 and x.dim() == 3
@@ -139,11 +150,23 @@ class _GruLayer(torch.autograd.Function):
         dy = dy.contiguous()
         dgi = torch.empty(F * m, ndir * 3 * H, device=x.device, dtype=torch.float32)
         dgh = torch.empty_like(dgi)
-        ks = int(L.cvc_gru_seq_bwd_ksplit(H))
-        work = torch.empty(ndir * (2 * m * H + 3 * H * 64 + ks * m * ((H + 127) // 128) * 128), device=x.device, dtype=torch.float32)
-        hip._check(L.cvc_gru_seq_bwd(dy.data_ptr(), ndir * H, m * ndir * H, gates.data_ptr(), ndir * 4 * H, m * ndir * 4 * H, y.data_ptr(),
-                                     ndir * H, m * ndir * H, w_hh.data_ptr(), m, F, H, ndir, dgi.data_ptr(), dgh.data_ptr(),
-                                     work.data_ptr(), st), "cvc_gru_seq_bwd")
+        global last_bwd_form
+        done = False
+        if BWD_PERSISTENT and H % 256 == 0 and H <= 1024:
+            wt = torch.stack([pack_gru_weights_t(w_hh[d], H) for d in range(ndir)])
+            slots = torch.empty(F * ndir * 3 * H * 64, device=x.device, dtype=torch.float32)
+            sync = torch.zeros(int(L.cvc_gru_bwd_persistent_sync_words()), device=x.device, dtype=torch.int32)
+            rc = L.cvc_gru_seq_bwd_persistent(dy.data_ptr(), ndir * H, m * ndir * H, gates.data_ptr(), ndir * 4 * H, m * ndir * 4 * H,
+                                              y.data_ptr(), ndir * H, m * ndir * H, wt.data_ptr(), m, F, H, ndir, dgi.data_ptr(),
+                                              dgh.data_ptr(), slots.data_ptr(), sync.data_ptr(), st)
+            done = rc == 0 and int(sync[4]) == 0
+        if not done:
+            ks = int(L.cvc_gru_seq_bwd_ksplit(H))
+            work = torch.empty(ndir * (2 * m * H + 3 * H * 64 + ks * m * ((H + 127) // 128) * 128), device=x.device, dtype=torch.float32)
+            hip._check(L.cvc_gru_seq_bwd(dy.data_ptr(), ndir * H, m * ndir * H, gates.data_ptr(), ndir * 4 * H, m * ndir * 4 * H, y.data_ptr(),
+                                         ndir * H, m * ndir * H, w_hh.data_ptr(), m, F, H, ndir, dgi.data_ptr(), dgh.data_ptr(),
+                                         work.data_ptr(), st), "cvc_gru_seq_bwd")
+        last_bwd_form = "persistent" if done else "steps"
         ni = ctx.needs_input_grad
         Gi = hip.TileOperand(dgi, kmajor=True) if (ni[1]) else None           # dG^T packed once
         d_x = hip.tile_mm(dgi, w_ih, b_kmajor=True) if ni[0] else None          # [F*m, in]

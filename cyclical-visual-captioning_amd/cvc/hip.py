@@ -78,6 +78,8 @@ SIGNATURES = {
     "cvc_gru_persistent_sync_words": [],
     "cvc_gru_seq_persistent_train_fwd": [_P, _P, _LL, _LL, _P, _P, _I, _I, _I, _I, _P, _P, _LL, _LL, _P, _LL, _LL, _P, _P],
     "cvc_gru_seq_bwd_ksplit": [_I],
+    "cvc_gru_bwd_persistent_sync_words": [],
+    "cvc_gru_seq_bwd_persistent": [_P, _LL, _LL, _P, _LL, _LL, _P, _LL, _LL, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "cvc_linear_nn_planes_fwd": [_P, _I, _I, C.POINTER(NNSeg), _I, _I, _P, _P],
     "cvc_gru_seq_bwd": [_P, _LL, _LL, _P, _LL, _LL, _P, _LL, _LL, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "cvc_gru_seq_persistent_fwd": [_P, _P, _LL, _LL, _P, _P, _I, _I, _I, _I, _P, _P, _LL, _LL, _P, _P],

@@ -202,6 +202,16 @@ int cvc_gru_seq_persistent_train_fwd(const float* wp, const float* gi, long long
  * Outputs dgi, dgh: [F * M rows (t * M + m), ndir * 3H] -- pre-activation gradients of the input / hidden side, from which the
  * caller takes dW_ih, dX, dW_hh and the biases in dense GEMMs over all steps.  work: ndir * (2 M H + 192 H + ksplit * M *
  * ceil(H/128) * 128) floats, ksplit = cvc_gru_seq_bwd_ksplit(H).  M <= 64, H % 8 == 0. */
+/* Persistent form of cvc_gru_seq_bwd (csrc/gru_bwd_persistent.hip): one cooperative launch for the whole sequence, W_hh columns
+ * in registers, dgh exchanged through per-step slots.  wt = W_hh^T packed [ndir][H/8][3H/8][8 units][8 k]
+ * (cvc.gru.pack_gru_weights_t), slots = F * ndir * 3H * 64 floats, sync = cvc_gru_bwd_persistent_sync_words() words (word 4
+ * non-zero afterwards = barrier time-out: outputs invalid, repeat with cvc_gru_seq_bwd).  H % 256 == 0, H <= 1024, M <= 64;
+ * CVC_E_BADARG without launching otherwise. */
+int cvc_gru_bwd_persistent_sync_words(void);
+int cvc_gru_seq_bwd_persistent(const float* dy, long long dy_ld_m, long long dy_ld_t, const float* gates, long long g_ld_m,
+                               long long g_ld_t, const float* y, long long y_ld_m, long long y_ld_t, const float* wt,
+                               int M, int F, int H, int ndir, float* dgi, float* dgh, float* slots, unsigned* sync,
+                               cvc_stream_t stream);
 int cvc_gru_seq_bwd_ksplit(int H);
 int cvc_gru_seq_bwd(const float* dy, long long dy_ld_m, long long dy_ld_t, const float* gates, long long g_ld_m,
                     long long g_ld_t, const float* y, long long y_ld_m, long long y_ld_t, const float* w_hh, int M,
