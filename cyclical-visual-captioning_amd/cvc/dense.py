@@ -27,17 +27,32 @@ def _weight_operand(lin: nn.Linear):
 
 
 def usable(x: torch.Tensor) -> bool:
+    """Inference path (packed weight operand cached on the module)."""
     return (ENABLED and x.is_cuda and x.dtype == torch.float32 and not torch.is_grad_enabled()
+            and x.numel() // max(1, x.shape[-1]) >= MIN_ROWS)
+
+
+def usable_train(x: torch.Tensor) -> bool:
+    """Autograd path: cvc.functional.linear (tile GEMM forward for many rows, tile GEMM dW / dX in the backward)."""
+    return (ENABLED and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
             and x.numel() // max(1, x.shape[-1]) >= MIN_ROWS)
 
 
 def apply(layer: nn.Module, x: torch.Tensor) -> torch.Tensor:
     """layer(x) for `nn.Linear` or `nn.Sequential(nn.Linear, nn.ReLU[, nn.Dropout])` in eval mode."""
     lin = layer if isinstance(layer, nn.Linear) else (layer[0] if isinstance(layer, nn.Sequential) and len(layer) > 0 else None)
-    if not isinstance(lin, nn.Linear) or not usable(x) or layer.training:
+    if not isinstance(lin, nn.Linear):
         return layer(x)
     rest = [] if layer is lin else list(layer)[1:]
     if not all(isinstance(m, (nn.ReLU, nn.Dropout)) for m in rest):
+        return layer(x)
+    if usable_train(x) and x.shape[-1] % 4 == 0 and lin.out_features % 4 == 0:
+        from . import functional as F_                      # under autograd: the hot path's linear (no library GEMM either way)
+        y = F_.linear(x, lin.weight, lin.bias)
+        for m in rest:
+            y = m(y)                                        # ReLU / Dropout as the module has them
+        return y
+    if not usable(x) or layer.training:
         return layer(x)
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])

@@ -351,9 +351,12 @@ def test_encoder_with_hip_gru_matches_library_gru_forward_and_backward(tmp_path)
     inp = to_dev(synth.encoder_inputs(Dw, 3), torch.device("cuda:0"))
     from cvc.misc import utils
     overlaps = utils.bbox_overlaps(inp["proposals"], inp["gt_bboxs"], inp["frm_mask"] | inp["pnt_mask_in"][:, 1:].unsqueeze(-1))
+    from cvc import dense
     res = {}
     for hip_gru in (True, False):
         backbone.HIP_GRU = hip_gru
+        dense.ENABLED = hip_gru                     # ... and its dense layers on the tile GEMM (cvc/dense.py) vs the library
+        min_rows, dense.MIN_ROWS = dense.MIN_ROWS, 8      # (this test's 45 rows would otherwise stay on the library kernels)
         try:
             with torch.no_grad():
                 out_inf = run_encoder(enc, inp, overlaps)
@@ -365,6 +368,8 @@ def test_encoder_with_hip_gru_matches_library_gru_forward_and_backward(tmp_path)
             res[hip_gru] = (out_inf, out, {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None})
         finally:
             backbone.HIP_GRU = True
+            dense.ENABLED = True
+            dense.MIN_ROWS = min_rows
     for a, b in ((res[True][0], res[False][0]), (res[True][1], res[False][1])):
         for name, x, y in zip(OUT, a, b):
             if torch.is_tensor(x) and x.dtype.is_floating_point:
