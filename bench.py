@@ -345,6 +345,20 @@ def run_encoder(args, d, dev):
 
     piece_ms["2-layer BiGRU forward + backward, HIP path (cvc.gru.gru_forward_train: cvc_gru_seq_bwd + tile GEMM)"] = round(timed(fb_hip, 3), 3)
     piece_ms["2-layer BiGRU forward + backward, library module (MIOpen)"] = round(timed(fb_lib, 3), 3)
+    # the whole encoder under autograd (forward + backward of a probe loss over its outputs), HIP kernels vs library modules
+    from cvc import dense as dense_mod
+
+    def enc_fb():
+        enc.zero_grad(set_to_none=True)
+        outs = fwd()
+        sum(o.float().pow(2).mean() for o in outs[:6] if torch.is_tensor(o) and o.dtype.is_floating_point).backward()
+
+    enc.train()
+    piece_ms["whole encoder forward + backward, HIP GRU + tile-GEMM dense layers"] = round(timed(enc_fb, 3), 3)
+    backbone.HIP_GRU, dense_mod.ENABLED = False, False
+    piece_ms["whole encoder forward + backward, library GRU + library GEMMs"] = round(timed(enc_fb, 3), 3)
+    backbone.HIP_GRU, dense_mod.ENABLED = True, True
+    enc.eval()
     gru_mod.eval()
     with torch.no_grad():
         backbone.HIP_GRU = False
