@@ -3,7 +3,11 @@
 
   python bench.py                                                     # BASELINE config 2, 300 timed decodes (>= 1 s)
   python bench.py --gpus 1 --steps 20 --warmup 5                      # what the driver runs
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus 8 [--mode train --config cfg4]               # starts the 8 rank processes itself (torch.distributed.run
+                                                                      # child, before anything here touches a GPU)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...      # or under a launcher
+--gpus N is a promise: the line carries n_gpus = N only if N ranks joined the process group (checked with an all-reduce);
+anything else exits non-zero without a line.
 
 A "step" is one pass of the hot path over one batch: the full T-step greedy decode of B clips
 (embed, att-LSTM, both attentions, lang-LSTM, vocab projection, word selection per decode step),
@@ -17,6 +21,9 @@ Extra objects in the JSON line:
                    events in this process; `kernels` lists every kernel of the step the same way.
   cpu_baseline  -- the CPU oracle (torch fp32, the reference's own ATen op sequence) timed on this
                    box's host cores on the same workload (rank 0, N=1 only).
+  secondary     -- default run only (N=1, headline config): short measurements (>= 0.3 s each) of the other BASELINE configs --
+                   config 3 beam 5, config 3 cyclical train step, config 4 per-GPU train step, config 5 greedy + beam 5, the
+                   once-per-clip encoder -- each with its own ms_per_step and roofline.  The headline fields are not affected.
 """
 from __future__ import annotations
 
@@ -62,8 +69,16 @@ def parse():
                         "computing waves (default of the library)")
     p.add_argument("--lstm-blocks", type=int, default=None, choices=[1, 2],
                    help="packed decode LSTM gate GEMM (A/B): 32-row weight blocks per workgroup (library default 1)")
+    p.add_argument("--gsk", type=int, default=None, choices=[0, 1],
+                   help="packed path (A/B): 1 = grouped stream-K schedule (measured slower; off by default)")
+    p.add_argument("--embgate", type=int, default=None, choices=[0, 1],
+                   help="packed path (A/B): 0 = the 7-launch schedule without the embedding-gate table; default = on")
     p.add_argument("--train-graph", action="store_true", help="--mode train: capture the whole training step in a HIP graph")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--spawn", action="store_true",
+                   help="start the rank processes through the torch.distributed.run child also for --gpus 1 (the path every N > 1 run takes)")
+    p.add_argument("--no-secondary", action="store_true", help="default decode run: skip the short runs of the other configs")
+    p.add_argument("--secondary-seconds", type=float, default=0.35, help="timed seconds per secondary measurement")
     p.add_argument("--cpu-repeats", type=int, default=3)
     p.add_argument("--seed", type=int, default=1234)
     return p.parse_args()
@@ -88,7 +103,7 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def pmc_traffic(kernel, args, over, mode="decode"):
+def pmc_traffic(kernel, args, over, mode="decode", beam=None, config_name=None):
     """HBM bytes per launch of `kernel` from the tracked PMC collection (profiles/traffic.json, written by
     tools/collect_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very command).
     The file records the hash of the kernel sources it was collected on; numbers from any other build are REFUSED
@@ -104,7 +119,7 @@ def pmc_traffic(kernel, args, over, mode="decode"):
     have = build_hip.source_hash()
     if tf.get("source_hash") != have:
         return None, f"stale: collected on kernel sources {tf.get('source_hash')}, this build is {have}"
-    want = dict(config=args.config, beam=args.beam, mode=mode)
+    want = dict(config=config_name or args.config, beam=args.beam if beam is None else beam, mode=mode)
     got = {k: tf.get("workload", {}).get(k) for k in want}
     from cvc import synth as _synth
     same_dims = (got.get("config") in _synth.CONFIGS and want["config"] in _synth.CONFIGS
@@ -134,12 +149,31 @@ def algorithmic_work(d, beam):
     w["h2attn"] = dict(bound="hbm", bytes=4 * (A * R + A) + 4 * rows * (R + A), flops=2 * rows * A * R)
     w["logits"] = dict(bound="hbm", bytes=4 * (V * R + V) + 4 * rows * (R + V), flops=2 * rows * V * R)
     w["word_select"] = dict(bound="hbm", bytes=4 * rows * 6 * ((V + 31) // 32) + 4 * rows * E)
+    # grouped stream-K schedule (csrc/gemm_gsk.hip): the same weight bytes regrouped -- every launch streams its groups' weights
+    # once; the partial tiles (fp32, 256 x 64 per segment) are written by the stream-K launch and read by its consumer
+    tile_b = 4 * 256 * 64
+    n_lstm_tiles, segs = R // 64, lambda k: k / 32 / 21.0 + 1       # ~ segments per tile at ~21 chunks per workgroup
+    w["att_early_logits"] = dict(bound="hbm", bytes=4 * (4 * R * 2 * R + V * R) + 4 * rows * 2 * R +
+                                 int(tile_b * (n_lstm_tiles * segs(2 * R) + (V + 255) // 256 * segs(R))),
+                                 flops=2 * rows * (4 * R * 2 * R + V * R))
+    w["lang_early_h2attn"] = dict(bound="hbm", bytes=4 * (4 * R * 2 * R + A * R) + 4 * rows * 2 * R +
+                                  int(tile_b * (n_lstm_tiles * segs(2 * R) + (A + 255) // 256 * segs(R))),
+                                  flops=2 * rows * (4 * R * 2 * R + A * R))
+    w["att_late"] = dict(bound="hbm", bytes=4 * (4 * R * E) + 4 * rows * (E + 4 * R + 3 * R) + int(tile_b * n_lstm_tiles * segs(2 * R)),
+                         flops=2 * rows * 4 * R * E)
+    w["lang_late"] = dict(bound="hbm", bytes=4 * (4 * R * R + 8 * R) + 4 * rows * (R + 3 * R) + int(tile_b * n_lstm_tiles * segs(2 * R)),
+                          flops=2 * rows * 4 * R * R)
     return w
 
 
-def run_train(args, d, dev, rank, world):
+def run_train(args, d, dev, rank, world, steps=None, warmup=None, min_warm=None, cpu_baseline=True, config_name=None, probe=True):
     """Cyclical training step (BASELINE configs 3-ii / 4): decode -> localize -> reconstruct forward,
-    backward, one RCCL gradient all-reduce (world > 1), clip_grad_norm_(0.1), Adam.  Train-mode dropout."""
+    backward, one RCCL gradient all-reduce (world > 1), clip_grad_norm_(0.1), Adam.  Train-mode dropout.
+    Returns the bench line (rank 0) or None."""
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
+    min_warm = args.min_warm_seconds if min_warm is None else min_warm
+    config_name = config_name or args.config
     import argparse as ap
     from cvc import synth, opts as cvc_opts
     from cvc.model.captioner import DecodeAndGroundCaptionerGVDROI, PrecomputedRegionFeatures
@@ -166,29 +200,46 @@ def run_train(args, d, dev, rank, world):
     dist_on = dist.is_available() and dist.is_initialized()
     step = tr.train_step_graphed if args.train_graph else tr.train_step
     w0 = time.perf_counter()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step(batch)
     torch.cuda.synchronize()
-    while time.perf_counter() - w0 < args.min_warm_seconds:
+    while time.perf_counter() - w0 < min_warm:
         step(batch)
         torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
+
+    def timed_region(n):
+        if dist_on:
+            dist.barrier()
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss_ = step(batch)[0]
         torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step(batch)[0]
-    torch.cuda.synchronize()
-    el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-    if dist_on:
-        dist.barrier()
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    el = float(el.item())
-    ms_step = el / args.steps * 1e3
+        el_ = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if dist_on:
+            dist.barrier()
+            dist.all_reduce(el_, op=dist.ReduceOp.MAX)
+        return float(el_.item()), loss_
+
+    el, loss = timed_region(steps)
+    ms_step = el / steps * 1e3
+    # exposed exchange time (N > 1): the same steps with the gradient exchange switched off (every rank then trains on its own
+    # shard: a measurement, not a training mode); exposed = step with exchange - step without
+    exchange = None
+    if world > 1 and reducer.exchange:
+        reducer.exchange, keep_overlap = False, reducer.overlap
+        reducer.overlap = False
+        el0, _ = timed_region(steps)
+        reducer.exchange, reducer.overlap = True, keep_overlap
+        ms0 = el0 / steps * 1e3
+        grad_bytes = sum(a.numel() * 4 for a in reducer.arenas)
+        exchange = dict(ms_per_step_without_exchange=round(ms0, 3), exposed_ms=round(ms_step - ms0, 3), gradient_bytes=grad_bytes,
+                        algorithm="per bucket: in-place reduce_scatter + all_gather on RCCL, launched from post-accumulate-grad hooks",
+                        backend=reducer.backend, buckets=len(reducer.arenas))
 
     # ---- per-entry-point GPU time of one step: HIP events around every C-ABI launch (eager steps, launch stream)
     roof, kernels, cpu = None, [], None
-    if rank == 0:
+    if rank == 0 and probe:
         from cvc import hip
         work = train_work(d)
         timers = hip.enable_timers()
@@ -222,7 +273,7 @@ def run_train(args, d, dev, rank, world):
                             share=round((ms_step - ours) / ms_step, 4)))
         dom = next((e for e in kernels if "bound" in e), None)
         if dom is not None:
-            traffic, note = pmc_traffic(dom["kernel"], args, None, mode="train")
+            traffic, note = pmc_traffic(dom["kernel"], args, None, mode="train", beam=1, config_name=config_name)
             if dom["bound"] == "mfma":
                 roof = dict(kernel=dom["kernel"], bound="mfma", achieved=dom["achieved_TFLOPs"], peak=dom["mfma_peak_TFLOPs"],
                             unit="TFLOP/s", frac=dom["frac_mfma"], traffic=traffic, traffic_source=note, avg_us=dom["avg_us"],
@@ -234,7 +285,7 @@ def run_train(args, d, dev, rank, world):
                             algorithmic_bytes=dom["algorithmic_bytes"])
         # ---- CPU baseline: the oracle's cyclical forward + autograd backward on this box's host cores, one step of the
         # same workload (eval-mode dropout: the reference's train-mode backward does not run on torch 2.x)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and cpu_baseline and not args.no_cpu_baseline:
             from oracle import ref_cpu as O
             ncores = usable_cores()
             torch.set_num_threads(ncores)
@@ -259,24 +310,28 @@ def run_train(args, d, dev, rank, world):
                        seconds=round(best, 3))
     if rank == 0:
         line = {
-            "metric": "cyclical train decode-steps/sec (BxT per fwd+bwd+update)", "value": round(d.B * d.T * world * args.steps / el, 1),
-            "unit": "decode-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "cyclical train decode-steps/sec (BxT per fwd+bwd+update)", "value": round(d.B * d.T * world * steps / el, 1),
+            "unit": "decode-steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "samples_per_s": round(d.B * world * args.steps / el, 2), "loss": float(loss),
-            "config": {"workload": f"{args.config}: cyclical train step (decode+localize+reconstruct fwd, bwd, clip, Adam), train-mode dropout",
-                       "B_per_gpu": d.B, "N": d.N, "F": d.F, "D": d.R, "T": d.T, "hip_graph": bool(args.train_graph),
-                       "parallelism": f"dp{world}: clips sharded, one RCCL gradient all-reduce per step"},
-            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels}
+            "dtype": "f32", "data": "synthetic", "samples_per_s": round(d.B * world * steps / el, 2), "loss": float(loss),
+            "config": {"workload": f"{config_name}: cyclical train step (decode+localize+reconstruct fwd, bwd, clip, Adam), train-mode dropout",
+                       "B_per_gpu": d.B, "global_batch": d.B * world, "N": d.N, "F": d.F, "D": d.R, "T": d.T, "hip_graph": bool(args.train_graph),
+                       "parallelism": f"dp{world}: clips sharded, one RCCL gradient exchange per step"},
+            "roofline": roof, "cpu_baseline": cpu, "exchange": exchange, "kernels": kernels}
         if cpu:
             line["gpu_over_cpu"] = round(line["value"] / cpu["value"], 1)
-        print(json.dumps(line), flush=True)
+        return line
+    return None
 
 
-def run_encoder(args, d, dev):
+def run_encoder(args, d, dev, brief=False, steps=None, warmup=None):
     """Once-per-clip encoder (cvc/model/backbone.py, mirror of the reference's RegionalFeatureExtractorGVD, backbone.py:189-351)
     at the hot path's dimensions: raw frame features [B, F, 3072] and region features [B, N, G] -> the tensors the decoder reads.
-    It is library work (hipBLASLt GEMMs, MIOpen GRU); this mode times its pieces so that the next round can decide which
-    deserve kernels.  clips/s, not decode-steps/s: the encoder runs once per clip, the decoder T times."""
+    The frame-context GRU and the dense layers run on the HIP kernels (cvc/gru.py, cvc/dense.py); this mode times the forward, its
+    pieces and (not brief) forward + backward against the library modules.  clips/s, not decode-steps/s: the encoder runs once per
+    clip, the decoder T times.  Returns the bench line."""
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     import argparse as ap
     from cvc import synth
     from cvc.model import backbone
@@ -309,10 +364,63 @@ def run_encoder(args, d, dev):
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
 
+    from cvc import hip
     with torch.no_grad():
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             fwd()
-        ms = timed(fwd, max(3, min(args.steps, 30)))
+        ms = timed(fwd, max(3, min(steps, 30)))
+        # ---- per-entry-point GPU time of one forward (HIP events around every C-ABI launch) and the dominant kernel's roofline
+        timers = hip.enable_timers()
+        fwd(); torch.cuda.synchronize(); timers.clear()
+        for _ in range(2):
+            fwd()
+        torch.cuda.synchronize()
+        hip.disable_timers()
+    tot = {k: sum(a.elapsed_time(b) for a, b in v) / 2 for k, v in timers.items()}
+    cnt = {k: len(v) // 2 for k, v in timers.items()}
+    B_, F_, N_, R_, A_, G_ = d.B, d.F, d.N, d.R, d.A, d.G
+    H_ = R_ // 2
+    pool_in = enc.pool_feat_size
+    work = {
+        # recurrence of one GRU layer, both directions: W_hh once, the input projections of every step read, every h_t written
+        "cvc_gru_seq_persistent_fwd": dict(bytes=2 * (4 * 2 * 3 * H_ * H_ + 4 * B_ * F_ * 2 * 3 * H_ + 4 * B_ * F_ * 2 * H_), flops=2 * 2 * B_ * F_ * 2 * 3 * H_ * H_),
+        "cvc_gru_seq_fwd": dict(bytes=2 * (4 * F_ * 2 * 3 * H_ * H_ + 4 * B_ * F_ * 2 * 3 * H_ + 4 * B_ * F_ * 2 * H_), flops=2 * 2 * B_ * F_ * 2 * 3 * H_ * H_),
+        # every dense product of the forward on the tile GEMM: GRU input projections (2 layers), frame embeddings, ctx2att_fc, region side
+        "cvc_tile_gemm": dict(bytes=0, flops=2 * B_ * F_ * (2 * R_ * 3 * R_ + 2048 * H_ + 1024 * H_ + R_ * A_) +
+                              2 * B_ * N_ * (G_ * G_ + pool_in * R_ + R_ * A_)),
+    }
+    kernels = []
+    for name in sorted(tot, key=lambda k: -tot[k]):
+        ent = dict(kernel=name, launches=cnt[name], ms=round(tot[name], 3), share=round(tot[name] / ms, 4))
+        wk = work.get(name)
+        if wk:
+            secs = tot[name] * 1e-3
+            ent.update(achieved_GBs=round(wk["bytes"] / secs / 1e9, 1), achieved_TFLOPs=round(wk["flops"] / secs / 1e12, 2),
+                       algorithmic_bytes=wk["bytes"], algorithmic_flops=wk["flops"])
+        kernels.append(ent)
+    roof = None
+    dom = next((e for e in kernels if "achieved_GBs" in e), None)
+    if dom is not None:
+        if dom["kernel"] == "cvc_tile_gemm":
+            peak = MFMA_BF16_PEAK_TFLOPS / 6
+            roof = dict(kernel=dom["kernel"], bound="mfma", achieved=dom["achieved_TFLOPs"], peak=round(peak, 1), unit="TFLOP/s",
+                        frac=round(dom["achieved_TFLOPs"] / peak, 4), traffic=None, ms=dom["ms"],
+                        peak_note="fp32-equivalent flops; split products issue 6 bf16 MFMAs each: dense bf16 peak / 6")
+        else:
+            roof = dict(kernel=dom["kernel"], bound="hbm", achieved=dom["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4), traffic=None, ms=dom["ms"], algorithmic_bytes=dom["algorithmic_bytes"],
+                        note="the recurrence is a chain of F dependent steps (10.6 us each: arrival poll, state from L2, MFMAs, "
+                             "write-through store): latency-bound far below either roof, DESIGN.md section 7")
+    line = {
+        "metric": "once-per-clip encoder clips/sec (not the headline metric)", "value": round(d.B / (ms * 1e-3), 1),
+        "unit": "clips/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}: RegionalFeatureExtractorGVD forward (eval), raw frame features [B,{d.F},3072] + region "
+                               f"features [B,{d.N},{d.G}]", "B_per_gpu": d.B, "N": d.N, "F": d.F, "D": d.R, "G": d.G},
+        "roofline": roof, "cpu_baseline": None, "kernels": kernels}
+    if brief:
+        return line
+    with torch.no_grad():
         # pieces (same tensors, eval mode)
         B, N, F = d.B, d.N, d.F
         regions = inp["region_feats"]
@@ -362,17 +470,10 @@ def run_encoder(args, d, dev):
     gru_mod.eval()
     with torch.no_grad():
         backbone.HIP_GRU = False
-        ms_library = timed(fwd, max(3, min(args.steps, 10)))
+        ms_library = timed(fwd, max(3, min(steps, 10)))
         backbone.HIP_GRU = True
-    print(json.dumps({
-        "metric": "once-per-clip encoder clips/sec (not the headline metric)", "value": round(d.B / (ms * 1e-3), 1),
-        "unit": "clips/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.config}: RegionalFeatureExtractorGVD forward (eval), raw frame features [B,{d.F},3072] + region "
-                               f"features [B,{d.N},{d.G}]", "B_per_gpu": d.B, "N": d.N, "F": d.F, "D": d.R, "G": d.G},
-        "decode_ms_for_comparison": "T-step greedy decode of the same B clips: see the default mode (4.1 ms at cfg2)",
-        "ms_per_step_with_library_gru": round(ms_library, 3),
-        "pieces_ms": piece_ms, "roofline": None, "cpu_baseline": None}), flush=True)
+    line.update(ms_per_step_with_library_gru=round(ms_library, 3), pieces_ms=piece_ms)
+    return line
 
 
 def train_work(d):
@@ -399,63 +500,43 @@ def train_work(d):
     return w
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if args.tile_loaders is not None:
-        from cvc import hip as _hip
-        _hip.lib().cvc_tile_gemm_loaders(int(args.tile_loaders))
-    if args.lstm_blocks is not None:
-        from cvc import hip as _hip
-        _hip.lib().cvc_packed_lstm_wg_blocks(int(args.lstm_blocks))
-    # under torchrun (RANK set) the process group is always initialised, also for a single rank, so that the
-    # barrier / max-over-ranks path is the same code at every N
-    dist_on = "RANK" in os.environ and "WORLD_SIZE" in os.environ
-    if dist_on:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+def spawn_ranks(args) -> int:
+    """--gpus N (N > 1) outside a launcher: start the N rank processes as a torch.distributed.run child and hand its exit code
+    back.  Nothing here has touched a GPU (torch.cuda.device_count() does not initialise one), so no process that holds GPU
+    state is ever replaced or forked.  Fails loudly -- non-zero, no bench line -- when the machine has fewer than N devices or
+    any rank fails to come up (the launcher then returns non-zero itself)."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but this machine shows {n_dev} GPU(s); refusing to run fewer ranks than asked for "
+              f"(there is no CPU fallback)", file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this pool
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
 
-    import dataclasses
-    from cvc import synth
+
+def run_decode(args, d, dev, rank, world, dist_on, beam, steps, warmup, min_warm, cpu_baseline, over, config_name, sd_np=None):
+    """The headline measurement: K timed full decodes of B clips (graph replay), per-kernel HIP-event timing, roofline, CPU oracle.
+    Returns the bench line on rank 0, None elsewhere."""
+    from cvc import synth, hip
     from cvc.decode import DecodeEngine, DecodeWeights
-    from cvc import hip
-    hip.lib()
-
-    d = synth.CONFIGS[args.config]
-    over = {k: getattr(args, k) for k in ("B", "N", "F", "R", "A", "E", "V", "T") if getattr(args, k) is not None}
-    if over:
-        d = dataclasses.replace(d, **over)
-    if args.mode == "encoder":
-        if rank == 0:
-            run_encoder(args, d, dev)
-        if dist_on:
-            import torch.distributed as dist
-            dist.destroy_process_group()
-        return
-    if args.mode == "train":
-        run_train(args, d, dev, rank, world)
-        if dist_on:
-            import torch.distributed as dist
-            dist.destroy_process_group()
-        return
     seed = args.seed + rank                       # every rank decodes its own clips
-    sd_np = synth.hot_path_state_dict(d, args.seed)
+    if sd_np is None:
+        sd_np = synth.hot_path_state_dict(d, args.seed)
     feats_np = synth.clip_features(d, seed)
     W = DecodeWeights({k: torch.from_numpy(v).to(dev) for k, v in sd_np.items()})
     feats = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in feats_np.items()}
-    eng = DecodeEngine(W, feats, d.T, synth.UNK_IDX, beam=args.beam,
-                       gate_ksplit=None if args.gate_ksplit is None else (bool(args.gate_ksplit) if args.gate_ksplit < 2 else "fused"))
-    from cvc import hip as _hip
-    gemm_mode = _hip.gemm_packed_split(-1)
+    eng = DecodeEngine(W, feats, d.T, synth.UNK_IDX, beam=beam,
+                       gate_ksplit=None if args.gate_ksplit is None else (bool(args.gate_ksplit) if args.gate_ksplit < 2 else "fused"),
+                       gsk=None if args.gsk is None else bool(args.gsk), embgate=None if args.embgate is None else bool(args.embgate))
+    gemm_mode = hip.gemm_packed_split(-1)
     if not args.no_graph:
         eng.capture()
 
@@ -467,15 +548,15 @@ def main():
             torch.cuda.synchronize()
 
     w0 = time.perf_counter()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         eng.run()
     torch.cuda.synchronize()
-    while time.perf_counter() - w0 < args.min_warm_seconds:      # untimed: DVFS / cache warm-up beyond the W steps
+    while time.perf_counter() - w0 < min_warm:      # untimed: DVFS / cache warm-up beyond the W steps
         eng.run()
         torch.cuda.synchronize()
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         eng.run()
     torch.cuda.synchronize()
     t_local = time.perf_counter() - t0
@@ -485,73 +566,86 @@ def main():
         import torch.distributed as dist
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    units = d.B * d.T * world * args.steps
+    units = d.B * d.T * world * steps
     value = units / elapsed
+    if rank != 0:
+        return None
 
     # ---- per-kernel durations with HIP events on the launch stream (eager pass, same buffers)
     kernels, roof = [], None
-    if rank == 0:
-        work = algorithmic_work(d, args.beam)
-        split_mode = gemm_mode
-        acc = {}
-        eng.run_timed()                            # warm
-        for _ in range(3):
-            for k, v in eng.run_timed().items():
-                acc.setdefault(k, []).extend(v)
-        decode_ms = sum(float(np.sum(v)) / 3 for v in acc.values())
-        for name, ms in acc.items():
-            avg = float(np.mean(ms))
-            wk = work.get(name)
-            ent = dict(kernel=name, avg_us=round(avg * 1e3, 2), launches_per_decode=len(ms) // 3,
-                       share=round(float(np.sum(ms)) / 3 / decode_ms, 4) if decode_ms > 0 else None)
-            if wk:
-                gbs = wk["bytes"] / (avg * 1e-3) / 1e9
-                ent.update(algorithmic_bytes=wk["bytes"], achieved_GBs=round(gbs, 1), frac_hbm=round(gbs / HBM_PEAK_GBS, 4))
-                bound = "hbm"
-                if "flops" in wk:
-                    # matrix work as EXECUTED: the packed path takes every fp32 product as six bf16 cross terms
-                    # (cvc_gemm_packed_split), the row-major path issues fp32 MFMAs
-                    split = (eng.packed and split_mode > 0) or getattr(eng, "tile", False)
-                    mult, peak, what = (6, MFMA_BF16_PEAK_TFLOPS, "bf16 32x32x16, 6 per fp32 product") if split else \
-                                       (1, MFMA_F32_PEAK_TFLOPS, "f32 32x32x2")
-                    tf = mult * wk["flops"] / (avg * 1e-3) / 1e12
-                    ent.update(algorithmic_flops=wk["flops"], mfma=what, executed_mfma_flops=mult * wk["flops"],
-                               achieved_TFLOPs=round(tf, 2), mfma_peak_TFLOPs=peak, frac_mfma=round(tf / peak, 4))
-                    # the binding roof is the one with the larger floor time
-                    if mult * wk["flops"] / (peak * 1e12) > wk["bytes"] / (HBM_PEAK_GBS * 1e9):
-                        bound = "mfma"
-                ent["bound"] = bound
-            kernels.append(ent)
-        kernels.sort(key=lambda e: -(e["share"] or 0))
-        # dominant KERNEL, not launch: the two LSTM gate GEMMs of a step are launches of one kernel symbol; when their combined
-        # share is the largest the roofline is quoted on the longer of the two launches (its own bytes over its own duration)
-        dom = next(e for e in kernels if "achieved_GBs" in e)
-        gates = [e for e in kernels if e["kernel"] in ("att_lstm", "lang_lstm") and "achieved_GBs" in e]
-        gate_share = sum(e["share"] or 0 for e in gates)
-        if gates and gate_share >= (dom["share"] or 0):
-            dom = max(gates, key=lambda e: e["avg_us"])
-            dom["share_of_kernel_symbol"] = round(gate_share, 4)
-        traffic, traffic_note = pmc_traffic(dom["kernel"], args, over)
-        if dom["bound"] == "mfma":
-            roof = dict(kernel=dom["kernel"], bound="mfma", achieved=dom["achieved_TFLOPs"], peak=dom["mfma_peak_TFLOPs"],
-                        unit="TFLOP/s", frac=dom["frac_mfma"], traffic=traffic, traffic_source=traffic_note,
-                        avg_us=dom["avg_us"], hbm_frac=dom["frac_hbm"])
-        else:
-            roof = dict(kernel=dom["kernel"], bound="hbm", achieved=dom["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=dom["frac_hbm"], traffic=traffic, traffic_source=traffic_note, avg_us=dom["avg_us"],
-                        algorithmic_bytes=dom["algorithmic_bytes"])
+    work = algorithmic_work(d, beam)
+    if getattr(eng, "embgate", False):
+        # embedding-gate schedule: the att-LSTM streams only the recurrent K range (2R) and gathers one 4R-row of the per-checkpoint
+        # table per clip
+        R_, rows_ = d.R, d.B
+        work["att_lstm"] = dict(bound="hbm", bytes=4 * (4 * R_ * 2 * R_) + 4 * rows_ * (2 * R_ + 3 * R_ + 4 * R_ + 4 * R_),
+                                flops=2 * rows_ * 4 * R_ * 2 * R_)
+        work["word_select"] = dict(bound="hbm", bytes=4 * rows_ * 6 * ((d.V + 31) // 32))
+    if getattr(eng, "gsk", False):
+        work["word_select"] = dict(bound="hbm", bytes=int(4 * 256 * 64 * ((d.V + 255) // 256) * (d.R / 32 / 21.0 + 1)) + 4 * d.B * d.E)
+    split_mode = gemm_mode
+    acc = {}
+    eng.run_timed()                            # warm
+    for _ in range(3):
+        for k, v in eng.run_timed().items():
+            acc.setdefault(k, []).extend(v)
+    decode_ms = sum(float(np.sum(v)) / 3 for v in acc.values())
+    for name, ms in acc.items():
+        avg = float(np.mean(ms))
+        wk = work.get(name)
+        ent = dict(kernel=name, avg_us=round(avg * 1e3, 2), launches_per_decode=len(ms) // 3,
+                   share=round(float(np.sum(ms)) / 3 / decode_ms, 4) if decode_ms > 0 else None)
+        if wk:
+            gbs = wk["bytes"] / (avg * 1e-3) / 1e9
+            ent.update(algorithmic_bytes=wk["bytes"], achieved_GBs=round(gbs, 1), frac_hbm=round(gbs / HBM_PEAK_GBS, 4))
+            bound = "hbm"
+            if "flops" in wk:
+                # matrix work as EXECUTED: the packed path takes every fp32 product as six bf16 cross terms
+                # (cvc_gemm_packed_split), the row-major path issues fp32 MFMAs
+                split = (eng.packed and split_mode > 0) or getattr(eng, "tile", False)
+                mult, peak, what = (6, MFMA_BF16_PEAK_TFLOPS, "bf16 32x32x16, 6 per fp32 product") if split else \
+                                   (1, MFMA_F32_PEAK_TFLOPS, "f32 32x32x2")
+                tf = mult * wk["flops"] / (avg * 1e-3) / 1e12
+                ent.update(algorithmic_flops=wk["flops"], mfma=what, executed_mfma_flops=mult * wk["flops"],
+                           achieved_TFLOPs=round(tf, 2), mfma_peak_TFLOPs=peak, frac_mfma=round(tf / peak, 4))
+                # the binding roof is the one with the larger floor time
+                if mult * wk["flops"] / (peak * 1e12) > wk["bytes"] / (HBM_PEAK_GBS * 1e9):
+                    bound = "mfma"
+            ent["bound"] = bound
+        kernels.append(ent)
+    kernels.sort(key=lambda e: -(e["share"] or 0))
+    # dominant KERNEL, not launch: the two LSTM gate GEMMs of a step are launches of one kernel symbol; when their combined
+    # share is the largest the roofline is quoted on the longer of the two launches (its own bytes over its own duration)
+    dom = next(e for e in kernels if "achieved_GBs" in e)
+    gates = [e for e in kernels if e["kernel"] in ("att_lstm", "lang_lstm") and "achieved_GBs" in e]
+    sk = [e for e in kernels if e["kernel"] in ("att_early_logits", "lang_early_h2attn") and "achieved_GBs" in e]
+    if sk and sum(e["share"] or 0 for e in sk) >= (dom["share"] or 0):         # the two stream-K launches are one kernel symbol
+        gates = sk
+    gate_share = sum(e["share"] or 0 for e in gates)
+    if gates and gate_share >= (dom["share"] or 0):
+        dom = max(gates, key=lambda e: e["avg_us"])
+        dom["share_of_kernel_symbol"] = round(gate_share, 4)
+    traffic, traffic_note = pmc_traffic(dom["kernel"], args, over, beam=beam, config_name=config_name)
+    if dom["bound"] == "mfma":
+        roof = dict(kernel=dom["kernel"], bound="mfma", achieved=dom["achieved_TFLOPs"], peak=dom["mfma_peak_TFLOPs"],
+                    unit="TFLOP/s", frac=dom["frac_mfma"], traffic=traffic, traffic_source=traffic_note,
+                    avg_us=dom["avg_us"], hbm_frac=dom["frac_hbm"])
+    else:
+        roof = dict(kernel=dom["kernel"], bound="hbm", achieved=dom["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=dom["frac_hbm"], traffic=traffic, traffic_source=traffic_note, avg_us=dom["avg_us"],
+                    algorithmic_bytes=dom["algorithmic_bytes"])
 
     # ---- CPU baseline: the oracle on this box's host cores, same workload (rank 0, N=1 only)
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if world == 1 and cpu_baseline and not args.no_cpu_baseline:
         from oracle import ref_cpu as O
         ncores = usable_cores()
         torch.set_num_threads(ncores)
         P_cpu, f_cpu = O.to_torch(sd_np), O.to_torch(feats_np)
         best = None
         with torch.no_grad():
-            fn = (lambda: O.greedy_sample(P_cpu, f_cpu, d.T, synth.UNK_IDX)) if args.beam == 1 else \
-                (lambda: O.beam_search(P_cpu, f_cpu, d.T, synth.UNK_IDX, args.beam))
+            fn = (lambda: O.greedy_sample(P_cpu, f_cpu, d.T, synth.UNK_IDX)) if beam == 1 else \
+                (lambda: O.beam_search(P_cpu, f_cpu, d.T, synth.UNK_IDX, beam))
             fn()
             for _ in range(args.cpu_repeats):
                 c0 = time.perf_counter()
@@ -562,22 +656,139 @@ def main():
                    sample=f"one full decode of the same workload (B={d.B}, T={d.T}), warm-up 1, best of {args.cpu_repeats}; "
                           f"torch {torch.__version__} CPU, {ncores} host cores", seconds=round(best, 3))
 
+    sched = ("grouped stream-K (early K ranges of the gate GEMMs ride with logits / h2attn)" if getattr(eng, "gsk", False) else
+             ("embedding-gate table (att-LSTM GEMM over K = 2R + one table row per word)" if getattr(eng, "embgate", False) else
+              "one GEMM over the full K per cell"))
+    line = {
+        "metric": f"caption decode-steps/sec (BxT) at N={d.N},D={d.R}", "value": round(value, 1), "unit": "decode-steps/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{config_name}: greedy caption decode" if beam == 1 else f"{config_name}: beam={beam} caption decode",
+                   "B_per_gpu": d.B, "N": d.N, "F": d.F, "D": d.R, "A": d.A, "E": d.E, "V": d.V, "T": d.T, "beam": beam,
+                   "hip_graph": not args.no_graph, "parallelism": f"clips sharded over {world} rank(s), no collective",
+                   "gemm_arithmetic": ("f32 in / f32 accumulate; products = exact 3-way bf16 split of both operands, 6 leading "
+                                       "cross terms on the bf16 MFMA (error vs f64 <= the f32-MFMA path's, tests/test_gpu_parity.py)")
+                   if ((eng.packed and gemm_mode > 0) or getattr(eng, "tile", False)) else "f32 MFMA",
+                   "engine_path": "packed" if eng.packed else ("tile" if getattr(eng, "tile", False) else "ring"),
+                   "schedule": sched if eng.packed else None},
+        "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+    }
+    if cpu:
+        line["gpu_over_cpu"] = round(value / cpu["value"], 1)
+    del eng
+    return line
+
+
+def brief(line):
+    """One secondary entry: what was measured, its time and its roofline (the per-kernel table stays with the headline)."""
+    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "exchange")
+    out = {k: line[k] for k in keep if k in line and line[k] is not None}
+    ks = [k for k in line.get("kernels", []) if "kernel" in k][:4]
+    out["top_kernels"] = [{kk: k[kk] for kk in ("kernel", "avg_us", "ms", "ms_per_step", "share", "frac_hbm", "frac_mfma") if kk in k} for k in ks]
+    return out
+
+
+def run_secondary(args, dev):
+    """Short runs of the other BASELINE configs (>= args.secondary_seconds of timed steps each), same process, rank 0 of an N=1 run.
+    A failing entry records its error instead of taking the headline line down with it."""
+    import dataclasses
+    from cvc import synth
+    secs = args.secondary_seconds
+    out = []
+
+    def attempt(name, fn):
+        t0 = time.perf_counter()
+        try:
+            e = fn()
+        except Exception as ex:       # noqa: BLE001 -- recorded, not hidden: the entry says what failed
+            e = {"error": f"{type(ex).__name__}: {ex}"}
+        e["name"] = name
+        e["wall_s"] = round(time.perf_counter() - t0, 2)
+        out.append(e)
+        torch.cuda.empty_cache()
+
+    def decode(cfg, beam, est_ms):
+        d = synth.CONFIGS[cfg]
+        steps = max(3, int(secs * 1e3 / est_ms) + 1)
+        return brief(run_decode(args, d, dev, 0, 1, False, beam, steps, 2, 0.15, False, {}, cfg))
+
+    def train(cfg, est_ms):
+        d = synth.CONFIGS[cfg]
+        steps = max(3, int(secs * 1e3 / est_ms) + 1)
+        return brief(run_train(args, d, dev, 0, 1, steps=steps, warmup=2, min_warm=0.2, cpu_baseline=False, config_name=cfg))
+
+    attempt("cfg3 beam=5 decode", lambda: decode("cfg3", 5, 11.0))
+    attempt("cfg3 cyclical train step (B=64)", lambda: train("cfg3", 25.0))
+    attempt("cfg4 cyclical train step, one GPU's share (B=32 per GPU; the 8-GPU job adds the gradient exchange)", lambda: train("cfg4", 15.0))
+    attempt("cfg5 greedy decode", lambda: decode("cfg5", 1, 19.0))
+    attempt("cfg5 beam=5 decode", lambda: decode("cfg5", 5, 48.0))
+    attempt("once-per-clip encoder (cfg2 size)", lambda: brief(run_encoder(args, synth.CONFIGS["cfg2"], dev, brief=True, steps=8, warmup=2)))
+    return out
+
+
+def main():
+    args = parse()
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if (args.gpus > 1 or args.spawn) and not under_launcher:
+        # N ranks were asked for and nobody started them: do it here, BEFORE anything below touches a GPU
+        raise SystemExit(spawn_ranks(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: n_gpus must be the number of ranks that run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if args.tile_loaders is not None:
+        from cvc import hip as _hip
+        _hip.lib().cvc_tile_gemm_loaders(int(args.tile_loaders))
+    if args.lstm_blocks is not None:
+        from cvc import hip as _hip
+        _hip.lib().cvc_packed_lstm_wg_blocks(int(args.lstm_blocks))
+    # under a launcher (RANK set) the process group is always initialised, also for a single rank, so that the
+    # barrier / max-over-ranks path is the same code at every N
+    dist_on = under_launcher
+    ranks_joined = 1
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        one = torch.ones(1, device=dev, dtype=torch.float64)
+        dist.all_reduce(one)                                # every rank that joined adds 1: the count RCCL itself reports
+        ranks_joined = int(round(float(one.item())))
+        if ranks_joined != args.gpus or dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: {ranks_joined} rank(s) joined the process group, --gpus asked for {args.gpus}")
+
+    import dataclasses
+    from cvc import synth
+    from cvc import hip
+    hip.lib()
+
+    d = synth.CONFIGS[args.config]
+    over = {k: getattr(args, k) for k in ("B", "N", "F", "R", "A", "E", "V", "T") if getattr(args, k) is not None}
+    if over:
+        d = dataclasses.replace(d, **over)
+    line = None
+    if args.mode == "encoder":
+        if rank == 0:
+            line = run_encoder(args, d, dev)
+    elif args.mode == "train":
+        line = run_train(args, d, dev, rank, world)
+    else:
+        line = run_decode(args, d, dev, rank, world, dist_on, args.beam, args.steps, args.warmup, args.min_warm_seconds, True, over, args.config)
+        default_run = (args.config == "cfg2" and not over and args.beam == 1 and world == 1 and not args.no_secondary and
+                       args.gsk is None and args.embgate is None and args.gate_ksplit is None and not args.no_graph)
+        if rank == 0 and default_run:
+            t0 = time.perf_counter()
+            line["secondary"] = run_secondary(args, dev)
+            line["secondary_wall_s"] = round(time.perf_counter() - t0, 1)
     if rank == 0:
-        line = {
-            "metric": f"caption decode-steps/sec (BxT) at N={d.N},D={d.R}", "value": round(value, 1), "unit": "decode-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: greedy caption decode" if args.beam == 1 else f"{args.config}: beam={args.beam} caption decode",
-                       "B_per_gpu": d.B, "N": d.N, "F": d.F, "D": d.R, "A": d.A, "E": d.E, "V": d.V, "T": d.T, "beam": args.beam,
-                       "hip_graph": not args.no_graph, "parallelism": f"clips sharded over {world} rank(s), no collective",
-                       "gemm_arithmetic": ("f32 in / f32 accumulate; products = exact 3-way bf16 split of both operands, 6 leading "
-                                           "cross terms on the bf16 MFMA (error vs f64 <= the f32-MFMA path's, tests/test_gpu_parity.py)")
-                       if ((eng.packed and gemm_mode > 0) or getattr(eng, "tile", False)) else "f32 MFMA",
-                       "engine_path": "packed" if eng.packed else ("tile" if getattr(eng, "tile", False) else "ring")},
-            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
-        }
-        if cpu:
-            line["gpu_over_cpu"] = round(value / cpu["value"], 1)
+        line["ranks_joined"] = ranks_joined
         print(json.dumps(line), flush=True)
     if dist_on:
         import torch.distributed as dist

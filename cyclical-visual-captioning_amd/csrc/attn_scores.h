@@ -2,6 +2,7 @@
 // the same streaming dot product) and the grounder (captioner.py:154-158).  See attn_fwd.hip.
 #pragma once
 #include "cvc_common.h"
+#include "gsk.h"
 #include <type_traits>
 
 namespace {
@@ -24,6 +25,8 @@ struct ScoreArgs {
     float inv_temp;
     int nq, A;                     // nq = queries handled by this launch
     int nq_total, q0;              // row = clip * nq_total + q0 + qi
+    int q_from_slab;               // the query is the sum of a stream-K group's partial tiles (gsk.h) instead of q / q_nparts
+    GskSegs q_slab;
 };
 
 // QG = queries per group: the group's accumulators are independent chains for the VALU and its LDS reads / wave reductions are
@@ -50,7 +53,15 @@ __global__ __launch_bounds__(SCORE_WG) void attn_scores_kernel(ScoreArgs a) {
 
     for (int i = tid * 4; i < nq_pad * A; i += SCORE_WG * 4) {
         f32x4 v = {0, 0, 0, 0};
-        if (i < nq * A) {
+        if (i < nq * A && a.q_from_slab) {
+            // column block col / 32 of the h2attn group: tile = blk / 8, its segments summed in order; row = the query's batch row
+            const int col = i % A, row = clip * a.nq_total + a.q0 + i / A, blk = col >> 5;
+            const int nseg = gsk_nseg(a.q_slab, blk >> 3);
+            const float* src = gsk_part(a.q_slab, blk >> 3, 0, blk & 7) + (size_t)row * 32 + (col & 31);
+            v = ld4(src);
+            for (int p = 1; p < nseg; ++p) v += ld4(src + (size_t)p * (8 * 2048));
+            if (a.q_bias != nullptr) v += ld4(a.q_bias + col);
+        } else if (i < nq * A) {
             const float* src = a.q + ((size_t)clip * a.nq_total + a.q0) * A + i;
             v = ld4(src);
             for (int p = 1; p < a.q_nparts; ++p) v += ld4(src + (size_t)p * a.q_part_stride);
@@ -209,7 +220,7 @@ int launch_scores(const ScoreArgs& a, dim3 grid, size_t lds, hipStream_t st) {
 // a clip (plus alpha_net's weight) fit 64 KB of LDS.
 inline int run_scores(int kind, const float* q, const float* w_a, const float* b_a, float inv_temp,
                       const cvc_attn_set* sets, int nsets, int nclip, int nq, int A, hipStream_t st,
-                      int q_nparts = 1, const float* q_bias = nullptr) {
+                      int q_nparts = 1, const float* q_bias = nullptr, const GskSegs* q_slab = nullptr) {
     int q_per_launch = (int)((64 * 1024) / ((size_t)A * 4)) - 1;
     if (q_per_launch < 1) return CVC_E_TOOBIG;
     if (q_per_launch > nq) q_per_launch = nq;
@@ -224,6 +235,8 @@ inline int run_scores(int kind, const float* q, const float* w_a, const float* b
     const int chunks1 = nsets > 1 ? (sets[1].n + ROWS_PER_WG - 1) / ROWS_PER_WG : 0;
     sa.q = q; sa.w_a = w_a; sa.b_a = b_a; sa.inv_temp = inv_temp; sa.A = A; sa.nq_total = nq;
     sa.q_nparts = q_nparts < 1 ? 1 : q_nparts; sa.q_bias = q_bias; sa.q_part_stride = (long long)nclip * nq * A;
+    sa.q_from_slab = q_slab != nullptr;
+    sa.q_slab = q_slab != nullptr ? *q_slab : GskSegs{};
     dim3 g1(sa.chunks0 + chunks1, nclip);
     for (int q0 = 0; q0 < nq; q0 += q_per_launch) {
         sa.q0 = q0;

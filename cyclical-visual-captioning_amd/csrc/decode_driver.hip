@@ -7,9 +7,15 @@
 #include <stdint.h>
 #include "../../include/cvc_hip.h"
 
+// stream-K launch shapes of the packed path (include/cvc_hip.h, "Grouped stream-K form"): host arithmetic done once per plan
+struct gsk_launch {
+    int U;
+    int unit0[2], maxseg[2];
+};
 struct cvc_decode_plan {
     cvc_decode_desc d;
     int launches;
+    gsk_launch ga, go, gl;      // {att-early, logits}, {logits}, {lang-early, h2attn}
 };
 
 namespace {
@@ -83,6 +89,101 @@ int run_packed(cvc_decode_plan* p, hipStream_t st) {
     return 0;
 }
 
+// ---- packed path, embedding-gate schedule: the embedded word's share of the att-LSTM gates is a row of a per-checkpoint table
+// (cvc_packed_lstm_embgate_fwd); XA = [h_lang | h_att], K = 2R; word selection writes only the word (no embedded-word buffer)
+int run_packed_eg(cvc_decode_plan* p, hipStream_t st) {
+    const cvc_decode_desc& d = p->d;
+    const int rows = d.B, R = d.R, A = d.A, V = d.V;
+    const size_t qbytes = (size_t)64 * 4 * sizeof(float);
+    int n = 0;
+    CVC_TRY(reset(d.xa[0], nullptr, (size_t)(2 * R / 4) * qbytes, st));
+    CVC_TRY(reset(d.xl[0], nullptr, (size_t)(3 * R / 4) * qbytes, st));
+    CVC_TRY(reset(d.ca[0], nullptr, (size_t)(R / 4) * qbytes, st));
+    CVC_TRY(reset(d.cl[0], nullptr, (size_t)(R / 4) * qbytes, st));
+    CVC_TRY(reset(d.words, nullptr, (size_t)rows * sizeof(int64_t), st));
+    cvc_gemm_seg seg{d.fc, nullptr, d.w_fc, R, R, d.ld_w_fc, 0};
+    CVC_TRY(cvc_linear_fwd(&seg, 1, d.b_ih_att, d.b_hh_att, rows, 4 * R, d.gate_fc, 4 * R, st));
+    for (int t = 0; t < d.T; ++t) {
+        const int rd = t & 1, wr = (t + 1) & 1;
+        float *XA_r = d.xa[rd], *XA_w = d.xa[wr], *XL_r = d.xl[rd], *XL_w = d.xl[wr];
+        CVC_TRY(cvc_packed_lstm_embgate_fwd((const float*)d.w_att, XA_r, 2 * R, nullptr, nullptr, d.gate_fc, d.emb_gate,
+                                            d.words + (size_t)t * rows, d.ca[rd], rows, R, quad_off(XL_r, R), quad_off(XA_w, R),
+                                            d.ca[wr], st));
+        CVC_TRY(cvc_packed_linear_fwd((const float*)d.w_h, quad_off(XL_r, R), R, nullptr, rows, A, d.qsplit, d.q_parts, A, nullptr, st));
+        cvc_attn_set sets[2];
+        attn_sets(d, t, rows, sets);
+        CVC_TRY(cvc_attn_scores_qparts(d.attn_kind, d.q_parts, d.qsplit, d.b_h, d.w_a, d.b_a, d.inv_temp, sets, 2, d.B, 1, A, st));
+        CVC_TRY(cvc_attn_wsum_quad(sets, 2, d.B, 1, R, XL_r, st));
+        CVC_TRY(cvc_packed_lstm_fwd((const float*)d.w_lang, XL_r, 3 * R, d.b_ih_lang, d.b_hh_lang, nullptr, d.cl[rd], rows, R, XA_w,
+                                    quad_off(XL_w, 2 * R), d.cl[wr], st));
+        CVC_TRY(cvc_packed_linear_fwd((const float*)d.w_o, XA_w, R, d.b_o, rows, V, 1, nullptr, V, d.top2_part, st));
+        CVC_TRY(cvc_top2_final(d.top2_part, (V + 31) / 32, rows, d.unk_idx, d.words + (size_t)(t + 1) * rows, 1,
+                               d.logprob ? d.logprob + (size_t)t * rows : nullptr, nullptr, 0, nullptr, 0, st));
+    }
+    p->launches = n;
+    return 0;
+}
+
+// ---- packed path, grouped stream-K schedule (7 launches per step, every one of them chip-filling):
+//   att-late    : W_att[:, emb] x relu(Emb[word]) + partial tiles of (h_lang, h_att) from the previous step's launch 6 + hoisted fc
+//                 term, cell update -> h_att(t)
+//   stream-K    : lang-early (h_att(t), h_lang(t-1))  ||  h2attn (h_att(t))
+//   scores      : query summed from the h2attn partial tiles
+//   weighted sum
+//   lang-late   : W_lang[:, ctx] x ctx + partial tiles of launch 2 + biases, cell update -> h_lang(t)
+//   stream-K    : att-early of step t+1 (h_lang(t), h_att(t))  ||  vocabulary logits (h_lang(t))
+//   word select : logits summed from the partial tiles, top-2 / UNK rule, next step's embedded word
+int run_packed_gsk(cvc_decode_plan* p, hipStream_t st) {
+    const cvc_decode_desc& d = p->d;
+    const int rows = d.B, R = d.R, E = d.E, A = d.A, V = d.V;
+    const size_t qbytes = (size_t)64 * 4 * sizeof(float);
+    int n = 0;
+    CVC_TRY(reset(d.xa[0], d.xa0_init, (size_t)((2 * R + E) / 4) * qbytes, st));
+    CVC_TRY(reset(d.xl[0], nullptr, (size_t)(3 * R / 4) * qbytes, st));
+    CVC_TRY(reset(d.ca[0], nullptr, (size_t)(R / 4) * qbytes, st));
+    CVC_TRY(reset(d.cl[0], nullptr, (size_t)(R / 4) * qbytes, st));
+    CVC_TRY(reset(d.words, nullptr, (size_t)rows * sizeof(int64_t), st));
+    cvc_gemm_seg seg{d.fc, nullptr, d.w_fc, R, R, d.ld_w_fc, 0};
+    CVC_TRY(cvc_linear_fwd(&seg, 1, d.b_ih_att, d.b_hh_att, rows, 4 * R, d.gate_fc, 4 * R, st));
+    const long long ws_att = (long long)((2 * R + E) / 4) * 128, ws_lang = (long long)(3 * R / 4) * 128, ws_r = (long long)(R / 4) * 128;
+    const float* w_att = (const float*)d.w_att;
+    const float* w_lang = (const float*)d.w_lang;
+    const int nblk_v = (V + 31) / 32;
+    const cvc_gsk_segs seg_att{d.slab_att, p->ga.unit0[0], 2 * R / 32, p->ga.U, p->ga.maxseg[0]};
+    const cvc_gsk_segs seg_o_a{d.slab_o, p->ga.unit0[1], R / 32, p->ga.U, p->ga.maxseg[1]};
+    const cvc_gsk_segs seg_o_o{d.slab_o, 0, R / 32, p->go.U, p->go.maxseg[0]};
+    const cvc_gsk_segs seg_lang{d.slab_lang, p->gl.unit0[0], 2 * R / 32, p->gl.U, p->gl.maxseg[0]};
+    const cvc_gsk_segs seg_q{d.slab_q, p->gl.unit0[1], R / 32, p->gl.U, p->gl.maxseg[1]};
+    for (int t = 0; t < d.T; ++t) {
+        const int rd = t & 1, wr = (t + 1) & 1;
+        float *XA_r = d.xa[rd], *XA_w = d.xa[wr], *XL_r = d.xl[rd], *XL_w = d.xl[wr];
+        // step 0 starts from the zero state: the early K range contributes nothing
+        CVC_TRY(cvc_packed_lstm_late_fwd(w_att + (size_t)(R / 4) * 128, ws_att, quad_off(XA_r, R), E, nullptr, nullptr, d.gate_fc,
+                                         d.ca[rd], rows, R, quad_off(XL_r, R), quad_off(XA_w, R + E), d.ca[wr],
+                                         t == 0 ? nullptr : &seg_att, st));
+        cvc_gsk_group gl[2] = {
+            {w_lang, ws_lang, XL_r, R / 8, 2 * R / 32, 0, R / 32, d.slab_lang, p->gl.maxseg[0]},
+            {(const float*)d.w_h, ws_r, quad_off(XL_r, R), A / 32, R / 32, 0, 0, d.slab_q, p->gl.maxseg[1]}};
+        CVC_TRY(cvc_gsk_gemm(gl, 2, p->gl.U, st));
+        cvc_attn_set sets[2];
+        attn_sets(d, t, rows, sets);
+        CVC_TRY(cvc_attn_scores_qslab(d.attn_kind, &seg_q, d.b_h, d.w_a, d.b_a, d.inv_temp, sets, 2, d.B, 1, A, st));
+        CVC_TRY(cvc_attn_wsum_quad(sets, 2, d.B, 1, R, XL_r, st));
+        CVC_TRY(cvc_packed_lstm_late_fwd(w_lang, ws_lang, XL_r, R, d.b_ih_lang, d.b_hh_lang, nullptr, d.cl[rd], rows, R, XA_w,
+                                         quad_off(XL_w, 2 * R), d.cl[wr], &seg_lang, st));
+        const bool last = t + 1 == d.T;
+        cvc_gsk_group ga[2] = {
+            {w_att, ws_att, XA_w, R / 8, 2 * R / 32, R / 32, E / 32, d.slab_att, p->ga.maxseg[0]},
+            {(const float*)d.w_o, ws_r, XA_w, nblk_v, R / 32, 0, 0, d.slab_o, last ? p->go.maxseg[0] : p->ga.maxseg[1]}};
+        if (last) CVC_TRY(cvc_gsk_gemm(ga + 1, 1, p->go.U, st));        // no next step: the vocabulary projection alone
+        else CVC_TRY(cvc_gsk_gemm(ga, 2, p->ga.U, st));
+        CVC_TRY(cvc_top2_slab(last ? &seg_o_o : &seg_o_a, d.b_o, V, rows, d.unk_idx, d.words + (size_t)(t + 1) * rows, 1,
+                              d.logprob ? d.logprob + (size_t)t * rows : nullptr, d.embed, E, quad_off(XA_w, R), 0, st));
+    }
+    p->launches = n;
+    return 0;
+}
+
 // ---- tile path: beam search or more than 64 rows (12 launches per step)
 int run_tile(cvc_decode_plan* p, hipStream_t st) {
     const cvc_decode_desc& d = p->d;
@@ -149,8 +250,10 @@ int validate(const cvc_decode_desc& d) {
     if (d.path == 0) {
         if (d.beam != 1 || d.B > 64 || (d.R & 31) || (d.E & 31) || (d.A & 31) || d.qsplit < 1) return CVC_E_BADARG;
         if (!d.w_fc || !d.top2_part || !d.xa[0] || !d.xa[1] || !d.xl[0] || !d.xl[1] || !d.ca[0] || !d.ca[1] || !d.cl[0] || !d.cl[1] ||
-            !d.xa0_init)
+            (!d.xa0_init && !d.emb_gate))
             return CVC_E_BADARG;
+        if (d.emb_gate != nullptr && d.gsk_nwg > 0) return CVC_E_BADARG;
+        if (d.gsk_nwg < 0 || (d.gsk_nwg > 0 && ((d.R & 63) || !d.slab_att || !d.slab_lang || !d.slab_q || !d.slab_o))) return CVC_E_BADARG;
     } else if (d.path == 1) {
         if ((d.R & 15) || (d.E & 15) || d.ks_gate < 1 || d.ks_q < 1 || d.ks_o < 1 || d.ks_fc < 1) return CVC_E_BADARG;
         if (!d.w_fc_frag || !d.xaf || !d.xlf || !d.xhf || !d.xff || !d.parts_gate || !d.parts_o || !d.parts_fc || !d.logits || !d.q ||
@@ -173,6 +276,15 @@ extern "C" int cvc_decode_plan_create(const cvc_decode_desc* desc, cvc_decode_pl
     if (!p) return CVC_E_BADARG;
     p->d = *desc;
     p->launches = 0;
+    if (desc->path == 0 && desc->gsk_nwg > 0) {
+        const int R = desc->R, nt_r = R / 64, nt_v = ((desc->V + 31) / 32 + 7) / 8, nt_a = (desc->A / 32 + 7) / 8;
+        const int nta[2] = {nt_r, nt_v}, nca[2] = {2 * R / 32, R / 32};
+        const int ntl[2] = {nt_r, nt_a};
+        rc = cvc_gsk_plan(nta, nca, 2, desc->gsk_nwg, &p->ga.U, p->ga.unit0, p->ga.maxseg);
+        if (!rc) rc = cvc_gsk_plan(nta + 1, nca + 1, 1, desc->gsk_nwg, &p->go.U, p->go.unit0, p->go.maxseg);
+        if (!rc) rc = cvc_gsk_plan(ntl, nca, 2, desc->gsk_nwg, &p->gl.U, p->gl.unit0, p->gl.maxseg);
+        if (rc) { delete p; return rc; }
+    }
     *plan = p;
     return 0;
 }
@@ -190,7 +302,11 @@ extern "C" int cvc_decode_num_launches(const cvc_decode_plan* plan) { return pla
 
 extern "C" int cvc_decode_greedy(cvc_decode_plan* plan, cvc_stream_t stream) {
     if (!plan || plan->d.beam != 1) return CVC_E_BADARG;
-    return plan->d.path == 0 ? run_packed(plan, (hipStream_t)stream) : run_tile(plan, (hipStream_t)stream);
+    if (plan->d.path == 0) {
+        if (plan->d.emb_gate != nullptr) return run_packed_eg(plan, (hipStream_t)stream);
+        return plan->d.gsk_nwg > 0 ? run_packed_gsk(plan, (hipStream_t)stream) : run_packed(plan, (hipStream_t)stream);
+    }
+    return run_tile(plan, (hipStream_t)stream);
 }
 
 extern "C" int cvc_decode_beam(cvc_decode_plan* plan, cvc_stream_t stream) {

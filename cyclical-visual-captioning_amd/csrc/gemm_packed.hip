@@ -1,6 +1,7 @@
 // Packed GEMM of the decode engine (split out of gemm_skinny.hip; the row-major kernels live there).
 #include "cvc_common.h"
 #include "gemm_split.h"
+#include "gsk.h"
 
 // ==========================================================================================
 // Packed path for the decode engine: both MFMA operands are stored fragment-native in HBM, so a
@@ -52,6 +53,15 @@ struct PackedArgs {
     long long gru_gi_ld;
     float* gru_y[2];          // this step's output rows of direction d: row m at + m * gru_y_ld, H columns
     long long gru_y_ld;
+    // embedding-gate table (cvc_packed_lstm_embgate_fwd): the embedded word's share of the gates is a row gather, not a GEMM
+    const float* emb_gate;    // [V][R/8][32] = W_ih[:, emb columns] x relu(Emb[v]) in packed gate-row order, or null
+    const int64_t* word;      // [M] the word of every batch row
+    // word selection fused into the vocabulary projection (cvc_packed_linear_select_fwd): the last workgroup to arrive merges the
+    // per-block top-2 records of all rows
+    unsigned* sel_counter;    // one word of device memory, zero between launches
+    int64_t* sel_word; int sel_word_stride; float* sel_logprob; int sel_unk;
+    long long wstride;        // floats between consecutive 32-row blocks of wp (0: dense, nquad * 128)
+    GskSegs early;            // SLAB form (cvc_packed_lstm_late_fwd): partial tiles of the K range a stream-K launch already covered
 };
 
 #ifndef CVC_LIN_W_NT
@@ -81,9 +91,13 @@ __device__ __forceinline__ float sum_partials(const float* red, int row, int ldm
 // NB = 2: waves w and w + NW/2 take the SAME K chunks for two different blocks, on the same SIMD and in lock step, so the
 // second request for an activation line is served by the CU's L1 (or merged with the pending miss): L2 activation reads per
 // launch halve (402 -> 201 MB for the lang cell), with half as many workgroups.
-template <int MT, bool LSTM, int DEPTH, bool SPLIT, int NW, bool GRU = false, int NB = 1>
+// SLAB (LSTM decode form, 8 waves): this launch covers only the LATE K range of the cell; the partial tiles of the rest, produced
+// earlier by the grouped stream-K kernel (gemm_gsk.hip), are summed in segment order and join the cross-wave reduction as a
+// ninth partial.
+template <int MT, bool LSTM, int DEPTH, bool SPLIT, int NW, bool GRU = false, int NB = 1, bool SLAB = false>
 __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs a) {
     static_assert(!GRU || LSTM, "the GRU step shares the LSTM form's work split");
+    static_assert(!SLAB || (LSTM && !GRU && NB == 1 && NW == 8), "slab sum: LSTM decode form, 8 waves, one block per workgroup");
     static_assert(NB == 1 || (LSTM && !GRU && NW == 8 && NB == 2), "two blocks per workgroup: LSTM form, 8 waves");
     constexpr int NWK = NW / NB;                               // waves that split K for one block
     if constexpr (GRU) {                                       // direction of this workgroup
@@ -95,7 +109,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
     }
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     constexpr int LDM = MT * 32 + 1;
-    __shared__ float red[NW * 32 * LDM + NW * 64 * 6];
+    __shared__ float red[(NW + (SLAB ? 1 : 0)) * 32 * LDM + NW * 64 * 6];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, kh = lane >> 5;
@@ -110,7 +124,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
     const int wblk = NB == 1 ? 0 : wave / NWK, kw = NB == 1 ? wave : wave % NWK;       // this wave's block and K slot
     const int n_my = nchunk > kw ? (nchunk - kw + NWK - 1) / NWK : 0;     // chunks c0 + kw + NWK*j
     // per-lane bases: quad q of this block lives at wp + ((blk * nquad + q) * 32 + i) * 4
-    const float* wl = a.wp + ((size_t)((int)blockIdx.x * NB + wblk) * a.nquad * 32 + i) * 4 + (size_t)(c0 + kw) * 8 * 128 + kh * 4 * 128;
+    const float* wl = a.wp + (size_t)((int)blockIdx.x * NB + wblk) * a.wstride + (size_t)i * 4 + (size_t)(c0 + kw) * 8 * 128 + kh * 4 * 128;
     const float* xl = a.xq + (size_t)i * 4 + (size_t)(c0 + kw) * 8 * 256 + kh * 4 * 256;
     constexpr size_t WSTEP = (size_t)NWK * 8 * 128, XSTEP = (size_t)NWK * 8 * 256;   // floats per wave-chunk step
 #ifndef CVC_ROT_MUL
@@ -146,6 +160,20 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
             for (int mt = 0; mt < MT; ++mt) f.x[mt][q] = ld4(x + q * 256 + mt * 128);
         }
     };
+
+    // embedding-gate form: the table row of this thread's epilogue work item (batch row tid & 63, hidden quad (tid >> 6) & 1) is
+    // requested before the K loop -- word, then 4 x 16 bytes of a row that nobody else touches (HBM latency): left to the epilogue
+    // it was 4 us of exposed round trips per launch
+    f32x4 eadd4[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    if constexpr (LSTM && !GRU) {
+        if (a.emb_gate != nullptr && tid < NB * 2 * 64) {
+            const int em0 = tid & 63;
+            const long long eword = a.word[em0 < a.M ? em0 : a.M - 1];
+            const float* trow = a.emb_gate + (size_t)eword * 4 * a.R + (size_t)((int)blockIdx.x * NB + (tid >> 7)) * 32 + ((tid >> 6) & 1) * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) eadd4[g] = ld4(trow + g * 8);
+        }
+    }
 
     f32x16 acc[MT];
 #pragma unroll
@@ -249,6 +277,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
     const size_t eqoff = ((size_t)(ejq / 4) * 64 + em) * 4;
     f32x4 ecp = {0, 0, 0, 0}, eadd[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     f32x4 eadd2[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, eadd3[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+
     if (GRU && ework) {
         // eadd: r, z: x-projection + both biases; n: x-projection + b_in; [3]: b_hn (multiplied by r with the h-projection)
         const float* gi = a.gru_gi[blockIdx.y] + (size_t)em * a.gru_gi_ld + ejq;
@@ -277,6 +306,20 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
         }
     }
 
+    // SLAB: this block's early partial tiles, 16 bytes per thread and segment (row m = tid >> 3, gate rows 4 (tid & 7) ..+3);
+    // unconditional loads of a clamped segment index, summed in segment order below
+    constexpr int SLAB_MAXS = 10;
+    f32x4 sv[SLAB ? SLAB_MAXS : 1];
+    int s_nseg = 0;
+    const float* s_p0 = nullptr;
+    if constexpr (SLAB) {
+        const int tile = (int)blockIdx.x >> 3, j = (int)blockIdx.x & 7;
+        s_nseg = gsk_nseg(a.early, tile);
+        s_p0 = gsk_part(a.early, tile, 0, j) + (size_t)tid * 4;          // float4 #tid of the [64 rows][32 gate rows] tile: coalesced
+#pragma unroll
+        for (int s = 0; s < SLAB_MAXS; ++s) sv[s] = ld4(s_p0 + (size_t)(s < s_nseg ? s : s_nseg - 1) * (8 * 2048));
+    }
+
     // linear variant with the fused top-2 epilogue: the biases of the columns this wave scans, requested here too
     constexpr int ECPW = 32 / NW;
     float ebias[ECPW];
@@ -294,6 +337,16 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
             const int row = (r & 3) + 8 * (r >> 2) + 4 * kh;
             red[(wave * 32 + row) * LDM + mt * 32 + i] = acc[mt][r];
         }
+    if constexpr (SLAB) {
+        f32x4 t = sv[0];
+#pragma unroll
+        for (int s = 1; s < SLAB_MAXS; ++s) t += s < s_nseg ? sv[s] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = SLAB_MAXS; s < s_nseg; ++s) t += ld4(s_p0 + (size_t)s * (8 * 2048));          // (more segments than the unrolled part)
+        if ((tid >> 3) < MT * 32) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[(NW * 32 + (tid & 7) * 4 + e) * LDM + (tid >> 3)] = t[e];
+        }
+    }
     __syncthreads();
 
     if constexpr (GRU) {
@@ -318,13 +371,17 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
         if (ework) {
             f32x4 hv, cv, gv[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) eadd[g] = (eadd[g] + eadd2[g]) + eadd3[g];      // (an absent term is an exact zero)
+            for (int g = 0; g < 4; ++g) eadd[g] = ((eadd[g] + eadd2[g]) + eadd3[g]) + eadd4[g];      // (an absent term is an exact zero)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int jj = eqd * 4 + e;
                 float pre[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) pre[g] = sum_partials<NWK>(ered, g * 8 + jj, LDM, em) + eadd[g][e];
+                for (int g = 0; g < 4; ++g) {
+                    float sp = sum_partials<NWK>(ered, g * 8 + jj, LDM, em);
+                    if constexpr (SLAB) sp += red[(NW * 32 + g * 8 + jj) * LDM + em];
+                    pre[g] = sp + eadd[g][e];
+                }
                 const float ig = fast_sigmoid(pre[0]), fg = fast_sigmoid(pre[1]);
                 const float gg = fast_tanh(pre[2]), og = fast_sigmoid(pre[3]);
                 const float c2 = fg * ecp[e] + ig * gg;
@@ -390,7 +447,77 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
                     mx = nm;
                 }
                 float* rec = a.top2_part + ((size_t)blockIdx.x * 64 + lane) * 6;
-                rec[0] = v1; rec[1] = __int_as_float(i1); rec[2] = v2; rec[3] = __int_as_float(i2); rec[4] = mx; rec[5] = se;
+                if (a.sel_counter != nullptr) {
+                    // write-through (sc1) stores: the merging workgroup may run on another XCD (cdna guide, Guideline 16 R1)
+                    const float r6[6] = {v1, __int_as_float(i1), v2, __int_as_float(i2), mx, se};
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) __hip_atomic_store(rec + k, r6[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    rec[0] = v1; rec[1] = __int_as_float(i1); rec[2] = v2; rec[3] = __int_as_float(i2); rec[4] = mx; rec[5] = se;
+                }
+            }
+            if (a.sel_counter != nullptr) {
+                // ---- word selection (captioner.py:415-422, 437) by the LAST workgroup to arrive: every record it reads was written
+                // in this launch and never read before in it, so no cache can hold a stale copy; the counter goes back to zero
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                int* flag = reinterpret_cast<int*>(scratch);
+                if (tid == 0) {
+                    const unsigned old = __hip_atomic_fetch_add(a.sel_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool last = old == gridDim.x - 1;
+                    if (last) {
+                        __hip_atomic_store(a.sel_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    }
+                    flag[0] = last ? 1 : 0;
+                }
+                __syncthreads();
+                if (flag[0] == 0) return;
+                __syncthreads();                                          // (flag read by everyone before scratch is reused)
+                // thread (row m = lane, slice w = wave): records w, w + NW, ... merged in index order; then the NW slices per row
+                const int nb = (int)gridDim.x;
+                float t1 = -__builtin_inff(), t2 = -__builtin_inff(), gm = -__builtin_inff(), gs = 0.f;
+                int j1 = 0x7fffffff, j2 = 0x7fffffff;
+                auto better = [](float va, int ia, float vb, int ib) { return (va > vb) | ((va == vb) & (ia < ib)); };
+                auto merge1 = [&](float u1, int k1, float u2, int k2, float um, float us) {
+                    if (better(u1, k1, t1, j1)) {
+                        if (better(t1, j1, u2, k2)) { t2 = t1; j2 = j1; } else { t2 = u2; j2 = k2; }
+                        t1 = u1; j1 = k1;
+                    } else if (better(u1, k1, t2, j2)) { t2 = u1; j2 = k1; }
+                    const float nm = fmaxf(gm, um);
+                    gs = (nm == -__builtin_inff()) ? 0.f : gs * __expf(gm - nm) + us * __expf(um - nm);
+                    gm = nm;
+                };
+                const int mrow = lane < M ? lane : M - 1;
+                // the records were stored write-through: every read is a round trip to memory, so a batch of them is requested
+                // before the first merge (unconditional loads of a clamped index; one record at a time this tail took 20 us)
+                constexpr int RB = 8;
+                for (int b0 = wave; b0 < nb; b0 += NW * RB) {
+                    f32x2 r0[RB], r1[RB], r2[RB];
+#pragma unroll
+                    for (int k = 0; k < RB; ++k) {
+                        const int b = b0 + k * NW;
+                        const f32x2* q2 = reinterpret_cast<const f32x2*>(a.top2_part + ((size_t)(b < nb ? b : nb - 1) * 64 + mrow) * 6);
+                        r0[k] = q2[0]; r1[k] = q2[1]; r2[k] = q2[2];
+                    }
+#pragma unroll
+                    for (int k = 0; k < RB; ++k)
+                        if (b0 + k * NW < nb) merge1(r0[k].x, __float_as_int(r0[k].y), r1[k].x, __float_as_int(r1[k].y), r2[k].x, r2[k].y);
+                }
+                float* r8 = scratch + ((size_t)wave * 64 + lane) * 6;
+                r8[0] = t1; r8[1] = __int_as_float(j1); r8[2] = t2; r8[3] = __int_as_float(j2); r8[4] = gm; r8[5] = gs;
+                __syncthreads();
+                if (wave == 0 && lane < M) {
+                    for (int w = 1; w < NW; ++w) {
+                        const float* q4 = scratch + ((size_t)w * 64 + lane) * 6;
+                        merge1(q4[0], __float_as_int(q4[1]), q4[2], __float_as_int(q4[3]), q4[4], q4[5]);
+                    }
+                    const bool use2 = (j1 == a.sel_unk) && j2 != 0x7fffffff;          // captioner.py:417-421
+                    int wsel = use2 ? j2 : j1;
+                    if (wsel == 0x7fffffff || wsel < 0) wsel = 0;                      // all-NaN logits (see top2_final_kernel)
+                    a.sel_word[(size_t)lane * a.sel_word_stride] = wsel;
+                    if (a.sel_logprob != nullptr) a.sel_logprob[lane] = (use2 ? t2 : t1) - (gm + __logf(gs));
+                }
             }
         }
     }
@@ -415,8 +542,10 @@ extern "C" int cvc_packed_lstm_wg_blocks(int n) {
 }
 
 template <bool LSTM>
-static int launch_packed(const PackedArgs& a, int blocks, hipStream_t st) {
+static int launch_packed(const PackedArgs& a_in, int blocks, hipStream_t st) {
+    PackedArgs a = a_in;
     if (a.M < 1 || a.M > 64 || (a.nquad & 7) || a.nquad < 8) return CVC_E_BADARG;
+    if (a.wstride == 0) a.wstride = (long long)a.nquad * 128;
     const dim3 grid(blocks, LSTM || a.ksplit < 1 ? 1 : a.ksplit);
     if constexpr (LSTM) {
         // decode form, 64-row workgroups (two blocks each): halves the L2 activation reads
@@ -447,6 +576,44 @@ extern "C" int cvc_packed_lstm_fwd(const float* wp, const float* xq, int K, cons
     a.bias = b_ih; a.bias2 = b_hh; a.gate_bias = gate_bias; a.c_prev_q = c_prev_q; a.c_out_q = c_out_q;
     a.h_dst1_q = h_dst1_q; a.h_dst2_q = h_dst2_q; a.ksplit = 1;
     return launch_packed<true>(a, R / 8, (hipStream_t)stream);
+}
+
+extern "C" int cvc_packed_lstm_embgate_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
+                                           const float* gate_bias, const float* emb_gate, const int64_t* word,
+                                           const float* c_prev_q, int M, int R, float* h_dst1_q, float* h_dst2_q,
+                                           float* c_out_q, cvc_stream_t stream) {
+    if (!wp || !xq || !c_prev_q || !c_out_q || !emb_gate || !word || (K & 31) || R < 8 || (R & 7)) return CVC_E_BADARG;
+    PackedArgs a{};
+    a.wp = wp; a.xq = xq; a.nquad = K / 4; a.M = M; a.Nout = 4 * R; a.R = R;
+    a.bias = b_ih; a.bias2 = b_hh; a.gate_bias = gate_bias; a.c_prev_q = c_prev_q; a.c_out_q = c_out_q;
+    a.h_dst1_q = h_dst1_q; a.h_dst2_q = h_dst2_q; a.ksplit = 1; a.emb_gate = emb_gate; a.word = word;
+    return launch_packed<true>(a, R / 8, (hipStream_t)stream);
+}
+
+extern "C" int cvc_packed_lstm_late_fwd(const float* wp, long long w_blk_stride, const float* xq, int K, const float* b_ih,
+                                        const float* b_hh, const float* gate_bias, const float* c_prev_q, int M, int R,
+                                        float* h_dst1_q, float* h_dst2_q, float* c_out_q, const cvc_gsk_segs* early,
+                                        cvc_stream_t stream) {
+    if (!wp || !xq || !c_prev_q || !c_out_q || (K & 31) || K < 32 || R < 8 || (R & 7) || M < 1 || M > 64 ||
+        w_blk_stride < (long long)(K / 4) * 128 || (w_blk_stride & 3))
+        return CVC_E_BADARG;
+    if (cvc_gemm_split_mode != 2) return CVC_E_BADARG;                  // the stream-K schedule is built on the 8-wave split form
+    PackedArgs a{};
+    a.wp = wp; a.xq = xq; a.nquad = K / 4; a.M = M; a.Nout = 4 * R; a.R = R; a.wstride = w_blk_stride;
+    a.bias = b_ih; a.bias2 = b_hh; a.gate_bias = gate_bias; a.c_prev_q = c_prev_q; a.c_out_q = c_out_q;
+    a.h_dst1_q = h_dst1_q; a.h_dst2_q = h_dst2_q; a.ksplit = 1;
+    const dim3 grid(R / 8);
+    hipStream_t st = (hipStream_t)stream;
+    if (early != nullptr) {
+        if (!early->slab || early->nchunk < 1 || early->U < 1 || early->maxseg < 1 || early->unit0 < 0 || (R & 63)) return CVC_E_BADARG;
+        a.early = *early;
+        if (M <= 32) hipLaunchKernelGGL((skinny_gemm_packed_kernel<1, true, CVC_PACKED_DEPTH8, true, 8, false, 1, true>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, true, CVC_PACKED_DEPTH8, true, 8, false, 1, true>), grid, dim3(512), 0, st, a);
+    } else {
+        if (M <= 32) hipLaunchKernelGGL((skinny_gemm_packed_kernel<1, true, CVC_PACKED_DEPTH8, true, 8>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, true, CVC_PACKED_DEPTH8, true, 8>), grid, dim3(512), 0, st, a);
+    }
+    return cvc_launch_status();
 }
 
 extern "C" int cvc_packed_lstm_train_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
@@ -483,6 +650,7 @@ extern "C" int cvc_gru_seq_fwd(const float* wp, const float* gi, long long gi_ld
     a.nquad = Kp / 4; a.M = M; a.Nout = 4 * H; a.R = H; a.bias = b_ih; a.bias2 = b_hh; a.ksplit = 1;
     a.wp = wp; a.gru_w_stride = (long long)(H / 8) * (Kp / 4) * 128; a.gru_h_stride = hsz;
     a.gru_gi_ld = gi_ld_m; a.gru_y_ld = y_ld_m;
+    a.wstride = (long long)a.nquad * 128;
     const dim3 grid(H / 8, ndir);
     for (int s = 0; s < F; ++s) {
         a.xq = hq + (size_t)(s & 1) * hsz * ndir;
@@ -588,6 +756,17 @@ extern "C" int cvc_pack_quad_segs(const float* const* xs, const long long* ldx, 
     a.nseg = nseg; a.M = M; a.xq = xq;
     hipLaunchKernelGGL(pack_quad_segs_kernel, dim3((q * 64 + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
     return cvc_launch_status();
+}
+
+extern "C" int cvc_packed_linear_select_fwd(const float* wp, const float* xq, int K, const float* bias, int M, int Nout,
+                                            float* top2_part, unsigned* counter, int unk_idx, int64_t* word, int word_stride,
+                                            float* logprob, cvc_stream_t stream) {
+    if (!wp || !xq || (K & 31) || Nout < 2 || !top2_part || !counter || !word || word_stride < 1 || M < 1 || M > 64) return CVC_E_BADARG;
+    PackedArgs a{};
+    a.wp = wp; a.xq = xq; a.nquad = K / 4; a.M = M; a.Nout = Nout; a.R = 0;
+    a.bias = bias; a.ksplit = 1; a.top2_part = top2_part;
+    a.sel_counter = counter; a.sel_unk = unk_idx; a.sel_word = word; a.sel_word_stride = word_stride; a.sel_logprob = logprob;
+    return launch_packed<false>(a, (Nout + 31) / 32, (hipStream_t)stream);
 }
 
 extern "C" int cvc_packed_linear_fwd(const float* wp, const float* xq, int K, const float* bias, int M, int Nout,

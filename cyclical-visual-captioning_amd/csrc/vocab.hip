@@ -5,6 +5,7 @@
 // All of it is small elementwise / row-reduction work next to the streaming kernels; the
 // point is to keep it on the device and inside the captured decode graph.
 #include "cvc_common.h"
+#include "gsk.h"
 #include <math.h>
 
 namespace {
@@ -214,6 +215,93 @@ __global__ __launch_bounds__(WG) void top2_final_kernel(const float* part, int n
         int w = use2 ? t.i2 : t.i1;
         if (w == 0x7fffffff || w < 0) w = 0;               // all-NaN logits: no record ever compared greater; the word is
                                                            // also a gather address (table + w * E) here and next step
+        word[(size_t)row * wstride] = w;
+        if (logprob != nullptr) logprob[row] = (use2 ? t.v2 : t.v1) - (mx + logf(se));
+        chosen = w;
+    }
+    if (emb_out != nullptr) {
+        __syncthreads();
+        const float* src = table + (size_t)chosen * E;
+        for (int e = threadIdx.x * 4; e < E; e += WG * 4) {
+            f32x4 v = ld4(src + e);
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            if (emb_ld > 0) st4(emb_out + (size_t)row * emb_ld + e, v);
+            else st4(emb_out + ((size_t)(e >> 2) * 64 + row) * 4, v);       // emb_ld == 0: quad layout [E/4][64][4]
+        }
+    }
+}
+
+// Word selection straight from the partial tiles of a stream-K vocabulary GEMM (gemm_gsk.hip): one workgroup per batch row sums
+// the segments of its 32-column blocks (+ bias), takes top-2 / max / sum-exp over the row and finishes like top2_final_kernel.
+// ITEMS float4 items per thread (item = 4 columns of one block), every segment load of every item requested before the first
+// sum: the kernel is one round trip to the slabs, not ITEMS x segments of them.
+template <int ITEMS>
+__global__ __launch_bounds__(WG) void top2_slab_kernel(GskSegs g, const float* bias, int V, int unk, int64_t* word, int wstride,
+                                                       float* logprob, const float* table, int E, float* emb_out, int emb_ld) {
+    __shared__ float red[4];
+    __shared__ Top2 tred[4];
+    __shared__ int chosen;
+    constexpr int MAXS = 6;
+    const int row = blockIdx.x;
+    const int nitem = ((V + 31) >> 5) * 8;
+    f32x4 sv[ITEMS][MAXS], bv[ITEMS];
+    int nseg[ITEMS], col0[ITEMS];
+    const float* p0[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const int it = min((int)threadIdx.x + k * WG, nitem - 1);          // past the end: re-read the last item (masked below)
+        const int blk = it >> 3, rq = it & 7;
+        nseg[k] = gsk_nseg(g, blk >> 3);
+        col0[k] = (int)threadIdx.x + k * WG < nitem ? blk * 32 + rq * 4 : V;
+        p0[k] = gsk_part(g, blk >> 3, 0, blk & 7) + (size_t)row * 32 + rq * 4;
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s) sv[k][s] = ld4(p0[k] + (size_t)(s < nseg[k] ? s : nseg[k] - 1) * (8 * 2048));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bv[k][e] = (bias != nullptr && col0[k] + e < V) ? bias[col0[k] + e] : 0.f;
+    }
+    Top2 t{-INFINITY, 0x7fffffff, -INFINITY, 0x7fffffff};
+    float mx = -INFINITY;
+    f32x4 val[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        f32x4 x = sv[k][0];
+#pragma unroll
+        for (int s = 1; s < MAXS; ++s) x += s < nseg[k] ? sv[k][s] : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = MAXS; s < nseg[k]; ++s) x += ld4(p0[k] + (size_t)s * (8 * 2048));
+        x += bv[k];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int v = col0[k] + e;
+            const float xv = v < V ? x[e] : -INFINITY;
+            val[k][e] = xv;
+            if (v < V) {
+                if (better(xv, v, t.v1, t.i1)) { t.v2 = t.v1; t.i2 = t.i1; t.v1 = xv; t.i1 = v; }
+                else if (better(xv, v, t.v2, t.i2)) { t.v2 = xv; t.i2 = v; }
+                mx = fmaxf(mx, xv);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        Top2 u;
+        u.v1 = __shfl_xor(t.v1, o, 64); u.i1 = __shfl_xor(t.i1, o, 64);
+        u.v2 = __shfl_xor(t.v2, o, 64); u.i2 = __shfl_xor(t.i2, o, 64);
+        t = merge(t, u);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) tred[wave] = t;
+    mx = block_max(mx, red);                       // (contains the barriers that publish tred)
+    t = merge(merge(tred[0], tred[1]), merge(tred[2], tred[3]));
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) se += val[k][e] == -INFINITY ? 0.f : expf(val[k][e] - mx);
+    se = block_sum(se, red);
+    if (threadIdx.x == 0) {
+        const bool use2 = (t.i1 == unk) && t.i2 != 0x7fffffff;          // captioner.py:417-421
+        int w = use2 ? t.i2 : t.i1;
+        if (w == 0x7fffffff || w < 0) w = 0;               // all-NaN logits: see top2_final_kernel
         word[(size_t)row * wstride] = w;
         if (logprob != nullptr) logprob[row] = (use2 ? t.v2 : t.v1) - (mx + logf(se));
         chosen = w;
@@ -604,6 +692,26 @@ extern "C" int cvc_top2_final(const float* part, int nblocks, int M, int unk_idx
     if (emb_out != nullptr && (!table || E < 4 || (E & 3) || (emb_ld & 3) || (emb_ld != 0 && emb_ld < E))) return CVC_E_BADARG;
     hipLaunchKernelGGL(top2_final_kernel, dim3(M), dim3(WG), 0, (hipStream_t)stream, part, nblocks, unk_idx, word, word_stride,
                        logprob, table, E, emb_out, emb_ld);
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_top2_slab(const cvc_gsk_segs* logits, const float* bias, int V, int M, int unk_idx, int64_t* word,
+                             int word_stride, float* logprob, const float* table, int E, float* emb_out, int emb_ld,
+                             cvc_stream_t stream) {
+    if (!logits || !logits->slab || logits->nchunk < 1 || logits->U < 1 || logits->maxseg < 1 || logits->unit0 < 0 || !word || V < 2 ||
+        M < 1 || M > 64 || word_stride < 1)
+        return CVC_E_BADARG;
+    if (emb_out != nullptr && (!table || E < 4 || (E & 3) || (emb_ld & 3) || (emb_ld != 0 && emb_ld < E))) return CVC_E_BADARG;
+    const int nitem = ((V + 31) / 32) * 8;
+    hipStream_t st = (hipStream_t)stream;
+    if (nitem <= 5 * WG)
+        hipLaunchKernelGGL(top2_slab_kernel<5>, dim3(M), dim3(WG), 0, st, *logits, bias, V, unk_idx, word, word_stride, logprob, table, E,
+                           emb_out, emb_ld);
+    else if (nitem <= 8 * WG)
+        hipLaunchKernelGGL(top2_slab_kernel<8>, dim3(M), dim3(WG), 0, st, *logits, bias, V, unk_idx, word, word_stride, logprob, table, E,
+                           emb_out, emb_ld);
+    else
+        return CVC_E_TOOBIG;
     return cvc_launch_status();
 }
 

@@ -8,6 +8,10 @@ Per step (7 launches, nothing returns to the host, no allocation):
   lang-LSTM : concat-GEMM over [ctx_regions + ctx_frames | h_att] + h_lang(t-1), fused cell update
   logits    : W_o h_lang + b_o
   word      : top-2 with UNK suppression (greedy) or beam selection + state gather
+Greedy with <= 64 rows and R % 64 == 0 runs the same arithmetic as the grouped stream-K schedule (csrc/gemm_gsk.hip,
+csrc/decode_driver.hip::run_packed_gsk): the K ranges of a gate GEMM that do not depend on the step's critical path (h_lang,
+h_att) are multiplied one launch early, in the same balanced launch as the small GEMM of that moment (logits / h2attn), and
+the late launch (embedded word / attended context) sums their partial tiles -- still 7 launches per step.
 The whole loop can be captured once into a HIP graph (torch.cuda.CUDAGraph) and replayed.
 Dropout is inactive (model.eval(), trainer.py:158).  State buffers ping-pong so that no kernel
 writes a tensor another workgroup of the same launch still reads.
@@ -80,6 +84,24 @@ def pack_weights(w: torch.Tensor, lstm_R: Optional[int] = None, pad_quads: int =
         padded[:, :k // 4] = out
         return padded
     return out.contiguous()
+
+
+def lstm_packed_rows(R: int, device) -> torch.Tensor:
+    """checkpoint row of every packed gate row: packed row 32 b + i is row (i >> 3) * R + 8 b + (i & 7) of a [4R, K] gate matrix"""
+    i = torch.arange(32, device=device)
+    return (((i >> 3) * R + (i & 7)).view(1, 32) + (torch.arange(R // 8, device=device) * 8).view(-1, 1)).reshape(-1)
+
+
+EMBGATE_MAX_BYTES = 1 << 30      # largest embedding-gate table the engine builds on its own (cfg2: 164 MB, cfg5: 328 MB)
+
+
+def embgate_table(W: "DecodeWeights") -> torch.Tensor:
+    """[V, 4R] table of cvc_packed_lstm_embgate_fwd: row v = W_ih_att[:, emb columns] x relu(Emb[v]) (the xt segment of
+    decoder_core.py:45-48 with xt = embed(it), captioner.py:53-68 in eval mode), gate rows in packed block order.  One dense
+    product per checkpoint binding on the tile GEMM (split products, fp32-grade) -- no library GEMM."""
+    R, E = W.R, W.E
+    w_emb = W.w_ih_att[:, 2 * R:2 * R + E][lstm_packed_rows(R, W.embed.device)].contiguous()          # [4R (packed order), E]
+    return hip.tile_mm(torch.relu(W.embed), w_emb)                                                   # [V, 4R]
 
 
 def to_quad(x: torch.Tensor) -> torch.Tensor:
@@ -174,9 +196,13 @@ class DecodeEngine:
 
     def __init__(self, weights: DecodeWeights, feats: Dict[str, torch.Tensor], T: int, unk_idx: int, beam: int = 1,
                  inv_temp: float = 1.0, own_features: bool = False, path: str = "auto", gate_ksplit: Optional[bool] = None,
-                 driver: bool = True):
+                 driver: bool = True, gsk: Optional[bool] = None, embgate: Optional[bool] = None):
         """driver: enqueue the decode through the C-ABI drivers cvc_decode_greedy / cvc_decode_beam (one host call per decode);
         False walks the launch list in Python (one ctypes call per kernel; tests compare the two).
+        embgate: packed path only -- the embedding-gate schedule (the embedded word's share of the att-LSTM gates is a row of
+        a per-checkpoint table: 34 MB less to stream per step at config 2, and the gate GEMM no longer waits for the word).  None = on when the table fits EMBGATE_MAX_BYTES; tests compare on / off.
+        gsk: packed path only -- True selects the grouped stream-K schedule (csrc/gemm_gsk.hip; measured slower than the
+        embedding-gate schedule, kept selectable and tested; needs R % 64 == 0, split-product arithmetic).
         path: "auto" picks packed (greedy, <= 64 rows) / tile (> 64 rows or beams) / ring (odd widths); "ring" forces the
         row-major fallback kernels (tests compare the paths).
         own_features: keep private copies of the clip features, so that the bound launch list (and a captured HIP
@@ -244,6 +270,14 @@ class DecodeEngine:
         self.gate_ksplit = GATE_KSPLIT_DEFAULT if gate_ksplit is None else gate_ksplit
         self.gate_fused = self.gate_ksplit == "fused"
         self.gate_ksplit = bool(self.gate_ksplit)
+        gsk_ok = self.packed and R % 64 == 0 and not self.gate_ksplit and hip.gemm_packed_split(-1) == 2
+        if gsk and not gsk_ok:
+            raise RuntimeError("DecodeEngine: the stream-K schedule needs the packed path, R % 64 == 0 and cvc_gemm_packed_split(2)")
+        self.gsk = False if gsk is None else bool(gsk)
+        eg_ok = self.packed and not self.gsk and not self.gate_ksplit
+        if embgate and not eg_ok:
+            raise RuntimeError("DecodeEngine: the embedding-gate schedule needs the packed path without gsk / gate_ksplit")
+        self.embgate = (eg_ok and 4 * V * 4 * R <= EMBGATE_MAX_BYTES) if embgate is None else bool(embgate)
         # more than 64 live rows (beam search, big greedy batches): bf16-fragment tile GEMMs (csrc/gemm_tile.hip)
         self.tile = (not self.packed) and (self.beam > 1 or rows > 64) and R % 16 == 0 and W.E % 16 == 0 and path != "ring"
         self._plan = None
@@ -286,6 +320,13 @@ class DecodeEngine:
                 arr = getattr(d, name)
                 arr[0], arr[1] = ptr(bufs[0]), ptr(bufs[1])
             d.xa0_init = ptr(self.XA0_init)
+            if self.embgate:
+                d.w_att = ptr(W.p_att2)
+                d.emb_gate, d.sel_counter = ptr(W.t_embgate), ptr(self.sel_counter)
+            if self.gsk:
+                d.gsk_nwg = self.gsk_nwg
+                d.slab_att, d.slab_lang, d.slab_q, d.slab_o = (ptr(self.slab_att), ptr(self.slab_lang), ptr(self.slab_q),
+                                                              ptr(self.slab_o))
         else:
             d.path = 1
             d.ks_gate, d.ks_q, d.ks_o, d.ks_fc = self.ks_gate, self.ks_q, self.ks_o, self.ks_fc
@@ -330,12 +371,18 @@ class DecodeEngine:
             W.p_lang = pack_weights(torch.cat([W.w_ih_lang, W.w_hh_lang], 1), R)
             W.p_h = pack_weights(W.w_h)
             W.p_o = pack_weights(W.w_o)
+        if self.embgate and not hasattr(W, "p_att2"):
+            W.p_att2 = pack_weights(torch.cat([W.w_ih_att[:, 0:R], W.w_hh_att], 1), R)        # K = 2R: [h_lang | h_att]
+            W.t_embgate = embgate_table(W)
         zq = lambda k: torch.zeros(k // 4, 64, 4, device=dev, dtype=torch.float32)
-        self.XA, self.XL = [zq(2 * R + E), zq(2 * R + E)], [zq(3 * R), zq(3 * R)]
+        ka = 2 * R if self.embgate else 2 * R + E
+        self.XA, self.XL = [zq(ka), zq(ka)], [zq(3 * R), zq(3 * R)]
+        self.sel_counter = torch.zeros(4, device=dev, dtype=torch.int32)
         self.cA, self.cL = [zq(R), zq(R)], [zq(R), zq(R)]
         bos = torch.relu(W.embed[0]).view(1, E).expand(self.rows, E).contiguous()
-        self.XA0_init = zq(2 * R + E)
-        self.XA0_init[R // 4:(R + E) // 4] = to_quad(bos)
+        self.XA0_init = zq(ka)
+        if not self.embgate:
+            self.XA0_init[R // 4:(R + E) // 4] = to_quad(bos)
         L = hip.lib()
         self.ks_att = int(L.cvc_packed_lstm_ks_slices(2 * R + E, R)) if self.gate_ksplit else 0
         self.ks_lang = int(L.cvc_packed_lstm_ks_slices(3 * R, R)) if self.gate_ksplit else 0
@@ -346,6 +393,19 @@ class DecodeEngine:
         if self.ks_att or self.ks_lang:
             self.gate_slab = torch.empty(max(self.ks_att, self.ks_lang) * (R // 8) * 2048, device=dev, dtype=torch.float32)
             self.gate_counters = torch.zeros(R // 64, device=dev, dtype=torch.int32)
+        if self.gsk:
+            # launch shapes of the stream-K schedule (host arithmetic, same call the C driver makes) and the partial-tile slabs
+            A, V = W.A, W.V
+            self.gsk_nwg = int(torch.cuda.get_device_properties(dev).multi_processor_count)
+            nt_r, nt_v, nt_a = R // 64, ((V + 31) // 32 + 7) // 8, (A // 32 + 7) // 8
+            self.plan_a = hip.gsk_plan([nt_r, nt_v], [2 * R // 32, R // 32], self.gsk_nwg)     # att-early || logits
+            self.plan_o = hip.gsk_plan([nt_v], [R // 32], self.gsk_nwg)                        # logits alone (last step)
+            self.plan_l = hip.gsk_plan([nt_r, nt_a], [2 * R // 32, R // 32], self.gsk_nwg)     # lang-early || h2attn
+            slab = lambda ntile, maxseg: torch.zeros(ntile * maxseg * 16384, device=dev, dtype=torch.float32)
+            self.slab_att = slab(nt_r, self.plan_a["maxseg"][0])
+            self.slab_o = slab(nt_v, max(self.plan_a["maxseg"][1], self.plan_o["maxseg"][0]))
+            self.slab_lang = slab(nt_r, self.plan_l["maxseg"][0])
+            self.slab_q = slab(nt_a, self.plan_l["maxseg"][1])
 
     def _build_packed(self):
         L, W = hip.lib(), self.W
@@ -359,6 +419,10 @@ class DecodeEngine:
                                                   4 * R)))
         self._keep.append(seg_fc)
         nblk_v = (V + 31) // 32
+        if self.gsk:
+            return out + self._build_gsk_steps()
+        if self.embgate:
+            return out + self._build_embgate_steps()
         for t in range(self.T):
             rd, wr = t & 1, (t + 1) & 1
             XA_r, XA_w, XL_r, XL_w = self.XA[rd], self.XA[wr], self.XL[rd], self.XL[wr]
@@ -405,6 +469,98 @@ class DecodeEngine:
             out.append(("word_select", L.cvc_top2_final, (ptr(self.top2_part), nblk_v, rows, self.unk, ptr(self.words[t + 1]), 1,
                                                           ptr(self.logprob[t]), ptr(W.embed), E, qoff(XA_w, R), 0)))
             self._keep.append(sets)
+        return out
+
+    def _build_embgate_steps(self):
+        """The T steps of the embedding-gate schedule (the launch list csrc/decode_driver.hip::run_packed_eg enqueues)."""
+        L, W = hip.lib(), self.W
+        B, N, Fr, R, A, V, rows = self.B, self.N, self.F, W.R, W.A, W.V, self.rows
+        fc, conv, pconv, pool, ppool = self.feats
+        ptr = lambda t: None if t is None else t.data_ptr()
+        qoff = lambda buf, k0: buf.data_ptr() + (k0 // 4) * 64 * 4 * 4
+        out = []
+        for t in range(self.T):
+            rd, wr = t & 1, (t + 1) & 1
+            XA_r, XA_w, XL_r, XL_w = self.XA[rd], self.XA[wr], self.XL[rd], self.XL[wr]
+            out.append(("att_lstm", L.cvc_packed_lstm_embgate_fwd, (ptr(W.p_att2), ptr(XA_r), 2 * R, None, None, ptr(self.gate_fc),
+                                                                    ptr(W.t_embgate), ptr(self.words[t]), ptr(self.cA[rd]), rows, R,
+                                                                    qoff(XL_r, R), qoff(XA_w, R), ptr(self.cA[wr]))))
+            out.append(("h2attn", L.cvc_packed_linear_fwd, (ptr(W.p_h), qoff(XL_r, R), R, None, rows, A, self.QSPLIT,
+                                                            ptr(self.q_parts), A, None)))
+            sets = (hip.AttnSet * 2)()
+            sets[0] = hip.AttnSet(ptr(ppool), ptr(pool), ptr(self.mask), None, ptr(self.scores_r), None,
+                                  ptr(self.att_steps[t]), None, N, self.stream_r)
+            sets[1] = hip.AttnSet(ptr(pconv), ptr(conv), None, None, ptr(self.scores_f), None, ptr(self.attn_f), None, Fr,
+                                  self.stream_f)
+            out.append(("attn_scores", L.cvc_attn_scores_qparts, (W.kind, ptr(self.q_parts), self.QSPLIT, ptr(W.b_h), ptr(W.w_a),
+                                                                  ptr(W.b_a), self.inv_temp, sets, 2, B, 1, A)))
+            out.append(("attn_wsum", L.cvc_attn_wsum_quad, (sets, 2, B, 1, R, ptr(XL_r))))
+            out.append(("lang_lstm", L.cvc_packed_lstm_fwd, (ptr(W.p_lang), ptr(XL_r), 3 * R, ptr(W.b_ih_lang), ptr(W.b_hh_lang),
+                                                             None, ptr(self.cL[rd]), rows, R, ptr(XA_w), qoff(XL_w, 2 * R),
+                                                             ptr(self.cL[wr]))))
+            # (cvc_packed_linear_select_fwd, the one-launch form whose last workgroup merges the records, measured 34.9 us against
+            # 20.0 + 7.4 us for these two launches: atomics, fence and a serial merge on one CU cost more than a launch boundary)
+            out.append(("logits", L.cvc_packed_linear_fwd, (ptr(W.p_o), ptr(XA_w), R, ptr(W.b_o), rows, V, 1, None, V,
+                                                            ptr(self.top2_part))))
+            out.append(("word_select", L.cvc_top2_final, (ptr(self.top2_part), (V + 31) // 32, rows, self.unk, ptr(self.words[t + 1]), 1,
+                                                          ptr(self.logprob[t]), None, 0, None, 0)))
+            self._keep.append(sets)
+        return out
+
+    def _build_gsk_steps(self):
+        """The T steps of the grouped stream-K schedule (the launch list csrc/decode_driver.hip::run_packed_gsk enqueues)."""
+        L, W = hip.lib(), self.W
+        B, N, Fr, R, A, E, V, rows = self.B, self.N, self.F, W.R, W.A, W.E, W.V, self.rows
+        fc, conv, pconv, pool, ppool = self.feats
+        ptr = lambda t: None if t is None else t.data_ptr()
+        qoff = lambda buf, k0: buf.data_ptr() + (k0 // 4) * 64 * 4 * 4
+        ws_att, ws_lang, ws_r = (2 * R + E) // 4 * 128, 3 * R // 4 * 128, R // 4 * 128
+        pa, po, pl = self.plan_a, self.plan_o, self.plan_l
+        segs = lambda slab, plan, g, nchunk: hip.GskSegs(ptr(slab), plan["unit0"][g], nchunk, plan["U"], plan["maxseg"][g])
+        seg_att, seg_o_a = segs(self.slab_att, pa, 0, 2 * R // 32), segs(self.slab_o, pa, 1, R // 32)
+        seg_o_o = segs(self.slab_o, po, 0, R // 32)
+        seg_lang, seg_q = segs(self.slab_lang, pl, 0, 2 * R // 32), segs(self.slab_q, pl, 1, R // 32)
+        self._keep += [seg_att, seg_o_a, seg_o_o, seg_lang, seg_q]
+        byref = C.byref
+        out = []
+        for t in range(self.T):
+            rd, wr = t & 1, (t + 1) & 1
+            XA_r, XA_w, XL_r, XL_w = self.XA[rd], self.XA[wr], self.XL[rd], self.XL[wr]
+            out.append(("att_late", L.cvc_packed_lstm_late_fwd, (ptr(W.p_att) + (R // 4) * 128 * 4, ws_att, qoff(XA_r, R), E, None, None,
+                                                                 ptr(self.gate_fc), ptr(self.cA[rd]), rows, R, qoff(XL_r, R),
+                                                                 qoff(XA_w, R + E), ptr(self.cA[wr]),
+                                                                 None if t == 0 else byref(seg_att))))
+            gl = (hip.GskGroup * 2)()
+            gl[0] = hip.GskGroup(ptr(W.p_lang), ws_lang, ptr(XL_r), R // 8, 2 * R // 32, 0, R // 32, ptr(self.slab_lang), pl["maxseg"][0])
+            gl[1] = hip.GskGroup(ptr(W.p_h), ws_r, qoff(XL_r, R), A // 32, R // 32, 0, 0, ptr(self.slab_q), pl["maxseg"][1])
+            out.append(("lang_early_h2attn", L.cvc_gsk_gemm, (gl, 2, pl["U"])))
+            sets = (hip.AttnSet * 2)()
+            sets[0] = hip.AttnSet(ptr(ppool), ptr(pool), ptr(self.mask), None, ptr(self.scores_r), None,
+                                  ptr(self.att_steps[t]), None, N, self.stream_r)
+            sets[1] = hip.AttnSet(ptr(pconv), ptr(conv), None, None, ptr(self.scores_f), None, ptr(self.attn_f), None, Fr,
+                                  self.stream_f)
+            out.append(("attn_scores", L.cvc_attn_scores_qslab, (W.kind, byref(seg_q), ptr(W.b_h), ptr(W.w_a), ptr(W.b_a),
+                                                                 self.inv_temp, sets, 2, B, 1, A)))
+            out.append(("attn_wsum", L.cvc_attn_wsum_quad, (sets, 2, B, 1, R, ptr(XL_r))))
+            out.append(("lang_late", L.cvc_packed_lstm_late_fwd, (ptr(W.p_lang), ws_lang, ptr(XL_r), R, ptr(W.b_ih_lang),
+                                                                  ptr(W.b_hh_lang), None, ptr(self.cL[rd]), rows, R, ptr(XA_w),
+                                                                  qoff(XL_w, 2 * R), ptr(self.cL[wr]), byref(seg_lang))))
+            last = t + 1 == self.T
+            ga = (hip.GskGroup * 2)()
+            ga[0] = hip.GskGroup(ptr(W.p_att), ws_att, ptr(XA_w), R // 8, 2 * R // 32, R // 32, E // 32, ptr(self.slab_att), pa["maxseg"][0])
+            ga[1] = hip.GskGroup(ptr(W.p_o), ws_r, ptr(XA_w), (V + 31) // 32, R // 32, 0, 0, ptr(self.slab_o),
+                                 po["maxseg"][0] if last else pa["maxseg"][1])
+            if last:        # no next step: the vocabulary projection alone
+                go = (hip.GskGroup * 1)()
+                go[0] = ga[1]
+                out.append(("att_early_logits", L.cvc_gsk_gemm, (go, 1, po["U"])))
+                self._keep.append(go)
+            else:
+                out.append(("att_early_logits", L.cvc_gsk_gemm, (ga, 2, pa["U"])))
+            out.append(("word_select", L.cvc_top2_slab, (byref(seg_o_o if last else seg_o_a), ptr(W.b_o), V, rows, self.unk,
+                                                         ptr(self.words[t + 1]), 1, ptr(self.logprob[t]), ptr(W.embed), E,
+                                                         qoff(XA_w, R), 0)))
+            self._keep += [sets, gl, ga]
         return out
 
     # ------------------------------------------------------------------ tile path (rows > 64 or beam search)

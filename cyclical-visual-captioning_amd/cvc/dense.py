@@ -17,7 +17,7 @@ MIN_ROWS = 1024          # below this the launch-bound library kernel is as good
 
 def _weight_operand(lin: nn.Linear):
     w = lin.weight
-    stamp = (w.data_ptr(), w._version)
+    stamp = (hip.weights_generation(), w.data_ptr(), w._version)      # generation: updates that leave _version alone (fused Adam)
     ent = getattr(lin, "_cvc_tile_operand", None)      # lives on the module
     if ent is not None and ent[0] == stamp:
         return ent[1]
@@ -53,6 +53,9 @@ def apply(layer: nn.Module, x: torch.Tensor) -> torch.Tensor:
             y = m(y)                                        # ReLU / Dropout as the module has them
         return y
     if not usable(x) or layer.training:
+        if x.is_cuda and ENABLED and x.numel() // max(1, x.shape[-1]) >= MIN_ROWS:
+            hip.warn_once("dense-library", "a dense encoder layer over >= %d rows runs on the library GEMM (%s)" % (
+                MIN_ROWS, "module in train() mode without autograd" if layer.training else f"dtype {x.dtype}"))
         return layer(x)
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])

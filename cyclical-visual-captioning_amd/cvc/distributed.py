@@ -94,8 +94,9 @@ class GradReducer:
       dW GEMM finishes separately), biases ride with their cell's weight_hh.
     * With RCCL ("nccl") a bucket goes as in-place reduce_scatter + all_gather over the xGMI mesh, two calls on the
       communicator's stream issued back to back from the hook; other backends (gloo in the CPU tests) use one all_reduce.
-    * Parameters that never receive a gradient keep an all-zero view: Adam leaves them unchanged,
-      exactly as skipping them does, and no rank-dependent None-ness can desynchronise the message sizes.
+    * Parameters that never receive a gradient are found on the first step (every rank must see the same
+      set: checked) and keep `.grad = None` from then on, as in the reference -- optimizers skip them (no weight decay, no Adam
+      state); their arena slots stay zero, so message sizes never depend on None-ness.
     Expected exposed time at BASELINE config 4 (8 x MI355X, 486 MB of gradients, 7 xGMI links per GPU): the 445 MB that
     complete at t = 0 cost 2 x 7/8 x 445 MB per GPU over 7 links = 0.7 ms at the 153 GB/s link peak, ~2 ms at a third of it,
     against a ~29 ms step; the head's 41 MB overlap the decode loop's BPTT.
@@ -166,7 +167,14 @@ class GradReducer:
         self._work: List = []
         self.exchange = self.world > 1 or (always_exchange and dist.is_initialized())
         self.overlap = overlap and self.exchange
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for b in groups for _, p in b] if self.exchange else []
+        # hooks also without an exchange: the first step learns which parameters ever receive a gradient (see finalize)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for b in groups for _, p in b]
+        self._dead: set = set()                               # ids of parameters that never receive a gradient: .grad stays None
+        self._learned = False
+        self._late_after_launch: List[int] = []
+        from . import functional as _F
+        _F.LATE_GRAD_LISTENERS.append(self._on_late_grad)
+        self._late_listener_owner = _F
 
     # ------------------------------------------------------------------ gradient bookkeeping
     def zero_grad(self):
@@ -175,11 +183,21 @@ class GradReducer:
             a.zero_()
         for b in self.buckets:
             for _, p in b:
+                if id(p) in self._dead:                       # never receives a gradient: None, as in the reference (optimizers skip
+                    continue                                  # it: no weight decay, no Adam state -- trainer.py:118-122, opts.py:109)
                 v = self._views[id(p)]
                 if p.grad is None or p.grad.data_ptr() != v.data_ptr():
                     p.grad = v
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+
+    def _on_late_grad(self, w):
+        """cvc.functional's deferred-dW flush wrote into w.grad at the end of backward (a use of the weight got no gradient): no
+        hook fired for it.  Harmless unless the bucket's exchange was already launched -- then the late add races with / is
+        missing from the collective, and finalize() refuses to continue."""
+        i = self._bucket_of.get(id(w))
+        if i is not None and self.exchange and self._launched[i]:
+            self._late_after_launch.append(i)
 
     def _on_grad(self, p):
         i = self._bucket_of[id(p)]
@@ -188,7 +206,7 @@ class GradReducer:
             v.copy_(p.grad)
             p.grad = v
         self._ready[i] += 1
-        if self._expected is None:
+        if not self._learned:
             self._seen_first[i].add(id(p))
         elif self.overlap and not self._launched[i] and self._ready[i] >= self._expected[i]:
             self._launch(i)
@@ -211,6 +229,10 @@ class GradReducer:
     def finalize(self, average: bool = True):
         """Call after backward(): exchanges what the hooks did not, waits.  average=True leaves every gradient divided by
         the world size; average=False leaves SUMS for clip_() to fold the 1/G into its single multiply."""
+        if self._late_after_launch:
+            late, self._late_after_launch = sorted(set(self._late_after_launch)), []
+            raise RuntimeError(f"GradReducer: a weight gradient was written into bucket(s) {late} after their exchange had been "
+                               "launched (deferred dW flush at the end of backward): run with overlap=False for this graph")
         if self.exchange:
             if self._expected is None:
                 # first step: every rank must expect the same arrivals per bucket (same model, same graph) -- checked once
@@ -231,6 +253,18 @@ class GradReducer:
             if average:
                 for a in self.arenas:
                     a.mul_(1.0 / self.world)
+        if not self._learned:
+            # first step done: parameters that received no gradient keep .grad = None from now on (the reference's optimizers
+            # skip them -- with weight_decay > 0 an all-zero gradient would still decay them and allocate Adam state); their
+            # arena slots stay zero, so the exchanged message sizes are unchanged.  Multi-rank: agreement was checked above.
+            self._learned = True
+            if self._expected is None:
+                self._expected = [len(s) for s in self._seen_first]
+            for i, b in enumerate(self.buckets):
+                for _, p in b:
+                    if id(p) not in self._seen_first[i]:
+                        self._dead.add(id(p))
+                        p.grad = None
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
 
@@ -248,3 +282,6 @@ class GradReducer:
         for h in self._hooks:
             h.remove()
         self._hooks.clear()
+        lst = self._late_listener_owner.LATE_GRAD_LISTENERS
+        if self._on_late_grad in lst:
+            lst.remove(self._on_late_grad)

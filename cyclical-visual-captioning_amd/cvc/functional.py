@@ -76,9 +76,12 @@ class _WeightGradBatcher:
                         w.grad = g
                     else:
                         w.grad.add_(g.view_as(w.grad))       # in place: .grad may be a view into a gradient arena
+                    for fn in LATE_GRAD_LISTENERS:           # (no post-accumulate hook fires for this write: tell whoever
+                        fn(w)                                #  exchanges gradients, cvc.distributed.GradReducer)
         self.uses.clear()
 
 
+LATE_GRAD_LISTENERS = []      # callables(weight): a leftover dW was added to weight.grad at the end of backward, outside AccumulateGrad
 _BATCHER = _WeightGradBatcher()
 
 

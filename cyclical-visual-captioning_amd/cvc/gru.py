@@ -49,6 +49,11 @@ BWD_PERSISTENT = True      # False: always the per-step backward (A/B switch)
 last_bwd_form = None
 
 
+class GruUnavailable(RuntimeError):
+    """The persistent recurrence could not run this call (grid not co-resident, barrier time-out): the caller falls back to the
+    library module (cvc/model/backbone.py) instead of aborting the training run."""
+
+
 def supported(gru: nn.Module, x: torch.Tensor) -> bool:
     """Shapes / modules the inference path takes."""
     return (isinstance(gru, nn.GRU) and gru.batch_first and gru.bias and gru.hidden_size % 8 == 0 and x.dim() == 3
@@ -64,7 +69,8 @@ def _layer_operands(gru: nn.GRU):
     """Per layer: (W_ih of both directions as a tile operand, packed W_hh [ndir][...], b_ih [ndir, 3H], b_hh [ndir, 3H]);
     rebuilt when any parameter changed."""
     params = list(gru.parameters())
-    stamp = tuple((p.data_ptr(), p._version) for p in params)
+    # (the generation covers updates that leave _version alone: fused Adam, graph replays -- hip.bump_weights_generation)
+    stamp = (hip.weights_generation(),) + tuple((p.data_ptr(), p._version) for p in params)
     ent = getattr(gru, "_cvc_gru_pack", None)          # lives on the module (no table keyed by ids / addresses)
     if ent is not None and ent[0] == stamp:
         return ent[1]
@@ -103,7 +109,8 @@ def gru_forward(gru: nn.GRU, x: torch.Tensor) -> torch.Tensor:
             args = (wp.data_ptr(), gi.data_ptr(), ndir * 3 * H, m * ndir * 3 * H, b_ih.data_ptr(), b_hh.data_ptr(), m, F, H, ndir,
                     hq.data_ptr(), y.data_ptr(), ld_m, ld_t)
             done = False
-            if PERSISTENT and H % 128 == 0 and H <= 1024:
+            # (the persistent form reports a barrier time-out through a word the host reads back: not while a graph is captured)
+            if PERSISTENT and H % 128 == 0 and H <= 1024 and not torch.cuda.is_current_stream_capturing():
                 sync = torch.zeros(int(L.cvc_gru_persistent_sync_words()), device=x.device, dtype=torch.int32)
                 slots = torch.empty((F + 1) * ndir * H * 64, device=x.device, dtype=torch.float32)     # one state slot per step
                 pargs = args[:10] + (slots.data_ptr(),) + args[11:]
@@ -136,8 +143,8 @@ class _GruLayer(torch.autograd.Function):
         rc = L.cvc_gru_seq_persistent_train_fwd(wp.data_ptr(), gi.data_ptr(), ndir * 3 * H, m * ndir * 3 * H, b_ih.contiguous().data_ptr(),
                                                 b_hh.contiguous().data_ptr(), m, F, H, ndir, slots.data_ptr(), y.data_ptr(), ndir * H,
                                                 m * ndir * H, gates.data_ptr(), ndir * 4 * H, m * ndir * 4 * H, sync.data_ptr(), st)
-        if rc != 0 or int(sync[4]) != 0:
-            raise RuntimeError("cvc.gru: the persistent recurrence could not run (rc=%d, barrier word=%d)" % (rc, int(sync[4])))
+        if rc != 0 or int(sync[4]) != 0:          # (host sync: this path is not graph-capturable, see backbone.py)
+            raise GruUnavailable("cvc.gru: the persistent recurrence could not run (rc=%d, barrier word=%d)" % (rc, int(sync[4]) if rc == 0 else -1))
         ctx.save_for_backward(x, w_ih, w_hh, gates, y)
         ctx.dims = (m, F, H, ndir)
         return y

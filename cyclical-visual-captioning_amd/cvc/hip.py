@@ -37,6 +37,17 @@ class NNSeg(C.Structure):
 _P, _I, _F, _LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 
 
+class GskGroup(C.Structure):
+    """cvc_gsk_group: one GEMM of a grouped stream-K launch (include/cvc_hip.h, "Grouped stream-K form")."""
+    _fields_ = [("wp", C.c_void_p), ("w_blk_stride", C.c_longlong), ("xq", C.c_void_p), ("nblk", C.c_int), ("nchunk", C.c_int),
+                ("skip_at", C.c_int), ("skip_n", C.c_int), ("slab", C.c_void_p), ("maxseg", C.c_int)]
+
+
+class GskSegs(C.Structure):
+    """cvc_gsk_segs: where a consumer finds one group's partial tiles."""
+    _fields_ = [("slab", C.c_void_p), ("unit0", C.c_int), ("nchunk", C.c_int), ("U", C.c_int), ("maxseg", C.c_int)]
+
+
 class DecodeDesc(C.Structure):
     """cvc_decode_desc of include/cvc_hip.h, field for field (tests/test_cabi.py compares the size with the C compiler's)."""
     _fields_ = (
@@ -54,7 +65,8 @@ class DecodeDesc(C.Structure):
         [(n, C.c_longlong) for n in ("xaf_stride", "xlf_stride", "xhf_stride", "xff_stride")] +
         [(n, C.c_void_p) for n in ("parts_gate", "parts_o", "parts_fc", "logits")] +
         [(n, C.c_void_p) for n in ("h_att", "c_att", "h_lang", "c_lang", "c_att_prev", "c_lang_prev", "zero_state")] +
-        [("beam_ws", C.c_void_p)])
+        [("beam_ws", C.c_void_p)] +
+        [("gsk_nwg", C.c_int)] + [(n, C.c_void_p) for n in ("slab_att", "slab_lang", "slab_q", "slab_o", "emb_gate", "sel_counter")])
 
 # name -> argtypes, exactly the declarations of include/cvc_hip.h (tests/test_cabi.py checks both)
 SIGNATURES = {
@@ -68,6 +80,13 @@ SIGNATURES = {
     "cvc_packed_lstm_fwd": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "cvc_packed_linear_fwd": [_P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P],
     "cvc_packed_lstm_wg_blocks": [_I],
+    "cvc_packed_lstm_embgate_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "cvc_packed_linear_select_fwd": [_P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _I, _P, _P],
+    "cvc_gsk_plan": [C.POINTER(_I), C.POINTER(_I), _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)],
+    "cvc_gsk_gemm": [C.POINTER(GskGroup), _I, _I, _P],
+    "cvc_packed_lstm_late_fwd": [_P, _LL, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, C.POINTER(GskSegs), _P],
+    "cvc_attn_scores_qslab": [_I, C.POINTER(GskSegs), _P, _P, _P, _F, C.POINTER(AttnSet), _I, _I, _I, _I, _P],
+    "cvc_top2_slab": [C.POINTER(GskSegs), _P, _I, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P],
     "cvc_packed_lstm_train_fwd": [_P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     "cvc_pack_lstm_weights": [_P, _I, _P, _I, _I, _P, _P],
     "cvc_pack_quad_segs": [C.POINTER(_P), C.POINTER(_LL), C.POINTER(_I), _I, _I, _P, _P],
@@ -159,6 +178,35 @@ def version() -> str:
     return lib().cvc_version().decode()
 
 
+# --------------------------------------------------------------------------- weights generation
+# Packed copies of parameters (the decode engine's weight packs, the encoder's GRU / dense-layer operands) are keyed on the
+# parameters' (data_ptr, _version).  A fused optimizer kernel and a HIP-graph replay of the training step update parameters
+# WITHOUT bumping _version, so every such cache also carries this process-wide generation; whoever updates weights behind
+# autograd's back bumps it (Trainer after every optimizer step, the captioner's invalidate_decode_cache()).
+_weights_generation = 0
+
+
+def weights_generation() -> int:
+    return _weights_generation
+
+
+_warned = set()
+
+
+def warn_once(key: str, msg: str):
+    """One warning per process and reason: a path that leaves the HIP kernels for a library module says so (and why) once."""
+    if key not in _warned:
+        _warned.add(key)
+        import warnings
+        warnings.warn("cvc: " + msg, RuntimeWarning, stacklevel=3)
+
+
+def bump_weights_generation() -> int:
+    global _weights_generation
+    _weights_generation += 1
+    return _weights_generation
+
+
 # --------------------------------------------------------------------------- per-entry-point HIP-event timing (bench.py)
 _raw_fns = {}
 
@@ -226,6 +274,16 @@ def _mask(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     elif t.dtype != torch.uint8:
         t = (t != 0).contiguous().view(torch.uint8)
     return t.contiguous()
+
+
+def gsk_plan(ntile: Sequence[int], nchunk: Sequence[int], nwg: int) -> dict:
+    """Host arithmetic of a grouped stream-K launch (cvc_gsk_plan): units per workgroup, each group's first unit and the
+    segments per tile its slab must hold."""
+    n = len(ntile)
+    arr = lambda v: (C.c_int * n)(*[int(x) for x in v])
+    U, unit0, maxseg = C.c_int(), (C.c_int * n)(), (C.c_int * n)()
+    _check(lib().cvc_gsk_plan(arr(ntile), arr(nchunk), n, int(nwg), C.byref(U), unit0, maxseg), "cvc_gsk_plan")
+    return dict(U=U.value, unit0=list(unit0), maxseg=list(maxseg), nwg=int(nwg))
 
 
 # --------------------------------------------------------------------------- attention

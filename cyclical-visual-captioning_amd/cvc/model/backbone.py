@@ -3,8 +3,11 @@ side of the hot path.  Mirrors the reference's `RegionalFeatureExtractorGVD`
 (model/backbone.py:12-351): same constructor inputs (`opts` + the four Detectron pickles), same
 `state_dict` keys, same 10-tuple returned to the captioner (backbone.py:350-351).
 
-It runs once per clip (not once per decode step), so it is library work: plain GEMMs (hipBLASLt) and
-the MIOpen GRU, no hand-written kernels.  What differs from the reference's formulation:
+It runs once per clip (not once per decode step).  Its heavy pieces run on the build's own kernels: the 2-layer bidirectional
+frame-context GRU (cvc/gru.py: tile-GEMM input projections + persistent recurrence, inference and autograd) and the dense layers
+over the B*F frame rows / B*N region rows (cvc/dense.py on the tile GEMM); whatever falls outside their range (CPU tensors, an
+nn.LSTM frame encoder, odd widths, a HIP graph under capture) uses the library module and says so once (cvc.hip.warn_once).
+What differs from the reference's formulation:
 
   * the class-similarity logits are one `[DET+1, G] x [B, G, N]` product instead of a product
     against a per-clip expanded copy of the class table (backbone.py:222-233);
@@ -24,7 +27,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import dense, gru as gru_hip
+from .. import dense, hip, gru as gru_hip
 
 HIP_GRU = True     # inference: frame-context GRU on the HIP kernels (cvc/gru.py); False = the library module everywhere
 
@@ -186,6 +189,26 @@ class RegionalFeatureExtractorGVD(nn.Module):
         return (per_caption(fc_feats), segs_feat, per_caption(pool_feats), per_caption(g_pool_feats),
                 per_caption(pnt_mask), per_caption(overlaps), sample_idx_mask, cls_pred, cls_loss)
 
+    def _frame_context(self, x):
+        """The 2-layer bidirectional frame-context RNN (backbone.py:103-106, 335-338): HIP kernels where they apply, else the
+        library module -- and then says why, once."""
+        enc = self.context_enc
+        capturing = x.is_cuda and torch.cuda.is_current_stream_capturing()
+        if HIP_GRU and not torch.is_grad_enabled() and gru_hip.supported(enc, x):
+            return gru_hip.gru_forward(enc, x)                        # inference: persistent / per-step recurrence + tile GEMM
+        if HIP_GRU and torch.is_grad_enabled() and gru_hip.supported_train(enc, x) and not capturing:
+            try:
+                return gru_hip.gru_forward_train(enc, x)              # autograd on the same kernels (cvc_gru_seq_bwd)
+            except gru_hip.GruUnavailable as e:                       # barrier time-out / grid not co-resident: keep training
+                hip.warn_once("gru-train-unavailable", f"frame-context GRU falls back to the library module for this run: {e}")
+        elif x.is_cuda and HIP_GRU:
+            why = ("a HIP graph is being captured (the persistent recurrence reports time-outs through a host read)" if capturing else
+                   f"{type(enc).__name__} / hidden size {enc.hidden_size} is outside the HIP recurrence's range "
+                   "(nn.GRU, batch_first, H % 8 == 0; under autograd H % 128 == 0 and H <= 1024)")
+            hip.warn_once("gru-library:" + why[:24], "frame-context RNN runs on the library module (MIOpen): " + why)
+        enc.flatten_parameters()
+        return enc(x)[0]
+
     def forward(self, segs_feat, proposals, num, mask_boxes, region_feats, gt_boxes, overlaps, sample_idx,
                 eval_obj_ground=False, replicate_feat=True):
         """reference backbone.py:296-351"""
@@ -201,13 +224,7 @@ class RegionalFeatureExtractorGVD(nn.Module):
             rgb, motion = conv_feats[..., :RGB_DIM], conv_feats[..., RGB_DIM:RGB_DIM + MOTION_DIM]
             x = torch.cat((dense.apply(self.att_embed[0], rgb), dense.apply(self.att_embed[1], motion)), dim=2)
             x = self.att_embed_aux(x.transpose(1, 2)).transpose(1, 2).contiguous()      # BatchNorm1d over channels
-            if HIP_GRU and not torch.is_grad_enabled() and gru_hip.supported(self.context_enc, x):
-                x = gru_hip.gru_forward(self.context_enc, x)          # inference: persistent / per-step recurrence + tile GEMM
-            elif HIP_GRU and torch.is_grad_enabled() and gru_hip.supported_train(self.context_enc, x):
-                x = gru_hip.gru_forward_train(self.context_enc, x)    # autograd on the same kernels (cvc_gru_seq_bwd)
-            else:
-                self.context_enc.flatten_parameters()                 # CPU, shapes outside the kernels' range: the library module
-                x = self.context_enc(x)[0]
+            x = self._frame_context(x)
             x = x.masked_fill(sample_idx_mask, 0)
             conv_feats = x if self.seq_per_img == 1 else x.repeat_interleave(self.seq_per_img, dim=0)
             p_conv_feats = dense.apply(self.ctx2att_fc, conv_feats)

@@ -22,6 +22,7 @@ import torch
 import torch.nn as nn
 
 from .. import functional as F_
+from .. import hip
 from ..decode import DecodeEngine, DecodeWeights
 from ..misc import utils
 from .decoder_core import AttenedDecoderCore, TopDownDecoderCore
@@ -260,6 +261,7 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         a HIP-graph replay of the training step, or a fused optimizer kernel (Trainer calls this after every step)."""
         self._decode_cache = None
         self._engine_cache = None
+        hip.bump_weights_generation()            # the encoder's packed GRU / dense operands are keyed on it (cvc/gru.py, cvc/dense.py)
 
     @torch.no_grad()
     def _sample(self, segs_feat, seq, proposals, gt_caption, num, mask_boxes, gt_boxes, region_feats, frm_mask, sample_idx,

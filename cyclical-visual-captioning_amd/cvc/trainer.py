@@ -105,7 +105,10 @@ class Trainer:
         which is what the captioner's cached decode binding watches: drop it explicitly."""
         inval = getattr(self.model, "invalidate_decode_cache", None)
         if inval is not None:
-            inval()
+            inval()                               # (bumps the weights generation as well)
+        else:
+            from . import hip
+            hip.bump_weights_generation()
 
     # ------------------------------------------------------------------ HIP-graph training step
     def _core_step(self, b):

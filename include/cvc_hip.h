@@ -149,6 +149,23 @@ int cvc_packed_lstm_fwd(const float* wp, const float* xq, int K, const float* b_
                         float* h_dst2_q, float* c_out_q, cvc_stream_t stream);
 int cvc_packed_linear_fwd(const float* wp, const float* xq, int K, const float* bias, int M, int Nout,
                           int ksplit, float* y, int ldy, float* top2_part, cvc_stream_t stream);
+/* Embedding-gate table form of the att-LSTM (decoder_core.py:45-50 with xt = relu(Emb[word]), captioner.py:53-68 in eval mode):
+ * the embedded word's share of the gates, W_ih[:, emb columns] x relu(Emb[v]), depends on the word alone, so it is tabulated once
+ * per checkpoint -- emb_gate [V][R/8][32] fp32, gate rows in the packed block order of wp (cvc.decode.embgate_table) -- and the
+ * step adds row word[m] in the epilogue: wp / xq then cover only the recurrent inputs (K = 2R: h_lang, h_att), 20 % fewer weight
+ * bytes per step, and the gate GEMM no longer waits for the word.  Otherwise cvc_packed_lstm_fwd. */
+int cvc_packed_lstm_embgate_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
+                                const float* gate_bias, const float* emb_gate, const int64_t* word, const float* c_prev_q,
+                                int M, int R, float* h_dst1_q, float* h_dst2_q, float* c_out_q, cvc_stream_t stream);
+/* Vocabulary projection + word selection in ONE launch (captioner.py:437 + :415-422): cvc_packed_linear_fwd's top-2 records
+ * (top2_part [ceil(Nout/32)][64][6], stored write-through) are merged by the last workgroup to arrive -- counter: one word of
+ * device memory, zero before the first use, left zero -- which writes word[m * word_stride] (UNK rule, ties -> lowest index) and
+ * logprob[m] (nullable).  Same results as cvc_packed_linear_fwd + cvc_top2_final; measured SLOWER than the two launches at
+ * config 2 (34.9 vs 20.0 + 7.4 us: arrival atomics, the acquire fence and a serial merge on one CU cost more than a launch
+ * boundary), so the decode drivers do not use it.  Kept as a tested entry point. */
+int cvc_packed_linear_select_fwd(const float* wp, const float* xq, int K, const float* bias, int M, int Nout,
+                                 float* top2_part, unsigned* counter, int unk_idx, int64_t* word, int word_stride,
+                                 float* logprob, cvc_stream_t stream);
 /* A/B + test hook: 32-row weight blocks per workgroup of cvc_packed_lstm_fwd (1 = default; 2: two blocks share every
  * activation line through the CU's L1 -- halves the L2 reads, measured 60 % slower because half the CUs then do all the
  * operand splitting; same results up to the fp32 summation order over K).  Returns the previous setting; n < 1 only queries. */
@@ -241,6 +258,55 @@ int cvc_packed_lstm_ks_fwd(const float* wp, const float* xq, int K, const float*
 int cvc_packed_lstm_ksf_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
                             const float* gate_bias, const float* c_prev_q, int M, int R, float* h_dst1_q,
                             float* h_dst2_q, float* c_out_q, float* slab, unsigned* counters, cvc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Grouped stream-K form of the decode step's skinny GEMMs (csrc/gemm_gsk.hip).  The gate GEMM of an LSTM cell
+ * (decoder_core.py:50, 61) is cut along K into an EARLY part -- the K segments whose inputs exist before the step's critical
+ * path reaches the cell (att-LSTM: h_lang(t-1), h_att(t-1); lang-LSTM: h_att(t), h_lang(t-1)) -- and a LATE part (the embedded
+ * word; the attended context).  The early part of the NEXT cell runs in the same launch as the small GEMM that sits on the
+ * critical path at that moment (vocabulary logits, captioner.py:437; h2attn, modules.py:112): one launch = up to three GEMMs
+ * ("groups") that read the same kind of operands, flattened into one space of UNITS (256 weight rows x one 32-k chunk) that is
+ * dealt out evenly, U units per workgroup, so that every CU streams the same number of weight bytes whatever the shapes are.
+ * A workgroup's run of units inside one 256-row tile is a SEGMENT; its partial product goes to the group's slab
+ *     slab[tile][seg][8 blocks][64 rows][32 gate rows]  (fp32),   seg = workgroup - first workgroup of the tile,
+ * and the consumer (cvc_packed_lstm_late_fwd, cvc_attn_scores_qslab, cvc_top2_slab) sums a tile's segments in segment order:
+ * results do not depend on scheduling.  Operand layouts are those of the packed path (wp, xq above); the 32-k activation chunk
+ * is fetched and split into bf16 terms once per workgroup and shared by its 8 waves through LDS. */
+typedef struct cvc_gsk_group {
+    const float* wp;          /* packed weights [nblk][*][32][4], pointing at physical chunk 0 of this GEMM's K space */
+    long long w_blk_stride;   /* floats between consecutive 32-row blocks of wp                                       */
+    const float* xq;          /* quad-layout activations, physical chunk 0                                            */
+    int nblk;                 /* valid 32-row blocks; tiles of 8 blocks (a short last tile is allowed)                */
+    int nchunk;               /* 32-k chunks per tile walked by this launch, indexed v = 0 .. nchunk-1                */
+    int skip_at, skip_n;      /* physical chunk of v: v < skip_at ? v : v + skip_n  (steps over the late K segment)   */
+    float* slab;              /* >= ceil(nblk/8) * maxseg * 16384 floats                                              */
+    int maxseg;               /* segments allocated per tile (cvc_gsk_plan)                                           */
+} cvc_gsk_group;
+typedef struct cvc_gsk_segs { /* what a consumer needs to find and sum one group's partial tiles                       */
+    const float* slab;
+    int unit0;                /* first unit of the group in the launch's unit space                                   */
+    int nchunk;               /* units per tile                                                                       */
+    int U;                    /* units per workgroup                                                                  */
+    int maxseg;
+} cvc_gsk_segs;
+/* Host arithmetic of a launch: ntile[g] tiles of nchunk[g] chunks each -> U (units per workgroup for at most nwg workgroups;
+ * nwg <= 0: one per CU of the current device), unit0[g] and the segments per tile maxseg[g] the slabs must hold. */
+int cvc_gsk_plan(const int* ntile, const int* nchunk, int ngroups, int nwg, int* U, int* unit0, int* maxseg);
+int cvc_gsk_gemm(const cvc_gsk_group* groups, int ngroups, int U, cvc_stream_t stream);   /* ngroups <= 3, M <= 64 rows */
+/* LATE part of a cell + finish: gates = wp[:, K range] x xq (full-K packed kernel, K % 32 == 0) + the early part's partial tiles
+ * (`early` nullable: none, e.g. step 0 from the zero state) + biases; cell update as cvc_packed_lstm_fwd. */
+int cvc_packed_lstm_late_fwd(const float* wp, long long w_blk_stride, const float* xq, int K, const float* b_ih,
+                             const float* b_hh, const float* gate_bias, const float* c_prev_q, int M, int R,
+                             float* h_dst1_q, float* h_dst2_q, float* c_out_q, const cvc_gsk_segs* early,
+                             cvc_stream_t stream);
+/* cvc_attn_scores_qparts with the query given as the partial tiles of a stream-K h2attn group (A / 32 blocks) */
+int cvc_attn_scores_qslab(int kind, const cvc_gsk_segs* q, const float* q_bias, const float* w_a, const float* b_a,
+                          float inv_temp, const cvc_attn_set* sets, int nsets, int nclip, int nq, int A,
+                          cvc_stream_t stream);
+/* cvc_top2_final with the logits given as the partial tiles of a stream-K vocabulary group (ceil(V/32) blocks) + bias [V]:
+ * sums the segments, top-2 with the UNK rule, log-prob, next step's embedded word (captioner.py:415-424, 437).  M <= 64. */
+int cvc_top2_slab(const cvc_gsk_segs* logits, const float* bias, int V, int M, int unk_idx, int64_t* word, int word_stride,
+                  float* logprob, const float* table, int E, float* emb_out, int emb_ld, cvc_stream_t stream);
 
 /* Packed path arithmetic.  mode 2 (default) / 1: every fp32 operand is split exactly into three bf16 terms
  * (v = hi + mid + lo) and each product taken as its six leading cross terms on the bf16 MFMA, fp32
@@ -478,6 +544,18 @@ typedef struct cvc_decode_desc {
     float *parts_gate, *parts_o, *parts_fc, *logits;           /* tile                                                        */
     float *h_att, *c_att, *h_lang, *c_lang, *c_att_prev, *c_lang_prev; const float* zero_state;   /* tile: [rows, R] each     */
     float *beam_ws;                       /* beam: >= 17 * rows floats                                                       */
+    /* packed path, grouped stream-K schedule (gsk_nwg > 0; needs R % 64 == 0): workgroups per stream-K launch (the CU count) and
+     * the four groups' slabs, each >= ceil(nblk / 8) * maxseg * 16384 floats with maxseg from cvc_gsk_plan over the launches
+     * {att-early (R/8 blocks, 2R/32 chunks), logits (ceil(V/32), R/32)}, {logits alone} and {lang-early (R/8, 2R/32), h2attn
+     * (A/32, R/32)}.  gsk_nwg == 0: the one-launch-per-GEMM schedule (cvc_packed_lstm_fwd / cvc_packed_linear_fwd).           */
+    int gsk_nwg;
+    float *slab_att, *slab_lang, *slab_q, *slab_o;
+    /* packed path, embedding-gate schedule (emb_gate != NULL; excludes gsk_nwg > 0): emb_gate = the table of
+     * cvc_packed_lstm_embgate_fwd, w_att = the gate matrix packed over K = 2R (h_lang | h_att), xa = [2R/4][64][4] buffers,
+     * xa0_init is not read; sel_counter is reserved (the one-launch select form, cvc_packed_linear_select_fwd, is not on the
+     * default path: measured slower than two launches).                                                                       */
+    const float* emb_gate;
+    unsigned* sel_counter;
 } cvc_decode_desc;
 typedef struct cvc_decode_plan cvc_decode_plan;
 int cvc_decode_plan_create(const cvc_decode_desc* desc, cvc_decode_plan** plan);   /* validates, copies the descriptor       */

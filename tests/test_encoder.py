@@ -405,3 +405,52 @@ def test_gru_hip_autograd_full_size_vs_library_cpu():
     assert rel(xg.grad.cpu(), want_dx) < 1e-4
     for k, p in gd.named_parameters():
         assert rel(p.grad.cpu(), want[k]) < 1e-4, (k, rel(p.grad.cpu(), want[k]))
+
+
+@pytest.mark.gpu
+def test_encoder_packs_follow_weight_updates_that_bypass_version_counters(tmp_path):
+    """Eval -> optimizer step -> eval: a fused Adam step (and a HIP-graph replay of the training step) changes parameters without
+    touching their _version, which is all the encoder's packed GRU / dense operands used to watch -- every evaluation after the
+    first then ran on the weights of the first.  Trainer._weights_changed / invalidate_decode_cache bump hip.weights_generation(),
+    which is part of the packs' stamps: the second evaluation must match the library modules on the UPDATED weights."""
+    import dataclasses
+    from cvc import dense, hip
+    from cvc.model import backbone
+    from cvc.model.backbone import RegionalFeatureExtractorGVD
+    Dw = dataclasses.replace(D, R=256, A=64, F=9, B=5)
+    tables = synth.detectron_tables(Dw, 4)
+    o = make_opts(Dw, seq_per_img=1, enable_BUTD=False, att_input_mode="both", num_sampled_frm=4, finetune_cnn=False,
+                  att_feat_size=Dw.G, fc_feat_size=synth.SEG_FEAT_DIM, t_attn_size=Dw.F, second_drop_prob=0.3, att_model="topdown",
+                  t_attn_mode="bigru", itod={i + 1: "d%d" % i for i in range(Dw.DET)},
+                  vg_cls=["vg%d" % i for i in range(tables["glove_vg_cls"].shape[0])],
+                  glove_clss=torch.from_numpy(tables["glove_clss"]), glove_vg_cls=torch.from_numpy(tables["glove_vg_cls"]),
+                  detectron_tables=tables, test_mode=True)
+    torch.manual_seed(1)
+    enc = RegionalFeatureExtractorGVD(o).to("cuda:0").eval()
+    inp = to_dev(synth.encoder_inputs(Dw, 4), torch.device("cuda:0"))
+    from cvc.misc import utils
+    overlaps = utils.bbox_overlaps(inp["proposals"], inp["gt_bboxs"], inp["frm_mask"] | inp["pnt_mask_in"][:, 1:].unsqueeze(-1))
+    min_rows, dense.MIN_ROWS = dense.MIN_ROWS, 8
+    try:
+        def evaluate(hip_path):
+            backbone.HIP_GRU, dense.ENABLED = hip_path, hip_path
+            with torch.no_grad():
+                return [x.clone() for x in run_encoder(enc, inp, overlaps)[:6]]
+        first = evaluate(True)
+        # a parameter update of the kind the trainer makes: in place, _version untouched (torch._foreach / fused kernels do this;
+        # here: a raw write through .data, which bypasses the version counter the same way)
+        params = [p for p in enc.parameters() if p.requires_grad]
+        versions = [p._version for p in params]
+        g = torch.Generator(device="cuda:0").manual_seed(5)
+        for p in params:
+            p.data.add_(torch.randn(p.shape, device=p.device, generator=g) * 0.05 * p.data.abs().mean())
+        assert [p._version for p in params] == versions
+        stale = evaluate(True)                                # nobody announced the update: the packs are still the old ones
+        assert all(torch.equal(a, b) for a, b in zip(first[1:3], stale[1:3]))
+        hip.bump_weights_generation()                         # what Trainer._weights_changed() does after every optimizer step
+        fresh, lib_out = evaluate(True), evaluate(False)
+        assert not torch.equal(first[1], fresh[1])
+        for name, x, y in zip(OUT, fresh, lib_out):
+            np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=2e-4, atol=2e-5, err_msg=name)
+    finally:
+        backbone.HIP_GRU, dense.ENABLED, dense.MIN_ROWS = True, True, min_rows
