@@ -729,11 +729,20 @@ def run_secondary(args, dev):
 def main():
     args = parse()
     under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
     if (args.gpus > 1 or args.spawn) and not under_launcher:
         # N ranks were asked for and nobody started them: do it here, BEFORE anything below touches a GPU
         raise SystemExit(spawn_ranks(args))
+    # stdout carries ONE thing: the bench line.  Libraries that write to file descriptor 1 from native code (RCCL prints a
+    # version banner there when a communicator comes up) are sent to stderr; the line itself goes to the saved descriptor.
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(line_fd, (json.dumps(line) + "\n").encode())
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -789,7 +798,7 @@ def main():
             line["secondary_wall_s"] = round(time.perf_counter() - t0, 1)
     if rank == 0:
         line["ranks_joined"] = ranks_joined
-        print(json.dumps(line), flush=True)
+        emit(line)
     if dist_on:
         import torch.distributed as dist
         dist.destroy_process_group()

@@ -50,6 +50,9 @@ __global__ __launch_bounds__(SCORE_WG) void attn_scores_kernel(ScoreArgs a) {
     const cvc_attn_set& S = a.set[s];
     const int A = a.A, nq = a.nq, n = S.n;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // what a masked position is filled with: -1e8 (modules.py:42-46, 125-129), or -inf for with_sentinel=True (modules.py:40-41,
+    // 123-124; cvc_attn_set.stream bit 2)
+    const float fill = (S.stream & 4) ? -__builtin_inff() : CVC_MIN_VALUE;
 
     for (int i = tid * 4; i < nq_pad * A; i += SCORE_WG * 4) {
         f32x4 v = {0, 0, 0, 0};
@@ -168,11 +171,11 @@ __global__ __launch_bounds__(SCORE_WG) void attn_scores_kernel(ScoreArgs a) {
             for (int u = 0; u < QG; ++u) {
                 if (q0 + u < nq && lane == 0) {
                     float sc = KIND == CVC_ATTN_ADDITIVE ? acc[u] + (a.b_a != nullptr ? a.b_a[0] : 0.f) : acc[u] * a.inv_temp;
-                    if (masked) sc = CVC_MIN_VALUE;
+                    if (masked) sc = fill;
                     const size_t o = ((size_t)clip * a.nq_total + a.q0 + q0 + u) * n + r;
                     S.scores[o] = sc;
                     if (S.frame_masked != nullptr)
-                        S.frame_masked[o] = S.frame_mask[o] != 0 ? CVC_MIN_VALUE : sc;
+                        S.frame_masked[o] = S.frame_mask[o] != 0 ? fill : sc;
                 }
             }
         }

@@ -294,8 +294,9 @@ class _Attention(torch.autograd.Function):
         nclip = feats[0].shape[0]
         sets = []
         for s in range(nsets):
-            m, fmk = masks[s]
-            sets.append({"proj": _c(feats[2 * s]), "ctx": _c(feats[2 * s + 1]), "mask": m, "frame_mask": fmk})
+            m, fmk = masks[s][:2]
+            sets.append({"proj": _c(feats[2 * s]), "ctx": _c(feats[2 * s + 1]), "mask": m, "frame_mask": fmk,
+                         "sentinel": len(masks[s]) > 2 and bool(masks[s][2])})
         w_flat = None if w_a is None else w_a.reshape(-1)
         outs, ctx_sum = hip.attn_fwd(kind, q, w_flat, b_a, inv_temp, sets, nclip, nq, want_ctx=True, want_sum=nsets > 1)
         ctx.kind, ctx.inv_temp, ctx.nq, ctx.nsets, ctx.nclip = kind, inv_temp, nq, nsets, nclip
@@ -375,13 +376,15 @@ class _Attention(torch.autograd.Function):
 
 
 def attention(kind: int, q: Tensor, w_a: Optional[Tensor], b_a: Optional[Tensor], inv_temp: float,
-              sets: Sequence[Tuple[Tensor, Tensor, Optional[Tensor], Optional[Tensor]]]):
-    """sets: (proj_context, context, mask, proposal_frame_mask) per feature set.
+              sets: Sequence[Tuple[Tensor, Tensor, Optional[Tensor], Optional[Tensor]]], with_sentinel: bool = False):
+    """sets: (proj_context, context, mask, proposal_frame_mask) per feature set.  with_sentinel: masked positions are filled
+    with -inf instead of -1e8 (modules.py:40-41, 123-124).
     Returns (ctx_total, [(ctx_s, attn_s, frame_masked_s or None)])."""
     nclip = sets[0][0].shape[0]
     nq = q.shape[0] // nclip
     assert nq * nclip == q.shape[0], "query rows must be a multiple of the number of clips"
-    masks = tuple((s[2], s[3]) for s in sets)
+    ws = list(with_sentinel) if isinstance(with_sentinel, (list, tuple)) else [with_sentinel] * len(sets)      # per set, or one for all
+    masks = tuple((s[2], s[3], bool(w)) for s, w in zip(sets, ws))
     feats = [t for s in sets for t in (s[0], s[1])]
     res = _Attention.apply(kind, float(inv_temp), nq, masks, q, w_a, b_a, *feats)
     out = []

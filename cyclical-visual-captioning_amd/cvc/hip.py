@@ -309,7 +309,7 @@ def attn_fwd(kind: int, q: torch.Tensor, w_a: Optional[torch.Tensor], b_a: Optio
         fm = torch.empty_like(scores) if fmk is not None else None
         ctx_out = torch.empty(rows, R, device=q.device, dtype=torch.float32) if want_ctx else None
         arr[i] = AttnSet(_dev(s["proj"], name="proj"), _dev(s["ctx"], name="ctx"), _dev(m, torch.uint8), _dev(fmk, torch.uint8),
-                         _dev(scores), _dev(fm), _dev(attn), _dev(ctx_out), n)
+                         _dev(scores), _dev(fm), _dev(attn), _dev(ctx_out), n, 4 if s.get("sentinel") else 0)
         keep += [m, fmk]
         outs.append((scores, fm, attn, ctx_out))
     ctx_sum = torch.empty(rows, R, device=q.device, dtype=torch.float32) if want_sum else None

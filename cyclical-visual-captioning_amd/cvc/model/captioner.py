@@ -21,6 +21,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
+from .. import dropout
 from .. import functional as F_
 from .. import hip
 from ..decode import DecodeEngine, DecodeWeights
@@ -108,15 +109,14 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         z = torch.zeros(4, batch_size, self.rnn_size, device=self.device)
         return tuple(z.unbind(0))
 
-    def _embed(self, word):
-        """embed = Embedding -> ReLU -> Dropout (reference :53-68); lookup+ReLU(+mask) is one kernel."""
+    def _embed(self, word, site=None):
+        """embed = Embedding -> ReLU -> Dropout (reference :53-68); lookup+ReLU(+mask) is one kernel.  site: the dropout site's
+        name (cvc/dropout.py) so that a test can dictate the mask."""
         drop_p = self.embed[2].p if (self.training and len(self.embed) > 2) else 0.0
         table = self.embed[0].weight
         drop = None
         if drop_p > 0:
-            shape = tuple(word.shape) + (table.shape[1],)
-            drop = torch.bernoulli(torch.full(shape, 1.0 - drop_p, device=table.device)).div_(1.0 - drop_p)
-            drop = drop.reshape(-1, table.shape[1])
+            drop = dropout.keep_mask(site or "emb", (word.numel(), table.shape[1]), drop_p, table.device)
         return F_.embed_relu(table, word, drop)
 
     def _logprobs(self, output):
@@ -191,7 +191,7 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
 
         # ---- Loop A: teacher-forced decode (sequential: LSTM recurrence)            reference :242-270
         state = self._init_step_state(B)
-        emb_all = self._embed(gt_caption[:, :T])                                     # [B, T, E], one launch
+        emb_all = self._embed(gt_caption[:, :T], "emb_a")                            # [B, T, E], one launch
         outputs, masked_attn = [], []
         # one unbind per tensor instead of T selects: a select's backward is a zero-filled [B, T, E] tensor plus an
         # accumulation per step, unbind's is a single stack
@@ -199,7 +199,7 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         for t in range(T):
             output, state, _roi_attn, frame_masked_attn, _wp = self.decoder_core.step(
                 emb_steps[t], fc_feats, conv_feats, p_conv_feats, pool_feats, p_pool_feats, region_mask, state,
-                proposal_frame_mask=step_fmask[t])
+                proposal_frame_mask=step_fmask[t], drop_site="out_a.%d" % t)
             outputs.append(output)
             masked_attn.append(frame_masked_attn)
         att2_weights = torch.stack(masked_attn, dim=1)                               # pre-softmax (:273)
@@ -226,17 +226,18 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
             return lm_loss.reshape(1), att2_loss.reshape(1), ground_loss.reshape(1), cls_loss.reshape(1)
 
         # ---- argmax cut, Loop B: localize (no recurrence -> all T in one attention call)  :313-338
-        loc_emb = self._embed(output_seq)                                            # [B, T, E]
+        loc_emb = self._embed(output_seq, "emb_b")                                   # [B, T, E]
         loc_pool, loc_conv, _prob = self.localizer_core.forward_all_steps(loc_emb, conv_feats, p_conv_feats, pool_feats,
                                                                            p_pool_feats, region_mask)
 
         # ---- Loop C: reconstruct from the localized regions (sequential)             reference :348-362
         state = self._init_step_state(B)
-        emb_all_c = self._embed(gt_caption[:, :T]) if self.training else emb_all      # fresh dropout mask in training
+        emb_all_c = self._embed(gt_caption[:, :T], "emb_c") if self.training else emb_all      # fresh dropout mask in training
         rec_outputs = []
         emb_steps_c, pool_steps, conv_steps = emb_all_c.unbind(1), loc_pool.unbind(1), loc_conv.unbind(1)
         for t in range(T):
-            output, state = self.attended_roi_decoder_core.step(emb_steps_c[t], fc_feats, pool_steps[t], conv_steps[t], state)
+            output, state = self.attended_roi_decoder_core.step(emb_steps_c[t], fc_feats, pool_steps[t], conv_steps[t], state,
+                                                                drop_site="out_c.%d" % t)
             rec_outputs.append(output)
         lm_recon_loss = self.xe_criterion.from_logits(self._logits(torch.stack(rec_outputs, 1).view(B * T, -1)), target)
         return (lm_loss.reshape(1), att2_loss.reshape(1), ground_loss.reshape(1), cls_loss.reshape(1),

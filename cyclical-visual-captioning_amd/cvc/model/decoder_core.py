@@ -6,6 +6,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from .. import dropout
 from .. import functional as F_
 from .modules import AdditiveSoftAttention, SoftAttention, _soft_attn_pair
 
@@ -40,17 +41,15 @@ class TopDownDecoderCore(nn.Module):
     def forward(self, embedded_word, fc_feats, conv_feats, p_conv_feats, pool_feats, p_pool_feats, pnt_mask,
                 state, proposal_frame_mask=None, with_sentinel=False):
         """The reference's call: state = (h [2, B, R], c [2, B, R]) in and out (layer 0 = attention LSTM, 1 = language LSTM)."""
-        if with_sentinel:
-            raise NotImplementedError("with_sentinel=True is not part of the caption-decode hot path")
         (h_att, h_lang), (c_att, c_lang) = state[0].unbind(0), state[1].unbind(0)
         output, st, roi_attn, frame_masked_attn, weighted_pool_feat = self.step(
             embedded_word, fc_feats, conv_feats, p_conv_feats, pool_feats, p_pool_feats, pnt_mask, (h_att, c_att, h_lang, c_lang),
-            proposal_frame_mask)
+            proposal_frame_mask, with_sentinel=with_sentinel)
         h_att, c_att, h_lang, c_lang = st[:4]
         return output, (torch.stack([h_att, h_lang]), torch.stack([c_att, c_lang])), roi_attn, frame_masked_attn, weighted_pool_feat
 
     def step(self, embedded_word, fc_feats, conv_feats, p_conv_feats, pool_feats, p_pool_feats, pnt_mask, state,
-             proposal_frame_mask=None):
+             proposal_frame_mask=None, drop_site=None, with_sentinel=False):
         """forward() on an unstacked state (h_att, c_att, h_lang, c_lang): what the captioner's T-step loops call --
         stacking the state every step costs ~17 small kernels per step in the backward pass (the selects' zero-filled
         gradients, their accumulation, the stack / unbind pairs)."""
@@ -65,10 +64,11 @@ class TopDownDecoderCore(nn.Module):
         # regions (masked, optional frame-masked copy) and frames share the query: one launch
         ctx_sum, ((weighted_pool_feat, roi_attn, frame_masked_attn), _frames) = _soft_attn_pair(
             self.soft_attn, h_attn[0],
-            [(p_pool_feats, pool_feats, pnt_mask, proposal_frame_mask), (p_conv_feats, conv_feats, None, None)])
+            [(p_pool_feats, pool_feats, pnt_mask, proposal_frame_mask), (p_conv_feats, conv_feats, None, None)],
+            with_sentinel=(with_sentinel, False))          # the region set only, as the reference forwards it (decoder_core.py:55-56)
         *h_new, c_lang = F_.lstm_cell([ctx_sum, h_attn[1 % k]], h_lang_s, c_lang, *_cell(self.lang_lstm), copies=k)
-        return (self.dropout(h_new[0]), (h_attn[2 % k], c_attn, h_new[1 % k], c_lang, h_new[2 % k]), roi_attn, frame_masked_attn,
-                weighted_pool_feat)
+        return (dropout.apply(self.dropout, h_new[0], drop_site), (h_attn[2 % k], c_attn, h_new[1 % k], c_lang, h_new[2 % k]), roi_attn,
+                frame_masked_attn, weighted_pool_feat)
 
 
 class AttenedDecoderCore(nn.Module):
@@ -91,7 +91,7 @@ class AttenedDecoderCore(nn.Module):
         h_att, c_att, h_lang, c_lang = st[:4]
         return output, (torch.stack([h_att, h_lang]), torch.stack([c_att, c_lang]))
 
-    def step(self, embedded_word, fc_feats, weighted_pool_feat, attn_conv, state):
+    def step(self, embedded_word, fc_feats, weighted_pool_feat, attn_conv, state, drop_site=None):
         """forward() on an unstacked state (h_att, c_att, h_lang, c_lang), see TopDownDecoderCore.step"""
         h_att, c_att, h_lang, c_lang = state[:4]
         h_lang_s = state[4] if len(state) > 4 else h_lang
@@ -100,4 +100,4 @@ class AttenedDecoderCore(nn.Module):
         *h_attn, c_attn = F_.lstm_cell(xs, h_att, c_att, *_cell(self.att_lstm), copies=2 if grad else 1)
         *h_new, c_lang = F_.lstm_cell([weighted_pool_feat + attn_conv, h_attn[0]], h_lang_s, c_lang, *_cell(self.lang_lstm),
                                       copies=3 if grad else 1)
-        return self.dropout(h_new[0]), (h_attn[-1], c_attn, h_new[1 % len(h_new)], c_lang, h_new[2 % len(h_new)])
+        return dropout.apply(self.dropout, h_new[0], drop_site), (h_attn[-1], c_attn, h_new[1 % len(h_new)], c_lang, h_new[2 % len(h_new)])

@@ -17,12 +17,11 @@ class LocalizerNoLSTMCore(nn.Module):
 
     def forward(self, embedded_word, fc_feats, conv_feats, p_conv_feats, pool_feats, p_pool_feats, attn_mask, state,
                 consistent_decoder_state, proposal_frame_mask=None, with_sentinel=False):
-        if with_sentinel:
-            raise NotImplementedError("with_sentinel=True is not part of the caption-decode hot path")
-        # the frame-masked copy is computed by the reference and dropped (:36-37): skip it
+        # the frame-masked copy is computed by the reference and dropped (:36-37): skip it; with_sentinel reaches the region
+        # attention only (:37), as -inf fill
         _, ((loc_feat, loc_prob, _), (loc_conv, _, _)) = _soft_attn_pair(
             self.soft_attn, embedded_word,
-            [(p_pool_feats, pool_feats, attn_mask, None), (p_conv_feats, conv_feats, None, None)])
+            [(p_pool_feats, pool_feats, attn_mask, None), (p_conv_feats, conv_feats, None, None)], with_sentinel=(with_sentinel, False))
         return loc_feat, loc_conv, loc_prob, state
 
     def forward_all_steps(self, embedded_words, conv_feats, p_conv_feats, pool_feats, p_pool_feats, attn_mask):

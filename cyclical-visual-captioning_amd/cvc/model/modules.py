@@ -13,13 +13,6 @@ from .. import functional as F_
 from .. import hip
 
 
-def _reject_sentinel(with_sentinel):
-    if with_sentinel:
-        # reference: -inf masking for a sentinel column (modules.py:40-41,123-124); every caller in
-        # the reference passes with_sentinel=False (decoder_core.py:55, localizer_core.py:37)
-        raise NotImplementedError("with_sentinel=True is not part of the caption-decode hot path")
-
-
 class SoftAttention(nn.Module):
     """Dot-product soft attention (reference model/modules.py:7-76)."""
 
@@ -30,11 +23,12 @@ class SoftAttention(nn.Module):
         self.min_value = -1e8   # finite: an all-masked row softmaxes to uniform, not NaN
 
     def forward(self, h, proj_context, context=None, mask=None, proposal_frame_mask=None, with_sentinel=False):
-        _reject_sentinel(with_sentinel)
+        """with_sentinel=True fills masked positions with -inf instead of min_value (reference modules.py:40-41; no reference
+        caller uses it: decoder_core.py:55, localizer_core.py:37 pass False)."""
         q = F_.linear(h, self.h2attn.weight, self.h2attn.bias)
         src = proj_context if context is None else context
         _, ((ctx, attn, fm),) = F_.attention(hip.ATTN_DOT, q, None, None, 1.0 / float(self.temp),
-                                             [(proj_context, src, mask, proposal_frame_mask)])
+                                             [(proj_context, src, mask, proposal_frame_mask)], with_sentinel=with_sentinel)
         return ctx, attn, fm
 
 
@@ -52,25 +46,25 @@ class AdditiveSoftAttention(nn.Module):
         self.min_value = -1e8
 
     def forward(self, h, proj_context, context=None, mask=None, proposal_frame_mask=None, with_sentinel=False):
-        _reject_sentinel(with_sentinel)
+        """with_sentinel=True: -inf fill (reference modules.py:123-124, 136-138)."""
         q = F_.linear(h, self.h2attn.weight, self.h2attn.bias)
         src = proj_context if context is None else context
         _, ((ctx, attn, fm),) = F_.attention(hip.ATTN_ADDITIVE, q, self.alpha_net.weight, self.alpha_net.bias, 1.0,
-                                             [(proj_context, src, mask, proposal_frame_mask)])
+                                             [(proj_context, src, mask, proposal_frame_mask)], with_sentinel=with_sentinel)
         return ctx, attn, fm
 
-    def forward_pair(self, h, sets):
+    def forward_pair(self, h, sets, with_sentinel=False):
         """Both feature sets of a decoder step in one launch (decoder_core.py:54-56 calls the
-        module twice with the same query): returns (ctx_sum, [(ctx, attn, fm)] per set)."""
+        module twice with the same query): returns (ctx_sum, [(ctx, attn, fm)] per set).  with_sentinel: bool or one per set."""
         q = F_.linear(h, self.h2attn.weight, self.h2attn.bias)
-        return F_.attention(hip.ATTN_ADDITIVE, q, self.alpha_net.weight, self.alpha_net.bias, 1.0, sets)
+        return F_.attention(hip.ATTN_ADDITIVE, q, self.alpha_net.weight, self.alpha_net.bias, 1.0, sets, with_sentinel=with_sentinel)
 
 
-def _soft_attn_pair(mod, h, sets):
+def _soft_attn_pair(mod, h, sets, with_sentinel=False):
     if isinstance(mod, AdditiveSoftAttention):
-        return mod.forward_pair(h, sets)
+        return mod.forward_pair(h, sets, with_sentinel)
     q = F_.linear(h, mod.h2attn.weight, mod.h2attn.bias)
-    return F_.attention(hip.ATTN_DOT, q, None, None, 1.0 / float(mod.temp), sets)
+    return F_.attention(hip.ATTN_DOT, q, None, None, 1.0 / float(mod.temp), sets, with_sentinel=with_sentinel)
 
 
 def proj_masking(feat, projector, mask=None):

@@ -54,7 +54,10 @@ typedef struct {
     int n;
     int stream;                 /* cache policy of the feature reads: bit 0 = proj, bit 1 = ctx read with
                                  * non-temporal loads (a stream that should not displace what is re-read
-                                 * every step from the 256 MB Infinity Cache); 0 = default, cacheable      */
+                                 * every step from the 256 MB Infinity Cache); 0 = default, cacheable.
+                                 * bit 2 = with_sentinel (modules.py:40-41, 123-124): masked positions are
+                                 * filled with -inf instead of -1e8 (a fully masked row then softmaxes to
+                                 * NaN, as in the reference)                                               */
 } cvc_attn_set;
 
 /* q [rows, A] is h2attn(h) (bias included).  kind ADDITIVE: s = w_a . tanh(proj_n + q) + b_a[0]

@@ -32,9 +32,11 @@ MIN_VALUE = -1e8  # model/modules.py:22,98 -- finite, so an all-masked row is un
 
 # ----------------------------------------------------------------------------- attention
 def additive_attention(h: Tensor, p_ctx: Tensor, ctx: Optional[Tensor], mask: Optional[Tensor],
-                       frame_mask: Optional[Tensor], w_h: Tensor, b_h: Tensor, w_a: Tensor, b_a: Tensor
-                       ) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
-    """model/modules.py:100-159 (AdditiveSoftAttention.forward); no temperature (:120)."""
+                       frame_mask: Optional[Tensor], w_h: Tensor, b_h: Tensor, w_a: Tensor, b_a: Tensor,
+                       with_sentinel: bool = False) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
+    """model/modules.py:100-159 (AdditiveSoftAttention.forward); no temperature (:120).  with_sentinel: -inf fill (:123-124,
+    :136-138) instead of -1e8."""
+    MIN_VALUE = -float("inf") if with_sentinel else globals()["MIN_VALUE"]
     n = p_ctx.size(1)
     q = F.linear(h, w_h, b_h).unsqueeze(1)                       # :109-110
     e = torch.tanh(p_ctx + q)                                    # :111-112
@@ -52,9 +54,10 @@ def additive_attention(h: Tensor, p_ctx: Tensor, ctx: Optional[Tensor], mask: Op
 
 
 def dot_attention(h: Tensor, p_ctx: Tensor, ctx: Optional[Tensor], mask: Optional[Tensor],
-                  frame_mask: Optional[Tensor], w_h: Tensor, b_h: Tensor, temp: float = 1.0
-                  ) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
-    """model/modules.py:24-76 (SoftAttention.forward)."""
+                  frame_mask: Optional[Tensor], w_h: Tensor, b_h: Tensor, temp: float = 1.0,
+                  with_sentinel: bool = False) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
+    """model/modules.py:24-76 (SoftAttention.forward).  with_sentinel: -inf fill (:40-41, :53-55) instead of -1e8."""
+    MIN_VALUE = -float("inf") if with_sentinel else globals()["MIN_VALUE"]
     q = F.linear(h, w_h, b_h)                                    # :31
     s = torch.bmm(p_ctx, q.unsqueeze(2)).squeeze(2)              # :34-35
     s = s / temp                                                 # :37
@@ -380,9 +383,13 @@ def frame_mask_on_proposals(box_mask_t: Tensor, frm_mask: Tensor, pnt_mask: Tens
 def cyclical_forward(P: Dict[str, Tensor], feats: Dict[str, Tensor], batch: Dict[str, Tensor], *, T: int,
                      vocab_size: int, train_decoder_only: bool = False, global_img: bool = True,
                      softattn_type: str = "additive", localizer_temp: float = 1.0, seq_per_img: int = 1,
-                     collect: Optional[dict] = None):
-    """model/captioner.py:196-382 (_forward_3_loops), eval-mode dropout.  feats is what the
-    once-per-clip encoder returned (:231-233); returns (lm, att2, ground, cls[, lm_recon])."""
+                     collect: Optional[dict] = None, dropout: Optional[Dict[str, Tensor]] = None):
+    """model/captioner.py:196-382 (_forward_3_loops).  feats is what the once-per-clip encoder returned (:231-233); returns
+    (lm, att2, ground, cls[, lm_recon]).  dropout = None: eval mode.  Train mode (model.train(): nn.Dropout on the embedded word,
+    captioner.py:53-68, and on the language LSTM's output, decoder_core.py:62, 109) with DICTATED masks -- the reference draws
+    them from the global generator; for parity with another implementation they are inputs here: keep / (1 - p) tensors
+    "emb_a" / "emb_b" / "emb_c" [B, T, E] (loops A, B, C) and "out_a" / "out_c" [T, B, R]."""
+    dm = (lambda key, t: None) if dropout is None else (lambda key, t: dropout[key][:, t] if key.startswith("emb") else dropout[key][t])
     fc, conv, pconv = feats["fc_feats"], feats["conv_feats"], feats["p_conv_feats"]
     pool, ppool, gpool, pnt_mask = feats["pool_feats"], feats["p_pool_feats"], feats["g_pool_feats"], feats["pnt_mask"]
     B, N = pool.size(0), pool.size(1)
@@ -396,12 +403,13 @@ def cyclical_forward(P: Dict[str, Tensor], feats: Dict[str, Tensor], batch: Dict
     mask = pnt_mask[:, 1:]
     logps, fmasked, roi_labels, fmo = [], [], [], []
     for t in range(T):                                                                        # :242 Loop A
-        e = embed(P, gt[:, t])                                                                # :243-244
+        e = embed(P, gt[:, t], dm("emb_a", t))                                                # :243-244
         roi_labels.append(bbox_target(box_mask[:, :, :, t + 1], overlaps))                    # :246-248
         fm_t = frame_mask_on_proposals(box_mask[:, 0, :, t + 1], frm_mask, pnt_mask)          # :251-260
         fmo.append(fm_t)
         out, state, a_r, fm, _ = decoder_step(P, e, fc, conv, pconv, pool, ppool, mask, state, fm_t[:, 1:],
-                                              global_img=global_img, softattn_type=softattn_type)  # :262-264
+                                              global_img=global_img, softattn_type=softattn_type,
+                                              out_drop=dm("out_a", t))                           # :262-264
         logps.append(logits_logsoftmax(P, out))                                               # :266
         fmasked.append(fm)
     att2_w = torch.stack(fmasked, 1)                                                          # :273 (pre-softmax)
@@ -424,15 +432,16 @@ def cyclical_forward(P: Dict[str, Tensor], feats: Dict[str, Tensor], batch: Dict
     out_seq = lang.max(2)[1]                                                                  # :313 argmax cut
     loc_pool, loc_conv = [], []
     for t in range(T):                                                                        # :320 Loop B
-        e = embed(P, out_seq[:, t])
+        e = embed(P, out_seq[:, t], dm("emb_b", t))
         lp_, lc_, _ = localizer_step(P, e, conv, pconv, pool, ppool, mask, fmo[:, t, 1:], temp=localizer_temp)
         loc_pool.append(lp_)
         loc_conv.append(lc_)
     state = init_hidden(B, fc.size(1))                                                        # :346-347
     rec = []
     for t in range(T):                                                                        # :348 Loop C
-        e = embed(P, gt[:, t])
-        out, state = reconstructor_step(P, e, fc, loc_pool[t], loc_conv[t], state, global_img=global_img)
+        e = embed(P, gt[:, t], dm("emb_c", t))
+        out, state = reconstructor_step(P, e, fc, loc_pool[t], loc_conv[t], state, global_img=global_img,
+                                        out_drop=dm("out_c", t))
         rec.append(logits_logsoftmax(P, out))                                                 # :361
     rec = torch.stack(rec, 1)
     lm_recon = language_criterion(rec.view(-1, rec.size(2)), target)                          # :378-379

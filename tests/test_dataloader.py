@@ -73,13 +73,18 @@ def test_collate_and_batch_trim(dataset_opts):
     B, P = len(ds), ds.max_proposal
     assert batch[0].dtype == torch.float64 and batch[0].shape == (B, ds.t_attn_size, 8)
     assert batch[4].shape == (B, P, 7) and batch[5].shape == (B, 100, 6) and batch[6].shape == (B, 1, 100, ds.seq_length + 1)
-    assert batch[7] == ["v_vid00_segment_00", "v_vid01_segment_00", "v_vid01_segment_01"]
+    assert batch[7] == ["v_vid00_segment_00", "v_vid01_segment_00", "v_vid01_segment_01", "v_vid03_segment_00"]
     num = batch[3]
+    # the last segment overflows every padded array (dataloader_anet.py:351-352 clip to max_proposal / max_gt_box = 100): its
+    # counts are the clipped ones
+    assert int(num[-1, 1]) == P and int(num[-1, 2]) == 100
+    sub = [x[:3] if torch.is_tensor(x) else x for x in batch]              # the ordinary segments: trimming has something to cut
+    num = sub[3]
     n_prop, n_box = int(num[:, 1].max()), int(num[:, 2].max())
     assert n_prop <= P and 1 <= n_box < 100
     # everything beyond the batch maximum is padding: proposals zero / masked, boxes zero, box mask True
-    assert float(batch[4][:, n_prop:].abs().max() if n_prop < P else 0) == 0 and bool(batch[11][:, n_prop:].all())
-    assert float(batch[5][:, n_box:].abs().max()) == 0 and bool(batch[6][:, :, n_box:].all()) and bool(batch[9][:, :, n_box:].all())
+    assert float(sub[4][:, n_prop:].abs().max() if n_prop < P else 0) == 0 and bool(sub[11][:, n_prop:].all())
+    assert float(sub[5][:, n_box:].abs().max()) == 0 and bool(sub[6][:, :, n_box:].all()) and bool(sub[9][:, :, n_box:].all())
 
 
 def test_proposal_file_without_h5py_names_the_npz_twin(tmp_path):

@@ -36,6 +36,7 @@ def close(a, b, **tol):
 
 
 _CACHE = {}
+_BEAM_MATCH = {}        # (config, beam) -> (identical rank-0 sequences, clips), filled by _beam_check; reported at the end of the module
 
 
 def _inputs(name, seed):
@@ -65,6 +66,12 @@ def _beam_check(name, seed, dev, beam=5, min_same=0.9):
     assert seq.shape == (d.B, d.T) and att.shape == (d.B, d.T, d.N) and sc.shape == (d.B, beam)
     assert bool((sc[:, :-1] >= sc[:, 1:] - 1e-6).all())
     same = (seq.cpu() == seq_o).all(1)
+    # the observed rate goes to the test output (pytest -rP / -s, and the GPU log the driver keeps): a slide from 64/64 to 58/64
+    # stays inside the 90 % bar but must be visible
+    worst = float((sc_o[:, 0] - sc[:, 0].cpu()).max())
+    print(f"[beam-check] {name} beam={beam}: {int(same.sum())}/{d.B} rank-0 sequences identical to the oracle's; "
+          f"largest oracle-minus-engine best-score gap {worst:.2e}")
+    _BEAM_MATCH[(name, beam)] = (int(same.sum()), d.B)
     assert int(same.sum()) >= min_same * d.B, f"only {int(same.sum())} of {d.B} rank-0 sequences match the oracle"
     close(att[same.to(dev)], att_o[same], **SEQ_TOL)
     close(sc[same.to(dev)][:, 0], sc_o[same][:, 0], rtol=2e-4, atol=2e-4)
@@ -252,3 +259,11 @@ def test_nan_logits_keep_selected_indices_in_range(dev):
     sd["logit.bias"] = np.full_like(sd["logit.bias"], np.nan)
     seq, att = DecodeEngine(DecodeWeights(to_dev(sd, dev)), to_dev(synth.clip_features(d, 5), dev), d.T, synth.UNK_IDX).run()
     assert bool(((seq >= 0) & (seq < d.V)).all())
+
+
+def test_zz_report_beam_match_rates():
+    """Not a check of its own: writes the match rates observed by the full-size beam tests of this module into the pytest
+    summary (record via warnings so that -q runs show them too)."""
+    import warnings
+    for (name, beam), (n, B) in sorted(_BEAM_MATCH.items()):
+        warnings.warn(f"beam match rate {name} beam={beam}: {n}/{B} rank-0 sequences identical to the oracle's")

@@ -77,6 +77,31 @@ def test_a2_dot_attention_golden(tiny, g1, temp):
     close(ctx, g1[pre + "ctx"], **OP_TOL); close(a, g1[pre + "attn"], **OP_TOL); close(fm, g1[pre + "fm"], **OP_TOL)
 
 
+def test_with_sentinel_minus_inf_fill_golden(tiny, dev):
+    """with_sentinel=True through the module shims (modules.py:40-41, 123-124; forwarded by the cores to the region attention,
+    decoder_core.py:55, localizer_core.py:37): masked positions are filled with -inf -- against the reference's own outputs
+    (tests/golden/g7_sentinel.npz).  Clip 2 is fully masked: NaN there, as in the reference."""
+    from conftest import Golden
+    g7 = Golden("g7_sentinel.npz")
+    d, model, f, _, u = tiny
+    mask = f["pnt_mask"][:, 1:]
+    core, loc = model.decoder_core, model.localizer_core
+    ctx, a, fm = core.soft_attn(u["h"], f["p_pool_feats"], context=f["pool_feats"], mask=mask, proposal_frame_mask=u["fmask"], with_sentinel=True)
+    close(ctx, g7["add.ctx"], **OP_TOL); close(a, g7["add.attn"], **OP_TOL); close(fm, g7["add.fm"], **OP_TOL)
+    assert torch.isnan(a[2]).all() and torch.isinf(fm).any()
+    dot = type(loc.soft_attn)(d.E, d.A, temp=2.5).to(dev)
+    dot.load_state_dict(loc.soft_attn.state_dict())
+    ctx, a, fm = dot(u["emb"], f["p_pool_feats"], context=f["pool_feats"], mask=mask, proposal_frame_mask=u["fmask"], with_sentinel=True)
+    close(ctx, g7["dot.ctx"], **OP_TOL); close(a, g7["dot.attn"], **OP_TOL); close(fm, g7["dot.fm"], **OP_TOL)
+    o, st, ra, fma, wp = core(u["emb"], f["fc_feats"], f["conv_feats"], f["p_conv_feats"], f["pool_feats"], f["p_pool_feats"], mask,
+                              (u["state_h"], u["state_c"]), proposal_frame_mask=u["fmask"], with_sentinel=True)
+    close(o, g7["core.out"], **OP_TOL); close(st[0], g7["core.h"], **OP_TOL); close(st[1], g7["core.c"], **OP_TOL)
+    close(ra, g7["core.roi_attn"], **OP_TOL); close(fma, g7["core.fm"], **OP_TOL); close(wp, g7["core.ctx_r"], **OP_TOL)
+    a_, b_, c_, _ = loc(u["emb"], f["fc_feats"], f["conv_feats"], f["p_conv_feats"], f["pool_feats"], f["p_pool_feats"], mask, None, None,
+                        proposal_frame_mask=u["fmask"], with_sentinel=True)
+    close(a_, g7["loc.loc_pool"], **OP_TOL); close(b_, g7["loc.loc_conv"], **OP_TOL); close(c_, g7["loc.prob"], **OP_TOL)
+
+
 def test_a3_decoder_step_golden(tiny, g1):
     d, model, f, _, u = tiny
     out, (h, c), ra, fm, ctx_r = model.decoder_core(u["emb"], f["fc_feats"], f["conv_feats"], f["p_conv_feats"],

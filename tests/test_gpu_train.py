@@ -270,3 +270,71 @@ def test_gradient_exchange_on_rccl_one_rank_equals_no_exchange():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------ train-mode (dropout ON) parity with dictated masks
+def _dropout_masks(d, seed, p=0.5):
+    """keep / (1 - p) masks for every dropout site of one cyclical pass (cvc/dropout.py names): the SAME tensors go to the
+    product (through cvc.dropout.injected) and to the oracle (cyclical_forward(dropout=...))."""
+    g = torch.Generator().manual_seed(seed)
+    draw = lambda *shape: torch.bernoulli(torch.full(shape, 1.0 - p), generator=g) / (1.0 - p)
+    return dict(emb_a=draw(d.B, d.T, d.E), emb_b=draw(d.B, d.T, d.E), emb_c=draw(d.B, d.T, d.E),
+                out_a=draw(d.T, d.B, d.R), out_c=draw(d.T, d.B, d.R))
+
+
+def _train_mode_parity(d, seed, mix, loss_tol, grad_tol=5e-4):
+    from helpers import build_model, to_dev, model_call
+    from oracle import ref_cpu as O
+    from cvc import dropout
+    dev = torch.device("cuda:0")
+    sd, f, b = synth.hot_path_state_dict(d, seed), synth.clip_features(d, seed), synth.label_glue_batch(d, seed)
+    masks = _dropout_masks(d, seed + 1)
+    P = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in O.to_torch(sd).items()}
+    for k in list(P):                                           # the reconstructor shares the decoder's LSTM cells
+        if k.startswith("attended_roi_decoder_core.") and "lstm" in k:
+            P[k] = P[k.replace("attended_roi_decoder_core.", "decoder_core.")]
+    ref = O.cyclical_forward(P, O.to_torch(f), O.to_torch(b), T=d.T, vocab_size=d.V, dropout=masks)
+    ref_eval = O.cyclical_forward(P, O.to_torch(f), O.to_torch(b), T=d.T, vocab_size=d.V)
+    assert abs(float(ref[0]) - float(ref_eval[0])) > 1e-3          # the masks do change the pass (not an eval-mode rerun)
+    O.training_loss(ref, xe_loss_weight=mix[0], w_att2=mix[1], w_cls=0.0, caption_consistency_loss_weight=mix[2]).backward()
+    model = build_model(d, sd, dev).train()
+    used = []
+
+    def source(site, shape):
+        used.append(site)
+        if site.startswith("emb_"):
+            return masks[site].reshape(shape)
+        kind, t = site.split(".")
+        return masks[kind][int(t)]
+    with dropout.injected(source):
+        out = model_call(model, to_dev(f, dev), to_dev(b, dev), False)
+    assert sorted(set(used)) == sorted(["emb_a", "emb_b", "emb_c"] + ["out_a.%d" % t for t in range(d.T)] + ["out_c.%d" % t for t in range(d.T)])
+    for got, want in zip(out, ref):
+        assert float(got.detach().mean()) == pytest.approx(float(want.detach().mean()), rel=loss_tol, abs=loss_tol / 10)
+    lm, a2, _g, _cls, rec = [x.mean() for x in out]
+    (mix[0] * lm + mix[1] * a2 + mix[2] * rec).backward()
+    checked = 0
+    for n, p in model.named_parameters():
+        if n.startswith("roi_feat_extractor") or n not in P:
+            continue
+        if P[n].grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+            continue
+        want = P[n].grad.double()
+        err = float((p.grad.cpu().double() - want).norm())
+        assert err <= grad_tol * float(want.norm()) + 1e-6, (n, err, float(want.norm()))
+        checked += 1
+    assert checked >= 15
+
+
+@pytest.mark.parametrize("cfg,mix", [("tiny", (0.5, 0.05, 0.5)), ("tiny", (0.5, 0.0, 0.5)), ("cfg1", (0.5, 0.0, 0.5))])
+def test_train_mode_cyclical_pass_with_dictated_dropout_masks_vs_oracle(cfg, mix):
+    """The whole cyclical pass in train() mode -- Dropout(0.5) on the three word embeddings (captioner.py:53-68) and on the
+    language LSTM's output of every step of loops A and C (decoder_core.py:62, 109) -- with the same keep-masks on both sides:
+    five losses and every parameter gradient against the oracle's autograd.  (The timed training bench runs in train mode.)"""
+    _train_mode_parity(synth.CONFIGS[cfg], 4242, mix, loss_tol=2e-5)
+
+
+def test_train_mode_cyclical_pass_cfg3_full_size_vs_oracle():
+    """... and once at BASELINE config 3 size (B=64, D=2048, T=20)."""
+    _train_mode_parity(synth.CONFIGS["cfg3"], 1305, (0.5, 0.0, 0.5), loss_tol=1e-4)

@@ -72,6 +72,22 @@ def test_a2_dot_attention(tiny, g1, temp):
     close(ctx, g1[pre + "ctx"]); close(a, g1[pre + "attn"]); close(fm, g1[pre + "fm"])
 
 
+def test_with_sentinel_minus_inf_fill_golden(tiny):
+    """with_sentinel=True (modules.py:40-41, 123-124): masked positions filled with -inf -- the oracle against the reference's own
+    outputs (tests/golden/g7_sentinel.npz, tools/make_golden.py g7).  The fully masked clip is NaN there, as in the reference."""
+    from conftest import Golden
+    g7 = Golden("g7_sentinel.npz")
+    d, P, f, _, u = tiny
+    mask = f["pnt_mask"][:, 1:]
+    w = [P["decoder_core.soft_attn." + k] for k in ("h2attn.weight", "h2attn.bias", "alpha_net.weight", "alpha_net.bias")]
+    ctx, a, fm = O.additive_attention(u["h"], f["p_pool_feats"], f["pool_feats"], mask, u["fmask"], *w, with_sentinel=True)
+    close(ctx, g7["add.ctx"]); close(a, g7["add.attn"]); close(fm, g7["add.fm"])
+    assert np.isnan(g7["add.attn"][2]).all() and np.isinf(g7["add.fm"]).any()
+    w = [P["localizer_core.soft_attn." + k] for k in ("h2attn.weight", "h2attn.bias")]
+    ctx, a, fm = O.dot_attention(u["emb"], f["p_pool_feats"], f["pool_feats"], mask, u["fmask"], *w, 2.5, with_sentinel=True)
+    close(ctx, g7["dot.ctx"]); close(a, g7["dot.attn"]); close(fm, g7["dot.fm"])
+
+
 def test_a4_lstm_cell_forms_agree(tiny):
     d, P, f, _, u = tiny
     x = torch.cat([u["state_h"][1], f["fc_feats"], u["emb"]], 1)

@@ -506,6 +506,48 @@ def g6_dataloader(path):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+def g7_sentinel(path):
+    """with_sentinel=True (model/modules.py:40-41, 53-55, 123-124, 136-138: masked positions filled with -inf instead of -1e8),
+    through the two attention modules and the two cores that forward the flag (decoder_core.py:55, localizer_core.py:37).  Same
+    tiny inputs as g1 (clip 2 fully masked: its rows are NaN in the reference, which is part of the contract)."""
+    d = synth.CONFIGS["tiny"]
+    seed = 1234
+    sd = synth.hot_path_state_dict(d, seed)
+    feats_np = synth.clip_features(d, seed, full_mask_clip=2)
+    B, N, R, A, E = d.B, d.N, d.R, d.A, d.E
+    h = t(synth.normal((B, R), seed, "unit.h") * 0.5)
+    emb = t(np.maximum(synth.normal((B, E), seed, "unit.emb"), 0))
+    st_h = t(synth.normal((2, B, R), seed, "unit.state_h") * 0.5)
+    st_c = t(synth.normal((2, B, R), seed, "unit.state_c") * 0.5)
+    fmask = t(synth.uniform((B, N), seed, "unit.fmask") < 0.4)
+    ft = feats_to_torch(feats_np, False)
+    mask = ft["pnt_mask"][:, 1:]
+    opts = make_opts(d)
+    out = OrderedDict()
+    out["meta.seed"] = np.asarray(seed)
+    add = AdditiveSoftAttention(R, A)
+    add.load_state_dict({k.split("soft_attn.")[1]: t(v) for k, v in sd.items() if k.startswith("decoder_core.soft_attn.")})
+    ctx, a, fm = add(h, ft["p_pool_feats"], context=ft["pool_feats"], mask=mask, proposal_frame_mask=fmask, with_sentinel=True)
+    put(out, "add.", dict(ctx=ctx, attn=a, fm=fm))
+    dot = SoftAttention(E, A, temp=2.5)
+    dot.load_state_dict({k.split("soft_attn.")[1]: t(v) for k, v in sd.items() if k.startswith("localizer_core.soft_attn.")})
+    ctx, a, fm = dot(emb, ft["p_pool_feats"], context=ft["pool_feats"], mask=mask, proposal_frame_mask=fmask, with_sentinel=True)
+    put(out, "dot.", dict(ctx=ctx, attn=a, fm=fm))
+    core = TopDownDecoderCore(opts)
+    core.load_state_dict({k[len("decoder_core."):]: t(v) for k, v in sd.items() if k.startswith("decoder_core.")})
+    core.eval()
+    o, st, ra, fma, wp = core(emb, ft["fc_feats"], ft["conv_feats"], ft["p_conv_feats"], ft["pool_feats"],
+                              ft["p_pool_feats"], mask, (st_h, st_c), proposal_frame_mask=fmask, with_sentinel=True)
+    put(out, "core.", dict(out=o, h=st[0], c=st[1], roi_attn=ra, fm=fma, ctx_r=wp))
+    loc = LocalizerNoLSTMCore(opts)
+    loc.load_state_dict({k[len("localizer_core."):]: t(v) for k, v in sd.items() if k.startswith("localizer_core.")})
+    a, b_, c_, _ = loc(emb, ft["fc_feats"], ft["conv_feats"], ft["p_conv_feats"], ft["pool_feats"],
+                       ft["p_pool_feats"], mask, None, None, proposal_frame_mask=fmask, with_sentinel=True)
+    put(out, "loc.", dict(loc_pool=a, loc_conv=b_, prob=c_))
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
     gdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gdir, exist_ok=True)
@@ -515,7 +557,8 @@ if __name__ == "__main__":
             "g3": lambda: g3_shards(os.path.join(gdir, "g3_shards.npz")),
             "g4": lambda: g4_config_surface(os.path.join(gdir, "config_surface.json")),
             "g5": lambda: g5_encoder(os.path.join(gdir, "g5_encoder.npz")),
-            "g6": lambda: g6_dataloader(os.path.join(gdir, "g6_dataloader.npz"))}
+            "g6": lambda: g6_dataloader(os.path.join(gdir, "g6_dataloader.npz")),
+            "g7": lambda: g7_sentinel(os.path.join(gdir, "g7_sentinel.npz"))}
     for name, job in jobs.items():
         if not only or name in only:
             job()
