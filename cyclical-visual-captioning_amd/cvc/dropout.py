@@ -6,6 +6,8 @@ per step of the decode and reconstruction loops).  Every site has a name:
 
     emb_a, emb_b, emb_c              [B * T, E]   embedded words of loop A (decode), B (localize), C (reconstruct)
     out_a.<t>, out_c.<t>             [B, R]       output of step t of loop A / loop C
+    vis_embed                        [B, T, G]    the grounder's class embeddings, roi_feat_extractor.vis_embed (model/backbone.py:55-57,
+                                                  used at captioner.py:284)
 
 `keep_mask(site, shape, p, device)` returns the site's keep-mask ALREADY divided by (1 - p) (what the kernels multiply by).
 By default it is drawn with torch.bernoulli; under `injected(fn)` it is whatever fn(site, shape) returns -- the train-mode

@@ -207,7 +207,11 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
 
         # ---- grounder over all T                                                      reference :282-294
         xt_clamp = torch.clamp(input_seq[:, 1:T + 1, 0].clone() - self.vocab_size, min=0)
-        xt_all = self.roi_feat_extractor.vis_embed(xt_clamp)
+        ve = self.roi_feat_extractor.vis_embed                                       # Embedding -> ReLU -> Dropout (backbone.py:55-57)
+        if dropout.active() and self.training and isinstance(ve, nn.Sequential) and len(ve) == 3:
+            xt_all = dropout.apply(ve[2], ve[1](ve[0](xt_clamp)), "vis_embed")       # dictated mask (train-mode parity tests)
+        else:
+            xt_all = ve(xt_clamp)
         if hasattr(self.roi_feat_extractor, 'vis_classifiers_bias'):
             bias = self.roi_feat_extractor.vis_classifiers_bias[xt_clamp].type(xt_all.type()).unsqueeze(2).expand(
                 B, T, num_rois)

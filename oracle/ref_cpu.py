@@ -388,7 +388,8 @@ def cyclical_forward(P: Dict[str, Tensor], feats: Dict[str, Tensor], batch: Dict
     (lm, att2, ground, cls[, lm_recon]).  dropout = None: eval mode.  Train mode (model.train(): nn.Dropout on the embedded word,
     captioner.py:53-68, and on the language LSTM's output, decoder_core.py:62, 109) with DICTATED masks -- the reference draws
     them from the global generator; for parity with another implementation they are inputs here: keep / (1 - p) tensors
-    "emb_a" / "emb_b" / "emb_c" [B, T, E] (loops A, B, C) and "out_a" / "out_c" [T, B, R]."""
+    "emb_a" / "emb_b" / "emb_c" [B, T, E] (loops A, B, C), "out_a" / "out_c" [T, B, R], and "vis_embed" [B, T, G] for the grounder's
+    class embeddings (roi_feat_extractor.vis_embed is Embedding -> ReLU -> Dropout, model/backbone.py:55-57)."""
     dm = (lambda key, t: None) if dropout is None else (lambda key, t: dropout[key][:, t] if key.startswith("emb") else dropout[key][t])
     fc, conv, pconv = feats["fc_feats"], feats["conv_feats"], feats["p_conv_feats"]
     pool, ppool, gpool, pnt_mask = feats["pool_feats"], feats["p_pool_feats"], feats["g_pool_feats"], feats["pnt_mask"]
@@ -418,6 +419,8 @@ def cyclical_forward(P: Dict[str, Tensor], feats: Dict[str, Tensor], batch: Dict
     fmo = torch.stack(fmo, 1)                                                                 # :278-279
     xt_clamp = torch.clamp(iseq[:, 1:T + 1, 0] - vocab_size, min=0)                           # :282-283
     xt_all = torch.relu(F.embedding(xt_clamp, P["roi_feat_extractor.vis_embed.0.weight"]))   # :284
+    if dropout is not None:
+        xt_all = xt_all * dropout["vis_embed"]                                                # backbone.py:57 in train mode
     bias = P["roi_feat_extractor.vis_classifiers_bias"][xt_clamp].unsqueeze(2).expand(B, T, N)  # :287-288
     ground_w = grounder(xt_all, gpool, fmo[:, :, 1:], bias + att2_w)                          # :293-294
     target = gt[:, 1:T + 1]

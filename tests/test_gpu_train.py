@@ -279,7 +279,7 @@ def _dropout_masks(d, seed, p=0.5):
     g = torch.Generator().manual_seed(seed)
     draw = lambda *shape: torch.bernoulli(torch.full(shape, 1.0 - p), generator=g) / (1.0 - p)
     return dict(emb_a=draw(d.B, d.T, d.E), emb_b=draw(d.B, d.T, d.E), emb_c=draw(d.B, d.T, d.E),
-                out_a=draw(d.T, d.B, d.R), out_c=draw(d.T, d.B, d.R))
+                out_a=draw(d.T, d.B, d.R), out_c=draw(d.T, d.B, d.R), vis_embed=draw(d.B, d.T, d.G))
 
 
 def _train_mode_parity(d, seed, mix, loss_tol, grad_tol=5e-4):
@@ -295,20 +295,20 @@ def _train_mode_parity(d, seed, mix, loss_tol, grad_tol=5e-4):
             P[k] = P[k.replace("attended_roi_decoder_core.", "decoder_core.")]
     ref = O.cyclical_forward(P, O.to_torch(f), O.to_torch(b), T=d.T, vocab_size=d.V, dropout=masks)
     ref_eval = O.cyclical_forward(P, O.to_torch(f), O.to_torch(b), T=d.T, vocab_size=d.V)
-    assert abs(float(ref[0]) - float(ref_eval[0])) > 1e-3          # the masks do change the pass (not an eval-mode rerun)
+    assert abs(float(ref[0].detach()) - float(ref_eval[0].detach())) > 1e-3          # the masks do change the pass (not an eval-mode rerun)
     O.training_loss(ref, xe_loss_weight=mix[0], w_att2=mix[1], w_cls=0.0, caption_consistency_loss_weight=mix[2]).backward()
     model = build_model(d, sd, dev).train()
     used = []
 
     def source(site, shape):
         used.append(site)
-        if site.startswith("emb_"):
+        if site.startswith("emb_") or site == "vis_embed":
             return masks[site].reshape(shape)
         kind, t = site.split(".")
         return masks[kind][int(t)]
     with dropout.injected(source):
         out = model_call(model, to_dev(f, dev), to_dev(b, dev), False)
-    assert sorted(set(used)) == sorted(["emb_a", "emb_b", "emb_c"] + ["out_a.%d" % t for t in range(d.T)] + ["out_c.%d" % t for t in range(d.T)])
+    assert sorted(set(used)) == sorted(["emb_a", "emb_b", "emb_c", "vis_embed"] + ["out_a.%d" % t for t in range(d.T)] + ["out_c.%d" % t for t in range(d.T)])
     for got, want in zip(out, ref):
         assert float(got.detach().mean()) == pytest.approx(float(want.detach().mean()), rel=loss_tol, abs=loss_tol / 10)
     lm, a2, _g, _cls, rec = [x.mean() for x in out]
