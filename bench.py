@@ -383,6 +383,8 @@ def run_encoder(args, d, dev, brief=False, steps=None, warmup=None):
     pool_in = enc.pool_feat_size
     work = {
         # recurrence of one GRU layer, both directions: W_hh once, the input projections of every step read, every h_t written
+        # (2 layers) x (W_hh of both directions once + the input projections of every step read + every h_t written);
+        # flops: h W_hh^T of every step, both directions, both layers
         "cvc_gru_seq_persistent_fwd": dict(bytes=2 * (4 * 2 * 3 * H_ * H_ + 4 * B_ * F_ * 2 * 3 * H_ + 4 * B_ * F_ * 2 * H_), flops=2 * 2 * B_ * F_ * 2 * 3 * H_ * H_),
         "cvc_gru_seq_fwd": dict(bytes=2 * (4 * F_ * 2 * 3 * H_ * H_ + 4 * B_ * F_ * 2 * 3 * H_ + 4 * B_ * F_ * 2 * H_), flops=2 * 2 * B_ * F_ * 2 * 3 * H_ * H_),
         # every dense product of the forward on the tile GEMM: GRU input projections (2 layers), frame embeddings, ctx2att_fc, region side

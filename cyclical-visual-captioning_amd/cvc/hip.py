@@ -139,6 +139,9 @@ SIGNATURES = {
     "cvc_tile_pack_cols": [_P, _LL, _I, _I, _P, _LL, _P],
     "cvc_tile_reorder_pack": [_P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _LL, _P, _LL, _I, _I, _P],
     "cvc_attn_wsum_frag": [C.POINTER(AttnSet), _I, _I, _I, _I, _P, _LL, _P],
+    "cvc_class_softmax_fwd": [_P, _LL, _P, _P, _I, _I, _I, _P, _P, _P],
+    "cvc_layernorm_cat_fwd": [C.POINTER(_P), C.POINTER(_LL), C.POINTER(_I), _I, _LL, _F, _P, _LL, _P],
+    "cvc_frame_embed_fwd": [_P, _P, _I, _P, _P, _I, _P, _P, _LL, _P, _P],
     "cvc_decode_plan_create": [C.POINTER(DecodeDesc), C.POINTER(C.c_void_p)],
     "cvc_decode_plan_destroy": [_P],
     "cvc_decode_plan_set_features": [_P, _P, _P, _P, _P, _P, _P],

@@ -27,7 +27,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .. import dense, hip, gru as gru_hip
+from .. import dense, encoder_ops, hip, gru as gru_hip
 
 HIP_GRU = True     # inference: frame-context GRU on the HIP kernels (cvc/gru.py); False = the library module everywhere
 
@@ -163,11 +163,23 @@ class RegionalFeatureExtractorGVD(nn.Module):
 
         fc = segs_feat.mean(dim=1)
         seg_info = self.seg_info_embed(num[:, 3:7].float())
-        fc_feats = torch.cat((F.layer_norm(fc, [self.fc_feat_size - SEG_INFO_SIZE]),
-                              F.layer_norm(seg_info, [SEG_INFO_SIZE])), dim=-1)
+        # inference on the GPU: the fused kernels of csrc/encoder_ops.hip
+        fused = encoder_ops.usable(region_feats, self) and segs_feat.dtype == torch.float32
+        if not fused and region_feats.is_cuda and not torch.is_grad_enabled():
+            hip.warn_once("encoder-ops-library", "the encoder's class-similarity softmax / layer norms / frame-embedding epilogue run "
+                          "on library kernels (module in train() mode or non-fp32 input)")
+        if fused:
+            fc_feats = encoder_ops.layernorm_cat([fc.float(), seg_info])
+        else:
+            fc_feats = torch.cat((F.layer_norm(fc, [self.fc_feat_size - SEG_INFO_SIZE]),
+                                  F.layer_norm(seg_info, [SEG_INFO_SIZE])), dim=-1)
 
         g_pool_feats = project_and_mask(region_feats, self.ctx2pool_grd, keep)
-        sim = self.class_similarity(g_pool_feats, pnt_mask[:, 1:])
+        sim_rows = None
+        if fused:
+            sim, sim_rows = encoder_ops.class_similarity(self, g_pool_feats, pnt_mask[:, 1:])
+        else:
+            sim = self.class_similarity(g_pool_feats, pnt_mask[:, 1:])
 
         if self.test_mode:
             cls_pred, cls_loss = 0, torch.zeros(1, device=dev)
@@ -178,10 +190,13 @@ class RegionalFeatureExtractorGVD(nn.Module):
         if not self.enable_BUTD:
             loc = torch.cat((proposals[:, :, :4] / 720., proposals[:, :, 4:5] / float(self.num_sampled_frm)), dim=2)
             loc_feats = self.loc_fc(loc.detach())
-            label_feat = sim.transpose(1, 2)
-            pool_feats = torch.cat((F.layer_norm(g_pool_feats, [g_pool_feats.size(-1)]),
-                                    F.layer_norm(loc_feats, [GLOVE_DIM]),
-                                    F.layer_norm(label_feat, [label_feat.size(-1)])), dim=2)
+            if fused:
+                pool_feats = encoder_ops.layernorm_cat([g_pool_feats, loc_feats, sim_rows])
+            else:
+                label_feat = sim.transpose(1, 2)
+                pool_feats = torch.cat((F.layer_norm(g_pool_feats, [g_pool_feats.size(-1)]),
+                                        F.layer_norm(loc_feats, [GLOVE_DIM]),
+                                        F.layer_norm(label_feat, [label_feat.size(-1)])), dim=2)
 
         def per_caption(x):
             return x if S == 1 else x.repeat_interleave(S, dim=0)
@@ -222,8 +237,11 @@ class RegionalFeatureExtractorGVD(nn.Module):
 
         if self.att_input_mode in ('both', 'featmap'):
             rgb, motion = conv_feats[..., :RGB_DIM], conv_feats[..., RGB_DIM:RGB_DIM + MOTION_DIM]
-            x = torch.cat((dense.apply(self.att_embed[0], rgb), dense.apply(self.att_embed[1], motion)), dim=2)
-            x = self.att_embed_aux(x.transpose(1, 2)).transpose(1, 2).contiguous()      # BatchNorm1d over channels
+            if encoder_ops.usable(conv_feats, self) and dense.usable(rgb) and (self.rnn_size // 2) % 4 == 0:
+                x = encoder_ops.frame_embed(self, rgb, motion)              # GEMMs + one fused epilogue (BN folded)
+            else:
+                x = torch.cat((dense.apply(self.att_embed[0], rgb), dense.apply(self.att_embed[1], motion)), dim=2)
+                x = self.att_embed_aux(x.transpose(1, 2)).transpose(1, 2).contiguous()      # BatchNorm1d over channels
             x = self._frame_context(x)
             x = x.masked_fill(sample_idx_mask, 0)
             conv_feats = x if self.seq_per_img == 1 else x.repeat_interleave(self.seq_per_img, dim=0)

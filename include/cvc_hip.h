@@ -505,6 +505,25 @@ int cvc_attn_wsum_frag(const cvc_attn_set* sets, int nsets, int nclip, int nq, i
                        long long frag_mblk_stride, cvc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Once-per-clip encoder, inference (model/backbone.py:189-351): the small fused pieces between its
+ * dense products (cvc_tile_gemm) and its frame-context GRU (cvc_gru_seq_*).
+ */
+/* Class similarity (backbone.py:222-235): logits [B*N, ld_logits] = region features x class table^T (a cvc_tile_gemm product);
+ * + bias[C] (nullable); regions with pad[b, n] != 0 filled with -1e8 in every class; softmax over the C classes;
+ * out [B, C, N] (the reference's layout) and, if asked, out_rows [B*N, C] (what the region features concatenate, :274-277). */
+int cvc_class_softmax_fwd(const float* logits, long long ld_logits, const float* bias, const uint8_t* pad, int B, int N,
+                          int C, float* out, float* out_rows, cvc_stream_t stream);
+/* out[row, :] = [ F.layer_norm(x_0[row], [d_0]) | ... ] for up to three inputs (no affine, biased variance, eps):
+ * backbone.py:215-216 (fc | seg_info) and :274-277 (region | location | class-probability features). */
+int cvc_layernorm_cat_fwd(const float* const* xs, const long long* ldx, const int* widths, int nseg, long long rows, float eps,
+                          float* out, long long ld_out, cvc_stream_t stream);
+/* Frame embeddings (backbone.py:325-333) after their two dense products y0 [rows, c0], y1 [rows, c1] (bias-free):
+ * out [rows, c0 + c1] = relu( scale * cat(relu(y0 + b0), relu(y1 + b1)) + shift ), scale / shift = BatchNorm1d in eval mode
+ * folded per channel (gamma / sqrt(running_var + eps), beta - running_mean * scale).  c0, c1 % 4 == 0. */
+int cvc_frame_embed_fwd(const float* y0, const float* b0, int c0, const float* y1, const float* b1, int c1, const float* scale,
+                        const float* shift, long long rows, float* out, cvc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Whole-decode drivers: the T-step sampler of model/captioner.py:384-443 (`_sample`: exactly T decoder steps from BOS,
  * top-2 with UNK suppression, no EOS early exit) and its beam-search counterpart (build-defined) as ONE
  * host call that enqueues every launch of the decode on the caller's stream -- no Python in the loop, no allocation, no host

@@ -351,11 +351,11 @@ def test_encoder_with_hip_gru_matches_library_gru_forward_and_backward(tmp_path)
     inp = to_dev(synth.encoder_inputs(Dw, 3), torch.device("cuda:0"))
     from cvc.misc import utils
     overlaps = utils.bbox_overlaps(inp["proposals"], inp["gt_bboxs"], inp["frm_mask"] | inp["pnt_mask_in"][:, 1:].unsqueeze(-1))
-    from cvc import dense
+    from cvc import dense, encoder_ops
     res = {}
     for hip_gru in (True, False):
         backbone.HIP_GRU = hip_gru
-        dense.ENABLED = hip_gru                     # ... and its dense layers on the tile GEMM (cvc/dense.py) vs the library
+        dense.ENABLED = encoder_ops.ENABLED = hip_gru   # ... and its dense layers / fused pieces on the own kernels vs the library
         min_rows, dense.MIN_ROWS = dense.MIN_ROWS, 8      # (this test's 45 rows would otherwise stay on the library kernels)
         try:
             with torch.no_grad():
@@ -368,7 +368,7 @@ def test_encoder_with_hip_gru_matches_library_gru_forward_and_backward(tmp_path)
             res[hip_gru] = (out_inf, out, {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None})
         finally:
             backbone.HIP_GRU = True
-            dense.ENABLED = True
+            dense.ENABLED = encoder_ops.ENABLED = True
             dense.MIN_ROWS = min_rows
     for a, b in ((res[True][0], res[False][0]), (res[True][1], res[False][1])):
         for name, x, y in zip(OUT, a, b):
@@ -432,8 +432,10 @@ def test_encoder_packs_follow_weight_updates_that_bypass_version_counters(tmp_pa
     overlaps = utils.bbox_overlaps(inp["proposals"], inp["gt_bboxs"], inp["frm_mask"] | inp["pnt_mask_in"][:, 1:].unsqueeze(-1))
     min_rows, dense.MIN_ROWS = dense.MIN_ROWS, 8
     try:
+        from cvc import encoder_ops
+
         def evaluate(hip_path):
-            backbone.HIP_GRU, dense.ENABLED = hip_path, hip_path
+            backbone.HIP_GRU, dense.ENABLED, encoder_ops.ENABLED = hip_path, hip_path, hip_path
             with torch.no_grad():
                 return [x.clone() for x in run_encoder(enc, inp, overlaps)[:6]]
         first = evaluate(True)
@@ -456,3 +458,87 @@ def test_encoder_packs_follow_weight_updates_that_bypass_version_counters(tmp_pa
             np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=2e-4, atol=2e-5, err_msg=name)
     finally:
         backbone.HIP_GRU, dense.ENABLED, dense.MIN_ROWS = True, True, min_rows
+        encoder_ops.ENABLED = True
+
+
+# ------------------------------------------------------------------ fused inference pieces (csrc/encoder_ops.hip)
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,C,G", [(64, 100, 432, 2048), (3, 7, 7, 24), (5, 33, 100, 36)])
+def test_class_similarity_softmax_kernel(B, N, C, G):
+    """logits (tile GEMM) + bias + pad fill + softmax over classes, in both layouts, against the torch formulation of
+    backbone.py:222-235 (fp64); padded regions come out uniform (-1e8 in every class), as in the reference."""
+    from cvc import hip
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B + C)
+    feats = torch.randn(B, N, G, generator=g).to(dev)
+    table = torch.randn(C, G, generator=g).to(dev) * 0.3
+    bias = torch.randn(C, generator=g).to(dev)
+    pad = (torch.rand(B, N, generator=g) < 0.3).to(dev)
+    logits = hip.tile_mm(feats.reshape(B * N, G), hip.TileOperand(table))
+    sim, rows = torch.empty(B, C, N, device=dev), torch.empty(B, N, C, device=dev)
+    hip._check(hip.lib().cvc_class_softmax_fwd(logits.data_ptr(), C, bias.data_ptr(), hip._mask(pad).data_ptr(), B, N, C, sim.data_ptr(),
+                                               rows.data_ptr(), hip._stream()), "cvc_class_softmax_fwd")
+    ref = torch.matmul(table.double(), feats.double().transpose(1, 2)) + bias.double().view(1, -1, 1)
+    ref = torch.softmax(ref.masked_fill(pad.unsqueeze(1), -1e8), dim=1)
+    # (a probability's relative error is the ABSOLUTE error of its logit: |logit| reaches ~40 here, fp32 products over K = 2048)
+    np.testing.assert_allclose(sim.cpu().numpy(), ref.float().cpu().numpy(), rtol=2e-4, atol=1e-7)
+    assert torch.equal(rows, sim.transpose(1, 2).contiguous())
+    np.testing.assert_allclose(sim[pad.unsqueeze(1).expand(B, C, N)].cpu().numpy(), 1.0 / C, rtol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,widths", [(6400, (2048, 300, 432)), (64, (3072, 4)), (5, (7,)), (33, (24, 300, 7))])
+def test_layernorm_concat_kernel(rows, widths):
+    from cvc import encoder_ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(rows)
+    xs = [(torch.randn(rows, w, generator=g) * (1 + i) + i).to(dev) for i, w in enumerate(widths)]
+    got = encoder_ops.layernorm_cat(xs)
+    ref = torch.cat([torch.nn.functional.layer_norm(x.double(), [x.shape[-1]]) for x in xs], -1)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.float().cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_encoder_forward_wide_golden_on_the_hip_forms(tmp_path):
+    """The reference encoder's own eval outputs at rnn_size 256 (tests/golden/g8_encoder_wide.npz, tools/make_golden.py g8) against
+    the mirror on the GPU with every HIP form active: persistent GRU recurrence (H = 128), frame / region rows on the tile GEMM,
+    fused class-similarity softmax, layer norms + concat, frame-embedding epilogue with the folded BatchNorm."""
+    import dataclasses
+    from cvc import dense, gru as gru_hip
+    from cvc.model.backbone import RegionalFeatureExtractorGVD
+    g8 = Golden("g8_encoder_wide.npz")
+    Dw = dataclasses.replace(D, B=5, N=20, F=9, R=256, A=64, E=32, K=3)
+    seed = int(g8["meta.seed"])
+    tables = synth.detectron_tables(Dw, seed)
+    dev = torch.device("cuda:0")
+    inp = to_dev(synth.encoder_inputs(Dw, seed), dev)
+    from cvc.misc import utils
+    overlaps = utils.bbox_overlaps(inp["proposals"], inp["gt_bboxs"], inp["frm_mask"] | inp["pnt_mask_in"][:, 1:].unsqueeze(-1))
+    min_rows, dense.MIN_ROWS = dense.MIN_ROWS, 8
+    try:
+        for name, over in (("train.", {}), ("test.", dict(test_mode=True))):
+            o = make_opts(Dw, seq_per_img=1, enable_BUTD=False, att_input_mode="both", num_sampled_frm=4, finetune_cnn=False,
+                          att_feat_size=Dw.G, fc_feat_size=synth.SEG_FEAT_DIM, t_attn_size=Dw.F, second_drop_prob=0.3, att_model="topdown",
+                          t_attn_mode="bigru", itod={i + 1: "d%d" % i for i in range(Dw.DET)},
+                          vg_cls=["vg%d" % i for i in range(tables["glove_vg_cls"].shape[0])],
+                          glove_clss=torch.from_numpy(tables["glove_clss"]), glove_vg_cls=torch.from_numpy(tables["glove_vg_cls"]),
+                          detectron_tables=tables, **dict(dict(test_mode=False), **over))
+            enc = RegionalFeatureExtractorGVD(o)
+            ctor = {k: v.detach().clone() for k, v in enc.state_dict().items() if k in synth.ENCODER_CTOR_KEYS}
+            enc.load_state_dict({k: (ctor[k] if k in ctor else torch.from_numpy(np.asarray(synth.encoder_fill(k, v.shape, seed))))
+                                 for k, v in enc.state_dict().items()})
+            enc = enc.to(dev).eval()
+            gru_hip.last_form = None
+            with torch.no_grad():
+                res = run_encoder(enc, inp, overlaps)
+            assert gru_hip.last_form == "persistent"                       # the HIP recurrence ran (not the library module)
+            assert getattr(enc, "_cvc_class_table", None) is not None and getattr(enc, "_cvc_bn_fold", None) is not None   # fused pieces ran
+            for k, x in zip(OUT, res[:8]):
+                want = g8[name + "out." + k]
+                if x.dtype.is_floating_point:
+                    np.testing.assert_allclose(x.cpu().numpy(), want, rtol=2e-4, atol=2e-5, err_msg=name + k)
+                else:
+                    np.testing.assert_array_equal(x.cpu().numpy(), want, err_msg=name + k)
+            np.testing.assert_allclose(res[9].cpu().numpy(), g8[name + "out.cls_loss"], rtol=2e-4, atol=1e-6)
+    finally:
+        dense.MIN_ROWS = min_rows

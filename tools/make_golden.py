@@ -441,6 +441,34 @@ def g5_encoder(path):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+WIDE = dict(B=5, N=20, F=9, R=256, A=64, E=32, K=3)      # encoder widths at which the HIP forms run (GRU hidden size 128)
+
+
+def g8_encoder_wide(path):
+    """The reference encoder's eval forward at a width the build's HIP kernels take (rnn_size 256 -> GRU hidden size 128: the
+    persistent recurrence; frame / region rows on the tile GEMM; the fused class-similarity, layer-norm and frame-embedding
+    kernels): outputs only, both test_mode settings.  Inputs and weights come from cvc.synth (same seed) on the test side."""
+    import dataclasses
+    import misc.utils as ref_utils
+    d = dataclasses.replace(synth.CONFIGS["tiny"], **WIDE)
+    seed = 1239
+    tables = synth.detectron_tables(d, seed)
+    inp = synth.encoder_inputs(d, seed)
+    out = OrderedDict()
+    out["meta.seed"] = np.asarray(seed)
+    bt = {k: t(v) for k, v in inp.items()}
+    overlaps = ref_utils.bbox_overlaps(bt["proposals"], bt["gt_bboxs"], (bt["frm_mask"] | bt["pnt_mask_in"][:, 1:].unsqueeze(-1)))
+    for name, over in (("train.", {}), ("test.", dict(test_mode=True))):
+        enc, ctor = build_reference_encoder(d, tables, seed, 1, **over)
+        with torch.no_grad():
+            res = enc(bt["segs_feat"], bt["proposals"], bt["num"], bt["box_mask"], bt["region_feats"], bt["gt_bboxs"], overlaps,
+                      bt["sample_idx"])
+        put(out, name + "out.", dict(zip(ENC_OUT, res[:8])))
+        out[name + "out.cls_loss"] = res[9].detach().numpy()
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
 def g6_dataloader(path):
     """The reference's misc/dataloader_anet.py::DataLoader itself, run over the tiny synthetic dataset of
     cvc.data_fixture (written in the reference's own file formats), with stand-ins ONLY for the third-party modules this
@@ -558,7 +586,8 @@ if __name__ == "__main__":
             "g4": lambda: g4_config_surface(os.path.join(gdir, "config_surface.json")),
             "g5": lambda: g5_encoder(os.path.join(gdir, "g5_encoder.npz")),
             "g6": lambda: g6_dataloader(os.path.join(gdir, "g6_dataloader.npz")),
-            "g7": lambda: g7_sentinel(os.path.join(gdir, "g7_sentinel.npz"))}
+            "g7": lambda: g7_sentinel(os.path.join(gdir, "g7_sentinel.npz")),
+            "g8": lambda: g8_encoder_wide(os.path.join(gdir, "g8_encoder_wide.npz"))}
     for name, job in jobs.items():
         if not only or name in only:
             job()
