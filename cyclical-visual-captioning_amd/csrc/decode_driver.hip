@@ -201,13 +201,21 @@ int run_tile(cvc_decode_plan* p, hipStream_t st) {
                                    4 * R, st));
     void* xl_hatt = frag_off(d.xlf, R);
     void* xl_hlang = frag_off(d.xlf, 2 * R);
-    CVC_TRY(cvc_tile_reorder_pack(nullptr, d.words, beam, d.zero_state, d.zero_state, d.zero_state, d.zero_state, d.embed, E, V,
+    // embedding-gate form (d.emb_gate): XA = [h_lang | h_att], the word's share of the gates is added by the finishing launch
+    const bool eg = d.emb_gate != nullptr;
+    const int E_pack = eg ? 0 : E, ka = 2 * R + E_pack;
+    CVC_TRY(cvc_tile_reorder_pack(nullptr, d.words, beam, d.zero_state, d.zero_state, d.zero_state, d.zero_state, d.embed, E_pack, V,
                                   d.c_att_prev, d.c_lang_prev, d.xaf, d.xaf_stride, xl_hlang, d.xlf_stride, rows, R, st));
     const long long gs = (long long)rows * 4 * R;
     for (int t = 0; t < d.T; ++t) {
-        CVC_TRY(cvc_tile_gemm(d.w_att, d.xaf, d.xaf_stride, 2 * R + E, rows, 4 * R, d.ks_gate, d.parts_gate, 4 * R, gs, st));
-        CVC_TRY(cvc_tile_lstm_finish(d.parts_gate, d.ks_gate, gs, nullptr, nullptr, d.gate_fc, beam, d.c_att_prev, rows, R, d.c_att,
-                                     d.h_att, xl_hatt, d.xlf_stride, nullptr, 0, st));
+        CVC_TRY(cvc_tile_gemm(d.w_att, d.xaf, d.xaf_stride, ka, rows, 4 * R, d.ks_gate, d.parts_gate, 4 * R, gs, st));
+        if (eg)
+            CVC_TRY(cvc_tile_lstm_finish_embgate(d.parts_gate, d.ks_gate, gs, nullptr, nullptr, d.gate_fc, beam, d.emb_gate,
+                                                 d.words + (size_t)t * rows, V, d.c_att_prev, rows, R, d.c_att, d.h_att, xl_hatt,
+                                                 d.xlf_stride, nullptr, 0, st));
+        else
+            CVC_TRY(cvc_tile_lstm_finish(d.parts_gate, d.ks_gate, gs, nullptr, nullptr, d.gate_fc, beam, d.c_att_prev, rows, R, d.c_att,
+                                         d.h_att, xl_hatt, d.xlf_stride, nullptr, 0, st));
         CVC_TRY(cvc_tile_gemm(d.w_h, xl_hatt, d.xlf_stride, R, rows, A, d.ks_q, d.q_parts, A, (long long)rows * A, st));
         CVC_TRY(cvc_tile_linear_finish(d.q_parts, d.ks_q, (long long)rows * A, A, d.b_h, nullptr, rows, A, d.q, A, st));
         cvc_attn_set sets[2];
@@ -234,7 +242,7 @@ int run_tile(cvc_decode_plan* p, hipStream_t st) {
             parent = par;
         }
         if (t + 1 < d.T)
-            CVC_TRY(cvc_tile_reorder_pack(parent, word_next, beam, d.h_att, d.c_att, d.h_lang, d.c_lang, d.embed, E, V, d.c_att_prev,
+            CVC_TRY(cvc_tile_reorder_pack(parent, word_next, beam, d.h_att, d.c_att, d.h_lang, d.c_lang, d.embed, E_pack, V, d.c_att_prev,
                                           d.c_lang_prev, d.xaf, d.xaf_stride, xl_hlang, d.xlf_stride, rows, R, st));
     }
     p->launches = n;

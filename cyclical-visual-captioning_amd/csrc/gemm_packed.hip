@@ -54,7 +54,7 @@ struct PackedArgs {
     float* gru_y[2];          // this step's output rows of direction d: row m at + m * gru_y_ld, H columns
     long long gru_y_ld;
     // embedding-gate table (cvc_packed_lstm_embgate_fwd): the embedded word's share of the gates is a row gather, not a GEMM
-    const float* emb_gate;    // [V][R/8][32] = W_ih[:, emb columns] x relu(Emb[v]) in packed gate-row order, or null
+    const float* emb_gate;    // [V][4R] = relu(Emb[v]) x W_ih[:, emb columns]^T, checkpoint gate order (gate * R + unit), or null
     const int64_t* word;      // [M] the word of every batch row
     // word selection fused into the vocabulary projection (cvc_packed_linear_select_fwd): the last workgroup to arrive merges the
     // per-block top-2 records of all rows
@@ -169,9 +169,10 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
         if (a.emb_gate != nullptr && tid < NB * 2 * 64) {
             const int em0 = tid & 63;
             const long long eword = a.word[em0 < a.M ? em0 : a.M - 1];
-            const float* trow = a.emb_gate + (size_t)eword * 4 * a.R + (size_t)((int)blockIdx.x * NB + (tid >> 7)) * 32 + ((tid >> 6) & 1) * 4;
+            // table in checkpoint order [V][4R]: gate g of hidden unit u at g * R + u
+            const float* trow = a.emb_gate + (size_t)eword * 4 * a.R + (size_t)((int)blockIdx.x * NB + (tid >> 7)) * 8 + ((tid >> 6) & 1) * 4;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) eadd4[g] = ld4(trow + g * 8);
+            for (int g = 0; g < 4; ++g) eadd4[g] = ld4(trow + (size_t)g * a.R);
         }
     }
 
@@ -616,11 +617,29 @@ extern "C" int cvc_packed_lstm_late_fwd(const float* wp, long long w_blk_stride,
     return cvc_launch_status();
 }
 
+static int packed_lstm_train_impl(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh, const float* gate_pre,
+                                  const float* c_prev, int M, int R, float* h_out, float* c_out, float* gates_out, float* h_out2,
+                                  float* h_out3, cvc_stream_t stream);
+
 extern "C" int cvc_packed_lstm_train_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
                                          const float* c_prev, int M, int R, float* h_out, float* c_out, float* gates_out,
                                          float* h_out2, float* h_out3, cvc_stream_t stream) {
+    return packed_lstm_train_impl(wp, xq, K, b_ih, b_hh, nullptr, c_prev, M, R, h_out, c_out, gates_out, h_out2, h_out3, stream);
+}
+
+extern "C" int cvc_packed_lstm_train_pre_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
+                                             const float* gate_pre, const float* c_prev, int M, int R, float* h_out, float* c_out,
+                                             float* gates_out, float* h_out2, float* h_out3, cvc_stream_t stream) {
+    if (!gate_pre) return CVC_E_BADARG;
+    return packed_lstm_train_impl(wp, xq, K, b_ih, b_hh, gate_pre, c_prev, M, R, h_out, c_out, gates_out, h_out2, h_out3, stream);
+}
+
+static int packed_lstm_train_impl(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh, const float* gate_pre,
+                                  const float* c_prev, int M, int R, float* h_out, float* c_out, float* gates_out, float* h_out2,
+                                  float* h_out3, cvc_stream_t stream) {
     if (!wp || !xq || !c_prev || !h_out || !c_out || (K & 31) || R < 8 || (R & 7)) return CVC_E_BADARG;
     PackedArgs a{};
+    a.gate_bias = gate_pre;
     a.h_rm2 = h_out2; a.h_rm3 = h_out3;
     a.wp = wp; a.xq = xq; a.nquad = K / 4; a.M = M; a.Nout = 4 * R; a.R = R;
     a.bias = b_ih; a.bias2 = b_hh; a.c_prev_rm = c_prev; a.h_rm = h_out; a.c_rm = c_out; a.gates_rm = gates_out; a.ksplit = 1;
@@ -678,9 +697,11 @@ extern "C" int cvc_gru_seq_fwd(const float* wp, const float* gi, long long gi_ld
 namespace {
 
 struct PackWArgs {
-    const float* w_ih; const float* w_hh;   // [4R, K_ih], [4R, K_hh] row-major (the checkpoint layout)
-    int K_ih, K_hh, R;
-    float* wp;                              // [R/8][(K_ih + K_hh)/4][32][4]
+    const float* w[4];                      // up to 4 column ranges [4R, width_s] (pointer at the range's first column), row-major
+    long long ld[4];                        // leading dimension of the matrix each range lives in
+    int q_end[4];                           // running quad count after each range
+    int nseg, R;
+    float* wp;                              // [R/8][sum width_s / 4][32][4]
 };
 
 // one workgroup: the 32 gate rows of one block x 64 quads, transposed through LDS so that both the reads (1 KB runs of a
@@ -689,15 +710,18 @@ __global__ __launch_bounds__(256) void pack_lstm_w_kernel(PackWArgs a) {
     __shared__ f32x4 tile[64][33];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int blk = blockIdx.x, q0 = blockIdx.y * 64;
-    const int nquad = (a.K_ih + a.K_hh) >> 2, q = q0 + lane;
+    const int nquad = a.q_end[a.nseg - 1], q = q0 + lane;
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) s += (i < a.nseg - 1 && q >= a.q_end[i]) ? 1 : 0;
+    const int qs = q - (s ? a.q_end[s - 1] : 0);
+    const float* src = s == 0 ? a.w[0] : (s == 1 ? a.w[1] : (s == 2 ? a.w[2] : a.w[3]));
+    const long long ld = s == 0 ? a.ld[0] : (s == 1 ? a.ld[1] : (s == 2 ? a.ld[2] : a.ld[3]));
 #pragma unroll
     for (int r = wave; r < 32; r += 4) {
         const size_t n = (size_t)(r >> 3) * a.R + blk * 8 + (r & 7);
         f32x4 v = {0, 0, 0, 0};
-        if (q < nquad) {
-            const int k = q * 4;
-            v = k < a.K_ih ? ld4(a.w_ih + n * a.K_ih + k) : ld4(a.w_hh + n * a.K_hh + (k - a.K_ih));
-        }
+        if (q < nquad) v = ld4(src + n * ld + qs * 4);
         tile[lane][r] = v;
     }
     __syncthreads();
@@ -733,14 +757,30 @@ __global__ __launch_bounds__(256) void pack_quad_segs_kernel(PackXArgs a) {
 
 }  // namespace
 
+extern "C" int cvc_pack_lstm_segs(const float* const* ws, const long long* lds, const int* widths, int nseg, int R, float* wp,
+                                  cvc_stream_t stream) {
+    if (!ws || !lds || !widths || !wp || nseg < 1 || nseg > 4 || R < 8 || (R & 7)) return CVC_E_BADARG;
+    PackWArgs a{};
+    int q = 0;
+    for (int s = 0; s < nseg; ++s) {
+        if (!ws[s] || widths[s] < 4 || (widths[s] & 3) || lds[s] < widths[s] || (lds[s] & 3) || ((uintptr_t)ws[s] & 15)) return CVC_E_BADARG;
+        q += widths[s] / 4;
+        a.w[s] = ws[s]; a.ld[s] = lds[s]; a.q_end[s] = q;
+    }
+    if (q & 7) return CVC_E_BADARG;                              // K a multiple of 32
+    a.nseg = nseg; a.R = R; a.wp = wp;
+    hipLaunchKernelGGL(pack_lstm_w_kernel, dim3(R / 8, (q + 63) / 64), dim3(256), 0, (hipStream_t)stream, a);
+    return cvc_launch_status();
+}
+
 extern "C" int cvc_pack_lstm_weights(const float* w_ih, int K_ih, const float* w_hh, int K_hh, int R, float* wp,
                                      cvc_stream_t stream) {
     if (!w_ih || !w_hh || !wp || K_ih < 4 || K_hh < 4 || (K_ih & 3) || (K_hh & 3) || ((K_ih + K_hh) & 31) || R < 8 || (R & 7))
         return CVC_E_BADARG;
-    PackWArgs a{w_ih, w_hh, K_ih, K_hh, R, wp};
-    const int nquad = (K_ih + K_hh) / 4;
-    hipLaunchKernelGGL(pack_lstm_w_kernel, dim3(R / 8, (nquad + 63) / 64), dim3(256), 0, (hipStream_t)stream, a);
-    return cvc_launch_status();
+    const float* ws[2] = {w_ih, w_hh};
+    const long long lds[2] = {K_ih, K_hh};
+    const int widths[2] = {K_ih, K_hh};
+    return cvc_pack_lstm_segs(ws, lds, widths, 2, R, wp, stream);
 }
 
 extern "C" int cvc_pack_quad_segs(const float* const* xs, const long long* ldx, const int* widths, int nseg, int M, float* xq,

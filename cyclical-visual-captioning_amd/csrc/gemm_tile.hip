@@ -379,6 +379,7 @@ struct LstmFinishArgs {
     uint16_t* frag1; long long frag1_stride;                 // h' as activation fragments (pointer at its first k step), nullable
     uint16_t* frag2; long long frag2_stride;
     int M, R;
+    const float* emb_gate; const int64_t* word; int V;       // embedding-gate table [V, 4R] checkpoint order + the row's word; nullable
 };
 
 // Wide-wave form of tile_gemm_ld_kernel: 4 computing waves, each 2 weight blocks x MH row tiles (2 x MH accumulator tiles),
@@ -576,6 +577,14 @@ __global__ __launch_bounds__(256) void tile_lstm_finish_kernel(LstmFinishArgs a)
 #pragma unroll
         for (int g = 0; g < 4; ++g) gbv[g] = ld4(gb + g * R);
     }
+    f32x4 egv[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (a.emb_gate != nullptr) {                              // the embedded word's share of the gates: a table row, not a GEMM
+        long long w = a.word[m];
+        if (w < 0 || w >= a.V) w = 0;
+        const float* eg = a.emb_gate + (size_t)w * 4 * R + j;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) egv[g] = ld4(eg + g * R);
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         pre[g] = v[g][0];
@@ -588,7 +597,7 @@ __global__ __launch_bounds__(256) void tile_lstm_finish_kernel(LstmFinishArgs a)
             for (int g = 0; g < 4; ++g) pre[g] += ld4(src + g * 8 + (size_t)p * a.part_stride);
     }
 #pragma unroll
-    for (int g = 0; g < 4; ++g) pre[g] = ((pre[g] + bi[g]) + bh[g]) + gbv[g];      // (an absent term adds an exact zero)
+    for (int g = 0; g < 4; ++g) pre[g] = (((pre[g] + bi[g]) + bh[g]) + gbv[g]) + egv[g];      // (an absent term adds an exact zero)
     const f32x4 cp = cp0;
     f32x4 hv, cv;
 #pragma unroll
@@ -813,12 +822,36 @@ extern "C" int cvc_tile_rows_alloc(int M) {
     return chunks * 2 * MH * 32;
 }
 
+static int tile_lstm_finish_impl(const float* parts, int nparts, long long part_stride, const float* b_ih, const float* b_hh,
+                                 const float* gate_bias, int gb_div, const float* c_prev, int M, int R, float* c_out,
+                                 float* h_out, void* frag1, long long frag1_stride, void* frag2, long long frag2_stride,
+                                 const float* emb_gate, const int64_t* word, int V, cvc_stream_t stream);
+
 extern "C" int cvc_tile_lstm_finish(const float* parts, int nparts, long long part_stride, const float* b_ih, const float* b_hh,
                                     const float* gate_bias, int gb_div, const float* c_prev, int M, int R, float* c_out,
                                     float* h_out, void* frag1, long long frag1_stride, void* frag2, long long frag2_stride,
                                     cvc_stream_t stream) {
+    return tile_lstm_finish_impl(parts, nparts, part_stride, b_ih, b_hh, gate_bias, gb_div, c_prev, M, R, c_out, h_out, frag1, frag1_stride,
+                                 frag2, frag2_stride, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int cvc_tile_lstm_finish_embgate(const float* parts, int nparts, long long part_stride, const float* b_ih,
+                                            const float* b_hh, const float* gate_bias, int gb_div, const float* emb_gate,
+                                            const int64_t* word, int V, const float* c_prev, int M, int R, float* c_out,
+                                            float* h_out, void* frag1, long long frag1_stride, void* frag2,
+                                            long long frag2_stride, cvc_stream_t stream) {
+    if (!emb_gate || !word || V < 1) return CVC_E_BADARG;
+    return tile_lstm_finish_impl(parts, nparts, part_stride, b_ih, b_hh, gate_bias, gb_div, c_prev, M, R, c_out, h_out, frag1, frag1_stride,
+                                 frag2, frag2_stride, emb_gate, word, V, stream);
+}
+
+static int tile_lstm_finish_impl(const float* parts, int nparts, long long part_stride, const float* b_ih, const float* b_hh,
+                                 const float* gate_bias, int gb_div, const float* c_prev, int M, int R, float* c_out,
+                                 float* h_out, void* frag1, long long frag1_stride, void* frag2, long long frag2_stride,
+                                 const float* emb_gate, const int64_t* word, int V, cvc_stream_t stream) {
     if (!parts || nparts < 1 || !c_prev || !c_out || M < 1 || R < 16 || (R & 15) || gb_div < 1) return CVC_E_BADARG;
     LstmFinishArgs a;
+    a.emb_gate = emb_gate; a.word = word; a.V = V;
     a.parts = parts; a.nparts = nparts; a.part_stride = part_stride; a.b_ih = b_ih; a.b_hh = b_hh; a.gate_bias = gate_bias;
     a.gb_div = gb_div; a.c_prev = c_prev; a.c_out = c_out; a.h_out = h_out; a.frag1 = (uint16_t*)frag1; a.frag1_stride = frag1_stride;
     a.frag2 = (uint16_t*)frag2; a.frag2_stride = frag2_stride; a.M = M; a.R = R;
@@ -883,9 +916,11 @@ extern "C" int cvc_tile_reorder_pack(const int64_t* parent, const int64_t* word,
                                      const float* h_lang, const float* c_lang, const float* table, int E, int V,
                                      float* c_att_prev, float* c_lang_prev, void* xa, long long xa_stride, void* xl_hlang,
                                      long long xl_stride, int rows, int R, cvc_stream_t stream) {
-    if (!word || !h_att || !c_att || !h_lang || !c_lang || !table || !c_att_prev || !c_lang_prev || !xa || !xl_hlang)
+    // E == 0 (table may then be null): xa = [h_lang | h_att] only -- the embedding-gate form, where the word enters through
+    // cvc_tile_lstm_finish_embgate
+    if (!word || !h_att || !c_att || !h_lang || !c_lang || (!table && E != 0) || !c_att_prev || !c_lang_prev || !xa || !xl_hlang)
         return CVC_E_BADARG;
-    if (rows < 1 || beam < 1 || R < 16 || (R & 15) || E < 16 || (E & 15) || V < 1) return CVC_E_BADARG;
+    if (rows < 1 || beam < 1 || R < 16 || (R & 15) || E < 0 || (E & 15) || V < 1) return CVC_E_BADARG;
     ReorderArgs a;
     a.parent = parent; a.word = word; a.beam = beam; a.h_att = h_att; a.c_att = c_att; a.h_lang = h_lang; a.c_lang = c_lang;
     a.table = table; a.E = E; a.V = V; a.c_att_prev = c_att_prev; a.c_lang_prev = c_lang_prev; a.xa = (uint16_t*)xa;

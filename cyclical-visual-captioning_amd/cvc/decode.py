@@ -96,12 +96,11 @@ EMBGATE_MAX_BYTES = 1 << 30      # largest embedding-gate table the engine build
 
 
 def embgate_table(W: "DecodeWeights") -> torch.Tensor:
-    """[V, 4R] table of cvc_packed_lstm_embgate_fwd: row v = W_ih_att[:, emb columns] x relu(Emb[v]) (the xt segment of
-    decoder_core.py:45-48 with xt = embed(it), captioner.py:53-68 in eval mode), gate rows in packed block order.  One dense
-    product per checkpoint binding on the tile GEMM (split products, fp32-grade) -- no library GEMM."""
+    """[V, 4R] table of cvc_packed_lstm_embgate_fwd / cvc_tile_lstm_finish_embgate: row v = relu(Emb[v]) x W_ih_att[:, emb
+    columns]^T (the xt segment of decoder_core.py:45-48 with xt = embed(it), captioner.py:53-68 in eval mode), gates in checkpoint
+    order.  One dense product per checkpoint binding on the tile GEMM (split products, fp32-grade) -- no library GEMM."""
     R, E = W.R, W.E
-    w_emb = W.w_ih_att[:, 2 * R:2 * R + E][lstm_packed_rows(R, W.embed.device)].contiguous()          # [4R (packed order), E]
-    return hip.tile_mm(torch.relu(W.embed), w_emb)                                                   # [V, 4R]
+    return hip.tile_mm(torch.relu(W.embed), W.w_ih_att[:, 2 * R:2 * R + E])                          # [V, 4R]
 
 
 def to_quad(x: torch.Tensor) -> torch.Tensor:
@@ -274,12 +273,12 @@ class DecodeEngine:
         if gsk and not gsk_ok:
             raise RuntimeError("DecodeEngine: the stream-K schedule needs the packed path, R % 64 == 0 and cvc_gemm_packed_split(2)")
         self.gsk = False if gsk is None else bool(gsk)
-        eg_ok = self.packed and not self.gsk and not self.gate_ksplit
-        if embgate and not eg_ok:
-            raise RuntimeError("DecodeEngine: the embedding-gate schedule needs the packed path without gsk / gate_ksplit")
-        self.embgate = (eg_ok and 4 * V * 4 * R <= EMBGATE_MAX_BYTES) if embgate is None else bool(embgate)
         # more than 64 live rows (beam search, big greedy batches): bf16-fragment tile GEMMs (csrc/gemm_tile.hip)
         self.tile = (not self.packed) and (self.beam > 1 or rows > 64) and R % 16 == 0 and W.E % 16 == 0 and path != "ring"
+        eg_ok = (self.packed and not self.gsk and not self.gate_ksplit) or self.tile
+        if embgate and not eg_ok:
+            raise RuntimeError("DecodeEngine: the embedding-gate schedule needs the packed path (without gsk / gate_ksplit) or the tile path")
+        self.embgate = (eg_ok and 4 * V * 4 * R <= EMBGATE_MAX_BYTES) if embgate is None else bool(embgate)
         self._plan = None
         if self.packed:
             self._alloc_packed()
@@ -330,7 +329,9 @@ class DecodeEngine:
         else:
             d.path = 1
             d.ks_gate, d.ks_q, d.ks_o, d.ks_fc = self.ks_gate, self.ks_q, self.ks_o, self.ks_fc
-            d.w_att, d.w_lang, d.w_h, d.w_o, d.w_fc_frag = ptr(W.t_att), ptr(W.t_lang), ptr(W.t_h), ptr(W.t_o), ptr(W.t_fc)
+            d.w_att, d.w_lang, d.w_h, d.w_o, d.w_fc_frag = ptr(W.t_att2 if self.embgate else W.t_att), ptr(W.t_lang), ptr(W.t_h), ptr(W.t_o), ptr(W.t_fc)
+            if self.embgate:
+                d.emb_gate = ptr(W.t_embgate)
             d.gate_fc, d.q, d.q_parts, d.logits = ptr(self.gate_fc_clip), ptr(self.q), ptr(self.parts_q), ptr(self.logits)
             for name, t in (("xaf", self.XAf), ("xlf", self.XLf), ("xhf", self.XHf), ("xff", self.XFf)):
                 p_, s_ = hip._frag_ptr(t)
@@ -582,8 +583,13 @@ class DecodeEngine:
           XH = h_lang(t)                                             vocabulary head input"""
         W, R, E, A, V = self.W, self.W.R, self.W.E, self.W.A, self.W.V
         dev = self.fc.device
-        if not hasattr(W, "t_att"):
+        if self.embgate and not hasattr(W, "t_att2"):
+            W.t_att2 = pack_weights_tile(torch.cat([W.w_ih_att[:, 0:R], W.w_hh_att], 1), R)     # K = 2R: [h_lang | h_att]
+            if not hasattr(W, "t_embgate"):
+                W.t_embgate = embgate_table(W)
+        if not self.embgate and not hasattr(W, "t_att"):
             W.t_att = pack_weights_tile(torch.cat([W.w_ih_att[:, 0:R], W.w_ih_att[:, 2 * R:2 * R + E], W.w_hh_att], 1), R)
+        if not hasattr(W, "t_lang"):
             W.t_lang = pack_weights_tile(torch.cat([W.w_ih_lang, W.w_hh_lang], 1), R)
             W.t_h = pack_weights_tile(W.w_h)
             W.t_o = pack_weights_tile(W.w_o)
@@ -591,9 +597,10 @@ class DecodeEngine:
         rows, B = self.rows, self.B
         ra, rb = hip.tile_rows_alloc(rows), hip.tile_rows_alloc(B)
         zf = lambda r, k: torch.zeros(r // 32, k // 16, 3, 2, 32, 8, device=dev, dtype=torch.int16)
-        self.XAf, self.XLf, self.XHf, self.XFf = zf(ra, 2 * R + E), zf(ra, 3 * R), zf(ra, R), zf(rb, R)
+        self.ka_tile = 2 * R if self.embgate else 2 * R + E
+        self.XAf, self.XLf, self.XHf, self.XFf = zf(ra, self.ka_tile), zf(ra, 3 * R), zf(ra, R), zf(rb, R)
         f32 = dict(device=dev, dtype=torch.float32)
-        self.ks_gate, self.ks_q, self.ks_o, self.ks_fc = (self._ksplit(4 * R, min(2 * R + E, 3 * R)), self._ksplit(A, R),
+        self.ks_gate, self.ks_q, self.ks_o, self.ks_fc = (self._ksplit(4 * R, min(self.ka_tile, 3 * R)), self._ksplit(A, R),
                                                           self._ksplit(V, R), self._ksplit(4 * R, R))
         self.parts_gate = torch.empty(self.ks_gate, rows, 4 * R, **f32)
         self.parts_q = torch.empty(self.ks_q, rows, A, **f32)
@@ -624,15 +631,23 @@ class DecodeEngine:
         xl_hlang, _ = fp(self.XLf, 2 * R)
         xh_p, xh_s = fp(self.XHf)
         zero = ptr(self.t_zero)
-        out.append(("beam_reorder", L.cvc_tile_reorder_pack, (None, ptr(self.words[0]), beam, zero, zero, zero, zero, ptr(W.embed), E, V,
+        eg = self.embgate
+        E_pack = 0 if eg else E                        # embedding-gate form: no embedding segment in XA, the word enters in the finish
+        out.append(("beam_reorder", L.cvc_tile_reorder_pack, (None, ptr(self.words[0]), beam, zero, zero, zero, zero, ptr(W.embed), E_pack, V,
                                                               ptr(self.t_c_att_prev), ptr(self.t_c_lang_prev), xa_p, xa_s, xl_hlang,
                                                               xl_s, rows, R)))
         for t in range(self.T):
-            out.append(("att_lstm", L.cvc_tile_gemm, (ptr(W.t_att), xa_p, xa_s, 2 * R + E, rows, 4 * R, self.ks_gate,
+            out.append(("att_lstm", L.cvc_tile_gemm, (ptr(W.t_att2 if eg else W.t_att), xa_p, xa_s, self.ka_tile, rows, 4 * R, self.ks_gate,
                                                       ptr(self.parts_gate), 4 * R, rows * 4 * R)))
-            out.append(("att_finish", L.cvc_tile_lstm_finish, (ptr(self.parts_gate), self.ks_gate, rows * 4 * R, None, None,
-                                                               ptr(self.gate_fc_clip), beam, ptr(self.t_c_att_prev), rows, R,
-                                                               ptr(self.t_c_att), ptr(self.t_h_att), xl_hatt, xl_s, None, 0)))
+            if eg:
+                out.append(("att_finish", L.cvc_tile_lstm_finish_embgate, (ptr(self.parts_gate), self.ks_gate, rows * 4 * R, None, None,
+                                                                           ptr(self.gate_fc_clip), beam, ptr(W.t_embgate), ptr(self.words[t]), V,
+                                                                           ptr(self.t_c_att_prev), rows, R, ptr(self.t_c_att),
+                                                                           ptr(self.t_h_att), xl_hatt, xl_s, None, 0)))
+            else:
+                out.append(("att_finish", L.cvc_tile_lstm_finish, (ptr(self.parts_gate), self.ks_gate, rows * 4 * R, None, None,
+                                                                   ptr(self.gate_fc_clip), beam, ptr(self.t_c_att_prev), rows, R,
+                                                                   ptr(self.t_c_att), ptr(self.t_h_att), xl_hatt, xl_s, None, 0)))
             out.append(("h2attn", L.cvc_tile_gemm, (ptr(W.t_h), xl_hatt, xl_s, R, rows, A, self.ks_q, ptr(self.parts_q), A, rows * A)))
             sets = (hip.AttnSet * 2)()
             sets[0] = hip.AttnSet(ptr(ppool), ptr(pool), ptr(self.mask), None, ptr(self.scores_r), None,
@@ -668,7 +683,7 @@ class DecodeEngine:
             if t + 1 < self.T:
                 out.append(("beam_reorder", L.cvc_tile_reorder_pack, (parent, ptr(self.words[t + 1]), beam, ptr(self.t_h_att),
                                                                       ptr(self.t_c_att), ptr(self.t_h_lang), ptr(self.t_c_lang),
-                                                                      ptr(W.embed), E, V, ptr(self.t_c_att_prev),
+                                                                      ptr(W.embed), E_pack, V, ptr(self.t_c_att_prev),
                                                                       ptr(self.t_c_lang_prev), xa_p, xa_s, xl_hlang, xl_s, rows, R)))
             self._keep.append(sets)
         return out

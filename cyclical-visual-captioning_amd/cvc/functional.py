@@ -181,18 +181,96 @@ def new_step() -> None:
     hip.lstm_train_new_step()
 
 
-class _LstmCell(torch.autograd.Function):
-    """nn.LSTMCell over a virtual concat of input segments (decoder_core.py:45-50, 59-61)."""
+HOIST = True      # training loops: multiply the input segments known for all T steps once, before the loop (A/B switch)
+
+
+class _HoistedGates(torch.autograd.Function):
+    """G[t] = sum_s x_s[t] W_ih[:, cols_s]^T for every step t at once -- the input segments of a training loop's LSTM cell that do
+    not depend on the recurrence (the embedded teacher-forced words, fc_feats, the localized context of the reconstruction
+    loop; model/captioner.py:243-264, 348-360 feed them step by step).  One dense product over T * B rows instead of T passes over
+    those weight columns.  The weight matrix is NOT a differentiable input here: its gradient, columns of these segments
+    included, is the cell's T-batched dW product (the cell keeps stashing every segment), so autograd sees one producer."""
 
     @staticmethod
-    def forward(ctx, w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, wp, copies, *xs):
+    def forward(ctx, w_ih, cols, per_step, T, B, *xs):
+        # xs[s]: [T * B, k] (rows t * B + b) when per_step[s], else [B, k] (the same every step)
+        prod = lambda x, c0, n: (hip.tile_mm(_c(x), w_ih[:, c0:c0 + n]) if x.shape[0] > 64 else
+                                 hip.linear_fwd([{"x": _c(x), "w": w_ih[:, c0:c0 + n]}], None, x.shape[0], w_ih.shape[0]))
+        G = None
+        for x, (c0, n), ps in zip(xs, cols, per_step):
+            if ps:
+                g = prod(x, c0, n)
+                G = g if G is None else G.add_(g)
+        if G is None:
+            G = w_ih.new_zeros(T * B, w_ih.shape[0])
+        G = G.view(T, B, -1)
+        for x, (c0, n), ps in zip(xs, cols, per_step):
+            if not ps:
+                G.add_(prod(x, c0, n).unsqueeze(0))
+        ctx.save_for_backward(w_ih)
+        ctx.cols, ctx.per_step, ctx.T, ctx.B = cols, per_step, T, B
+        ctx.set_materialize_grads(False)
+        return G
+
+    @staticmethod
+    def backward(ctx, dG):
+        (w_ih,) = ctx.saved_tensors
+        n_in = 5 + len(ctx.cols)
+        if dG is None:
+            return (None,) * n_in
+        T, B = ctx.T, ctx.B
+        dG = _c(dG).view(T * B, -1)
+        d_xs = []
+        for i, ((c0, n), ps) in enumerate(zip(ctx.cols, ctx.per_step)):
+            if not ctx.needs_input_grad[5 + i]:
+                d_xs.append(None)
+            elif ps:
+                d_xs.append(hip.tile_mm(dG, w_ih[:, c0:c0 + n], b_kmajor=True) if T * B > 64 else _mm_nn(dG, w_ih[:, c0:c0 + n]))
+            else:                                                   # a segment shared by all steps: the steps' gradients add up
+                d_xs.append(_mm_nn(dG.view(T, B, -1).sum(0), w_ih[:, c0:c0 + n]))
+        return (None, None, None, None, None, *d_xs)
+
+
+def hoisted_gates(w_ih: Tensor, segs, T: int, B: int):
+    """segs: ((x, col0), ...) with x [B, k] (constant over the steps) or [B, T, k]; -> a list of T tensors [B, 4R], or None when
+    hoisting is off / not applicable (the cell then multiplies every segment itself)."""
+    if not (HOIST and w_ih.is_cuda and w_ih.is_contiguous() and PACKED_LSTM_FORWARD and T >= 1 and w_ih.shape[0] % 32 == 0):
+        return None
+    xs, cols, per_step = [], [], []
+    for x, c0 in segs:
+        ps = x.dim() == 3
+        if ps:
+            x = x.transpose(0, 1).reshape(T * B, x.shape[2])        # rows t * B + b: G[t] is then a contiguous [B, 4R] slice
+        if x.shape[1] % 4 != 0 or c0 % 4 != 0 or x.dtype != torch.float32:
+            return None
+        xs.append(x)
+        cols.append((int(c0), int(x.shape[1])))
+        per_step.append(ps)
+    G = _HoistedGates.apply(w_ih, tuple(cols), tuple(per_step), int(T), int(B), *xs)
+    return list(G.unbind(0))
+
+
+class _LstmCell(torch.autograd.Function):
+    """nn.LSTMCell over a virtual concat of input segments (decoder_core.py:45-50, 59-61).  gate_pre / hoisted: the segments flagged
+    in `hoisted` were multiplied for all steps beforehand (_HoistedGates) and arrive summed in gate_pre [M, 4R]; the launch then
+    streams only the other columns of weight_ih (the pack `wp` covers exactly those) and weight_hh."""
+
+    @staticmethod
+    def forward(ctx, w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, wp, copies, gate_pre, hoisted, *xs):
         xs = [_rows(x) for x in xs]
         h_prev, c_prev = _c(h_prev), _c(c_prev)
         k0 = sum(x.shape[1] for x in xs)
         assert k0 == w_ih.shape[1], ("LSTM input width mismatch", k0, tuple(w_ih.shape))
         need_bwd = any(ctx.needs_input_grad)
         M, R = c_prev.shape
-        if wp is not None and all(x.data_ptr() % 16 == 0 for x in (*xs, h_prev)):
+        ctx.hoisted = tuple(hoisted) if gate_pre is not None else tuple(False for _ in xs)
+        rec = [x for x, hz in zip(xs, ctx.hoisted) if not hz]
+        if gate_pre is not None:
+            assert wp is not None, "a hoisted cell runs on the packed gate GEMM"
+            h, c, gates = hip.lstm_cell_train_fwd(rec, h_prev, c_prev, wp, b_ih, b_hh, want_gates=need_bwd, copies=copies,
+                                                  gate_pre=_c(gate_pre))
+            hs = h if copies > 1 else (h,)
+        elif wp is not None and all(x.data_ptr() % 16 == 0 for x in (*xs, h_prev)):
             # the decode engine's packed gate GEMM; `wp` is the pack lstm_cell() found on (or built for) the weight tensors
             h, c, gates = hip.lstm_cell_train_fwd(xs, h_prev, c_prev, wp, b_ih, b_hh, want_gates=need_bwd, copies=copies)
             hs = h if copies > 1 else (h,)
@@ -225,10 +303,13 @@ class _LstmCell(torch.autograd.Function):
             d_hs = [torch.zeros_like(c_new)]      # (keeps the deferred-weight-gradient use count exact)
         d_hs = [_c(g) for g in d_hs] + [None] * (3 - len(d_hs))
         M, K = gates.shape
-        # dX ranges that need a gradient: (weight, first column, width) in the order h_prev, xs...
+        # dX ranges that need a gradient: (weight, first column, width) in the order h_prev, xs... (a hoisted segment's gradient
+        # comes from _HoistedGates' one product over all steps, not from here)
+        XS0 = 10                                                      # index of xs[0] among forward's inputs
+        want_x = [bool(ni[XS0 + i]) and not ctx.hoisted[i] for i in range(len(xs))]
         ranges, k0 = ([(w_hh, 0, w_hh.shape[1])] if ni[4] else []), 0
         for i, x in enumerate(xs):
-            if ni[8 + i]:
+            if want_x[i]:
                 ranges.append((w_ih, k0, x.shape[1]))
             k0 += x.shape[1]
         use_nn = bool(ranges) and hip.linear_nn_ok(M, K, ranges)
@@ -257,27 +338,43 @@ class _LstmCell(torch.autograd.Function):
         if use_nn:                      # every needed dX from one pass over the weights (csrc/gemm_nn.hip)
             got = iter(hip.linear_nn(pw[2], M, K, ranges))
             d_h_prev = next(got) if ni[4] else None
-            d_xs = [next(got) if ni[8 + i] else None for i in range(len(xs))]
+            d_xs = [next(got) if want_x[i] else None for i in range(len(xs))]
         else:                           # widths the kernel does not take (not multiples of 4): library GEMM
             d_h_prev = _mm_nn(d_gates, w_hh) if ni[4] else None
             d_xs, k0 = [], 0
             for i, x in enumerate(xs):
                 k = x.shape[1]
-                d_xs.append(_mm_nn(d_gates, w_ih[:, k0:k0 + k]) if ni[8 + i] else None)
+                d_xs.append(_mm_nn(d_gates, w_ih[:, k0:k0 + k]) if want_x[i] else None)
                 k0 += k
         return (d_w_ih, d_w_hh, d_b if ni[2] else None, d_b if ni[3] else None, d_h_prev,
-                d_c_prev if ni[5] else None, None, None, *d_xs)
+                d_c_prev if ni[5] else None, None, None, (d_gates if ni[8] else None), None, *d_xs)
 
 
-def lstm_cell(xs: Sequence[Tensor], h_prev: Tensor, c_prev: Tensor, w_ih, w_hh, b_ih, b_hh, copies: int = 1):
+def lstm_cell(xs: Sequence[Tensor], h_prev: Tensor, c_prev: Tensor, w_ih, w_hh, b_ih, b_hh, copies: int = 1,
+              gate_pre: Optional[Tensor] = None, hoisted: Optional[Sequence[bool]] = None):
     """-> (h', c'), or with copies = k > 1: (h'_1, ..., h'_k, c') -- k tensors holding the same h', one per consumer, so that
-    autograd has no fan-out to accumulate (their gradients are summed inside the cell's backward kernel)."""
+    autograd has no fan-out to accumulate (their gradients are summed inside the cell's backward kernel).
+    gate_pre [M, 4R] + hoisted (one flag per segment of xs): this step's slice of hoisted_gates() for the flagged segments."""
     wp = None
     M, R = c_prev.shape
-    if (PACKED_LSTM_FORWARD and w_ih.is_cuda and w_ih.is_contiguous() and w_hh.is_contiguous()
-            and hip.lstm_train_ok(M, R, [x.shape[1] for x in xs] + [h_prev.shape[1]])):
+    packable = PACKED_LSTM_FORWARD and w_ih.is_cuda and w_ih.is_contiguous() and w_hh.is_contiguous()
+    if gate_pre is not None:
+        widths = [x.shape[1] for x, hz in zip(xs, hoisted) if not hz] + [h_prev.shape[1]]
+        ok = packable and hip.lstm_train_ok(M, R, widths) and all(x.data_ptr() % 16 == 0 for x in (*xs, h_prev))
+        if not ok:
+            # shapes the packed kernel does not take: the plain cell over ALL segments (xs holds every one of them); gate_pre is
+            # ignored, so its producer receives no gradient and the hoisted segments get theirs from this cell instead
+            return lstm_cell(xs, h_prev, c_prev, w_ih, w_hh, b_ih, b_hh, copies=copies)
+        cols, k0 = [], 0
+        for x, hz in zip(xs, hoisted):
+            if not hz:
+                cols.append((k0, x.shape[1]))
+            k0 += x.shape[1]
+        wp = hip.lstm_train_pack(w_ih, w_hh, cols=cols)
+        return _LstmCell.apply(w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, wp, max(1, min(3, int(copies))), gate_pre, tuple(hoisted), *xs)
+    if packable and hip.lstm_train_ok(M, R, [x.shape[1] for x in xs] + [h_prev.shape[1]]):
         wp = hip.lstm_train_pack(w_ih, w_hh)          # lives on the parameter object; rebuilt once per optimizer step
-    return _LstmCell.apply(w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, wp, max(1, min(3, int(copies))), *xs)
+    return _LstmCell.apply(w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, wp, max(1, min(3, int(copies))), None, None, *xs)
 
 
 # ------------------------------------------------------------------------------- attention

@@ -89,6 +89,8 @@ SIGNATURES = {
     "cvc_top2_slab": [C.POINTER(GskSegs), _P, _I, _I, _I, _P, _I, _P, _P, _I, _P, _I, _P],
     "cvc_packed_lstm_train_fwd": [_P, _P, _I, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     "cvc_pack_lstm_weights": [_P, _I, _P, _I, _I, _P, _P],
+    "cvc_pack_lstm_segs": [C.POINTER(_P), C.POINTER(_LL), C.POINTER(_I), _I, _I, _P, _P],
+    "cvc_packed_lstm_train_pre_fwd": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
     "cvc_pack_quad_segs": [C.POINTER(_P), C.POINTER(_LL), C.POINTER(_I), _I, _I, _P, _P],
     "cvc_beam_backtrack": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "cvc_gru_seq_fwd": [_P, _P, _LL, _LL, _P, _P, _I, _I, _I, _I, _P, _P, _LL, _LL, _P],
@@ -133,6 +135,7 @@ SIGNATURES = {
     "cvc_tile_gemm_loaders": [_I],
     "cvc_tile_gemm": [_P, _P, _LL, _I, _I, _I, _I, _P, _I, _LL, _P],
     "cvc_tile_lstm_finish": [_P, _I, _LL, _P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _LL, _P, _LL, _P],
+    "cvc_tile_lstm_finish_embgate": [_P, _I, _LL, _P, _P, _P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P, _LL, _P, _LL, _P],
     "cvc_tile_linear_finish": [_P, _I, _LL, _I, _P, _P, _I, _I, _P, _I, _P],
     "cvc_tile_pack_rows": [_P, _I, _P, _I, _I, _I, _P, _LL, _P],
     "cvc_tile_pack_rows_any": [_P, _LL, _I, _I, _P, _LL, _P],
@@ -414,21 +417,32 @@ def lstm_train_ok(M: int, R: int, widths: Sequence[int]) -> bool:
     return 1 <= M <= 64 and R % 8 == 0 and all(w % 4 == 0 and w >= 4 for w in widths) and sum(widths) % 32 == 0
 
 
-def lstm_train_pack(w_ih: torch.Tensor, w_hh: torch.Tensor) -> torch.Tensor:
-    """Packed copy [R/8][(K_ih + K_hh)/4][32][4] of an LSTM cell's weights for cvc_packed_lstm_train_fwd.  The pack lives ON
-    the weight tensor object (it dies with it: no table keyed by addresses that a later tensor could reuse) and is rebuilt
-    when the step generation, either tensor's version counter or either address changed."""
+def lstm_train_pack(w_ih: torch.Tensor, w_hh: torch.Tensor, cols: Optional[Sequence] = None) -> torch.Tensor:
+    """Packed copy [R/8][K/4][32][4] of an LSTM cell's weights for cvc_packed_lstm_train_fwd: all of weight_ih, or only its
+    column ranges `cols` = ((col0, width), ...) (the recurrent inputs of a hoisted cell), followed by weight_hh.  The packs live
+    ON the weight tensor object (they die with it: no table keyed by addresses that a later tensor could reuse), one per `cols`,
+    and are rebuilt when the step generation, either tensor's version counter or either address changed."""
     R = w_hh.shape[1]
+    key = None if cols is None else tuple((int(c0), int(n)) for c0, n in cols)
     stamp = (_train_generation, w_ih._version, w_hh._version, w_ih.data_ptr(), w_hh.data_ptr(), tuple(w_ih.shape))
-    ent = getattr(w_ih, "_cvc_train_pack", None)
+    packs = getattr(w_ih, "_cvc_train_packs", None)
+    if packs is None:
+        packs = w_ih._cvc_train_packs = {}
+    ent = packs.get(key)
     if ent is not None and ent[1] == stamp:
         return ent[0]
-    K_ih, K_hh = w_ih.shape[1], w_hh.shape[1]
-    shape = (R // 8, (K_ih + K_hh) // 4, 32, 4)
+    K_hh = w_hh.shape[1]
+    ranges = [(0, w_ih.shape[1])] if key is None else list(key)
+    K = sum(n for _, n in ranges) + K_hh
+    shape = (R // 8, K // 4, 32, 4)
     wp = ent[0] if (ent is not None and tuple(ent[0].shape) == shape and ent[0].device == w_ih.device) else \
         torch.empty(*shape, device=w_ih.device, dtype=torch.float32)
-    _check(lib().cvc_pack_lstm_weights(_dev(w_ih), K_ih, _dev(w_hh), K_hh, R, _dev(wp), _stream()), "cvc_pack_lstm_weights")
-    w_ih._cvc_train_pack = (wp, stamp)
+    n = len(ranges) + 1
+    ptrs = (_P * n)(*[w_ih.data_ptr() + 4 * c0 for c0, _ in ranges], w_hh.data_ptr())
+    lds = (_LL * n)(*[w_ih.stride(0)] * len(ranges), w_hh.stride(0))
+    ws = (_I * n)(*[nn_ for _, nn_ in ranges], K_hh)
+    _check(lib().cvc_pack_lstm_segs(ptrs, lds, ws, n, R, _dev(wp), _stream()), "cvc_pack_lstm_segs")
+    packs[key] = (wp, stamp)
     return wp
 
 
@@ -443,17 +457,23 @@ def pack_quad_segs(xs: Sequence[torch.Tensor]) -> torch.Tensor:
     return xq
 
 
-def lstm_cell_train_fwd(xs: Sequence[torch.Tensor], h_prev, c_prev, wp, b_ih, b_hh, want_gates: bool = True, copies: int = 1):
+def lstm_cell_train_fwd(xs: Sequence[torch.Tensor], h_prev, c_prev, wp, b_ih, b_hh, want_gates: bool = True, copies: int = 1,
+                        gate_pre: Optional[torch.Tensor] = None):
     """nn.LSTMCell forward on the packed gate GEMM (cvc_packed_lstm_train_fwd) from the pack `lstm_train_pack` built:
-    -> h (a tuple of `copies` identical tensors when copies > 1), c, activated gates (or None)."""
+    -> h (a tuple of `copies` identical tensors when copies > 1), c, activated gates (or None).  gate_pre [M, 4R]: the
+    contribution of input segments multiplied beforehand for all steps (hoisted cell); xs are then the remaining segments."""
     M, R = c_prev.shape
     xq = pack_quad_segs([*xs, h_prev])
     hs = [torch.empty_like(c_prev) for _ in range(max(1, min(3, copies)))]
     c = torch.empty_like(c_prev)
     gates = torch.empty(M, 4 * R, device=c_prev.device, dtype=torch.float32) if want_gates else None
-    _check(lib().cvc_packed_lstm_train_fwd(_dev(wp), _dev(xq), xq.shape[0] * 4, _dev(b_ih), _dev(b_hh), _dev(c_prev), M, R,
-                                           _dev(hs[0]), _dev(c), _dev(gates), _dev(hs[1]) if len(hs) > 1 else None,
-                                           _dev(hs[2]) if len(hs) > 2 else None, _stream()), "cvc_packed_lstm_train_fwd")
+    tail = (_dev(c_prev), M, R, _dev(hs[0]), _dev(c), _dev(gates), _dev(hs[1]) if len(hs) > 1 else None,
+            _dev(hs[2]) if len(hs) > 2 else None, _stream())
+    if gate_pre is None:
+        _check(lib().cvc_packed_lstm_train_fwd(_dev(wp), _dev(xq), xq.shape[0] * 4, _dev(b_ih), _dev(b_hh), *tail), "cvc_packed_lstm_train_fwd")
+    else:
+        _check(lib().cvc_packed_lstm_train_pre_fwd(_dev(wp), _dev(xq), xq.shape[0] * 4, _dev(b_ih), _dev(b_hh), _dev(gate_pre), *tail),
+               "cvc_packed_lstm_train_pre_fwd")
     return (hs[0] if copies <= 1 else tuple(hs)), c, gates
 
 

@@ -196,10 +196,17 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         # one unbind per tensor instead of T selects: a select's backward is a zero-filled [B, T, E] tensor plus an
         # accumulation per step, unbind's is a single stack
         emb_steps = emb_all.unbind(1)
+        # the att-LSTM's inputs that do not depend on the recurrence (fc_feats, the teacher-forced embedded words) are multiplied
+        # for all T steps in one dense product; the per-step launches stream only the recurrent columns (cvc.functional)
+        R = self.rnn_size
+        hoist = torch.is_grad_enabled() and fc_feats.is_cuda
+        w_att = self.decoder_core.att_lstm.weight_ih
+        att_segs = (lambda e: [(fc_feats, R), (e, 2 * R)]) if self.opts.global_img_in_attn_lstm else (lambda e: [(e, R)])
+        g_att = F_.hoisted_gates(w_att, att_segs(emb_all), T, B) if hoist else None
         for t in range(T):
             output, state, _roi_attn, frame_masked_attn, _wp = self.decoder_core.step(
                 emb_steps[t], fc_feats, conv_feats, p_conv_feats, pool_feats, p_pool_feats, region_mask, state,
-                proposal_frame_mask=step_fmask[t], drop_site="out_a.%d" % t)
+                proposal_frame_mask=step_fmask[t], drop_site="out_a.%d" % t, gate_pre_att=None if g_att is None else g_att[t])
             outputs.append(output)
             masked_attn.append(frame_masked_attn)
         att2_weights = torch.stack(masked_attn, dim=1)                               # pre-softmax (:273)
@@ -239,9 +246,16 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         emb_all_c = self._embed(gt_caption[:, :T], "emb_c") if self.training else emb_all      # fresh dropout mask in training
         rec_outputs = []
         emb_steps_c, pool_steps, conv_steps = emb_all_c.unbind(1), loc_pool.unbind(1), loc_conv.unbind(1)
+        # loop C knows even more of its inputs beforehand: the localized context of every step (loop B's output)
+        g_att_c = F_.hoisted_gates(w_att, att_segs(emb_all_c), T, B) if hoist else None
+        ctx_all = (loc_pool + loc_conv) if hoist else None                                  # [B, T, R], one add instead of T
+        g_lang_c = F_.hoisted_gates(self.attended_roi_decoder_core.lang_lstm.weight_ih, [(ctx_all, 0)], T, B) if hoist else None
+        ctx_steps = ctx_all.unbind(1) if g_lang_c is not None else None
         for t in range(T):
-            output, state = self.attended_roi_decoder_core.step(emb_steps_c[t], fc_feats, pool_steps[t], conv_steps[t], state,
-                                                                drop_site="out_c.%d" % t)
+            output, state = self.attended_roi_decoder_core.step(
+                emb_steps_c[t], fc_feats, pool_steps[t], conv_steps[t], state, drop_site="out_c.%d" % t,
+                gate_pre_att=None if g_att_c is None else g_att_c[t], gate_pre_lang=None if g_lang_c is None else g_lang_c[t],
+                ctx_sum=None if ctx_steps is None else ctx_steps[t])
             rec_outputs.append(output)
         lm_recon_loss = self.xe_criterion.from_logits(self._logits(torch.stack(rec_outputs, 1).view(B * T, -1)), target)
         return (lm_loss.reshape(1), att2_loss.reshape(1), ground_loss.reshape(1), cls_loss.reshape(1),

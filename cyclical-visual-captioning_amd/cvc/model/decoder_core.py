@@ -49,7 +49,7 @@ class TopDownDecoderCore(nn.Module):
         return output, (torch.stack([h_att, h_lang]), torch.stack([c_att, c_lang])), roi_attn, frame_masked_attn, weighted_pool_feat
 
     def step(self, embedded_word, fc_feats, conv_feats, p_conv_feats, pool_feats, p_pool_feats, pnt_mask, state,
-             proposal_frame_mask=None, drop_site=None, with_sentinel=False):
+             proposal_frame_mask=None, drop_site=None, with_sentinel=False, gate_pre_att=None):
         """forward() on an unstacked state (h_att, c_att, h_lang, c_lang): what the captioner's T-step loops call --
         stacking the state every step costs ~17 small kernels per step in the backward pass (the selects' zero-filled
         gradients, their accumulation, the stack / unbind pairs)."""
@@ -60,7 +60,10 @@ class TopDownDecoderCore(nn.Module):
         h_lang_s = state[4] if len(state) > 4 else h_lang
         k = 3 if (torch.is_grad_enabled() and H_COPIES) else 1
         xs = [h_lang, fc_feats, embedded_word] if self.opts.global_img_in_attn_lstm else [h_lang, embedded_word]
-        *h_attn, c_attn = F_.lstm_cell(xs, h_att, c_att, *_cell(self.att_lstm), copies=k)
+        # gate_pre_att: this step's slice of F_.hoisted_gates over (fc_feats, embedded word) -- multiplied for all T steps before
+        # the loop, so the per-step launch streams only the h_lang columns of weight_ih and weight_hh
+        *h_attn, c_attn = F_.lstm_cell(xs, h_att, c_att, *_cell(self.att_lstm), copies=k, gate_pre=gate_pre_att,
+                                       hoisted=None if gate_pre_att is None else (False,) + (True,) * (len(xs) - 1))
         # regions (masked, optional frame-masked copy) and frames share the query: one launch
         ctx_sum, ((weighted_pool_feat, roi_attn, frame_masked_attn), _frames) = _soft_attn_pair(
             self.soft_attn, h_attn[0],
@@ -91,13 +94,18 @@ class AttenedDecoderCore(nn.Module):
         h_att, c_att, h_lang, c_lang = st[:4]
         return output, (torch.stack([h_att, h_lang]), torch.stack([c_att, c_lang]))
 
-    def step(self, embedded_word, fc_feats, weighted_pool_feat, attn_conv, state, drop_site=None):
+    def step(self, embedded_word, fc_feats, weighted_pool_feat, attn_conv, state, drop_site=None, gate_pre_att=None, gate_pre_lang=None,
+             ctx_sum=None):
         """forward() on an unstacked state (h_att, c_att, h_lang, c_lang), see TopDownDecoderCore.step"""
         h_att, c_att, h_lang, c_lang = state[:4]
         h_lang_s = state[4] if len(state) > 4 else h_lang
         grad = torch.is_grad_enabled() and H_COPIES
         xs = [h_lang, fc_feats, embedded_word] if self.opts.global_img_in_attn_lstm else [h_lang, embedded_word]
-        *h_attn, c_attn = F_.lstm_cell(xs, h_att, c_att, *_cell(self.att_lstm), copies=2 if grad else 1)
-        *h_new, c_lang = F_.lstm_cell([weighted_pool_feat + attn_conv, h_attn[0]], h_lang_s, c_lang, *_cell(self.lang_lstm),
-                                      copies=3 if grad else 1)
+        *h_attn, c_attn = F_.lstm_cell(xs, h_att, c_att, *_cell(self.att_lstm), copies=2 if grad else 1, gate_pre=gate_pre_att,
+                                       hoisted=None if gate_pre_att is None else (False,) + (True,) * (len(xs) - 1))
+        # ctx_sum: weighted_pool_feat + attn_conv of this step, taken from the sum over all T steps the caller formed once;
+        # gate_pre_lang: its hoisted product with weight_ih[:, :R] (the localized context does not depend on this loop's recurrence)
+        ctx = ctx_sum if ctx_sum is not None else weighted_pool_feat + attn_conv
+        *h_new, c_lang = F_.lstm_cell([ctx, h_attn[0]], h_lang_s, c_lang, *_cell(self.lang_lstm), copies=3 if grad else 1,
+                                      gate_pre=gate_pre_lang, hoisted=None if gate_pre_lang is None else (True, False))
         return dropout.apply(self.dropout, h_new[0], drop_site), (h_attn[-1], c_attn, h_new[1 % len(h_new)], c_lang, h_new[2 % len(h_new)])

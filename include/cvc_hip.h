@@ -154,7 +154,7 @@ int cvc_packed_linear_fwd(const float* wp, const float* xq, int K, const float* 
                           int ksplit, float* y, int ldy, float* top2_part, cvc_stream_t stream);
 /* Embedding-gate table form of the att-LSTM (decoder_core.py:45-50 with xt = relu(Emb[word]), captioner.py:53-68 in eval mode):
  * the embedded word's share of the gates, W_ih[:, emb columns] x relu(Emb[v]), depends on the word alone, so it is tabulated once
- * per checkpoint -- emb_gate [V][R/8][32] fp32, gate rows in the packed block order of wp (cvc.decode.embgate_table) -- and the
+ * per checkpoint -- emb_gate [V][4R] fp32, gates in checkpoint order (gate * R + unit; cvc.decode.embgate_table) -- and the
  * step adds row word[m] in the epilogue: wp / xq then cover only the recurrent inputs (K = 2R: h_lang, h_att), 20 % fewer weight
  * bytes per step, and the gate GEMM no longer waits for the word.  Otherwise cvc_packed_lstm_fwd. */
 int cvc_packed_lstm_embgate_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
@@ -188,6 +188,18 @@ int cvc_pack_lstm_weights(const float* w_ih, int K_ih, const float* w_hh, int K_
                           cvc_stream_t stream);
 int cvc_pack_quad_segs(const float* const* xs, const long long* ldx, const int* widths, int nseg, int M, float* xq,
                        cvc_stream_t stream);
+/* Hoisted form of the training cell: input segments whose values are known for all T steps before the loop (the embedded
+ * teacher-forced words, fc_feats, the localized context of the reconstruction loop) are multiplied ONCE for all T * B rows (a dense
+ * product), and the per-step launch streams only the recurrent columns of the gate matrix:
+ *   cvc_pack_lstm_segs : up to 4 column ranges [4R, width_s] (pointer at the first column, leading dimension ld_s) of row-major
+ *                        weights -> wp over K = sum width_s (the recurrent ranges of weight_ih, then weight_hh);
+ *   cvc_packed_lstm_train_pre_fwd : cvc_packed_lstm_train_fwd + gate_pre [M, 4R] (row-major, checkpoint gate order), the hoisted
+ *                        ranges' contribution to this step's pre-activations. */
+int cvc_pack_lstm_segs(const float* const* ws, const long long* lds, const int* widths, int nseg, int R, float* wp,
+                       cvc_stream_t stream);
+int cvc_packed_lstm_train_pre_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
+                                  const float* gate_pre, const float* c_prev, int M, int R, float* h_out, float* c_out,
+                                  float* gates_out, float* h_out2, float* h_out3, cvc_stream_t stream);
 
 /* GRU over a whole sequence, one or both directions: the recurrent half of nn.GRU(batch_first, h0 = 0) as the encoder's frame
  * context uses it (backbone.py:103-106, 335-338; gate order r, z, n; n = tanh(W_in x + b_in + r * (W_hn h + b_hn)),
@@ -481,6 +493,13 @@ int cvc_tile_lstm_finish(const float* parts, int nparts, long long part_stride, 
                          const float* gate_bias, int gb_div, const float* c_prev, int M, int R, float* c_out,
                          float* h_out, void* frag1, long long frag1_stride, void* frag2, long long frag2_stride,
                          cvc_stream_t stream);
+/* the same with the embedded word's share of the gates taken from the embedding-gate table (see cvc_packed_lstm_embgate_fwd):
+ * + emb_gate[word[m], :] (checkpoint order [V, 4R]; a word outside [0, V) reads row 0).  The gate GEMM then covers K = 2R
+ * (h_lang | h_att) and cvc_tile_reorder_pack is called with E = 0. */
+int cvc_tile_lstm_finish_embgate(const float* parts, int nparts, long long part_stride, const float* b_ih, const float* b_hh,
+                                 const float* gate_bias, int gb_div, const float* emb_gate, const int64_t* word, int V,
+                                 const float* c_prev, int M, int R, float* c_out, float* h_out, void* frag1,
+                                 long long frag1_stride, void* frag2, long long frag2_stride, cvc_stream_t stream);
 /* y[m, n] = sum_s parts[s][m, n] + bias[n] + bias2[n]  (nn.Linear epilogue: vocabulary logits, hoisted fc gate term) */
 int cvc_tile_linear_finish(const float* parts, int nparts, long long part_stride, int ld, const float* bias,
                            const float* bias2, int M, int N, float* y, int ldy, cvc_stream_t stream);
@@ -495,7 +514,8 @@ int cvc_tile_pack_rows_any(const float* x, long long ldx, int M, int K, void* xb
 int cvc_tile_pack_cols(const float* x, long long ldx, int S, int C, void* xb, long long x_mblk_stride, cvc_stream_t stream);
 /* Beam-state reorder fused with next step's operand packing: row r continues hypothesis (r / beam) * beam + parent[r]
  * (parent NULL: r).  c_*_prev[r] = c_*[src]; xa = [h_lang[src] | relu(table[word[r]]) | h_att[src]] as fragments (K = 2R + E,
- * decoder_core.py:45-48 without the hoisted fc segment); xl_hlang (lang-LSTM input, third K segment) = h_lang[src]. */
+ * decoder_core.py:45-48 without the hoisted fc segment; E = 0: no embedding segment, table may be NULL -- the embedding-gate
+ * form); xl_hlang (lang-LSTM input, third K segment) = h_lang[src]. */
 int cvc_tile_reorder_pack(const int64_t* parent, const int64_t* word, int beam, const float* h_att, const float* c_att,
                           const float* h_lang, const float* c_lang, const float* table, int E, int V,
                           float* c_att_prev, float* c_lang_prev, void* xa, long long xa_stride, void* xl_hlang,

@@ -271,7 +271,7 @@ def test_stream_k_entry_points_reject_bad_arguments(dev, lib):
 def test_embedding_gate_table_form_of_the_att_lstm(dev, lib, M, R, E, V):
     """cvc_packed_lstm_embgate_fwd (K = 2R GEMM + a row of the per-checkpoint table W_ih[:, emb] x relu(Emb[v])) against
     cvc_packed_lstm_fwd over [h_lang | relu(Emb[word]) | h_att] and against fp64; the table itself against fp64."""
-    from cvc.decode import pack_weights, to_quad, from_quad, lstm_packed_rows
+    from cvc.decode import pack_weights, to_quad, from_quad
     hip, L = lib, lib.lib()
     g = torch.Generator().manual_seed(M + R + 1)
     K = 2 * R + E
@@ -281,9 +281,8 @@ def test_embedding_gate_table_form_of_the_att_lstm(dev, lib, M, R, E, V):
     hl, ha = torch.randn(M, R, generator=g).to(dev), torch.randn(M, R, generator=g).to(dev)
     gb = (torch.randn(M, 4 * R, generator=g) * 0.2).to(dev)
     c_prev = torch.randn(M, R, generator=g).to(dev)
-    rows = lstm_packed_rows(R, dev)
-    table = hip.tile_mm(torch.relu(emb), w[:, R:R + E][rows].contiguous())                       # [V, 4R] packed order
-    t_ref = (torch.relu(emb).double() @ w[:, R:R + E].double().t())[:, rows]
+    table = hip.tile_mm(torch.relu(emb), w[:, R:R + E])                                          # [V, 4R], checkpoint gate order
+    t_ref = torch.relu(emb).double() @ w[:, R:R + E].double().t()
     close(table, t_ref.float(), rtol=2e-5, atol=2e-5)
     wp2 = pack_weights(torch.cat([w[:, :R], w[:, R + E:]], 1), R)
     xq2, cq = to_quad(torch.cat([hl, ha], 1)), to_quad(c_prev)
@@ -378,6 +377,35 @@ def test_embedding_gate_schedule_equals_one_launch_per_gemm_schedule(dev, lib, B
     close(a[1][same], ref[1][same], **SEQ_TOL)
     close(e.logprob[:, same], e_ref.logprob[:, same], **SEQ_TOL)
     assert lib.lib().cvc_decode_num_launches(e._plan) == 6 + 7 * d.T
+    e.capture()
+    for _ in range(2):
+        assert all(torch.equal(x, y) for x, y in zip(a, e.run()))
+
+
+@pytest.mark.parametrize("B,beam,dims", [(20, 5, dict(N=30, F=12, R=256, A=64, E=48, V=300, T=5)), (70, 1, dict(N=9, F=4, R=64, A=32, E=32, V=97, T=3)),
+                                         (3, 3, dict(N=7, F=5, R=32, A=16, E=16, V=50, T=4))])
+def test_tile_path_embedding_gate_form_equals_full_k_form(dev, lib, B, beam, dims):
+    """Beam search / more than 64 rows (tile path): the embedding-gate form (gate GEMM over K = 2R, the word's share from the
+    table in cvc_tile_lstm_finish_embgate) against the form with the embedding segment in the GEMM: same hypotheses up to
+    near-ties, scores / attention within the recurrent tolerance; C driver == Python launch list bit for bit."""
+    from helpers import to_dev
+    from cvc.decode import DecodeEngine, DecodeWeights
+    d = dataclasses.replace(synth.CONFIGS["tiny"], B=B, **dims)
+    sd, f_np = synth.hot_path_state_dict(d, 31 + B), synth.clip_features(d, 31 + B)
+    W, f = DecodeWeights(to_dev(sd, dev)), to_dev(f_np, dev)
+    e_ref = DecodeEngine(W, f, d.T, synth.UNK_IDX, beam=beam, embgate=False)
+    e = DecodeEngine(W, f, d.T, synth.UNK_IDX, beam=beam)
+    e_py = DecodeEngine(W, f, d.T, synth.UNK_IDX, beam=beam, driver=False)
+    assert e.tile and e.embgate and e_py.embgate and not e_ref.embgate
+    ref = [x.clone() for x in e_ref.run()]
+    a = [x.clone() for x in e.run()]
+    b = [x.clone() for x in e_py.run()]
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    same = (a[0] == ref[0]).all(1)
+    assert int(same.sum()) >= B - max(1, B // 16)
+    close(a[1][same], ref[1][same], **SEQ_TOL)
+    if beam > 1:
+        close(a[2][same], ref[2][same], rtol=2e-4, atol=2e-4)
     e.capture()
     for _ in range(2):
         assert all(torch.equal(x, y) for x, y in zip(a, e.run()))
