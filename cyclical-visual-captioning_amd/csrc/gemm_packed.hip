@@ -2,6 +2,7 @@
 #include "cvc_common.h"
 #include "gemm_split.h"
 #include "gsk.h"
+#include "dropout_rng.h"
 
 // ==========================================================================================
 // Packed path for the decode engine: both MFMA operands are stored fragment-native in HBM, so a
@@ -60,6 +61,7 @@ struct PackedArgs {
     // per-block top-2 records of all rows
     unsigned* sel_counter;    // one word of device memory, zero between launches
     int64_t* sel_word; int sel_word_stride; float* sel_logprob; int sel_unk;
+    DropSpec h3_drop;         // training form: h_rm3 receives nn.Dropout(h') with the counter-based mask of element m * R + j
     long long wstride;        // floats between consecutive 32-row blocks of wp (0: dense, nquad * 128)
     GskSegs early;            // SLAB form (cvc_packed_lstm_late_fwd): partial tiles of the K range a stream-K launch already covered
 };
@@ -72,6 +74,9 @@ template <int MT>
 struct PFrag {
     f32x4 w[4];
     f32x4 x[MT][4];
+#if defined(CVC_PABL) && CVC_PABL == 6
+    f32x4 x2[MT][2];     // ablation: the extra 50 % of activation bytes a pre-split (3 x bf16) operand would bring in
+#endif
 };
 
 // NW waves split K (chunk c goes to wave c % NW).  NW = 8 puts two waves on every SIMD, each with a shallower
@@ -85,6 +90,21 @@ __device__ __forceinline__ float sum_partials(const float* red, int row, int ldm
         v += (red[(4 * 32 + row) * ldm + m] + red[(5 * 32 + row) * ldm + m]) +
              (red[(6 * 32 + row) * ldm + m] + red[(7 * 32 + row) * ldm + m]);
     return v;
+}
+
+// running top-2 / log-sum-exp of word selection (captioner.py:415-422, 437), merged record by record in a fixed order
+struct SelState { float t1, t2, gm, gs; int j1, j2; };
+__device__ __forceinline__ SelState sel_init() { return SelState{-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), 0.f, 0x7fffffff, 0x7fffffff}; }
+__device__ __forceinline__ bool sel_better(float va, int ia, float vb, int ib) { return (va > vb) | ((va == vb) & (ia < ib)); }
+__device__ __forceinline__ SelState sel_merge(SelState s, float u1, int k1, float u2, int k2, float um, float us) {
+    if (sel_better(u1, k1, s.t1, s.j1)) {
+        if (sel_better(s.t1, s.j1, u2, k2)) { s.t2 = s.t1; s.j2 = s.j1; } else { s.t2 = u2; s.j2 = k2; }
+        s.t1 = u1; s.j1 = k1;
+    } else if (sel_better(u1, k1, s.t2, s.j2)) { s.t2 = u1; s.j2 = k1; }
+    const float nm = fmaxf(s.gm, um);
+    s.gs = (nm == -__builtin_inff()) ? 0.f : s.gs * __expf(s.gm - nm) + us * __expf(um - nm);
+    s.gm = nm;
+    return s;
 }
 
 // NB = 32-row weight blocks per workgroup (LSTM decode form only; selectable experiment, see cvc_packed_lstm_wg_blocks).
@@ -159,12 +179,25 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) f.x[mt][q] = ld4(x + q * 256 + mt * 128);
         }
+#if defined(CVC_PABL) && CVC_PABL == 6
+        {
+            int ja = jr + (n_my >> 1);
+            ja = ja >= n_my ? ja - n_my : ja;
+            const float* xa = xl + (size_t)ja * XSTEP;                // lines this workgroup touched half a loop ago: L2 hits
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) f.x2[mt][s2] = ld4(xa + (s2 + 2) * 256 + mt * 128 + 64);
+        }
+#endif
     };
 
     // embedding-gate form: the table row of this thread's epilogue work item (batch row tid & 63, hidden quad (tid >> 6) & 1) is
     // requested before the K loop -- word, then 4 x 16 bytes of a row that nobody else touches (HBM latency): left to the epilogue
     // it was 4 us of exposed round trips per launch
     f32x4 eadd4[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    // (Folding the previous step's word selection into this launch -- every workgroup merging the 157 x 64 top-2 records itself
+    // -- was built and measured: +8 us on this kernel against 6.5 + 1.5 us for the selection launch it removes; not kept.)
     if constexpr (LSTM && !GRU) {
         if (a.emb_gate != nullptr && tid < NB * 2 * 64) {
             const int em0 = tid & 63;
@@ -183,7 +216,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
         for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
 
     auto mma = [&](const PFrag<MT>& f) __attribute__((always_inline)) {
-#if defined(CVC_PABL) && CVC_PABL >= 2
+#if defined(CVC_PABL) && CVC_PABL >= 2 && CVC_PABL <= 4
 #pragma unroll
         for (int q = 0; q < 4; ++q) {                               // ablation: memory side only, keep the loads live
             asm volatile("" ::"v"(f.w[q]));
@@ -199,7 +232,18 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
                 const Split3 W = split8(f.w[2 * s2], f.w[2 * s2 + 1]);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
+#if defined(CVC_PABL) && (CVC_PABL == 5 || CVC_PABL == 6)
+                    // ablation: activations arrive pre-split (no VALU work on them; 5: same bytes, 6: 1.5 x the bytes) -- timing only
+                    Split3 X;
+                    X.hi = __builtin_bit_cast(u32x4, f.x[mt][2 * s2]); X.mid = __builtin_bit_cast(u32x4, f.x[mt][2 * s2 + 1]);
+#if CVC_PABL == 6
+                    X.lo = __builtin_bit_cast(u32x4, f.x2[mt][s2]);
+#else
+                    X.lo = X.hi;
+#endif
+#else
                     const Split3 X = split8(f.x[mt][2 * s2], f.x[mt][2 * s2 + 1]);
+#endif
                     acc[mt] = mfma_bf16(W.mid, X.mid, acc[mt]);
                     acc[mt] = mfma_bf16(W.lo, X.hi, acc[mt]);
                     acc[mt] = mfma_bf16(W.hi, X.lo, acc[mt]);
@@ -281,7 +325,8 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
 
     if (GRU && ework) {
         // eadd: r, z: x-projection + both biases; n: x-projection + b_in; [3]: b_hn (multiplied by r with the h-projection)
-        const float* gi = a.gru_gi[blockIdx.y] + (size_t)em * a.gru_gi_ld + ejq;
+        // (selects, not a runtime index: indexing the kernel-argument arrays made hipcc copy the whole struct to scratch, 344 B per lane)
+        const float* gi = (blockIdx.y == 0 ? a.gru_gi[0] : a.gru_gi[1]) + (size_t)em * a.gru_gi_ld + ejq;
         ecp = ld4(a.xq + eqoff);                                      // h_prev of these 4 hidden units
 #pragma unroll
         for (int g = 0; g < 3; ++g) {
@@ -364,7 +409,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
                 hv[e] = ng + zg * (ecp[e] - ng);                       // (1 - z) n + z h
             }
             st4(a.h_dst1_q + eqoff, hv);
-            st4(a.gru_y[blockIdx.y] + (size_t)em * a.gru_y_ld + ejq, hv);
+            st4((blockIdx.y == 0 ? a.gru_y[0] : a.gru_y[1]) + (size_t)em * a.gru_y_ld + ejq, hv);
         }
     } else if (LSTM) {
         // unit u -> (batch row m fastest, quad-of-hidden qd in 0..1): a thread finishes 4 hidden units
@@ -395,7 +440,16 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
             if (a.h_dst2_q != nullptr) st4(a.h_dst2_q + eqoff, hv);
             if (a.h_rm != nullptr) st4(a.h_rm + (size_t)em * R + ejq, hv);
             if (a.h_rm2 != nullptr) st4(a.h_rm2 + (size_t)em * R + ejq, hv);
-            if (a.h_rm3 != nullptr) st4(a.h_rm3 + (size_t)em * R + ejq, hv);
+            if (a.h_rm3 != nullptr) {
+                f32x4 hd = hv;
+                if (a.h3_drop.state != nullptr) {                  // decoder_core.py:62, 109: output = dropout(h_lang), fused
+                    const uint32_t s0 = a.h3_drop.state[0], s1 = a.h3_drop.state[1], s2 = a.h3_drop.state[2];
+                    const uint32_t i0 = (uint32_t)em * (uint32_t)R + (uint32_t)ejq;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hd[e] *= cvc_drop_mult(a.h3_drop, s0, s1, s2, i0 + e);
+                }
+                st4(a.h_rm3 + (size_t)em * R + ejq, hd);
+            }
             if (a.c_rm != nullptr) st4(a.c_rm + (size_t)em * R + ejq, cv);
             if (a.gates_rm != nullptr) {
 #pragma unroll
@@ -477,18 +531,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
                 __syncthreads();                                          // (flag read by everyone before scratch is reused)
                 // thread (row m = lane, slice w = wave): records w, w + NW, ... merged in index order; then the NW slices per row
                 const int nb = (int)gridDim.x;
-                float t1 = -__builtin_inff(), t2 = -__builtin_inff(), gm = -__builtin_inff(), gs = 0.f;
-                int j1 = 0x7fffffff, j2 = 0x7fffffff;
-                auto better = [](float va, int ia, float vb, int ib) { return (va > vb) | ((va == vb) & (ia < ib)); };
-                auto merge1 = [&](float u1, int k1, float u2, int k2, float um, float us) {
-                    if (better(u1, k1, t1, j1)) {
-                        if (better(t1, j1, u2, k2)) { t2 = t1; j2 = j1; } else { t2 = u2; j2 = k2; }
-                        t1 = u1; j1 = k1;
-                    } else if (better(u1, k1, t2, j2)) { t2 = u1; j2 = k1; }
-                    const float nm = fmaxf(gm, um);
-                    gs = (nm == -__builtin_inff()) ? 0.f : gs * __expf(gm - nm) + us * __expf(um - nm);
-                    gm = nm;
-                };
+                SelState ss = sel_init();
                 const int mrow = lane < M ? lane : M - 1;
                 // the records were stored write-through: every read is a round trip to memory, so a batch of them is requested
                 // before the first merge (unconditional loads of a clamped index; one record at a time this tail took 20 us)
@@ -503,21 +546,21 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
                     }
 #pragma unroll
                     for (int k = 0; k < RB; ++k)
-                        if (b0 + k * NW < nb) merge1(r0[k].x, __float_as_int(r0[k].y), r1[k].x, __float_as_int(r1[k].y), r2[k].x, r2[k].y);
+                        if (b0 + k * NW < nb) ss = sel_merge(ss, r0[k].x, __float_as_int(r0[k].y), r1[k].x, __float_as_int(r1[k].y), r2[k].x, r2[k].y);
                 }
                 float* r8 = scratch + ((size_t)wave * 64 + lane) * 6;
-                r8[0] = t1; r8[1] = __int_as_float(j1); r8[2] = t2; r8[3] = __int_as_float(j2); r8[4] = gm; r8[5] = gs;
+                r8[0] = ss.t1; r8[1] = __int_as_float(ss.j1); r8[2] = ss.t2; r8[3] = __int_as_float(ss.j2); r8[4] = ss.gm; r8[5] = ss.gs;
                 __syncthreads();
                 if (wave == 0 && lane < M) {
                     for (int w = 1; w < NW; ++w) {
                         const float* q4 = scratch + ((size_t)w * 64 + lane) * 6;
-                        merge1(q4[0], __float_as_int(q4[1]), q4[2], __float_as_int(q4[3]), q4[4], q4[5]);
+                        ss = sel_merge(ss, q4[0], __float_as_int(q4[1]), q4[2], __float_as_int(q4[3]), q4[4], q4[5]);
                     }
-                    const bool use2 = (j1 == a.sel_unk) && j2 != 0x7fffffff;          // captioner.py:417-421
-                    int wsel = use2 ? j2 : j1;
+                    const bool use2 = (ss.j1 == a.sel_unk) && ss.j2 != 0x7fffffff;          // captioner.py:417-421
+                    int wsel = use2 ? ss.j2 : ss.j1;
                     if (wsel == 0x7fffffff || wsel < 0) wsel = 0;                      // all-NaN logits (see top2_final_kernel)
                     a.sel_word[(size_t)lane * a.sel_word_stride] = wsel;
-                    if (a.sel_logprob != nullptr) a.sel_logprob[lane] = (use2 ? t2 : t1) - (gm + __logf(gs));
+                    if (a.sel_logprob != nullptr) a.sel_logprob[lane] = (use2 ? ss.t2 : ss.t1) - (ss.gm + __logf(ss.gs));
                 }
             }
         }
@@ -619,7 +662,16 @@ extern "C" int cvc_packed_lstm_late_fwd(const float* wp, long long w_blk_stride,
 
 static int packed_lstm_train_impl(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh, const float* gate_pre,
                                   const float* c_prev, int M, int R, float* h_out, float* c_out, float* gates_out, float* h_out2,
-                                  float* h_out3, cvc_stream_t stream);
+                                  float* h_out3, cvc_stream_t stream, DropSpec h3_drop = DropSpec{nullptr, 0, 0, 0.f});
+
+extern "C" int cvc_packed_lstm_train_drop_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
+                                              const float* gate_pre, const float* c_prev, int M, int R, float* h_out, float* c_out,
+                                              float* gates_out, float* h_out2, float* h_drop_out, const uint32_t* rng_state,
+                                              unsigned site, float p, cvc_stream_t stream) {
+    if (!h_drop_out || !rng_state || p < 0.f || p >= 1.f) return CVC_E_BADARG;
+    return packed_lstm_train_impl(wp, xq, K, b_ih, b_hh, gate_pre, c_prev, M, R, h_out, c_out, gates_out, h_out2, h_drop_out, stream,
+                                  cvc_drop_spec(rng_state, site, p));
+}
 
 extern "C" int cvc_packed_lstm_train_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
                                          const float* c_prev, int M, int R, float* h_out, float* c_out, float* gates_out,
@@ -636,10 +688,11 @@ extern "C" int cvc_packed_lstm_train_pre_fwd(const float* wp, const float* xq, i
 
 static int packed_lstm_train_impl(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh, const float* gate_pre,
                                   const float* c_prev, int M, int R, float* h_out, float* c_out, float* gates_out, float* h_out2,
-                                  float* h_out3, cvc_stream_t stream) {
+                                  float* h_out3, cvc_stream_t stream, DropSpec h3_drop) {
     if (!wp || !xq || !c_prev || !h_out || !c_out || (K & 31) || R < 8 || (R & 7)) return CVC_E_BADARG;
     PackedArgs a{};
     a.gate_bias = gate_pre;
+    a.h3_drop = h3_drop;
     a.h_rm2 = h_out2; a.h_rm3 = h_out3;
     a.wp = wp; a.xq = xq; a.nquad = K / 4; a.M = M; a.Nout = 4 * R; a.R = R;
     a.bias = b_ih; a.bias2 = b_hh; a.c_prev_rm = c_prev; a.h_rm = h_out; a.c_rm = c_out; a.gates_rm = gates_out; a.ksplit = 1;

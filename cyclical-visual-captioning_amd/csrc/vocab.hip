@@ -6,6 +6,7 @@
 // point is to keep it on the device and inside the captured decode graph.
 #include "cvc_common.h"
 #include "gsk.h"
+#include "dropout_rng.h"
 #include <math.h>
 
 namespace {
@@ -30,7 +31,7 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 }
 
 // ------------------------------------------------------------------ embedding
-__global__ __launch_bounds__(WG) void embed_relu_fwd_kernel(const float* table, const int64_t* idx, const float* drop,
+__global__ __launch_bounds__(WG) void embed_relu_fwd_kernel(const float* table, const int64_t* idx, const float* drop, DropSpec rng,
                                                             int M, int E, float* out) {
     const int m = blockIdx.y;
     const int e = (blockIdx.x * WG + threadIdx.x) * 4;
@@ -38,7 +39,27 @@ __global__ __launch_bounds__(WG) void embed_relu_fwd_kernel(const float* table, 
     f32x4 v = ld4(table + (size_t)idx[m] * E + e);
     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     if (drop != nullptr) v *= ld4(drop + (size_t)m * E + e);
+    if (rng.state != nullptr) {                               // mask of element (m, e) generated here (dropout_rng.h)
+        const uint32_t s0 = rng.state[0], s1 = rng.state[1], s2 = rng.state[2], i0 = (uint32_t)m * (uint32_t)E + (uint32_t)e;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= cvc_drop_mult(rng, s0, s1, s2, i0 + k);
+    }
     st4(out + (size_t)m * E + e, v);
+}
+
+// y = x * mask(site, element index): nn.Dropout with the counter-based masks, for the sites no producing kernel fuses
+__global__ __launch_bounds__(WG) void dropout_rng_kernel(const float* x, DropSpec rng, size_t n, float* y) {
+    const size_t i = ((size_t)blockIdx.x * WG + threadIdx.x) * 4;
+    if (i >= n) return;
+    const uint32_t s0 = rng.state[0], s1 = rng.state[1], s2 = rng.state[2];
+    if (i + 4 <= n) {
+        f32x4 v = ld4(x + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] *= cvc_drop_mult(rng, s0, s1, s2, (uint32_t)(i + k));
+        st4(y + i, v);
+    } else {
+        for (size_t k = i; k < n; ++k) y[k] = x[k] * cvc_drop_mult(rng, s0, s1, s2, (uint32_t)k);
+    }
 }
 
 // Deterministic scatter-add without atomics and without a host round trip: the host passes a stable argsort
@@ -50,7 +71,7 @@ __global__ __launch_bounds__(WG) void embed_relu_fwd_kernel(const float* table, 
 // is thereby summed by run/EMB_CHUNK workgroups in parallel instead of one workgroup walking it row by row.
 constexpr int EMB_CHUNK = 16;
 
-__global__ __launch_bounds__(WG) void embed_bwd_pieces_kernel(const int64_t* idx, const int64_t* order, const float* drop,
+__global__ __launch_bounds__(WG) void embed_bwd_pieces_kernel(const int64_t* idx, const int64_t* order, const float* drop, DropSpec rng,
                                                               const float* d_out, int M, int E, float* part) {
     const int r0 = blockIdx.y * EMB_CHUNK;
     const int e = (blockIdx.x * WG + threadIdx.x) * 4;
@@ -70,6 +91,11 @@ __global__ __launch_bounds__(WG) void embed_bwd_pieces_kernel(const int64_t* idx
         }
         f32x4 g = ld4(d_out + (size_t)m * E + e);
         if (drop != nullptr) g *= ld4(drop + (size_t)m * E + e);
+        if (rng.state != nullptr) {                           // the forward's mask, regenerated
+            const uint32_t s0 = rng.state[0], s1 = rng.state[1], s2 = rng.state[2], i0 = (uint32_t)m * (uint32_t)E + (uint32_t)e;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] *= cvc_drop_mult(rng, s0, s1, s2, i0 + k);
+        }
         acc += g;
     }
     st4(part + (size_t)start * E + e, acc);
@@ -386,7 +412,8 @@ __global__ __launch_bounds__(WG) void vocab_nll_bwd_kernel(const float* logits, 
 // ------------------------------------------------------------------ LSTM pointwise backward
 __global__ __launch_bounds__(WG) void lstm_pointwise_bwd_kernel(const float* d_h, const float* d_h2, const float* d_h3, const float* d_c,
                                                                 const float* gates, const float* c_prev, const float* c_new, int M,
-                                                                int R, float* d_gates, float* d_c_prev, float* d_gates_q) {
+                                                                int R, float* d_gates, float* d_c_prev, float* d_gates_q,
+                                                                DropSpec rng3) {
     const int j = blockIdx.x * WG + threadIdx.x;
     const int m = blockIdx.y;
     if (j >= R) return;
@@ -394,7 +421,10 @@ __global__ __launch_bounds__(WG) void lstm_pointwise_bwd_kernel(const float* d_h
     const float ig = gates[g0], fg = gates[g0 + R], gg = gates[g0 + 2 * R], og = gates[g0 + 3 * R];
     const float tc = tanhf(c_new[o]);
     // h' may have gone out as up to three tensors (one per consumer): their gradients are summed here, not by autograd
-    const float dh = ((d_h != nullptr ? d_h[o] : 0.f) + (d_h2 != nullptr ? d_h2[o] : 0.f)) + (d_h3 != nullptr ? d_h3[o] : 0.f);
+    // (rng3: the third tensor went out through nn.Dropout fused into the cell's launch -- its gradient takes the same mask)
+    float dh3 = d_h3 != nullptr ? d_h3[o] : 0.f;
+    if (rng3.state != nullptr) dh3 *= cvc_drop_mult(rng3, rng3.state[0], rng3.state[1], rng3.state[2], (uint32_t)o);
+    const float dh = ((d_h != nullptr ? d_h[o] : 0.f) + (d_h2 != nullptr ? d_h2[o] : 0.f)) + dh3;
     const float dcn = (d_c != nullptr ? d_c[o] : 0.f) + dh * og * (1.f - tc * tc);
     const float d0 = dcn * gg * ig * (1.f - ig), d1 = dcn * c_prev[o] * fg * (1.f - fg);
     const float d2 = dcn * ig * (1.f - gg * gg), d3 = dh * tc * og * (1.f - og);
@@ -638,22 +668,54 @@ __global__ __launch_bounds__(WG) void gather_rows_kernel(const float* src, const
 
 extern "C" const char* cvc_version(void) { return "cvc_hip 0.1 gfx950"; }
 
+static int embed_fwd_impl(const float* table, const int64_t* idx, const float* drop, DropSpec rng, int M, int E, float* out,
+                          cvc_stream_t stream) {
+    if (!table || !idx || !out || M < 1 || E < 4 || (E & 3) || (long long)M * E > 0xffffffffll) return CVC_E_BADARG;
+    hipLaunchKernelGGL(embed_relu_fwd_kernel, dim3((E / 4 + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, table, idx,
+                       drop, rng, M, E, out);
+    return cvc_launch_status();
+}
+
+static int embed_bwd_impl(const float* table, const int64_t* idx, const int64_t* order, const float* drop, DropSpec rng,
+                          const float* d_out, int M, int E, float* d_table, float* workspace, cvc_stream_t stream) {
+    if (!table || !idx || !order || !d_out || !d_table || !workspace || M < 1 || E < 4 || (E & 3)) return CVC_E_BADARG;
+    const int gx = (E / 4 + WG - 1) / WG;
+    hipLaunchKernelGGL(embed_bwd_pieces_kernel, dim3(gx, (M + EMB_CHUNK - 1) / EMB_CHUNK), dim3(WG), 0, (hipStream_t)stream, idx,
+                       order, drop, rng, d_out, M, E, workspace);
+    hipLaunchKernelGGL(embed_bwd_runs_kernel, dim3(gx, M), dim3(WG), 0, (hipStream_t)stream, table, idx, order, workspace, M, E,
+                       d_table);
+    return cvc_launch_status();
+}
+
 extern "C" int cvc_embed_relu_fwd(const float* table, const int64_t* idx, const float* drop, int M, int E, float* out,
                                   cvc_stream_t stream) {
-    if (!table || !idx || !out || M < 1 || E < 4 || (E & 3)) return CVC_E_BADARG;
-    hipLaunchKernelGGL(embed_relu_fwd_kernel, dim3((E / 4 + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, table, idx,
-                       drop, M, E, out);
-    return cvc_launch_status();
+    return embed_fwd_impl(table, idx, drop, cvc_drop_spec(nullptr, 0, 0.f), M, E, out, stream);
 }
 
 extern "C" int cvc_embed_relu_bwd(const float* table, const int64_t* idx, const int64_t* order, const float* drop,
                                   const float* d_out, int M, int E, float* d_table, float* workspace, cvc_stream_t stream) {
-    if (!table || !idx || !order || !d_out || !d_table || !workspace || M < 1 || E < 4 || (E & 3)) return CVC_E_BADARG;
-    const int gx = (E / 4 + WG - 1) / WG;
-    hipLaunchKernelGGL(embed_bwd_pieces_kernel, dim3(gx, (M + EMB_CHUNK - 1) / EMB_CHUNK), dim3(WG), 0, (hipStream_t)stream, idx,
-                       order, drop, d_out, M, E, workspace);
-    hipLaunchKernelGGL(embed_bwd_runs_kernel, dim3(gx, M), dim3(WG), 0, (hipStream_t)stream, table, idx, order, workspace, M, E,
-                       d_table);
+    return embed_bwd_impl(table, idx, order, drop, cvc_drop_spec(nullptr, 0, 0.f), d_out, M, E, d_table, workspace, stream);
+}
+
+extern "C" int cvc_embed_relu_rng_fwd(const float* table, const int64_t* idx, const uint32_t* rng_state, unsigned site, float p, int M,
+                                      int E, float* out, cvc_stream_t stream) {
+    if (!rng_state || p < 0.f || p >= 1.f) return CVC_E_BADARG;
+    return embed_fwd_impl(table, idx, nullptr, cvc_drop_spec(rng_state, site, p), M, E, out, stream);
+}
+
+extern "C" int cvc_embed_relu_rng_bwd(const float* table, const int64_t* idx, const int64_t* order, const uint32_t* rng_state,
+                                      unsigned site, float p, const float* d_out, int M, int E, float* d_table, float* workspace,
+                                      cvc_stream_t stream) {
+    if (!rng_state || p < 0.f || p >= 1.f) return CVC_E_BADARG;
+    return embed_bwd_impl(table, idx, order, nullptr, cvc_drop_spec(rng_state, site, p), d_out, M, E, d_table, workspace, stream);
+}
+
+extern "C" int cvc_dropout_rng(const float* x, long long n, const uint32_t* rng_state, unsigned site, float p, float* y,
+                               cvc_stream_t stream) {
+    if (!x || !y || !rng_state || n < 1 || n > 0xffffffffll || p < 0.f || p >= 1.f || ((uintptr_t)x & 15) || ((uintptr_t)y & 15))
+        return CVC_E_BADARG;
+    hipLaunchKernelGGL(dropout_rng_kernel, dim3((unsigned)((n / 4 + WG) / WG)), dim3(WG), 0, (hipStream_t)stream, x,
+                       cvc_drop_spec(rng_state, site, p), (size_t)n, y);
     return cvc_launch_status();
 }
 
@@ -745,7 +807,7 @@ extern "C" int cvc_lstm_pointwise_bwd(const float* d_h, const float* d_c, const 
     if (!gates || !c_prev || !c_new || !d_gates || !d_c_prev || M < 1 || R < 1) return CVC_E_BADARG;
     if (d_gates_q != nullptr && (M > 64 || (R & 3))) return CVC_E_BADARG;
     hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3((R + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, d_h, nullptr, nullptr,
-                       d_c, gates, c_prev, c_new, M, R, d_gates, d_c_prev, d_gates_q);
+                       d_c, gates, c_prev, c_new, M, R, d_gates, d_c_prev, d_gates_q, cvc_drop_spec(nullptr, 0, 0.f));
     return cvc_launch_status();
 }
 
@@ -756,7 +818,19 @@ extern "C" int cvc_lstm_pointwise_bwd3(const float* d_h, const float* d_h2, cons
     if (!gates || !c_prev || !c_new || !d_gates || !d_c_prev || M < 1 || R < 1) return CVC_E_BADARG;
     if (d_gates_q != nullptr && (M > 64 || (R & 3))) return CVC_E_BADARG;
     hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3((R + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, d_h, d_h2, d_h3, d_c,
-                       gates, c_prev, c_new, M, R, d_gates, d_c_prev, d_gates_q);
+                       gates, c_prev, c_new, M, R, d_gates, d_c_prev, d_gates_q, cvc_drop_spec(nullptr, 0, 0.f));
+    return cvc_launch_status();
+}
+
+// ... where the third copy of h' went out through the dropout fused into cvc_packed_lstm_train_drop_fwd: d_h3 takes that mask
+extern "C" int cvc_lstm_pointwise_bwd3_drop(const float* d_h, const float* d_h2, const float* d_h3, const uint32_t* rng_state,
+                                            unsigned site, float p, const float* d_c, const float* gates, const float* c_prev,
+                                            const float* c_new, int M, int R, float* d_gates, float* d_c_prev, float* d_gates_q,
+                                            cvc_stream_t stream) {
+    if (!gates || !c_prev || !c_new || !d_gates || !d_c_prev || M < 1 || R < 1 || !rng_state || p < 0.f || p >= 1.f) return CVC_E_BADARG;
+    if (d_gates_q != nullptr && (M > 64 || (R & 3))) return CVC_E_BADARG;
+    hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3((R + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, d_h, d_h2, d_h3, d_c,
+                       gates, c_prev, c_new, M, R, d_gates, d_c_prev, d_gates_q, cvc_drop_spec(rng_state, site, p));
     return cvc_launch_status();
 }
 

@@ -480,6 +480,7 @@ class DecodeEngine:
         ptr = lambda t: None if t is None else t.data_ptr()
         qoff = lambda buf, k0: buf.data_ptr() + (k0 // 4) * 64 * 4 * 4
         out = []
+        nblk_v = (V + 31) // 32
         for t in range(self.T):
             rd, wr = t & 1, (t + 1) & 1
             XA_r, XA_w, XL_r, XL_w = self.XA[rd], self.XA[wr], self.XL[rd], self.XL[wr]
@@ -503,7 +504,7 @@ class DecodeEngine:
             # 20.0 + 7.4 us for these two launches: atomics, fence and a serial merge on one CU cost more than a launch boundary)
             out.append(("logits", L.cvc_packed_linear_fwd, (ptr(W.p_o), ptr(XA_w), R, ptr(W.b_o), rows, V, 1, None, V,
                                                             ptr(self.top2_part))))
-            out.append(("word_select", L.cvc_top2_final, (ptr(self.top2_part), (V + 31) // 32, rows, self.unk, ptr(self.words[t + 1]), 1,
+            out.append(("word_select", L.cvc_top2_final, (ptr(self.top2_part), nblk_v, rows, self.unk, ptr(self.words[t + 1]), 1,
                                                           ptr(self.logprob[t]), None, 0, None, 0)))
             self._keep.append(sets)
         return out

@@ -256,7 +256,7 @@ class _LstmCell(torch.autograd.Function):
     streams only the other columns of weight_ih (the pack `wp` covers exactly those) and weight_hh."""
 
     @staticmethod
-    def forward(ctx, w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, wp, copies, gate_pre, hoisted, *xs):
+    def forward(ctx, w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, wp, copies, gate_pre, hoisted, drop, *xs):
         xs = [_rows(x) for x in xs]
         h_prev, c_prev = _c(h_prev), _c(c_prev)
         k0 = sum(x.shape[1] for x in xs)
@@ -265,16 +265,18 @@ class _LstmCell(torch.autograd.Function):
         M, R = c_prev.shape
         ctx.hoisted = tuple(hoisted) if gate_pre is not None else tuple(False for _ in xs)
         rec = [x for x, hz in zip(xs, ctx.hoisted) if not hz]
-        if gate_pre is not None:
-            assert wp is not None, "a hoisted cell runs on the packed gate GEMM"
-            h, c, gates = hip.lstm_cell_train_fwd(rec, h_prev, c_prev, wp, b_ih, b_hh, want_gates=need_bwd, copies=copies,
-                                                  gate_pre=_c(gate_pre))
-            hs = h if copies > 1 else (h,)
-        elif wp is not None and all(x.data_ptr() % 16 == 0 for x in (*xs, h_prev)):
+        # drop = (generator state, site id, p): one more output, nn.Dropout(h') with the mask generated inside the cell's kernel
+        hd = None
+        if wp is not None and (gate_pre is not None or all(x.data_ptr() % 16 == 0 for x in (*xs, h_prev))):
             # the decode engine's packed gate GEMM; `wp` is the pack lstm_cell() found on (or built for) the weight tensors
-            h, c, gates = hip.lstm_cell_train_fwd(xs, h_prev, c_prev, wp, b_ih, b_hh, want_gates=need_bwd, copies=copies)
+            # (a hoisted cell streams only the segments that were not multiplied beforehand)
+            h, c, gates = hip.lstm_cell_train_fwd(rec if gate_pre is not None else xs, h_prev, c_prev, wp, b_ih, b_hh,
+                                                  want_gates=need_bwd, copies=copies, gate_pre=_c(gate_pre), drop=drop)
+            if drop is not None:
+                h, hd = h
             hs = h if copies > 1 else (h,)
         else:
+            assert gate_pre is None, "a hoisted cell runs on the packed gate GEMM"
             segs, k0 = [], 0
             for x in xs:
                 segs.append({"x": x, "w": w_ih[:, k0:k0 + x.shape[1]]})
@@ -282,7 +284,10 @@ class _LstmCell(torch.autograd.Function):
             segs.append({"x": h_prev, "w": w_hh})
             h, c, gates = hip.lstm_cell_fwd(segs, b_ih, b_hh, c_prev, want_gates=need_bwd)
             hs = (h,) + tuple(h.clone() for _ in range(copies - 1))
+            if drop is not None:
+                hd = hip.dropout_rng(h, *drop)
         ctx.ncopy = len(hs)
+        ctx.drop = drop
         ctx.set_materialize_grads(False)          # an unused h or c arrives as None, not as a zero-filled tensor
         if need_bwd:
             ctx.save_for_backward(w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, c, gates, *xs)
@@ -290,22 +295,31 @@ class _LstmCell(torch.autograd.Function):
             ctx.defer = bool(ctx.needs_input_grad[0] and ctx.needs_input_grad[1])
             if ctx.defer:
                 _BATCHER.note_use(ctx.key)
-        return (*hs, c)
+        return (*hs, c) if drop is None else (*hs, hd, c)
 
     @staticmethod
     def backward(ctx, *d):
-        # d = (gradients of the `ncopy` copies of h'..., d_c): the copies' gradients are summed inside the gate-gradient kernel
+        # d = (gradients of the `ncopy` copies of h'..., [of the dropped copy,] d_c): summed inside the gate-gradient kernel
         w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, c_new, gates, *xs = ctx.saved_tensors
         ni = ctx.needs_input_grad
         d_hs = [g for g in d[:ctx.ncopy] if g is not None]
-        d_c = d[ctx.ncopy]
-        if not d_hs and d_c is None:
+        d_hd = None
+        if ctx.drop is not None:
+            d_hd, d_c = d[ctx.ncopy], d[ctx.ncopy + 1]
+        else:
+            d_c = d[ctx.ncopy]
+        if not d_hs and d_c is None and d_hd is None:
             d_hs = [torch.zeros_like(c_new)]      # (keeps the deferred-weight-gradient use count exact)
-        d_hs = [_c(g) for g in d_hs] + [None] * (3 - len(d_hs))
+        if ctx.drop is not None:
+            # the dropped copy's gradient rides in the third slot, where the kernel multiplies it by the regenerated mask
+            assert len(d_hs) <= 2
+            d_hs = [_c(g) for g in d_hs] + [None] * (2 - len(d_hs)) + [_c(d_hd) if d_hd is not None else None]
+        else:
+            d_hs = [_c(g) for g in d_hs] + [None] * (3 - len(d_hs))
         M, K = gates.shape
         # dX ranges that need a gradient: (weight, first column, width) in the order h_prev, xs... (a hoisted segment's gradient
         # comes from _HoistedGates' one product over all steps, not from here)
-        XS0 = 10                                                      # index of xs[0] among forward's inputs
+        XS0 = 11                                                      # index of xs[0] among forward's inputs
         want_x = [bool(ni[XS0 + i]) and not ctx.hoisted[i] for i in range(len(xs))]
         ranges, k0 = ([(w_hh, 0, w_hh.shape[1])] if ni[4] else []), 0
         for i, x in enumerate(xs):
@@ -313,7 +327,8 @@ class _LstmCell(torch.autograd.Function):
                 ranges.append((w_ih, k0, x.shape[1]))
             k0 += x.shape[1]
         use_nn = bool(ranges) and hip.linear_nn_ok(M, K, ranges)
-        pw = hip.lstm_pointwise_bwd(d_hs[0], _c(d_c), gates, c_prev, c_new, want_quad=use_nn, d_h2=d_hs[1], d_h3=d_hs[2])
+        pw = hip.lstm_pointwise_bwd(d_hs[0], _c(d_c), gates, c_prev, c_new, want_quad=use_nn, d_h2=d_hs[1], d_h3=d_hs[2],
+                                    drop3=ctx.drop)
         d_gates, d_c_prev = pw[0], pw[1]
         d_w_ih = d_w_hh = d_b = None
         if ctx.defer:
@@ -347,16 +362,20 @@ class _LstmCell(torch.autograd.Function):
                 d_xs.append(_mm_nn(d_gates, w_ih[:, k0:k0 + k]) if want_x[i] else None)
                 k0 += k
         return (d_w_ih, d_w_hh, d_b if ni[2] else None, d_b if ni[3] else None, d_h_prev,
-                d_c_prev if ni[5] else None, None, None, (d_gates if ni[8] else None), None, *d_xs)
+                d_c_prev if ni[5] else None, None, None, (d_gates if ni[8] else None), None, None, *d_xs)
 
 
 def lstm_cell(xs: Sequence[Tensor], h_prev: Tensor, c_prev: Tensor, w_ih, w_hh, b_ih, b_hh, copies: int = 1,
-              gate_pre: Optional[Tensor] = None, hoisted: Optional[Sequence[bool]] = None):
+              gate_pre: Optional[Tensor] = None, hoisted: Optional[Sequence[bool]] = None, drop=None):
     """-> (h', c'), or with copies = k > 1: (h'_1, ..., h'_k, c') -- k tensors holding the same h', one per consumer, so that
     autograd has no fan-out to accumulate (their gradients are summed inside the cell's backward kernel).
-    gate_pre [M, 4R] + hoisted (one flag per segment of xs): this step's slice of hoisted_gates() for the flagged segments."""
+    gate_pre [M, 4R] + hoisted (one flag per segment of xs): this step's slice of hoisted_gates() for the flagged segments.
+    drop = (generator state, site id, p) (cvc/dropout.py): -> (h'_1, ..[h'_2], dropout(h'), c'), copies <= 2 -- the cell's kernel
+    writes nn.Dropout(h') as one more tensor, mask generated in the kernel (decoder_core.py:62, 109)."""
     wp = None
     M, R = c_prev.shape
+    if drop is not None:
+        copies = min(2, int(copies))
     packable = PACKED_LSTM_FORWARD and w_ih.is_cuda and w_ih.is_contiguous() and w_hh.is_contiguous()
     if gate_pre is not None:
         widths = [x.shape[1] for x, hz in zip(xs, hoisted) if not hz] + [h_prev.shape[1]]
@@ -364,17 +383,18 @@ def lstm_cell(xs: Sequence[Tensor], h_prev: Tensor, c_prev: Tensor, w_ih, w_hh, 
         if not ok:
             # shapes the packed kernel does not take: the plain cell over ALL segments (xs holds every one of them); gate_pre is
             # ignored, so its producer receives no gradient and the hoisted segments get theirs from this cell instead
-            return lstm_cell(xs, h_prev, c_prev, w_ih, w_hh, b_ih, b_hh, copies=copies)
+            return lstm_cell(xs, h_prev, c_prev, w_ih, w_hh, b_ih, b_hh, copies=copies, drop=drop)
         cols, k0 = [], 0
         for x, hz in zip(xs, hoisted):
             if not hz:
                 cols.append((k0, x.shape[1]))
             k0 += x.shape[1]
         wp = hip.lstm_train_pack(w_ih, w_hh, cols=cols)
-        return _LstmCell.apply(w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, wp, max(1, min(3, int(copies))), gate_pre, tuple(hoisted), *xs)
+        return _LstmCell.apply(w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, wp, max(1, min(3, int(copies))), gate_pre, tuple(hoisted), drop,
+                               *xs)
     if packable and hip.lstm_train_ok(M, R, [x.shape[1] for x in xs] + [h_prev.shape[1]]):
         wp = hip.lstm_train_pack(w_ih, w_hh)          # lives on the parameter object; rebuilt once per optimizer step
-    return _LstmCell.apply(w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, wp, max(1, min(3, int(copies))), None, None, *xs)
+    return _LstmCell.apply(w_ih, w_hh, b_ih, b_hh, h_prev, c_prev, wp, max(1, min(3, int(copies))), None, None, drop, *xs)
 
 
 # ------------------------------------------------------------------------------- attention
@@ -494,23 +514,29 @@ def attention(kind: int, q: Tensor, w_a: Optional[Tensor], b_a: Optional[Tensor]
 # ------------------------------------------------------------------------------- embedding / vocab head
 class _EmbedRelu(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, table, idx, drop):
+    def forward(ctx, table, idx, drop, rng):
         idx = idx.contiguous()
-        out = hip.embed_relu_fwd(table, idx, drop)
+        # rng = (generator state, site id, p): the keep-mask is generated inside the kernel (cvc/dropout.py), forward and backward
+        out = hip.embed_relu_rng_fwd(table, idx, *rng) if rng is not None else hip.embed_relu_fwd(table, idx, drop)
         ctx.save_for_backward(table, idx, drop if drop is not None else table.new_zeros(()))
         ctx.has_drop = drop is not None
+        ctx.rng = rng
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         table, idx, drop = ctx.saved_tensors
-        return hip.embed_relu_bwd(table, idx, drop if ctx.has_drop else None, d_out.contiguous()), None, None
+        if ctx.rng is not None:
+            return hip.embed_relu_rng_bwd(table, idx, *ctx.rng, d_out.contiguous()), None, None, None
+        return hip.embed_relu_bwd(table, idx, drop if ctx.has_drop else None, d_out.contiguous()), None, None, None
 
 
-def embed_relu(table: Tensor, idx: Tensor, drop: Optional[Tensor] = None) -> Tensor:
-    """relu(Embedding(idx)) (* dropout keep-mask / (1-p)), captioner.py:53-68."""
+def embed_relu(table: Tensor, idx: Tensor, drop: Optional[Tensor] = None, rng=None) -> Tensor:
+    """relu(Embedding(idx)) (* dropout keep-mask / (1-p)), captioner.py:53-68.  drop: the mask as a tensor; rng = (state, site,
+    p): the mask generated in the kernel instead (one or the other)."""
+    assert drop is None or rng is None
     shape = idx.shape
-    out = _EmbedRelu.apply(table, idx.reshape(-1), drop)
+    out = _EmbedRelu.apply(table, idx.reshape(-1), drop, rng)
     return out.reshape(*shape, -1)
 
 

@@ -119,6 +119,11 @@ SIGNATURES = {
     "cvc_pack_quad": [_P, _LL, _I, _I, _P, _P],
     "cvc_embed_relu_fwd": [_P, _P, _P, _I, _I, _P, _P],
     "cvc_embed_relu_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
+    "cvc_embed_relu_rng_fwd": [_P, _P, _P, C.c_uint, _F, _I, _I, _P, _P],
+    "cvc_embed_relu_rng_bwd": [_P, _P, _P, _P, C.c_uint, _F, _P, _I, _I, _P, _P, _P],
+    "cvc_dropout_rng": [_P, _LL, _P, C.c_uint, _F, _P, _P],
+    "cvc_packed_lstm_train_drop_fwd": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, C.c_uint, _F, _P],
+    "cvc_lstm_pointwise_bwd3_drop": [_P, _P, _P, _P, C.c_uint, _F, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "cvc_log_softmax_fwd": [_P, _I, _I, _P, _P],
     "cvc_log_softmax_bwd": [_P, _P, _I, _I, _P, _P],
     "cvc_nll_bwd": [_P, _P, _P, _I, _I, _P, _P],
@@ -458,15 +463,26 @@ def pack_quad_segs(xs: Sequence[torch.Tensor]) -> torch.Tensor:
 
 
 def lstm_cell_train_fwd(xs: Sequence[torch.Tensor], h_prev, c_prev, wp, b_ih, b_hh, want_gates: bool = True, copies: int = 1,
-                        gate_pre: Optional[torch.Tensor] = None):
+                        gate_pre: Optional[torch.Tensor] = None, drop=None):
     """nn.LSTMCell forward on the packed gate GEMM (cvc_packed_lstm_train_fwd) from the pack `lstm_train_pack` built:
     -> h (a tuple of `copies` identical tensors when copies > 1), c, activated gates (or None).  gate_pre [M, 4R]: the
-    contribution of input segments multiplied beforehand for all steps (hoisted cell); xs are then the remaining segments."""
+    contribution of input segments multiplied beforehand for all steps (hoisted cell); xs are then the remaining segments.
+    drop = (rng_state, site, p): one more output tensor, nn.Dropout(h') with the in-kernel mask (copies <= 2 then):
+    -> (h or tuple of h, h_dropped), c, gates."""
     M, R = c_prev.shape
     xq = pack_quad_segs([*xs, h_prev])
-    hs = [torch.empty_like(c_prev) for _ in range(max(1, min(3, copies)))]
     c = torch.empty_like(c_prev)
     gates = torch.empty(M, 4 * R, device=c_prev.device, dtype=torch.float32) if want_gates else None
+    if drop is not None:
+        state, site, p = drop
+        hs = [torch.empty_like(c_prev) for _ in range(max(1, min(2, copies)))]
+        hd = torch.empty_like(c_prev)
+        _check(lib().cvc_packed_lstm_train_drop_fwd(_dev(wp), _dev(xq), xq.shape[0] * 4, _dev(b_ih), _dev(b_hh), _dev(gate_pre),
+                                                    _dev(c_prev), M, R, _dev(hs[0]), _dev(c), _dev(gates),
+                                                    _dev(hs[1]) if len(hs) > 1 else None, _dev(hd), _rng_ptr(state), int(site),
+                                                    float(p), _stream()), "cvc_packed_lstm_train_drop_fwd")
+        return ((hs[0] if copies <= 1 else tuple(hs)), hd), c, gates
+    hs = [torch.empty_like(c_prev) for _ in range(max(1, min(3, copies)))]
     tail = (_dev(c_prev), M, R, _dev(hs[0]), _dev(c), _dev(gates), _dev(hs[1]) if len(hs) > 1 else None,
             _dev(hs[2]) if len(hs) > 2 else None, _stream())
     if gate_pre is None:
@@ -477,13 +493,20 @@ def lstm_cell_train_fwd(xs: Sequence[torch.Tensor], h_prev, c_prev, wp, b_ih, b_
     return (hs[0] if copies <= 1 else tuple(hs)), c, gates
 
 
-def lstm_pointwise_bwd(d_h, d_c, gates, c_prev, c_new, want_quad=False, d_h2=None, d_h3=None):
+def lstm_pointwise_bwd(d_h, d_c, gates, c_prev, c_new, want_quad=False, d_h2=None, d_h3=None, drop3=None):
     """-> d_gates [M,4R], d_c_prev [M,R] (+ d_gates in the quad layout [R][64][4] for linear_nn when asked).  d_h2, d_h3: the
-    gradients of further copies of h' (summed with d_h inside the kernel)."""
+    gradients of further copies of h' (summed with d_h inside the kernel).  drop3 = (rng_state, site, p): d_h3 is the gradient
+    of the copy that left the cell through the fused dropout and takes that mask."""
     M, R = c_prev.shape
     d_gates = torch.empty_like(gates)
     d_c_prev = torch.empty_like(c_prev)
     d_gates_q = torch.empty(R, 64, 4, device=gates.device, dtype=torch.float32) if want_quad else None
+    if drop3 is not None and d_h3 is not None:
+        state, site, p = drop3
+        _check(lib().cvc_lstm_pointwise_bwd3_drop(_dev(d_h), _dev(d_h2), _dev(d_h3), _rng_ptr(state), int(site), float(p), _dev(d_c),
+                                                  _dev(gates), _dev(c_prev), _dev(c_new), M, R, _dev(d_gates), _dev(d_c_prev),
+                                                  _dev(d_gates_q), _stream()), "cvc_lstm_pointwise_bwd3_drop")
+        return (d_gates, d_c_prev, d_gates_q) if want_quad else (d_gates, d_c_prev)
     _check(lib().cvc_lstm_pointwise_bwd3(_dev(d_h), _dev(d_h2), _dev(d_h3), _dev(d_c), _dev(gates), _dev(c_prev), _dev(c_new), M, R,
                                          _dev(d_gates), _dev(d_c_prev), _dev(d_gates_q), _stream()), "cvc_lstm_pointwise_bwd3")
     return (d_gates, d_c_prev, d_gates_q) if want_quad else (d_gates, d_c_prev)
@@ -534,6 +557,39 @@ def embed_relu_fwd(table, idx, drop=None):
     _check(lib().cvc_embed_relu_fwd(_dev(table), _dev(idx, torch.int64), _dev(drop), M, E, _dev(out), _stream()),
            "cvc_embed_relu_fwd")
     return out
+
+
+def _rng_ptr(state: torch.Tensor):
+    """device pointer of a dropout generator state (cvc/dropout.py: >= 3 int32 words {seed_lo, seed_hi, step})"""
+    if not (state.is_cuda and state.dtype == torch.int32 and state.is_contiguous() and state.numel() >= 3):
+        raise RuntimeError("dropout generator state: contiguous int32 device tensor of >= 3 words")
+    return state.data_ptr()
+
+
+def embed_relu_rng_fwd(table, idx, state, site: int, p: float):
+    """relu(table[idx]) * in-kernel keep-mask of (site, element index) (cvc_embed_relu_rng_fwd)"""
+    M, E = idx.shape[0], table.shape[1]
+    out = torch.empty(M, E, device=table.device, dtype=torch.float32)
+    _check(lib().cvc_embed_relu_rng_fwd(_dev(table), _dev(idx, torch.int64), _rng_ptr(state), int(site), float(p), M, E, _dev(out),
+                                        _stream()), "cvc_embed_relu_rng_fwd")
+    return out
+
+
+def embed_relu_rng_bwd(table, idx, state, site: int, p: float, d_out):
+    d_table = torch.zeros_like(table)
+    order = torch.argsort(idx, stable=True)
+    ws = torch.empty(idx.shape[0], table.shape[1], device=table.device, dtype=torch.float32)
+    _check(lib().cvc_embed_relu_rng_bwd(_dev(table), _dev(idx, torch.int64), _dev(order, torch.int64), _rng_ptr(state), int(site),
+                                        float(p), _dev(d_out), idx.shape[0], table.shape[1], _dev(d_table), _dev(ws), _stream()),
+           "cvc_embed_relu_rng_bwd")
+    return d_table
+
+
+def dropout_rng(x, state, site: int, p: float):
+    """x * in-kernel keep-mask of (site, flat element index) (cvc_dropout_rng); its own backward on the gradient"""
+    y = torch.empty_like(x)
+    _check(lib().cvc_dropout_rng(_dev(x), x.numel(), _rng_ptr(state), int(site), float(p), _dev(y), _stream()), "cvc_dropout_rng")
+    return y
 
 
 def embed_relu_bwd(table, idx, drop, d_out):

@@ -115,6 +115,8 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         drop_p = self.embed[2].p if (self.training and len(self.embed) > 2) else 0.0
         table = self.embed[0].weight
         drop = None
+        if 0 < drop_p < 1 and site is not None and dropout.in_kernel(table):
+            return F_.embed_relu(table, word, rng=(dropout.rng_state(table.device), dropout.site_id(site), float(drop_p)))
         if drop_p > 0:
             drop = dropout.keep_mask(site or "emb", (word.numel(), table.shape[1]), drop_p, table.device)
         return F_.embed_relu(table, word, drop)
@@ -167,6 +169,8 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         input_seq = input_seq.view(-1, input_seq.size(2), input_seq.size(3))
         input_seq_update = input_seq.data.clone()
         B = gt_caption.size(0)
+        if self.training and dropout.in_kernel(self.logit.weight):
+            dropout.advance(self.device)              # this pass's masks: step word of the in-kernel generator += 1, on the device
 
         overlaps, (fc_feats, conv_feats, p_conv_feats, pool_feats, p_pool_feats, g_pool_feats, pnt_mask, _ov, _cls_pred,
                    cls_loss) = self._encode(segs_feat, proposals, num, mask_boxes, region_feats, gt_boxes, frm_mask,
@@ -215,7 +219,11 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         # ---- grounder over all T                                                      reference :282-294
         xt_clamp = torch.clamp(input_seq[:, 1:T + 1, 0].clone() - self.vocab_size, min=0)
         ve = self.roi_feat_extractor.vis_embed                                       # Embedding -> ReLU -> Dropout (backbone.py:55-57)
-        if dropout.active() and self.training and isinstance(ve, nn.Sequential) and len(ve) == 3:
+        ve_seq = self.training and isinstance(ve, nn.Sequential) and len(ve) == 3 and isinstance(ve[2], nn.Dropout)
+        if ve_seq and 0 < ve[2].p < 1 and dropout.in_kernel(ve[0].weight) and isinstance(ve[0], nn.Embedding) and ve[0].weight.shape[1] % 4 == 0:
+            # lookup + ReLU + dropout in the embedding kernel, mask generated there
+            xt_all = F_.embed_relu(ve[0].weight, xt_clamp, rng=(dropout.rng_state(xt_clamp.device), dropout.site_id("vis_embed"), float(ve[2].p)))
+        elif dropout.active() and ve_seq:
             xt_all = dropout.apply(ve[2], ve[1](ve[0](xt_clamp)), "vis_embed")       # dictated mask (train-mode parity tests)
         else:
             xt_all = ve(xt_clamp)

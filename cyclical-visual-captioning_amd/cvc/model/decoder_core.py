@@ -20,6 +20,13 @@ import os as _os
 H_COPIES = _os.environ.get("CVC_H_COPIES", "1") != "0"   # False: one h' tensor per cell, autograd sums its consumers' gradients (A/B)
 
 
+def _fused_drop(module: nn.Dropout, site, like):
+    """(generator state, site id, p) when this step's output dropout runs inside the language cell's kernel, else None"""
+    if site is None or not module.training or not (0 < module.p < 1) or not dropout.in_kernel(like):
+        return None
+    return dropout.rng_state(like.device), dropout.site_id(site), float(module.p)
+
+
 class TopDownDecoderCore(nn.Module):
     """reference model/decoder_core.py:8-66"""
 
@@ -69,6 +76,12 @@ class TopDownDecoderCore(nn.Module):
             self.soft_attn, h_attn[0],
             [(p_pool_feats, pool_feats, pnt_mask, proposal_frame_mask), (p_conv_feats, conv_feats, None, None)],
             with_sentinel=(with_sentinel, False))          # the region set only, as the reference forwards it (decoder_core.py:55-56)
+        drop = _fused_drop(self.dropout, drop_site, h_lang_s)
+        if drop is not None:
+            # output = dropout(h_lang) written by the cell's own kernel, mask generated there (cvc/dropout.py)
+            *h_new, output, c_lang = F_.lstm_cell([ctx_sum, h_attn[1 % k]], h_lang_s, c_lang, *_cell(self.lang_lstm), copies=min(k, 2),
+                                                  drop=drop)
+            return output, (h_attn[2 % k], c_attn, h_new[0], c_lang, h_new[-1]), roi_attn, frame_masked_attn, weighted_pool_feat
         *h_new, c_lang = F_.lstm_cell([ctx_sum, h_attn[1 % k]], h_lang_s, c_lang, *_cell(self.lang_lstm), copies=k)
         return (dropout.apply(self.dropout, h_new[0], drop_site), (h_attn[2 % k], c_attn, h_new[1 % k], c_lang, h_new[2 % k]), roi_attn,
                 frame_masked_attn, weighted_pool_feat)
@@ -106,6 +119,12 @@ class AttenedDecoderCore(nn.Module):
         # ctx_sum: weighted_pool_feat + attn_conv of this step, taken from the sum over all T steps the caller formed once;
         # gate_pre_lang: its hoisted product with weight_ih[:, :R] (the localized context does not depend on this loop's recurrence)
         ctx = ctx_sum if ctx_sum is not None else weighted_pool_feat + attn_conv
+        drop = _fused_drop(self.dropout, drop_site, h_lang_s)
+        if drop is not None:
+            *h_new, output, c_lang = F_.lstm_cell([ctx, h_attn[0]], h_lang_s, c_lang, *_cell(self.lang_lstm), copies=2 if grad else 1,
+                                                  gate_pre=gate_pre_lang, hoisted=None if gate_pre_lang is None else (True, False),
+                                                  drop=drop)
+            return output, (h_attn[-1], c_attn, h_new[0], c_lang, h_new[-1])
         *h_new, c_lang = F_.lstm_cell([ctx, h_attn[0]], h_lang_s, c_lang, *_cell(self.lang_lstm), copies=3 if grad else 1,
                                       gate_pre=gate_pre_lang, hoisted=None if gate_pre_lang is None else (True, False))
         return dropout.apply(self.dropout, h_new[0], drop_site), (h_attn[-1], c_attn, h_new[1 % len(h_new)], c_lang, h_new[2 % len(h_new)])

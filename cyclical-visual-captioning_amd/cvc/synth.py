@@ -319,3 +319,30 @@ def encoder_inputs(d: Dims, seed: int = 1234) -> "OrderedDict[str, np.ndarray]":
     o["sample_idx"] = np.stack([lo, hi], axis=1).astype(np.int64)
     o["pnt_mask_in"] = np.arange(N + 1)[None, :] > o["num"][:, 1:2]
     return o
+
+
+# ------------------------------------------------------------------------------- in-kernel dropout, restated
+def dropout_hash(seed_lo: int, seed_hi: int, step: int, site: int, idx: np.ndarray) -> np.ndarray:
+    """csrc/dropout_rng.h::cvc_drop_hash on the host, word for word (uint32 arithmetic, wrapping)."""
+    u = np.uint32
+    with np.errstate(over="ignore"):
+        x = (idx.astype(np.uint32) * u(0x9E3779B1) + u((site * 0x85EBCA77) & 0xFFFFFFFF) + u((step * 0xC2B2AE3D) & 0xFFFFFFFF)
+             + u(seed_lo & 0xFFFFFFFF))
+        x ^= x >> u(16); x *= u(0x7FEB352D); x ^= x >> u(15); x *= u(0x846CA68B); x ^= x >> u(16)
+        x += u(seed_hi & 0xFFFFFFFF)
+        x ^= x >> u(15); x *= u(0x2C1B3C6D); x ^= x >> u(12); x *= u(0x297A2D39); x ^= x >> u(15)
+    return x
+
+
+def dropout_keep(seed_lo: int, seed_hi: int, step: int, site: int, n: int, p: float) -> np.ndarray:
+    """The multipliers (0 or 1 / (1 - p), fp32) the kernels apply to elements 0 .. n-1 of dropout site `site` at generator state
+    (seed_lo, seed_hi, step): element i is DROPPED when its hash is below p * 2^32 (cvc_drop_spec / cvc_drop_mult)."""
+    t = float(np.float32(p)) * 4294967296.0
+    thresh = np.uint32(0xFFFFFFFF if t >= 4294967295.0 else int(t))
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    out = np.empty(n, dtype=np.float32)
+    for lo in range(0, n, 1 << 22):
+        hi = min(n, lo + (1 << 22))
+        h = dropout_hash(seed_lo, seed_hi, step, site, np.arange(lo, hi, dtype=np.uint32))
+        out[lo:hi] = np.where(h >= thresh, scale, np.float32(0.0))
+    return out

@@ -200,6 +200,12 @@ int cvc_pack_lstm_segs(const float* const* ws, const long long* lds, const int* 
 int cvc_packed_lstm_train_pre_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
                                   const float* gate_pre, const float* c_prev, int M, int R, float* h_out, float* c_out,
                                   float* gates_out, float* h_out2, float* h_out3, cvc_stream_t stream);
+/* ... with output = nn.Dropout(h') (decoder_core.py:62, 109) fused: h_drop_out [M, R] receives h' times the counter-based
+ * keep-mask of element m * R + j (see cvc_dropout_rng); gate_pre nullable; h_out / h_out2 are the plain copies of h'. */
+int cvc_packed_lstm_train_drop_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
+                                   const float* gate_pre, const float* c_prev, int M, int R, float* h_out, float* c_out,
+                                   float* gates_out, float* h_out2, float* h_drop_out, const uint32_t* rng_state,
+                                   unsigned site, float p, cvc_stream_t stream);
 
 /* GRU over a whole sequence, one or both directions: the recurrent half of nn.GRU(batch_first, h0 = 0) as the encoder's frame
  * context uses it (backbone.py:103-106, 335-338; gate order r, z, n; n = tanh(W_in x + b_in + r * (W_hn h + b_hn)),
@@ -358,6 +364,11 @@ int cvc_lstm_pointwise_bwd(const float* d_h, const float* d_c, const float* gate
 int cvc_lstm_pointwise_bwd3(const float* d_h, const float* d_h2, const float* d_h3, const float* d_c,
                             const float* gates, const float* c_prev, const float* c_new, int M, int R,
                             float* d_gates, float* d_c_prev, float* d_gates_q, cvc_stream_t stream);
+/* ... where the third copy left the cell through the fused dropout of cvc_packed_lstm_train_drop_fwd: d_h3 takes that mask */
+int cvc_lstm_pointwise_bwd3_drop(const float* d_h, const float* d_h2, const float* d_h3, const uint32_t* rng_state,
+                                 unsigned site, float p, const float* d_c, const float* gates, const float* c_prev,
+                                 const float* c_new, int M, int R, float* d_gates, float* d_c_prev, float* d_gates_q,
+                                 cvc_stream_t stream);
 
 /* Backward-data product of the skinny layers, autograd of nn.LSTMCell / nn.Linear
  * (decoder_core.py:45-50, 59-61, 99-108):  dst_s[M, ncols_s] = dY[M, K] x W_s[K, ncols_s]  for up to 6
@@ -393,6 +404,23 @@ int cvc_embed_relu_fwd(const float* table, const int64_t* idx, const float* drop
 int cvc_embed_relu_bwd(const float* table, const int64_t* idx, const int64_t* order, const float* drop,
                        const float* d_out, int M, int E, float* d_table, float* workspace,
                        cvc_stream_t stream);
+
+/* Counter-based dropout (nn.Dropout of the training pass: captioner.py:53-68, decoder_core.py:62, 109, backbone.py:55-57) with the
+ * keep-masks generated INSIDE the consuming kernels -- no mask tensors, no library RNG launches:
+ *   keep(element) = hash(seed, step, site, flat element index) >= p * 2^32,   multiplier = keep ? 1 / (1 - p) : 0
+ * (csrc/dropout_rng.h; cvc/synth.py::dropout_keep restates the hash on the host for the train-mode parity tests).
+ * rng_state: 3 words of DEVICE memory {seed_lo, seed_hi, step}; the host advances `step` with a device-side add once per
+ * training step, so a HIP-graph replay of the step draws fresh masks.  site: which dropout of the pass (cvc/dropout.py).
+ *   cvc_embed_relu_rng_fwd / _bwd : cvc_embed_relu_fwd / _bwd with the mask of element (m, e) at flat index m * E + e;
+ *   cvc_dropout_rng               : y[i] = x[i] * multiplier(i), n elements (16-byte aligned), for sites no producer fuses
+ *                                   (its own backward: the same call on the gradient). */
+int cvc_embed_relu_rng_fwd(const float* table, const int64_t* idx, const uint32_t* rng_state, unsigned site, float p, int M,
+                           int E, float* out, cvc_stream_t stream);
+int cvc_embed_relu_rng_bwd(const float* table, const int64_t* idx, const int64_t* order, const uint32_t* rng_state,
+                           unsigned site, float p, const float* d_out, int M, int E, float* d_table, float* workspace,
+                           cvc_stream_t stream);
+int cvc_dropout_rng(const float* x, long long n, const uint32_t* rng_state, unsigned site, float p, float* y,
+                    cvc_stream_t stream);
 
 /* In-place-capable row log-softmax: logp[m, :] = logits[m, :] - logsumexp(logits[m, :]) */
 int cvc_log_softmax_fwd(const float* logits, int M, int V, float* logp, cvc_stream_t stream);

@@ -282,13 +282,35 @@ def _dropout_masks(d, seed, p=0.5):
                 out_a=draw(d.T, d.B, d.R), out_c=draw(d.T, d.B, d.R), vis_embed=draw(d.B, d.T, d.G))
 
 
-def _train_mode_parity(d, seed, mix, loss_tol, grad_tol=5e-4):
+def _train_mode_parity(d, seed, mix, loss_tol, grad_tol=5e-4, in_kernel=False):
+    """in_kernel=False: masks drawn here and dictated to both sides.  in_kernel=True: the product generates its masks INSIDE the
+    kernels (csrc/dropout_rng.h) and the oracle receives their host restatement (cvc.dropout.host_mask -> synth.dropout_keep)."""
     from helpers import build_model, to_dev, model_call
     from oracle import ref_cpu as O
     from cvc import dropout
     dev = torch.device("cuda:0")
     sd, f, b = synth.hot_path_state_dict(d, seed), synth.clip_features(d, seed), synth.label_glue_batch(d, seed)
-    masks = _dropout_masks(d, seed + 1)
+    model = build_model(d, sd, dev).train()
+    if in_kernel:
+        assert dropout.IN_KERNEL
+        dropout.seed(seed * 7919 + 13)
+        for _ in range(3):
+            dropout.advance(dev)                                # not the first step of the generator
+        step0 = int(dropout.rng_state(dev)[2].item())
+        out = model_call(model, to_dev(f, dev), to_dev(b, dev), False)
+        assert int(dropout.rng_state(dev)[2].item()) == step0 + 1            # one advance per training pass
+        pe, pv, po = model.embed[2].p, model.roi_feat_extractor.vis_embed[2].p, model.decoder_core.dropout.p
+        hm = lambda site, shape, p: dropout.host_mask(site, shape, p, dev)
+        masks = dict(emb_a=hm("emb_a", (d.B, d.T, d.E), pe), emb_b=hm("emb_b", (d.B, d.T, d.E), pe), emb_c=hm("emb_c", (d.B, d.T, d.E), pe),
+                     vis_embed=hm("vis_embed", (d.B, d.T, d.G), pv),
+                     out_a=torch.stack([hm("out_a.%d" % t, (d.B, d.R), po) for t in range(d.T)]),
+                     out_c=torch.stack([hm("out_c.%d" % t, (d.B, d.R), po) for t in range(d.T)]))
+        for k, m in masks.items():
+            frac = float((m == 0).float().mean())
+            assert m.numel() < 4000 or 0.4 < frac < 0.6, (k, frac)      # p = 0.5 sites: about half of every mask is zero
+        assert not torch.equal(masks["emb_a"], masks["emb_c"]) and not torch.equal(masks["out_a"][0], masks["out_a"][1])
+    else:
+        masks = _dropout_masks(d, seed + 1)
     P = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in O.to_torch(sd).items()}
     for k in list(P):                                           # the reconstructor shares the decoder's LSTM cells
         if k.startswith("attended_roi_decoder_core.") and "lstm" in k:
@@ -297,7 +319,6 @@ def _train_mode_parity(d, seed, mix, loss_tol, grad_tol=5e-4):
     ref_eval = O.cyclical_forward(P, O.to_torch(f), O.to_torch(b), T=d.T, vocab_size=d.V)
     assert abs(float(ref[0].detach()) - float(ref_eval[0].detach())) > 1e-3          # the masks do change the pass (not an eval-mode rerun)
     O.training_loss(ref, xe_loss_weight=mix[0], w_att2=mix[1], w_cls=0.0, caption_consistency_loss_weight=mix[2]).backward()
-    model = build_model(d, sd, dev).train()
     used = []
 
     def source(site, shape):
@@ -306,9 +327,10 @@ def _train_mode_parity(d, seed, mix, loss_tol, grad_tol=5e-4):
             return masks[site].reshape(shape)
         kind, t = site.split(".")
         return masks[kind][int(t)]
-    with dropout.injected(source):
-        out = model_call(model, to_dev(f, dev), to_dev(b, dev), False)
-    assert sorted(set(used)) == sorted(["emb_a", "emb_b", "emb_c", "vis_embed"] + ["out_a.%d" % t for t in range(d.T)] + ["out_c.%d" % t for t in range(d.T)])
+    if not in_kernel:
+        with dropout.injected(source):
+            out = model_call(model, to_dev(f, dev), to_dev(b, dev), False)
+        assert sorted(set(used)) == sorted(["emb_a", "emb_b", "emb_c", "vis_embed"] + ["out_a.%d" % t for t in range(d.T)] + ["out_c.%d" % t for t in range(d.T)])
     for got, want in zip(out, ref):
         assert float(got.detach().mean()) == pytest.approx(float(want.detach().mean()), rel=loss_tol, abs=loss_tol / 10)
     lm, a2, _g, _cls, rec = [x.mean() for x in out]
@@ -336,5 +358,69 @@ def test_train_mode_cyclical_pass_with_dictated_dropout_masks_vs_oracle(cfg, mix
 
 
 def test_train_mode_cyclical_pass_cfg3_full_size_vs_oracle():
-    """... and once at BASELINE config 3 size (B=64, D=2048, T=20)."""
-    _train_mode_parity(synth.CONFIGS["cfg3"], 1305, (0.5, 0.0, 0.5), loss_tol=1e-4)
+    """... and once at BASELINE config 3 size (B=64, D=2048, T=20), with the masks generated inside the kernels."""
+    _train_mode_parity(synth.CONFIGS["cfg3"], 1305, (0.5, 0.0, 0.5), loss_tol=1e-4, in_kernel=True)
+
+
+@pytest.mark.parametrize("cfg,mix", [("tiny", (0.5, 0.05, 0.5)), ("cfg1", (0.5, 0.0, 0.5))])
+def test_train_mode_cyclical_pass_with_in_kernel_dropout_vs_oracle(cfg, mix):
+    """Train mode as it ships: every nn.Dropout of the pass takes its keep-mask from the counter-based generator inside the
+    consuming kernel (embedding lookups, the language cell's epilogue and its gate-gradient kernel); the oracle gets the same
+    masks from the generator's host restatement.  Five losses + every parameter gradient."""
+    _train_mode_parity(synth.CONFIGS[cfg], 977, mix, loss_tol=2e-5, in_kernel=True)
+
+
+def test_in_kernel_dropout_kernels_equal_host_restatement():
+    """cvc_dropout_rng, cvc_embed_relu_rng_fwd/_bwd, cvc_packed_lstm_train_drop_fwd and cvc_lstm_pointwise_bwd3_drop against
+    synth.dropout_keep: the multipliers are exactly 0 or 1 / (1 - p) at exactly the restated positions; masks change with step
+    and site; p = 0.3 and 0.5."""
+    from cvc import dropout, hip, functional as F_
+    dev = torch.device("cuda:0")
+    dropout.seed(0xDEADBEEF12345)
+    st = dropout.rng_state(dev)
+    for p in (0.3, 0.5):
+        x = torch.randn(37, 129, device=dev)                                      # n % 4 != 0: the tail path
+        xp = torch.randn(40, 128, device=dev)
+        for site in ("emb_b", "out_a.3", "out_c.19"):
+            for xx in (xp, x.reshape(-1)[: x.numel() // 4 * 4 + 1].clone()):
+                y = hip.dropout_rng(xx, st, dropout.site_id(site), p)
+                m = dropout.host_mask(site, xx.shape, p, dev).to(dev)
+                assert torch.equal(y, xx * m)
+        m0 = dropout.host_mask("emb_a", (64, 64), p, dev)
+        dropout.advance(dev)
+        m1 = dropout.host_mask("emb_a", (64, 64), p, dev)
+        assert not torch.equal(m0, m1) and not torch.equal(m1, dropout.host_mask("emb_c", (64, 64), p, dev))
+        assert abs(float((m1 == 0).float().mean()) - p) < 0.03
+        # embedding: forward and backward
+        V, E, M = 50, 64, 96
+        table = torch.randn(V, E, device=dev, requires_grad=True)
+        idx = torch.randint(0, V, (M,), device=dev)
+        out = F_.embed_relu(table, idx, rng=(st, dropout.site_id("emb_c"), p))
+        mk = dropout.host_mask("emb_c", (M, E), p, dev).to(dev)
+        assert torch.equal(out, torch.relu(table.detach()[idx]) * mk)
+        g = torch.randn(M, E, device=dev)
+        out.backward(g)
+        t2 = table.detach().clone().requires_grad_(True)
+        (torch.relu(t2[idx]) * mk).backward(g)
+        assert torch.allclose(table.grad, t2.grad, rtol=1e-5, atol=1e-5)
+        # language cell with the fused output dropout: the dropped copy is h' times the mask, its gradient takes the mask
+        R, B = 64, 8
+        w_ih = torch.randn(4 * R, 2 * R, device=dev, requires_grad=True); w_hh = torch.randn(4 * R, R, device=dev, requires_grad=True)
+        b_ih = torch.randn(4 * R, device=dev, requires_grad=True); b_hh = torch.randn(4 * R, device=dev, requires_grad=True)
+        with torch.no_grad():
+            w_ih *= 0.1; w_hh *= 0.1
+        xs = [torch.randn(B, R, device=dev, requires_grad=True) for _ in range(2)]
+        h0 = torch.randn(B, R, device=dev, requires_grad=True); c0 = torch.randn(B, R, device=dev, requires_grad=True)
+        for copies in (1, 2):
+            outs = F_.lstm_cell(xs, h0, c0, w_ih, w_hh, b_ih, b_hh, copies=copies, drop=(st, dropout.site_id("out_a.7"), p))
+            assert len(outs) == copies + 2
+            *hs, hd, c1 = outs
+            mk = dropout.host_mask("out_a.7", (B, R), p, dev).to(dev)
+            assert torch.equal(hd, hs[0] * mk) and all(torch.equal(h, hs[0]) for h in hs)
+            gd, gh, gc = torch.randn(B, R, device=dev), torch.randn(B, R, device=dev), torch.randn(B, R, device=dev)
+            ins = [w_ih, w_hh, b_ih, b_hh, h0, c0, *xs]
+            got = torch.autograd.grad([hd, hs[-1], c1], ins, [gd, gh, gc])
+            *hs2, c2 = F_.lstm_cell(xs, h0, c0, w_ih, w_hh, b_ih, b_hh, copies=1)
+            want = torch.autograd.grad([hs2[0], c2], ins, [gd * mk + gh, gc])
+            for a_, b_ in zip(got, want):
+                assert torch.allclose(a_, b_, rtol=1e-4, atol=1e-5)
