@@ -106,7 +106,7 @@ int run_packed_eg(cvc_decode_plan* p, hipStream_t st) {
     for (int t = 0; t < d.T; ++t) {
         const int rd = t & 1, wr = (t + 1) & 1;
         float *XA_r = d.xa[rd], *XA_w = d.xa[wr], *XL_r = d.xl[rd], *XL_w = d.xl[wr];
-        CVC_TRY(cvc_packed_lstm_embgate_fwd((const float*)d.w_att, XA_r, 2 * R, nullptr, nullptr, d.gate_fc, d.emb_gate,
+        CVC_TRY((d.att_w_cached ? cvc_packed_lstm_embgate_cached_fwd : cvc_packed_lstm_embgate_fwd)((const float*)d.w_att, XA_r, 2 * R, nullptr, nullptr, d.gate_fc, d.emb_gate,
                                             d.words + (size_t)t * rows, d.ca[rd], rows, R, quad_off(XL_r, R), quad_off(XA_w, R),
                                             d.ca[wr], st));
         CVC_TRY(cvc_packed_linear_fwd((const float*)d.w_h, quad_off(XL_r, R), R, nullptr, rows, A, d.qsplit, d.q_parts, A, nullptr, st));

@@ -61,10 +61,23 @@ struct PackedArgs {
     // per-block top-2 records of all rows
     unsigned* sel_counter;    // one word of device memory, zero between launches
     int64_t* sel_word; int sel_word_stride; float* sel_logprob; int sel_unk;
+    int w_cached;             // lstm decode form: 1 = the gate weights keep the default cache policy (Infinity-Cache resident by plan)
     DropSpec h3_drop;         // training form: h_rm3 receives nn.Dropout(h') with the counter-based mask of element m * R + j
     long long wstride;        // floats between consecutive 32-row blocks of wp (0: dense, nquad * 128)
     GskSegs early;            // SLAB form (cvc_packed_lstm_late_fwd): partial tiles of the K range a stream-K launch already covered
 };
+
+#ifdef CVC_TS
+// diagnostic build (-DCVC_TS): per-workgroup timestamps (100 MHz constant clock) of the LSTM gate GEMM's phases, last launch wins;
+// slot 0: K >= 6144 (language cell), slot 1: shorter K.  [slot][workgroup][wave][4] = entry, first chunk multiplied, K loop done, end
+__device__ unsigned long long cvc_ts_buf[2 * 256 * 8 * 4];
+extern "C" int cvc_debug_ts_read(unsigned long long* dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(cvc_ts_buf), sizeof(cvc_ts_buf)) == hipSuccess ? 0 : -1;
+}
+#define CVC_TS_MARK(k) do { if (LSTM && !GRU && lane == 0 && blockIdx.x < 256) ts_[k] = wall_clock64(); } while (0)
+#else
+#define CVC_TS_MARK(k) do {} while (0)
+#endif
 
 #ifndef CVC_LIN_W_NT
 #define CVC_LIN_W_NT 0      // 1: also stream the linear layers' weights non-temporally (A/B switch)
@@ -114,7 +127,8 @@ __device__ __forceinline__ SelState sel_merge(SelState s, float u1, int k1, floa
 // SLAB (LSTM decode form, 8 waves): this launch covers only the LATE K range of the cell; the partial tiles of the rest, produced
 // earlier by the grouped stream-K kernel (gemm_gsk.hip), are summed in segment order and join the cross-wave reduction as a
 // ninth partial.
-template <int MT, bool LSTM, int DEPTH, bool SPLIT, int NW, bool GRU = false, int NB = 1, bool SLAB = false>
+// WC: the LSTM gate weights keep the default cache policy instead of streaming non-temporally (experiment: cvc_packed_lstm_cached_weights)
+template <int MT, bool LSTM, int DEPTH, bool SPLIT, int NW, bool GRU = false, int NB = 1, bool SLAB = false, bool WC = false>
 __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs a) {
     static_assert(!GRU || LSTM, "the GRU step shares the LSTM form's work split");
     static_assert(!SLAB || (LSTM && !GRU && NB == 1 && NW == 8), "slab sum: LSTM decode form, 8 waves, one block per workgroup");
@@ -134,6 +148,10 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, kh = lane >> 5;
     const int M = a.M, R = a.R;
+#ifdef CVC_TS
+    unsigned long long ts_[4] = {0, 0, 0, 0};
+#endif
+    CVC_TS_MARK(0);
 
     int nchunk = a.nquad >> 3, c0 = 0;
     if (!LSTM && a.ksplit > 1) {                              // K slice of this workgroup (whole chunks)
@@ -171,7 +189,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
         for (int q = 0; q < 4; ++q) {
             // gate weights (369 MB per step) are streamed; the small linear layers' weights (vocabulary head, h2attn:
             // 49 MB) keep the default policy so that they can stay in the Infinity Cache between steps
-            if constexpr ((LSTM && !GRU) || CVC_LIN_W_NT) f.w[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + q * 128));
+            if constexpr (((LSTM && !GRU) || CVC_LIN_W_NT) && !WC) f.w[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + q * 128));
             else f.w[q] = ld4(w + q * 128);
 #if defined(CVC_PABL) && CVC_PABL == 3
             if (j > 0) continue;                                     // ablation: stream the weights only
@@ -279,6 +297,9 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
             for (int s = 0; s < DEPTH; ++s) {
                 load(ring[(s + DEPTH - 1) % DEPTH], j + s + DEPTH - 1);
                 mma(ring[s]);
+#ifdef CVC_TS
+                if (s == 0 && j == 0) CVC_TS_MARK(1);
+#endif
                 if constexpr (SPLIT) {
 #pragma unroll
                     for (int g = 0; g < 4 + 4 * MT; ++g) {
@@ -313,6 +334,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
         }
     }
 
+    CVC_TS_MARK(2);
     // LSTM: the cell update's global operands (one work item per thread: batch row m, 4 hidden units) are requested
     // BEFORE the cross-wave LDS stage, so that their latency runs under it
     const int em = tid & 63, eqd = (tid >> 6) & 1, eb = tid >> 7;       // (batch row, hidden quad, block of the workgroup)
@@ -456,6 +478,14 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
                 for (int g = 0; g < 4; ++g) st4(a.gates_rm + (size_t)em * 4 * R + g * R + ejq, gv[g]);
             }
         }
+#ifdef CVC_TS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CVC_TS_MARK(3);
+        if (lane == 0 && blockIdx.x < 256) {
+            unsigned long long* d = cvc_ts_buf + ((size_t)((a.nquad >= 1536 ? 0 : 1) * 256 + blockIdx.x) * 8 + wave) * 4;
+            d[0] = ts_[0]; d[1] = ts_[1]; d[2] = ts_[2]; d[3] = ts_[3];
+        }
+#endif
     } else {
         const int n0 = blockIdx.x * 32;
         const bool lead = blockIdx.y == 0;
@@ -598,6 +628,13 @@ static int launch_packed(const PackedArgs& a_in, int blocks, hipStream_t st) {
             return cvc_launch_status();
         }
     }
+    if constexpr (LSTM) {
+        // (gate weights with the default cache policy: cvc_packed_lstm_embgate_cached_fwd)
+        if (cvc_gemm_split_mode == 2 && a.w_cached && a.M > 32) {
+            hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, true, CVC_PACKED_DEPTH8, true, 8, false, 1, false, true>), grid, dim3(512), 0, st, a);
+            return cvc_launch_status();
+        }
+    }
     if (cvc_gemm_split_mode == 2) {            // split products, 8 waves (2 per SIMD), ring depth CVC_PACKED_DEPTH8
         if (a.M <= 32) hipLaunchKernelGGL((skinny_gemm_packed_kernel<1, LSTM, CVC_PACKED_DEPTH8, true, 8>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, LSTM, CVC_PACKED_DEPTH8, true, 8>), grid, dim3(512), 0, st, a);
@@ -631,6 +668,21 @@ extern "C" int cvc_packed_lstm_embgate_fwd(const float* wp, const float* xq, int
     a.wp = wp; a.xq = xq; a.nquad = K / 4; a.M = M; a.Nout = 4 * R; a.R = R;
     a.bias = b_ih; a.bias2 = b_hh; a.gate_bias = gate_bias; a.c_prev_q = c_prev_q; a.c_out_q = c_out_q;
     a.h_dst1_q = h_dst1_q; a.h_dst2_q = h_dst2_q; a.ksplit = 1; a.emb_gate = emb_gate; a.word = word;
+    return launch_packed<true>(a, R / 8, (hipStream_t)stream);
+}
+
+// ... with the gate weights read under the default cache policy instead of streamed non-temporally: for a gate matrix that the
+// caller's cache plan keeps in the 256 MiB Infinity Cache between steps (cvc.decode.cache_plan: at config 2 the attention cell's
+// 134 MB; its launch 40.3 -> 35.4 us, the decode +1.8 %).  64-row split-product form only; other shapes run the streaming kernel.
+extern "C" int cvc_packed_lstm_embgate_cached_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
+                                                  const float* gate_bias, const float* emb_gate, const int64_t* word,
+                                                  const float* c_prev_q, int M, int R, float* h_dst1_q, float* h_dst2_q,
+                                                  float* c_out_q, cvc_stream_t stream) {
+    if (!wp || !xq || !c_prev_q || !c_out_q || !emb_gate || !word || (K & 31) || R < 8 || (R & 7)) return CVC_E_BADARG;
+    PackedArgs a{};
+    a.wp = wp; a.xq = xq; a.nquad = K / 4; a.M = M; a.Nout = 4 * R; a.R = R;
+    a.bias = b_ih; a.bias2 = b_hh; a.gate_bias = gate_bias; a.c_prev_q = c_prev_q; a.c_out_q = c_out_q;
+    a.h_dst1_q = h_dst1_q; a.h_dst2_q = h_dst2_q; a.ksplit = 1; a.emb_gate = emb_gate; a.word = word; a.w_cached = 1;
     return launch_packed<true>(a, R / 8, (hipStream_t)stream);
 }
 

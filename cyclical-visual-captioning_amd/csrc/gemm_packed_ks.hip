@@ -18,6 +18,16 @@
 #include "cvc_common.h"
 #include "gemm_split.h"
 
+#ifdef CVC_TS
+__device__ unsigned long long cvc_ks_ts_buf[256 * 8];      // diagnostic build: per-workgroup phase timestamps of the exchange finish
+extern "C" int cvc_debug_ks_ts_read(unsigned long long* dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(cvc_ks_ts_buf), sizeof(cvc_ks_ts_buf)) == hipSuccess ? 0 : -1;
+}
+#define KS_TS(k) do { if (tid == 0) cvc_ks_ts_buf[blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define KS_TS(k) do {} while (0)
+#endif
+
 namespace {
 
 struct KsArgs {
@@ -34,6 +44,11 @@ struct KsArgs {
     const float* b_ih; const float* b_hh; const float* gate_bias; const float* c_prev_q;
     float* c_out_q; float* h_dst1_q; float* h_dst2_q;
     int M, R;
+    // exchange finish (cvc_packed_lstm_ksx_fwd): every K slice of a tile finishes one of the tile's 8 blocks
+    unsigned* flags;     // [R / 64][8] arrival words (+ one error word at [R / 8]): slice ks of a tile stores `seq` when its slab rows are out
+    unsigned seq;        // differs from the value of the previous launch on these flags
+    const float* emb_gate; const int64_t* word;     // embedding-gate table [V][4R] + the batch rows' words, or null
+    int local;           // 1: XCD-local exchange (plain slab stores, L2-served reads, the XCD id checked); 0: system-scope exchange
 };
 
 using u16x4 = __attribute__((ext_vector_type(4))) uint16_t;
@@ -64,8 +79,36 @@ __device__ __forceinline__ void stage_x(char* stage, const f32x4 v, int wave, in
 
 template <int NS> __device__ __forceinline__ void ks_finish_item(const KsArgs& a, int blk, int m, int hq);
 
-// FUSED_NS = 0: partial tiles only (a finishing launch follows); > 0: that many K slices, fused finish
-template <int FUSED_NS>
+// 16-byte load / store that no cache level may serve or keep (sc0 sc1: system scope) -- the exchange between workgroups that may
+// sit on different XCDs (cdna guide, Guideline 16: {sc0 sc1 stores and loads on both sides})
+__device__ __forceinline__ f32x4 ld4_sys(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// ... served by L2, never by this CU's L1 (sc1): a same-XCD producer's acknowledged stores are there
+__device__ __forceinline__ f32x4 ld4_l2(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// ... non-temporal: bypasses this CU's L1, served by the XCD's L2 wherever the line is (dirty lines of same-XCD producers included)
+__device__ __forceinline__ f32x4 ld4_nt(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ unsigned ld1_nt(const unsigned* p) {
+    unsigned v;
+    asm volatile("global_load_dword %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// FUSED_NS = 0: partial tiles only (a finishing launch follows); > 0: that many K slices, fused finish -- by the last slice of a
+// tile to arrive, or with XCHG by ALL of them: slice ks finishes block ks of the tile once the tile's 8 slabs are out
+template <int FUSED_NS, bool XCHG = false>
 __global__ __launch_bounds__(512) void packed_ks_kernel(KsArgs a) {
     __shared__ __attribute__((aligned(16))) char lds[2 * XSTAGE];
     __shared__ int last_arrival;
@@ -73,6 +116,7 @@ __global__ __launch_bounds__(512) void packed_ks_kernel(KsArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, kh = lane >> 5;
     const int S = a.ksplit;
+    KS_TS(0);
     int ks = (int)blockIdx.x % S, tile = (int)blockIdx.x / S;
     if (FUSED_NS > 0 && ((a.nblk >> 3) & 7) == 0) {
         // all K slices of a tile on ONE XCD (workgroup x runs on XCD x % 8): the slabs the last arriver sums are then in its
@@ -89,6 +133,39 @@ __global__ __launch_bounds__(512) void packed_ks_kernel(KsArgs a) {
     const float* wl = a.wp + (size_t)blk * a.wstride + (size_t)i * 4 + (size_t)c_lo * 8 * 128 + kh * 4 * 128;
     // activations: this wave's quad of chunk c, one row per lane
     const float* xl = a.xq + ((size_t)(c_lo * 8 + wave) * 64 + lane) * 4;
+
+    // XCHG: this workgroup finishes block (tile, ks); a thread of waves 0 / 1 owns (batch row m, hidden quad hq) of it and
+    // requests the cell update's operands NOW -- nothing of them depends on the GEMM, and the table row is an HBM round trip
+    const int fm = tid >> 1, fhq = tid & 1, fblk = tile * 8 + ks, fj = fblk * 8 + fhq * 4;
+    const bool fwork = XCHG && tid < 128 && fm < a.M;
+    const size_t fqoff = ((size_t)(fj >> 2) * 64 + fm) * 4;
+    f32x4 fcp = {0, 0, 0, 0}, fadd[4][4];
+    if constexpr (XCHG) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) fadd[g][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (fwork) {
+            fcp = ld4(a.c_prev_q + fqoff);
+            if (a.b_ih != nullptr) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) fadd[g][0] = ld4(a.b_ih + g * a.R + fj);
+            }
+            if (a.b_hh != nullptr) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) fadd[g][1] = ld4(a.b_hh + g * a.R + fj);
+            }
+            if (a.gate_bias != nullptr) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) fadd[g][2] = ld4(a.gate_bias + (size_t)fm * 4 * a.R + g * a.R + fj);
+            }
+            if (a.emb_gate != nullptr) {
+                const float* trow = a.emb_gate + (size_t)a.word[fm] * 4 * a.R + fj;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) fadd[g][3] = ld4(trow + (size_t)g * a.R);
+            }
+        }
+    }
 
     f32x16 acc[2];
 #pragma unroll
@@ -149,6 +226,7 @@ __global__ __launch_bounds__(512) void packed_ks_kernel(KsArgs a) {
         }
     }
 
+    KS_TS(1);
     // partial tile -> slab[ks][blk][m][row]: row = e + 8 rq + 4 kh for register 4 rq + e, so a lane stores float4s
     float* out = a.slab + (((size_t)ks * a.nblk + blk) * 64) * 32;
     if constexpr (FUSED_NS > 0) {
@@ -163,7 +241,7 @@ __global__ __launch_bounds__(512) void packed_ks_kernel(KsArgs a) {
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
             const f32x4 v = {acc[mt][4 * rq], acc[mt][4 * rq + 1], acc[mt][4 * rq + 2], acc[mt][4 * rq + 3]};
-            if constexpr (FUSED_NS > 0) {
+            if (FUSED_NS > 0 && !(XCHG && a.local)) {
                 // straight through L2 to memory: visible to whichever workgroup arrives last, without a write-back fence
                 // (buffer_wbl2 walks the whole L2: measured 30 us per use in csrc/gru_persistent.hip)
                 float* pp = out + (size_t)m * 32 + 8 * rq + 4 * kh;
@@ -173,7 +251,88 @@ __global__ __launch_bounds__(512) void packed_ks_kernel(KsArgs a) {
             }
         }
     }
-    if constexpr (FUSED_NS > 0) {
+    if constexpr (XCHG) {
+        // ---- exchange finish.  Slab rows out (write-through, acknowledged) -> this slice's arrival word -> wait for the tile's
+        // 8 words -> sum block (tile, ks) over the slices in slice order -> cell update.  All 8 slices of a tile are resident
+        // together (grid = 256 workgroups of 512 threads, one per CU); the wait is bounded and reports through the error word.
+        constexpr int S = FUSED_NS;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        KS_TS(2);
+        unsigned* fl = a.flags + (size_t)tile * 8;
+        // XCD-local form: the slab rows were ordinary stores -- acknowledged = in THIS XCD's L2, which is what a reader on the same
+        // XCD is served from when it bypasses its L1 (sc1 loads).  Whether the tile's 8 slices do share an XCD is not assumed: every
+        // arrival word carries its writer's XCC_ID and a reader accepts the tile only when all 8 equal its own; anything else (another
+        // placement, words that never show up because they sit in another XCD's L2) ends in the error word, never in a result.
+        const unsigned xcc = a.local ? (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) : 0u;      // HW_REG_XCC_ID[3:0]
+        const unsigned mine = (a.seq << 4) | xcc;
+        if (tid == 0) {
+            if (a.local) __hip_atomic_store(fl + ks, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // plain store
+            else __hip_atomic_store(fl + ks, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (wave == 0) {
+            bool ok = false;
+            for (int spin = 0; spin < (1 << 20); ++spin) {
+                // (agent-scope relaxed load = sc1: served by L2, never by this CU's L1)
+                unsigned v = mine;
+                if (lane < S) {
+                    if (a.local == 1 || a.local == 2) v = ld1_nt(fl + lane);
+                    else if (a.local) v = __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else v = __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                if (__builtin_amdgcn_ballot_w64(v != mine) == 0) { ok = true; break; }
+                if (__builtin_amdgcn_ballot_w64((v >> 4) == a.seq && v != mine) != 0) break;       // a slice of this launch on another XCD
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0) last_arrival = ok ? 1 : 0;
+        }
+        __syncthreads();
+        if (!last_arrival) {                                              // not co-resident / a lost workgroup: say so, do not hang
+            if (tid == 0) __hip_atomic_store(a.flags + (size_t)(a.nblk >> 3) * 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        KS_TS(3);
+        // thread (m = tid >> 3, rows 4 (tid & 7) .. + 3 of the block): the 8 slices' float4s requested together, summed in slice order
+        const int sm = tid >> 3, srq = tid & 7;
+        const float* sp = a.slab + (((size_t)fblk * 64 + sm) * 32) + srq * 4;
+        f32x4 sv[S];
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+            const float* q = sp + (size_t)k * a.nblk * 64 * 32;
+            // (1: ordinary loads -- this CU has not touched these lines since the launch began, its L1 cannot hold them)
+            sv[k] = a.local == 1 ? ld4(q) : (a.local == 2 ? ld4_nt(q) : (a.local == 3 ? ld4_l2(q) : ld4_sys(q)));
+        }
+        static_assert(S == 8, "the wait below names the 8 destination registers");
+        // (the loads are inline assembly: the wait carries their destinations so that no use can be scheduled above it)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(sv[0]), "+v"(sv[1]), "+v"(sv[2]), "+v"(sv[3]), "+v"(sv[4]), "+v"(sv[5]), "+v"(sv[6]), "+v"(sv[7]) :: "memory");
+        f32x4 t = sv[0];
+#pragma unroll
+        for (int k = 1; k < S; ++k) t += sv[k];
+        KS_TS(4);
+        float* sums = reinterpret_cast<float*>(lds);                      // [64][33] (the activation stages are done with)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sums[sm * 33 + srq * 4 + e] = t[e];
+        __syncthreads();
+        if (fwork) {
+            f32x4 hv, cv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float pre[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    pre[g] = (((sums[fm * 33 + g * 8 + fhq * 4 + e] + fadd[g][0][e]) + fadd[g][1][e]) + fadd[g][2][e]) + fadd[g][3][e];
+                const float ig = fast_sigmoid(pre[0]), fg = fast_sigmoid(pre[1]);
+                const float gg = fast_tanh(pre[2]), og = fast_sigmoid(pre[3]);
+                const float c2 = fg * fcp[e] + ig * gg;
+                cv[e] = c2;
+                hv[e] = og * fast_tanh(c2);
+            }
+            st4(a.c_out_q + fqoff, cv);
+            if (a.h_dst1_q != nullptr) st4(a.h_dst1_q + fqoff, hv);
+            if (a.h_dst2_q != nullptr) st4(a.h_dst2_q + fqoff, hv);
+        }
+        KS_TS(5);
+    } else if constexpr (FUSED_NS > 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                                  // every wave's slab rows are acknowledged
         if (tid == 0) {
@@ -364,5 +523,39 @@ extern "C" int cvc_packed_lstm_ksf_fwd(const float* wp, const float* xq, int K, 
         case 2: hipLaunchKernelGGL(packed_ks_kernel<2>, g, dim3(512), 0, (hipStream_t)stream, a); break;
         default: hipLaunchKernelGGL(packed_ks_kernel<1>, g, dim3(512), 0, (hipStream_t)stream, a); break;
     }
+    return cvc_launch_status();
+}
+
+static int cvc_ksx_local = 1;
+// The exchange's memory path: 1 (default) = XCD-local (ordinary slab stores, L2-served reads, every arrival word carrying its writer's
+// XCC_ID and checked), 0 = system scope (write-through stores, system-scope loads: placement-independent, ~12 us slower per launch --
+// 16.8 MB of write-through stores take 10 us to be acknowledged).  Returns the previous setting; < 0 queries.
+extern "C" int cvc_packed_lstm_ksx_local(int on) {
+    const int prev = cvc_ksx_local;
+    if (on >= 0) cvc_ksx_local = on > 3 ? 1 : on;
+    return prev;
+}
+
+// K-split gate GEMM whose finish is shared by all K slices of a tile ("exchange finish"): same operands and results as
+// cvc_packed_lstm_ks_fwd, one launch, no finishing launch and no idle chip while one workgroup per tile finishes.
+//   flags : R / 8 + 1 words of device memory ([R / 64][8] arrival words + the error word), zero before the first use;
+//   seq   : any value that differs from the previous launch's on these flags (and from 0);
+//   emb_gate / word : the embedding-gate form of the attention cell (cvc_packed_lstm_embgate_fwd), or null.
+// Needs its R / 8 workgroups of 512 threads resident together (R <= 2048 on a 256-CU chip; one per CU); a slice that waits longer
+// than the bound stores 1 to the error word flags[R / 8] and leaves its block unfinished.
+extern "C" int cvc_packed_lstm_ksx_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
+                                       const float* gate_bias, const float* emb_gate, const int64_t* word, const float* c_prev_q,
+                                       int M, int R, float* h_dst1_q, float* h_dst2_q, float* c_out_q, float* slab,
+                                       unsigned* flags, unsigned seq, cvc_stream_t stream) {
+    if (!wp || !xq || !c_prev_q || !c_out_q || !slab || !flags || seq == 0 || M < 1 || M > 64 || (emb_gate && !word)) return CVC_E_BADARG;
+    const int S = cvc_packed_lstm_ks_slices(K, R);
+    if (S != 8 || (R / 64) * S > 256) return CVC_E_BADARG;             // the exchange is built for 8 slices (R = 2048: 256 workgroups)
+    KsArgs a{};
+    a.wp = wp; a.xq = xq; a.nquad = K / 4; a.nblk = R / 8; a.ksplit = S; a.slab = slab; a.wstride = (long long)(K / 4) * 128;
+    a.b_ih = b_ih; a.b_hh = b_hh; a.gate_bias = gate_bias; a.c_prev_q = c_prev_q;
+    a.c_out_q = c_out_q; a.h_dst1_q = h_dst1_q; a.h_dst2_q = h_dst2_q; a.M = M; a.R = R;
+    a.flags = flags; a.seq = seq & 0x0fffffffu; a.emb_gate = emb_gate; a.word = word; a.local = cvc_ksx_local;
+    if (a.seq == 0) return CVC_E_BADARG;
+    hipLaunchKernelGGL((packed_ks_kernel<8, true>), dim3((R / 64) * S), dim3(512), 0, (hipStream_t)stream, a);
     return cvc_launch_status();
 }

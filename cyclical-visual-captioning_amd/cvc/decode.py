@@ -19,6 +19,7 @@ writes a tensor another workgroup of the same launch still reads.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -167,26 +168,38 @@ def pack_weights_tile(w: torch.Tensor, lstm_R: Optional[int] = None) -> torch.Te
 GATE_KSPLIT_DEFAULT = False   # measured (profiles/README.md, r02): the K-split kernel itself is 8-9 us faster per GEMM, its finishing launch costs the same
 KS_PAD_QUADS = 0          # extra quads between the 32-row weight blocks of the K-split gate GEMM (measured: no effect; 0 = share the dense pack)
 
-CACHE_BUDGET = 208 << 20      # bytes re-read every step that are left cacheable in the 256 MiB Infinity Cache
+# bytes re-read every step that are left cacheable in the 256 MiB Infinity Cache (CVC_CACHE_BUDGET_MB: A/B override)
+CACHE_BUDGET = int(os.environ.get("CVC_CACHE_BUDGET_MB", "208")) << 20
+CACHE_GATE_WEIGHTS = os.environ.get("CVC_ATT_W_CACHED", "1") != "0"       # False: gate weights always stream (A/B)
 
 
-def cache_plan(linear_weight_bytes: int, feature_bytes: Dict[str, int], budget: int = CACHE_BUDGET) -> Dict[str, bool]:
-    """Which per-step feature streams stay cacheable (True) and which are read non-temporally (False).
+def cache_plan(linear_weight_bytes: int, feature_bytes: Dict[str, int], budget: int = CACHE_BUDGET,
+               gate_weight_bytes: Optional[int] = None) -> Dict[str, bool]:
+    """Which per-step streams stay cacheable (True) and which are read non-temporally (False).
 
-    A decode step re-reads the same ~0.9 GB; the Infinity Cache holds 256 MiB of it.  The LSTM gate weights always
-    stream; the small linear weights (vocabulary head, h2attn) always stay cacheable; of the four feature tensors the
-    subset with the most bytes that still fits the budget stays cacheable (every cached byte is one HBM byte less
-    per step), the rest is marked `stream` in its cvc_attn_set.  Measured at cfg2: nothing streamed 283 k steps/s,
-    this plan 302-304 k."""
+    A decode step re-reads the same ~0.85 GB; the Infinity Cache holds 256 MiB of it.  The small linear weights (vocabulary
+    head, h2attn) always stay cacheable.  gate_weight_bytes: the attention cell's gate matrix in the embedding-gate schedule
+    (key "att_w" of the result) -- it goes first when it fits next to them: the gate GEMM is bound by the latency of its
+    weight loads, not by bandwidth, so a cached byte buys more there than in the attention passes, which stream at the
+    memory's rate either way (measured at cfg2: its launch 40.3 -> 35.4 us; decode 322 -> 328 k steps/s).  The language
+    cell's matrix (201 MB at cfg2) never fits and always streams.  Of the four feature tensors the subset with the most
+    bytes that still fits the remaining room stays cacheable, the rest is marked `stream` in its cvc_attn_set.
+    Measured at cfg2: nothing streamed 283 k steps/s, features only 302-304 k (round 2) / 322 k (round 3 kernels)."""
     names = list(feature_bytes)
     room = budget - linear_weight_bytes
+    plan = {}
+    if gate_weight_bytes is not None:
+        plan["att_w"] = bool(CACHE_GATE_WEIGHTS and 0 < gate_weight_bytes <= room)
+        if plan["att_w"]:
+            room -= gate_weight_bytes
     best, best_bytes = (), 0
     for pick in range(1 << len(names)):
         chosen = [n for i, n in enumerate(names) if pick >> i & 1]
         tot = sum(feature_bytes[n] for n in chosen)
         if best_bytes < tot <= room:
             best, best_bytes = tuple(chosen), tot
-    return {n: n in best for n in names}
+    plan.update({n: n in best for n in names})
+    return plan
 
 
 class DecodeEngine:
@@ -226,10 +239,6 @@ class DecodeEngine:
         self.own_features = own_features
         self.feats = (fc, conv, pconv, pool, ppool)
         nb = lambda t: t.numel() * t.element_size()
-        keep = cache_plan(4 * (V * R + A * R), {"ppool": nb(ppool), "pconv": nb(pconv), "pool": nb(pool), "conv": nb(conv)})
-        # cvc_attn_set.stream: bit 0 = proj read non-temporally, bit 1 = ctx
-        self.stream_r = (0 if keep["ppool"] else 1) | (0 if keep["pool"] else 2)
-        self.stream_f = (0 if keep["pconv"] else 1) | (0 if keep["conv"] else 2)
         rows = self.rows = B * self.beam
         f32 = dict(device=dev, dtype=torch.float32)
         z = lambda *s: torch.zeros(*s, **f32)
@@ -279,6 +288,14 @@ class DecodeEngine:
         if embgate and not eg_ok:
             raise RuntimeError("DecodeEngine: the embedding-gate schedule needs the packed path (without gsk / gate_ksplit) or the tile path")
         self.embgate = (eg_ok and 4 * V * 4 * R <= EMBGATE_MAX_BYTES) if embgate is None else bool(embgate)
+        # what stays in the Infinity Cache between steps: small linear weights, then (embedding-gate schedule on the packed path) the
+        # attention cell's gate matrix over K = 2R if it fits, then the largest subset of the feature tensors
+        keep = cache_plan(4 * (V * R + A * R), {"ppool": nb(ppool), "pconv": nb(pconv), "pool": nb(pool), "conv": nb(conv)},
+                          gate_weight_bytes=4 * 4 * R * 2 * R if (self.packed and self.embgate and rows > 32) else None)
+        self.att_w_cached = bool(keep.get("att_w", False))
+        # cvc_attn_set.stream: bit 0 = proj read non-temporally, bit 1 = ctx
+        self.stream_r = (0 if keep["ppool"] else 1) | (0 if keep["pool"] else 2)
+        self.stream_f = (0 if keep["pconv"] else 1) | (0 if keep["conv"] else 2)
         self._plan = None
         if self.packed:
             self._alloc_packed()
@@ -322,6 +339,7 @@ class DecodeEngine:
             if self.embgate:
                 d.w_att = ptr(W.p_att2)
                 d.emb_gate, d.sel_counter = ptr(W.t_embgate), ptr(self.sel_counter)
+                d.att_w_cached = int(self.att_w_cached)
             if self.gsk:
                 d.gsk_nwg = self.gsk_nwg
                 d.slab_att, d.slab_lang, d.slab_q, d.slab_o = (ptr(self.slab_att), ptr(self.slab_lang), ptr(self.slab_q),
@@ -484,7 +502,7 @@ class DecodeEngine:
         for t in range(self.T):
             rd, wr = t & 1, (t + 1) & 1
             XA_r, XA_w, XL_r, XL_w = self.XA[rd], self.XA[wr], self.XL[rd], self.XL[wr]
-            out.append(("att_lstm", L.cvc_packed_lstm_embgate_fwd, (ptr(W.p_att2), ptr(XA_r), 2 * R, None, None, ptr(self.gate_fc),
+            out.append(("att_lstm", L.cvc_packed_lstm_embgate_cached_fwd if self.att_w_cached else L.cvc_packed_lstm_embgate_fwd, (ptr(W.p_att2), ptr(XA_r), 2 * R, None, None, ptr(self.gate_fc),
                                                                     ptr(W.t_embgate), ptr(self.words[t]), ptr(self.cA[rd]), rows, R,
                                                                     qoff(XL_r, R), qoff(XA_w, R), ptr(self.cA[wr]))))
             out.append(("h2attn", L.cvc_packed_linear_fwd, (ptr(W.p_h), qoff(XL_r, R), R, None, rows, A, self.QSPLIT,

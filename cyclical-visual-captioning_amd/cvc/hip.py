@@ -66,7 +66,8 @@ class DecodeDesc(C.Structure):
         [(n, C.c_void_p) for n in ("parts_gate", "parts_o", "parts_fc", "logits")] +
         [(n, C.c_void_p) for n in ("h_att", "c_att", "h_lang", "c_lang", "c_att_prev", "c_lang_prev", "zero_state")] +
         [("beam_ws", C.c_void_p)] +
-        [("gsk_nwg", C.c_int)] + [(n, C.c_void_p) for n in ("slab_att", "slab_lang", "slab_q", "slab_o", "emb_gate", "sel_counter")])
+        [("gsk_nwg", C.c_int)] + [(n, C.c_void_p) for n in ("slab_att", "slab_lang", "slab_q", "slab_o", "emb_gate", "sel_counter")] +
+        [("att_w_cached", C.c_int)])
 
 # name -> argtypes, exactly the declarations of include/cvc_hip.h (tests/test_cabi.py checks both)
 SIGNATURES = {
@@ -81,6 +82,7 @@ SIGNATURES = {
     "cvc_packed_linear_fwd": [_P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P],
     "cvc_packed_lstm_wg_blocks": [_I],
     "cvc_packed_lstm_embgate_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "cvc_packed_lstm_embgate_cached_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "cvc_packed_linear_select_fwd": [_P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _I, _P, _P],
     "cvc_gsk_plan": [C.POINTER(_I), C.POINTER(_I), _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)],
     "cvc_gsk_gemm": [C.POINTER(GskGroup), _I, _I, _P],
@@ -107,6 +109,8 @@ SIGNATURES = {
     "cvc_packed_lstm_ks_slices": [_I, _I],
     "cvc_packed_lstm_ks_fwd": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _LL, _P],
     "cvc_packed_lstm_ksf_fwd": [_P, _P, _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P],
+    "cvc_packed_lstm_ksx_local": [_I],
+    "cvc_packed_lstm_ksx_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P, C.c_uint, _P],
     "cvc_attn_wsum": [C.POINTER(AttnSet), _I, _I, _I, _I, _P, _P],
     "cvc_attn_bwd": [_I, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "cvc_linear_fwd": [C.POINTER(GemmSeg), _I, _P, _P, _I, _I, _P, _I, _P],

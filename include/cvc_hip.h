@@ -160,6 +160,12 @@ int cvc_packed_linear_fwd(const float* wp, const float* xq, int K, const float* 
 int cvc_packed_lstm_embgate_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
                                 const float* gate_bias, const float* emb_gate, const int64_t* word, const float* c_prev_q,
                                 int M, int R, float* h_dst1_q, float* h_dst2_q, float* c_out_q, cvc_stream_t stream);
+/* ... reading the gate weights under the default cache policy (a gate matrix the caller's cache plan keeps in the Infinity Cache
+ * between steps) instead of streaming them non-temporally; same operands, same results */
+int cvc_packed_lstm_embgate_cached_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
+                                       const float* gate_bias, const float* emb_gate, const int64_t* word,
+                                       const float* c_prev_q, int M, int R, float* h_dst1_q, float* h_dst2_q,
+                                       float* c_out_q, cvc_stream_t stream);
 /* Vocabulary projection + word selection in ONE launch (captioner.py:437 + :415-422): cvc_packed_linear_fwd's top-2 records
  * (top2_part [ceil(Nout/32)][64][6], stored write-through) are merged by the last workgroup to arrive -- counter: one word of
  * device memory, zero before the first use, left zero -- which writes word[m * word_stride] (UNK rule, ties -> lowest index) and
@@ -279,6 +285,18 @@ int cvc_packed_lstm_ks_fwd(const float* wp, const float* xq, int K, const float*
 int cvc_packed_lstm_ksf_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
                             const float* gate_bias, const float* c_prev_q, int M, int R, float* h_dst1_q,
                             float* h_dst2_q, float* c_out_q, float* slab, unsigned* counters, cvc_stream_t stream);
+/* ... with the finish shared by ALL K slices of a tile (exchange finish): slice ks of a 256-row tile finishes the tile's block ks
+ * once the tile's 8 partial tiles are out (write-through slab rows + one arrival word per slice, system-scope loads on the
+ * reading side: correct wherever the workgroups run; tiles are placed on one XCD for speed only).  One launch, no finishing
+ * launch.  flags: R / 8 + 1 words of device memory, zero before the first use ([R / 64][8] arrival words + the error word at
+ * [R / 8], set to 1 by a slice whose bounded wait ran out); seq: non-zero and different from the previous launch's on these
+ * flags; emb_gate / word: the embedding-gate form (cvc_packed_lstm_embgate_fwd), nullable.  R = 2048 (8 slices, 256 workgroups
+ * of 512 threads, all resident together). */
+int cvc_packed_lstm_ksx_local(int on);   /* 1 (default): XCD-local exchange, XCC_ID-checked; 0: system-scope exchange; < 0 queries */
+int cvc_packed_lstm_ksx_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
+                            const float* gate_bias, const float* emb_gate, const int64_t* word, const float* c_prev_q,
+                            int M, int R, float* h_dst1_q, float* h_dst2_q, float* c_out_q, float* slab,
+                            unsigned* flags, unsigned seq, cvc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Grouped stream-K form of the decode step's skinny GEMMs (csrc/gemm_gsk.hip).  The gate GEMM of an LSTM cell
@@ -626,6 +644,7 @@ typedef struct cvc_decode_desc {
      * default path: measured slower than two launches).                                                                       */
     const float* emb_gate;
     unsigned* sel_counter;
+    int att_w_cached;                     /* embedding-gate schedule: 1 = w_att is read with the default cache policy (cvc_packed_lstm_embgate_cached_fwd) */
 } cvc_decode_desc;
 typedef struct cvc_decode_plan cvc_decode_plan;
 int cvc_decode_plan_create(const cvc_decode_desc* desc, cvc_decode_plan** plan);   /* validates, copies the descriptor       */

@@ -463,6 +463,66 @@ def test_packed_lstm_ksplit_equals_full_k_kernel(dev, lib, M, R, E):
     close(hk, h_ref.float(), rtol=2e-5, atol=2e-5); close(ck, c_ref.float(), rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("M,eg,mode", [(64, False, 1), (64, True, 1), (37, True, 1), (64, True, 0)])
+def test_packed_lstm_exchange_finish_equals_full_k_kernel(dev, lib, M, eg, mode):
+    """cvc_packed_lstm_ksx_fwd (K split over 8 workgroups per 256-row tile, every slice finishing one of the tile's blocks after
+    the in-launch exchange of the partial tiles) at R = 2048, with and without the embedding-gate term, XCD-local (mode 1) and
+    system-scope (mode 0) exchange: against the full-K kernel (fp32 noise: another K summation order) and fp64, the same bits
+    launch after launch, and the error word stays clear."""
+    from cvc.decode import pack_weights, to_quad, from_quad
+    R, V = 2048, 97
+    g = torch.Generator().manual_seed(M + 7 * eg + mode)
+    K = 2 * R if eg else 3 * R
+    w = (torch.randn(4 * R, K, generator=g) / K ** 0.5).to(dev)
+    x = torch.randn(M, K, generator=g).to(dev)
+    b1, b2 = (torch.randn(4 * R, generator=g) * 0.1).to(dev), (torch.randn(4 * R, generator=g) * 0.1).to(dev)
+    gb = (torch.randn(M, 4 * R, generator=g) * 0.2).to(dev)
+    c_prev = torch.randn(M, R, generator=g).to(dev)
+    table = (torch.randn(V, 4 * R, generator=g) * 0.3).to(dev) if eg else None
+    word = torch.randint(0, V, (M,), generator=g).to(dev) if eg else None
+    wp, xq, cq = pack_weights(w, R), to_quad(x), to_quad(c_prev)
+    L = lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda t: None if t is None else t.data_ptr()
+    new3 = lambda: [torch.zeros(R // 4, 64, 4, device=dev) for _ in range(3)]
+    h1, h2, c2 = new3()
+    if eg:
+        rc = L.cvc_packed_lstm_embgate_fwd(p(wp), p(xq), K, p(b1), p(b2), p(gb), p(table), p(word), p(cq), M, R, p(h1), p(h2), p(c2), st)
+    else:
+        rc = L.cvc_packed_lstm_fwd(p(wp), p(xq), K, p(b1), p(b2), p(gb), p(cq), M, R, p(h1), p(h2), p(c2), st)
+    assert rc == 0
+    hf, cf = from_quad(h1, M), from_quad(c2, M)
+    slab = torch.empty(8 * (R // 8) * 2048, device=dev)
+    flags = torch.zeros(R // 8 + 1, dtype=torch.int32, device=dev)
+    prev = L.cvc_packed_lstm_ksx_local(mode)
+    try:
+        first = None
+        for seq in range(1, 6):
+            h1, h2, c2 = new3()
+            rc = L.cvc_packed_lstm_ksx_fwd(p(wp), p(xq), K, p(b1), p(b2), p(gb), p(table), p(word), p(cq), M, R, p(h1), p(h2), p(c2),
+                                           p(slab), p(flags), seq, st)
+            assert rc == 0
+            got = (from_quad(h1, M), from_quad(h2, M), from_quad(c2, M))
+            assert int(flags[R // 8]) == 0, "exchange finish: a slice's wait ran out (workgroups of a tile not resident together / not on one XCD)"
+            assert torch.equal(got[0], got[1])
+            if first is not None:
+                assert torch.equal(got[0], first[0]) and torch.equal(got[2], first[2])
+            first = got
+    finally:
+        L.cvc_packed_lstm_ksx_local(prev)
+    close(first[0], hf, rtol=2e-5, atol=2e-5); close(first[2], cf, rtol=2e-5, atol=2e-5)
+    pre = x.double() @ w.double().t() + b1.double() + b2.double() + gb.double()
+    if eg:
+        pre = pre + table.double()[word]
+    i_, f_, gg, o_ = pre.chunk(4, 1)
+    c_ref = torch.sigmoid(f_) * c_prev.double() + torch.sigmoid(i_) * torch.tanh(gg)
+    h_ref = torch.sigmoid(o_) * torch.tanh(c_ref)
+    close(first[0], h_ref.float(), rtol=2e-5, atol=2e-5); close(first[2], c_ref.float(), rtol=2e-5, atol=2e-5)
+    # a repeated seq is refused by contract only (the caller's duty); seq 0 is refused outright
+    assert L.cvc_packed_lstm_ksx_fwd(p(wp), p(xq), K, p(b1), p(b2), p(gb), p(table), p(word), p(cq), M, R, p(h1), p(h2), p(c2), p(slab),
+                                     p(flags), 0, st) != 0
+
+
 @pytest.mark.parametrize("M,K,N,ksplit", [(320, 6144, 8192, 4), (320, 2048, 5000, 6), (150, 512, 130, 3), (65, 32, 50, 2),
                                           (700, 256, 256, 1), (1, 16, 1, 1)])
 def test_tile_gemm_vs_fp64(dev, lib, M, K, N, ksplit):

@@ -104,6 +104,11 @@ def test_cache_plan_keeps_the_largest_subset_that_fits():
     assert all(cache_plan(1000, {"ppool": 100, "pconv": 100, "pool": 100, "conv": 100}).values())
     plan = cache_plan(0, cfg2, budget=100 << 20)
     assert sum(cfg2[k] for k, v in plan.items() if v) == 26214400 + 52428800   # best fit under 100 MiB
+    # embedding-gate schedule: the attention cell's gate matrix (K = 2R) goes first when it fits next to the small linear weights
+    att_w = 4 * 4 * 2048 * 2 * 2048
+    assert cache_plan(int(49.2e6), cfg2, gate_weight_bytes=att_w) == {"att_w": True, "ppool": True, "pconv": False, "pool": False, "conv": False}
+    big = cache_plan(int(116e6), cfg5, gate_weight_bytes=4 * 4 * 4096 * 2 * 4096)
+    assert big["att_w"] is False and not any(big.values())                     # 537 MB of gate weights: streams, as everything else
 
 
 def test_equal_clip_shards_give_every_rank_the_same_step_count():
