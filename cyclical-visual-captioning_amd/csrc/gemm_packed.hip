@@ -630,6 +630,8 @@ static int launch_packed(const PackedArgs& a_in, int blocks, hipStream_t st) {
     }
     if constexpr (LSTM) {
         // (gate weights with the default cache policy: cvc_packed_lstm_embgate_cached_fwd)
+        // (measured alternatives at cfg2: the language cell's 201 MB instead -- its launch 54.2 -> 48.8 us, the attention cell's back
+        // to 40.5: 323-325 k against 326 k; both matrices: over the cache's size, slower than none)
         if (cvc_gemm_split_mode == 2 && a.w_cached && a.M > 32) {
             hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, true, CVC_PACKED_DEPTH8, true, 8, false, 1, false, true>), grid, dim3(512), 0, st, a);
             return cvc_launch_status();
