@@ -52,6 +52,65 @@ __global__ __launch_bounds__(512) void ingress(const float* __restrict__ xq, siz
     out[(size_t)blockIdx.x * 512 + tid] = s[0] + s[1] + s[2] + s[3];
 }
 
+// ---- is the serialisation of HBM-sourced and L2-sourced loads per WAVE (in-order return behind vmcnt) or per CU?  Same bytes as
+// `ingress<true, true>`, but the roles are split: waves 0..NWW-1 stream ALL the weights of the workgroup (nt, HBM), the other waves
+// read ALL the activations (L2 hits).  If the two kinds only wait for each other inside a wave, this runs at max(weights, acts).
+template <int NWW, int DEPTH>
+__global__ __launch_bounds__(512) void ingress_roles(const float* __restrict__ xq, const float* __restrict__ wp, int nchunk, float* out) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kh = lane >> 5;
+    const bool wrole = wave < NWW;
+    const int nw = wrole ? NWW : 8 - NWW, w = wrole ? wave : wave - NWW;
+    const float* x0 = xq + (size_t)i * 4 + kh * 4 * 256;
+    const float* w0 = wp + (size_t)blockIdx.x * nchunk * 8 * 128 + (size_t)i * 4 + kh * 4 * 128;
+    const int n_my = nchunk / nw;
+    const int rot = (blockIdx.x * 5) % n_my;
+    f32x4 s = {0, 0, 0, 0};
+    if (wrole) {
+        f32x4 ring[DEPTH][4];
+        auto load = [&](f32x4 (&f)[4], int j) __attribute__((always_inline)) {
+            int jr = j + rot; jr = jr >= n_my ? jr - n_my : jr;
+            const int c = w + nw * jr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w0 + (size_t)c * 8 * 128 + q * 128));
+        };
+#pragma unroll
+        for (int d = 0; d < DEPTH - 1; ++d) load(ring[d], d);
+        for (int j = 0; j < n_my; j += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const int jn = j + d + DEPTH - 1;
+                load(ring[(d + DEPTH - 1) % DEPTH], jn < n_my ? jn : n_my - 1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s += ring[d][q];
+            }
+        }
+    } else {
+        f32x4 ring[DEPTH][8];
+        auto load = [&](f32x4 (&f)[8], int j) __attribute__((always_inline)) {
+            int jr = j + rot; jr = jr >= n_my ? jr - n_my : jr;
+            const int c = w + nw * jr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f[2 * q] = *reinterpret_cast<const f32x4*>(x0 + (size_t)c * 8 * 256 + q * 256);
+                f[2 * q + 1] = *reinterpret_cast<const f32x4*>(x0 + (size_t)c * 8 * 256 + q * 256 + 128);
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < DEPTH - 1; ++d) load(ring[d], d);
+        for (int j = 0; j < n_my; j += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const int jn = j + d + DEPTH - 1;
+                load(ring[(d + DEPTH - 1) % DEPTH], jn < n_my ? jn : n_my - 1);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) s += ring[d][q];
+            }
+        }
+    }
+    out[(size_t)blockIdx.x * 512 + tid] = s[0] + s[1] + s[2] + s[3];
+}
+
 // ---- skeleton of the K-split kernel (gemm_packed_ks.hip): 8 waves, each streams ITS 32 weight rows (4 nt dwordx4 loads per chunk);
 // XA activation loads per wave and chunk (1 = the K-split kernel's share of the common chunk), optional barrier per chunk (the
 // lock step the LDS hand-over needs), NM dependent-free bf16 MFMAs and NV VALU ops per chunk (24 / ~130 in the real kernel)
@@ -138,6 +197,14 @@ int main() {
     {
         float us = time([&] { hipLaunchKernelGGL((ingress<true, true, 4>), dim3(nwg), dim3(512), 0, 0, xq, xbytes / 4, 1, wp, nchunk, 1, out); }, 10, true);
         printf("weights + activations, depth 4: %7.1f us\n", us);
+    }
+    {
+        float us = time([&] { hipLaunchKernelGGL((ingress_roles<4, 3>), dim3(nwg), dim3(512), 0, 0, xq, wp, nchunk, out); }, 10, true);
+        printf("roles split, 4 weight waves (depth 3) + 4 activation waves: %7.1f us\n", us);
+        us = time([&] { hipLaunchKernelGGL((ingress_roles<4, 6>), dim3(nwg), dim3(512), 0, 0, xq, wp, nchunk, out); }, 10, true);
+        printf("roles split, 4 weight waves (depth 6) + 4 activation waves: %7.1f us\n", us);
+        us = time([&] { hipLaunchKernelGGL((ingress_roles<6, 4>), dim3(nwg), dim3(512), 0, 0, xq, wp, nchunk, out); }, 10, true);
+        printf("roles split, 6 weight waves (depth 4) + 2 activation waves: %7.1f us\n", us);
     }
     printf("K-split skeleton (256 gate rows x K/8 per workgroup), lang cell 201 MB of weights:\n");
 #define RUN(XA, SYNC, NM, NV, D) { float us = time([&] { hipLaunchKernelGGL((ks_skeleton<XA, SYNC, NM, NV, D>), dim3(nwg), dim3(512), 0, 0, xq, wp, nchunk, out); }, 10, true); \
