@@ -37,6 +37,16 @@ class NNSeg(C.Structure):
 _P, _I, _F, _LL = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 
 
+class OptimSeg(C.Structure):
+    """cvc_optim_seg (include/cvc_hip.h): one parameter of the fused clip + Adam step"""
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("step", C.c_void_p), ("n", C.c_longlong),
+                ("lr", C.c_float), ("weight_decay", C.c_float)]
+
+
+class OptimChunk(C.Structure):
+    _fields_ = [("seg", C.c_int), ("pad", C.c_int), ("start", C.c_longlong)]
+
+
 class GskGroup(C.Structure):
     """cvc_gsk_group: one GEMM of a grouped stream-K launch (include/cvc_hip.h, "Grouped stream-K form")."""
     _fields_ = [("wp", C.c_void_p), ("w_blk_stride", C.c_longlong), ("xq", C.c_void_p), ("nblk", C.c_int), ("nchunk", C.c_int),
@@ -160,6 +170,8 @@ SIGNATURES = {
     "cvc_decode_num_launches": [_P],
     "cvc_decode_greedy": [_P, _P],
     "cvc_decode_beam": [_P, _P],
+    "cvc_optim_chunk_elems": [],
+    "cvc_adam_clip_step": [_P, _I, _P, _I, _F, _F, _F, _F, _F, _I, _P, _P, _P],
     "cvc_comm_unique_id": [_P],
     "cvc_comm_init": [_I, _I, _P, C.POINTER(C.c_void_p)],
     "cvc_allreduce_grads": [_P, _P, _LL, _P],

@@ -89,14 +89,21 @@ class Trainer:
         """zero_grad -> backward -> [gradient exchange] -> clip_grad_norm_ -> step (trainer.py:116-122).  With a GradReducer
         the gradients live in flat arenas: one fill to zero them, the exchange in place, one multiply to clip (1/G folded in)."""
         red = self.grad_reducer
+        fused = getattr(self.optimizer, "clip_and_step", None)     # cvc.optim.ClipAdam: norm + clip + Adam in three launches
         if red is None:
             self.optimizer.zero_grad(set_to_none=set_to_none)
             loss.backward()
+            if fused is not None:
+                fused(self.opts.grad_clip, 1.0)
+                return
             nn.utils.clip_grad_norm_(self.model.parameters(), self.opts.grad_clip)
         else:
             red.zero_grad()
             loss.backward()
             red.finalize(average=False)                      # the one exchange step of the path
+            if fused is not None:
+                fused(self.opts.grad_clip, 1.0 / red.world)  # (the arenas hold sums over ranks: 1 / G folded into the coefficient)
+                return
             red.clip_(self.opts.grad_clip, summed=True)
         self.optimizer.step()
 
@@ -297,6 +304,9 @@ def write_grounding_json(grd_output, o):
     return path
 
 
+CLIP_ADAM = os.environ.get("CVC_CLIP_ADAM", "1") != "0"      # False: torch.optim.Adam (fused) + the library's clip (A/B)
+
+
 def build_optimizer(model, opt, capturable: bool = False):
     """One param group per tensor; 0.1x LR for ctx2pool_grd / vis_embed (reference main.py:171-191).
     capturable=True keeps Adam's step counters on the device (needed by Trainer.train_step_graphed)."""
@@ -311,6 +321,9 @@ def build_optimizer(model, opt, capturable: bool = False):
     if opt.optim == 'adam':
         # fused = one pass over (p, g, m, v) per tensor instead of the foreach path's ~9 passes (Adam was 8 % of the step)
         fused = all(p['params'][0].is_cuda for p in params)
+        if fused and CLIP_ADAM:
+            from .optim import ClipAdam                      # clip_grad_norm_ + step in one pass over p / g / m / v (csrc/optim.hip)
+            return ClipAdam(params)
         return torch.optim.Adam(params, capturable=capturable, fused=fused)
     if opt.optim == 'adamax':
         return torch.optim.Adamax(params)

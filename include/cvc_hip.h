@@ -659,6 +659,28 @@ int cvc_decode_greedy(cvc_decode_plan* plan, cvc_stream_t stream);
 int cvc_decode_beam(cvc_decode_plan* plan, cvc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Optimizer step of the training path (trainer.py:116-122: nn.utils.clip_grad_norm_ -> optimizer.step(); Adam with one group per
+ * tensor, main.py:171-191).  cvc_adam_clip_step = global L2 norm of all gradients (chunk sums combined in chunk order:
+ * deterministic), clip coefficient min(1, max_norm / (inv_world * norm + 1e-6)) * inv_world (inv_world = 1 / ranks when the
+ * gradients are sums over ranks; max_norm <= 0: no clipping), every segment's step count += 1, then torch.optim.Adam's update
+ * (amsgrad = False) on (p, g * coef, m, v) in ONE pass; write_grad != 0 also stores the clipped gradient back, as clip_grad_norm_
+ * leaves it.  Three launches, nothing read back by the host (graph-capturable).
+ *   segs   : DEVICE array of nseg parameter segments;   chunks : DEVICE array of nchunk (segment, start) pairs covering every
+ *            segment in pieces of cvc_optim_chunk_elems() elements (start a multiple of it), in any fixed order;
+ *   partial: nchunk floats of scratch;   norm_coef: 2 floats out -- [0] the norm of the (averaged) gradient, [1] the coefficient. */
+typedef struct {
+    float *p, *g, *m, *v;     /* parameter, gradient, exp_avg, exp_avg_sq: n floats each */
+    float* step;              /* the parameter's step count, one float32 on the device (torch's `step` state) */
+    long long n;
+    float lr, weight_decay;
+} cvc_optim_seg;
+typedef struct { int seg; int pad; long long start; } cvc_optim_chunk;
+int cvc_optim_chunk_elems(void);
+int cvc_adam_clip_step(const cvc_optim_seg* segs, int nseg, const cvc_optim_chunk* chunks, int nchunk, float max_norm,
+                       float inv_world, float beta1, float beta2, float eps, int write_grad, float* partial,
+                       float* norm_coef, cvc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Multi-GPU training: the one exchange step of the path.  The reference reduces gradients inside nn.DataParallel
  * (main.py:169; per-replica token-mean losses, unweighted mean over replicas, trainer.py:101-122); with one process per GPU
  * that is a SUM all-reduce of the gradients over RCCL / xGMI followed by 1/G, which the caller folds into its clip multiply

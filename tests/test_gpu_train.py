@@ -424,3 +424,77 @@ def test_in_kernel_dropout_kernels_equal_host_restatement():
             want = torch.autograd.grad([hs2[0], c2], ins, [gd * mk + gh, gc])
             for a_, b_ in zip(got, want):
                 assert torch.allclose(a_, b_, rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------ optimizer step on the HIP kernels
+@pytest.mark.parametrize("weight_decay,max_norm", [(0.0, 0.5), (0.01, 0.5), (0.0, 1e6)])
+def test_clip_adam_equals_clip_grad_norm_plus_torch_adam(weight_decay, max_norm):
+    """cvc.optim.ClipAdam.clip_and_step (csrc/optim.hip: norm partials, coefficient + step counters, one pass over p / g / m / v)
+    against nn.utils.clip_grad_norm_ + torch.optim.Adam.step() (trainer.py:116-122) over six steps: parameters, both moments,
+    step counts, the clipped gradients left in .grad, the norm; per-group learning rates (main.py:171-191), odd sizes, a
+    parameter that never gets a gradient, a 4-byte-aligned view; and the state_dict layout torch.optim.Adam loads."""
+    from cvc.optim import ClipAdam
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    big = torch.randn(3 * 65536 + 7, generator=g)
+    shapes = [(257, 129), (65536 * 2,), (5,), (1,), (64, 1024)]
+    base = [torch.randn(*s, generator=g) for s in shapes]
+    arena = torch.randn(1000 + 1, generator=g)
+
+    def make():
+        ps = [torch.nn.Parameter(b.clone().to(dev)) for b in base]
+        ps.append(torch.nn.Parameter(big.clone().to(dev)))
+        a = arena.clone().to(dev)
+        ps.append(torch.nn.Parameter(a[1:]))                       # 4-byte aligned storage offset: the scalar path of the kernels
+        dead = torch.nn.Parameter(torch.ones(8, device=dev))       # never receives a gradient
+        groups = [{"params": [p], "lr": 1e-3 * (0.1 if i % 3 == 0 else 1.0), "weight_decay": weight_decay, "betas": (0.8, 0.99)}
+                  for i, p in enumerate(ps + [dead])]
+        return ps, dead, groups
+    pa, dead_a, ga = make()
+    pb, dead_b, gb = make()
+    ref = torch.optim.Adam(ga)
+    opt = ClipAdam(gb)
+    for it in range(6):
+        grads = [torch.randn(p.shape, generator=g) * (3.0 if it % 2 else 0.01) for p in pa]
+        for p, q, gr in zip(pa, pb, grads):
+            p.grad = gr.clone().to(dev)
+            q.grad = gr.clone().to(dev)
+        n_ref = torch.nn.utils.clip_grad_norm_(pa + [dead_a], max_norm)
+        ref.step()
+        n_got = opt.clip_and_step(max_norm, 1.0)
+        assert float(n_got) == pytest.approx(float(n_ref), rel=2e-6)
+        for p, q in zip(pa, pb):
+            assert torch.allclose(q, p, rtol=2e-6, atol=1e-6), it
+            assert torch.allclose(q.grad, p.grad, rtol=2e-6, atol=1e-9)                       # the clipped gradient, written back
+            sa, sb = ref.state[p], opt.state[q]
+            # (fp32 rounding of m + (g - m) (1 - beta1) under cancellation: absolute, at the scale of the gradients)
+            assert torch.allclose(sb["exp_avg"], sa["exp_avg"], rtol=2e-6, atol=2e-6)
+            assert torch.allclose(sb["exp_avg_sq"], sa["exp_avg_sq"], rtol=5e-6, atol=1e-8)
+            assert float(sb["step"]) == float(sa["step"]) == it + 1
+    assert torch.equal(dead_b, torch.ones(8, device=dev)) and len(opt.state[dead_b]) == 0           # skipped, as torch skips it
+    # gradients that are sums over 4 ranks: the 1 / G is folded into the coefficient
+    pc, _dc, gc = make()
+    pd, _dd, gd = make()
+    o1, o2 = ClipAdam(gc), ClipAdam(gd)
+    grads = [torch.randn(p.shape, generator=g) for p in pc]
+    for p, q, gr in zip(pc, pd, grads):
+        p.grad = (gr / 4).to(dev); q.grad = gr.clone().to(dev)
+    o1.clip_and_step(max_norm, 1.0); o2.clip_and_step(max_norm, 0.25)
+    for p, q in zip(pc, pd):
+        assert torch.allclose(q, p, rtol=2e-6, atol=2e-7) and torch.allclose(q.grad, p.grad, rtol=2e-6, atol=1e-9)
+    # a torch.optim.Adam resumes from ClipAdam's state_dict and the other way round
+    sd = opt.state_dict()
+    ref2 = torch.optim.Adam(make()[2], capturable=True)
+    ref2.load_state_dict(sd)
+    opt2 = ClipAdam(make()[2])
+    opt2.load_state_dict(ref.state_dict())
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+    # step() alone = the unclipped update
+    pe, _de, ge = make()
+    pf, _df, gf = make()
+    r3, o3 = torch.optim.Adam(ge), ClipAdam(gf)
+    for p, q, gr in zip(pe, pf, grads):
+        p.grad = gr.clone().to(dev); q.grad = gr.clone().to(dev)
+    r3.step(); o3.step()
+    for p, q in zip(pe, pf):
+        assert torch.allclose(q, p, rtol=2e-6, atol=2e-7) and torch.equal(q.grad, p.grad)
