@@ -2,7 +2,7 @@
 #   bench lines (greedy default, driver-style 20 steps, beam 5, cfg5 greedy, train, encoder), rocprofv3 kernel-trace summaries of the same
 #   commands, and the FETCH_SIZE / WRITE_SIZE PMC passes (separate runs, --kernel-trace only) that tools/collect_traffic.py
 #   turns into profiles/traffic.json.
-TAG=${1:-r02}
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof
@@ -43,7 +43,24 @@ for what in greedy beam5 train encoder; do
   python3 $R/tools/rocpd_summary.py $DB > $O/${TAG}_${what}_kernel_stats.md 2>&1
   rm -rf $O/kt
 done
-ls -la $O | head -40
+# ---- round 3 additions
+# decode-step timeline (per-position duration + idle gap) from a graph-replay kernel trace
+rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-secondary > $O/kt_timeline.log 2>&1
+DB=$(find $O/kt -name "*.db" | head -1)
+python3 $R/tools/rocpd_step_timeline.py $DB 7 > $O/${TAG}_greedy_step_timeline.md 2>&1
+rm -rf $O/kt
+# L2-side counters of the gate GEMM forms (full K / exchange finish / K-split + finishing launch), standalone launches
+rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_sum TCC_READ_sum -d $O/pmc_l2a -o a -- python3 $R/tools/bench_ksx.py > $O/pmc_l2a.log 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $O/pmc_l2b -o b -- python3 $R/tools/bench_ksx.py > $O/pmc_l2b.log 2>&1
+{ echo "## TCP_TCC_READ_REQ_sum / TCC_READ_sum (requests per dispatch), tools/bench_ksx.py"; python3 $R/tools/rocpd_pmc.py $(find $O/pmc_l2a -name "*.db" | head -1);
+  echo; echo "## TCC_HIT_sum / TCC_MISS_sum"; python3 $R/tools/rocpd_pmc.py $(find $O/pmc_l2b -name "*.db" | head -1); } > $O/${TAG}_pmc_l2_gate_gemm.md 2>&1
+rm -rf $O/pmc_l2a $O/pmc_l2b
+python3 $R/tools/bench_ksx.py > $O/${TAG}_gate_gemm_forms.log 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w $R/tools/l2_ingress.hip -o /tmp/l2i && /tmp/l2i > $O/${TAG}_l2_ingress.log 2>&1
+# the N-rank entry path at N = 1 (bench.py starts its rank processes itself): decode line and config 4's per-GPU training step
+python3 $R/bench.py --gpus 1 --spawn --steps 20 --warmup 5 --no-secondary > $O/bench_${TAG}_spawn1_greedy.json 2> $O/bench_spawn.err
+python3 $R/bench.py --gpus 1 --spawn --mode train --config cfg4 --steps 30 --warmup 3 > $O/bench_${TAG}_spawn1_train_cfg4.json 2>> $O/bench_spawn.err
+ls -la $O | head -60
 head -c 700 $O/bench_${TAG}_greedy.json; echo
 for f in beam5 cfg5_greedy cfg5_beam5 train; do python3 -c "
 import json,sys
