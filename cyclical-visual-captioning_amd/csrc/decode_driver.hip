@@ -79,6 +79,10 @@ int run_packed(cvc_decode_plan* p, hipStream_t st) {
         attn_sets(d, t, rows, sets);
         CVC_TRY(cvc_attn_scores_qparts(d.attn_kind, d.q_parts, d.qsplit, d.b_h, d.w_a, d.b_a, d.inv_temp, sets, 2, d.B, 1, A, st));
         CVC_TRY(cvc_attn_wsum_quad(sets, 2, d.B, 1, R, XL_r, st));
+        if (d.lang_ksx)      // K-split gate GEMM, every K slice of a tile finishing one of its blocks after the in-launch exchange
+            CVC_TRY(cvc_packed_lstm_ksx_fwd((const float*)d.w_lang, XL_r, 3 * R, d.b_ih_lang, d.b_hh_lang, nullptr, nullptr, nullptr, d.cl[rd],
+                                            rows, R, XA_w, quad_off(XL_w, 2 * R), d.cl[wr], d.ksx_slab, d.ksx_flags, (unsigned)(t + 1), st));
+        else
         CVC_TRY(cvc_packed_lstm_fwd((const float*)d.w_lang, XL_r, 3 * R, d.b_ih_lang, d.b_hh_lang, nullptr, d.cl[rd], rows, R, XA_w,
                                     quad_off(XL_w, 2 * R), d.cl[wr], st));
         CVC_TRY(cvc_packed_linear_fwd((const float*)d.w_o, XA_w, R, d.b_o, rows, V, 1, nullptr, V, d.top2_part, st));
@@ -114,6 +118,10 @@ int run_packed_eg(cvc_decode_plan* p, hipStream_t st) {
         attn_sets(d, t, rows, sets);
         CVC_TRY(cvc_attn_scores_qparts(d.attn_kind, d.q_parts, d.qsplit, d.b_h, d.w_a, d.b_a, d.inv_temp, sets, 2, d.B, 1, A, st));
         CVC_TRY(cvc_attn_wsum_quad(sets, 2, d.B, 1, R, XL_r, st));
+        if (d.lang_ksx)      // K-split gate GEMM, every K slice of a tile finishing one of its blocks after the in-launch exchange
+            CVC_TRY(cvc_packed_lstm_ksx_fwd((const float*)d.w_lang, XL_r, 3 * R, d.b_ih_lang, d.b_hh_lang, nullptr, nullptr, nullptr, d.cl[rd],
+                                            rows, R, XA_w, quad_off(XL_w, 2 * R), d.cl[wr], d.ksx_slab, d.ksx_flags, (unsigned)(t + 1), st));
+        else
         CVC_TRY(cvc_packed_lstm_fwd((const float*)d.w_lang, XL_r, 3 * R, d.b_ih_lang, d.b_hh_lang, nullptr, d.cl[rd], rows, R, XA_w,
                                     quad_off(XL_w, 2 * R), d.cl[wr], st));
         CVC_TRY(cvc_packed_linear_fwd((const float*)d.w_o, XA_w, R, d.b_o, rows, V, 1, nullptr, V, d.top2_part, st));
@@ -261,6 +269,7 @@ int validate(const cvc_decode_desc& d) {
             (!d.xa0_init && !d.emb_gate))
             return CVC_E_BADARG;
         if (d.emb_gate != nullptr && d.gsk_nwg > 0) return CVC_E_BADARG;
+        if (d.lang_ksx && (!d.ksx_slab || !d.ksx_flags || d.R != 2048 || d.T < 2 || d.gsk_nwg > 0)) return CVC_E_BADARG;
         if (d.gsk_nwg < 0 || (d.gsk_nwg > 0 && ((d.R & 63) || !d.slab_att || !d.slab_lang || !d.slab_q || !d.slab_o))) return CVC_E_BADARG;
     } else if (d.path == 1) {
         if ((d.R & 15) || (d.E & 15) || d.ks_gate < 1 || d.ks_q < 1 || d.ks_o < 1 || d.ks_fc < 1) return CVC_E_BADARG;

@@ -526,10 +526,11 @@ extern "C" int cvc_packed_lstm_ksf_fwd(const float* wp, const float* xq, int K, 
     return cvc_launch_status();
 }
 
-static int cvc_ksx_local = 1;
-// The exchange's memory path: 1 (default) = XCD-local (ordinary slab stores, L2-served reads, every arrival word carrying its writer's
-// XCC_ID and checked), 0 = system scope (write-through stores, system-scope loads: placement-independent, ~12 us slower per launch --
-// 16.8 MB of write-through stores take 10 us to be acknowledged).  Returns the previous setting; < 0 queries.
+static int cvc_ksx_local = 3;
+// The exchange's memory path: 1 / 2 / 3 (default 3) = XCD-local -- ordinary slab stores (acknowledged = in the XCD's L2), every arrival
+// word carrying its writer's XCC_ID and checked; the slab rows read back with ordinary (1), non-temporal (2) or sc1 (3) loads --; 0 =
+// system scope (write-through stores, system-scope loads: placement-independent, 5-6 us slower per launch: 16.8 MB of write-through
+// stores take ~10 us to be acknowledged).  Returns the previous setting; < 0 queries.
 extern "C" int cvc_packed_lstm_ksx_local(int on) {
     const int prev = cvc_ksx_local;
     if (on >= 0) cvc_ksx_local = on > 3 ? 1 : on;

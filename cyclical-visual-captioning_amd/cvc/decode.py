@@ -170,6 +170,11 @@ KS_PAD_QUADS = 0          # extra quads between the 32-row weight blocks of the 
 
 # bytes re-read every step that are left cacheable in the 256 MiB Infinity Cache (CVC_CACHE_BUDGET_MB: A/B override)
 CACHE_BUDGET = int(os.environ.get("CVC_CACHE_BUDGET_MB", "208")) << 20
+# The language cell on the K-split gate GEMM with the exchange finish.  Off by default: standalone (operands flushed from the caches
+# between calls) it is 10 us faster than the full-K kernel (61.0 -> 51.3 us), inside the decode graph it is not (329.5 / 327.3 k
+# steps/s without it, 326.1 / 323.5 k with it on one box: the 16.8 MB of partial tiles pass through the L2 / Infinity Cache that
+# holds the attention cell's weights, whose launch slows down by 1.5 us).  CVC_LANG_KSX=1 or lang_ksx=True switches it on.
+LANG_KSX_DEFAULT = os.environ.get("CVC_LANG_KSX", "0") == "1"
 CACHE_GATE_WEIGHTS = os.environ.get("CVC_ATT_W_CACHED", "1") != "0"       # False: gate weights always stream (A/B)
 
 
@@ -208,11 +213,15 @@ class DecodeEngine:
 
     def __init__(self, weights: DecodeWeights, feats: Dict[str, torch.Tensor], T: int, unk_idx: int, beam: int = 1,
                  inv_temp: float = 1.0, own_features: bool = False, path: str = "auto", gate_ksplit: Optional[bool] = None,
-                 driver: bool = True, gsk: Optional[bool] = None, embgate: Optional[bool] = None):
+                 driver: bool = True, gsk: Optional[bool] = None, embgate: Optional[bool] = None, lang_ksx: Optional[bool] = None):
         """driver: enqueue the decode through the C-ABI drivers cvc_decode_greedy / cvc_decode_beam (one host call per decode);
         False walks the launch list in Python (one ctypes call per kernel; tests compare the two).
         embgate: packed path only -- the embedding-gate schedule (the embedded word's share of the att-LSTM gates is a row of
         a per-checkpoint table: 34 MB less to stream per step at config 2, and the gate GEMM no longer waits for the word).  None = on when the table fits EMBGATE_MAX_BYTES; tests compare on / off.
+        lang_ksx: packed path, R = 2048 -- the language cell on the K-split gate GEMM with the exchange finish
+        (cvc_packed_lstm_ksx_fwd: activations read once per 256 gate rows instead of once per 32; the tile's 8 K slices
+        exchange their partial tiles inside the launch).  None = off (measured no faster inside the decode graph; CVC_LANG_KSX=1:
+        on); the exchange's error word is checked after the first decode and the engine re-binds without it if it is set.
         gsk: packed path only -- True selects the grouped stream-K schedule (csrc/gemm_gsk.hip; measured slower than the
         embedding-gate schedule, kept selectable and tested; needs R % 64 == 0, split-product arithmetic).
         path: "auto" picks packed (greedy, <= 64 rows) / tile (> 64 rows or beams) / ring (odd widths); "ring" forces the
@@ -297,6 +306,16 @@ class DecodeEngine:
         self.stream_r = (0 if keep["ppool"] else 1) | (0 if keep["pool"] else 2)
         self.stream_f = (0 if keep["pconv"] else 1) | (0 if keep["conv"] else 2)
         self._plan = None
+        self._driver = driver
+        ksx_ok = (self.packed and not self.gsk and not self.gate_ksplit and R == 2048 and self.T > 1 and
+                  hip.gemm_packed_split(-1) == 2 and int(hip.lib().cvc_packed_lstm_ks_slices(3 * R, R)) == 8)
+        if lang_ksx and not ksx_ok:
+            raise RuntimeError("DecodeEngine: lang_ksx needs the packed path at R = 2048, T > 1, split-product arithmetic")
+        self.lang_ksx = ksx_ok and (LANG_KSX_DEFAULT if lang_ksx is None else bool(lang_ksx))
+        self._ksx_checked = False
+        if self.lang_ksx:
+            self.ksx_slab = torch.empty(8 * (R // 8) * 2048, device=dev, dtype=torch.float32)
+            self.ksx_flags = torch.zeros(R // 8 + 1, device=dev, dtype=torch.int32)
         if self.packed:
             self._alloc_packed()
             self._launches = self._build_packed()
@@ -340,6 +359,8 @@ class DecodeEngine:
                 d.w_att = ptr(W.p_att2)
                 d.emb_gate, d.sel_counter = ptr(W.t_embgate), ptr(self.sel_counter)
                 d.att_w_cached = int(self.att_w_cached)
+            if self.lang_ksx:
+                d.lang_ksx, d.ksx_slab, d.ksx_flags = 1, ptr(self.ksx_slab), ptr(self.ksx_flags)
             if self.gsk:
                 d.gsk_nwg = self.gsk_nwg
                 d.slab_att, d.slab_lang, d.slab_q, d.slab_o = (ptr(self.slab_att), ptr(self.slab_lang), ptr(self.slab_q),
@@ -479,6 +500,8 @@ class DecodeEngine:
                                                                     ptr(W.b_hh_lang), None, ptr(self.cL[rd]), rows, R, ptr(XA_w),
                                                                     qoff(XL_w, 2 * R), ptr(self.cL[wr]), ptr(self.gate_slab),
                                                                     wp_lang.stride(0))))
+            elif self.lang_ksx:
+                out.append(self._lang_ksx_launch(t, XL_r, XA_w, XL_w, rd, wr))
             else:
                 out.append(("lang_lstm", L.cvc_packed_lstm_fwd, (ptr(W.p_lang), ptr(XL_r), 3 * R, ptr(W.b_ih_lang), ptr(W.b_hh_lang),
                                                                  None, ptr(self.cL[rd]), rows, R, ptr(XA_w), qoff(XL_w, 2 * R),
@@ -489,6 +512,15 @@ class DecodeEngine:
                                                           ptr(self.logprob[t]), ptr(W.embed), E, qoff(XA_w, R), 0)))
             self._keep.append(sets)
         return out
+
+    def _lang_ksx_launch(self, t, XL_r, XA_w, XL_w, rd, wr):
+        """The language cell of step t on cvc_packed_lstm_ksx_fwd (same operands and destinations as the full-K launch)."""
+        L, W, R = hip.lib(), self.W, self.W.R
+        ptr = lambda x: None if x is None else x.data_ptr()
+        qoff = lambda buf, k0: buf.data_ptr() + (k0 // 4) * 64 * 4 * 4
+        return ("lang_lstm", L.cvc_packed_lstm_ksx_fwd, (ptr(W.p_lang), ptr(XL_r), 3 * R, ptr(W.b_ih_lang), ptr(W.b_hh_lang), None, None, None,
+                                                          ptr(self.cL[rd]), self.rows, R, ptr(XA_w), qoff(XL_w, 2 * R), ptr(self.cL[wr]),
+                                                          ptr(self.ksx_slab), ptr(self.ksx_flags), t + 1))
 
     def _build_embgate_steps(self):
         """The T steps of the embedding-gate schedule (the launch list csrc/decode_driver.hip::run_packed_eg enqueues)."""
@@ -515,9 +547,12 @@ class DecodeEngine:
             out.append(("attn_scores", L.cvc_attn_scores_qparts, (W.kind, ptr(self.q_parts), self.QSPLIT, ptr(W.b_h), ptr(W.w_a),
                                                                   ptr(W.b_a), self.inv_temp, sets, 2, B, 1, A)))
             out.append(("attn_wsum", L.cvc_attn_wsum_quad, (sets, 2, B, 1, R, ptr(XL_r))))
-            out.append(("lang_lstm", L.cvc_packed_lstm_fwd, (ptr(W.p_lang), ptr(XL_r), 3 * R, ptr(W.b_ih_lang), ptr(W.b_hh_lang),
-                                                             None, ptr(self.cL[rd]), rows, R, ptr(XA_w), qoff(XL_w, 2 * R),
-                                                             ptr(self.cL[wr]))))
+            if self.lang_ksx:
+                out.append(self._lang_ksx_launch(t, XL_r, XA_w, XL_w, rd, wr))
+            else:
+                out.append(("lang_lstm", L.cvc_packed_lstm_fwd, (ptr(W.p_lang), ptr(XL_r), 3 * R, ptr(W.b_ih_lang), ptr(W.b_hh_lang),
+                                                                 None, ptr(self.cL[rd]), rows, R, ptr(XA_w), qoff(XL_w, 2 * R),
+                                                                 ptr(self.cL[wr]))))
             # (cvc_packed_linear_select_fwd, the one-launch form whose last workgroup merges the records, measured 34.9 us against
             # 20.0 + 7.4 us for these two launches: atomics, fence and a serial merge on one CU cost more than a launch boundary)
             out.append(("logits", L.cvc_packed_linear_fwd, (ptr(W.p_o), ptr(XA_w), R, ptr(W.b_o), rows, V, 1, None, V,
@@ -884,8 +919,35 @@ class DecodeEngine:
                                                     self.B, self.beam, self.T, self.N, self.bt_seq.data_ptr(),
                                                     self.bt_att.data_ptr(), hip._stream()), "cvc_beam_backtrack")
 
+    def check_ksx(self):
+        """(host sync, once per engine) After the first decode with lang_ksx: if a K slice's wait for its tile ran out -- the
+        tile's workgroups were not resident together or not on one XCD -- the exchange's error word is set and that decode is
+        not valid: re-bind on the full-K kernel and say so.  Returns True when the engine was re-bound."""
+        if not self.lang_ksx or self._ksx_checked:
+            return False
+        self._ksx_checked = True
+        torch.cuda.synchronize()
+        if int(self.ksx_flags[-1]) == 0:
+            return False
+        hip.warn_once("lang-ksx", "decode: the K-split language cell's in-launch exchange reported a failed wait (workgroup placement); "
+                      "falling back to the full-K gate GEMM")
+        self.lang_ksx = False
+        self._launches = self._build_packed()
+        if self._plan is not None:
+            hip.lib().cvc_decode_plan_destroy(self._plan)
+            self._plan = None
+            self._bind_driver()
+        return True
+
     def capture(self):
         """Capture the T-step loop into a HIP graph (launch-bound inner loop -> one replay)."""
+        if self.lang_ksx and not self._ksx_checked:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._run_once()
+            torch.cuda.current_stream().wait_stream(s)
+            self.check_ksx()
         key = (self.packed, self.tile, self.beam > 1)
         if key not in DecodeEngine._warm:                 # first capture of this path in the process: run once outside capture
             s = torch.cuda.Stream()                       # (module load, lazy init); later engines skip the extra decode
@@ -907,6 +969,8 @@ class DecodeEngine:
             self.graph.replay()
         else:
             self._run_once()
+            if self.lang_ksx and not self._ksx_checked and self.check_ksx():
+                self._run_once()                           # the fallback's results
         if self.beam == 1:
             return self.words[1:].t(), self.att_steps.permute(1, 0, 2)
         return self._backtrack()

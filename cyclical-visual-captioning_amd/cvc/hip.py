@@ -77,7 +77,7 @@ class DecodeDesc(C.Structure):
         [(n, C.c_void_p) for n in ("h_att", "c_att", "h_lang", "c_lang", "c_att_prev", "c_lang_prev", "zero_state")] +
         [("beam_ws", C.c_void_p)] +
         [("gsk_nwg", C.c_int)] + [(n, C.c_void_p) for n in ("slab_att", "slab_lang", "slab_q", "slab_o", "emb_gate", "sel_counter")] +
-        [("att_w_cached", C.c_int)])
+        [("att_w_cached", C.c_int), ("lang_ksx", C.c_int), ("ksx_slab", C.c_void_p), ("ksx_flags", C.c_void_p)])
 
 # name -> argtypes, exactly the declarations of include/cvc_hip.h (tests/test_cabi.py checks both)
 SIGNATURES = {

@@ -645,6 +645,12 @@ typedef struct cvc_decode_desc {
     const float* emb_gate;
     unsigned* sel_counter;
     int att_w_cached;                     /* embedding-gate schedule: 1 = w_att is read with the default cache policy (cvc_packed_lstm_embgate_cached_fwd) */
+    /* packed path: lang_ksx = 1 runs the language cell on the K-split gate GEMM with the exchange finish (cvc_packed_lstm_ksx_fwd;
+     * R = 2048 shapes, T > 1): ksx_slab >= 8 * (R / 8) * 2048 floats, ksx_flags R / 8 + 1 words, zero before the first decode
+     * (the last word is the error word the caller checks after its first decode). */
+    int lang_ksx;
+    float* ksx_slab;
+    unsigned* ksx_flags;
 } cvc_decode_desc;
 typedef struct cvc_decode_plan cvc_decode_plan;
 int cvc_decode_plan_create(const cvc_decode_desc* desc, cvc_decode_plan** plan);   /* validates, copies the descriptor       */

@@ -409,3 +409,33 @@ def test_tile_path_embedding_gate_form_equals_full_k_form(dev, lib, B, beam, dim
     e.capture()
     for _ in range(2):
         assert all(torch.equal(x, y) for x, y in zip(a, e.run()))
+
+
+def test_language_cell_on_the_exchange_finish_kernel_equals_default_schedule(dev, lib):
+    """DecodeEngine(lang_ksx=True) at R = 2048 (the K-split gate GEMM with the in-launch exchange for the language cell) against
+    the default schedule: same words up to near-ties, attention and log-probs within the recurrent tolerance (another K summation
+    order); C driver == Python launch list bit for bit; eager == HIP-graph replay; the exchange's error word stays clear."""
+    from helpers import to_dev
+    from cvc.decode import DecodeEngine, DecodeWeights
+    B = 64
+    d = dataclasses.replace(synth.CONFIGS["tiny"], B=B, N=10, F=6, R=2048, A=64, E=64, V=200, T=3)
+    sd, f_np = synth.hot_path_state_dict(d, 5), synth.clip_features(d, 5)
+    W, f = DecodeWeights(to_dev(sd, dev)), to_dev(f_np, dev)
+    e_ref = DecodeEngine(W, f, d.T, synth.UNK_IDX, lang_ksx=False)
+    e = DecodeEngine(W, f, d.T, synth.UNK_IDX, lang_ksx=True)
+    e_py = DecodeEngine(W, f, d.T, synth.UNK_IDX, lang_ksx=True, driver=False)
+    assert e.lang_ksx and e_py.lang_ksx and not e_ref.lang_ksx and e._plan is not None and e_py._plan is None
+    ref = [x.clone() for x in e_ref.run()]
+    a = [x.clone() for x in e.run()]
+    b = [x.clone() for x in e_py.run()]
+    assert e.lang_ksx and e_py.lang_ksx, "the exchange reported a failed wait and the engine fell back"
+    assert int(e.ksx_flags[-1]) == 0 and int(e_py.ksx_flags[-1]) == 0
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    same = (a[0] == ref[0]).all(1)
+    assert int(same.sum()) >= B - 2
+    close(a[1][same], ref[1][same], **SEQ_TOL)
+    close(e.logprob[:, same], e_ref.logprob[:, same], **SEQ_TOL)
+    e.capture()
+    for _ in range(2):
+        assert all(torch.equal(x, y) for x, y in zip(a, e.run()))
+    assert int(e.ksx_flags[-1]) == 0

@@ -463,11 +463,11 @@ def test_packed_lstm_ksplit_equals_full_k_kernel(dev, lib, M, R, E):
     close(hk, h_ref.float(), rtol=2e-5, atol=2e-5); close(ck, c_ref.float(), rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("M,eg,mode", [(64, False, 1), (64, True, 1), (37, True, 1), (64, True, 0)])
+@pytest.mark.parametrize("M,eg,mode", [(64, False, 3), (64, True, 1), (37, True, 2), (64, True, 0), (1, False, 3)])
 def test_packed_lstm_exchange_finish_equals_full_k_kernel(dev, lib, M, eg, mode):
     """cvc_packed_lstm_ksx_fwd (K split over 8 workgroups per 256-row tile, every slice finishing one of the tile's blocks after
-    the in-launch exchange of the partial tiles) at R = 2048, with and without the embedding-gate term, XCD-local (mode 1) and
-    system-scope (mode 0) exchange: against the full-K kernel (fp32 noise: another K summation order) and fp64, the same bits
+    the in-launch exchange of the partial tiles) at R = 2048, with and without the embedding-gate term, XCD-local (modes 1-3: the
+    slab rows read back with ordinary / non-temporal / sc1 loads) and system-scope (mode 0) exchange: against the full-K kernel (fp32 noise: another K summation order) and fp64, the same bits
     launch after launch, and the error word stays clear."""
     from cvc.decode import pack_weights, to_quad, from_quad
     R, V = 2048, 97

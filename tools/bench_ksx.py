@@ -2,7 +2,7 @@
 last-arriver finish, K-split with the exchange finish (cvc_packed_lstm_ksx_fwd).  Time per call (weights flushed out of the
 Infinity Cache between calls, as in the decode step), result against the full-K kernel, error word, run-to-run bits."""
 import sys, torch
-sys.path.insert(0, "cyclical-visual-captioning_amd")
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))), "cyclical-visual-captioning_amd"))
 from cvc import hip
 from cvc.decode import pack_weights, to_quad, from_quad
 dev = torch.device("cuda:0")

@@ -1,6 +1,6 @@
 """Gate GEMM (cvc_packed_lstm_fwd) time against the number of batch rows: how much of the launch is activation ingress."""
 import sys, torch
-sys.path.insert(0, "cyclical-visual-captioning_amd")
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))), "cyclical-visual-captioning_amd"))
 from cvc import hip
 from cvc.decode import pack_weights, to_quad
 dev = torch.device("cuda:0")

@@ -5,7 +5,7 @@ import ctypes as C
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, "cyclical-visual-captioning_amd")
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))), "cyclical-visual-captioning_amd"))
 from cvc import synth, hip
 from cvc.decode import DecodeEngine, DecodeWeights
 
