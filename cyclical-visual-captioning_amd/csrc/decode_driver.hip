@@ -107,18 +107,27 @@ int run_packed_eg(cvc_decode_plan* p, hipStream_t st) {
     CVC_TRY(reset(d.words, nullptr, (size_t)rows * sizeof(int64_t), st));
     cvc_gemm_seg seg{d.fc, nullptr, d.w_fc, R, R, d.ld_w_fc, 0};
     CVC_TRY(cvc_linear_fwd(&seg, 1, d.b_ih_att, d.b_hh_att, rows, 4 * R, d.gate_fc, 4 * R, st));
+    const long long ws_att = (long long)(2 * R / 4) * 128, ws_lang = (long long)(3 * R / 4) * 128;     // block strides of the packs
+    const bool split2 = cvc_gemm_packed_split(-1) == 2;
     for (int t = 0; t < d.T; ++t) {
         const int rd = t & 1, wr = (t + 1) & 1;
         float *XA_r = d.xa[rd], *XA_w = d.xa[wr], *XL_r = d.xl[rd], *XL_w = d.xl[wr];
-        CVC_TRY((d.att_w_cached ? cvc_packed_lstm_embgate_cached_fwd : cvc_packed_lstm_embgate_fwd)((const float*)d.w_att, XA_r, 2 * R, nullptr, nullptr, d.gate_fc, d.emb_gate,
-                                            d.words + (size_t)t * rows, d.ca[rd], rows, R, quad_off(XL_r, R), quad_off(XA_w, R),
-                                            d.ca[wr], st));
+        // step 0 multiplies the all-zero initial state (h_lang = h_att = 0): an exact zero times a finite weight adds nothing, so the
+        // attention cell contracts over one chunk only (its gates are the table row + the hoisted fc term) and the language cell
+        // below stops before its h_lang columns
+        const bool first = t == 0 && split2;
+        CVC_TRY(cvc_packed_lstm_embgate_ex_fwd((const float*)d.w_att, ws_att, XA_r, first ? 32 : 2 * R, nullptr, nullptr, d.gate_fc,
+                                               d.emb_gate, d.words + (size_t)t * rows, d.ca[rd], rows, R, quad_off(XL_r, R),
+                                               quad_off(XA_w, R), d.ca[wr], d.att_w_cached, st));
         CVC_TRY(cvc_packed_linear_fwd((const float*)d.w_h, quad_off(XL_r, R), R, nullptr, rows, A, d.qsplit, d.q_parts, A, nullptr, st));
         cvc_attn_set sets[2];
         attn_sets(d, t, rows, sets);
         CVC_TRY(cvc_attn_scores_qparts(d.attn_kind, d.q_parts, d.qsplit, d.b_h, d.w_a, d.b_a, d.inv_temp, sets, 2, d.B, 1, A, st));
         CVC_TRY(cvc_attn_wsum_quad(sets, 2, d.B, 1, R, XL_r, st));
-        if (d.lang_ksx)      // K-split gate GEMM, every K slice of a tile finishing one of its blocks after the in-launch exchange
+        if (first)           // (h_lang(-1) = 0 sits in the last third of XL: K = 2R of the 3R packed columns)
+            CVC_TRY(cvc_packed_lstm_late_fwd((const float*)d.w_lang, ws_lang, XL_r, 2 * R, d.b_ih_lang, d.b_hh_lang, nullptr, d.cl[rd], rows,
+                                             R, XA_w, quad_off(XL_w, 2 * R), d.cl[wr], nullptr, st));
+        else if (d.lang_ksx) // K-split gate GEMM, every K slice of a tile finishing one of its blocks after the in-launch exchange
             CVC_TRY(cvc_packed_lstm_ksx_fwd((const float*)d.w_lang, XL_r, 3 * R, d.b_ih_lang, d.b_hh_lang, nullptr, nullptr, nullptr, d.cl[rd],
                                             rows, R, XA_w, quad_off(XL_w, 2 * R), d.cl[wr], d.ksx_slab, d.ksx_flags, (unsigned)(t + 1), st));
         else

@@ -629,7 +629,7 @@ static int launch_packed(const PackedArgs& a_in, int blocks, hipStream_t st) {
         }
     }
     if constexpr (LSTM) {
-        // (gate weights with the default cache policy: cvc_packed_lstm_embgate_cached_fwd)
+        // (gate weights with the default cache policy: cvc_packed_lstm_embgate_ex_fwd's w_cached)
         // (measured alternatives at cfg2: the language cell's 201 MB instead -- its launch 54.2 -> 48.8 us, the attention cell's back
         // to 40.5: 323-325 k against 326 k; both matrices: over the cache's size, slower than none)
         if (cvc_gemm_split_mode == 2 && a.w_cached && a.M > 32) {
@@ -673,18 +673,22 @@ extern "C" int cvc_packed_lstm_embgate_fwd(const float* wp, const float* xq, int
     return launch_packed<true>(a, R / 8, (hipStream_t)stream);
 }
 
-// ... with the gate weights read under the default cache policy instead of streamed non-temporally: for a gate matrix that the
-// caller's cache plan keeps in the 256 MiB Infinity Cache between steps (cvc.decode.cache_plan: at config 2 the attention cell's
-// 134 MB; its launch 40.3 -> 35.4 us, the decode +1.8 %).  64-row split-product form only; other shapes run the streaming kernel.
-extern "C" int cvc_packed_lstm_embgate_cached_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
-                                                  const float* gate_bias, const float* emb_gate, const int64_t* word,
-                                                  const float* c_prev_q, int M, int R, float* h_dst1_q, float* h_dst2_q,
-                                                  float* c_out_q, cvc_stream_t stream) {
-    if (!wp || !xq || !c_prev_q || !c_out_q || !emb_gate || !word || (K & 31) || R < 8 || (R & 7)) return CVC_E_BADARG;
+// ... the general form.  w_cached: the gate weights are read under the default cache policy instead of streamed non-temporally --
+// for a gate matrix that the caller's cache plan keeps in the 256 MiB Infinity Cache between steps (cvc.decode.cache_plan: at
+// config 2 the attention cell's 134 MB; its launch 40.3 -> 35.4 us, the decode +1.8 %; 64-row split-product form, other shapes
+// run the streaming kernel).  w_blk_stride / K: the contraction may stop short of the packed matrix's K (K a multiple of 32,
+// w_blk_stride = floats between its 32-row blocks, 0 = dense K / 4 * 128) -- the first decode step multiplies an all-zero
+// recurrent state, and an exact zero times a finite weight adds nothing: the driver passes K = 32 there.
+extern "C" int cvc_packed_lstm_embgate_ex_fwd(const float* wp, long long w_blk_stride, const float* xq, int K, const float* b_ih,
+                                              const float* b_hh, const float* gate_bias, const float* emb_gate, const int64_t* word,
+                                              const float* c_prev_q, int M, int R, float* h_dst1_q, float* h_dst2_q,
+                                              float* c_out_q, int w_cached, cvc_stream_t stream) {
+    if (!wp || !xq || !c_prev_q || !c_out_q || !emb_gate || !word || (K & 31) || K < 32 || R < 8 || (R & 7)) return CVC_E_BADARG;
+    if (w_blk_stride != 0 && (w_blk_stride < (long long)(K / 4) * 128 || (w_blk_stride & 3))) return CVC_E_BADARG;
     PackedArgs a{};
-    a.wp = wp; a.xq = xq; a.nquad = K / 4; a.M = M; a.Nout = 4 * R; a.R = R;
+    a.wp = wp; a.xq = xq; a.nquad = K / 4; a.M = M; a.Nout = 4 * R; a.R = R; a.wstride = w_blk_stride;
     a.bias = b_ih; a.bias2 = b_hh; a.gate_bias = gate_bias; a.c_prev_q = c_prev_q; a.c_out_q = c_out_q;
-    a.h_dst1_q = h_dst1_q; a.h_dst2_q = h_dst2_q; a.ksplit = 1; a.emb_gate = emb_gate; a.word = word; a.w_cached = 1;
+    a.h_dst1_q = h_dst1_q; a.h_dst2_q = h_dst2_q; a.ksplit = 1; a.emb_gate = emb_gate; a.word = word; a.w_cached = w_cached ? 1 : 0;
     return launch_packed<true>(a, R / 8, (hipStream_t)stream);
 }
 

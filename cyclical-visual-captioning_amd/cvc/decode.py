@@ -534,9 +534,13 @@ class DecodeEngine:
         for t in range(self.T):
             rd, wr = t & 1, (t + 1) & 1
             XA_r, XA_w, XL_r, XL_w = self.XA[rd], self.XA[wr], self.XL[rd], self.XL[wr]
-            out.append(("att_lstm", L.cvc_packed_lstm_embgate_cached_fwd if self.att_w_cached else L.cvc_packed_lstm_embgate_fwd, (ptr(W.p_att2), ptr(XA_r), 2 * R, None, None, ptr(self.gate_fc),
-                                                                    ptr(W.t_embgate), ptr(self.words[t]), ptr(self.cA[rd]), rows, R,
-                                                                    qoff(XL_r, R), qoff(XA_w, R), ptr(self.cA[wr]))))
+            # step 0 multiplies the all-zero initial state: one chunk of the attention cell's K, the language cell without its
+            # h_lang columns (see run_packed_eg)
+            first = t == 0 and hip.gemm_packed_split(-1) == 2
+            out.append(("att_lstm", L.cvc_packed_lstm_embgate_ex_fwd, (ptr(W.p_att2), (2 * R // 4) * 128, ptr(XA_r), 32 if first else 2 * R, None, None,
+                                                                       ptr(self.gate_fc), ptr(W.t_embgate), ptr(self.words[t]), ptr(self.cA[rd]),
+                                                                       rows, R, qoff(XL_r, R), qoff(XA_w, R), ptr(self.cA[wr]),
+                                                                       1 if self.att_w_cached else 0)))
             out.append(("h2attn", L.cvc_packed_linear_fwd, (ptr(W.p_h), qoff(XL_r, R), R, None, rows, A, self.QSPLIT,
                                                             ptr(self.q_parts), A, None)))
             sets = (hip.AttnSet * 2)()
@@ -547,7 +551,11 @@ class DecodeEngine:
             out.append(("attn_scores", L.cvc_attn_scores_qparts, (W.kind, ptr(self.q_parts), self.QSPLIT, ptr(W.b_h), ptr(W.w_a),
                                                                   ptr(W.b_a), self.inv_temp, sets, 2, B, 1, A)))
             out.append(("attn_wsum", L.cvc_attn_wsum_quad, (sets, 2, B, 1, R, ptr(XL_r))))
-            if self.lang_ksx:
+            if first:
+                out.append(("lang_lstm", L.cvc_packed_lstm_late_fwd, (ptr(W.p_lang), (3 * R // 4) * 128, ptr(XL_r), 2 * R, ptr(W.b_ih_lang),
+                                                                      ptr(W.b_hh_lang), None, ptr(self.cL[rd]), rows, R, ptr(XA_w),
+                                                                      qoff(XL_w, 2 * R), ptr(self.cL[wr]), None)))
+            elif self.lang_ksx:
                 out.append(self._lang_ksx_launch(t, XL_r, XA_w, XL_w, rd, wr))
             else:
                 out.append(("lang_lstm", L.cvc_packed_lstm_fwd, (ptr(W.p_lang), ptr(XL_r), 3 * R, ptr(W.b_ih_lang), ptr(W.b_hh_lang),

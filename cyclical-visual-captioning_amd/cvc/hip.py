@@ -92,7 +92,7 @@ SIGNATURES = {
     "cvc_packed_linear_fwd": [_P, _P, _I, _P, _I, _I, _I, _P, _I, _P, _P],
     "cvc_packed_lstm_wg_blocks": [_I],
     "cvc_packed_lstm_embgate_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
-    "cvc_packed_lstm_embgate_cached_fwd": [_P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "cvc_packed_lstm_embgate_ex_fwd": [_P, _LL, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _I, _P],
     "cvc_packed_linear_select_fwd": [_P, _P, _I, _P, _I, _I, _P, _P, _I, _P, _I, _P, _P],
     "cvc_gsk_plan": [C.POINTER(_I), C.POINTER(_I), _I, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)],
     "cvc_gsk_gemm": [C.POINTER(GskGroup), _I, _I, _P],

@@ -160,12 +160,15 @@ int cvc_packed_linear_fwd(const float* wp, const float* xq, int K, const float* 
 int cvc_packed_lstm_embgate_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
                                 const float* gate_bias, const float* emb_gate, const int64_t* word, const float* c_prev_q,
                                 int M, int R, float* h_dst1_q, float* h_dst2_q, float* c_out_q, cvc_stream_t stream);
-/* ... reading the gate weights under the default cache policy (a gate matrix the caller's cache plan keeps in the Infinity Cache
- * between steps) instead of streaming them non-temporally; same operands, same results */
-int cvc_packed_lstm_embgate_cached_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
-                                       const float* gate_bias, const float* emb_gate, const int64_t* word,
-                                       const float* c_prev_q, int M, int R, float* h_dst1_q, float* h_dst2_q,
-                                       float* c_out_q, cvc_stream_t stream);
+/* ... the general form.  w_cached != 0: the gate weights are read under the default cache policy (a gate matrix the caller's cache
+ * plan keeps in the Infinity Cache between steps) instead of streamed non-temporally.  w_blk_stride / K: the contraction may stop
+ * short of the packed matrix's K (K a multiple of 32; w_blk_stride = floats between its 32-row blocks, 0 = dense): the first
+ * decode step multiplies an all-zero recurrent state, which adds nothing -- the decode driver passes K = 32 there.
+ * Same results as cvc_packed_lstm_embgate_fwd over the same K. */
+int cvc_packed_lstm_embgate_ex_fwd(const float* wp, long long w_blk_stride, const float* xq, int K, const float* b_ih,
+                                   const float* b_hh, const float* gate_bias, const float* emb_gate, const int64_t* word,
+                                   const float* c_prev_q, int M, int R, float* h_dst1_q, float* h_dst2_q,
+                                   float* c_out_q, int w_cached, cvc_stream_t stream);
 /* Vocabulary projection + word selection in ONE launch (captioner.py:437 + :415-422): cvc_packed_linear_fwd's top-2 records
  * (top2_part [ceil(Nout/32)][64][6], stored write-through) are merged by the last workgroup to arrive -- counter: one word of
  * device memory, zero before the first use, left zero -- which writes word[m * word_stride] (UNK rule, ties -> lowest index) and
@@ -644,7 +647,7 @@ typedef struct cvc_decode_desc {
      * default path: measured slower than two launches).                                                                       */
     const float* emb_gate;
     unsigned* sel_counter;
-    int att_w_cached;                     /* embedding-gate schedule: 1 = w_att is read with the default cache policy (cvc_packed_lstm_embgate_cached_fwd) */
+    int att_w_cached;                     /* embedding-gate schedule: 1 = w_att is read with the default cache policy (cvc_packed_lstm_embgate_ex_fwd) */
     /* packed path: lang_ksx = 1 runs the language cell on the K-split gate GEMM with the exchange finish (cvc_packed_lstm_ksx_fwd;
      * R = 2048 shapes, T > 1): ksx_slab >= 8 * (R / 8) * 2048 floats, ksx_flags R / 8 + 1 words, zero before the first decode
      * (the last word is the error word the caller checks after its first decode). */
