@@ -1,0 +1,9 @@
+#!/bin/bash
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+mkdir -p gpurun_out/r03c
+export CVC_EXTRA_HIPCC_FLAGS="-DCVC_PACKED_DEPTH=3"
+python cyclical-visual-captioning_amd/build_hip.py --force > /dev/null 2>&1
+python tools/runs/r03_concurrency_probe.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r03c/conc.log
+export CVC_EXTRA_HIPCC_FLAGS=""
+python cyclical-visual-captioning_amd/build_hip.py --force > /dev/null 2>&1
+cat gpurun_out/r03c/conc.log
