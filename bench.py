@@ -576,6 +576,7 @@ def run_decode(args, d, dev, rank, world, dist_on, beam, steps, warmup, min_warm
     # ---- per-kernel durations with HIP events on the launch stream (eager pass, same buffers)
     kernels, roof = [], None
     work = algorithmic_work(d, beam)
+    split_mode_now = gemm_mode
     if getattr(eng, "embgate", False):
         # embedding-gate schedule: the att-LSTM streams only the recurrent K range (2R) and gathers one 4R-row of the per-checkpoint
         # table per clip
@@ -583,6 +584,17 @@ def run_decode(args, d, dev, rank, world, dist_on, beam, steps, warmup, min_warm
         work["att_lstm"] = dict(bound="hbm", bytes=4 * (4 * R_ * 2 * R_) + 4 * rows_ * (2 * R_ + 3 * R_ + 4 * R_ + 4 * R_),
                                 flops=2 * rows_ * 4 * R_ * 2 * R_)
         work["word_select"] = dict(bound="hbm", bytes=4 * rows_ * 6 * ((d.V + 31) // 32))
+        if split_mode_now == 2 and d.T > 1:
+            # step 0 multiplies the all-zero initial state and contracts over less K (one chunk for the attention cell, 2R of 3R for
+            # the language cell): the per-launch figures are the averages over the decode's T launches, as the durations are
+            T_ = d.T
+            wa, wl = work["att_lstm"], work["lang_lstm"]
+            a0 = 4 * (4 * R_ * 32) + 4 * rows_ * (32 + 3 * R_ + 4 * R_ + 4 * R_)
+            l0 = 4 * (4 * R_ * 2 * R_ + 8 * R_) + 4 * rows_ * (2 * R_ + 3 * R_)
+            work["att_lstm"] = dict(bound="hbm", bytes=((T_ - 1) * wa["bytes"] + a0) // T_,
+                                    flops=((T_ - 1) * wa["flops"] + 2 * rows_ * 4 * R_ * 32) // T_)
+            work["lang_lstm"] = dict(bound="hbm", bytes=((T_ - 1) * wl["bytes"] + l0) // T_,
+                                     flops=((T_ - 1) * wl["flops"] + 2 * rows_ * 4 * R_ * 2 * R_) // T_)
     if getattr(eng, "gsk", False):
         work["word_select"] = dict(bound="hbm", bytes=int(4 * 256 * 64 * ((d.V + 255) // 256) * (d.R / 32 / 21.0 + 1)) + 4 * d.B * d.E)
     split_mode = gemm_mode
