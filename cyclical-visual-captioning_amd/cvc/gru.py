@@ -94,33 +94,47 @@ def gru_forward(gru: nn.GRU, x: torch.Tensor) -> torch.Tensor:
     layers = _layer_operands(gru)
     out = torch.empty(B, F, ndir * H, device=x.device, dtype=torch.float32)
     L, st = hip.lib(), hip._stream()
-    for b0 in range(0, B, 64):
-        m = min(64, B - b0)
-        cur = x[b0:b0 + m].transpose(0, 1).contiguous().view(F * m, -1)            # time-major rows (t, clip)
-        hq = torch.empty(2 * ndir * ((H + 31) // 32 * 32) * 64, device=x.device, dtype=torch.float32)
-        for l, (w_ih, wp, b_ih, b_hh) in enumerate(layers):
-            gi = hip.tile_mm(cur, w_ih)                                              # [F*m, ndir*3H], no bias
-            last = l == len(layers) - 1
-            if last:
-                y, ld_m, ld_t = out[b0:b0 + m], F * ndir * H, ndir * H
-            else:
-                y = torch.empty(F * m, ndir * H, device=x.device, dtype=torch.float32)
-                ld_m, ld_t = ndir * H, m * ndir * H
-            args = (wp.data_ptr(), gi.data_ptr(), ndir * 3 * H, m * ndir * 3 * H, b_ih.data_ptr(), b_hh.data_ptr(), m, F, H, ndir,
-                    hq.data_ptr(), y.data_ptr(), ld_m, ld_t)
-            done = False
-            # (the persistent form reports a barrier time-out through a word the host reads back: not while a graph is captured)
-            if PERSISTENT and H % 128 == 0 and H <= 1024 and not torch.cuda.is_current_stream_capturing():
-                sync = torch.zeros(int(L.cvc_gru_persistent_sync_words()), device=x.device, dtype=torch.int32)
-                slots = torch.empty((F + 1) * ndir * H * 64, device=x.device, dtype=torch.float32)     # one state slot per step
-                pargs = args[:10] + (slots.data_ptr(),) + args[11:]
-                if L.cvc_gru_seq_persistent_fwd(*pargs, sync.data_ptr(), st) == 0:
-                    done = int(sync[4]) == 0          # (host sync) a barrier time-out leaves the error word set: redo per step
-            if not done:
-                hip._check(L.cvc_gru_seq_fwd(*args, st), "cvc_gru_seq_fwd")
-            global last_form
-            last_form = "persistent" if done else "steps"
-            cur = y
+    global last_form
+    try_persistent = PERSISTENT and H % 128 == 0 and H <= 1024 and not torch.cuda.is_current_stream_capturing()
+
+    def run(persistent: bool):
+        """All chunks and layers in one go; returns the persistent launches' error words (device tensors, not read here)."""
+        words = []
+        for b0 in range(0, B, 64):
+            m = min(64, B - b0)
+            cur = x[b0:b0 + m].transpose(0, 1).contiguous().view(F * m, -1)            # time-major rows (t, clip)
+            hq = torch.empty(2 * ndir * ((H + 31) // 32 * 32) * 64, device=x.device, dtype=torch.float32)
+            for l, (w_ih, wp, b_ih, b_hh) in enumerate(layers):
+                gi = hip.tile_mm(cur, w_ih)                                              # [F*m, ndir*3H], no bias
+                last = l == len(layers) - 1
+                if last:
+                    y, ld_m, ld_t = out[b0:b0 + m], F * ndir * H, ndir * H
+                else:
+                    y = torch.empty(F * m, ndir * H, device=x.device, dtype=torch.float32)
+                    ld_m, ld_t = ndir * H, m * ndir * H
+                args = (wp.data_ptr(), gi.data_ptr(), ndir * 3 * H, m * ndir * 3 * H, b_ih.data_ptr(), b_hh.data_ptr(), m, F, H, ndir,
+                        hq.data_ptr(), y.data_ptr(), ld_m, ld_t)
+                if persistent:
+                    sync = torch.zeros(int(L.cvc_gru_persistent_sync_words()), device=x.device, dtype=torch.int32)
+                    slots = torch.empty((F + 1) * ndir * H * 64, device=x.device, dtype=torch.float32)     # one state slot per step
+                    pargs = args[:10] + (slots.data_ptr(),) + args[11:]
+                    if L.cvc_gru_seq_persistent_fwd(*pargs, sync.data_ptr(), st) != 0:
+                        return None                                                    # launch refused (shape / residency): per-step form
+                    words.append(sync[4:5])
+                else:
+                    hip._check(L.cvc_gru_seq_fwd(*args, st), "cvc_gru_seq_fwd")
+                cur = y
+        return words
+
+    if try_persistent:
+        # every layer (and 64-clip chunk) is enqueued before the error words are looked at: ONE host read per call instead of one
+        # per layer; a barrier time-out anywhere leaves its word set and the whole call is redone in the per-step form
+        words = run(True)
+        if words is not None and int(torch.cat(words).abs().sum()) == 0:
+            last_form = "persistent"
+            return out
+    run(False)
+    last_form = "steps"
     return out
 
 
