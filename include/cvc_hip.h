@@ -695,7 +695,10 @@ int cvc_adam_clip_step(const cvc_optim_seg* segs, int nseg, const cvc_optim_chun
  * that is a SUM all-reduce of the gradients over RCCL / xGMI followed by 1/G, which the caller folds into its clip multiply
  * (cvc.distributed.GradReducer.clip_).  cvc_comm_unique_id (rank 0) -> share the 128 bytes with every rank by any means ->
  * cvc_comm_init on every rank -> cvc_allreduce_grads(comm, flat gradient arena, floats, stream) per bucket, in place, stream
- * ordered, no host synchronisation.  Return codes: 0, CVC_E_*, or 1000 + ncclResult_t.  librccl is dlopen'ed on first use.
+ * ordered, no host synchronisation.  The exchange is the one cvc.distributed.GradReducer issues through torch.distributed: an
+ * in-place ncclReduceScatter (every rank sums ITS 1 / G of the arena) + an in-place ncclAllGather, back to back (count divisible
+ * by the world size; otherwise one ncclAllReduce).  Return codes: 0, CVC_E_*, or 1000 + ncclResult_t.  librccl is dlopen'ed on
+ * first use.
  */
 int cvc_comm_unique_id(void* out128);
 int cvc_comm_init(int world, int rank, const void* id128, void** comm);
