@@ -580,11 +580,11 @@ def run_decode(args, d, dev, rank, world, dist_on, beam, steps, warmup, min_warm
     if getattr(eng, "embgate", False):
         # embedding-gate schedule: the att-LSTM streams only the recurrent K range (2R) and gathers one 4R-row of the per-checkpoint
         # table per clip
-        R_, rows_ = d.R, d.B
+        R_, rows_ = d.R, d.B * beam          # every live hypothesis row is multiplied (beam > 1: the tile path's finishing launch adds the table row)
         work["att_lstm"] = dict(bound="hbm", bytes=4 * (4 * R_ * 2 * R_) + 4 * rows_ * (2 * R_ + 3 * R_ + 4 * R_ + 4 * R_),
                                 flops=2 * rows_ * 4 * R_ * 2 * R_)
         work["word_select"] = dict(bound="hbm", bytes=4 * rows_ * 6 * ((d.V + 31) // 32))
-        if split_mode_now == 2 and d.T > 1:
+        if eng.packed and split_mode_now == 2 and d.T > 1:
             # step 0 multiplies the all-zero initial state and contracts over less K (one chunk for the attention cell, 2R of 3R for
             # the language cell): the per-launch figures are the averages over the decode's T launches, as the durations are
             T_ = d.T

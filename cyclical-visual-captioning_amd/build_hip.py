@@ -37,8 +37,20 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
+STAMP = os.path.join(OUT_DIR, "libcvc_hip.flags")     # the extra hipcc flags the in-tree .so was built with
+
+
+def extra_flags() -> str:
+    return " ".join(os.environ.get("CVC_EXTRA_HIPCC_FLAGS", "").split())
+
+
 def up_to_date() -> bool:
+    """sources older than the .so AND the .so built with the flags asked for now: an ablation build (CVC_EXTRA_HIPCC_FLAGS=-D...)
+    left behind by an interrupted experiment script is never taken for the product library"""
     if not os.path.exists(OUT):
+        return False
+    built_with = open(STAMP).read().strip() if os.path.exists(STAMP) else ""
+    if built_with != extra_flags():
         return False
     t = os.path.getmtime(OUT)
     return all(os.path.getmtime(f) <= t for f in deps())
@@ -67,6 +79,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(extra_flags() + "\n")
     return OUT
 
 

@@ -73,7 +73,8 @@ __global__ __launch_bounds__(OPT_WG) void optim_finalize_kernel(const OptSeg* se
     if (threadIdx.x == 0) {
         const float total = sqrtf(t) * inv;
         out[0] = total;
-        out[1] = max_norm > 0.f ? fminf(max_norm / (total + 1e-6f), 1.0f) * inv : inv;
+        // a NaN norm poisons every gradient, as torch's clip_grad_norm_ does (clamp(NaN, max=1) = NaN; fminf would return 1)
+        out[1] = max_norm > 0.f ? (total != total ? total : fminf(max_norm / (total + 1e-6f), 1.0f) * inv) : inv;
     }
     for (int s = threadIdx.x; s < nseg; s += OPT_WG) segs[s].step[0] += 1.0f;
 }

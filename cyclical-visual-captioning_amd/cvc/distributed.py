@@ -164,6 +164,10 @@ class GradReducer:
         self._launched = [False] * len(groups)
         self._expected: Optional[List[int]] = None           # gradient arrivals per bucket, learned on the first step
         self._seen_first: List[set] = [set() for _ in groups]
+        self._seen_late: List[set] = [set() for _ in groups]   # first step: weights whose gradient arrived through the deferred-dW flush
+        self._live: Optional[List[frozenset]] = None          # per bucket: ids whose hook must fire before the bucket may leave
+        self._arrived: List[set] = [set() for _ in groups]
+        self._names: Dict[int, str] = {id(p): n for b in groups for n, p in b}
         self._work: List = []
         self.exchange = self.world > 1 or (always_exchange and dist.is_initialized())
         self.overlap = overlap and self.exchange
@@ -190,13 +194,31 @@ class GradReducer:
                     p.grad = v
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._arrived = [set() for _ in self.buckets]
+
+    def _revive(self, p):
+        """A parameter that was marked dead (no gradient on the first step) receives one after all: its arena slot would never
+        have been exchanged or cleared -- refuse loudly instead of training on a gradient the other ranks do not see."""
+        raise RuntimeError(f"GradReducer: parameter {self._names.get(id(p), '?')} received no gradient on the first step (and was "
+                           "dropped from the exchange, as the reference's optimizers skip None gradients) but receives one now: "
+                           "the set of trained parameters must not change between steps")
 
     def _on_late_grad(self, w):
         """cvc.functional's deferred-dW flush wrote into w.grad at the end of backward (a use of the weight got no gradient): no
         hook fired for it.  Harmless unless the bucket's exchange was already launched -- then the late add races with / is
         missing from the collective, and finalize() refuses to continue."""
         i = self._bucket_of.get(id(w))
-        if i is not None and self.exchange and self._launched[i]:
+        if i is None:
+            return
+        if id(w) in self._dead:
+            self._revive(w)
+        v = self._views[id(w)]
+        if w.grad is not None and w.grad.data_ptr() != v.data_ptr():   # the flush installed its own tensor (w.grad was None): into the arena
+            v.copy_(w.grad)
+            w.grad = v
+        if not self._learned:
+            self._seen_late[i].add(id(w))                   # live, but no hook will ever announce it: not part of _expected
+        if self.exchange and self._launched[i]:
             self._late_after_launch.append(i)
 
     def _on_grad(self, p):
@@ -205,10 +227,15 @@ class GradReducer:
         if p.grad is not v and p.grad.data_ptr() != v.data_ptr():      # autograd installed its own tensor: move it into the arena
             v.copy_(p.grad)
             p.grad = v
+        if id(p) in self._dead:
+            self._revive(p)
         self._ready[i] += 1
+        self._arrived[i].add(id(p))
         if not self._learned:
             self._seen_first[i].add(id(p))
-        elif self.overlap and not self._launched[i] and self._ready[i] >= self._expected[i]:
+        elif self.overlap and not self._launched[i] and self._arrived[i] >= self._live[i] and not self._seen_late[i]:
+            # every parameter of the bucket whose hook fired on the first step has arrived (identities, not counts); a bucket
+            # that also holds late-flushed weights leaves at finalize()
             self._launch(i)
 
     def _launch(self, i: int):
@@ -236,14 +263,18 @@ class GradReducer:
         if self.exchange:
             if self._expected is None:
                 # first step: every rank must expect the same arrivals per bucket (same model, same graph) -- checked once
-                counts = torch.tensor([len(s) for s in self._seen_first], dtype=torch.int64, device=self.arenas[0].device)
+                # (identities, not only counts: a hash of the names of the live parameters of every bucket)
+                import zlib
+                sig = [zlib.crc32("\n".join(sorted(self._names[q] for q in (s_ | l_))).encode()) + (len(s_) << 32)
+                       for s_, l_ in zip(self._seen_first, self._seen_late)]
+                counts = torch.tensor(sig, dtype=torch.int64, device=self.arenas[0].device)
                 lo, hi = counts.clone(), counts.clone()
                 dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
                 dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
                 if not torch.equal(lo, hi):
                     raise RuntimeError("GradReducer: ranks disagree on which parameters receive gradients: "
                                        f"{lo.tolist()} vs {hi.tolist()}")
-                self._expected = [int(c) for c in counts.tolist()]
+                self._expected = [len(s_) for s_ in self._seen_first]
             for i in range(len(self.buckets)):
                 if not self._launched[i]:
                     self._launch(i)
@@ -260,13 +291,15 @@ class GradReducer:
             self._learned = True
             if self._expected is None:
                 self._expected = [len(s) for s in self._seen_first]
+            self._live = [frozenset(s_) for s_ in self._seen_first]
             for i, b in enumerate(self.buckets):
                 for _, p in b:
-                    if id(p) not in self._seen_first[i]:
+                    if id(p) not in self._seen_first[i] and id(p) not in self._seen_late[i]:
                         self._dead.add(id(p))
                         p.grad = None
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._arrived = [set() for _ in self.buckets]
 
     def clip_(self, max_norm: float, summed: bool = True) -> torch.Tensor:
         """clip_grad_norm_(parameters, max_norm) over the arenas (trainer.py:120-121): global L2 norm of the averaged

@@ -78,7 +78,16 @@ def seed(n: int) -> None:
     global _seed
     _seed = int(n) & 0xFFFFFFFFFFFFFFFF
     for st in _states.values():
-        st.copy_(torch.tensor(_words(_seed), dtype=torch.int32))
+        st.copy_(torch.tensor(_words(_rank_seed(_seed)), dtype=torch.int32))
+
+
+def _rank_seed(s: int) -> int:
+    """Data-parallel ranks are all seeded with the same opts.seed (cvc.main); the hash has no rank term, so without this every
+    rank would draw bit-identical masks for its shard -- the reference's DataParallel replicas draw independent ones.  Rank 0 (and a
+    single process) keeps the plain seed."""
+    import torch.distributed as dist
+    r = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+    return (s ^ (r * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
 
 
 def _words(s: int):
@@ -95,7 +104,7 @@ def rng_state(device) -> torch.Tensor:
     if st is None:
         if _seed is None:
             _seed = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
-        st = torch.tensor(_words(_seed), dtype=torch.int32).to(device)
+        st = torch.tensor(_words(_rank_seed(_seed)), dtype=torch.int32).to(device)
         _states[key] = st
     return st
 

@@ -31,7 +31,9 @@ class ClipAdam(torch.optim.Adam):
         kw.pop("fused", None); kw.pop("foreach", None); kw.pop("capturable", None)
         # capturable=True: the step counters are float32 tensors on the parameters' device, which is what the kernel increments
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, capturable=True, foreach=False, fused=False)
-        self._table = None          # (key, device segment table, chunk table, scratch, norm_coef, keep-alive)
+        self._table = None          # (key, device segment table, chunk table, scratch, norm_coef, ...)
+        self._seg_host = None       # host copy of the segment table (lr / weight_decay are rewritten in place when they change)
+        self._retired = []          # tables replaced by a rebuild: kept alive, a captured HIP graph may still replay on them
         self.last_norm: Optional[torch.Tensor] = None       # device scalar: norm of the (averaged) gradient of the last clipped step
 
     # ------------------------------------------------------------------ state, exactly as torch.optim.Adam lays it out
@@ -64,12 +66,17 @@ class ClipAdam(torch.optim.Adam):
                     st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32, device=p.device)
                 lr = group["lr"]
                 segs.append((p, p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"], float(lr), float(group["weight_decay"])))
-                key.append((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr(),
-                            float(lr), float(group["weight_decay"])))
+                key.append((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"].data_ptr()))
         if not segs:
             return None
         key = (tuple(key), betas, eps)
         if self._table is not None and self._table[0] == key:
+            # same tensors: only the learning rates / weight decays may have moved (a scheduler).  They live in the device table,
+            # rewritten IN PLACE so that a captured graph replaying this table honours them
+            lr_wd = np.array([(s_[5], s_[6]) for s_ in segs], dtype=np.float32)
+            if not (np.array_equal(self._seg_host["lr"], lr_wd[:, 0]) and np.array_equal(self._seg_host["wd"], lr_wd[:, 1])):
+                self._seg_host["lr"], self._seg_host["wd"] = lr_wd[:, 0], lr_wd[:, 1]
+                self._table[1].copy_(torch.from_numpy(self._seg_host.view(np.uint8).copy()).pin_memory(), non_blocking=False)
             return self._table
         dev = segs[0][0].device
         chunk = int(hip.lib().cvc_optim_chunk_elems())
@@ -87,8 +94,17 @@ class ClipAdam(torch.optim.Adam):
         chunk_t = torch.from_numpy(chunk_np.view(np.uint8)).to(dev)
         partial = torch.empty(len(chunk_np), dtype=torch.float32, device=dev)
         norm_coef = torch.zeros(2, dtype=torch.float32, device=dev)
+        if self._table is not None:
+            self._retired.append(self._table)
+        self._seg_host = seg_np
         self._table = (key, seg_t, chunk_t, partial, norm_coef, len(segs), len(chunk_np), betas, eps)
         return self._table
+
+    def sync_hyperparameters(self):
+        """Push the param groups' current lr / weight_decay into the device table (in place).  Eager steps do this on their own;
+        call it before replaying a HIP graph that captured clip_and_step (Trainer.train_step_graphed does)."""
+        if self._table is not None:
+            self._build_table()
 
     # ------------------------------------------------------------------ the step
     @torch.no_grad()

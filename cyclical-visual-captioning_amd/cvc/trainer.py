@@ -91,7 +91,9 @@ class Trainer:
         red = self.grad_reducer
         fused = getattr(self.optimizer, "clip_and_step", None)     # cvc.optim.ClipAdam: norm + clip + Adam in three launches
         if red is None:
-            self.optimizer.zero_grad(set_to_none=set_to_none)
+            # ClipAdam keys its device segment table on the gradients' addresses: keep them (zero in place) instead of fresh
+            # tensors every step, which would rebuild and re-upload the table per step
+            self.optimizer.zero_grad(set_to_none=set_to_none and fused is None)
             loss.backward()
             if fused is not None:
                 fused(self.opts.grad_clip, 1.0)
@@ -154,6 +156,9 @@ class Trainer:
             elif isinstance(v, dict):
                 for kk, vv in v.items():
                     static[k][kk].copy_(vv)
+        sync = getattr(self.optimizer, "sync_hyperparameters", None)
+        if sync is not None:
+            sync()                                # a scheduler may have moved the learning rates since the capture
         g.replay()
         self._weights_changed()
         return res

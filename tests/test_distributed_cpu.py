@@ -112,3 +112,53 @@ def test_shard_batch_dict_and_tuple():
     s0, s1 = shard_batch(b, 0, 2), shard_batch(b, 1, 2)
     assert s0["a"].shape[0] == 3 and s1["a"].shape[0] == 2 and len(s0["ids"]) == 3 and s0["k"] == 3
     assert torch.equal(torch.cat([s0["a"], s1["a"]]), b["a"])
+
+
+class _TwoUses(torch.autograd.Function):
+    """A weight used twice per pass through cvc.functional's deferred-dW batcher: each backward call stashes its dW, the
+    last outstanding use returns the sum -- exactly what the LSTM cells' T uses per step do."""
+
+    @staticmethod
+    def forward(ctx, w, x):
+        from cvc import functional as F_
+        ctx.key = ("test", w.data_ptr())
+        ctx.save_for_backward(w, x)
+        F_._BATCHER.note_use(ctx.key)
+        return (w * x).sum().reshape(1)
+
+    @staticmethod
+    def backward(ctx, g):
+        from cvc import functional as F_
+        w, x = ctx.saved_tensors
+        got = F_._BATCHER.add(ctx.key, (g * x,), (w,), lambda items: (sum(i[0] for i in items),))
+        return (got[0] if got is not None else None), None
+
+
+def test_late_flushed_weight_stays_live_and_in_the_arena():
+    """a weight whose gradient arrives only through the end-of-backward flush (one of its uses got no
+    gradient, so the use counter never reached zero) fires no post-accumulate hook.  It must not be marked dead on the first
+    step: its gradient must stay in the arena view (exchanged, zeroed, seen by the optimizer) on every step."""
+    from cvc.distributed import GradReducer
+    w = torch.nn.Parameter(torch.ones(5))
+    v = torch.nn.Parameter(torch.ones(3))          # an ordinary parameter (hook fires)
+    dead = torch.nn.Parameter(torch.ones(2))       # never used
+    red = GradReducer([("rest.w", w), ("rest.v", v), ("rest.dead", dead)])
+    x1, x2 = torch.arange(5.0), torch.full((5,), 2.0)
+    for step in range(3):
+        red.zero_grad()
+        a = _TwoUses.apply(w, x1)
+        _unused = _TwoUses.apply(w, x2)            # second use: no gradient reaches it -> leftover -> late flush
+        (a.sum() + (v * 3).sum()).backward()
+        red.finalize()
+        assert w.grad is not None and w.grad.data_ptr() == red._views[id(w)].data_ptr(), step
+        np.testing.assert_allclose(w.grad.numpy(), x1.numpy())
+        np.testing.assert_allclose(v.grad.numpy(), np.full(3, 3.0))
+        assert dead.grad is None or float(dead.grad.abs().max()) == 0.0
+        from cvc import functional as F_
+        F_._BATCHER.uses.clear()
+    assert id(w) not in red._dead and id(dead) in red._dead
+    # a parameter dropped as dead that later receives a gradient is refused loudly
+    red.zero_grad()
+    with pytest.raises(RuntimeError, match="received no gradient on the first step"):
+        (dead * 2).sum().backward()
+    red.remove_hooks()

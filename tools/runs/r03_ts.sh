@@ -1,5 +1,8 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
+# whatever happens below, the in-tree library is rebuilt without ablation flags on exit (build_hip.py also stamps the flags of a
+# build and refuses to call a .so built with other flags up to date)
+trap 'CVC_EXTRA_HIPCC_FLAGS= python cyclical-visual-captioning_amd/build_hip.py --force > /dev/null 2>&1' EXIT
 mkdir -p gpurun_out/r03m
 export CVC_EXTRA_HIPCC_FLAGS="-DCVC_TS"
 python cyclical-visual-captioning_amd/build_hip.py --force > /dev/null 2>&1
