@@ -191,6 +191,174 @@ extern "C" int cvc_attn_bwd(int kind, const float* q, const float* w_a, float in
     return cvc_launch_status();
 }
 
+// ---- both feature sets of a decoder step in one backward (the C-driven training loop, csrc/train_driver.hip) ----------------
+namespace {
+
+struct SoftmaxBwd2Args {
+    const float* attn[2];
+    const float* d_fm[2];
+    float* d_scores[2];
+    int n[2];
+    int have_da;
+};
+
+// grid (rows, sets): softmax_bwd_kernel for set blockIdx.y
+__global__ __launch_bounds__(WG) void softmax_bwd2_kernel(SoftmaxBwd2Args a) {
+    __shared__ float red[4];
+    const bool s1 = blockIdx.y != 0;
+    const float* attn = s1 ? a.attn[1] : a.attn[0];
+    const float* d_fm = s1 ? a.d_fm[1] : a.d_fm[0];
+    float* d_scores = s1 ? a.d_scores[1] : a.d_scores[0];
+    const int n = s1 ? a.n[1] : a.n[0];
+    const size_t o = (size_t)blockIdx.x * n;
+    float dot = 0.f;
+    if (a.have_da)
+        for (int i = threadIdx.x; i < n; i += WG) dot += attn[o + i] * d_scores[o + i];
+    dot = block_sum4(dot, red);
+    for (int i = threadIdx.x; i < n; i += WG) {
+        float ds = a.have_da ? attn[o + i] * (d_scores[o + i] - dot) : 0.f;
+        if (d_fm != nullptr) ds += d_fm[o + i];
+        d_scores[o + i] = ds;
+    }
+}
+
+struct ScoreBwd2Args {
+    const float* q;        // [rows, A]
+    const float* w_a;      // [A]
+    const float* proj[2];  // [nclip, n_s, A]
+    const float* d_scores[2];
+    float* d_proj[2];      // accumulate, or null
+    int n[2];
+    int nsets;
+    float* d_q;            // [rows, A]
+    float* d_q_q;          // [A/4][64][4] or null
+    float* d_w_part;       // [rows, A] or null
+    float inv_temp;
+    int nq, A;
+};
+
+// attn_score_bwd_kernel over both sets: the query row's d_q (and the d_w_alpha partial) is the sum over the sets, taken in set
+// order inside the workgroup -- no second launch, no add.  Same row batching as the one-set kernel.
+template <int KIND, bool WANT_DP>
+__global__ __launch_bounds__(WG) void attn_score_bwd2_kernel(ScoreBwd2Args a) {
+    __shared__ f32x4 part[2][4][64];
+    const int clip = blockIdx.y, cb = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int A = a.A;
+    const int col = cb * 256 + lane * 4;
+    const bool ok = col < A;
+    f32x4 w4 = {0, 0, 0, 0};
+    if (KIND == CVC_ATTN_ADDITIVE && ok) w4 = ld4(a.w_a + col);
+    for (int qi = 0; qi < a.nq; ++qi) {
+        const size_t row = (size_t)clip * a.nq + qi;
+        f32x4 q4 = ok ? ld4(a.q + row * A + col) : f32x4{0, 0, 0, 0};
+        f32x4 dq = {0, 0, 0, 0}, dw = {0, 0, 0, 0};
+        for (int s = 0; s < a.nsets; ++s) {
+            const int n = s ? a.n[1] : a.n[0];
+            const float* P = (s ? a.proj[1] : a.proj[0]) + (size_t)clip * n * A + col;
+            float* dP = nullptr;
+            if constexpr (WANT_DP) {
+                dP = s ? a.d_proj[1] : a.d_proj[0];
+                if (dP != nullptr) dP += (size_t)clip * n * A + col;
+            }
+            const float* ds_row = (s ? a.d_scores[1] : a.d_scores[0]) + row * n;
+            auto one = [&](const float ds, const f32x4 p, const int i) __attribute__((always_inline)) {
+                f32x4 dpre;
+                if (KIND == CVC_ATTN_ADDITIVE) {
+                    f32x4 t;
+                    t.x = fast_tanh(p.x + q4.x); t.y = fast_tanh(p.y + q4.y);
+                    t.z = fast_tanh(p.z + q4.z); t.w = fast_tanh(p.w + q4.w);
+                    dpre = ds * w4 * (1.f - t * t);
+                    dw += ds * t;
+                    dq += dpre;
+                } else {
+                    const float g = ds * a.inv_temp;
+                    dpre = g * q4;
+                    dq += g * p;
+                }
+                if constexpr (WANT_DP) {
+                    if (dP != nullptr) st4(dP + (size_t)i * A, ld4(dP + (size_t)i * A) + dpre);
+                }
+            };
+            if (ok) {
+                int i = wave;
+                for (; i + 28 < n; i += 32) {
+                    f32x4 p[8];
+                    float ds[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { p[k] = ld4(P + (size_t)(i + 4 * k) * A); ds[k] = ds_row[i + 4 * k]; }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) one(ds[k], p[k], i + 4 * k);
+                }
+                for (; i < n; i += 4) one(ds_row[i], ld4(P + (size_t)i * A), i);
+            }
+        }
+        __syncthreads();
+        part[0][wave][lane] = dq;
+        part[1][wave][lane] = dw;
+        __syncthreads();
+        if (wave == 0 && ok) {
+            const f32x4 v = (part[0][0][lane] + part[0][1][lane]) + (part[0][2][lane] + part[0][3][lane]);
+            st4(a.d_q + row * A + col, v);
+            if (a.d_q_q != nullptr) st4(a.d_q_q + ((size_t)(col >> 2) * 64 + row) * 4, v);
+            if (KIND == CVC_ATTN_ADDITIVE && a.d_w_part != nullptr)
+                st4(a.d_w_part + row * A + col,
+                    (part[1][0][lane] + part[1][1][lane]) + (part[1][2][lane] + part[1][3][lane]));
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int cvc_attn_bwd_pair(int kind, const float* q, const float* w_a, float inv_temp, const cvc_attn_set* sets, int nsets,
+                                 const float* d_ctx, int nclip, int nq, int A, int R, float* d_q, float* d_q_q, float* d_w_part,
+                                 float* const* d_proj, float* const* d_ctxfeat, cvc_stream_t stream) {
+    if (!q || !sets || nsets < 1 || nsets > 2 || !d_q || nclip < 1 || nq < 1 || (A & 3) || (R & 3)) return CVC_E_BADARG;
+    if (kind != CVC_ATTN_ADDITIVE && kind != CVC_ATTN_DOT) return CVC_E_BADARG;
+    if (kind == CVC_ATTN_ADDITIVE && !w_a) return CVC_E_BADARG;
+    const int rows = nclip * nq;
+    if (d_q_q != nullptr && rows > 64) return CVC_E_BADARG;
+    for (int s = 0; s < nsets; ++s)
+        if (!sets[s].proj || !sets[s].ctx || !sets[s].attn || !sets[s].scores || sets[s].n < 1) return CVC_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (d_ctx != nullptr) {
+        // d_attn[row, i] = d_ctx[row, :] . ctx[clip, i, :] for both sets: the forward's dot-product score pass over the contexts
+        cvc_attn_set ss[2]{};
+        for (int s = 0; s < nsets; ++s) {
+            ss[s].proj = sets[s].ctx; ss[s].ctx = sets[s].ctx; ss[s].scores = sets[s].scores; ss[s].attn = sets[s].scores;
+            ss[s].n = sets[s].n;
+        }
+        int rc = run_scores(CVC_ATTN_DOT, d_ctx, nullptr, nullptr, 1.f, ss, nsets, nclip, nq, R, st);
+        if (rc) return rc;
+    }
+    SoftmaxBwd2Args sm{};
+    ScoreBwd2Args a{};
+    for (int s = 0; s < 2; ++s) {
+        const cvc_attn_set& S = sets[s < nsets ? s : 0];
+        sm.attn[s] = S.attn; sm.d_fm[s] = S.frame_masked; sm.d_scores[s] = S.scores; sm.n[s] = S.n;
+        a.proj[s] = S.proj; a.d_scores[s] = S.scores; a.n[s] = S.n;
+        a.d_proj[s] = (d_proj != nullptr && s < nsets) ? d_proj[s] : nullptr;
+    }
+    sm.have_da = d_ctx != nullptr ? 1 : 0;
+    hipLaunchKernelGGL(softmax_bwd2_kernel, dim3(rows, nsets), dim3(WG), 0, st, sm);
+    a.q = q; a.w_a = w_a; a.nsets = nsets; a.d_q = d_q; a.d_q_q = d_q_q; a.d_w_part = d_w_part; a.inv_temp = inv_temp; a.nq = nq; a.A = A;
+    dim3 grid((A + 255) / 256, nclip);
+    const bool want_dp = a.d_proj[0] != nullptr || a.d_proj[1] != nullptr;
+    if (kind == CVC_ATTN_ADDITIVE) {
+        if (want_dp) hipLaunchKernelGGL((attn_score_bwd2_kernel<CVC_ATTN_ADDITIVE, true>), grid, dim3(WG), 0, st, a);
+        else hipLaunchKernelGGL((attn_score_bwd2_kernel<CVC_ATTN_ADDITIVE, false>), grid, dim3(WG), 0, st, a);
+    } else {
+        if (want_dp) hipLaunchKernelGGL((attn_score_bwd2_kernel<CVC_ATTN_DOT, true>), grid, dim3(WG), 0, st, a);
+        else hipLaunchKernelGGL((attn_score_bwd2_kernel<CVC_ATTN_DOT, false>), grid, dim3(WG), 0, st, a);
+    }
+    if (d_ctxfeat != nullptr && d_ctx != nullptr)
+        for (int s = 0; s < nsets; ++s)
+            if (d_ctxfeat[s] != nullptr)
+                hipLaunchKernelGGL(ctxfeat_bwd_kernel, dim3((R + 255) / 256, nclip), dim3(WG), 0, st, sets[s].attn, d_ctx, nq,
+                                   sets[s].n, R, d_ctxfeat[s]);
+    return cvc_launch_status();
+}
+
 // d_xt[b,t,:] = sum_n d[b,t,n] feats[b,n,:],  d_feats[b,n,:] = sum_t d[b,t,n] xt[b,t,:]   (either output may be null)
 extern "C" int cvc_grounder_bwd(const float* d, const float* xt, const float* feats, int B, int T, int N, int G, float* d_xt,
                                 float* d_feats, cvc_stream_t stream) {

@@ -28,6 +28,7 @@ struct WsumArgs {
     int ctx_quad;                 // 1: ctx_sum is written in the GEMM's quad layout [R/4][64][4] (rows <= 64)
                                   // 2: as bf16 split-term fragments of the tile GEMM (gemm_tile.hip), row-block stride below
     long long frag_stride;
+    float* ctx_sum_rm;            // one-query kernel: the summed context once more, row-major [rows, R] (training loops), or null
 };
 
 // 4 consecutive columns of row m as the three bf16 terms (hi, mid, lo: exact truncation split, gemm_split.h) inside the
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(WG) void attn_wsum_kernel(WsumArgs a) {
         else if (a.ctx_quad) st4(a.ctx_sum + ((size_t)(col >> 2) * 64 + row) * 4, total);
         else st4(a.ctx_sum + (size_t)row * R + col, total);
     }
+    if (a.ctx_sum_rm != nullptr && wave == 0 && col_ok) st4(a.ctx_sum_rm + (size_t)row * R + col, total);
 }
 
 // Several queries per clip (beams of a clip, the T localizer queries of a clip): one workgroup = (clip, 256-column block,
@@ -301,7 +303,7 @@ extern "C" int cvc_attn_scores_qslab(int kind, const cvc_gsk_segs* q, const floa
 }
 
 static int wsum_impl(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum, int ctx_quad,
-                     cvc_stream_t stream, long long frag_stride = 0);
+                     cvc_stream_t stream, long long frag_stride = 0, float* ctx_sum_rm = nullptr);
 
 extern "C" int cvc_attn_wsum(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum,
                              cvc_stream_t stream) {
@@ -320,8 +322,15 @@ extern "C" int cvc_attn_wsum_frag(const cvc_attn_set* sets, int nsets, int nclip
     return wsum_impl(sets, nsets, nclip, nq, R, (float*)ctx_frag, 2, stream, frag_mblk_stride);
 }
 
+// the summed context in the quad layout AND row-major (the training loops: next gate GEMM's operand + the dW product's rows)
+extern "C" int cvc_attn_wsum_quad_rm(const cvc_attn_set* sets, int nsets, int nclip, int R, float* ctx_sum_q, float* ctx_sum_rm,
+                                     cvc_stream_t stream) {
+    if (ctx_sum_q == nullptr || ctx_sum_rm == nullptr || nclip > 64) return CVC_E_BADARG;
+    return wsum_impl(sets, nsets, nclip, 1, R, ctx_sum_q, 1, stream, 0, ctx_sum_rm);
+}
+
 static int wsum_impl(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum, int ctx_quad,
-                     cvc_stream_t stream, long long frag_stride) {
+                     cvc_stream_t stream, long long frag_stride, float* ctx_sum_rm) {
     int n_max;
     int rc = check_sets(sets, nsets, nclip, nq, 0, R, &n_max);
     if (rc) return rc;
@@ -329,6 +338,8 @@ static int wsum_impl(const cvc_attn_set* sets, int nsets, int nclip, int nq, int
     wa.set[0] = sets[0];
     wa.set[1] = nsets > 1 ? sets[1] : sets[0];
     wa.nsets = nsets; wa.nq = nq; wa.R = R; wa.ctx_sum = ctx_sum; wa.ctx_quad = ctx_quad; wa.frag_stride = frag_stride;
+    wa.ctx_sum_rm = ctx_sum_rm;
+    if (ctx_sum_rm != nullptr && nq != 1) return CVC_E_BADARG;
     if (nq > 1) {
         // queries of a clip in groups of QB (the largest group whose softmax rows + partials fit 64 KB of LDS): the clip's
         // context rows are read once per group; if not even 2 fit, the one-query kernel below takes every row on its own

@@ -623,7 +623,7 @@ static int launch_packed(const PackedArgs& a_in, int blocks, hipStream_t st) {
     const dim3 grid(blocks, LSTM || a.ksplit < 1 ? 1 : a.ksplit);
     if constexpr (LSTM) {
         // decode form, 64-row workgroups (two blocks each): halves the L2 activation reads
-        if (cvc_gemm_split_mode == 2 && cvc_packed_lstm_blocks == 2 && (blocks & 1) == 0 && a.M > 32 && a.h_rm == nullptr) {
+        if (cvc_gemm_split_mode == 2 && cvc_packed_lstm_blocks == 2 && (blocks & 1) == 0 && a.M > 32 && a.h_rm == nullptr && a.c_prev_rm == nullptr) {
             hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, true, CVC_PACKED_DEPTH8, true, 8, false, 2>), dim3(blocks / 2), dim3(512), 0, st, a);
             return cvc_launch_status();
         }
@@ -755,6 +755,25 @@ static int packed_lstm_train_impl(const float* wp, const float* xq, int K, const
     a.wp = wp; a.xq = xq; a.nquad = K / 4; a.M = M; a.Nout = 4 * R; a.R = R;
     a.bias = b_ih; a.bias2 = b_hh; a.c_prev_rm = c_prev; a.h_rm = h_out; a.c_rm = c_out; a.gates_rm = gates_out; a.ksplit = 1;
     return launch_packed<true>(a, R / 8, (hipStream_t)stream);
+}
+
+// General training form (include/cvc_hip.h, "Training loops driven from C"): row-major state in / out, activated gates, up to
+// two plain row-major copies of h', the dropped copy, and the quad destinations of the decode form -- the C-driven training
+// loops hand h' to the next GEMMs without a packing launch.
+extern "C" int cvc_packed_lstm_step_fwd(const cvc_lstm_step* s, cvc_stream_t stream) {
+    if (!s || !s->wp || !s->xq || !s->c_prev || !s->c_out || (s->K & 31) || s->K < 32 || s->R < 8 || (s->R & 7) || s->M < 1 || s->M > 64)
+        return CVC_E_BADARG;
+    if ((s->row_bias != nullptr) != (s->row_index != nullptr)) return CVC_E_BADARG;
+    if (s->p < 0.f || s->p >= 1.f) return CVC_E_BADARG;
+    PackedArgs a{};
+    a.wp = s->wp; a.xq = s->xq; a.nquad = s->K / 4; a.M = s->M; a.Nout = 4 * s->R; a.R = s->R; a.ksplit = 1;
+    a.bias = s->b_ih; a.bias2 = s->b_hh; a.gate_bias = s->gate_pre;
+    a.emb_gate = s->row_bias; a.word = s->row_index;            // (the embedding-gate gather: one table row per batch row)
+    a.c_prev_rm = s->c_prev; a.c_rm = s->c_out; a.gates_rm = s->gates_out;
+    a.h_rm = s->h_out; a.h_rm2 = s->h_out2; a.h_rm3 = s->h_drop_out;
+    a.h3_drop = cvc_drop_spec(s->rng_state, s->site, s->p);
+    a.h_dst1_q = s->h_dst1_q; a.h_dst2_q = s->h_dst2_q;
+    return launch_packed<true>(a, s->R / 8, (hipStream_t)stream);
 }
 
 // ---- GRU over a whole sequence (the encoder's frame context, backbone.py:335-338): one launch per time step, both directions

@@ -1,0 +1,237 @@
+// Host-side drivers of the cyclical training pass's two recurrent loops and their back-propagation through time
+// (model/captioner.py:242-270 + decoder_core.py:30-66, captioner.py:348-362 + decoder_core.py:86-113): cvc_train_loop_fwd /
+// cvc_train_loop_bwd enqueue every launch of the T steps on the caller's stream from one descriptor -- what cvc/functional.py
+// used to drive step by step through autograd (one Function per cell / attention / linear, ~45 launches and ~17 framework
+// kernels per step), now one call per loop and direction, capturable into a HIP graph.  Nothing here touches the device except
+// through the C-ABI entry points of this library.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/cvc_hip.h"
+
+namespace {
+
+#define CVC_TRY(expr)             \
+    do {                          \
+        int rc_ = (expr);         \
+        ++n;                      \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+inline float* quad_off(float* buf, int k0) { return buf + (size_t)(k0 / 4) * 64 * 4; }
+
+__global__ __launch_bounds__(256) void zero16_kernel(uint4* dst, size_t n16) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = uint4{0, 0, 0, 0};
+}
+// zero fill as an ordinary kernel node (see decode_driver.hip: memset nodes raced with the first GEMM inside captured graphs)
+int zero(float* dst, size_t floats, hipStream_t st) {
+    if (floats == 0) return 0;
+    if ((floats & 3) || ((uintptr_t)dst & 15)) return CVC_E_BADARG;
+    const size_t n16 = floats / 4;
+    hipLaunchKernelGGL(zero16_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (uint4*)dst, n16);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+int validate(const cvc_train_loop& L, bool backward) {
+    if (L.kind != 0 && L.kind != 1) return CVC_E_BADARG;
+    if (L.B < 1 || L.B > 64 || L.T < 1 || L.R < 32 || (L.R & 31)) return CVC_E_BADARG;
+    if (!L.wp_att || !L.wp_lang || !L.gpre_att || !L.out || !L.h_att || !L.h_att_prev || !L.h_lang_prev || !L.c_att || !L.c_lang ||
+        !L.g_att || !L.g_lang || !L.xa[0] || !L.xa[1] || !L.xl[0] || !L.xl[1])
+        return CVC_E_BADARG;
+    if ((L.row_bias != nullptr) != (L.row_index != nullptr)) return CVC_E_BADARG;
+    if (L.p < 0.f || L.p >= 1.f || (L.p > 0.f && !L.rng_state)) return CVC_E_BADARG;
+    if (L.kind == 0) {
+        if (L.A < 4 || (L.A & 3) || L.N < 1 || L.F < 1) return CVC_E_BADARG;
+        if (L.attn_kind != CVC_ATTN_ADDITIVE && L.attn_kind != CVC_ATTN_DOT) return CVC_E_BADARG;
+        if (L.attn_kind == CVC_ATTN_ADDITIVE && !L.w_a) return CVC_E_BADARG;
+        if (!L.w_h || !L.b_h || !L.pool || !L.ppool || !L.conv || !L.pconv || !L.ctx || !L.q || !L.attn_r || !L.attn_f || !L.scores_ws)
+            return CVC_E_BADARG;
+        if ((L.frame_mask != nullptr) != (L.fm != nullptr)) return CVC_E_BADARG;
+    } else if (!L.gpre_lang) {
+        return CVC_E_BADARG;
+    }
+    if (backward) {
+        if (!L.d_out || !L.dg_att || !L.dg_lang || !L.bwd_ws || !L.w_ih_att || !L.w_hh_att || !L.w_ih_lang || !L.w_hh_lang) return CVC_E_BADARG;
+        if (L.ld_ih_att < L.R || L.ld_ih_lang < 2 * L.R || (L.ld_ih_att & 3) || (L.ld_ih_lang & 3)) return CVC_E_BADARG;
+        if (L.kind == 0 && (!L.dq || !L.ds_r || !L.ds_f || (L.attn_kind == CVC_ATTN_ADDITIVE && !L.dwa_part) || (L.A & 7))) return CVC_E_BADARG;
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- forward
+int run_fwd(const cvc_train_loop& L, hipStream_t st, int* launches) {
+    const int B = L.B, T = L.T, R = L.R, A = L.A, N = L.N, F = L.F;
+    const size_t BR = (size_t)B * R, BG = (size_t)B * 4 * R;
+    const int k_lang = L.kind == 0 ? 3 * R : 2 * R;      // K of the language cell's per-step GEMM
+    const int hl_off = L.kind == 0 ? 2 * R : R;          // h_lang(t-1)'s K offset inside XL
+    const int ha_off = L.kind == 0 ? R : 0;              // h_att(t)'s K offset inside XL
+    int n = 0;
+    // zero state: h_lang(-1) = h_att(-1) = 0 in the operand rings and the row-major rows, c(-1) = 0
+    CVC_TRY(zero(L.xa[0], (size_t)(2 * R / 4) * 256, st));
+    CVC_TRY(zero(quad_off(L.xl[0], hl_off), (size_t)(R / 4) * 256, st));
+    CVC_TRY(zero(L.c_att, BR, st));
+    CVC_TRY(zero(L.c_lang, BR, st));
+    CVC_TRY(zero(L.h_att_prev, BR, st));
+    CVC_TRY(zero(L.h_lang_prev, BR, st));
+    for (int t = 0; t < T; ++t) {
+        const int rd = t & 1, wr = (t + 1) & 1;
+        const bool last = t + 1 == T;
+        // ---- attention LSTM (decoder_core.py:45-50 / :99-104): recurrent columns streamed, fc + word terms hoisted
+        cvc_lstm_step a{};
+        a.wp = L.wp_att; a.xq = L.xa[rd]; a.K = 2 * R; a.M = B; a.R = R;
+        a.b_ih = L.b_ih_att; a.b_hh = L.b_hh_att;
+        a.gate_pre = L.gpre_att + (size_t)t * BG;
+        a.row_bias = L.row_bias; a.row_index = L.row_index;
+        a.c_prev = L.c_att + (size_t)t * BR; a.c_out = L.c_att + (size_t)(t + 1) * BR; a.gates_out = L.g_att + (size_t)t * BG;
+        a.h_out = L.h_att + (size_t)t * BR;
+        a.h_out2 = last ? nullptr : L.h_att_prev + (size_t)(t + 1) * BR;
+        a.h_dst1_q = quad_off(L.xl[rd], ha_off);
+        a.h_dst2_q = quad_off(L.xa[wr], R);
+        CVC_TRY(cvc_packed_lstm_step_fwd(&a, st));
+        if (L.kind == 0) {
+            // ---- additive / dot attention over regions + frames with one query (decoder_core.py:54-56, modules.py:100-159)
+            float* q = L.q + (size_t)t * B * A;
+            cvc_gemm_seg seg{L.h_att + (size_t)t * BR, nullptr, L.w_h, R, R, R, 0};
+            CVC_TRY(cvc_linear_fwd(&seg, 1, L.b_h, nullptr, B, A, q, A, st));
+            cvc_attn_set sets[2];
+            sets[0] = cvc_attn_set{L.ppool, L.pool, L.mask, L.frame_mask ? L.frame_mask + (size_t)t * B * N : nullptr, L.scores_ws,
+                                   L.fm ? L.fm + (size_t)t * B * N : nullptr, L.attn_r + (size_t)t * B * N, nullptr, N, 0};
+            sets[1] = cvc_attn_set{L.pconv, L.conv, nullptr, nullptr, L.scores_ws + (size_t)B * N, nullptr,
+                                   L.attn_f + (size_t)t * B * F, nullptr, F, 0};
+            CVC_TRY(cvc_attn_scores(L.attn_kind, q, L.w_a, L.b_a, L.inv_temp, sets, 2, B, 1, A, st));
+            CVC_TRY(cvc_attn_wsum_quad_rm(sets, 2, B, R, L.xl[rd], L.ctx + (size_t)t * BR, st));
+        }
+        // ---- language LSTM (decoder_core.py:59-62 / :106-109) + output dropout
+        cvc_lstm_step l{};
+        l.wp = L.wp_lang; l.xq = L.xl[rd]; l.K = k_lang; l.M = B; l.R = R;
+        l.b_ih = L.b_ih_lang; l.b_hh = L.b_hh_lang;
+        l.gate_pre = L.kind == 1 ? L.gpre_lang + (size_t)t * BG : nullptr;
+        l.c_prev = L.c_lang + (size_t)t * BR; l.c_out = L.c_lang + (size_t)(t + 1) * BR; l.gates_out = L.g_lang + (size_t)t * BG;
+        l.h_out = last ? nullptr : L.h_lang_prev + (size_t)(t + 1) * BR;
+        l.h_drop_out = L.out + (size_t)t * BR;
+        l.rng_state = L.p > 0.f ? L.rng_state : nullptr; l.site = L.site0 + (unsigned)t; l.p = L.p;
+        l.h_dst1_q = last ? nullptr : L.xa[wr];
+        l.h_dst2_q = last ? nullptr : quad_off(L.xl[wr], hl_off);
+        CVC_TRY(cvc_packed_lstm_step_fwd(&l, st));
+    }
+    if (launches) *launches = n;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- backward
+struct BwdWs {
+    float *dgq, *dqq, *d_ctx, *d_ha_a, *d_ha_b, *d_ha_prev, *d_hl_a, *d_hl_b, *d_c_att, *d_c_lang, *nn;
+    long long total;
+};
+BwdWs carve(float* base, int B, int R, int A) {
+    BwdWs w{};
+    size_t o = 0;
+    auto take = [&](size_t floats) { float* p = base ? base + o : nullptr; o += (floats + 63) / 64 * 64; return p; };
+    (void)B;
+    w.dgq = take((size_t)R * 256);                        // d_gates, quad layout [4R/4][64][4]
+    w.dqq = take((size_t)(A > 0 ? A : 4) / 4 * 256);      // d_q, quad layout [A/4][64][4]
+    const size_t br = (size_t)64 * R;
+    w.d_ctx = take(br); w.d_ha_a = take(br); w.d_ha_b = take(br); w.d_ha_prev = take(br);
+    w.d_hl_a = take(br); w.d_hl_b = take(br); w.d_c_att = take(br); w.d_c_lang = take(br);
+    // K-slice planes of cvc_linear_nn_fwd: ksplit * M * ntot floats with ksplit * slabs <= max(256, slabs)
+    const size_t slabs_max = (size_t)(3 * R + 127) / 128;
+    w.nn = take((size_t)64 * 128 * (slabs_max > 512 ? slabs_max : 512));
+    w.total = (long long)o;
+    return w;
+}
+
+// cvc_linear_nn_fwd with the K split cvc/hip.py::linear_nn chooses: one resident round of workgroups, >= 16 K rows per wave
+int nn(const float* dy_q, int K, int M, const cvc_nn_seg* segs, int nsegs, float* ws, hipStream_t st) {
+    int slabs = 0;
+    for (int s = 0; s < nsegs; ++s) slabs += (segs[s].ncols + 127) / 128;
+    const int resident = cvc_gemm_packed_split(-1) != 0 ? 256 : 512;
+    int ks = resident / (slabs > 0 ? slabs : 1);
+    if (ks > K / 8 / 16) ks = K / 8 / 16;
+    if (ks < 1) ks = 1;
+    return cvc_linear_nn_fwd(dy_q, K, M, segs, nsegs, ks, ws, st);
+}
+
+int run_bwd(const cvc_train_loop& L, hipStream_t st, int* launches) {
+    const int B = L.B, T = L.T, R = L.R, A = L.A, N = L.N, F = L.F;
+    const size_t BR = (size_t)B * R, BG = (size_t)B * 4 * R;
+    const BwdWs w = carve(L.bwd_ws, B, R, L.kind == 0 ? A : 0);
+    int n = 0;
+    for (int t = T - 1; t >= 0; --t) {
+        const bool last = t + 1 == T;
+        // ---- language cell: d_h = dropout'(d_out[t]) + the next step's two uses of h_lang(t)
+        CVC_TRY(cvc_lstm_pointwise_bwd4(last ? nullptr : w.d_hl_a, last ? nullptr : w.d_hl_b, nullptr, L.d_out + (size_t)t * BR,
+                                        L.p > 0.f ? L.rng_state : nullptr, L.site0 + (unsigned)t, L.p, last ? nullptr : w.d_c_lang,
+                                        L.g_lang + (size_t)t * BG, L.c_lang + (size_t)t * BR, L.c_lang + (size_t)(t + 1) * BR, B, R,
+                                        L.dg_lang + (size_t)t * BG, w.d_c_lang, w.dgq, st));
+        {
+            cvc_nn_seg segs[3];
+            int ns = 0;
+            if (L.kind == 0) segs[ns++] = cvc_nn_seg{L.w_ih_lang, w.d_ctx, L.ld_ih_lang, R, R};
+            segs[ns++] = cvc_nn_seg{L.w_ih_lang + R, w.d_ha_a, L.ld_ih_lang, R, R};
+            if (t > 0) segs[ns++] = cvc_nn_seg{L.w_hh_lang, w.d_hl_a, R, R, R};
+            CVC_TRY(nn(w.dgq, 4 * R, B, segs, ns, w.nn, st));
+        }
+        const float* d_ha_b = nullptr;
+        if (L.kind == 0) {
+            // ---- attention (both feature sets) and h2attn
+            cvc_attn_set sets[2]{};
+            sets[0].proj = L.ppool; sets[0].ctx = L.pool; sets[0].attn = L.attn_r + (size_t)t * B * N; sets[0].n = N;
+            sets[0].scores = L.ds_r + (size_t)t * B * N;
+            sets[0].frame_masked = L.d_fm ? const_cast<float*>(L.d_fm) + (size_t)t * B * N : nullptr;
+            sets[1].proj = L.pconv; sets[1].ctx = L.conv; sets[1].attn = L.attn_f + (size_t)t * B * F; sets[1].n = F;
+            sets[1].scores = L.ds_f + (size_t)t * B * F;
+            float* d_proj[2] = {L.d_ppool, L.d_pconv};
+            float* d_cf[2] = {L.d_pool, L.d_conv};
+            const bool any_dp = L.d_ppool || L.d_pconv, any_dc = L.d_pool || L.d_conv;
+            CVC_TRY(cvc_attn_bwd_pair(L.attn_kind, L.q + (size_t)t * B * A, L.w_a, L.inv_temp, sets, 2, w.d_ctx, B, 1, A, R,
+                                      L.dq + (size_t)t * B * A, w.dqq, L.dwa_part ? L.dwa_part + (size_t)t * B * A : nullptr,
+                                      any_dp ? d_proj : nullptr, any_dc ? d_cf : nullptr, st));
+            cvc_nn_seg seg{L.w_h, w.d_ha_b, R, R, R};
+            CVC_TRY(nn(w.dqq, A, B, &seg, 1, w.nn, st));
+            d_ha_b = w.d_ha_b;
+        }
+        // ---- attention cell: d_h = language cell's input + attention query + next step's recurrence
+        CVC_TRY(cvc_lstm_pointwise_bwd4(w.d_ha_a, d_ha_b, last ? nullptr : w.d_ha_prev, nullptr, nullptr, 0, 0.f,
+                                        last ? nullptr : w.d_c_att, L.g_att + (size_t)t * BG, L.c_att + (size_t)t * BR,
+                                        L.c_att + (size_t)(t + 1) * BR, B, R, L.dg_att + (size_t)t * BG, w.d_c_att, w.dgq, st));
+        if (t > 0) {
+            cvc_nn_seg segs[2] = {cvc_nn_seg{L.w_ih_att, w.d_hl_b, L.ld_ih_att, R, R}, cvc_nn_seg{L.w_hh_att, w.d_ha_prev, R, R, R}};
+            CVC_TRY(nn(w.dgq, 4 * R, B, segs, 2, w.nn, st));
+        }
+    }
+    if (launches) *launches = n;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" long long cvc_train_loop_bwd_ws(int B, int R, int A) {
+    if (B < 1 || B > 64 || R < 32 || A < 0) return 0;
+    return carve(nullptr, B, R, A).total;
+}
+
+extern "C" int cvc_train_loop_fwd(const cvc_train_loop* loop, cvc_stream_t stream) {
+    if (!loop) return CVC_E_BADARG;
+    int rc = validate(*loop, false);
+    if (rc) return rc;
+    return run_fwd(*loop, (hipStream_t)stream, nullptr);
+}
+
+extern "C" int cvc_train_loop_bwd(const cvc_train_loop* loop, cvc_stream_t stream) {
+    if (!loop) return CVC_E_BADARG;
+    int rc = validate(*loop, true);
+    if (rc) return rc;
+    return run_bwd(*loop, (hipStream_t)stream, nullptr);
+}
+
+// launches one call enqueues (what the drivers above count): the zero fills + per step 2 cells (+ h2attn, 2 attention passes),
+// backward per step 2 gate-gradient kernels, the backward-data products (+ the attention backward's 3 launches)
+extern "C" int cvc_train_loop_launches(const cvc_train_loop* loop, int backward) {
+    if (!loop || loop->T < 1) return 0;
+    const int T = loop->T;
+    if (!backward) return 6 + T * (loop->kind == 0 ? 5 : 2);
+    // nn = GEMM (+ plane sum); attention backward = score pass + softmax backward + score backward
+    const int per = loop->kind == 0 ? (1 + 2 + 3 + 2 + 1 + 2) : (1 + 2 + 1 + 2);
+    return T * per - 2;          // (step 0 has no recurrent product of the attention cell)
+}

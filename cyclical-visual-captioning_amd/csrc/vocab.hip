@@ -442,6 +442,38 @@ __global__ __launch_bounds__(WG) void lstm_pointwise_bwd_kernel(const float* d_h
     }
 }
 
+// four gradients of h' (the C-driven training loops: this step's other consumers, the next step's two cells, the dropped output),
+// summed in the order d_h1, d_h2, d_h3, d_hd * mask
+__global__ __launch_bounds__(WG) void lstm_pointwise_bwd4_kernel(const float* d_h1, const float* d_h2, const float* d_h3, const float* d_hd,
+                                                                 DropSpec rng, const float* d_c, const float* gates, const float* c_prev,
+                                                                 const float* c_new, int M, int R, float* d_gates, float* d_c_prev,
+                                                                 float* d_gates_q) {
+    const int j = blockIdx.x * WG + threadIdx.x;
+    const int m = blockIdx.y;
+    if (j >= R) return;
+    const size_t o = (size_t)m * R + j, g0 = (size_t)m * 4 * R + j;
+    const float ig = gates[g0], fg = gates[g0 + R], gg = gates[g0 + 2 * R], og = gates[g0 + 3 * R];
+    const float tc = tanhf(c_new[o]);
+    float dhd = d_hd != nullptr ? d_hd[o] : 0.f;
+    if (rng.state != nullptr) dhd *= cvc_drop_mult(rng, rng.state[0], rng.state[1], rng.state[2], (uint32_t)o);
+    const float dh = (((d_h1 != nullptr ? d_h1[o] : 0.f) + (d_h2 != nullptr ? d_h2[o] : 0.f)) + (d_h3 != nullptr ? d_h3[o] : 0.f)) + dhd;
+    const float dcn = (d_c != nullptr ? d_c[o] : 0.f) + dh * og * (1.f - tc * tc);
+    const float d0 = dcn * gg * ig * (1.f - ig), d1 = dcn * c_prev[o] * fg * (1.f - fg);
+    const float d2 = dcn * ig * (1.f - gg * gg), d3 = dh * tc * og * (1.f - og);
+    d_gates[g0] = d0;
+    d_gates[g0 + R] = d1;
+    d_gates[g0 + 2 * R] = d2;
+    d_gates[g0 + 3 * R] = d3;
+    d_c_prev[o] = dcn * fg;
+    if (d_gates_q != nullptr) {
+        const size_t q0 = ((size_t)(j >> 2) * 64 + m) * 4 + (j & 3), qs = (size_t)(R >> 2) * 256;
+        d_gates_q[q0] = d0;
+        d_gates_q[q0 + qs] = d1;
+        d_gates_q[q0 + 2 * qs] = d2;
+        d_gates_q[q0 + 3 * qs] = d3;
+    }
+}
+
 // ------------------------------------------------------------------ beam bookkeeping
 // Candidate (k, v) scores: score[k] + logit[k,v] - lse[k]; -inf for v == unk; a finished hypothesis
 // only offers (k, 0) at its carried score.  The `beam` best of a clip's beam*V candidates are among the
@@ -831,6 +863,17 @@ extern "C" int cvc_lstm_pointwise_bwd3_drop(const float* d_h, const float* d_h2,
     if (d_gates_q != nullptr && (M > 64 || (R & 3))) return CVC_E_BADARG;
     hipLaunchKernelGGL(lstm_pointwise_bwd_kernel, dim3((R + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, d_h, d_h2, d_h3, d_c,
                        gates, c_prev, c_new, M, R, d_gates, d_c_prev, d_gates_q, cvc_drop_spec(rng_state, site, p));
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_lstm_pointwise_bwd4(const float* d_h1, const float* d_h2, const float* d_h3, const float* d_hd,
+                                       const uint32_t* rng_state, unsigned site, float p, const float* d_c, const float* gates,
+                                       const float* c_prev, const float* c_new, int M, int R, float* d_gates, float* d_c_prev,
+                                       float* d_gates_q, cvc_stream_t stream) {
+    if (!gates || !c_prev || !c_new || !d_gates || !d_c_prev || M < 1 || R < 1 || p < 0.f || p >= 1.f) return CVC_E_BADARG;
+    if (d_gates_q != nullptr && (M > 64 || (R & 3))) return CVC_E_BADARG;
+    hipLaunchKernelGGL(lstm_pointwise_bwd4_kernel, dim3((R + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, d_h1, d_h2, d_h3, d_hd,
+                       cvc_drop_spec(rng_state, site, p), d_c, gates, c_prev, c_new, M, R, d_gates, d_c_prev, d_gates_q);
     return cvc_launch_status();
 }
 

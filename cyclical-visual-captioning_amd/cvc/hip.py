@@ -79,8 +79,41 @@ class DecodeDesc(C.Structure):
         [("gsk_nwg", C.c_int)] + [(n, C.c_void_p) for n in ("slab_att", "slab_lang", "slab_q", "slab_o", "emb_gate", "sel_counter")] +
         [("att_w_cached", C.c_int), ("lang_ksx", C.c_int), ("ksx_slab", C.c_void_p), ("ksx_flags", C.c_void_p)])
 
+class LstmStep(C.Structure):
+    """cvc_lstm_step of include/cvc_hip.h ("Training loops driven from C"), field for field"""
+    _fields_ = ([("wp", C.c_void_p), ("xq", C.c_void_p), ("K", C.c_int), ("M", C.c_int), ("R", C.c_int)] +
+                [(n, C.c_void_p) for n in ("b_ih", "b_hh", "gate_pre", "row_bias", "row_index", "c_prev", "c_out", "gates_out", "h_out",
+                                           "h_out2", "h_drop_out", "rng_state")] +
+                [("site", C.c_uint), ("p", C.c_float), ("h_dst1_q", C.c_void_p), ("h_dst2_q", C.c_void_p)])
+
+
+class TrainLoop(C.Structure):
+    """cvc_train_loop of include/cvc_hip.h, field for field (tests/test_cabi.py compares the size with the C compiler's)."""
+    _fields_ = (
+        [(n, C.c_int) for n in ("kind", "B", "T", "R", "A", "N", "F", "attn_kind")] + [("inv_temp", C.c_float)] +
+        [(n, C.c_void_p) for n in ("wp_att", "wp_lang", "b_ih_att", "b_hh_att", "b_ih_lang", "b_hh_lang", "w_ih_att", "w_hh_att",
+                                   "w_ih_lang", "w_hh_lang")] +
+        [("ld_ih_att", C.c_int), ("ld_ih_lang", C.c_int)] +
+        [(n, C.c_void_p) for n in ("w_h", "b_h", "w_a", "b_a", "gpre_att", "row_bias", "row_index", "gpre_lang", "pool", "ppool", "conv",
+                                   "pconv", "mask", "frame_mask", "rng_state")] +
+        [("site0", C.c_uint), ("p", C.c_float)] +
+        [(n, C.c_void_p) for n in ("out", "h_att", "h_att_prev", "h_lang_prev", "c_att", "c_lang", "g_att", "g_lang", "ctx", "q", "attn_r",
+                                   "attn_f", "fm", "scores_ws")] +
+        [("xa", C.c_void_p * 2), ("xl", C.c_void_p * 2)] +
+        [(n, C.c_void_p) for n in ("d_out", "d_fm", "dg_att", "dg_lang", "dq", "dwa_part", "ds_r", "ds_f", "d_pool", "d_ppool", "d_conv",
+                                   "d_pconv", "bwd_ws")])
+
+
 # name -> argtypes, exactly the declarations of include/cvc_hip.h (tests/test_cabi.py checks both)
 SIGNATURES = {
+    "cvc_packed_lstm_step_fwd": [C.POINTER(LstmStep), _P],
+    "cvc_attn_wsum_quad_rm": [C.POINTER(AttnSet), _I, _I, _I, _P, _P, _P],
+    "cvc_attn_bwd_pair": [_I, _P, _P, _F, C.POINTER(AttnSet), _I, _P, _I, _I, _I, _I, _P, _P, _P, C.POINTER(_P), C.POINTER(_P), _P],
+    "cvc_lstm_pointwise_bwd4": [_P, _P, _P, _P, _P, C.c_uint, _F, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "cvc_train_loop_bwd_ws": [_I, _I, _I],
+    "cvc_train_loop_fwd": [C.POINTER(TrainLoop), _P],
+    "cvc_train_loop_bwd": [C.POINTER(TrainLoop), _P],
+    "cvc_train_loop_launches": [C.POINTER(TrainLoop), _I],
     "cvc_attn_fwd": [_I, _P, _P, _P, _F, C.POINTER(AttnSet), _I, _I, _I, _I, _I, _P, _P],
     "cvc_attn_scores": [_I, _P, _P, _P, _F, C.POINTER(AttnSet), _I, _I, _I, _I, _P],
     "cvc_attn_scores_qparts": [_I, _P, _I, _P, _P, _P, _F, C.POINTER(AttnSet), _I, _I, _I, _I, _P],
@@ -196,6 +229,7 @@ def lib() -> C.CDLL:
             fn.argtypes = argtypes
             fn.restype = None if name in _VOID_RETURN else C.c_int
         l.cvc_version.restype = C.c_char_p
+        l.cvc_train_loop_bwd_ws.restype = C.c_longlong
         l.cvc_version.argtypes = []
         _lib = l
     return _lib
@@ -778,10 +812,12 @@ class TileOperand:
                    "cvc_tile_pack_rows_any")
 
 
-def tile_mm(a, b, a_kmajor: bool = False, b_kmajor: bool = False) -> torch.Tensor:
+def tile_mm(a, b, a_kmajor: bool = False, b_kmajor: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C[M, N] = sum_k A[m, k] B[n, k] on the tile GEMM (split products on the bf16 MFMA, fp32 accumulate, fp32-grade error):
     the dense products of the backward pass -- no library GEMM.  `a` is [M, K], or [K, M] with a_kmajor (read as its transpose);
-    `b` is [N, K], or [K, N] with b_kmajor; either may be a TileOperand packed earlier (shared operands are packed once)."""
+    `b` is [N, K], or [K, N] with b_kmajor; either may be a TileOperand packed earlier (shared operands are packed once).
+    out: [M, N] fp32 with unit inner stride and any row stride (a column block of a wider matrix: the weight-gradient products
+    write their segment of weight_ih in place)."""
     A = a if isinstance(a, TileOperand) else TileOperand(a, a_kmajor)
     B = b if isinstance(b, TileOperand) else TileOperand(b, b_kmajor)
     assert A.K == B.K, (A.rows, A.K, B.rows, B.K)
@@ -789,11 +825,16 @@ def tile_mm(a, b, a_kmajor: bool = False, b_kmajor: bool = False) -> torch.Tenso
     Kp = (A.K + 15) // 16 * 16
     ntile, chunks = (N + 127) // 128, (tile_rows_alloc(M) + 319) // 320
     ks = max(1, min(256 // max(1, ntile * chunks), (Kp // 16) // 8))
-    out = torch.empty(M, N, device=A.frags.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(M, N, device=A.frags.device, dtype=torch.float32)
+    elif not (out.is_cuda and out.dtype == torch.float32 and tuple(out.shape) == (M, N) and out.stride(1) == 1
+              and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0):
+        raise RuntimeError("cvc.hip.tile_mm: out must be an fp32 GPU [M, N] view with unit inner stride, 16-byte aligned rows")
+    ldy = out.stride(0)
     if ks == 1:
-        _check(L.cvc_tile_gemm(B.ptr, A.ptr, A.stride, Kp, M, N, 1, out.data_ptr(), N, M * N, st), "cvc_tile_gemm")
+        _check(L.cvc_tile_gemm(B.ptr, A.ptr, A.stride, Kp, M, N, 1, out.data_ptr(), ldy, M * ldy, st), "cvc_tile_gemm")
         return out
     parts = torch.empty(ks, M, N, device=out.device, dtype=torch.float32)
     _check(L.cvc_tile_gemm(B.ptr, A.ptr, A.stride, Kp, M, N, ks, parts.data_ptr(), N, M * N, st), "cvc_tile_gemm")
-    _check(L.cvc_tile_linear_finish(parts.data_ptr(), ks, M * N, N, None, None, M, N, out.data_ptr(), N, st), "cvc_tile_linear_finish")
+    _check(L.cvc_tile_linear_finish(parts.data_ptr(), ks, M * N, N, None, None, M, N, out.data_ptr(), ldy, st), "cvc_tile_linear_finish")
     return out

@@ -53,10 +53,14 @@ def _masked_nll_mean(txt_input, target):
     return (total / count).reshape(())
 
 
-def _masked_nll_mean_from_logits(logits, target):
-    """Same value as _masked_nll_mean(log_softmax(logits), target), plus the per-row argmax, from one fused pass."""
-    w = _text_mask(target).reshape(-1).to(torch.float32)
-    total, argmax = F_.vocab_nll(logits, target.reshape(-1), w)
+def _masked_nll_mean_from_logits(logits, target, t_major=False):
+    """Same value as _masked_nll_mean(log_softmax(logits), target), plus the per-row argmax, from one fused pass.
+    t_major: the rows of `logits` are ordered t * B + b (the C-driven training loops' outputs) instead of b * T + t."""
+    w = _text_mask(target).to(torch.float32)
+    if t_major:
+        total, argmax = F_.vocab_nll(logits, target.t().reshape(-1), w.t().reshape(-1))
+        return (total / w.sum()).reshape(()), argmax.view(target.shape[1], target.shape[0]).t()
+    total, argmax = F_.vocab_nll(logits, target.reshape(-1), w.reshape(-1))
     return (total / w.sum()).reshape(()), argmax.view(target.shape)
 
 
@@ -73,12 +77,12 @@ class LMCriterion(nn.Module):
         loss = _masked_nll_mean(txt_input, target)
         return (loss, *self.attention_losses(att2_weights, ground_weights, att2_target))
 
-    def from_logits(self, logits, att2_weights, ground_weights, target, att2_target, input_seq):
+    def from_logits(self, logits, att2_weights, ground_weights, target, att2_target, input_seq, t_major=False):
         """forward() fed raw logits instead of log-probs: -> (lm_loss, att2_loss, ground_loss, argmax [B, T]).
         SURVEY section 8(f) rank 2: the criterion folded into the vocabulary head's epilogue pass."""
         if not torch.cuda.is_current_stream_capturing():
             assert torch.sum(target >= self.vocab_size) == 0
-        loss, argmax = _masked_nll_mean_from_logits(logits, target)
+        loss, argmax = _masked_nll_mean_from_logits(logits, target, t_major)
         return (loss, *self.attention_losses(att2_weights, ground_weights, att2_target), argmax)
 
     @staticmethod
@@ -99,8 +103,8 @@ class LanguageCriterion(nn.Module):
     def forward(self, txt_input, target):
         return _masked_nll_mean(txt_input, target)
 
-    def from_logits(self, logits, target):
-        return _masked_nll_mean_from_logits(logits, target)[0]
+    def from_logits(self, logits, target, t_major=False):
+        return _masked_nll_mean_from_logits(logits, target, t_major)[0]
 
 
 def bbox_overlaps(rois, gt_box, frm_mask):

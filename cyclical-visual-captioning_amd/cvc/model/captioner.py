@@ -194,8 +194,12 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         step_fmask = frm_mask_output[:, :, 1:].permute(1, 0, 2).contiguous()           # [T, B, N]
 
         # ---- Loop A: teacher-forced decode (sequential: LSTM recurrence)            reference :242-270
-        state = self._init_step_state(B)
         emb_all = self._embed(gt_caption[:, :T], "emb_a")                            # [B, T, E], one launch
+        loops = self._loop_plan(B, fc_feats)
+        if loops is not None:
+            return self._forward_loops_driven(loops, emb_all, gt_caption, input_seq, fc_feats, conv_feats, p_conv_feats, pool_feats,
+                                              p_pool_feats, g_pool_feats, region_mask, step_fmask, frm_mask_output, roi_labels, cls_loss)
+        state = self._init_step_state(B)
         outputs, masked_attn = [], []
         # one unbind per tensor instead of T selects: a select's backward is a zero-filled [B, T, E] tensor plus an
         # accumulation per step, unbind's is a single stack
@@ -218,15 +222,7 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
 
         # ---- grounder over all T                                                      reference :282-294
         xt_clamp = torch.clamp(input_seq[:, 1:T + 1, 0].clone() - self.vocab_size, min=0)
-        ve = self.roi_feat_extractor.vis_embed                                       # Embedding -> ReLU -> Dropout (backbone.py:55-57)
-        ve_seq = self.training and isinstance(ve, nn.Sequential) and len(ve) == 3 and isinstance(ve[2], nn.Dropout)
-        if ve_seq and 0 < ve[2].p < 1 and dropout.in_kernel(ve[0].weight) and isinstance(ve[0], nn.Embedding) and ve[0].weight.shape[1] % 4 == 0:
-            # lookup + ReLU + dropout in the embedding kernel, mask generated there
-            xt_all = F_.embed_relu(ve[0].weight, xt_clamp, rng=(dropout.rng_state(xt_clamp.device), dropout.site_id("vis_embed"), float(ve[2].p)))
-        elif dropout.active() and ve_seq:
-            xt_all = dropout.apply(ve[2], ve[1](ve[0](xt_clamp)), "vis_embed")       # dictated mask (train-mode parity tests)
-        else:
-            xt_all = ve(xt_clamp)
+        xt_all = self._vis_embed(xt_clamp)
         if hasattr(self.roi_feat_extractor, 'vis_classifiers_bias'):
             bias = self.roi_feat_extractor.vis_classifiers_bias[xt_clamp].type(xt_all.type()).unsqueeze(2).expand(
                 B, T, num_rois)
@@ -268,6 +264,86 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         lm_recon_loss = self.xe_criterion.from_logits(self._logits(torch.stack(rec_outputs, 1).view(B * T, -1)), target)
         return (lm_loss.reshape(1), att2_loss.reshape(1), ground_loss.reshape(1), cls_loss.reshape(1),
                 lm_recon_loss.reshape(1))
+
+    # ------------------------------------------------------------------ training pass on the C-driven loops
+    def _loop_plan(self, B, like):
+        """(attention kind, 1 / temperature, dropout spec of loop A, of loop C) when the two recurrent loops of this pass can run
+        as one C-driven autograd node each (cvc/train_loops.py), else None (per-step path: dictated dropout masks, library
+        dropout, more than 64 clips, widths the packed kernels do not take)."""
+        from .. import train_loops
+        from .modules import AdditiveSoftAttention
+        dc, rc = self.decoder_core, self.attended_roi_decoder_core
+        sa = dc.soft_attn
+        R, E, A = self.rnn_size, self.embed[0].weight.shape[1], sa.h2attn.weight.shape[0]
+        if not train_loops.eligible(B, R, E, A, like) or dropout.active():
+            return None
+        if not (dc.att_lstm.weight_ih.is_contiguous() and dc.lang_lstm.weight_ih.is_contiguous() and sa.h2attn.weight.is_contiguous()):
+            return None
+        specs = []
+        for mod, site in ((dc.dropout, "out_a.0"), (rc.dropout, "out_c.0")):
+            if mod.training and mod.p > 0:
+                if not (mod.p < 1 and dropout.in_kernel(like)):
+                    return None
+                specs.append((dropout.rng_state(like.device), dropout.site_id(site), float(mod.p)))
+            else:
+                specs.append(None)
+        additive = isinstance(sa, AdditiveSoftAttention)
+        return (hip.ATTN_ADDITIVE if additive else hip.ATTN_DOT, 1.0 if additive else 1.0 / float(sa.temp), specs[0], specs[1])
+
+    def _forward_loops_driven(self, plan, emb_all, gt_caption, input_seq, fc_feats, conv_feats, p_conv_feats, pool_feats, p_pool_feats,
+                              g_pool_feats, region_mask, step_fmask, frm_mask_output, roi_labels, cls_loss):
+        """_forward_3_loops from loop A on (reference :242-382) with loops A and C as one autograd node each; rows of the loops'
+        outputs are t-major (t * B + b), so the vocabulary head and its criterion run on t-major rows too."""
+        from .. import train_loops
+        attn_kind, inv_temp, drop_a, drop_c = plan
+        B, T, R = emb_all.shape[0], self.seq_length, self.rnn_size
+        num_rois = pool_feats.shape[1]
+        dc = self.decoder_core
+        fc_in = fc_feats if self.opts.global_img_in_attn_lstm else None
+        arena = train_loops.LoopArena(1 if self.opts.train_decoder_only else 2, T, B, R, emb_all.shape[2], emb_all.device)
+        out_a, fm = train_loops.decode_loop(arena, emb_all, fc_in, (pool_feats, p_pool_feats, conv_feats, p_conv_feats), region_mask,
+                                            step_fmask, dc.att_lstm, dc.lang_lstm, dc.soft_attn, attn_kind, inv_temp, drop_a)
+        att2_weights = fm.transpose(0, 1)                                             # [B, T, N] pre-softmax (:273)
+        lang_logits = self._logits(out_a.view(T * B, R))                              # rows t * B + b
+
+        # ---- grounder over all T                                                      reference :282-294
+        xt_clamp = torch.clamp(input_seq[:, 1:T + 1, 0].clone() - self.vocab_size, min=0)
+        xt_all = self._vis_embed(xt_clamp)
+        if hasattr(self.roi_feat_extractor, 'vis_classifiers_bias'):
+            bias = self.roi_feat_extractor.vis_classifiers_bias[xt_clamp].type(xt_all.type()).unsqueeze(2).expand(B, T, num_rois)
+        else:
+            bias = 0
+        ground_weights = self._grounder(xt_all, g_pool_feats, frm_mask_output[:, :, 1:], bias + att2_weights)
+        if self.debug_collect is not None:
+            self.debug_collect.update(ground_weights=ground_weights, att2_weights=att2_weights, roi_labels=roi_labels,
+                                      frm_mask_output=frm_mask_output)
+        target = gt_caption[:, 1:T + 1].clone()
+        lm_loss, att2_loss, ground_loss, output_seq = self.critLM.from_logits(
+            lang_logits, att2_weights, ground_weights, target, roi_labels[:, :T, :].clone(), input_seq[:, 1:T + 1, 0].clone(),
+            t_major=True)
+        if self.opts.train_decoder_only:                                              # reference :297-307
+            return lm_loss.reshape(1), att2_loss.reshape(1), ground_loss.reshape(1), cls_loss.reshape(1)
+
+        # ---- argmax cut, Loop B: localize (all T in one attention call)               reference :313-338
+        loc_emb = self._embed(output_seq, "emb_b")                                   # [B, T, E]
+        ctx_all = self.localizer_core.forward_all_steps_sum(loc_emb, conv_feats, p_conv_feats, pool_feats, p_pool_feats, region_mask)
+
+        # ---- Loop C: reconstruct from the localized regions                          reference :348-362
+        emb_all_c = self._embed(gt_caption[:, :T], "emb_c") if self.training else emb_all      # fresh dropout mask in training
+        out_c = train_loops.recon_loop(arena, emb_all_c, fc_in, ctx_all, dc.att_lstm, dc.lang_lstm, dc.soft_attn, attn_kind, drop_c)
+        lm_recon_loss = self.xe_criterion.from_logits(self._logits(out_c.view(T * B, R)), target, t_major=True)
+        return (lm_loss.reshape(1), att2_loss.reshape(1), ground_loss.reshape(1), cls_loss.reshape(1), lm_recon_loss.reshape(1))
+
+    def _vis_embed(self, xt_clamp):
+        """roi_feat_extractor.vis_embed (Embedding -> ReLU -> Dropout, backbone.py:55-57) on the grounder's class indices"""
+        ve = self.roi_feat_extractor.vis_embed
+        ve_seq = self.training and isinstance(ve, nn.Sequential) and len(ve) == 3 and isinstance(ve[2], nn.Dropout)
+        if ve_seq and 0 < ve[2].p < 1 and dropout.in_kernel(ve[0].weight) and isinstance(ve[0], nn.Embedding) and ve[0].weight.shape[1] % 4 == 0:
+            # lookup + ReLU + dropout in the embedding kernel, mask generated there
+            return F_.embed_relu(ve[0].weight, xt_clamp, rng=(dropout.rng_state(xt_clamp.device), dropout.site_id("vis_embed"), float(ve[2].p)))
+        if dropout.active() and ve_seq:
+            return dropout.apply(ve[2], ve[1](ve[0](xt_clamp)), "vis_embed")         # dictated mask (train-mode parity tests)
+        return ve(xt_clamp)
 
     # ------------------------------------------------------------------ inference
     def decode_weights(self) -> DecodeWeights:

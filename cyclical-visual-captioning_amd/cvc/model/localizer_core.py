@@ -32,3 +32,11 @@ class LocalizerNoLSTMCore(nn.Module):
             self.soft_attn, embedded_words.reshape(B * T, E),
             [(p_pool_feats, pool_feats, attn_mask, None), (p_conv_feats, conv_feats, None, None)])
         return loc_feat.view(B, T, -1), loc_conv.view(B, T, -1), loc_prob.view(B, T, -1)
+
+    def forward_all_steps_sum(self, embedded_words, conv_feats, p_conv_feats, pool_feats, p_pool_feats, attn_mask):
+        """forward_all_steps returning only loc_feat + loc_conv [B, T, R] -- the one quantity the reconstruction loop reads
+        (decoder_core.py:106: weighted_pool_feat + attn_conv), summed inside the attention kernel."""
+        B, T, E = embedded_words.shape
+        total, _sets = _soft_attn_pair(self.soft_attn, embedded_words.reshape(B * T, E),
+                                       [(p_pool_feats, pool_feats, attn_mask, None), (p_conv_feats, conv_feats, None, None)])
+        return total.view(B, T, -1)

@@ -668,6 +668,118 @@ int cvc_decode_greedy(cvc_decode_plan* plan, cvc_stream_t stream);
 int cvc_decode_beam(cvc_decode_plan* plan, cvc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Training loops driven from C (round 4): the two recurrent loops of the cyclical training pass -- loop A, the teacher-forced
+ * decode (model/captioner.py:242-270 calling decoder_core.py:30-66), and loop C, the reconstruction from the localized regions
+ * (captioner.py:348-362 calling decoder_core.py:86-113) -- and their back-propagation through time, each ONE host call that
+ * enqueues every launch of the T steps on `stream` (capturable), like cvc_decode_greedy does for inference.  Nothing of the
+ * per-step work is left to the host framework: the cells hand h' to their consumers in the layouts those read (quad operand
+ * rings for the next gate GEMMs, row-major rows for the dense weight-gradient products that follow the loop), the gradient
+ * fan-in of h (three consumers per step) is summed inside the gate-gradient kernel, both feature sets of the attention go
+ * through one backward.
+ *
+ * What stays outside (dense, once per loop, on the tile GEMM): the hoisted input products -- gpre_att = relu(Emb[w_t]) x
+ * W_ih_att[:, emb]^T for all T steps, row_bias = fc_feats x W_ih_att[:, fc]^T + b_ih + b_hh, loop C's gpre_lang = (localized
+ * context) x W_ih_lang[:, :R]^T -- the vocabulary head, and after the backward loop every weight gradient as ONE product over the
+ * T * B sample rows from the row-major buffers below (dW_ih_att[:, :R] = dg_att^T h_lang_prev, dW_hh_att = dg_att^T h_att_prev,
+ * dW_ih_lang = dg_lang^T [ctx | h_att], dW_hh_lang = dg_lang^T h_lang_prev, dW_h2attn = dq^T h_att, ...).
+ *
+ * Building blocks, also exported on their own:
+ *   cvc_packed_lstm_step_fwd : the general training form of the packed gate GEMM + cell update (nn.LSTMCell,
+ *                              decoder_core.py:50, 61): every output of cvc_packed_lstm_train_drop_fwd AND the quad destinations
+ *                              of cvc_packed_lstm_fwd, plus a second per-row gate term gathered by row index;
+ *   cvc_attn_wsum_quad_rm    : cvc_attn_wsum_quad that also writes the summed context row-major [rows, R];
+ *   cvc_attn_bwd_pair        : cvc_attn_bwd for both feature sets of a decoder step at once (they share the query and d_ctx):
+ *                              one score pass, one softmax backward, one score backward whose d_q is the sum over the sets,
+ *                              written row-major and (nullable) in the quad layout cvc_linear_nn_fwd reads;
+ *   cvc_lstm_pointwise_bwd4  : cvc_lstm_pointwise_bwd3 with a fourth gradient of h', the one that left through the fused
+ *                              dropout (decoder_core.py:62, 109), summed in the order d_h1, d_h2, d_h3, d_hd.
+ */
+typedef struct cvc_lstm_step {
+    const float* wp;             /* packed gate weights (cvc_pack_lstm_segs), K columns                                  */
+    const float* xq;             /* quad-layout activations [K/4][64][4]                                                 */
+    int K, M, R;
+    const float *b_ih, *b_hh;    /* [4R], nullable                                                                       */
+    const float* gate_pre;       /* [M, 4R] row-major additive pre-activation term, nullable                             */
+    const float* row_bias;       /* [*, 4R]: row row_index[m] is added to row m's pre-activations, nullable              */
+    const int64_t* row_index;    /* [M] (with row_bias)                                                                  */
+    const float* c_prev;         /* [M, R] row-major                                                                     */
+    float *c_out, *gates_out;    /* [M, R]; activated gates [M, 4R] (i, f, g, o), nullable                               */
+    float *h_out, *h_out2;       /* row-major copies of h' [M, R], nullable                                              */
+    float* h_drop_out;           /* [M, R] nn.Dropout(h') with the counter-based mask (rng_state null or p == 0: h'), nullable */
+    const uint32_t* rng_state; unsigned site; float p;
+    float *h_dst1_q, *h_dst2_q;  /* h' in the quad layout at the consumers' K offsets, nullable                           */
+} cvc_lstm_step;
+int cvc_packed_lstm_step_fwd(const cvc_lstm_step* s, cvc_stream_t stream);
+
+int cvc_attn_wsum_quad_rm(const cvc_attn_set* sets, int nsets, int nclip, int R, float* ctx_sum_q, float* ctx_sum_rm,
+                          cvc_stream_t stream);            /* one query per clip (nq = 1), nclip <= 64 */
+
+/* sets[s]: proj / ctx / attn / n as in the forward; scores = d_scores out [rows, n] (the pre-softmax gradient; its sum is
+ * d_b_alpha); frame_masked = gradient of the frame-masked output (d_fm, INPUT, nullable); ctx_out unused.  d_ctx [rows, R] is
+ * the gradient of the summed context.  d_q [rows, A] row-major, d_q_q (nullable, rows <= 64) the same in the quad layout
+ * [A/4][64][4], d_w_part [rows, A] (additive only, nullable) per-row partials of d_w_alpha summed over the sets.
+ * d_proj[s] / d_ctxfeat[s] (nullable): ACCUMULATED feature gradients [nclip, n, A] / [nclip, n, R]. */
+int cvc_attn_bwd_pair(int kind, const float* q, const float* w_a, float inv_temp, const cvc_attn_set* sets, int nsets,
+                      const float* d_ctx, int nclip, int nq, int A, int R, float* d_q, float* d_q_q, float* d_w_part,
+                      float* const* d_proj, float* const* d_ctxfeat, cvc_stream_t stream);
+
+int cvc_lstm_pointwise_bwd4(const float* d_h1, const float* d_h2, const float* d_h3, const float* d_hd,
+                            const uint32_t* rng_state, unsigned site, float p, const float* d_c, const float* gates,
+                            const float* c_prev, const float* c_new, int M, int R, float* d_gates, float* d_c_prev,
+                            float* d_gates_q, cvc_stream_t stream);
+
+typedef struct cvc_train_loop {
+    int kind;                    /* 0 = loop A (decode step with attention), 1 = loop C (reconstruction step)            */
+    int B, T, R;                 /* B <= 64 clips, R % 32 == 0                                                           */
+    int A, N, F, attn_kind;      /* kind 0: attention sizes, CVC_ATTN_*                                                  */
+    float inv_temp;
+    /* ---- weights.  Packs (cvc_pack_lstm_segs, rebuilt once per optimizer step): wp_att over [W_ih_att[:, :R] | W_hh_att]
+     * (K = 2R: h_lang(t-1), h_att(t-1)); wp_lang over [W_ih_lang | W_hh_lang] (kind 0, K = 3R: ctx, h_att(t), h_lang(t-1)) or
+     * [W_ih_lang[:, R:] | W_hh_lang] (kind 1, K = 2R).  The row-major checkpoint tensors serve the backward-data products. */
+    const float *wp_att, *wp_lang;
+    const float *b_ih_att, *b_hh_att, *b_ih_lang, *b_hh_lang;
+    const float *w_ih_att, *w_hh_att, *w_ih_lang, *w_hh_lang;
+    int ld_ih_att, ld_ih_lang;   /* leading dimensions of weight_ih (R + [R] + E, 2R); weight_hh has R                   */
+    const float *w_h, *b_h;      /* kind 0: h2attn [A, R], [A]                                                           */
+    const float *w_a, *b_a;      /* kind 0, additive: alpha_net weight [A], bias [1]                                     */
+    /* ---- inputs */
+    const float* gpre_att;       /* [T][B][4R] hoisted gates of the attention cell (embedded word of every step)         */
+    const float* row_bias;       /* [B][4R] fc_feats term + both biases of the attention cell (then b_*_att are null), nullable */
+    const int64_t* row_index;    /* [B] = 0 .. B-1                                                                       */
+    const float* gpre_lang;      /* kind 1: [T][B][4R] hoisted gates of the language cell (localized context)            */
+    const float *pool, *ppool, *conv, *pconv;      /* kind 0: [B,N,R], [B,N,A], [B,F,R], [B,F,A]                         */
+    const uint8_t* mask;         /* kind 0: [B, N], nullable                                                             */
+    const uint8_t* frame_mask;   /* kind 0: [T][B][N], nullable                                                          */
+    const uint32_t* rng_state; unsigned site0; float p;     /* output dropout of step t: site site0 + t (p == 0: none)    */
+    /* ---- forward outputs = what the backward and the dense products read; t-major rows (t * B + b)                     */
+    float* out;                  /* [T][B][R] dropout(h_lang(t))                                                         */
+    float* h_att;                /* [T][B][R] h_att(t)                                                                   */
+    float* h_att_prev;           /* [T][B][R] h_att(t-1), row block 0 zero                                               */
+    float* h_lang_prev;          /* [T][B][R] h_lang(t-1), row block 0 zero                                              */
+    float *c_att, *c_lang;       /* [T+1][B][R], row block 0 zero                                                        */
+    float *g_att, *g_lang;       /* [T][B][4R] activated gates                                                           */
+    float* ctx;                  /* kind 0: [T][B][R] attended context (regions + frames)                                */
+    float* q;                    /* kind 0: [T][B][A] h2attn(h_att(t))                                                   */
+    float *attn_r, *attn_f;      /* kind 0: [T][B][N], [T][B][F] softmax weights                                         */
+    float* fm;                   /* kind 0: [T][B][N] frame-masked pre-softmax scores (with frame_mask), nullable        */
+    float* scores_ws;            /* kind 0: B * (N + F) floats                                                           */
+    float *xa[2], *xl[2];        /* quad operand rings: [2R/4][64][4] and [3R/4][64][4] (kind 1: 2R) each                */
+    /* ---- backward */
+    const float* d_out;          /* [T][B][R]                                                                            */
+    const float* d_fm;           /* kind 0: [T][B][N], nullable                                                          */
+    float *dg_att, *dg_lang;     /* [T][B][4R] pre-activation gate gradients                                             */
+    float* dq;                   /* kind 0: [T][B][A]                                                                    */
+    float* dwa_part;             /* kind 0, additive: [T][B][A]                                                          */
+    float *ds_r, *ds_f;          /* kind 0: [T][B][N], [T][B][F] gradients of the pre-softmax scores                     */
+    float *d_pool, *d_ppool, *d_conv, *d_pconv;    /* kind 0: accumulated feature gradients, nullable                    */
+    float* bwd_ws;               /* cvc_train_loop_bwd_ws(B, R, A) floats, ZERO before the first use                     */
+} cvc_train_loop;
+long long cvc_train_loop_bwd_ws(int B, int R, int A);
+int cvc_train_loop_fwd(const cvc_train_loop* loop, cvc_stream_t stream);
+int cvc_train_loop_bwd(const cvc_train_loop* loop, cvc_stream_t stream);
+int cvc_train_loop_launches(const cvc_train_loop* loop, int backward);     /* launches one call enqueues */
+
+/* ---------------------------------------------------------------------------------------
  * Optimizer step of the training path (trainer.py:116-122: nn.utils.clip_grad_norm_ -> optimizer.step(); Adam with one group per
  * tensor, main.py:171-191).  cvc_adam_clip_step = global L2 norm of all gradients (chunk sums combined in chunk order:
  * deterministic), clip coefficient min(1, max_norm / (inv_world * norm + 1e-6)) * inv_world (inv_world = 1 / ranks when the

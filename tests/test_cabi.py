@@ -13,7 +13,7 @@ HEADER = os.path.join(ROOT, "include", "cvc_hip.h")
 def declared_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|void|const char\*)\s+(cvc_\w+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|void|long long|const char\*)\s+(cvc_\w+)\s*\(", src)))
 
 
 def test_library_builds_and_loads():
@@ -67,6 +67,33 @@ def test_decode_descriptor_layout_matches_the_c_compiler(tmp_path):
     D = hip.DecodeDesc
     want = [ctypes.sizeof(D), D.inv_temp.offset, D.w_fc.offset, D.words.offset, D.xa.offset, D.beam_ws.offset]
     assert got == want, (got, want)
+
+
+def test_train_loop_descriptor_layouts_match_the_c_compiler(tmp_path):
+    """cvc.hip.TrainLoop / LstmStep (ctypes) against cvc_train_loop / cvc_lstm_step as the host C compiler lays them out"""
+    import subprocess
+    from cvc import hip
+    src = tmp_path / "probe.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(void) { printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n", '
+                   'sizeof(cvc_train_loop), offsetof(cvc_train_loop, inv_temp), offsetof(cvc_train_loop, ld_ih_att), '
+                   'offsetof(cvc_train_loop, w_h), offsetof(cvc_train_loop, site0), offsetof(cvc_train_loop, out), '
+                   'offsetof(cvc_train_loop, xa), offsetof(cvc_train_loop, bwd_ws), sizeof(cvc_lstm_step)); return 0; }\n' % HEADER)
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-o", str(exe), str(src)])
+    got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
+    D = hip.TrainLoop
+    want = [ctypes.sizeof(D), D.inv_temp.offset, D.ld_ih_att.offset, D.w_h.offset, D.site0.offset, D.out.offset, D.xa.offset,
+            D.bwd_ws.offset, ctypes.sizeof(hip.LstmStep)]
+    assert got == want, (got, want)
+
+
+def test_train_loop_rejects_incomplete_descriptors():
+    from cvc import hip
+    lib = hip.lib()
+    d = hip.TrainLoop()
+    assert lib.cvc_train_loop_fwd(ctypes.byref(d), None) == -1 and lib.cvc_train_loop_bwd(ctypes.byref(d), None) == -1
+    assert lib.cvc_train_loop_fwd(None, None) == -1
+    assert lib.cvc_train_loop_bwd_ws(64, 2048, 1024) > 0 and lib.cvc_train_loop_bwd_ws(65, 2048, 1024) == 0
 
 
 def test_decode_plan_rejects_incomplete_descriptors():

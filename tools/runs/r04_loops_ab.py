@@ -1,0 +1,81 @@
+"""A/B of the C-driven training loops (cvc/train_loops.py) against the per-step autograd path: losses + every parameter gradient,
+eval mode and train mode (in-kernel dropout: both paths hash the same (seed, step, site, index)), then timing at config 3."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "cyclical-visual-captioning_amd"), os.path.join(ROOT, "tests")]
+import dataclasses
+import numpy as np
+import torch
+from cvc import synth, train_loops, dropout
+from helpers import build_model, to_dev, model_call
+
+dev = torch.device("cuda:0")
+
+
+def run(model, f, b, mix=(0.5, 0.0, 0.0, 0.5)):
+    for p in model.parameters():
+        p.grad = None
+    ls = model_call(model, f, b, False)
+    loss = mix[0] * ls[0].mean() + mix[1] * ls[1].mean() + mix[2] * ls[3].mean() + (mix[3] * ls[4].mean() if len(ls) > 4 else 0)
+    loss.backward()
+    torch.cuda.synchronize()
+    return [l.detach().clone() for l in ls], {k: (p.grad.clone() if p.grad is not None else None) for k, p in model.named_parameters()}
+
+
+def compare(name, d, train, mix=(0.5, 0.0, 0.0, 0.5), **over):
+    sd = synth.hot_path_state_dict(d, 7)
+    if over.get("softattn_type") == "dot":
+        sd = {k: v for k, v in sd.items() if "alpha_net" not in k}
+    model = build_model(d, sd, dev, **over)
+    if train:
+        model.train()
+    f, b = to_dev(synth.clip_features(d, 7, full_mask_clip=1 if d.B > 1 else None), dev), to_dev(synth.label_glue_batch(d, 7), dev)
+    res = {}
+    for on in (False, True):
+        train_loops.ENABLED = on
+        dropout.seed(123)
+        res[on] = run(model, f, b, mix)
+    worst = 0.0
+    for a, r in zip(res[True][0], res[False][0]):
+        worst = max(worst, float((a - r).abs().max() / (r.abs().max() + 1e-12)))
+    gworst, gname = 0.0, None
+    for k, g in res[False][1].items():
+        g2 = res[True][1][k]
+        assert (g is None) == (g2 is None), (k, g is None, g2 is None)
+        if g is None:
+            continue
+        e = float((g - g2).norm() / (g.norm() + 1e-30))
+        if float(g.norm()) < 1e-6 and float((g - g2).norm()) < 1e-6:
+            # (alpha_net.bias without a supervised attention loss: its gradient is sum_n of a softmax backward = 0 up to rounding)
+            print(f"   {k}: |g| = {float(g.norm()):.2e} / {float(g2.norm()):.2e}, both rounding noise", flush=True)
+            continue
+        if e > gworst:
+            gworst, gname = e, k
+    print(f"{name}: train={train} losses rel {worst:.2e}  grads rel {gworst:.2e} ({gname})", flush=True)
+    assert worst < 2e-5 and gworst < 5e-4, name
+
+
+tiny = synth.CONFIGS["tiny"]
+compare("tiny", tiny, False)
+compare("tiny all losses", tiny, False, mix=(0.5, 0.3, 0.2, 0.5))
+compare("tiny", tiny, True)
+compare("tiny decoder-only", tiny, False, train_decoder_only=True)
+compare("tiny dot attention", tiny, False, softattn_type="dot", softmax_temp=2.0)
+mid = dataclasses.replace(synth.CONFIGS["cfg1"], B=5)
+compare("cfg1 B=5", mid, False)
+compare("cfg1 B=5", mid, True)
+if "--big" in sys.argv:
+    d = synth.CONFIGS["cfg3"]
+    compare("cfg3", d, True)
+    sd = synth.hot_path_state_dict(d, 7)
+    model = build_model(d, sd, dev).train()
+    f, b = to_dev(synth.clip_features(d, 7), dev), to_dev(synth.label_glue_batch(d, 7), dev)
+    for on in (False, True):
+        train_loops.ENABLED = on
+        for _ in range(3):
+            run(model, f, b)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            run(model, f, b)
+        print(f"cfg3 fwd+bwd loops={on}: {(time.perf_counter() - t0) / 10 * 1e3:.2f} ms", flush=True)
+print("ok")
