@@ -223,7 +223,8 @@ __global__ __launch_bounds__(WG) void softmax_bwd2_kernel(SoftmaxBwd2Args a) {
 }
 
 struct ScoreBwd2Args {
-    const float* q;        // [rows, A]
+    cvc_grad_src q;        // [rows, A], possibly as the split-K planes of the h2attn product (+ q_bias)
+    const float* q_bias;   // [A] or null
     const float* w_a;      // [A]
     const float* proj[2];  // [nclip, n_s, A]
     const float* d_scores[2];
@@ -251,7 +252,13 @@ __global__ __launch_bounds__(WG) void attn_score_bwd2_kernel(ScoreBwd2Args a) {
     if (KIND == CVC_ATTN_ADDITIVE && ok) w4 = ld4(a.w_a + col);
     for (int qi = 0; qi < a.nq; ++qi) {
         const size_t row = (size_t)clip * a.nq + qi;
-        f32x4 q4 = ok ? ld4(a.q + row * A + col) : f32x4{0, 0, 0, 0};
+        f32x4 q4 = {0, 0, 0, 0};
+        if (ok) {
+            const float* qp = a.q.p + row * a.q.ld + col;
+            q4 = ld4(qp);
+            for (int k = 1; k < a.q.nplanes; ++k) q4 += ld4(qp + (size_t)k * a.q.plane_stride);
+            if (a.q_bias != nullptr) q4 += ld4(a.q_bias + col);
+        }
         f32x4 dq = {0, 0, 0, 0}, dw = {0, 0, 0, 0};
         for (int s = 0; s < a.nsets; ++s) {
             const int n = s ? a.n[1] : a.n[0];
@@ -310,10 +317,15 @@ __global__ __launch_bounds__(WG) void attn_score_bwd2_kernel(ScoreBwd2Args a) {
 
 }  // namespace
 
-extern "C" int cvc_attn_bwd_pair(int kind, const float* q, const float* w_a, float inv_temp, const cvc_attn_set* sets, int nsets,
-                                 const float* d_ctx, int nclip, int nq, int A, int R, float* d_q, float* d_q_q, float* d_w_part,
-                                 float* const* d_proj, float* const* d_ctxfeat, cvc_stream_t stream) {
-    if (!q || !sets || nsets < 1 || nsets > 2 || !d_q || nclip < 1 || nq < 1 || (A & 3) || (R & 3)) return CVC_E_BADARG;
+extern "C" int cvc_attn_bwd_pair(int kind, const cvc_grad_src* q, const float* q_bias, const float* w_a, float inv_temp,
+                                 const cvc_attn_set* sets, int nsets, const cvc_grad_src* d_ctx_src, int nclip, int nq, int A, int R,
+                                 float* d_q, float* d_q_q, float* d_w_part, float* const* d_proj, float* const* d_ctxfeat,
+                                 cvc_stream_t stream) {
+    if (!q || !q->p || q->nplanes < 1 || q->ld < A || (q->ld & 3) || (q->plane_stride & 3)) return CVC_E_BADARG;
+    const float* d_ctx = d_ctx_src != nullptr ? d_ctx_src->p : nullptr;
+    if (d_ctx != nullptr && (d_ctx_src->nplanes < 1 || d_ctx_src->ld < R)) return CVC_E_BADARG;
+    if (d_ctx != nullptr && d_ctxfeat != nullptr && (d_ctx_src->nplanes != 1 || d_ctx_src->ld != R)) return CVC_E_BADARG;
+    if (!sets || nsets < 1 || nsets > 2 || !d_q || nclip < 1 || nq < 1 || (A & 3) || (R & 3)) return CVC_E_BADARG;
     if (kind != CVC_ATTN_ADDITIVE && kind != CVC_ATTN_DOT) return CVC_E_BADARG;
     if (kind == CVC_ATTN_ADDITIVE && !w_a) return CVC_E_BADARG;
     const int rows = nclip * nq;
@@ -328,7 +340,8 @@ extern "C" int cvc_attn_bwd_pair(int kind, const float* q, const float* w_a, flo
             ss[s].proj = sets[s].ctx; ss[s].ctx = sets[s].ctx; ss[s].scores = sets[s].scores; ss[s].attn = sets[s].scores;
             ss[s].n = sets[s].n;
         }
-        int rc = run_scores(CVC_ATTN_DOT, d_ctx, nullptr, nullptr, 1.f, ss, nsets, nclip, nq, R, st);
+        int rc = run_scores(CVC_ATTN_DOT, d_ctx, nullptr, nullptr, 1.f, ss, nsets, nclip, nq, R, st, d_ctx_src->nplanes, nullptr,
+                            nullptr, d_ctx_src->ld, d_ctx_src->plane_stride);
         if (rc) return rc;
     }
     SoftmaxBwd2Args sm{};
@@ -341,7 +354,7 @@ extern "C" int cvc_attn_bwd_pair(int kind, const float* q, const float* w_a, flo
     }
     sm.have_da = d_ctx != nullptr ? 1 : 0;
     hipLaunchKernelGGL(softmax_bwd2_kernel, dim3(rows, nsets), dim3(WG), 0, st, sm);
-    a.q = q; a.w_a = w_a; a.nsets = nsets; a.d_q = d_q; a.d_q_q = d_q_q; a.d_w_part = d_w_part; a.inv_temp = inv_temp; a.nq = nq; a.A = A;
+    a.q = *q; a.q_bias = q_bias; a.w_a = w_a; a.nsets = nsets; a.d_q = d_q; a.d_q_q = d_q_q; a.d_w_part = d_w_part; a.inv_temp = inv_temp; a.nq = nq; a.A = A;
     dim3 grid((A + 255) / 256, nclip);
     const bool want_dp = a.d_proj[0] != nullptr || a.d_proj[1] != nullptr;
     if (kind == CVC_ATTN_ADDITIVE) {

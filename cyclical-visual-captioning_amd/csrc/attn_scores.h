@@ -20,6 +20,7 @@ struct ScoreArgs {
     const float* q_bias;           // [A] added once (h2attn.bias) or null
     int q_nparts;
     long long q_part_stride;
+    long long q_ld;                // floats between the rows of q (A when dense; the K-slice planes of a backward-data product are wider)
     const float* w_a;              // [A] (additive)
     const float* b_a;              // device scalar (alpha_net.bias) or null
     float inv_temp;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(SCORE_WG) void attn_scores_kernel(ScoreArgs a) {
             for (int p = 1; p < nseg; ++p) v += ld4(src + (size_t)p * (8 * 2048));
             if (a.q_bias != nullptr) v += ld4(a.q_bias + col);
         } else if (i < nq * A) {
-            const float* src = a.q + ((size_t)clip * a.nq_total + a.q0) * A + i;
+            const float* src = a.q + ((size_t)clip * a.nq_total + a.q0 + i / A) * a.q_ld + i % A;
             v = ld4(src);
             for (int p = 1; p < a.q_nparts; ++p) v += ld4(src + (size_t)p * a.q_part_stride);
             if (a.q_bias != nullptr) v += ld4(a.q_bias + (i % A));
@@ -223,7 +224,8 @@ int launch_scores(const ScoreArgs& a, dim3 grid, size_t lds, hipStream_t st) {
 // a clip (plus alpha_net's weight) fit 64 KB of LDS.
 inline int run_scores(int kind, const float* q, const float* w_a, const float* b_a, float inv_temp,
                       const cvc_attn_set* sets, int nsets, int nclip, int nq, int A, hipStream_t st,
-                      int q_nparts = 1, const float* q_bias = nullptr, const GskSegs* q_slab = nullptr) {
+                      int q_nparts = 1, const float* q_bias = nullptr, const GskSegs* q_slab = nullptr, long long q_ld = 0,
+                      long long q_part_stride = 0) {
     int q_per_launch = (int)((64 * 1024) / ((size_t)A * 4)) - 1;
     if (q_per_launch < 1) return CVC_E_TOOBIG;
     if (q_per_launch > nq) q_per_launch = nq;
@@ -237,7 +239,9 @@ inline int run_scores(int kind, const float* q, const float* w_a, const float* b
     sa.chunks0 = (sets[0].n + ROWS_PER_WG - 1) / ROWS_PER_WG;
     const int chunks1 = nsets > 1 ? (sets[1].n + ROWS_PER_WG - 1) / ROWS_PER_WG : 0;
     sa.q = q; sa.w_a = w_a; sa.b_a = b_a; sa.inv_temp = inv_temp; sa.A = A; sa.nq_total = nq;
-    sa.q_nparts = q_nparts < 1 ? 1 : q_nparts; sa.q_bias = q_bias; sa.q_part_stride = (long long)nclip * nq * A;
+    sa.q_nparts = q_nparts < 1 ? 1 : q_nparts; sa.q_bias = q_bias;
+    sa.q_ld = q_ld > 0 ? q_ld : A;
+    sa.q_part_stride = q_part_stride > 0 ? q_part_stride : (long long)nclip * nq * A;
     sa.q_from_slab = q_slab != nullptr;
     sa.q_slab = q_slab != nullptr ? *q_slab : GskSegs{};
     dim3 g1(sa.chunks0 + chunks1, nclip);

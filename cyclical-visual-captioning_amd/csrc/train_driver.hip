@@ -48,6 +48,7 @@ int validate(const cvc_train_loop& L, bool backward) {
         if (!L.w_h || !L.b_h || !L.pool || !L.ppool || !L.conv || !L.pconv || !L.ctx || !L.q || !L.attn_r || !L.attn_f || !L.scores_ws)
             return CVC_E_BADARG;
         if ((L.frame_mask != nullptr) != (L.fm != nullptr)) return CVC_E_BADARG;
+        if (L.wp_h != nullptr && (L.q_split < 1 || L.q_split > 16 || (L.A & 31))) return CVC_E_BADARG;
     } else if (!L.gpre_lang) {
         return CVC_E_BADARG;
     }
@@ -91,15 +92,21 @@ int run_fwd(const cvc_train_loop& L, hipStream_t st, int* launches) {
         CVC_TRY(cvc_packed_lstm_step_fwd(&a, st));
         if (L.kind == 0) {
             // ---- additive / dot attention over regions + frames with one query (decoder_core.py:54-56, modules.py:100-159)
-            float* q = L.q + (size_t)t * B * A;
-            cvc_gemm_seg seg{L.h_att + (size_t)t * BR, nullptr, L.w_h, R, R, R, 0};
-            CVC_TRY(cvc_linear_fwd(&seg, 1, L.b_h, nullptr, B, A, q, A, st));
+            const int qs = L.wp_h ? L.q_split : 1;
+            float* q = L.q + (size_t)t * qs * B * A;
+            if (L.wp_h) {       // split-K over the chip on the packed kernel, planes summed (+ bias) while the score pass loads the query
+                CVC_TRY(cvc_packed_linear_fwd(L.wp_h, quad_off(L.xl[rd], ha_off), R, nullptr, B, A, qs, q, A, nullptr, st));
+            } else {
+                cvc_gemm_seg seg{L.h_att + (size_t)t * BR, nullptr, L.w_h, R, R, R, 0};
+                CVC_TRY(cvc_linear_fwd(&seg, 1, L.b_h, nullptr, B, A, q, A, st));
+            }
             cvc_attn_set sets[2];
             sets[0] = cvc_attn_set{L.ppool, L.pool, L.mask, L.frame_mask ? L.frame_mask + (size_t)t * B * N : nullptr, L.scores_ws,
                                    L.fm ? L.fm + (size_t)t * B * N : nullptr, L.attn_r + (size_t)t * B * N, nullptr, N, 0};
             sets[1] = cvc_attn_set{L.pconv, L.conv, nullptr, nullptr, L.scores_ws + (size_t)B * N, nullptr,
                                    L.attn_f + (size_t)t * B * F, nullptr, F, 0};
-            CVC_TRY(cvc_attn_scores(L.attn_kind, q, L.w_a, L.b_a, L.inv_temp, sets, 2, B, 1, A, st));
+            if (L.wp_h) CVC_TRY(cvc_attn_scores_qparts(L.attn_kind, q, qs, L.b_h, L.w_a, L.b_a, L.inv_temp, sets, 2, B, 1, A, st));
+            else CVC_TRY(cvc_attn_scores(L.attn_kind, q, L.w_a, L.b_a, L.inv_temp, sets, 2, B, 1, A, st));
             CVC_TRY(cvc_attn_wsum_quad_rm(sets, 2, B, R, L.xl[rd], L.ctx + (size_t)t * BR, st));
         }
         // ---- language LSTM (decoder_core.py:59-62 / :106-109) + output dropout
@@ -121,7 +128,8 @@ int run_fwd(const cvc_train_loop& L, hipStream_t st, int* launches) {
 
 // ---------------------------------------------------------------------------------------------------------------- backward
 struct BwdWs {
-    float *dgq, *dqq, *d_ctx, *d_ha_a, *d_ha_b, *d_ha_prev, *d_hl_a, *d_hl_b, *d_c_att, *d_c_lang, *nn;
+    float *dgq, *dqq, *d_ctx, *d_ha_a, *d_ha_b, *d_ha_prev, *d_hl_a, *d_hl_b, *d_c_att, *d_c_lang;
+    float *nn_l, *nn_h, *nn_a;       // K-slice planes of the three backward-data products of a step (each lives until its consumers ran)
     long long total;
 };
 BwdWs carve(float* base, int B, int R, int A) {
@@ -134,45 +142,64 @@ BwdWs carve(float* base, int B, int R, int A) {
     const size_t br = (size_t)64 * R;
     w.d_ctx = take(br); w.d_ha_a = take(br); w.d_ha_b = take(br); w.d_ha_prev = take(br);
     w.d_hl_a = take(br); w.d_hl_b = take(br); w.d_c_att = take(br); w.d_c_lang = take(br);
-    // K-slice planes of cvc_linear_nn_fwd: ksplit * M * ntot floats with ksplit * slabs <= max(256, slabs)
+    // planes of cvc_linear_nn_planes_fwd: ksplit * M * ntot floats with ksplit * slabs <= max(256, slabs)
     const size_t slabs_max = (size_t)(3 * R + 127) / 128;
-    w.nn = take((size_t)64 * 128 * (slabs_max > 512 ? slabs_max : 512));
+    const size_t plane = (size_t)64 * 128 * (slabs_max > 512 ? slabs_max : 512);
+    w.nn_l = take(plane); w.nn_h = take(plane); w.nn_a = take(plane);
     w.total = (long long)o;
     return w;
 }
 
-// cvc_linear_nn_fwd with the K split cvc/hip.py::linear_nn chooses: one resident round of workgroups, >= 16 K rows per wave
-int nn(const float* dy_q, int K, int M, const cvc_nn_seg* segs, int nsegs, float* ws, hipStream_t st) {
+// Backward-data product with the K split cvc/hip.py::linear_nn chooses (one resident round of workgroups, >= 16 K rows per wave),
+// WITHOUT the summing launch: out[s] describes where segment s's gradient lives -- the K-slice planes in `ws` (summed by the
+// consumer) or, unsplit, the segment's own dst.
+int nn(const float* dy_q, int K, int M, const cvc_nn_seg* segs, int nsegs, float* ws, cvc_grad_src* out, bool finished, hipStream_t st) {
     int slabs = 0;
     for (int s = 0; s < nsegs; ++s) slabs += (segs[s].ncols + 127) / 128;
     const int resident = cvc_gemm_packed_split(-1) != 0 ? 256 : 512;
     int ks = resident / (slabs > 0 ? slabs : 1);
     if (ks > K / 8 / 16) ks = K / 8 / 16;
     if (ks < 1) ks = 1;
-    return cvc_linear_nn_fwd(dy_q, K, M, segs, nsegs, ks, ws, st);
+    const long long ntot = (long long)slabs * 128;
+    int slab = 0;
+    for (int s = 0; s < nsegs; ++s) {
+        if (ks == 1 || finished) out[s] = cvc_grad_src{segs[s].dst, segs[s].ld_dst, 0, 1};
+        else out[s] = cvc_grad_src{ws + (size_t)slab * 128, ntot, (long long)M * ntot, ks};
+        slab += (segs[s].ncols + 127) / 128;
+    }
+    return finished ? cvc_linear_nn_fwd(dy_q, K, M, segs, nsegs, ks, ws, st) : cvc_linear_nn_planes_fwd(dy_q, K, M, segs, nsegs, ks, ws, st);
 }
 
 int run_bwd(const cvc_train_loop& L, hipStream_t st, int* launches) {
     const int B = L.B, T = L.T, R = L.R, A = L.A, N = L.N, F = L.F;
     const size_t BR = (size_t)B * R, BG = (size_t)B * 4 * R;
     const BwdWs w = carve(L.bwd_ws, B, R, L.kind == 0 ? A : 0);
+    const bool feat_grads = L.kind == 0 && (L.d_pool || L.d_conv);     // the context-feature gradient reads d_ctx as a finished tensor
+    const cvc_grad_src none{nullptr, 0, 0, 0};
+    cvc_grad_src g_hl_a = none, g_hl_b = none, g_ha_prev = none;       // what step t + 1 left for step t
     int n = 0;
     for (int t = T - 1; t >= 0; --t) {
         const bool last = t + 1 == T;
         // ---- language cell: d_h = dropout'(d_out[t]) + the next step's two uses of h_lang(t)
-        CVC_TRY(cvc_lstm_pointwise_bwd4(last ? nullptr : w.d_hl_a, last ? nullptr : w.d_hl_b, nullptr, L.d_out + (size_t)t * BR,
-                                        L.p > 0.f ? L.rng_state : nullptr, L.site0 + (unsigned)t, L.p, last ? nullptr : w.d_c_lang,
-                                        L.g_lang + (size_t)t * BG, L.c_lang + (size_t)t * BR, L.c_lang + (size_t)(t + 1) * BR, B, R,
-                                        L.dg_lang + (size_t)t * BG, w.d_c_lang, w.dgq, st));
+        {
+            const cvc_grad_src src[3] = {g_hl_a, g_hl_b, none};
+            CVC_TRY(cvc_lstm_pointwise_bwd4(src, L.d_out + (size_t)t * BR, L.p > 0.f ? L.rng_state : nullptr, L.site0 + (unsigned)t, L.p,
+                                            last ? nullptr : w.d_c_lang, L.g_lang + (size_t)t * BG, L.c_lang + (size_t)t * BR,
+                                            L.c_lang + (size_t)(t + 1) * BR, B, R, L.dg_lang + (size_t)t * BG, w.d_c_lang, w.dgq, st));
+        }
+        cvc_grad_src g_ctx = none, g_ha_a = none, g_ha_b = none;
         {
             cvc_nn_seg segs[3];
-            int ns = 0;
-            if (L.kind == 0) segs[ns++] = cvc_nn_seg{L.w_ih_lang, w.d_ctx, L.ld_ih_lang, R, R};
-            segs[ns++] = cvc_nn_seg{L.w_ih_lang + R, w.d_ha_a, L.ld_ih_lang, R, R};
-            if (t > 0) segs[ns++] = cvc_nn_seg{L.w_hh_lang, w.d_hl_a, R, R, R};
-            CVC_TRY(nn(w.dgq, 4 * R, B, segs, ns, w.nn, st));
+            cvc_grad_src out[3];
+            int ns = 0, i_ctx = -1, i_ha, i_hl = -1;
+            if (L.kind == 0) { i_ctx = ns; segs[ns++] = cvc_nn_seg{L.w_ih_lang, w.d_ctx, L.ld_ih_lang, R, R}; }
+            i_ha = ns; segs[ns++] = cvc_nn_seg{L.w_ih_lang + R, w.d_ha_a, L.ld_ih_lang, R, R};
+            if (t > 0) { i_hl = ns; segs[ns++] = cvc_nn_seg{L.w_hh_lang, w.d_hl_a, R, R, R}; }
+            CVC_TRY(nn(w.dgq, 4 * R, B, segs, ns, w.nn_l, out, feat_grads, st));
+            if (i_ctx >= 0) g_ctx = out[i_ctx];
+            g_ha_a = out[i_ha];
+            g_hl_a = i_hl >= 0 ? out[i_hl] : none;
         }
-        const float* d_ha_b = nullptr;
         if (L.kind == 0) {
             // ---- attention (both feature sets) and h2attn
             cvc_attn_set sets[2]{};
@@ -183,21 +210,28 @@ int run_bwd(const cvc_train_loop& L, hipStream_t st, int* launches) {
             sets[1].scores = L.ds_f + (size_t)t * B * F;
             float* d_proj[2] = {L.d_ppool, L.d_pconv};
             float* d_cf[2] = {L.d_pool, L.d_conv};
-            const bool any_dp = L.d_ppool || L.d_pconv, any_dc = L.d_pool || L.d_conv;
-            CVC_TRY(cvc_attn_bwd_pair(L.attn_kind, L.q + (size_t)t * B * A, L.w_a, L.inv_temp, sets, 2, w.d_ctx, B, 1, A, R,
+            const bool any_dp = L.d_ppool || L.d_pconv;
+            const int qs = L.wp_h ? L.q_split : 1;
+            const cvc_grad_src qsrc{L.q + (size_t)t * qs * B * A, A, (long long)B * A, qs};
+            CVC_TRY(cvc_attn_bwd_pair(L.attn_kind, &qsrc, L.wp_h ? L.b_h : nullptr, L.w_a, L.inv_temp, sets, 2, &g_ctx, B, 1, A, R,
                                       L.dq + (size_t)t * B * A, w.dqq, L.dwa_part ? L.dwa_part + (size_t)t * B * A : nullptr,
-                                      any_dp ? d_proj : nullptr, any_dc ? d_cf : nullptr, st));
+                                      any_dp ? d_proj : nullptr, feat_grads ? d_cf : nullptr, st));
             cvc_nn_seg seg{L.w_h, w.d_ha_b, R, R, R};
-            CVC_TRY(nn(w.dqq, A, B, &seg, 1, w.nn, st));
-            d_ha_b = w.d_ha_b;
+            CVC_TRY(nn(w.dqq, A, B, &seg, 1, w.nn_h, &g_ha_b, false, st));
         }
         // ---- attention cell: d_h = language cell's input + attention query + next step's recurrence
-        CVC_TRY(cvc_lstm_pointwise_bwd4(w.d_ha_a, d_ha_b, last ? nullptr : w.d_ha_prev, nullptr, nullptr, 0, 0.f,
-                                        last ? nullptr : w.d_c_att, L.g_att + (size_t)t * BG, L.c_att + (size_t)t * BR,
-                                        L.c_att + (size_t)(t + 1) * BR, B, R, L.dg_att + (size_t)t * BG, w.d_c_att, w.dgq, st));
+        {
+            const cvc_grad_src src[3] = {g_ha_a, g_ha_b, g_ha_prev};
+            CVC_TRY(cvc_lstm_pointwise_bwd4(src, nullptr, nullptr, 0, 0.f, last ? nullptr : w.d_c_att, L.g_att + (size_t)t * BG,
+                                            L.c_att + (size_t)t * BR, L.c_att + (size_t)(t + 1) * BR, B, R, L.dg_att + (size_t)t * BG,
+                                            w.d_c_att, w.dgq, st));
+        }
         if (t > 0) {
             cvc_nn_seg segs[2] = {cvc_nn_seg{L.w_ih_att, w.d_hl_b, L.ld_ih_att, R, R}, cvc_nn_seg{L.w_hh_att, w.d_ha_prev, R, R, R}};
-            CVC_TRY(nn(w.dgq, 4 * R, B, segs, 2, w.nn, st));
+            cvc_grad_src out[2];
+            CVC_TRY(nn(w.dgq, 4 * R, B, segs, 2, w.nn_a, out, false, st));
+            g_hl_b = out[0];
+            g_ha_prev = out[1];
         }
     }
     if (launches) *launches = n;
@@ -231,7 +265,8 @@ extern "C" int cvc_train_loop_launches(const cvc_train_loop* loop, int backward)
     if (!loop || loop->T < 1) return 0;
     const int T = loop->T;
     if (!backward) return 6 + T * (loop->kind == 0 ? 5 : 2);
-    // nn = GEMM (+ plane sum); attention backward = score pass + softmax backward + score backward
-    const int per = loop->kind == 0 ? (1 + 2 + 3 + 2 + 1 + 2) : (1 + 2 + 1 + 2);
-    return T * per - 2;          // (step 0 has no recurrent product of the attention cell)
+    // backward-data products leave their K-slice planes to the readers (no summing launch); attention backward = score pass + softmax
+    // backward + score backward
+    const int per = loop->kind == 0 ? (1 + 1 + 3 + 1 + 1 + 1) : (1 + 1 + 1 + 1);
+    return T * per - 1;          // (step 0 has no recurrent product of the attention cell)
 }

@@ -443,11 +443,19 @@ __global__ __launch_bounds__(WG) void lstm_pointwise_bwd_kernel(const float* d_h
 }
 
 // four gradients of h' (the C-driven training loops: this step's other consumers, the next step's two cells, the dropped output),
-// summed in the order d_h1, d_h2, d_h3, d_hd * mask
-__global__ __launch_bounds__(WG) void lstm_pointwise_bwd4_kernel(const float* d_h1, const float* d_h2, const float* d_h3, const float* d_hd,
-                                                                 DropSpec rng, const float* d_c, const float* gates, const float* c_prev,
-                                                                 const float* c_new, int M, int R, float* d_gates, float* d_c_prev,
-                                                                 float* d_gates_q) {
+// summed in the order d_h[0], d_h[1], d_h[2], d_hd * mask.  Each d_h[i] may arrive as the K-slice planes of the backward-data
+// product that produced it: summed here, in plane order, instead of by a launch of their own.
+struct HSrc3 { cvc_grad_src s[3]; };
+__device__ __forceinline__ float hsrc_load(const cvc_grad_src& g, int m, int j) {
+    if (g.p == nullptr) return 0.f;
+    const float* p = g.p + (size_t)m * g.ld + j;
+    float v = p[0];
+    for (int k = 1; k < g.nplanes; ++k) v += p[(size_t)k * g.plane_stride];
+    return v;
+}
+__global__ __launch_bounds__(WG) void lstm_pointwise_bwd4_kernel(HSrc3 src, const float* d_hd, DropSpec rng, const float* d_c,
+                                                                 const float* gates, const float* c_prev, const float* c_new, int M,
+                                                                 int R, float* d_gates, float* d_c_prev, float* d_gates_q) {
     const int j = blockIdx.x * WG + threadIdx.x;
     const int m = blockIdx.y;
     if (j >= R) return;
@@ -456,7 +464,7 @@ __global__ __launch_bounds__(WG) void lstm_pointwise_bwd4_kernel(const float* d_
     const float tc = tanhf(c_new[o]);
     float dhd = d_hd != nullptr ? d_hd[o] : 0.f;
     if (rng.state != nullptr) dhd *= cvc_drop_mult(rng, rng.state[0], rng.state[1], rng.state[2], (uint32_t)o);
-    const float dh = (((d_h1 != nullptr ? d_h1[o] : 0.f) + (d_h2 != nullptr ? d_h2[o] : 0.f)) + (d_h3 != nullptr ? d_h3[o] : 0.f)) + dhd;
+    const float dh = ((hsrc_load(src.s[0], m, j) + hsrc_load(src.s[1], m, j)) + hsrc_load(src.s[2], m, j)) + dhd;
     const float dcn = (d_c != nullptr ? d_c[o] : 0.f) + dh * og * (1.f - tc * tc);
     const float d0 = dcn * gg * ig * (1.f - ig), d1 = dcn * c_prev[o] * fg * (1.f - fg);
     const float d2 = dcn * ig * (1.f - gg * gg), d3 = dh * tc * og * (1.f - og);
@@ -866,13 +874,17 @@ extern "C" int cvc_lstm_pointwise_bwd3_drop(const float* d_h, const float* d_h2,
     return cvc_launch_status();
 }
 
-extern "C" int cvc_lstm_pointwise_bwd4(const float* d_h1, const float* d_h2, const float* d_h3, const float* d_hd,
-                                       const uint32_t* rng_state, unsigned site, float p, const float* d_c, const float* gates,
-                                       const float* c_prev, const float* c_new, int M, int R, float* d_gates, float* d_c_prev,
-                                       float* d_gates_q, cvc_stream_t stream) {
-    if (!gates || !c_prev || !c_new || !d_gates || !d_c_prev || M < 1 || R < 1 || p < 0.f || p >= 1.f) return CVC_E_BADARG;
+extern "C" int cvc_lstm_pointwise_bwd4(const cvc_grad_src* d_h, const float* d_hd, const uint32_t* rng_state, unsigned site, float p,
+                                       const float* d_c, const float* gates, const float* c_prev, const float* c_new, int M, int R,
+                                       float* d_gates, float* d_c_prev, float* d_gates_q, cvc_stream_t stream) {
+    if (!d_h || !gates || !c_prev || !c_new || !d_gates || !d_c_prev || M < 1 || R < 1 || p < 0.f || p >= 1.f) return CVC_E_BADARG;
     if (d_gates_q != nullptr && (M > 64 || (R & 3))) return CVC_E_BADARG;
-    hipLaunchKernelGGL(lstm_pointwise_bwd4_kernel, dim3((R + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, d_h1, d_h2, d_h3, d_hd,
+    HSrc3 src;
+    for (int i = 0; i < 3; ++i) {
+        src.s[i] = d_h[i];
+        if (src.s[i].p != nullptr && (src.s[i].nplanes < 1 || src.s[i].ld < R)) return CVC_E_BADARG;
+    }
+    hipLaunchKernelGGL(lstm_pointwise_bwd4_kernel, dim3((R + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, src, d_hd,
                        cvc_drop_spec(rng_state, site, p), d_c, gates, c_prev, c_new, M, R, d_gates, d_c_prev, d_gates_q);
     return cvc_launch_status();
 }

@@ -178,7 +178,9 @@ class GradReducer:
         self._late_after_launch: List[int] = []
         from . import functional as _F
         _F.LATE_GRAD_LISTENERS.append(self._on_late_grad)
+        _F.GRAD_SINKS.append(self)
         self._late_listener_owner = _F
+        self._written: set = set()                            # ids whose arena view was handed out for an in-place write this step
 
     # ------------------------------------------------------------------ gradient bookkeeping
     def zero_grad(self):
@@ -195,6 +197,29 @@ class GradReducer:
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._arrived = [set() for _ in self.buckets]
+        self._written = set()
+
+    # ---- gradient sink protocol (cvc.functional.GRAD_SINKS): the dense weight-gradient products write straight into the arena
+    def claim(self, p):
+        i = self._bucket_of.get(id(p))
+        if i is None or id(p) in self._dead or id(p) in self._written or self._launched[i]:
+            return None
+        v = self._views[id(p)]
+        if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+            return None
+        self._written.add(id(p))
+        return v
+
+    def written(self, p):
+        """the producer has enqueued its in-place write of p's gradient.  Recorded as an arrival (the first step learns from it which
+        parameters are live); the bucket itself leaves from the post-accumulate-grad hook, which autograd fires for p once ALL of
+        its producers have returned (also when they returned None), or at finalize()."""
+        i = self._bucket_of[id(p)]
+        if id(p) not in self._arrived[i]:
+            self._arrived[i].add(id(p))
+            self._ready[i] += 1
+        if not self._learned:
+            self._seen_first[i].add(id(p))
 
     def _revive(self, p):
         """A parameter that was marked dead (no gradient on the first step) receives one after all: its arena slot would never
@@ -219,18 +244,19 @@ class GradReducer:
         if not self._learned:
             self._seen_late[i].add(id(w))                   # live, but no hook will ever announce it: not part of _expected
         if self.exchange and self._launched[i]:
-            self._late_after_launch.append(i)
+            self._late_after_launch.append((i, self._names.get(id(w), "?"), "deferred dW flush at the end of backward"))
 
     def _on_grad(self, p):
         i = self._bucket_of[id(p)]
         v = self._views[id(p)]
+        if id(p) in self._dead:
+            self._revive(p)
         if p.grad is not v and p.grad.data_ptr() != v.data_ptr():      # autograd installed its own tensor: move it into the arena
             v.copy_(p.grad)
             p.grad = v
-        if id(p) in self._dead:
-            self._revive(p)
-        self._ready[i] += 1
-        self._arrived[i].add(id(p))
+        if id(p) not in self._arrived[i]:
+            self._arrived[i].add(id(p))
+            self._ready[i] += 1
         if not self._learned:
             self._seen_first[i].add(id(p))
         elif self.overlap and not self._launched[i] and self._arrived[i] >= self._live[i] and not self._seen_late[i]:
@@ -258,8 +284,8 @@ class GradReducer:
         the world size; average=False leaves SUMS for clip_() to fold the 1/G into its single multiply."""
         if self._late_after_launch:
             late, self._late_after_launch = sorted(set(self._late_after_launch)), []
-            raise RuntimeError(f"GradReducer: a weight gradient was written into bucket(s) {late} after their exchange had been "
-                               "launched (deferred dW flush at the end of backward): run with overlap=False for this graph")
+            raise RuntimeError(f"GradReducer: a weight gradient was written after its bucket's exchange had been launched "
+                               f"(bucket, parameter, how): {late}; run with overlap=False for this graph")
         if self.exchange:
             if self._expected is None:
                 # first step: every rank must expect the same arrivals per bucket (same model, same graph) -- checked once
@@ -300,6 +326,7 @@ class GradReducer:
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._arrived = [set() for _ in self.buckets]
+        self._written = set()
 
     def clip_(self, max_norm: float, summed: bool = True) -> torch.Tensor:
         """clip_grad_norm_(parameters, max_norm) over the arenas (trainer.py:120-121): global L2 norm of the averaged
@@ -318,3 +345,5 @@ class GradReducer:
         lst = self._late_listener_owner.LATE_GRAD_LISTENERS
         if self._on_late_grad in lst:
             lst.remove(self._on_late_grad)
+        if self in self._late_listener_owner.GRAD_SINKS:
+            self._late_listener_owner.GRAD_SINKS.remove(self)

@@ -84,6 +84,36 @@ class _WeightGradBatcher:
 LATE_GRAD_LISTENERS = []      # callables(weight): a leftover dW was added to weight.grad at the end of backward, outside AccumulateGrad
 _BATCHER = _WeightGradBatcher()
 
+# Gradient sinks: whoever owns the parameters' .grad storage for the whole run (cvc.distributed.GradReducer: flat arenas, zero-filled
+# at the start of a step) can hand a producer the .grad buffer itself -- the dense weight-gradient products then write their result
+# in place and return None to autograd: no AccumulateGrad add over the 486 MB of gradients, and the owner learns of the arrival at
+# once (bucket exchange launched as the product finishes).  sink.claim(param) -> a zero-filled tensor shaped like param that may be
+# OVERWRITTEN (at most once per step), or None; sink.written(param) after the producing kernel was enqueued.
+GRAD_SINKS = []
+
+
+def claim_grad(p):
+    """-> (buffer to overwrite, its sink) or (None, None)"""
+    if p is None or not p.requires_grad:
+        return None, None
+    for sink in GRAD_SINKS:
+        v = sink.claim(p)
+        if v is not None:
+            return v, sink
+    return None, None
+
+
+def _into_grad(param, compute):
+    """compute(out) -> tensor: run with out = the gradient owner's buffer for `param` when a sink hands it out (then autograd gets
+    None for this parameter), else with out = None and the result goes through autograd.  Only for parameters whose whole gradient
+    of a backward pass comes from this ONE call."""
+    buf, sink = claim_grad(param)
+    if buf is None:
+        return compute(None)
+    compute(buf)
+    sink.written(param)
+    return None
+
 
 def _mm_tn(d: Tensor, x: Tensor) -> Tensor:
     """dW = d^T x  ([S, N]^T [S, K] -> [N, K]): contraction over the S = T*B sample rows, on the tile GEMM."""
@@ -145,7 +175,10 @@ class _Linear(torch.autograd.Function):
             def flush(items):
                 D = torch.cat([i[0] for i in items], 0) if len(items) > 1 else items[0][0]
                 X = torch.cat([i[1] for i in items], 0) if len(items) > 1 else items[0][1]
-                return _mm_tn(D, X), (D.sum(0) if ctx.has_bias else None)
+                # (into the gradient owner's buffer when it hands one out: no AccumulateGrad add, see GRAD_SINKS)
+                dw = _into_grad(weight, lambda out: hip.tile_mm(D, X, a_kmajor=True, b_kmajor=True, out=out))
+                db = _into_grad(bias, lambda out: torch.sum(D, 0, out=out) if out is not None else D.sum(0)) if ctx.has_bias else None
+                return dw, db
 
             res = _BATCHER.add(ctx.key, (dy, x), (weight, bias), flush)
             if res is not None:

@@ -79,6 +79,11 @@ class DecodeDesc(C.Structure):
         [("gsk_nwg", C.c_int)] + [(n, C.c_void_p) for n in ("slab_att", "slab_lang", "slab_q", "slab_o", "emb_gate", "sel_counter")] +
         [("att_w_cached", C.c_int), ("lang_ksx", C.c_int), ("ksx_slab", C.c_void_p), ("ksx_flags", C.c_void_p)])
 
+class GradSrc(C.Structure):
+    """cvc_grad_src: a gradient given as the sum of K-slice planes"""
+    _fields_ = [("p", C.c_void_p), ("ld", C.c_longlong), ("plane_stride", C.c_longlong), ("nplanes", C.c_int)]
+
+
 class LstmStep(C.Structure):
     """cvc_lstm_step of include/cvc_hip.h ("Training loops driven from C"), field for field"""
     _fields_ = ([("wp", C.c_void_p), ("xq", C.c_void_p), ("K", C.c_int), ("M", C.c_int), ("R", C.c_int)] +
@@ -94,7 +99,8 @@ class TrainLoop(C.Structure):
         [(n, C.c_void_p) for n in ("wp_att", "wp_lang", "b_ih_att", "b_hh_att", "b_ih_lang", "b_hh_lang", "w_ih_att", "w_hh_att",
                                    "w_ih_lang", "w_hh_lang")] +
         [("ld_ih_att", C.c_int), ("ld_ih_lang", C.c_int)] +
-        [(n, C.c_void_p) for n in ("w_h", "b_h", "w_a", "b_a", "gpre_att", "row_bias", "row_index", "gpre_lang", "pool", "ppool", "conv",
+        [(n, C.c_void_p) for n in ("w_h", "b_h", "wp_h")] + [("q_split", C.c_int)] +
+        [(n, C.c_void_p) for n in ("w_a", "b_a", "gpre_att", "row_bias", "row_index", "gpre_lang", "pool", "ppool", "conv",
                                    "pconv", "mask", "frame_mask", "rng_state")] +
         [("site0", C.c_uint), ("p", C.c_float)] +
         [(n, C.c_void_p) for n in ("out", "h_att", "h_att_prev", "h_lang_prev", "c_att", "c_lang", "g_att", "g_lang", "ctx", "q", "attn_r",
@@ -108,8 +114,9 @@ class TrainLoop(C.Structure):
 SIGNATURES = {
     "cvc_packed_lstm_step_fwd": [C.POINTER(LstmStep), _P],
     "cvc_attn_wsum_quad_rm": [C.POINTER(AttnSet), _I, _I, _I, _P, _P, _P],
-    "cvc_attn_bwd_pair": [_I, _P, _P, _F, C.POINTER(AttnSet), _I, _P, _I, _I, _I, _I, _P, _P, _P, C.POINTER(_P), C.POINTER(_P), _P],
-    "cvc_lstm_pointwise_bwd4": [_P, _P, _P, _P, _P, C.c_uint, _F, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "cvc_attn_bwd_pair": [_I, C.POINTER(GradSrc), _P, _P, _F, C.POINTER(AttnSet), _I, C.POINTER(GradSrc), _I, _I, _I, _I, _P, _P, _P,
+                          C.POINTER(_P), C.POINTER(_P), _P],
+    "cvc_lstm_pointwise_bwd4": [C.POINTER(GradSrc), _P, _P, C.c_uint, _F, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
     "cvc_train_loop_bwd_ws": [_I, _I, _I],
     "cvc_train_loop_fwd": [C.POINTER(TrainLoop), _P],
     "cvc_train_loop_bwd": [C.POINTER(TrainLoop), _P],
@@ -498,6 +505,23 @@ def lstm_train_pack(w_ih: torch.Tensor, w_hh: torch.Tensor, cols: Optional[Seque
     ws = (_I * n)(*[nn_ for _, nn_ in ranges], K_hh)
     _check(lib().cvc_pack_lstm_segs(ptrs, lds, ws, n, R, _dev(wp), _stream()), "cvc_pack_lstm_segs")
     packs[key] = (wp, stamp)
+    return wp
+
+
+def linear_train_pack(w: torch.Tensor) -> torch.Tensor:
+    """Packed copy [Nout/32][K/4][32][4] of a linear layer's weight [Nout, K] for cvc_packed_linear_fwd (the training loop's
+    h2attn): lives on the weight tensor like the LSTM packs, rebuilt when the step generation / version / address changed."""
+    n, k = w.shape
+    assert n % 32 == 0 and k % 32 == 0
+    stamp = (_train_generation, w._version, w.data_ptr(), (n, k))
+    ent = getattr(w, "_cvc_linear_pack", None)
+    if ent is not None and ent[1] == stamp:
+        return ent[0]
+    wp = ent[0] if (ent is not None and tuple(ent[0].shape) == (n // 32, k // 4, 32, 4) and ent[0].device == w.device) else \
+        torch.empty(n // 32, k // 4, 32, 4, device=w.device, dtype=torch.float32)
+    with torch.no_grad():
+        wp.copy_(w.detach().view(n // 32, 32, k // 4, 4).permute(0, 2, 1, 3))       # one strided copy
+    w._cvc_linear_pack = (wp, stamp)
     return wp
 
 

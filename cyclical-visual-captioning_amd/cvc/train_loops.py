@@ -29,6 +29,7 @@ from . import functional as F_
 from . import hip
 
 ENABLED = os.environ.get("CVC_TRAIN_LOOPS", "1") != "0"        # False: the per-step autograd path (A/B switch)
+PACKED_H2ATTN = os.environ.get("CVC_TRAIN_PACKED_H2ATTN", "1") != "0"   # False: h2attn of loop A on the row-major ring kernel (A/B)
 
 Tensor = torch.Tensor
 
@@ -102,22 +103,40 @@ def _bwd_ws(B: int, R: int, A: int, device) -> Tensor:
     return t
 
 
+class _Out:
+    """where one weight's gradient goes: the owner's .grad buffer itself when a gradient sink hands it out (cvc.functional.
+    GRAD_SINKS: written in place, autograd gets None), else a fresh tensor returned through autograd"""
+
+    def __init__(self, param: Optional[Tensor]):
+        self.param = param
+        self.buf, self.sink = F_.claim_grad(param) if param is not None else (None, None)
+        self.t = self.buf if self.buf is not None else (torch.empty_like(param) if param is not None else None)
+
+    def done(self):
+        """-> what the Function returns for this weight"""
+        if self.sink is not None:
+            self.sink.written(self.param)
+            return None
+        return self.t
+
+
 def _weight_grads(arena: LoopArena, cfg, W):
-    """All weight gradients of the loops in `arena.done`, one product per (weight, input segment) over all their rows."""
+    """All weight gradients of the loops in `arena.done`, one product per (weight, input segment) over all their rows.
+    W: name -> parameter (w_ih_a, w_hh_a, b_ih_a, b_hh_a, w_ih_l, w_hh_l, b_ih_l, b_hh_l, w_h, b_h, w_a, b_a) + fc."""
     T, B, R, E = arena.T, arena.B, arena.R, arena.E
     slots = sorted(arena.done)
     n = T * B
-    rows = slice(slots[0] * n, (slots[-1] + 1) * n) if slots == list(range(slots[0], slots[-1] + 1)) else None
-    assert rows is not None
+    assert slots == list(range(slots[0], slots[-1] + 1))
+    rows = slice(slots[0] * n, (slots[-1] + 1) * n)
     nl = len(slots)
     DGa, DGl = arena.dg_att[rows], arena.dg_lang[rows]
     Hl, Ha_prev, Ha, Cx, Em = arena.h_lang_prev[rows], arena.h_att_prev[rows], arena.h_att[rows], arena.ctx[rows], arena.emb[rows]
-    w_ih_a, w_hh_a, w_ih_l, w_hh_l = W["w_ih_a"], W["w_hh_a"], W["w_ih_l"], W["w_hh_l"]
     g = {}
+    O = {k: _Out(W[k]) for k in ("w_ih_a", "w_hh_a", "b_ih_a", "b_hh_a", "w_ih_l", "w_hh_l", "b_ih_l", "b_hh_l")}
     # ---- attention cell: weight_ih = [h_lang | (fc) | emb], weight_hh
     Dp = hip.TileOperand(DGa, kmajor=True)                    # dG^T packed once for every product of the cell
     Hlp = hip.TileOperand(Hl, kmajor=True)                    # h_lang(t-1): att weight_ih[:, :R] AND lang weight_hh
-    d_ih = torch.empty_like(w_ih_a)
+    d_ih = O["w_ih_a"].t
     hip.tile_mm(Dp, Hlp, out=d_ih[:, :R])
     DGsum = DGa.view(nl * T, B, 4 * R).sum(0)                 # [B, 4R]: the fc columns' dY (fc is the same row every step), the biases
     e0 = R
@@ -125,28 +144,30 @@ def _weight_grads(arena: LoopArena, cfg, W):
         hip.tile_mm(DGsum, W["fc"], a_kmajor=True, b_kmajor=True, out=d_ih[:, R:2 * R])
         e0 = 2 * R
     hip.tile_mm(Dp, Em, b_kmajor=True, out=d_ih[:, e0:])
-    g["w_ih_a"] = d_ih
-    g["w_hh_a"] = hip.tile_mm(Dp, Ha_prev, b_kmajor=True)
-    g["b_a"] = DGsum.sum(0)
+    hip.tile_mm(Dp, Ha_prev, b_kmajor=True, out=O["w_hh_a"].t)
+    torch.sum(DGsum, 0, out=O["b_ih_a"].t)
+    O["b_hh_a"].t.copy_(O["b_ih_a"].t)
     # ---- language cell: weight_ih = [ctx | h_att], weight_hh
     Dl = hip.TileOperand(DGl, kmajor=True)
-    d_il = torch.empty_like(w_ih_l)
+    d_il = O["w_ih_l"].t
     hip.tile_mm(Dl, Cx, b_kmajor=True, out=d_il[:, :R])
     Hap = hip.TileOperand(Ha, kmajor=True)
     hip.tile_mm(Dl, Hap, out=d_il[:, R:])
-    g["w_ih_l"] = d_il
-    g["w_hh_l"] = hip.tile_mm(Dl, Hlp)
-    g["b_l"] = DGl.sum(0)
+    hip.tile_mm(Dl, Hlp, out=O["w_hh_l"].t)
+    torch.sum(DGl, 0, out=O["b_ih_l"].t)
+    O["b_hh_l"].t.copy_(O["b_ih_l"].t)
     # ---- h2attn / alpha_net: loop A's rows only
     if 0 in slots and arena.extra:
         x = arena.extra
         DQ = x["dq"].view(n, -1)
-        g["w_h"] = hip.tile_mm(DQ, arena.h_att[arena.rows(0)], a_kmajor=True, b_kmajor=True)
-        g["b_h"] = DQ.sum(0)
+        O["w_h"], O["b_h"] = _Out(W["w_h"]), _Out(W["b_h"])
+        hip.tile_mm(DQ, arena.h_att[arena.rows(0)], a_kmajor=True, b_kmajor=True, out=O["w_h"].t)
+        torch.sum(DQ, 0, out=O["b_h"].t)
         if x.get("dwa_part") is not None:
-            g["w_a"] = x["dwa_part"].view(n, -1).sum(0).reshape(W["w_a"].shape)
-            g["b_a_net"] = (x["ds_r"].sum() + x["ds_f"].sum()).reshape(1)
-    return g
+            O["w_a"], O["b_a"] = _Out(W["w_a"]), _Out(W["b_a"])
+            torch.sum(x["dwa_part"].view(n, -1), 0, out=O["w_a"].t.view(-1))
+            O["b_a"].t.copy_((x["ds_r"].sum() + x["ds_f"].sum()).reshape(1))
+    return {k: o.done() for k, o in O.items()}
 
 
 class _Loop(torch.autograd.Function):
@@ -208,11 +229,17 @@ class _Loop(torch.autograd.Function):
             A, N, Fr = w_h.shape[0], pool.shape[1], conv.shape[1]
             L.A, L.N, L.F, L.attn_kind, L.inv_temp = A, N, Fr, cfg.attn_kind, float(cfg.inv_temp)
             L.w_h, L.b_h, L.w_a, L.b_a = _ptr(w_h), _ptr(b_h), _ptr(None if w_a is None else w_a.reshape(-1)), _ptr(b_a)
+            qs = 1
+            if PACKED_H2ATTN and A % 32 == 0 and R % 128 == 0:
+                # the query GEMM split-K over the whole chip on the packed kernel; its planes are summed by the score pass
+                qs = 8 if R % 256 == 0 else 4
+                keep["wp_h"] = hip.linear_train_pack(w_h)
+                L.wp_h, L.q_split = _ptr(keep["wp_h"]), qs
             pool, ppool, conv, pconv = (t.contiguous() for t in (pool, ppool, conv, pconv))
             L.pool, L.ppool, L.conv, L.pconv = _ptr(pool), _ptr(ppool), _ptr(conv), _ptr(pconv)
             keep.update(pool=pool, ppool=ppool, conv=conv, pconv=pconv, mask=cfg.mask, fmask=cfg.frame_mask)
             L.mask, L.frame_mask = _ptr(cfg.mask), _ptr(cfg.frame_mask)
-            buf.update(q=e(T, B, A), attn_r=e(T, B, N), attn_f=e(T, B, Fr), scores=e(B, N + Fr))
+            buf.update(q=e(T, qs, B, A), attn_r=e(T, B, N), attn_f=e(T, B, Fr), scores=e(B, N + Fr))
             if cfg.frame_mask is not None:
                 fm = buf["fm"] = e(T, B, N)
             L.ctx, L.q, L.attn_r, L.attn_f, L.fm, L.scores_ws = (_ptr(arena.ctx[rows]), _ptr(buf["q"]), _ptr(buf["attn_r"]),
@@ -275,9 +302,9 @@ class _Loop(torch.autograd.Function):
         if kind == 1 and ni[4]:
             d_ctx = hip.tile_mm(DGl, w_ih_l[:, :R], b_kmajor=True).view(T, B, R).transpose(0, 1)
         # ---- weight gradients: by whichever loop finishes its backward last, over all loops' rows at once
-        W = dict(w_ih_a=w_ih_a, w_hh_a=w_hh_a, w_ih_l=w_ih_l, w_hh_l=w_hh_l, w_h=w_h, w_a=w_a, fc=fc)
-        order = ("w_ih_a", "w_hh_a", "b_a", "b_a", "w_ih_l", "w_hh_l", "b_l", "b_l", "w_h", "b_h", "w_a", "b_a_net")
+        order = ("w_ih_a", "w_hh_a", "b_ih_a", "b_hh_a", "w_ih_l", "w_hh_l", "b_ih_l", "b_hh_l", "w_h", "b_h", "w_a", "b_a")
         owners = (w_ih_a, w_hh_a, b_ih_a, b_hh_a, w_ih_l, w_hh_l, b_ih_l, b_hh_l, w_h, b_h, w_a, b_a)
+        W = dict(zip(order, owners), fc=fc)
 
         def flush(_items):
             g = _weight_grads(arena, cfg, W)

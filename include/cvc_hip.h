@@ -692,8 +692,19 @@ int cvc_decode_beam(cvc_decode_plan* plan, cvc_stream_t stream);
  *                              one score pass, one softmax backward, one score backward whose d_q is the sum over the sets,
  *                              written row-major and (nullable) in the quad layout cvc_linear_nn_fwd reads;
  *   cvc_lstm_pointwise_bwd4  : cvc_lstm_pointwise_bwd3 with a fourth gradient of h', the one that left through the fused
- *                              dropout (decoder_core.py:62, 109), summed in the order d_h1, d_h2, d_h3, d_hd.
+ *                              dropout (decoder_core.py:62, 109), summed in the order d_h[0], d_h[1], d_h[2], d_hd; each d_h[i]
+ *                              may be the K-slice planes of the product that produced it (cvc_grad_src).
  */
+/* A gradient that is the sum of `nplanes` partial planes -- what a K-split backward-data product leaves behind
+ * (cvc_linear_nn_planes_fwd): element (m, j) = sum_k p[k * plane_stride + m * ld + j], summed in plane order by the consumer, so
+ * the planes never need a summing launch of their own.  A finished tensor is nplanes = 1; p == NULL is an absent term (zero).
+ * (cvc_attn_bwd_pair with feature gradients d_ctxfeat requires d_ctx to be a finished tensor.) */
+typedef struct cvc_grad_src {
+    const float* p;
+    long long ld, plane_stride;
+    int nplanes;
+} cvc_grad_src;
+
 typedef struct cvc_lstm_step {
     const float* wp;             /* packed gate weights (cvc_pack_lstm_segs), K columns                                  */
     const float* xq;             /* quad-layout activations [K/4][64][4]                                                 */
@@ -718,12 +729,15 @@ int cvc_attn_wsum_quad_rm(const cvc_attn_set* sets, int nsets, int nclip, int R,
  * d_b_alpha); frame_masked = gradient of the frame-masked output (d_fm, INPUT, nullable); ctx_out unused.  d_ctx [rows, R] is
  * the gradient of the summed context.  d_q [rows, A] row-major, d_q_q (nullable, rows <= 64) the same in the quad layout
  * [A/4][64][4], d_w_part [rows, A] (additive only, nullable) per-row partials of d_w_alpha summed over the sets.
- * d_proj[s] / d_ctxfeat[s] (nullable): ACCUMULATED feature gradients [nclip, n, A] / [nclip, n, R]. */
-int cvc_attn_bwd_pair(int kind, const float* q, const float* w_a, float inv_temp, const cvc_attn_set* sets, int nsets,
-                      const float* d_ctx, int nclip, int nq, int A, int R, float* d_q, float* d_q_q, float* d_w_part,
-                      float* const* d_proj, float* const* d_ctxfeat, cvc_stream_t stream);
+ * d_proj[s] / d_ctxfeat[s] (nullable): ACCUMULATED feature gradients [nclip, n, A] / [nclip, n, R].
+ * q: the forward's query h2attn(h), as a finished [rows, A] tensor (nplanes = 1, q_bias null) or as the split-K planes the
+ * forward's cvc_packed_linear_fwd left (+ q_bias = h2attn.bias), summed on load. */
+int cvc_attn_bwd_pair(int kind, const cvc_grad_src* q, const float* q_bias, const float* w_a, float inv_temp,
+                      const cvc_attn_set* sets, int nsets, const cvc_grad_src* d_ctx, int nclip, int nq, int A, int R,
+                      float* d_q, float* d_q_q, float* d_w_part, float* const* d_proj, float* const* d_ctxfeat,
+                      cvc_stream_t stream);
 
-int cvc_lstm_pointwise_bwd4(const float* d_h1, const float* d_h2, const float* d_h3, const float* d_hd,
+int cvc_lstm_pointwise_bwd4(const cvc_grad_src* d_h /* [3] */, const float* d_hd,
                             const uint32_t* rng_state, unsigned site, float p, const float* d_c, const float* gates,
                             const float* c_prev, const float* c_new, int M, int R, float* d_gates, float* d_c_prev,
                             float* d_gates_q, cvc_stream_t stream);
@@ -741,6 +755,10 @@ typedef struct cvc_train_loop {
     const float *w_ih_att, *w_hh_att, *w_ih_lang, *w_hh_lang;
     int ld_ih_att, ld_ih_lang;   /* leading dimensions of weight_ih (R + [R] + E, 2R); weight_hh has R                   */
     const float *w_h, *b_h;      /* kind 0: h2attn [A, R], [A]                                                           */
+    const float* wp_h;           /* kind 0, nullable: h2attn packed [A/32][R/4][32][4] (cvc.decode.pack_weights): the query GEMM then
+                                  * runs split-K over the chip on the packed kernel (q_split planes summed by the score pass)
+                                  * instead of on the row-major ring kernel (q_split = 1)                                */
+    int q_split;
     const float *w_a, *b_a;      /* kind 0, additive: alpha_net weight [A], bias [1]                                     */
     /* ---- inputs */
     const float* gpre_att;       /* [T][B][4R] hoisted gates of the attention cell (embedded word of every step)         */
@@ -759,7 +777,7 @@ typedef struct cvc_train_loop {
     float *c_att, *c_lang;       /* [T+1][B][R], row block 0 zero                                                        */
     float *g_att, *g_lang;       /* [T][B][4R] activated gates                                                           */
     float* ctx;                  /* kind 0: [T][B][R] attended context (regions + frames)                                */
-    float* q;                    /* kind 0: [T][B][A] h2attn(h_att(t))                                                   */
+    float* q;                    /* kind 0: [T][q_split][B][A] h2attn(h_att(t)) (q_split > 1: split-K planes, bias not included) */
     float *attn_r, *attn_f;      /* kind 0: [T][B][N], [T][B][F] softmax weights                                         */
     float* fm;                   /* kind 0: [T][B][N] frame-masked pre-softmax scores (with frame_mask), nullable        */
     float* scores_ws;            /* kind 0: B * (N + F) floats                                                           */
