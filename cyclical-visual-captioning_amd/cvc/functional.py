@@ -659,3 +659,28 @@ class _Grounder(torch.autograd.Function):
 def grounder(xt: Tensor, feats: Tensor, bias: Optional[Tensor], mask: Optional[Tensor]) -> Tensor:
     """captioner.py:132-173, dot-product branch."""
     return _Grounder.apply(xt, feats, bias, mask)
+
+
+class _AttnNLL(torch.autograd.Function):
+    """att2_loss and ground_loss (misc/utils.py:150-162) of all T steps in one launch pair: -mean over the labelled proposals of
+    log_softmax(scores, 2), 0 when nothing is labelled (the reference branches on the host; here max(count, 1))."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, target):
+        loss, ws, tg = hip.attn_nll_fwd(x0, x1, target)
+        ctx.save_for_backward(x0, x1, tg, ws)
+        return loss[0:1], loss[1:2]
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        x0, x1, tg, ws = ctx.saved_tensors
+        ni = ctx.needs_input_grad
+        g0 = None if g0 is None else g0.contiguous()
+        g1 = None if g1 is None else g1.contiguous()
+        d0, d1 = hip.attn_nll_bwd(x0, x1, tg, ws, g0, g1, ni[0], ni[1])
+        return d0, d1, None
+
+
+def attn_nll(att2_weights: Tensor, ground_weights: Tensor, target: Tensor) -> Tuple[Tensor, Tensor]:
+    """-> (att2_loss [1], ground_loss [1])"""
+    return _AttnNLL.apply(att2_weights, ground_weights, target)

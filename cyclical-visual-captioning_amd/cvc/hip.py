@@ -117,6 +117,10 @@ SIGNATURES = {
     "cvc_attn_bwd_pair": [_I, C.POINTER(GradSrc), _P, _P, _F, C.POINTER(AttnSet), _I, C.POINTER(GradSrc), _I, _I, _I, _I, _P, _P, _P,
                           C.POINTER(_P), C.POINTER(_P), _P],
     "cvc_lstm_pointwise_bwd4": [C.POINTER(GradSrc), _P, _P, C.c_uint, _F, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "cvc_bbox_overlaps_fwd": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P],
+    "cvc_label_glue_fwd": [_P, _P, _LL, _LL, _LL, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
+    "cvc_attn_nll_fwd": [_P, _LL, _LL, _P, _LL, _LL, _P, _I, _I, _I, _P, _P, _P],
+    "cvc_attn_nll_bwd": [_P, _LL, _LL, _P, _LL, _LL, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "cvc_train_loop_bwd_ws": [_I, _I, _I],
     "cvc_train_loop_fwd": [C.POINTER(TrainLoop), _P],
     "cvc_train_loop_bwd": [C.POINTER(TrainLoop), _P],
@@ -771,6 +775,66 @@ def gather_rows(src, parent, beam: int):
     _check(lib().cvc_gather_rows(_dev(src), _dev(parent, torch.int64), rows, beam, width, _dev(dst), _stream()),
            "cvc_gather_rows")
     return dst
+
+
+# --------------------------------------------------------------------------- label glue / supervised attention criteria
+def bbox_overlaps(rois: torch.Tensor, gt: torch.Tensor, frm_mask: torch.Tensor, pnt_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """IoU [B, N, K] of proposals [B, N, >= 4] vs ground-truth boxes [B, K, >= 4] (cvc_bbox_overlaps_fwd); frm_mask [B, N, K] and
+    pnt_mask [B, N] (nullable) zero the overlap where set."""
+    B, N, K = frm_mask.shape
+    rois, gt = rois.contiguous(), gt.contiguous()
+    fm = _mask(frm_mask)
+    pm = None
+    if pnt_mask is not None:       # [B, N], any row stride (the trainer's pnt_mask[:, 1:]): a byte view, no copy
+        pm = pnt_mask.view(torch.uint8) if pnt_mask.dtype == torch.bool else (pnt_mask if pnt_mask.dtype == torch.uint8 else (pnt_mask != 0).view(torch.uint8))
+        if pm.stride(1) != 1:
+            pm = pm.contiguous()
+    ov = torch.empty(B, N, K, device=rois.device, dtype=torch.float32)
+    _check(lib().cvc_bbox_overlaps_fwd(_dev(rois), rois.shape[2], _dev(gt), gt.shape[2], _dev(fm, torch.uint8),
+                                       None if pm is None else pm.data_ptr(), 0 if pm is None else pm.stride(0), B, N, K, _dev(ov),
+                                       _stream()), "cvc_bbox_overlaps_fwd")
+    return ov
+
+
+def label_glue(ov: torch.Tensor, box_mask_kt: torch.Tensor, frm_mask: torch.Tensor, pnt_mask: torch.Tensor, want_steps: bool = True):
+    """ov [B, N, K]; box_mask_kt: bool view [B, K, T] (any strides) of mask_boxes[:, 0, :, 1:T+1]; frm_mask [B, N, K]; pnt_mask
+    [B, N + 1].  -> roi_labels [B, T, N] bool, frm_mask_output [B, T, N + 1] bool, step_fmask [T, B, N] bool (or None)."""
+    B, N, K = ov.shape
+    T = box_mask_kt.shape[2]
+    bm = box_mask_kt if box_mask_kt.dtype == torch.uint8 else box_mask_kt.view(torch.uint8) if box_mask_kt.dtype == torch.bool else (box_mask_kt != 0).view(torch.uint8)
+    fm, pm = _mask(frm_mask), _mask(pnt_mask)
+    labels = torch.empty(B, T, N, device=ov.device, dtype=torch.uint8)
+    fmo = torch.empty(B, T, N + 1, device=ov.device, dtype=torch.uint8)
+    steps = torch.empty(T, B, N, device=ov.device, dtype=torch.uint8) if want_steps else None
+    _check(lib().cvc_label_glue_fwd(_dev(ov), bm.data_ptr(), bm.stride(0), bm.stride(1), bm.stride(2), _dev(fm, torch.uint8),
+                                    _dev(pm, torch.uint8), B, N, K, T, _dev(labels, torch.uint8), _dev(fmo, torch.uint8),
+                                    _dev(steps, torch.uint8), _stream()), "cvc_label_glue_fwd")
+    return labels.view(torch.bool), fmo.view(torch.bool), (None if steps is None else steps.view(torch.bool))
+
+
+def attn_nll_fwd(x0: torch.Tensor, x1: Optional[torch.Tensor], target: torch.Tensor):
+    """-> loss [2] (or [1]), workspace (kept for the backward)"""
+    B, T, N = x0.shape
+    for x in (x0, x1):
+        if x is not None and not (x.is_cuda and x.dtype == torch.float32 and x.stride(2) == 1):
+            raise RuntimeError("cvc.hip.attn_nll: fp32 GPU tensors with unit inner stride (no CPU fallback)")
+    tg = _mask(target)
+    ws = torch.empty(5 * B * T + 1, device=x0.device, dtype=torch.float32)
+    loss = torch.empty(2 if x1 is not None else 1, device=x0.device, dtype=torch.float32)
+    _check(lib().cvc_attn_nll_fwd(x0.data_ptr(), x0.stride(0), x0.stride(1), None if x1 is None else x1.data_ptr(),
+                                  0 if x1 is None else x1.stride(0), 0 if x1 is None else x1.stride(1), _dev(tg, torch.uint8), B, T, N,
+                                  _dev(ws), _dev(loss), _stream()), "cvc_attn_nll_fwd")
+    return loss, ws, tg
+
+
+def attn_nll_bwd(x0, x1, tg, ws, g0, g1, want0: bool, want1: bool):
+    B, T, N = x0.shape
+    d0 = torch.empty(B, T, N, device=x0.device, dtype=torch.float32) if want0 else None
+    d1 = torch.empty(B, T, N, device=x0.device, dtype=torch.float32) if (want1 and x1 is not None) else None
+    _check(lib().cvc_attn_nll_bwd(x0.data_ptr(), x0.stride(0), x0.stride(1), None if x1 is None else x1.data_ptr(),
+                                  0 if x1 is None else x1.stride(0), 0 if x1 is None else x1.stride(1), _dev(tg, torch.uint8), B, T, N,
+                                  _dev(ws), _dev(g0), _dev(g1), _dev(d0), _dev(d1), _stream()), "cvc_attn_nll_bwd")
+    return d0, d1
 
 
 # --------------------------------------------------------------------------- tile path (rows > 64), csrc/gemm_tile.hip

@@ -90,6 +90,10 @@ class LMCriterion(nn.Module):
         # supervised attention / grounding losses (w_att2 = 0 by default).  The reference
         # branches on `att2_target.sum() != 0` and uses masked_select (:150-162); the same value without a host round
         # trip or a data-dependent shape: -sum(log_softmax * target) / max(count, 1), which is 0 when nothing is labelled.
+        if att2_weights.is_cuda and att2_weights.dtype == torch.float32 and ground_weights.dtype == torch.float32 \
+                and att2_weights.dim() == 3 and att2_weights.stride(2) == 1 and ground_weights.stride(2) == 1:
+            # both criteria of all T steps from one kernel pair (csrc/label_glue.hip), no library log_softmax / masked sums
+            return F_.attn_nll(att2_weights, ground_weights, att2_target)
         tgt = att2_target.to(att2_weights.dtype)
         count = tgt.sum().clamp(min=1.0)
         att2_loss = (-(F.log_softmax(att2_weights, dim=2) * tgt).sum() / count).reshape(1)

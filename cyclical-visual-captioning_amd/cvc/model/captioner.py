@@ -154,7 +154,10 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
                             frm_mask, sample_idx, pnt_mask)
 
     def _encode(self, segs_feat, proposals, num, mask_boxes, region_feats, gt_boxes, frm_mask, sample_idx, pnt_mask):
-        overlaps = utils.bbox_overlaps(proposals.data, gt_boxes.data, (frm_mask | pnt_mask[:, 1:].unsqueeze(-1)).data)
+        if proposals.is_cuda and proposals.dtype == torch.float32 and gt_boxes.dtype == torch.float32:
+            overlaps = hip.bbox_overlaps(proposals.data, gt_boxes.data, frm_mask.data, pnt_mask[:, 1:].data)     # one launch, bit-exact
+        else:
+            overlaps = utils.bbox_overlaps(proposals.data, gt_boxes.data, (frm_mask | pnt_mask[:, 1:].unsqueeze(-1)).data)
         return overlaps, self.roi_feat_extractor(segs_feat, proposals, num, mask_boxes, region_feats, gt_boxes, overlaps,
                                                  sample_idx)
 
@@ -167,7 +170,6 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         gt_caption = gt_caption[:, :self.seq_per_img, :].clone().view(-1, gt_caption.size(2))
         gt_caption = torch.cat((gt_caption.new_zeros(gt_caption.size(0), 1), gt_caption), 1)     # BOS = 0
         input_seq = input_seq.view(-1, input_seq.size(2), input_seq.size(3))
-        input_seq_update = input_seq.data.clone()
         B = gt_caption.size(0)
         if self.training and dropout.in_kernel(self.logit.weight):
             dropout.advance(self.device)              # this pass's masks: step word of the in-kernel generator += 1, on the device
@@ -180,11 +182,17 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         # ---- label glue for all T steps at once (reference :246-260 does it per step; none of it depends on
         # the recurrence): per-word proposal labels and the frame mask on proposals
         tgt_steps = slice(1, T + 1)
+        if overlaps.is_cuda and overlaps.dtype == torch.float32:
+            # one kernel for all T steps (csrc/label_glue.hip): bool results, bit-exact; the deprecated seq_update side effect of
+            # bbox_target (a clone nobody reads, misc/utils.py:363-371) is not reproduced
+            roi_labels, frm_mask_output, step_fmask = hip.label_glue(overlaps, mask_boxes[:, 0, :, tgt_steps], frm_mask, pnt_mask)
+            return self._forward_after_glue(gt_caption, input_seq, fc_feats, conv_feats, p_conv_feats, pool_feats, p_pool_feats,
+                                            g_pool_feats, region_mask, step_fmask, frm_mask_output, roi_labels, cls_loss)
         bm = mask_boxes[:, :, :, tgt_steps]                                           # [B, seq_per_img, K, T]
         ov = overlaps.unsqueeze(1).masked_fill(bm[:, 0].permute(0, 2, 1).unsqueeze(2).expand(B, T, num_rois, -1), 0)
         roi_labels = ov.max(3)[0] > 0.5                                                # [B, T, N]   (utils.bbox_target)
         no_prop = (roi_labels.sum(2) > 0) != (input_seq[:, tgt_steps, 2] > 0)          # deprecated seq_update side effect
-        upd = input_seq_update[:, tgt_steps]
+        upd = input_seq.data.clone()[:, tgt_steps]
         upd[..., 0] = torch.where(no_prop, upd[..., 3], upd[..., 0])
         upd[..., 1] = torch.where(no_prop, torch.zeros_like(upd[..., 1]), upd[..., 1])
         upd[..., 2] = torch.where(no_prop, torch.zeros_like(upd[..., 2]), upd[..., 2])
@@ -192,7 +200,15 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         frm_on_prop = torch.sum(~(box_mask_t | frm_mask.unsqueeze(1)), dim=3) <= 0     # [B, T, N]
         frm_mask_output = torch.cat((frm_on_prop.new_zeros(B, T, 1), frm_on_prop), dim=2) | pnt_mask.bool().unsqueeze(1)
         step_fmask = frm_mask_output[:, :, 1:].permute(1, 0, 2).contiguous()           # [T, B, N]
+        return self._forward_after_glue(gt_caption, input_seq, fc_feats, conv_feats, p_conv_feats, pool_feats, p_pool_feats,
+                                        g_pool_feats, region_mask, step_fmask, frm_mask_output, roi_labels, cls_loss)
 
+    def _forward_after_glue(self, gt_caption, input_seq, fc_feats, conv_feats, p_conv_feats, pool_feats, p_pool_feats, g_pool_feats,
+                            region_mask, step_fmask, frm_mask_output, roi_labels, cls_loss):
+        """_forward_3_loops from loop A on (reference :242-382)"""
+        T = self.seq_length
+        B = gt_caption.size(0)
+        num_rois = pool_feats.size(1)
         # ---- Loop A: teacher-forced decode (sequential: LSTM recurrence)            reference :242-270
         emb_all = self._embed(gt_caption[:, :T], "emb_a")                            # [B, T, E], one launch
         loops = self._loop_plan(B, fc_feats)

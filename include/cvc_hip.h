@@ -486,6 +486,34 @@ int cvc_grounder_bwd(const float* d, const float* xt, const float* feats, int B,
                      float* d_xt, float* d_feats, cvc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Label glue and the supervised attention criteria, all T steps per launch.
+ *   cvc_bbox_overlaps_fwd : misc/utils.py:335-338 -> misc/bbox_transform.py:224-272.  ov[b, n, k] = IoU(+1-pixel convention) of
+ *       proposal n (rois [B, N, ld_roi >= 4]: x1, y1, x2, y2, ...) and ground-truth box k (gt [B, K, ld_gt >= 4]); times 0 where
+ *       frm_mask[b, n, k] or pnt_mask[b, n] (uint8, nullable, row stride ld_pnt) is set; 0 for degenerate (1 x 1) ground-truth
+ *       boxes, -1 for degenerate proposals.  Evaluated in the reference's operation order, each operation rounded on its own.
+ *   cvc_label_glue_fwd : misc/utils.py:351-373 + model/captioner.py:246-260 for t = 0 .. T-1 at once.
+ *       box_mask element (b, k, t) at b * bm_stride_b + k * bm_stride_k + t * bm_stride_t (a view of mask_boxes[:, 0, :, 1:T+1]);
+ *       labels[b, t, n] = max_k (box_mask ? 0 : ov[b, n, k]) > 0.5;
+ *       frm_mask_output[b, t, 0] = pnt_mask[b, 0], [b, t, 1 + n] = (for every k: box_mask | frm_mask[b, n, k]) | pnt_mask[b, 1 + n]
+ *       (pnt_mask [B, N + 1] uint8); step_fmask [T, B, N] (nullable) = frm_mask_output[:, :, 1:] with the step leading (what the
+ *       decode loop's attention takes).  bool / integer results: bit-exact.
+ *   cvc_attn_nll_fwd / _bwd : misc/utils.py:150-162 for one or two score tensors x [B, T, N] (element (b, t, n) at
+ *       b * stride_b + t * stride_t + n; att2_weights and ground_weights share the target):
+ *       loss[i] = -sum(log_softmax(x_i, 2) * target) / max(sum(target), 1); workspace: 5 * B * T + 1 floats, kept for the backward;
+ *       d_x_i[b, t, n] (contiguous) = g_i[0] / count * (softmax(x_i)[n] * targets_in_row - target[n])  (g_i: device scalars). */
+int cvc_bbox_overlaps_fwd(const float* rois, int ld_roi, const float* gt, int ld_gt, const uint8_t* frm_mask,
+                          const uint8_t* pnt_mask, int ld_pnt, int B, int N, int K, float* ov, cvc_stream_t stream);
+int cvc_label_glue_fwd(const float* ov, const uint8_t* box_mask, long long bm_stride_b, long long bm_stride_k,
+                       long long bm_stride_t, const uint8_t* frm_mask, const uint8_t* pnt_mask, int B, int N, int K, int T,
+                       uint8_t* labels, uint8_t* frm_mask_output, uint8_t* step_fmask, cvc_stream_t stream);
+int cvc_attn_nll_fwd(const float* x0, long long x0_stride_b, long long x0_stride_t, const float* x1, long long x1_stride_b,
+                     long long x1_stride_t, const uint8_t* target, int B, int T, int N, float* workspace, float* loss,
+                     cvc_stream_t stream);
+int cvc_attn_nll_bwd(const float* x0, long long x0_stride_b, long long x0_stride_t, const float* x1, long long x1_stride_b,
+                     long long x1_stride_t, const uint8_t* target, int B, int T, int N, const float* workspace,
+                     const float* g0, const float* g1, float* d_x0, float* d_x1, cvc_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Beam bookkeeping (build-defined, SURVEY.md section 7 "Beam-search specification"):
  * per clip select the `beam` best of beam*V candidates score[b,k] + logp[b,k,v] with
  * logp[unk] = -inf, finished hypotheses frozen (only v = 0 at +0); beam <= 8, beam < V <= 8192.

@@ -1131,3 +1131,60 @@ def test_lstm_train_form_of_packed_gemm(dev, lib, M, R, widths):
 
 
 
+
+
+# ------------------------------------------------------------------ label glue + supervised attention criteria (section 8(f) rank 2)
+@pytest.mark.parametrize("cfg", ["tiny", "cfg1", "cfg3"])
+def test_label_glue_kernels_bit_exact_vs_oracle(dev, lib, cfg):
+    """cvc_bbox_overlaps_fwd / cvc_label_glue_fwd (all T steps per launch) against the oracle's per-step bbox_overlaps /
+    bbox_target / frame_mask_on_proposals: IoU values and every bool, bit for bit.  Degenerate boxes, frame mismatches and a
+    masked proposal column included."""
+    from oracle import ref_cpu as O
+    from cvc import hip
+    d = synth.CONFIGS[cfg]
+    b = synth.label_glue_batch(d, 31)
+    f = synth.clip_features(d, 31)
+    prop, gtb = torch.from_numpy(b["proposals"]).clone(), torch.from_numpy(b["gt_bboxs"]).clone()
+    prop[0, 1, 2:4] = prop[0, 1, 0:2]                       # degenerate proposal (1 x 1): -1 everywhere
+    gtb[-1, 0, 2:4] = gtb[-1, 0, 0:2]                       # degenerate ground-truth box: 0
+    frm_mask = torch.from_numpy(b["frm_mask"])
+    pnt = torch.from_numpy(f["pnt_mask"]).clone()
+    pnt[0, 3] = True
+    box_mask = torch.from_numpy(b["box_mask"])
+    T, N = d.T, d.N
+    ov_o = O.bbox_overlaps(prop, gtb, frm_mask | pnt[:, 1:].unsqueeze(-1))
+    ov = hip.bbox_overlaps(prop.to(dev), gtb.to(dev), frm_mask.to(dev), pnt[:, 1:].to(dev))
+    assert torch.equal(ov.cpu().view(torch.int32), ov_o.view(torch.int32)), float((ov.cpu() - ov_o).abs().max())
+    lab, fmo, steps = hip.label_glue(ov, box_mask.to(dev)[:, 0, :, 1:T + 1], frm_mask.to(dev), pnt.to(dev))
+    for t in range(T):
+        bm_t = box_mask[:, 0, :, t + 1]
+        assert torch.equal(lab[:, t].cpu(), O.bbox_target(bm_t, ov_o)), t
+        want = O.frame_mask_on_proposals(bm_t, frm_mask, pnt)
+        assert torch.equal(fmo[:, t].cpu(), want), t
+        assert torch.equal(steps[t].cpu(), want[:, 1:]), t
+    assert lab.any() and not lab.all() and fmo[:, :, 1:].any() and not fmo.all()
+
+
+@pytest.mark.parametrize("B,T,N", [(3, 4, 7), (64, 20, 100)])
+def test_attn_nll_kernels_vs_fp64(dev, lib, B, T, N):
+    """att2_loss / ground_loss (misc/utils.py:150-162) forward + backward from cvc_attn_nll_* against the formula in fp64; one
+    input a transposed view (the decode loop hands att2_weights over as [T, B, N] storage); the no-label case gives exactly 0."""
+    from cvc import functional as F_
+    g = torch.Generator().manual_seed(B + N)
+    x0s = torch.randn(T, B, N, generator=g).to(dev).requires_grad_(True)          # storage [T, B, N], used as [B, T, N]
+    x1 = (torch.randn(B, T, N, generator=g) * 3).to(dev).requires_grad_(True)
+    x1.data[0, 0, :3] = -1e8                                                       # masked slots of the grounder
+    tgt = (torch.rand(B, T, N, generator=g) < 0.05).to(dev)
+    l0, l1 = F_.attn_nll(x0s.transpose(0, 1), x1, tgt)
+    (0.3 * l0.sum() + 0.7 * l1.sum()).backward()
+    a0, a1 = x0s.detach().double().transpose(0, 1).clone().requires_grad_(True), x1.detach().double().clone().requires_grad_(True)
+    cnt = tgt.double().sum().clamp(min=1.0)
+    r0 = -(torch.log_softmax(a0, 2) * tgt.double()).sum() / cnt
+    r1 = -(torch.log_softmax(a1, 2) * tgt.double()).sum() / cnt
+    (0.3 * r0 + 0.7 * r1).backward()
+    np.testing.assert_allclose(float(l0), float(r0), rtol=2e-5)
+    np.testing.assert_allclose(float(l1), float(r1), rtol=2e-5)
+    np.testing.assert_allclose(x0s.grad.transpose(0, 1).cpu().double().numpy(), a0.grad.cpu().numpy(), rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(x1.grad.cpu().double().numpy(), a1.grad.cpu().numpy(), rtol=1e-4, atol=1e-7)
+    z0, z1 = F_.attn_nll(x0s.detach().transpose(0, 1), x1.detach(), torch.zeros_like(tgt))
+    assert float(z0) == 0.0 and float(z1) == 0.0
