@@ -178,6 +178,8 @@ int run_bwd(const cvc_train_loop& L, hipStream_t st, int* launches) {
     const cvc_grad_src none{nullptr, 0, 0, 0};
     cvc_grad_src g_hl_a = none, g_hl_b = none, g_ha_prev = none;       // what step t + 1 left for step t
     int n = 0;
+    if (L.dgsum_att) CVC_TRY(zero(L.dgsum_att, BG, st));
+    if (L.dgsum_lang) CVC_TRY(zero(L.dgsum_lang, BG, st));
     for (int t = T - 1; t >= 0; --t) {
         const bool last = t + 1 == T;
         // ---- language cell: d_h = dropout'(d_out[t]) + the next step's two uses of h_lang(t)
@@ -185,7 +187,8 @@ int run_bwd(const cvc_train_loop& L, hipStream_t st, int* launches) {
             const cvc_grad_src src[3] = {g_hl_a, g_hl_b, none};
             CVC_TRY(cvc_lstm_pointwise_bwd4(src, L.d_out + (size_t)t * BR, L.p > 0.f ? L.rng_state : nullptr, L.site0 + (unsigned)t, L.p,
                                             last ? nullptr : w.d_c_lang, L.g_lang + (size_t)t * BG, L.c_lang + (size_t)t * BR,
-                                            L.c_lang + (size_t)(t + 1) * BR, B, R, L.dg_lang + (size_t)t * BG, w.d_c_lang, w.dgq, st));
+                                            L.c_lang + (size_t)(t + 1) * BR, B, R, L.dg_lang + (size_t)t * BG, w.d_c_lang, w.dgq,
+                                            L.dgsum_lang, st));
         }
         cvc_grad_src g_ctx = none, g_ha_a = none, g_ha_b = none;
         {
@@ -224,7 +227,7 @@ int run_bwd(const cvc_train_loop& L, hipStream_t st, int* launches) {
             const cvc_grad_src src[3] = {g_ha_a, g_ha_b, g_ha_prev};
             CVC_TRY(cvc_lstm_pointwise_bwd4(src, nullptr, nullptr, 0, 0.f, last ? nullptr : w.d_c_att, L.g_att + (size_t)t * BG,
                                             L.c_att + (size_t)t * BR, L.c_att + (size_t)(t + 1) * BR, B, R, L.dg_att + (size_t)t * BG,
-                                            w.d_c_att, w.dgq, st));
+                                            w.d_c_att, w.dgq, L.dgsum_att, st));
         }
         if (t > 0) {
             cvc_nn_seg segs[2] = {cvc_nn_seg{L.w_ih_att, w.d_hl_b, L.ld_ih_att, R, R}, cvc_nn_seg{L.w_hh_att, w.d_ha_prev, R, R, R}};
@@ -268,5 +271,5 @@ extern "C" int cvc_train_loop_launches(const cvc_train_loop* loop, int backward)
     // backward-data products leave their K-slice planes to the readers (no summing launch); attention backward = score pass + softmax
     // backward + score backward
     const int per = loop->kind == 0 ? (1 + 1 + 3 + 1 + 1 + 1) : (1 + 1 + 1 + 1);
-    return T * per - 1;          // (step 0 has no recurrent product of the attention cell)
+    return T * per - 1 + (loop->dgsum_att ? 1 : 0) + (loop->dgsum_lang ? 1 : 0);          // (step 0 has no recurrent product of the attention cell)
 }

@@ -409,6 +409,75 @@ __global__ __launch_bounds__(WG) void vocab_nll_bwd_kernel(const float* logits, 
     d_logits[o] = gw == 0.f ? 0.f : gw * (expf(logits[o] - lse[m]) - (v == (int)target[m] ? 1.f : 0.f));
 }
 
+// Vocabulary head criterion folded into the GEMM's finishing pass (captioner.py:266, :313, :361 +
+// misc/utils.py:132-146, 181-192): the K-slice slabs of the head's tile GEMM are summed (+ bias) into registers, the row's
+// log-sum-exp, argmax and weighted NLL are taken there, and what is WRITTEN is not the logits but
+//     pre[m, v] = w[m] * (softmax(logits[m])[v] - [v == target[m]])
+// -- the gradient of the row's loss term with respect to the logits, which the backward scales by the upstream scalar.  The
+// [B*T, V] logits never exist as a tensor in training.  `pre` may alias slab 0 (every thread reads its columns of all slabs
+// before it writes).  V <= 256 * NLL_CACHE.
+constexpr int NLL_CACHE = 32;
+__global__ __launch_bounds__(WG) void vocab_head_nll_kernel(const float* parts, int nparts, long long part_stride, int ld, const float* bias,
+                                                            const int64_t* target, const float* w, int V, float* pre, int ld_pre,
+                                                            int64_t* argmax, float* row_loss) {
+    __shared__ float red[4];
+    __shared__ int ired[4];
+    __shared__ float xt_s;
+    const int row = blockIdx.x;
+    const float* x = parts + (size_t)row * ld;
+    const int tgt = (int)target[row];
+    float vals[NLL_CACHE];
+    float m = -INFINITY;
+    int mi = 0x7fffffff;
+#pragma unroll
+    for (int u = 0; u < NLL_CACHE; ++u) {
+        const int v = threadIdx.x + u * WG;
+        float xv = -INFINITY;
+        if (v < V) {
+            xv = x[v];
+            for (int p = 1; p < nparts; ++p) xv += x[(size_t)p * part_stride + v];
+            if (bias != nullptr) xv += bias[v];
+            if (xv > m) { m = xv; mi = v; }                   // ascending v per thread: first occurrence wins
+            if (v == tgt) xt_s = xv;
+        }
+        vals[u] = xv;
+    }
+    const float bm = block_max(m, red);
+    int cand = m == bm ? mi : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) ired[threadIdx.x >> 6] = cand;
+    __syncthreads();
+    const int best = min(min(ired[0], ired[1]), min(ired[2], ired[3]));
+    float s = 0.f;
+#pragma unroll
+    for (int u = 0; u < NLL_CACHE; ++u)
+        if (threadIdx.x + u * WG < V) s += expf(vals[u] - bm);
+    s = block_sum(s, red);
+    const float lse = bm + logf(s);
+    const float wm = w[row];
+    if (threadIdx.x == 0) {
+        if (argmax != nullptr) argmax[row] = best == 0x7fffffff ? 0 : best;
+        row_loss[row] = wm != 0.f ? wm * (lse - xt_s) : 0.f;
+    }
+    float* out = pre + (size_t)row * ld_pre;
+#pragma unroll
+    for (int u = 0; u < NLL_CACHE; ++u) {
+        const int v = threadIdx.x + u * WG;
+        if (v < V) out[v] = wm == 0.f ? 0.f : wm * (expf(vals[u] - lse) - (v == tgt ? 1.f : 0.f));
+    }
+}
+
+// y[i] = g[0] * x[i] (the backward of the fused head criterion: d_logits = upstream scalar x pre), float4 granules
+__global__ __launch_bounds__(WG) void scale_by_scalar_kernel(const float* x, const float* g, long long n4, float* y) {
+    const long long i = (long long)blockIdx.x * WG + threadIdx.x;
+    if (i >= n4) return;
+    const float s = g[0];
+    const f32x4 v = ld4(x + i * 4);
+    st4(y + i * 4, f32x4{v.x * s, v.y * s, v.z * s, v.w * s});
+}
+
 // ------------------------------------------------------------------ LSTM pointwise backward
 __global__ __launch_bounds__(WG) void lstm_pointwise_bwd_kernel(const float* d_h, const float* d_h2, const float* d_h3, const float* d_c,
                                                                 const float* gates, const float* c_prev, const float* c_new, int M,
@@ -455,13 +524,17 @@ __device__ __forceinline__ float hsrc_load(const cvc_grad_src& g, int m, int j) 
 }
 __global__ __launch_bounds__(WG) void lstm_pointwise_bwd4_kernel(HSrc3 src, const float* d_hd, DropSpec rng, const float* d_c,
                                                                  const float* gates, const float* c_prev, const float* c_new, int M,
-                                                                 int R, float* d_gates, float* d_c_prev, float* d_gates_q) {
+                                                                 int R, float* d_gates, float* d_c_prev, float* d_gates_q, float* dg_sum) {
     const int j = blockIdx.x * WG + threadIdx.x;
     const int m = blockIdx.y;
     if (j >= R) return;
     const size_t o = (size_t)m * R + j, g0 = (size_t)m * 4 * R + j;
     const float ig = gates[g0], fg = gates[g0 + R], gg = gates[g0 + 2 * R], og = gates[g0 + 3 * R];
     const float tc = tanhf(c_new[o]);
+    // running sum over the steps of the loop (dg_sum [M, 4R], zero before the last step's launch): the bias gradients and the dY of
+    // the step-invariant fc_feats columns, accumulated by the same thread launch after launch (stream-ordered: deterministic)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (dg_sum != nullptr) { s0 = dg_sum[g0]; s1 = dg_sum[g0 + R]; s2 = dg_sum[g0 + 2 * R]; s3 = dg_sum[g0 + 3 * R]; }
     float dhd = d_hd != nullptr ? d_hd[o] : 0.f;
     if (rng.state != nullptr) dhd *= cvc_drop_mult(rng, rng.state[0], rng.state[1], rng.state[2], (uint32_t)o);
     const float dh = ((hsrc_load(src.s[0], m, j) + hsrc_load(src.s[1], m, j)) + hsrc_load(src.s[2], m, j)) + dhd;
@@ -473,6 +546,7 @@ __global__ __launch_bounds__(WG) void lstm_pointwise_bwd4_kernel(HSrc3 src, cons
     d_gates[g0 + 2 * R] = d2;
     d_gates[g0 + 3 * R] = d3;
     d_c_prev[o] = dcn * fg;
+    if (dg_sum != nullptr) { dg_sum[g0] = s0 + d0; dg_sum[g0 + R] = s1 + d1; dg_sum[g0 + 2 * R] = s2 + d2; dg_sum[g0 + 3 * R] = s3 + d3; }
     if (d_gates_q != nullptr) {
         const size_t q0 = ((size_t)(j >> 2) * 64 + m) * 4 + (j & 3), qs = (size_t)(R >> 2) * 256;
         d_gates_q[q0] = d0;
@@ -833,6 +907,25 @@ extern "C" int cvc_vocab_nll_fwd(const float* logits, const int64_t* target, con
     return cvc_launch_status();
 }
 
+extern "C" int cvc_vocab_head_nll_fwd(const float* parts, int nparts, long long part_stride, int ld, const float* bias,
+                                      const int64_t* target, const float* w, int M, int V, float* pre, int ld_pre, int64_t* argmax,
+                                      float* row_loss, float* loss_sum, cvc_stream_t stream) {
+    if (!parts || nparts < 1 || !target || !w || !pre || !row_loss || !loss_sum || M < 1 || V < 1 || V > WG * NLL_CACHE || ld < V ||
+        ld_pre < V)
+        return CVC_E_BADARG;
+    hipLaunchKernelGGL(vocab_head_nll_kernel, dim3(M), dim3(WG), 0, (hipStream_t)stream, parts, nparts, part_stride, ld, bias, target, w, V,
+                       pre, ld_pre, argmax, row_loss);
+    hipLaunchKernelGGL(row_sum_kernel, dim3(1), dim3(WG), 0, (hipStream_t)stream, row_loss, M, loss_sum);
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_scale_by_scalar(const float* x, const float* g, long long n, float* y, cvc_stream_t stream) {
+    if (!x || !g || !y || n < 4 || (n & 3) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return CVC_E_BADARG;
+    const long long n4 = n / 4;
+    hipLaunchKernelGGL(scale_by_scalar_kernel, dim3((unsigned)((n4 + WG - 1) / WG)), dim3(WG), 0, (hipStream_t)stream, x, g, n4, y);
+    return cvc_launch_status();
+}
+
 extern "C" int cvc_vocab_nll_bwd(const float* logits, const float* lse, const int64_t* target, const float* w,
                                  const float* g, int M, int V, float* d_logits, cvc_stream_t stream) {
     if (!logits || !lse || !target || !w || !g || !d_logits || M < 1 || V < 1) return CVC_E_BADARG;
@@ -876,7 +969,7 @@ extern "C" int cvc_lstm_pointwise_bwd3_drop(const float* d_h, const float* d_h2,
 
 extern "C" int cvc_lstm_pointwise_bwd4(const cvc_grad_src* d_h, const float* d_hd, const uint32_t* rng_state, unsigned site, float p,
                                        const float* d_c, const float* gates, const float* c_prev, const float* c_new, int M, int R,
-                                       float* d_gates, float* d_c_prev, float* d_gates_q, cvc_stream_t stream) {
+                                       float* d_gates, float* d_c_prev, float* d_gates_q, float* dg_sum, cvc_stream_t stream) {
     if (!d_h || !gates || !c_prev || !c_new || !d_gates || !d_c_prev || M < 1 || R < 1 || p < 0.f || p >= 1.f) return CVC_E_BADARG;
     if (d_gates_q != nullptr && (M > 64 || (R & 3))) return CVC_E_BADARG;
     HSrc3 src;
@@ -885,7 +978,7 @@ extern "C" int cvc_lstm_pointwise_bwd4(const cvc_grad_src* d_h, const float* d_h
         if (src.s[i].p != nullptr && (src.s[i].nplanes < 1 || src.s[i].ld < R)) return CVC_E_BADARG;
     }
     hipLaunchKernelGGL(lstm_pointwise_bwd4_kernel, dim3((R + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, src, d_hd,
-                       cvc_drop_spec(rng_state, site, p), d_c, gates, c_prev, c_new, M, R, d_gates, d_c_prev, d_gates_q);
+                       cvc_drop_spec(rng_state, site, p), d_c, gates, c_prev, c_new, M, R, d_gates, d_c_prev, d_gates_q, dg_sum);
     return cvc_launch_status();
 }
 

@@ -129,7 +129,7 @@ def _mm_nn(dy: Tensor, w: Tensor) -> Tensor:
         seg = (w, 0, w.shape[1])
         if hip.linear_nn_ok(M, N, [seg]):
             return hip.linear_nn(hip.pack_quad(dy), M, N, [seg])[0]
-    return hip.tile_mm(dy, w, b_kmajor=True)
+    return hip.tile_mm(dy, hip.weight_operand(w, kmajor=True))       # (the weight's pack is shared by the step's products)
 
 
 # ------------------------------------------------------------------------------- linear
@@ -152,9 +152,7 @@ class _Linear(torch.autograd.Function):
             # many rows (a layer applied to all T steps at once): ONE pass over the weights on the tile GEMM; the skinny
             # kernel would re-stream them per 64-row slab
             x = torch.cat(xs, 1) if len(xs) > 1 else xs[0]
-            y = hip.tile_mm(x, weight)
-            if bias is not None:
-                y += bias
+            y = hip.tile_mm(x, hip.weight_operand(weight), bias=bias)
         else:
             y = hip.linear_fwd(segs, bias, M, weight.shape[0])
         ctx.save_for_backward(weight, bias, *xs)
@@ -167,32 +165,74 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         weight, bias, *xs = ctx.saved_tensors
-        dy = dy.contiguous()
-        d_w = d_b = None
-        if ctx.needs_input_grad[0]:
-            x = torch.cat(xs, 1) if len(xs) > 1 else xs[0]
+        return _linear_backward(ctx, weight, bias, xs, dy.contiguous(), ctx.needs_input_grad)
 
-            def flush(items):
-                D = torch.cat([i[0] for i in items], 0) if len(items) > 1 else items[0][0]
-                X = torch.cat([i[1] for i in items], 0) if len(items) > 1 else items[0][1]
-                # (into the gradient owner's buffer when it hands one out: no AccumulateGrad add, see GRAD_SINKS)
-                dw = _into_grad(weight, lambda out: hip.tile_mm(D, X, a_kmajor=True, b_kmajor=True, out=out))
-                db = _into_grad(bias, lambda out: torch.sum(D, 0, out=out) if out is not None else D.sum(0)) if ctx.has_bias else None
-                return dw, db
 
-            res = _BATCHER.add(ctx.key, (dy, x), (weight, bias), flush)
-            if res is not None:
-                d_w, d_b = res
-                if not (ctx.has_bias and ctx.needs_input_grad[1]):
-                    d_b = None
-        elif ctx.has_bias and ctx.needs_input_grad[1]:
-            d_b = dy.sum(0)
-        d_xs, k0 = [], 0
-        for i, x in enumerate(xs):
-            k = x.shape[1]
-            d_xs.append(_mm_nn(dy, weight[:, k0:k0 + k]) if ctx.needs_input_grad[2 + i] else None)
-            k0 += k
-        return (d_w, d_b, *d_xs)
+def _linear_backward(ctx, weight, bias, xs, dy, ni):
+    """autograd of y = cat(xs) W^T + b given dy: (d_w, d_b, *d_xs); dW deferred over all uses of the weight (_BATCHER).
+    ni: needs-grad flags in the order (weight, bias, *xs); ctx carries key / has_bias."""
+    d_w = d_b = None
+    if ni[0]:
+        x = torch.cat(xs, 1) if len(xs) > 1 else xs[0]
+
+        def flush(items):
+            D = torch.cat([i[0] for i in items], 0) if len(items) > 1 else items[0][0]
+            X = torch.cat([i[1] for i in items], 0) if len(items) > 1 else items[0][1]
+            # (into the gradient owner's buffer when it hands one out: no AccumulateGrad add, see GRAD_SINKS)
+            dw = _into_grad(weight, lambda out: hip.tile_mm(D, X, a_kmajor=True, b_kmajor=True, out=out))
+            db = _into_grad(bias, lambda out: torch.sum(D, 0, out=out) if out is not None else D.sum(0)) if ctx.has_bias else None
+            return dw, db
+
+        res = _BATCHER.add(ctx.key, (dy, x), (weight, bias), flush)
+        if res is not None:
+            d_w, d_b = res
+            if not (ctx.has_bias and ni[1]):
+                d_b = None
+    elif ctx.has_bias and ni[1]:
+        d_b = dy.sum(0)
+    d_xs, k0 = [], 0
+    for i, x in enumerate(xs):
+        k = x.shape[1]
+        d_xs.append(_mm_nn(dy, weight[:, k0:k0 + k]) if ni[2 + i] else None)
+        k0 += k
+    return (d_w, d_b, *d_xs)
+
+
+class _VocabHeadNLL(torch.autograd.Function):
+    """F.log_softmax(logit(x)) + masked NLL sum + per-row argmax (captioner.py:266, :313, :361; misc/utils.py:132-146, 181-192) with
+    the criterion folded into the finishing pass of the head's GEMM: the [M, V] logits are never written; what is kept for the
+    backward is pre = w * (softmax - onehot), which the backward scales by the upstream scalar and feeds to nn.Linear's products."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, target, w):
+        x = _rows(x)
+        parts = hip.tile_mm(x, hip.weight_operand(weight), parts_only=True)
+        loss, amax, pre = hip.vocab_head_nll_fwd(parts, bias, target.contiguous(), w.contiguous())
+        ctx.save_for_backward(weight, bias, x, pre)
+        ctx.has_bias = bias is not None
+        ctx.key = ("linear", weight.data_ptr())
+        if weight.requires_grad:
+            _BATCHER.note_use(ctx.key)
+        ctx.mark_non_differentiable(amax)
+        return loss, amax
+
+    @staticmethod
+    def backward(ctx, g, _g_amax):
+        weight, bias, x, pre = ctx.saved_tensors
+        dy = hip.scale_by_scalar(pre, g.contiguous().reshape(1))
+        ni = ctx.needs_input_grad
+        d_w, d_b, d_x = _linear_backward(ctx, weight, bias, [x], dy, (ni[1], ni[2], ni[0]))
+        return d_x, d_w, d_b, None, None
+
+
+def vocab_head_nll(x: Tensor, weight: Tensor, bias: Optional[Tensor], target: Tensor, w: Tensor) -> Tuple[Tensor, Tensor]:
+    """-> (sum_m w[m] * -log_softmax(x W^T + b)[m, target[m]] as a [1] tensor, argmax over V per row [M] int64); x [M, K]"""
+    return _VocabHeadNLL.apply(x, weight, bias, target.reshape(-1), w.reshape(-1))
+
+
+def vocab_head_nll_ok(x: Tensor, weight: Tensor) -> bool:
+    return bool(x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and weight.is_contiguous() and weight.shape[0] <= 8192
+                and weight.shape[0] % 4 == 0 and x.shape[0] > TILE_LINEAR_ROWS)
 
 
 def linear(xs, weight: Tensor, bias: Optional[Tensor] = None) -> Tensor:

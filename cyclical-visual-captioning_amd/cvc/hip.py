@@ -106,7 +106,7 @@ class TrainLoop(C.Structure):
         [(n, C.c_void_p) for n in ("out", "h_att", "h_att_prev", "h_lang_prev", "c_att", "c_lang", "g_att", "g_lang", "ctx", "q", "attn_r",
                                    "attn_f", "fm", "scores_ws")] +
         [("xa", C.c_void_p * 2), ("xl", C.c_void_p * 2)] +
-        [(n, C.c_void_p) for n in ("d_out", "d_fm", "dg_att", "dg_lang", "dq", "dwa_part", "ds_r", "ds_f", "d_pool", "d_ppool", "d_conv",
+        [(n, C.c_void_p) for n in ("d_out", "d_fm", "dg_att", "dg_lang", "dgsum_att", "dgsum_lang", "dq", "dwa_part", "ds_r", "ds_f", "d_pool", "d_ppool", "d_conv",
                                    "d_pconv", "bwd_ws")])
 
 
@@ -116,7 +116,9 @@ SIGNATURES = {
     "cvc_attn_wsum_quad_rm": [C.POINTER(AttnSet), _I, _I, _I, _P, _P, _P],
     "cvc_attn_bwd_pair": [_I, C.POINTER(GradSrc), _P, _P, _F, C.POINTER(AttnSet), _I, C.POINTER(GradSrc), _I, _I, _I, _I, _P, _P, _P,
                           C.POINTER(_P), C.POINTER(_P), _P],
-    "cvc_lstm_pointwise_bwd4": [C.POINTER(GradSrc), _P, _P, C.c_uint, _F, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P],
+    "cvc_lstm_pointwise_bwd4": [C.POINTER(GradSrc), _P, _P, C.c_uint, _F, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P],
+    "cvc_vocab_head_nll_fwd": [_P, _I, _LL, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P],
+    "cvc_scale_by_scalar": [_P, _P, _LL, _P, _P],
     "cvc_bbox_overlaps_fwd": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P],
     "cvc_label_glue_fwd": [_P, _P, _LL, _LL, _LL, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "cvc_attn_nll_fwd": [_P, _LL, _LL, _P, _LL, _LL, _P, _I, _I, _I, _P, _P, _P],
@@ -477,6 +479,21 @@ def lstm_train_new_step() -> None:
     the step whatever their autograd version says (a captured training step must contain the re-pack launch)."""
     global _train_generation
     _train_generation += 1
+    _step_operands.clear()
+
+
+# tile-GEMM operand packs of WEIGHTS (or column slices of them), shared by every product of one training step that reads the same
+# weight the same way: the vocabulary head is multiplied in both loops and read again by both backward-data products, the embedding
+# columns of the attention cell by both loops' hoisted products and both d_emb products.  Cleared at the start of every forward.
+_step_operands = {}
+
+
+def weight_operand(w: torch.Tensor, kmajor: bool = False) -> "TileOperand":
+    key = (w.data_ptr(), tuple(w.shape), tuple(w.stride()), bool(kmajor), _train_generation, w._version)
+    op = _step_operands.get(key)
+    if op is None:
+        op = _step_operands[key] = TileOperand(w.detach(), kmajor)
+    return op
 
 
 def lstm_train_ok(M: int, R: int, widths: Sequence[int]) -> bool:
@@ -728,6 +745,26 @@ def vocab_nll_fwd(logits, target, w, want_argmax=True):
     return loss, lse, amax
 
 
+def vocab_head_nll_fwd(parts, bias, target, w):
+    """parts [ks, M, V]: the vocabulary head's K-slice slabs.  -> loss_sum [1], argmax [M], pre [M, V] (aliasing slab 0)"""
+    ks, M, V = parts.shape
+    dev = parts.device
+    row_loss = torch.empty(M, device=dev, dtype=torch.float32)
+    loss = torch.empty(1, device=dev, dtype=torch.float32)
+    amax = torch.empty(M, device=dev, dtype=torch.int64)
+    pre = parts[0]
+    _check(lib().cvc_vocab_head_nll_fwd(_dev(parts), ks, M * V, V, _dev(bias), _dev(target, torch.int64), _dev(w), M, V, pre.data_ptr(), V,
+                                        _dev(amax, torch.int64), _dev(row_loss), _dev(loss), _stream()), "cvc_vocab_head_nll_fwd")
+    return loss, amax, pre
+
+
+def scale_by_scalar(x, g):
+    """g[0] * x with g a device scalar tensor (no host read)"""
+    y = torch.empty_like(x)
+    _check(lib().cvc_scale_by_scalar(_dev(x), _dev(g), x.numel(), _dev(y), _stream()), "cvc_scale_by_scalar")
+    return y
+
+
 def vocab_nll_bwd(logits, lse, target, w, g):
     M, V = logits.shape
     d = torch.empty_like(logits)
@@ -871,6 +908,39 @@ def tile_pack_rows(x: torch.Tensor, xb: torch.Tensor, k0: int = 0, idx: Optional
     return xb
 
 
+class _FragPool:
+    """Fragment buffers of TileOperand, reused across calls.  A buffer is keyed by everything that decides which of its bytes the
+    packers never write (rows, K -> the zero padding of the last row blocks / k step), so the padding is cleared ONCE per buffer
+    instead of by a fill launch per operand (27 per training step); buffers return to the pool when their operand dies.  All use is
+    stream-ordered on the launch stream.  Buffers taken while a HIP graph is being captured stay with that capture."""
+
+    def __init__(self):
+        self.free = {}
+
+    def take(self, rows: int, K: int, device):
+        rows_alloc = max(tile_rows_alloc(rows), (rows + 127) // 128 * 128)
+        key = (rows, K, str(device), torch.cuda.is_current_stream_capturing())
+        lst = self.free.get(key)
+        if lst:
+            return lst.pop(), key
+        frags = torch.empty(rows_alloc // 32, (K + 15) // 16, 3, 2, 32, 8, dtype=torch.int16, device=device)
+        # padding must read as zero: only what the packer does not write completely is cleared -- the row blocks past the last
+        # full one, and the last k step when K is not a multiple of 16 (the row packer writes whole quads, not whole k steps)
+        if rows_alloc > rows:
+            frags[rows // 32:].zero_()
+        if K % 16 != 0:
+            frags[:, -1].zero_()
+        return frags, key
+
+    def give(self, frags, key):
+        lst = self.free.setdefault(key, [])
+        if len(lst) < 8:
+            lst.append(frags)
+
+
+_FRAGS = _FragPool()
+
+
 class TileOperand:
     """One operand of tile_mm, packed once into bf16 split-term fragments (reusable as either side of several products)."""
 
@@ -883,14 +953,7 @@ class TileOperand:
         if t.stride(1) != 1:
             t = t.contiguous()
         self.rows, self.K = (t.shape[1], t.shape[0]) if kmajor else (t.shape[0], t.shape[1])
-        rows_alloc = max(tile_rows_alloc(self.rows), (self.rows + 127) // 128 * 128)
-        # padding must read as zero: only what the packer does not write completely is cleared -- the row blocks past the last
-        # full one, and the last k step when K is not a multiple of 16 (the row packer writes whole quads, not whole k steps)
-        self.frags = torch.empty(rows_alloc // 32, (self.K + 15) // 16, 3, 2, 32, 8, dtype=torch.int16, device=t.device)
-        if rows_alloc > self.rows:
-            self.frags[self.rows // 32:].zero_()
-        if self.K % 16 != 0:
-            self.frags[:, -1].zero_()
+        self.frags, self._key = _FRAGS.take(self.rows, self.K, t.device)
         self.ptr, self.stride = _frag_ptr(self.frags)
         L = lib()
         if kmajor:
@@ -899,8 +962,15 @@ class TileOperand:
             _check(L.cvc_tile_pack_rows_any(t.data_ptr(), t.stride(0), self.rows, self.K, self.ptr, self.stride, _stream()),
                    "cvc_tile_pack_rows_any")
 
+    def __del__(self):
+        try:
+            _FRAGS.give(self.frags, self._key)
+        except Exception:
+            pass
 
-def tile_mm(a, b, a_kmajor: bool = False, b_kmajor: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+
+def tile_mm(a, b, a_kmajor: bool = False, b_kmajor: bool = False, out: Optional[torch.Tensor] = None, parts_only: bool = False,
+            bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C[M, N] = sum_k A[m, k] B[n, k] on the tile GEMM (split products on the bf16 MFMA, fp32 accumulate, fp32-grade error):
     the dense products of the backward pass -- no library GEMM.  `a` is [M, K], or [K, M] with a_kmajor (read as its transpose);
     `b` is [N, K], or [K, N] with b_kmajor; either may be a TileOperand packed earlier (shared operands are packed once).
@@ -914,15 +984,20 @@ def tile_mm(a, b, a_kmajor: bool = False, b_kmajor: bool = False, out: Optional[
     ntile, chunks = (N + 127) // 128, (tile_rows_alloc(M) + 319) // 320
     ks = max(1, min(256 // max(1, ntile * chunks), (Kp // 16) // 8))
     if out is None:
-        out = torch.empty(M, N, device=A.frags.device, dtype=torch.float32)
+        out = torch.empty(0 if parts_only else M, N, device=A.frags.device, dtype=torch.float32)
     elif not (out.is_cuda and out.dtype == torch.float32 and tuple(out.shape) == (M, N) and out.stride(1) == 1
               and out.stride(0) % 4 == 0 and out.data_ptr() % 16 == 0):
         raise RuntimeError("cvc.hip.tile_mm: out must be an fp32 GPU [M, N] view with unit inner stride, 16-byte aligned rows")
     ldy = out.stride(0)
-    if ks == 1:
+    if parts_only:          # the K-slice slabs themselves, for a consumer that sums them (cvc_vocab_head_nll_fwd)
+        parts = torch.empty(ks, M, N, device=A.frags.device, dtype=torch.float32)
+        _check(L.cvc_tile_gemm(B.ptr, A.ptr, A.stride, Kp, M, N, ks, parts.data_ptr(), N, M * N, st), "cvc_tile_gemm")
+        return parts
+    if ks == 1 and bias is None:
         _check(L.cvc_tile_gemm(B.ptr, A.ptr, A.stride, Kp, M, N, 1, out.data_ptr(), ldy, M * ldy, st), "cvc_tile_gemm")
         return out
+    # bias [N]: added by the finishing pass (nn.Linear's epilogue), not by a framework add over the result
     parts = torch.empty(ks, M, N, device=out.device, dtype=torch.float32)
     _check(L.cvc_tile_gemm(B.ptr, A.ptr, A.stride, Kp, M, N, ks, parts.data_ptr(), N, M * N, st), "cvc_tile_gemm")
-    _check(L.cvc_tile_linear_finish(parts.data_ptr(), ks, M * N, N, None, None, M, N, out.data_ptr(), ldy, st), "cvc_tile_linear_finish")
+    _check(L.cvc_tile_linear_finish(parts.data_ptr(), ks, M * N, N, _dev(bias), None, M, N, out.data_ptr(), ldy, st), "cvc_tile_linear_finish")
     return out

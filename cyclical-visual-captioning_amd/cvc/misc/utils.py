@@ -64,6 +64,19 @@ def _masked_nll_mean_from_logits(logits, target, t_major=False):
     return (total / w.sum()).reshape(()), argmax.view(target.shape)
 
 
+def _masked_nll_mean_from_head(x, weight, bias, target, t_major=False):
+    """_masked_nll_mean_from_logits(x W^T + b, target) with the criterion folded into the vocabulary head's GEMM finish: the logits
+    are never materialised (cvc.functional.vocab_head_nll); falls back to the two-step form for shapes that kernel does not take."""
+    if not F_.vocab_head_nll_ok(x, weight):
+        return _masked_nll_mean_from_logits(F_.linear(x, weight, bias), target, t_major)
+    w = _text_mask(target).to(torch.float32)
+    if t_major:
+        total, argmax = F_.vocab_head_nll(x, weight, bias, target.t().reshape(-1), w.t().reshape(-1))
+        return (total / w.sum()).reshape(()), argmax.view(target.shape[1], target.shape[0]).t()
+    total, argmax = F_.vocab_head_nll(x, weight, bias, target.reshape(-1), w.reshape(-1))
+    return (total / w.sum()).reshape(()), argmax.view(target.shape)
+
+
 class LMCriterion(nn.Module):
     """reference misc/utils.py:127-172"""
 
@@ -83,6 +96,14 @@ class LMCriterion(nn.Module):
         if not torch.cuda.is_current_stream_capturing():
             assert torch.sum(target >= self.vocab_size) == 0
         loss, argmax = _masked_nll_mean_from_logits(logits, target, t_major)
+        return (loss, *self.attention_losses(att2_weights, ground_weights, att2_target), argmax)
+
+    def from_head(self, x, head, att2_weights, ground_weights, target, att2_target, input_seq, t_major=False):
+        """from_logits() fed the vocabulary head's INPUT x [rows, R] and the head module (nn.Linear): the head's GEMM and the
+        criterion run as one op, no logits tensor."""
+        if not torch.cuda.is_current_stream_capturing():
+            assert torch.sum(target >= self.vocab_size) == 0
+        loss, argmax = _masked_nll_mean_from_head(x, head.weight, head.bias, target, t_major)
         return (loss, *self.attention_losses(att2_weights, ground_weights, att2_target), argmax)
 
     @staticmethod
@@ -109,6 +130,9 @@ class LanguageCriterion(nn.Module):
 
     def from_logits(self, logits, target, t_major=False):
         return _masked_nll_mean_from_logits(logits, target, t_major)[0]
+
+    def from_head(self, x, head, target, t_major=False):
+        return _masked_nll_mean_from_head(x, head.weight, head.bias, target, t_major)[0]
 
 
 def bbox_overlaps(rois, gt_box, frm_mask):

@@ -320,7 +320,6 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         out_a, fm = train_loops.decode_loop(arena, emb_all, fc_in, (pool_feats, p_pool_feats, conv_feats, p_conv_feats), region_mask,
                                             step_fmask, dc.att_lstm, dc.lang_lstm, dc.soft_attn, attn_kind, inv_temp, drop_a)
         att2_weights = fm.transpose(0, 1)                                             # [B, T, N] pre-softmax (:273)
-        lang_logits = self._logits(out_a.view(T * B, R))                              # rows t * B + b
 
         # ---- grounder over all T                                                      reference :282-294
         xt_clamp = torch.clamp(input_seq[:, 1:T + 1, 0].clone() - self.vocab_size, min=0)
@@ -334,8 +333,9 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
             self.debug_collect.update(ground_weights=ground_weights, att2_weights=att2_weights, roi_labels=roi_labels,
                                       frm_mask_output=frm_mask_output)
         target = gt_caption[:, 1:T + 1].clone()
-        lm_loss, att2_loss, ground_loss, output_seq = self.critLM.from_logits(
-            lang_logits, att2_weights, ground_weights, target, roi_labels[:, :T, :].clone(), input_seq[:, 1:T + 1, 0].clone(),
+        # vocabulary head + criterion + the argmax cut of :313 as one op on the t-major rows (no logits tensor)
+        lm_loss, att2_loss, ground_loss, output_seq = self.critLM.from_head(
+            out_a.view(T * B, R), self.logit, att2_weights, ground_weights, target, roi_labels[:, :T, :], input_seq[:, 1:T + 1, 0],
             t_major=True)
         if self.opts.train_decoder_only:                                              # reference :297-307
             return lm_loss.reshape(1), att2_loss.reshape(1), ground_loss.reshape(1), cls_loss.reshape(1)
@@ -347,7 +347,7 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         # ---- Loop C: reconstruct from the localized regions                          reference :348-362
         emb_all_c = self._embed(gt_caption[:, :T], "emb_c") if self.training else emb_all      # fresh dropout mask in training
         out_c = train_loops.recon_loop(arena, emb_all_c, fc_in, ctx_all, dc.att_lstm, dc.lang_lstm, dc.soft_attn, attn_kind, drop_c)
-        lm_recon_loss = self.xe_criterion.from_logits(self._logits(out_c.view(T * B, R)), target, t_major=True)
+        lm_recon_loss = self.xe_criterion.from_head(out_c.view(T * B, R), self.logit, target, t_major=True)
         return (lm_loss.reshape(1), att2_loss.reshape(1), ground_loss.reshape(1), cls_loss.reshape(1), lm_recon_loss.reshape(1))
 
     def _vis_embed(self, xt_clamp):

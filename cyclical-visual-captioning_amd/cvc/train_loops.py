@@ -51,6 +51,7 @@ class LoopArena:
         self.h_lang_prev, self.h_att_prev, self.h_att, self.ctx = e(S, R), e(S, R), e(S, R), e(S, R)
         self.emb = e(S, E)
         self.dg_att, self.dg_lang = e(S, 4 * R), e(S, 4 * R)
+        self.dgsum_att, self.dgsum_lang = e(nslots, B, 4 * R), e(nslots, B, 4 * R)     # sums over the T steps, per loop (bias / fc gradients)
         self.extra = {}                 # slot 0's attention-side buffers (dq, dwa_part, ds_r, ds_f), set by its backward
         self.done = []                  # slots whose backward has run
 
@@ -73,7 +74,7 @@ class _Cfg:
 def _hoisted(x_tb: Tensor, w_cols: Tensor) -> Tensor:
     """[T * B, k] x W[:, cols]^T -> [T * B, 4R] on the tile GEMM (skinny kernel for <= 64 rows)"""
     if x_tb.shape[0] > 64:
-        return hip.tile_mm(x_tb, w_cols)
+        return hip.tile_mm(x_tb, hip.weight_operand(w_cols))
     return hip.linear_fwd([{"x": x_tb, "w": w_cols}], None, x_tb.shape[0], w_cols.shape[0])
 
 
@@ -138,7 +139,9 @@ def _weight_grads(arena: LoopArena, cfg, W):
     Hlp = hip.TileOperand(Hl, kmajor=True)                    # h_lang(t-1): att weight_ih[:, :R] AND lang weight_hh
     d_ih = O["w_ih_a"].t
     hip.tile_mm(Dp, Hlp, out=d_ih[:, :R])
-    DGsum = DGa.view(nl * T, B, 4 * R).sum(0)                 # [B, 4R]: the fc columns' dY (fc is the same row every step), the biases
+    # [B, 4R] sum over every step of every loop (accumulated by the gate-gradient kernel): the fc columns' dY (fc is the same row
+    # every step) and the biases
+    DGsum = arena.dgsum_att[slots[0]] if nl == 1 else arena.dgsum_att[slots[0]:slots[-1] + 1].sum(0)
     e0 = R
     if cfg.has_fc:
         hip.tile_mm(DGsum, W["fc"], a_kmajor=True, b_kmajor=True, out=d_ih[:, R:2 * R])
@@ -154,7 +157,7 @@ def _weight_grads(arena: LoopArena, cfg, W):
     Hap = hip.TileOperand(Ha, kmajor=True)
     hip.tile_mm(Dl, Hap, out=d_il[:, R:])
     hip.tile_mm(Dl, Hlp, out=O["w_hh_l"].t)
-    torch.sum(DGl, 0, out=O["b_ih_l"].t)
+    torch.sum(arena.dgsum_lang[slots[0]:slots[-1] + 1].view(nl * B, 4 * R), 0, out=O["b_ih_l"].t)
     O["b_hh_l"].t.copy_(O["b_ih_l"].t)
     # ---- h2attn / alpha_net: loop A's rows only
     if 0 in slots and arena.extra:
@@ -271,6 +274,7 @@ class _Loop(torch.autograd.Function):
         d_out = d_out.contiguous()
         L.d_out = _ptr(d_out)
         L.dg_att, L.dg_lang = _ptr(arena.dg_att[rows]), _ptr(arena.dg_lang[rows])
+        L.dgsum_att, L.dgsum_lang = _ptr(arena.dgsum_att[cfg.slot]), _ptr(arena.dgsum_lang[cfg.slot])
         grads_feat = [None, None, None, None]
         live = [d_out]
         if kind == 0:
@@ -294,13 +298,13 @@ class _Loop(torch.autograd.Function):
         # ---- gradients of the hoisted inputs (dense, once per loop)
         DGa, DGl = arena.dg_att[rows], arena.dg_lang[rows]
         e0 = 2 * R if cfg.has_fc else R
-        d_emb = hip.tile_mm(DGa, w_ih_a[:, e0:], b_kmajor=True).view(T, B, E).transpose(0, 1) if ni[2] else None
+        d_emb = hip.tile_mm(DGa, hip.weight_operand(w_ih_a[:, e0:], kmajor=True)).view(T, B, E).transpose(0, 1) if ni[2] else None
         d_fc = None
         if cfg.has_fc and ni[3]:
-            d_fc = F_._mm_nn(DGa.view(T, B, 4 * R).sum(0), w_ih_a[:, R:2 * R])
+            d_fc = F_._mm_nn(arena.dgsum_att[cfg.slot], w_ih_a[:, R:2 * R])
         d_ctx = None
         if kind == 1 and ni[4]:
-            d_ctx = hip.tile_mm(DGl, w_ih_l[:, :R], b_kmajor=True).view(T, B, R).transpose(0, 1)
+            d_ctx = hip.tile_mm(DGl, hip.weight_operand(w_ih_l[:, :R], kmajor=True)).view(T, B, R).transpose(0, 1)
         # ---- weight gradients: by whichever loop finishes its backward last, over all loops' rows at once
         order = ("w_ih_a", "w_hh_a", "b_ih_a", "b_hh_a", "w_ih_l", "w_hh_l", "b_ih_l", "b_hh_l", "w_h", "b_h", "w_a", "b_a")
         owners = (w_ih_a, w_hh_a, b_ih_a, b_hh_a, w_ih_l, w_hh_l, b_ih_l, b_hh_l, w_h, b_h, w_a, b_a)

@@ -474,6 +474,16 @@ int cvc_vocab_nll_fwd(const float* logits, const int64_t* target, const float* w
 int cvc_vocab_nll_bwd(const float* logits, const float* lse, const int64_t* target, const float* w,
                       const float* g, int M, int V, float* d_logits, cvc_stream_t stream);
 
+/* The same criterion folded into the finishing pass of the vocabulary head's tile GEMM (cvc_tile_gemm): parts = its K-slice slabs
+ * [nparts][M, ld] (slab stride part_stride), bias [V] (nullable).  Writes pre[m, v] = w[m] * (softmax(logits[m])[v] - [v ==
+ * target[m]]) (leading dimension ld_pre; may alias slab 0), argmax (nullable), row_loss and loss_sum as cvc_vocab_nll_fwd -- the
+ * [M, V] logits are never written.  Backward: d_logits = g[0] * pre (cvc_scale_by_scalar: y[i] = g[0] * x[i], n % 4 == 0).
+ * V <= 8192. */
+int cvc_vocab_head_nll_fwd(const float* parts, int nparts, long long part_stride, int ld, const float* bias,
+                           const int64_t* target, const float* w, int M, int V, float* pre, int ld_pre, int64_t* argmax,
+                           float* row_loss, float* loss_sum, cvc_stream_t stream);
+int cvc_scale_by_scalar(const float* x, const float* g, long long n, float* y, cvc_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Grounder (captioner.py:132-173, dot-product branch): out[b,t,n] = xt[b,t,:] . feats[b,n,:]
  * + bias[b,t,n], filled with -1e8 where mask[b,t,n].
@@ -768,7 +778,7 @@ int cvc_attn_bwd_pair(int kind, const cvc_grad_src* q, const float* q_bias, cons
 int cvc_lstm_pointwise_bwd4(const cvc_grad_src* d_h /* [3] */, const float* d_hd,
                             const uint32_t* rng_state, unsigned site, float p, const float* d_c, const float* gates,
                             const float* c_prev, const float* c_new, int M, int R, float* d_gates, float* d_c_prev,
-                            float* d_gates_q, cvc_stream_t stream);
+                            float* d_gates_q, float* dg_sum /* [M, 4R] += d_gates, nullable */, cvc_stream_t stream);
 
 typedef struct cvc_train_loop {
     int kind;                    /* 0 = loop A (decode step with attention), 1 = loop C (reconstruction step)            */
@@ -814,6 +824,7 @@ typedef struct cvc_train_loop {
     const float* d_out;          /* [T][B][R]                                                                            */
     const float* d_fm;           /* kind 0: [T][B][N], nullable                                                          */
     float *dg_att, *dg_lang;     /* [T][B][4R] pre-activation gate gradients                                             */
+    float *dgsum_att, *dgsum_lang;   /* [B][4R] their sums over the T steps (bias gradients, dY of the fc_feats columns), nullable */
     float* dq;                   /* kind 0: [T][B][A]                                                                    */
     float* dwa_part;             /* kind 0, additive: [T][B][A]                                                          */
     float *ds_r, *ds_f;          /* kind 0: [T][B][N], [T][B][F] gradients of the pre-softmax scores                     */
