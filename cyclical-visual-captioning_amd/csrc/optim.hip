@@ -109,20 +109,21 @@ __global__ __launch_bounds__(OPT_WG) void optim_adam_kernel(const OptSeg* segs, 
                 p[e] = pe; g[e] = ge; m[e] = me; v[e] = ve;
             }
             st4(s.p + i, p); st4(s.m + i, m); st4(s.v + i, v);
-            if (write_grad) st4(s.g + i, g);
+            if (write_grad == 1) st4(s.g + i, g);
+            else if (write_grad == 2) st4(s.g + i, f32x4{0.f, 0.f, 0.f, 0.f});
         }
         for (; i < end; ++i) {
             float p = s.p[i], g = s.g[i], m = s.m[i], v = s.v[i];
             upd(p, g, m, v);
             s.p[i] = p; s.m[i] = m; s.v[i] = v;
-            if (write_grad) s.g[i] = g;
+            if (write_grad) s.g[i] = write_grad == 2 ? 0.f : g;
         }
     } else {
         for (long long i = c.start + threadIdx.x; i < end; i += OPT_WG) {
             float p = s.p[i], g = s.g[i], m = s.m[i], v = s.v[i];
             upd(p, g, m, v);
             s.p[i] = p; s.m[i] = m; s.v[i] = v;
-            if (write_grad) s.g[i] = g;
+            if (write_grad) s.g[i] = write_grad == 2 ? 0.f : g;
         }
     }
 }

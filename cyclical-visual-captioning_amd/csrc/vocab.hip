@@ -114,7 +114,9 @@ __global__ __launch_bounds__(WG) void embed_bwd_runs_kernel(const float* table, 
     const f32x4 t = ld4(table + (size_t)w * E + e);
     acc.x = t.x > 0.f ? acc.x : 0.f; acc.y = t.y > 0.f ? acc.y : 0.f;
     acc.z = t.z > 0.f ? acc.z : 0.f; acc.w = t.w > 0.f ? acc.w : 0.f;
-    st4(d_table + (size_t)w * E + e, acc);
+    // ACCUMULATED: a fresh gradient starts from the caller's zero fill (0 + x = x exactly); the three embeddings of a cyclical
+    // pass (loops A, B, C share the table, captioner.py:53-68) add up in ONE buffer, call after call, instead of in three
+    st4(d_table + (size_t)w * E + e, ld4(d_table + (size_t)w * E + e) + acc);
 }
 
 // ------------------------------------------------------------------ log-softmax / top-2 / NLL

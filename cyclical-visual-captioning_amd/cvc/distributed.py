@@ -183,10 +183,18 @@ class GradReducer:
         self._written: set = set()                            # ids whose arena view was handed out for an in-place write this step
 
     # ------------------------------------------------------------------ gradient bookkeeping
+    def mark_zeroed(self):
+        """The optimizer step left every gradient it consumed zero (cvc.optim.ClipAdam.clip_and_step(zero_grad=True)): the next
+        zero_grad() skips its fills unless something writes a gradient in between."""
+        self._clean = True
+
     def zero_grad(self):
-        """One fill per bucket; re-attaches a view if something replaced a .grad (optimizer.zero_grad(set_to_none=True))."""
-        for a in self.arenas:
-            a.zero_()
+        """One fill per bucket (none when the optimizer step already zeroed what it read, see mark_zeroed); re-attaches a view if
+        something replaced a .grad (optimizer.zero_grad(set_to_none=True))."""
+        if not getattr(self, "_clean", False):
+            for a in self.arenas:
+                a.zero_()
+        self._clean = False
         for b in self.buckets:
             for _, p in b:
                 if id(p) in self._dead:                       # never receives a gradient: None, as in the reference (optimizers skip
@@ -215,6 +223,7 @@ class GradReducer:
         parameters are live); the bucket itself leaves from the post-accumulate-grad hook, which autograd fires for p once ALL of
         its producers have returned (also when they returned None), or at finalize()."""
         i = self._bucket_of[id(p)]
+        self._clean = False
         if id(p) not in self._arrived[i]:
             self._arrived[i].add(id(p))
             self._ready[i] += 1
@@ -235,6 +244,7 @@ class GradReducer:
         i = self._bucket_of.get(id(w))
         if i is None:
             return
+        self._clean = False
         if id(w) in self._dead:
             self._revive(w)
         v = self._views[id(w)]
@@ -249,6 +259,7 @@ class GradReducer:
     def _on_grad(self, p):
         i = self._bucket_of[id(p)]
         v = self._views[id(p)]
+        self._clean = False
         if id(p) in self._dead:
             self._revive(p)
         if p.grad is not v and p.grad.data_ptr() != v.data_ptr():      # autograd installed its own tensor: move it into the arena

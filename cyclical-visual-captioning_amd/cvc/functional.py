@@ -594,14 +594,33 @@ class _EmbedRelu(torch.autograd.Function):
         ctx.save_for_backward(table, idx, drop if drop is not None else table.new_zeros(()))
         ctx.has_drop = drop is not None
         ctx.rng = rng
+        ctx.key = ("embed", table.data_ptr())
+        if table.requires_grad:
+            _BATCHER.note_use(ctx.key)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
         table, idx, drop = ctx.saved_tensors
-        if ctx.rng is not None:
-            return hip.embed_relu_rng_bwd(table, idx, *ctx.rng, d_out.contiguous()), None, None, None
-        return hip.embed_relu_bwd(table, idx, drop if ctx.has_drop else None, d_out.contiguous()), None, None, None
+        item = (idx, drop if ctx.has_drop else None, ctx.rng, d_out.contiguous())
+
+        def flush(items):
+            # every lookup of the table in this pass (the embedded words of loops A, B, C) accumulates into ONE buffer -- the
+            # gradient owner's when it hands it out (GRAD_SINKS), else a fresh zero-filled one: one fill, no framework adds
+            buf, sink = claim_grad(table)
+            d_table = buf if buf is not None else torch.zeros_like(table)
+            for i_idx, i_drop, i_rng, i_d in items:
+                if i_rng is not None:
+                    hip.embed_relu_rng_bwd(table, i_idx, *i_rng, i_d, d_table=d_table)
+                else:
+                    hip.embed_relu_bwd(table, i_idx, i_drop, i_d, d_table=d_table)
+            if sink is not None:
+                sink.written(table)
+                return (None,)
+            return (d_table,)
+
+        got = _BATCHER.add(ctx.key, item, (table,), flush)
+        return (got[0] if got is not None else None), None, None, None
 
 
 def embed_relu(table: Tensor, idx: Tensor, drop: Optional[Tensor] = None, rng=None) -> Tensor:

@@ -670,9 +670,25 @@ def embed_relu_rng_fwd(table, idx, state, site: int, p: float):
     return out
 
 
-def embed_relu_rng_bwd(table, idx, state, site: int, p: float, d_out):
-    d_table = torch.zeros_like(table)
-    order = torch.argsort(idx, stable=True)
+_order_cache = {}
+
+
+def _embed_order(idx: torch.Tensor) -> torch.Tensor:
+    """stable argsort of the word indices (rows grouped by word), cached for the step: loops A and C embed the same words"""
+    key = (idx.data_ptr(), idx.numel(), idx._version, _train_generation)
+    o = _order_cache.get(key)
+    if o is None:
+        if len(_order_cache) > 16:
+            _order_cache.clear()
+        o = _order_cache[key] = (torch.argsort(idx, stable=True), idx)      # (idx kept alive: its address is the key)
+    return o[0]
+
+
+def embed_relu_rng_bwd(table, idx, state, site: int, p: float, d_out, d_table=None):
+    """d_table given: ACCUMULATED into (several lookups of one table add up in one buffer)"""
+    if d_table is None:
+        d_table = torch.zeros_like(table)
+    order = _embed_order(idx)
     ws = torch.empty(idx.shape[0], table.shape[1], device=table.device, dtype=torch.float32)
     _check(lib().cvc_embed_relu_rng_bwd(_dev(table), _dev(idx, torch.int64), _dev(order, torch.int64), _rng_ptr(state), int(site),
                                         float(p), _dev(d_out), idx.shape[0], table.shape[1], _dev(d_table), _dev(ws), _stream()),
@@ -687,9 +703,10 @@ def dropout_rng(x, state, site: int, p: float):
     return y
 
 
-def embed_relu_bwd(table, idx, drop, d_out):
-    d_table = torch.zeros_like(table)
-    order = torch.argsort(idx, stable=True)                      # rows grouped by word, original order inside a group
+def embed_relu_bwd(table, idx, drop, d_out, d_table=None):
+    if d_table is None:
+        d_table = torch.zeros_like(table)
+    order = _embed_order(idx)                                    # rows grouped by word, original order inside a group
     ws = torch.empty(idx.shape[0], table.shape[1], device=table.device, dtype=torch.float32)
     _check(lib().cvc_embed_relu_bwd(_dev(table), _dev(idx, torch.int64), _dev(order, torch.int64), _dev(drop), _dev(d_out),
                                     idx.shape[0], table.shape[1], _dev(d_table), _dev(ws), _stream()), "cvc_embed_relu_bwd")

@@ -69,12 +69,19 @@ def _masked_nll_mean_from_head(x, weight, bias, target, t_major=False):
     are never materialised (cvc.functional.vocab_head_nll); falls back to the two-step form for shapes that kernel does not take."""
     if not F_.vocab_head_nll_ok(x, weight):
         return _masked_nll_mean_from_logits(F_.linear(x, weight, bias), target, t_major)
-    w = _text_mask(target).to(torch.float32)
+    # the loss mask, its count and the t-major copies depend on the target alone: both heads of a cyclical pass (decode,
+    # reconstruction) score against the same target tensor, so they are formed once and kept on it
+    pre = getattr(target, "_cvc_nll_pre", None)
+    if pre is None or pre[0] != (target._version, t_major):
+        w = _text_mask(target).to(torch.float32)
+        tf, wf = (target.t().reshape(-1), w.t().reshape(-1)) if t_major else (target.reshape(-1), w.reshape(-1))
+        pre = ((target._version, t_major), tf.contiguous(), wf.contiguous(), w.sum())
+        target._cvc_nll_pre = pre
+    _, tf, wf, count = pre
+    total, argmax = F_.vocab_head_nll(x, weight, bias, tf, wf)
     if t_major:
-        total, argmax = F_.vocab_head_nll(x, weight, bias, target.t().reshape(-1), w.t().reshape(-1))
-        return (total / w.sum()).reshape(()), argmax.view(target.shape[1], target.shape[0]).t()
-    total, argmax = F_.vocab_head_nll(x, weight, bias, target.reshape(-1), w.reshape(-1))
-    return (total / w.sum()).reshape(()), argmax.view(target.shape)
+        return (total / count).reshape(()), argmax.view(target.shape[1], target.shape[0]).t()
+    return (total / count).reshape(()), argmax.view(target.shape)
 
 
 class LMCriterion(nn.Module):

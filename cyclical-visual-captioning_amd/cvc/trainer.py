@@ -65,11 +65,21 @@ class Trainer:
     def loss_mix(self, out):
         """trainer.py:92-109"""
         o = self.opts
-        lm_loss, att2_loss, _ground_loss, cls_loss = [x.mean() for x in out[:4]]
-        loss = o.xe_loss_weight * lm_loss + o.w_att2 * att2_loss + o.w_cls * cls_loss
-        lm_recon = out[4].mean() if len(out) > 4 else torch.zeros((), device=lm_loss.device)
+        # the reference takes .mean() of every loss because DataParallel gathers one value per replica; one process per GPU holds
+        # one value: the mean of a one-element tensor is that element (no reduction kernel, none in the backward)
+        one = lambda x: x.reshape(()) if x.numel() == 1 else x.mean()
+        lm_loss, att2_loss, _ground_loss, cls_loss = [one(x) for x in out[:4]]
+        lm_recon = one(out[4]) if len(out) > 4 else torch.zeros((), device=lm_loss.device)
+        # terms with a zero weight (w_att2 = w_cls = 0 by default, opts.py:72-75) add an exact zero and a zero gradient: left out
+        terms = [(o.xe_loss_weight, lm_loss), (o.w_att2, att2_loss), (o.w_cls, cls_loss)]
         if len(out) > 4:
-            loss = loss + o.caption_consistency_loss_weight * lm_recon
+            terms.append((o.caption_consistency_loss_weight, lm_recon))
+        loss = None
+        for wgt, val in terms:
+            if wgt != 0:
+                loss = wgt * val if loss is None else loss + wgt * val
+        if loss is None:
+            loss = 0.0 * lm_loss
         return loss, lm_loss, att2_loss, cls_loss, lm_recon
 
     def train_step(self, batch):
@@ -104,7 +114,10 @@ class Trainer:
             loss.backward()
             red.finalize(average=False)                      # the one exchange step of the path
             if fused is not None:
-                fused(self.opts.grad_clip, 1.0 / red.world)  # (the arenas hold sums over ranks: 1 / G folded into the coefficient)
+                # (the arenas hold sums over ranks: 1 / G folded into the coefficient; the gradients are read here for the last
+                # time, so the pass leaves them zero and the next step's zero_grad() has nothing to fill)
+                fused(self.opts.grad_clip, 1.0 / red.world, zero_grad=True)
+                red.mark_zeroed()
                 return
             red.clip_(self.opts.grad_clip, summed=True)
         self.optimizer.step()

@@ -421,7 +421,8 @@ int cvc_embed_relu_fwd(const float* table, const int64_t* idx, const float* drop
  * occurs; no atomics and no host round trip: `order` [M] is a stable argsort of idx, so the rows of a word
  * are contiguous in it; they are summed in a fixed two-level order (16-row pieces, then the pieces of a
  * word), so a word that owns many rows (BOS / padding) does not serialise.  workspace: M * E floats.
- * Rows of d_table for words that do not occur are left untouched (caller zero-fills). */
+ * The rows of the words that occur are ACCUMULATED into d_table (the caller zero-fills for a fresh gradient; several lookups of one
+ * table -- the three embeddings of a cyclical pass -- add up in one buffer, call after call); other rows are left untouched. */
 int cvc_embed_relu_bwd(const float* table, const int64_t* idx, const int64_t* order, const float* drop,
                        const float* d_out, int M, int E, float* d_table, float* workspace,
                        cvc_stream_t stream);
@@ -841,8 +842,9 @@ int cvc_train_loop_launches(const cvc_train_loop* loop, int backward);     /* la
  * tensor, main.py:171-191).  cvc_adam_clip_step = global L2 norm of all gradients (chunk sums combined in chunk order:
  * deterministic), clip coefficient min(1, max_norm / (inv_world * norm + 1e-6)) * inv_world (inv_world = 1 / ranks when the
  * gradients are sums over ranks; max_norm <= 0: no clipping), every segment's step count += 1, then torch.optim.Adam's update
- * (amsgrad = False) on (p, g * coef, m, v) in ONE pass; write_grad != 0 also stores the clipped gradient back, as clip_grad_norm_
- * leaves it.  Three launches, nothing read back by the host (graph-capturable).
+ * (amsgrad = False) on (p, g * coef, m, v) in ONE pass; write_grad == 1 also stores the clipped gradient back, as clip_grad_norm_
+ * leaves it; write_grad == 2 stores ZERO instead -- the next step's zero_grad() folded into this pass (the gradients of a step
+ * are read here for the last time).  Three launches, nothing read back by the host (graph-capturable).
  *   segs   : DEVICE array of nseg parameter segments;   chunks : DEVICE array of nchunk (segment, start) pairs covering every
  *            segment in pieces of cvc_optim_chunk_elems() elements (start a multiple of it), in any fixed order;
  *   partial: nchunk floats of scratch;   norm_coef: 2 floats out -- [0] the norm of the (averaged) gradient, [1] the coefficient. */

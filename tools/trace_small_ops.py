@@ -19,7 +19,11 @@ import bench  # noqa: E402
 
 def main():
     ops = sys.argv[1:] or ["aten::fill_", "aten::zeros", "aten::zeros_like", "aten::add", "aten::add_", "aten::cat",
-                           "aten::copy_", "aten::zero_", "aten::sum", "aten::mul"]
+                           "aten::copy_", "aten::zero_", "aten::sum", "aten::mul", "aten::clone", "aten::sort", "aten::argsort",
+                           "aten::_to_copy", "aten::where", "aten::clamp", "aten::index", "aten::gt", "aten::eq", "aten::ne", "aten::div",
+                           "aten::neg", "aten::mean", "aten::stack", "aten::sub", "aten::arange", "aten::masked_fill", "aten::ones_like",
+                           "aten::bitwise_or", "aten::bitwise_not", "aten::ge", "aten::index_put_", "aten::embedding",
+                           "aten::embedding_dense_backward", "aten::relu", "aten::threshold_backward", "aten::mul_", "aten::div_"]
     from cvc import synth, opts as cvc_opts
     from cvc.model.captioner import DecodeAndGroundCaptionerGVDROI, PrecomputedRegionFeatures
     from cvc.trainer import Trainer, build_optimizer
@@ -33,7 +37,8 @@ def main():
     model = DecodeAndGroundCaptionerGVDROI(o, roi_extractor=PrecomputedRegionFeatures(d.DET, d.G))
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.hot_path_state_dict(d, 1).items()}, strict=False)
     model = model.to(dev).train()
-    tr = Trainer(o, None, model, build_optimizer(model, o), None, None)
+    from cvc.distributed import GradReducer
+    tr = Trainer(o, None, model, build_optimizer(model, o), None, None, grad_reducer=GradReducer(model.named_parameters()))
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     feats = {k: t(v) for k, v in synth.clip_features(d, 1).items()}
     b = {k: t(v) for k, v in synth.label_glue_batch(d, 1).items()}
