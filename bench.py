@@ -73,7 +73,10 @@ def parse():
                    help="packed path (A/B): 1 = grouped stream-K schedule (measured slower; off by default)")
     p.add_argument("--embgate", type=int, default=None, choices=[0, 1],
                    help="packed path (A/B): 0 = the 7-launch schedule without the embedding-gate table; default = on")
-    p.add_argument("--train-graph", action="store_true", help="--mode train: capture the whole training step in a HIP graph")
+    p.add_argument("--train-graph", action="store_true", help="(default since round 4; kept for old command lines)")
+    p.add_argument("--no-train-graph", action="store_true",
+                   help="--mode train: time eager steps instead of replays of the step captured into one HIP graph (forward, backward, "
+                        "RCCL exchange, clip + Adam)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--spawn", action="store_true",
                    help="start the rank processes through the torch.distributed.run child also for --gpus 1 (the path every N > 1 run takes)")
@@ -187,7 +190,8 @@ def run_train(args, d, dev, rank, world, steps=None, warmup=None, min_warm=None,
     model = DecodeAndGroundCaptionerGVDROI(o, roi_extractor=PrecomputedRegionFeatures(d.DET, d.G))
     model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.hot_path_state_dict(d, args.seed).items()}, strict=False)
     model = model.to(dev).train()
-    optim = build_optimizer(model, o, capturable=args.train_graph)
+    use_graph = not args.no_train_graph
+    optim = build_optimizer(model, o, capturable=use_graph)
     reducer = GradReducer(model.named_parameters())        # flat gradient arenas (also for one rank: one fill / one clip multiply)
     tr = Trainer(o, None, model, optim, None, None, grad_reducer=reducer)
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
@@ -198,7 +202,7 @@ def run_train(args, d, dev, rank, world, steps=None, warmup=None, min_warm=None,
              feats["pnt_mask"][:, 1:])
     import torch.distributed as dist
     dist_on = dist.is_available() and dist.is_initialized()
-    step = tr.train_step_graphed if args.train_graph else tr.train_step
+    step = tr.train_step_graphed if use_graph else tr.train_step
     w0 = time.perf_counter()
     for _ in range(warmup):
         step(batch)
@@ -223,17 +227,31 @@ def run_train(args, d, dev, rank, world, steps=None, warmup=None, min_warm=None,
 
     el, loss = timed_region(steps)
     ms_step = el / steps * 1e3
+    eager_ms = None
+    if use_graph:                      # the same step launched eagerly (host-side launch path in the loop), for comparison
+        n_e = max(3, min(steps, 10))
+        tr.train_step(batch)
+        step_keep, step = step, tr.train_step
+        el_e, _ = timed_region(n_e)
+        step = step_keep
+        eager_ms = round(el_e / n_e * 1e3, 3)
     # exposed exchange time (N > 1): the same steps with the gradient exchange switched off (every rank then trains on its own
     # shard: a measurement, not a training mode); exposed = step with exchange - step without
     exchange = None
     if world > 1 and reducer.exchange:
+        # (eager steps on both sides: a captured graph holds the exchange it was captured with)
+        step_keep, step = step, tr.train_step
+        n_x = max(3, min(steps, 10))
+        el1, _ = timed_region(n_x)
         reducer.exchange, keep_overlap = False, reducer.overlap
         reducer.overlap = False
-        el0, _ = timed_region(steps)
+        el0, _ = timed_region(n_x)
         reducer.exchange, reducer.overlap = True, keep_overlap
-        ms0 = el0 / steps * 1e3
+        step = step_keep
+        ms0, ms1 = el0 / n_x * 1e3, el1 / n_x * 1e3
         grad_bytes = sum(a.numel() * 4 for a in reducer.arenas)
-        exchange = dict(ms_per_step_without_exchange=round(ms0, 3), exposed_ms=round(ms_step - ms0, 3), gradient_bytes=grad_bytes,
+        exchange = dict(ms_per_step_without_exchange=round(ms0, 3), ms_per_step_with_exchange=round(ms1, 3), exposed_ms=round(ms1 - ms0, 3),
+                        measured_on="eager steps", gradient_bytes=grad_bytes,
                         algorithm="per bucket: in-place reduce_scatter + all_gather on RCCL, launched from post-accumulate-grad hooks",
                         backend=reducer.backend, buckets=len(reducer.arenas))
 
@@ -315,7 +333,8 @@ def run_train(args, d, dev, rank, world, steps=None, warmup=None, min_warm=None,
             "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "samples_per_s": round(d.B * world * steps / el, 2), "loss": float(loss),
             "config": {"workload": f"{config_name}: cyclical train step (decode+localize+reconstruct fwd, bwd, clip, Adam), train-mode dropout",
-                       "B_per_gpu": d.B, "global_batch": d.B * world, "N": d.N, "F": d.F, "D": d.R, "T": d.T, "hip_graph": bool(args.train_graph),
+                       "B_per_gpu": d.B, "global_batch": d.B * world, "N": d.N, "F": d.F, "D": d.R, "T": d.T, "hip_graph": bool(use_graph),
+                       "eager_ms_per_step": eager_ms,
                        "parallelism": f"dp{world}: clips sharded, one RCCL gradient exchange per step"},
             "roofline": roof, "cpu_baseline": cpu, "exchange": exchange, "kernels": kernels}
         if cpu:

@@ -591,7 +591,7 @@ class _EmbedRelu(torch.autograd.Function):
         idx = idx.contiguous()
         # rng = (generator state, site id, p): the keep-mask is generated inside the kernel (cvc/dropout.py), forward and backward
         out = hip.embed_relu_rng_fwd(table, idx, *rng) if rng is not None else hip.embed_relu_fwd(table, idx, drop)
-        ctx.save_for_backward(table, idx, drop if drop is not None else table.new_zeros(()))
+        ctx.save_for_backward(table, idx, drop if drop is not None else table.new_empty(()))      # (placeholder, never read)
         ctx.has_drop = drop is not None
         ctx.rng = rng
         ctx.key = ("embed", table.data_ptr())
@@ -728,6 +728,7 @@ class _AttnNLL(torch.autograd.Function):
     def forward(ctx, x0, x1, target):
         loss, ws, tg = hip.attn_nll_fwd(x0, x1, target)
         ctx.save_for_backward(x0, x1, tg, ws)
+        ctx.set_materialize_grads(False)        # an unused loss (ground_loss is never optimised, trainer.py:93-95) arrives as None
         return loss[0:1], loss[1:2]
 
     @staticmethod
@@ -736,7 +737,10 @@ class _AttnNLL(torch.autograd.Function):
         ni = ctx.needs_input_grad
         g0 = None if g0 is None else g0.contiguous()
         g1 = None if g1 is None else g1.contiguous()
-        d0, d1 = hip.attn_nll_bwd(x0, x1, tg, ws, g0, g1, ni[0], ni[1])
+        want0, want1 = ni[0] and g0 is not None, ni[1] and g1 is not None
+        if not (want0 or want1):
+            return None, None, None
+        d0, d1 = hip.attn_nll_bwd(x0, x1, tg, ws, g0, g1, want0, want1)
         return d0, d1, None
 
 

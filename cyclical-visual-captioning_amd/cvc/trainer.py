@@ -142,12 +142,15 @@ class Trainer:
 
     def train_step_graphed(self, batch):
         """Same step as train_step, captured once into a HIP graph and replayed: the per-step Python / launch overhead
-        (~7k launches) disappears.  Requirements: constant batch shapes (inputs are copied into static buffers), an
-        optimizer built with capturable=True (build_optimizer(..., capturable=True)), single rank or a reducer without
-        hooks.  Returns a static tensor [loss, lm, att2, cls, recon] (clone to keep)."""
-        if self.grad_reducer is not None and self.grad_reducer.world > 1:
-            raise RuntimeError("train_step_graphed with a multi-rank GradReducer is not supported: the RCCL exchange is issued "
-                               "from autograd hooks on the communicator's stream and is not captured; use train_step")
+        disappears.  Requirements: constant batch shapes (inputs are copied into static buffers), an optimizer built with
+        capturable=True (build_optimizer(..., capturable=True)).  The gradient exchange of a multi-rank GradReducer is part of
+        the captured step when it runs on RCCL (backend "nccl": the collectives are issued on the communicator's stream behind
+        events of the capturing stream, which stream capture records as graph dependencies); other backends (gloo) cannot be
+        captured.  Returns a static tensor [loss, lm, att2, cls, recon] (clone to keep)."""
+        red = self.grad_reducer
+        if red is not None and red.exchange and red.backend != "nccl":
+            raise RuntimeError(f"train_step_graphed: the gradient exchange on backend {red.backend!r} cannot be captured into a HIP "
+                               "graph (only RCCL collectives are stream operations); use train_step")
         b = self._prepare(batch, True)
         if self._graph is None:
             static = {k: (v.clone() if isinstance(v, torch.Tensor) else ({kk: vv.clone() for kk, vv in v.items()} if isinstance(v, dict) else v))

@@ -238,7 +238,7 @@ def test_rccl_allreduce_cabi_one_rank():
 def test_gradient_exchange_on_rccl_one_rank_equals_no_exchange():
     """torch.distributed "nccl" (= RCCL) process group of one rank, no torchrun: a training step whose GradReducer issues the
     in-place reduce_scatter + all_gather from the autograd hooks must leave bit-identical parameters to the same step without
-    any exchange; and the graphed step refuses a multi-rank reducer loudly."""
+    any exchange; the step captured into a HIP graph WITH that exchange replays bit-identically; a non-RCCL backend is refused."""
     import torch.distributed as dist
     from cvc.distributed import GradReducer
     dev = torch.device("cuda:0")
@@ -262,11 +262,34 @@ def test_gradient_exchange_on_rccl_one_rank_equals_no_exchange():
             red.remove_hooks()
         for k in finals[0]:
             assert torch.equal(finals[0][k], finals[1][k]), k
+        # the whole step INCLUDING the RCCL exchange captured into one HIP graph: replays must reproduce the eager steps with the
+        # same exchange bit for bit (3 warm-up steps + 3 replays against 6 eager steps)
+        o, model, batch, Trainer, build_optimizer = _setup(dev, d, train_decoder_only=False)
+        model.eval()
+        red = GradReducer(model.named_parameters(), always_exchange=True)
+        tr = Trainer(o, None, model, build_optimizer(model, o, capturable=True), None, None, grad_reducer=red)
+        res = [tr.train_step_graphed(batch).clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        graphed = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        red.remove_hooks()
+        o, model, batch, Trainer, build_optimizer = _setup(dev, d, train_decoder_only=False)
+        model.eval()
+        red = GradReducer(model.named_parameters(), always_exchange=True)
+        tr = Trainer(o, None, model, build_optimizer(model, o, capturable=True), None, None, grad_reducer=red)
+        eager = [tr.train_step(batch) for _ in range(6)]
+        torch.cuda.synchronize()
+        red.remove_hooks()
+        for k in graphed:
+            assert torch.equal(graphed[k], model.state_dict()[k]), k
+        assert float(res[-1][0]) == float(eager[-1][0])
+        # a backend whose collectives are not stream operations cannot be captured: refused loudly
         o, model, batch, Trainer, build_optimizer = _setup(dev, d)
         red = GradReducer(model.named_parameters(), world=2)
+        red.backend = "gloo"
         tr = Trainer(o, None, model, build_optimizer(model, o, capturable=True), None, None, grad_reducer=red)
-        with pytest.raises(RuntimeError, match="multi-rank"):
+        with pytest.raises(RuntimeError, match="cannot be captured"):
             tr.train_step_graphed(batch)
+        red.remove_hooks()
     finally:
         if created:
             dist.destroy_process_group()
