@@ -305,15 +305,17 @@ def _dropout_masks(d, seed, p=0.5):
                 out_a=draw(d.T, d.B, d.R), out_c=draw(d.T, d.B, d.R), vis_embed=draw(d.B, d.T, d.G))
 
 
-def _train_mode_parity(d, seed, mix, loss_tol, grad_tol=5e-4, in_kernel=False):
+def _train_mode_parity(d, seed, mix, loss_tol, grad_tol=5e-4, in_kernel=False, reducer=None):
     """in_kernel=False: masks drawn here and dictated to both sides.  in_kernel=True: the product generates its masks INSIDE the
-    kernels (csrc/dropout_rng.h) and the oracle receives their host restatement (cvc.dropout.host_mask -> synth.dropout_keep)."""
+    kernels (csrc/dropout_rng.h) and the oracle receives their host restatement (cvc.dropout.host_mask -> synth.dropout_keep).
+    reducer: callable(model) -> GradReducer; the gradients then live in its arenas, are exchanged (finalize) before the check."""
     from helpers import build_model, to_dev, model_call
     from oracle import ref_cpu as O
     from cvc import dropout
     dev = torch.device("cuda:0")
     sd, f, b = synth.hot_path_state_dict(d, seed), synth.clip_features(d, seed), synth.label_glue_batch(d, seed)
     model = build_model(d, sd, dev).train()
+    red = reducer(model) if reducer is not None else None
     if in_kernel:
         assert dropout.IN_KERNEL
         dropout.seed(seed * 7919 + 13)
@@ -357,7 +359,12 @@ def _train_mode_parity(d, seed, mix, loss_tol, grad_tol=5e-4, in_kernel=False):
     for got, want in zip(out, ref):
         assert float(got.detach().mean()) == pytest.approx(float(want.detach().mean()), rel=loss_tol, abs=loss_tol / 10)
     lm, a2, _g, _cls, rec = [x.mean() for x in out]
+    if red is not None:
+        red.zero_grad()
     (mix[0] * lm + mix[1] * a2 + mix[2] * rec).backward()
+    if red is not None:
+        red.finalize(average=False)                 # the exchange (one rank: sums over one rank) -- in place on the arenas
+        torch.cuda.synchronize()
     checked = 0
     for n, p in model.named_parameters():
         if n.startswith("roi_feat_extractor") or n not in P:
@@ -365,11 +372,39 @@ def _train_mode_parity(d, seed, mix, loss_tol, grad_tol=5e-4, in_kernel=False):
         if P[n].grad is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
             continue
+        if red is not None:
+            assert p.grad.data_ptr() == red._views[id(p)].data_ptr(), n          # still the arena view after the exchange
         want = P[n].grad.double()
         err = float((p.grad.cpu().double() - want).norm())
         assert err <= grad_tol * float(want.norm()) + 1e-6, (n, err, float(want.norm()))
         checked += 1
     assert checked >= 15
+    return model, red
+
+
+def test_train_mode_cyclical_pass_cfg4_share_on_rccl_arenas_vs_oracle():
+    """BASELINE config 4 as far as one GPU can prove it: ONE rank's share of the 8-GPU job (B = 32 clips, D = 2048, T = 20), train
+    mode with the masks generated in the kernels, the gradients living in the GradReducer's flat arenas (486 MB at this size) and
+    exchanged over RCCL ("nccl", a one-rank group: in-place reduce_scatter + all_gather per bucket, the branch every rank of the
+    8-GPU job runs) -- five losses and every parameter gradient against the oracle's autograd."""
+    import torch.distributed as dist
+    from cvc.distributed import GradReducer
+    dev = torch.device("cuda:0")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29655", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        mk = lambda model: GradReducer(model.named_parameters(), always_exchange=True)
+        model, red = _train_mode_parity(synth.CONFIGS["cfg4"], 1404, (0.5, 0.0, 0.5), loss_tol=1e-4, in_kernel=True, reducer=mk)
+        assert red.backend == "nccl" and red.exchange
+        total = sum(a.numel() * 4 for a in red.arenas)
+        assert total > 480e6, total                                        # the real message: every trainable tensor of the hot path
+        assert all(a.numel() % red.world == 0 for a in red.arenas)        # equal shards: the reduce_scatter + all_gather branch
+        red.remove_hooks()
+    finally:
+        if created:
+            dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("cfg,mix", [("tiny", (0.5, 0.05, 0.5)), ("tiny", (0.5, 0.0, 0.5)), ("cfg1", (0.5, 0.0, 0.5))])
