@@ -255,6 +255,28 @@ def run_train(args, d, dev, rank, world, steps=None, warmup=None, min_warm=None,
                         algorithm="per bucket: in-place reduce_scatter + all_gather on RCCL, launched from post-accumulate-grad hooks",
                         backend=reducer.backend, buckets=len(reducer.arenas))
 
+    # ---- when does each gradient bucket become complete, relative to the end of the step (eager step, events on the launch
+    # stream)?  At N > 1 a bucket's exchange is enqueued at that moment, behind the product that completed it.
+    buckets = None
+    if rank == 0 and probe:
+        reducer.track_ready = True
+        tr.train_step(batch)
+        end_ev = torch.cuda.Event(enable_timing=True)
+        end_ev.record()
+        torch.cuda.synchronize()
+        reducer.track_ready = False
+        buckets = []
+        total_b = sum(a.numel() * 4 for a in reducer.arenas)
+        for i, a in enumerate(reducer.arenas):
+            ev = reducer.ready_events.get(i)
+            names = [n_ for n_, _ in reducer.buckets[i]]
+            buckets.append(dict(bucket=i, first=names[0], tensors=len(names), bytes=a.numel() * 4,
+                                ready_ms_before_step_end=None if ev is None else round(ev.elapsed_time(end_ev), 3),
+                                complete_by=(reducer.last_done_how[i] if i < len(getattr(reducer, "last_done_how", [])) else None) or "finalize",
+                                launched=bool(reducer.exchange)))
+        early = sum(b_["bytes"] for b_ in buckets if (b_["ready_ms_before_step_end"] or 0) >= 1.5)
+        buckets = dict(total_bytes=total_b, bytes_ready_1p5ms_before_end=early, fraction=round(early / total_b, 4), per_bucket=buckets)
+
     # ---- per-entry-point GPU time of one step: HIP events around every C-ABI launch (eager steps, launch stream)
     roof, kernels, cpu = None, [], None
     if rank == 0 and probe:
@@ -336,7 +358,7 @@ def run_train(args, d, dev, rank, world, steps=None, warmup=None, min_warm=None,
                        "B_per_gpu": d.B, "global_batch": d.B * world, "N": d.N, "F": d.F, "D": d.R, "T": d.T, "hip_graph": bool(use_graph),
                        "eager_ms_per_step": eager_ms,
                        "parallelism": f"dp{world}: clips sharded, one RCCL gradient exchange per step"},
-            "roofline": roof, "cpu_baseline": cpu, "exchange": exchange, "kernels": kernels}
+            "roofline": roof, "cpu_baseline": cpu, "exchange": exchange, "gradient_buckets": buckets, "kernels": kernels}
         if cpu:
             line["gpu_over_cpu"] = round(line["value"] / cpu["value"], 1)
         return line
@@ -714,7 +736,7 @@ def run_decode(args, d, dev, rank, world, dist_on, beam, steps, warmup, min_warm
 
 def brief(line):
     """One secondary entry: what was measured, its time and its roofline (the per-kernel table stays with the headline)."""
-    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "exchange")
+    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "exchange", "gradient_buckets")
     out = {k: line[k] for k in keep if k in line and line[k] is not None}
     ks = [k for k in line.get("kernels", []) if "kernel" in k][:4]
     out["top_kernels"] = [{kk: k[kk] for kk in ("kernel", "avg_us", "ms", "ms_per_step", "share", "frac_hbm", "frac_mfma") if kk in k} for k in ks]

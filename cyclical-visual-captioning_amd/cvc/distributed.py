@@ -181,6 +181,12 @@ class GradReducer:
         _F.GRAD_SINKS.append(self)
         self._late_listener_owner = _F
         self._written: set = set()                            # ids whose arena view was handed out for an in-place write this step
+        self._final: set = set()                              # ... whose producer declared the write complete (written(final=True))
+        self._hooked: set = set()                             # ids whose post-accumulate-grad hook has fired this step
+        self._done_how: List[Optional[str]] = [None] * len(groups)     # how each bucket became complete this step
+        self.track_ready = False                              # True: record an event when a bucket becomes complete (bench.py)
+        self._step_stream = None
+        self.ready_events: Dict[int, "torch.cuda.Event"] = {}
 
     # ------------------------------------------------------------------ gradient bookkeeping
     def mark_zeroed(self):
@@ -195,6 +201,8 @@ class GradReducer:
             for a in self.arenas:
                 a.zero_()
         self._clean = False
+        self.ready_events = {}
+        self._step_stream = torch.cuda.current_stream() if self.arenas and self.arenas[0].is_cuda else None
         for b in self.buckets:
             for _, p in b:
                 if id(p) in self._dead:                       # never receives a gradient: None, as in the reference (optimizers skip
@@ -205,7 +213,8 @@ class GradReducer:
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._arrived = [set() for _ in self.buckets]
-        self._written = set()
+        self._written, self._final, self._hooked = set(), set(), set()
+        self._done_how = [None] * len(self.buckets)
 
     # ---- gradient sink protocol (cvc.functional.GRAD_SINKS): the dense weight-gradient products write straight into the arena
     def claim(self, p):
@@ -218,17 +227,41 @@ class GradReducer:
         self._written.add(id(p))
         return v
 
-    def written(self, p):
+    def written(self, p, final: bool = False):
         """the producer has enqueued its in-place write of p's gradient.  Recorded as an arrival (the first step learns from it which
-        parameters are live); the bucket itself leaves from the post-accumulate-grad hook, which autograd fires for p once ALL of
-        its producers have returned (also when they returned None), or at finalize()."""
+        parameters are live).  final=True is the producer's word that this write is p's COMPLETE gradient of this backward pass (the
+        training loops' one flush per step): the bucket may then leave at once -- its exchange is enqueued behind the product that
+        just finished while the remaining weight-gradient products run.  Without it the bucket leaves from the
+        post-accumulate-grad hook, which autograd fires for p once ALL of its producers have returned, or at finalize()."""
         i = self._bucket_of[id(p)]
         self._clean = False
         if id(p) not in self._arrived[i]:
             self._arrived[i].add(id(p))
             self._ready[i] += 1
+        if final:
+            self._final.add(id(p))
         if not self._learned:
             self._seen_first[i].add(id(p))
+        elif final:
+            self._maybe_complete(i, "in-place write")
+
+    def _maybe_complete(self, i: int, how: str):
+        """bucket i holds every gradient it will get this step: note when (track_ready) and let it leave (overlap)"""
+        if self._done_how[i] is not None or not (self._arrived[i] >= self._live[i]) or self._seen_late[i]:
+            return
+        # parameters announced by a hook may still be written by a later producer unless every one of them is final or the hooks of
+        # all of them have fired (a hook fires after the parameter's last producer)
+        if not all((q in self._final) or (q in self._hooked) for q in self._live[i]):
+            return
+        self._done_how[i] = how
+        if self.track_ready:
+            # on the stream the step runs on (noted by zero_grad): a hook may run under another current stream -- autograd gives an
+            # AccumulateGrad node the stream its leaf was first used on, e.g. the warm-up stream of a graph capture
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(self._step_stream if self._step_stream is not None else torch.cuda.current_stream())
+            self.ready_events[i] = ev
+        if self.overlap and not self._launched[i]:
+            self._launch(i)
 
     def _revive(self, p):
         """A parameter that was marked dead (no gradient on the first step) receives one after all: its arena slot would never
@@ -268,12 +301,13 @@ class GradReducer:
         if id(p) not in self._arrived[i]:
             self._arrived[i].add(id(p))
             self._ready[i] += 1
+        self._hooked.add(id(p))
         if not self._learned:
             self._seen_first[i].add(id(p))
-        elif self.overlap and not self._launched[i] and self._arrived[i] >= self._live[i] and not self._seen_late[i]:
-            # every parameter of the bucket whose hook fired on the first step has arrived (identities, not counts); a bucket
-            # that also holds late-flushed weights leaves at finalize()
-            self._launch(i)
+        else:
+            # every parameter of the bucket that was live on the first step has arrived (identities, not counts); a bucket that
+            # also holds late-flushed weights leaves at finalize()
+            self._maybe_complete(i, "hook")
 
     def _launch(self, i: int):
         self._launched[i] = True
@@ -334,10 +368,36 @@ class GradReducer:
                     if id(p) not in self._seen_first[i] and id(p) not in self._seen_late[i]:
                         self._dead.add(id(p))
                         p.grad = None
+            self._compact()
+        self.last_done_how = list(self._done_how)             # (how every bucket became complete in the step that just ended)
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._arrived = [set() for _ in self.buckets]
-        self._written = set()
+        self._written, self._final, self._hooked = set(), set(), set()
+        self._done_how = [None] * len(self.buckets)
+
+    def _compact(self):
+        """End of the first step: the never-used parameters are known (the same set on every rank: checked) -- their slots leave the
+        arenas, so that no later exchange carries their zeros (66 MB of 581 MB at D = 2048: i2h_2, h2h_2, localied_fc, the
+        reconstructor's attention).  Live gradients keep their values and their order; every .grad is re-pointed at its new view
+        (the optimizer builds its segment table after this)."""
+        align = 64 * max(self.world, 1)
+        for i, b in enumerate(self.buckets):
+            if not any(id(p) in self._dead for _, p in b):
+                continue
+            live = [(n_, p) for n_, p in b if id(p) not in self._dead]
+            n = sum((p.numel() + 63) // 64 * 64 for _, p in live)
+            n = max(align, (n + align - 1) // align * align)
+            old = self.arenas[i]
+            arena = torch.zeros(n, device=old.device, dtype=old.dtype)
+            off = 0
+            for _, p in live:
+                v = arena[off:off + p.numel()].view_as(p)
+                v.copy_(self._views[id(p)])
+                self._views[id(p)] = v
+                p.grad = v
+                off += (p.numel() + 63) // 64 * 64
+            self.arenas[i] = arena
 
     def clip_(self, max_norm: float, summed: bool = True) -> torch.Tensor:
         """clip_grad_norm_(parameters, max_norm) over the arenas (trainer.py:120-121): global L2 norm of the averaged

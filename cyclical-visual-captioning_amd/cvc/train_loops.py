@@ -112,13 +112,15 @@ class _Out:
         self.param = param
         self.buf, self.sink = F_.claim_grad(param) if param is not None else (None, None)
         self.t = self.buf if self.buf is not None else (torch.empty_like(param) if param is not None else None)
+        self.announced = False
 
     def done(self):
-        """-> what the Function returns for this weight"""
-        if self.sink is not None:
-            self.sink.written(self.param)
-            return None
-        return self.t
+        """-> what the Function returns for this weight.  With a sink: announced as the parameter's COMPLETE gradient of this backward
+        (the loops' flush is its only producer), so its bucket's exchange can leave behind the product that was just enqueued."""
+        if self.sink is not None and not self.announced:
+            self.sink.written(self.param, final=True)
+            self.announced = True
+        return None if self.sink is not None else self.t
 
 
 def _weight_grads(arena: LoopArena, cfg, W):
@@ -132,9 +134,10 @@ def _weight_grads(arena: LoopArena, cfg, W):
     nl = len(slots)
     DGa, DGl = arena.dg_att[rows], arena.dg_lang[rows]
     Hl, Ha_prev, Ha, Cx, Em = arena.h_lang_prev[rows], arena.h_att_prev[rows], arena.h_att[rows], arena.ctx[rows], arena.emb[rows]
-    g = {}
     O = {k: _Out(W[k]) for k in ("w_ih_a", "w_hh_a", "b_ih_a", "b_hh_a", "w_ih_l", "w_hh_l", "b_ih_l", "b_hh_l")}
-    # ---- attention cell: weight_ih = [h_lang | (fc) | emb], weight_hh
+    # Largest gradient bucket first (cvc.distributed.GradReducer: every LSTM weight matrix is its own bucket, the biases ride with
+    # weight_hh), each announced as soon as its products are enqueued: its exchange then runs under the products that follow.
+    # ---- attention cell weight_ih = [h_lang | (fc) | emb]   (168 MB at D = 2048)
     Dp = hip.TileOperand(DGa, kmajor=True)                    # dG^T packed once for every product of the cell
     Hlp = hip.TileOperand(Hl, kmajor=True)                    # h_lang(t-1): att weight_ih[:, :R] AND lang weight_hh
     d_ih = O["w_ih_a"].t
@@ -147,18 +150,25 @@ def _weight_grads(arena: LoopArena, cfg, W):
         hip.tile_mm(DGsum, W["fc"], a_kmajor=True, b_kmajor=True, out=d_ih[:, R:2 * R])
         e0 = 2 * R
     hip.tile_mm(Dp, Em, b_kmajor=True, out=d_ih[:, e0:])
-    hip.tile_mm(Dp, Ha_prev, b_kmajor=True, out=O["w_hh_a"].t)
-    torch.sum(DGsum, 0, out=O["b_ih_a"].t)
-    O["b_hh_a"].t.copy_(O["b_ih_a"].t)
-    # ---- language cell: weight_ih = [ctx | h_att], weight_hh
+    O["w_ih_a"].done()
+    # ---- language cell weight_ih = [ctx | h_att]   (134 MB)
     Dl = hip.TileOperand(DGl, kmajor=True)
     d_il = O["w_ih_l"].t
     hip.tile_mm(Dl, Cx, b_kmajor=True, out=d_il[:, :R])
     Hap = hip.TileOperand(Ha, kmajor=True)
     hip.tile_mm(Dl, Hap, out=d_il[:, R:])
+    O["w_ih_l"].done()
+    # ---- the two weight_hh + biases   (67 MB each)
+    hip.tile_mm(Dp, Ha_prev, b_kmajor=True, out=O["w_hh_a"].t)
+    torch.sum(DGsum, 0, out=O["b_ih_a"].t)
+    O["b_hh_a"].t.copy_(O["b_ih_a"].t)
+    for k in ("w_hh_a", "b_ih_a", "b_hh_a"):
+        O[k].done()
     hip.tile_mm(Dl, Hlp, out=O["w_hh_l"].t)
     torch.sum(arena.dgsum_lang[slots[0]:slots[-1] + 1].view(nl * B, 4 * R), 0, out=O["b_ih_l"].t)
     O["b_hh_l"].t.copy_(O["b_ih_l"].t)
+    for k in ("w_hh_l", "b_ih_l", "b_hh_l"):
+        O[k].done()
     # ---- h2attn / alpha_net: loop A's rows only
     if 0 in slots and arena.extra:
         x = arena.extra
@@ -295,17 +305,8 @@ class _Loop(torch.autograd.Function):
         L.bwd_ws = _ptr(ws)
         hip._check(hip.lib().cvc_train_loop_bwd(C.byref(L), hip._stream()), "cvc_train_loop_bwd")
         arena.done.append(cfg.slot)
-        # ---- gradients of the hoisted inputs (dense, once per loop)
-        DGa, DGl = arena.dg_att[rows], arena.dg_lang[rows]
-        e0 = 2 * R if cfg.has_fc else R
-        d_emb = hip.tile_mm(DGa, hip.weight_operand(w_ih_a[:, e0:], kmajor=True)).view(T, B, E).transpose(0, 1) if ni[2] else None
-        d_fc = None
-        if cfg.has_fc and ni[3]:
-            d_fc = F_._mm_nn(arena.dgsum_att[cfg.slot], w_ih_a[:, R:2 * R])
-        d_ctx = None
-        if kind == 1 and ni[4]:
-            d_ctx = hip.tile_mm(DGl, hip.weight_operand(w_ih_l[:, :R], kmajor=True)).view(T, B, R).transpose(0, 1)
-        # ---- weight gradients: by whichever loop finishes its backward last, over all loops' rows at once
+        # ---- weight gradients: by whichever loop finishes its backward last, over all loops' rows at once -- BEFORE this loop's
+        # input gradients, so that the gradient buckets (486 MB) are complete, and their exchange under way, as early as possible
         order = ("w_ih_a", "w_hh_a", "b_ih_a", "b_hh_a", "w_ih_l", "w_hh_l", "b_ih_l", "b_hh_l", "w_h", "b_h", "w_a", "b_a")
         owners = (w_ih_a, w_hh_a, b_ih_a, b_hh_a, w_ih_l, w_hh_l, b_ih_l, b_hh_l, w_h, b_h, w_a, b_a)
         W = dict(zip(order, owners), fc=fc)
@@ -323,6 +324,16 @@ class _Loop(torch.autograd.Function):
             for i, gi in enumerate(got):
                 if gi is not None and owners[i] is not None and ni[9 + i]:
                     wg[i] = gi.view_as(owners[i]) if gi.numel() == owners[i].numel() else gi
+        # ---- gradients of the hoisted inputs (dense, once per loop)
+        DGa, DGl = arena.dg_att[rows], arena.dg_lang[rows]
+        e0 = 2 * R if cfg.has_fc else R
+        d_emb = hip.tile_mm(DGa, hip.weight_operand(w_ih_a[:, e0:], kmajor=True)).view(T, B, E).transpose(0, 1) if ni[2] else None
+        d_fc = None
+        if cfg.has_fc and ni[3]:
+            d_fc = F_._mm_nn(arena.dgsum_att[cfg.slot], w_ih_a[:, R:2 * R])
+        d_ctx = None
+        if kind == 1 and ni[4]:
+            d_ctx = hip.tile_mm(DGl, hip.weight_operand(w_ih_l[:, :R], kmajor=True)).view(T, B, R).transpose(0, 1)
         del live
         return (None, None, d_emb, d_fc, d_ctx, *grads_feat, *wg)
 
