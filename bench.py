@@ -107,34 +107,37 @@ def usable_cores() -> int:
 
 
 def pmc_traffic(kernel, args, over, mode="decode", beam=None, config_name=None):
-    """HBM bytes per launch of `kernel` from the tracked PMC collection (profiles/traffic.json, written by
-    tools/collect_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very command).
+    """HBM bytes per launch of `kernel` from the tracked PMC collection of THIS workload (profiles/traffic/<config>_beam<b>_<mode>.json,
+    written by tools/collect_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very command).
     The file records the hash of the kernel sources it was collected on; numbers from any other build are REFUSED
     (traffic = null plus the reason) instead of printed as if they were current."""
-    path = os.path.join(ROOT, "profiles", "traffic.json" if mode == "decode" else f"traffic_{mode}.json")
-    if not os.path.exists(path):
-        return None, f"profiles/{os.path.basename(path)} absent"
+    cfg = config_name or args.config
+    b = args.beam if beam is None else beam
+    from cvc import synth as _synth
+    # cfg2 and cfg3 are the same sizes: a decode collection of one serves the other
+    names = [cfg] + [c for c in _synth.CONFIGS if c != cfg and cfg in _synth.CONFIGS and _synth.CONFIGS[c] == _synth.CONFIGS[cfg]]
+    path = None
+    for c in names:
+        cand = os.path.join(ROOT, "profiles", "traffic", f"{c}_beam{b}_{mode}.json")
+        if os.path.exists(cand):
+            path = cand
+            break
+    if path is None:
+        return None, f"profiles/traffic/{cfg}_beam{b}_{mode}.json absent"
+    if over:
+        return None, "dimension overrides on the command line: the tracked collection is for the named config"
     try:
         tf = json.load(open(path))
     except Exception as e:
-        return None, f"profiles/traffic.json unreadable: {e}"
+        return None, f"{os.path.relpath(path, ROOT)} unreadable: {e}"
     import build_hip
     have = build_hip.source_hash()
     if tf.get("source_hash") != have:
         return None, f"stale: collected on kernel sources {tf.get('source_hash')}, this build is {have}"
-    want = dict(config=config_name or args.config, beam=args.beam if beam is None else beam, mode=mode)
-    got = {k: tf.get("workload", {}).get(k) for k in want}
-    from cvc import synth as _synth
-    same_dims = (got.get("config") in _synth.CONFIGS and want["config"] in _synth.CONFIGS
-                 and _synth.CONFIGS[got["config"]] == _synth.CONFIGS[want["config"]])       # cfg2 and cfg3 are the same sizes
-    if same_dims:
-        got["config"] = want["config"]
-    if over or got != want:
-        return None, f"collected for {tf.get('workload')}, not for this workload"
     ent = tf.get("kernels", {}).get(kernel)
     if not ent:
-        return None, f"no PMC entry for {kernel}"
-    return int(ent["hbm_bytes"]), f"{ent['symbol']} ({ent['dispatches']} dispatches; 2 x FETCH_SIZE + WRITE_SIZE, KiB units)"
+        return None, f"no PMC entry for {kernel} in {os.path.relpath(path, ROOT)}"
+    return int(ent["hbm_bytes"]), f"{ent['symbol'][:110]} ({ent['dispatches']} dispatches; 2 x FETCH_SIZE + WRITE_SIZE, KiB units; {os.path.basename(path)})"
 
 
 def algorithmic_work(d, beam):
@@ -277,39 +280,56 @@ def run_train(args, d, dev, rank, world, steps=None, warmup=None, min_warm=None,
         early = sum(b_["bytes"] for b_ in buckets if (b_["ready_ms_before_step_end"] or 0) >= 1.5)
         buckets = dict(total_bytes=total_b, bytes_ready_1p5ms_before_end=early, fraction=round(early / total_b, 4), per_bucket=buckets)
 
-    # ---- per-entry-point GPU time of one step: HIP events around every C-ABI launch (eager steps, launch stream)
+    # ---- GPU time of one step by launch role: HIP events around every C-ABI launch (eager steps, launch stream); the launches
+    # INSIDE the two C-driven loops come from the drivers' own per-launch event pairs (cvc_train_loop_profile)
     roof, kernels, cpu = None, [], None
     if rank == 0 and probe:
+        import ctypes as C
         from cvc import hip
+        L = hip.lib()
         work = train_work(d)
-        timers = hip.enable_timers()
         nprobe = 2
         tr.train_step(batch)
         torch.cuda.synchronize()
-        timers.clear()
+        cap = 4 * 16 * d.T * (nprobe + 1)
+        hip._check(L.cvc_train_loop_profile(cap), "cvc_train_loop_profile")
+        timers = hip.enable_timers()
         for _ in range(nprobe):
             tr.train_step(batch)
         torch.cuda.synchronize()
         hip.disable_timers()
-        tot = {k: sum(a.elapsed_time(b) for a, b in v) / nprobe for k, v in timers.items()}      # ms per step
-        cnt = {k: len(v) // nprobe for k, v in timers.items()}
+        kind, loop, ms = (C.c_int * cap)(), (C.c_int * cap)(), (C.c_float * cap)()
+        nrec = L.cvc_train_loop_profile_read(kind, loop, ms, cap)
+        L.cvc_train_loop_profile(0)
+        KN = ["zero_fill", "att_cell", "h2attn", "attn_scores", "attn_wsum", "lang_cell", "gate_grad_lang", "nn_lang", "attn_bwd",
+              "nn_h2attn", "gate_grad_att", "nn_att"]
+        LN = ["loopA.fwd", "loopC.fwd", "loopA.bwd", "loopC.bwd"]
+        tot, cnt = {}, {}
+        for i in range(nrec):
+            name = f"{LN[loop[i]]}.{KN[kind[i]]}"
+            tot[name] = tot.get(name, 0.0) + ms[i] / nprobe
+            cnt[name] = cnt.get(name, 0) + 1
+        cnt = {k: v // nprobe for k, v in cnt.items()}
+        for k, v in timers.items():                      # entry points called from Python (dense products, criteria, optimizer)
+            if k in ("cvc_train_loop_fwd", "cvc_train_loop_bwd"):
+                continue
+            tot[k] = sum(a.elapsed_time(b) for a, b in v) / nprobe
+            cnt[k] = len(v) // nprobe
         ours = sum(tot.values())
         for name in sorted(tot, key=lambda k: -tot[k]):
-            ent = dict(kernel=name, launches_per_step=cnt[name], ms_per_step=round(tot[name], 3), avg_us=round(tot[name] / cnt[name] * 1e3, 2),
+            ent = dict(kernel=name, launches_per_step=cnt[name], ms_per_step=round(tot[name], 3), avg_us=round(tot[name] / max(1, cnt[name]) * 1e3, 2),
                        share=round(tot[name] / ms_step, 4))
             wk = work.get(name)
-            if wk:
-                # work totals are per STEP (all launches of the entry point); per launch = total / launches
-                per_b, per_f = wk["bytes"] / cnt[name], wk["flops"] / cnt[name]
+            if wk:      # work per LAUNCH of this role
                 avg_s = tot[name] / cnt[name] * 1e-3
-                gbs, tf = per_b / avg_s / 1e9, per_f / avg_s / 1e12
-                peak_tf = MFMA_BF16_PEAK_TFLOPS / 6 if wk["mfma"] == "split" else MFMA_F32_PEAK_TFLOPS
-                bound = "mfma" if per_f / (peak_tf * 1e12) > per_b / (HBM_PEAK_GBS * 1e9) else "hbm"
-                ent.update(algorithmic_bytes=int(per_b), algorithmic_flops=int(per_f), achieved_GBs=round(gbs, 1),
+                gbs, tf = wk["bytes"] / avg_s / 1e9, wk.get("flops", 0) / avg_s / 1e12
+                peak_tf = MFMA_BF16_PEAK_TFLOPS / 6 if wk.get("mfma") == "split" else MFMA_F32_PEAK_TFLOPS
+                bound = "mfma" if wk.get("flops", 0) / (peak_tf * 1e12) > wk["bytes"] / (HBM_PEAK_GBS * 1e9) else "hbm"
+                ent.update(algorithmic_bytes=int(wk["bytes"]), algorithmic_flops=int(wk.get("flops", 0)), achieved_GBs=round(gbs, 1),
                            frac_hbm=round(gbs / HBM_PEAK_GBS, 4), achieved_TFLOPs=round(tf, 2), mfma_peak_TFLOPs=round(peak_tf, 1),
-                           frac_mfma=round(tf / peak_tf, 4), bound=bound, mfma=wk["mfma"])
+                           frac_mfma=round(tf / peak_tf, 4), bound=bound, mfma=wk.get("mfma", "none"))
             kernels.append(ent)
-        kernels.append(dict(kernel="(library / ATen kernels and gaps: Adam, clip, autograd glue)", ms_per_step=round(ms_step - ours, 3),
+        kernels.append(dict(kernel="(library / ATen kernels and gaps: autograd glue, sorts, small reductions)", ms_per_step=round(ms_step - ours, 3),
                             share=round((ms_step - ours) / ms_step, 4)))
         dom = next((e for e in kernels if "bound" in e), None)
         if dom is not None:
@@ -520,26 +540,25 @@ def run_encoder(args, d, dev, brief=False, steps=None, warmup=None):
 
 
 def train_work(d):
-    """Algorithmic bytes / flops per training STEP of the C-ABI entry points that carry the dense work (cyclical pass,
-    train_decoder_only = False; SURVEY.md section 8(d) training formulas).  Weights stream once per launch; M = B rows per
-    step-wise launch, M = B*T for the T-batched ones.  `mfma`: which matrix instruction executes the products."""
-    B, N, F, R, A, E, V, T = d.B, d.N, d.F, d.R, d.A, d.E, d.V, d.T
+    """Algorithmic bytes / flops PER LAUNCH of the roles inside the two C-driven training loops (cyclical pass; SURVEY.md section
+    8(d) training formulas).  Weights stream once per launch; M = B rows.  `mfma`: which matrix instruction executes the products.
+    Names = bench.py's launch roles (loop.direction.role, csrc/train_driver.hip)."""
+    B, N, F, R, A = d.B, d.N, d.F, d.R, d.A
+    gemm = lambda k, nout=4 * R: dict(bytes=4 * nout * k + 4 * B * (k + nout), flops=2 * B * nout * k, mfma="split")
     w = {}
-    k_att, k_lang = E + 3 * R, 3 * R                       # K of the two cells (fc segment included in training)
-    # forward cells: Loop A + Loop C, T launches each per cell
-    cells = dict(bytes=2 * T * 4 * (4 * R * (k_att + k_lang)) + 2 * T * 4 * B * (k_att + k_lang + 12 * R),
-                 flops=2 * T * 2 * B * 4 * R * (k_att + k_lang), mfma="split")
-    w["cvc_packed_lstm_train_fwd"] = cells           # the packed gate GEMM in its training form (default)
-    w["cvc_lstm_cell_fwd"] = cells                   # the row-major ring kernel (shapes the packed form does not take)
-    # backward-data of the cells: every input range except fc_feats (features carry no gradient in the bench)
-    kx = (E + 2 * R) + 3 * R
-    w["cvc_linear_nn_fwd"] = dict(bytes=2 * T * 4 * 4 * R * kx + 2 * T * 4 * B * (8 * R + kx), flops=2 * T * 2 * B * 4 * R * kx,
-                                  mfma="split")      # skinny_gemm_nn_split_kernel (cvc_gemm_packed_split != 0, the default)
-    # attention: Loop A (T launches, nq = 1) + Loop B (1 launch, nq = T): each streams proj + ctx of both sets once
-    att_bytes = 4 * B * (N + F) * (A + R)
-    w["cvc_attn_fwd"] = dict(bytes=(T + 1) * att_bytes, flops=(T + T) * B * (N + F) * (4 * A + 2 * R), mfma="none")
-    # backward: the context rows once (d_attn = d_ctx . C), the projected rows once (tanh recomputed) -- one call per feature set
-    w["cvc_attn_bwd"] = dict(bytes=(T + 1) * att_bytes, flops=2 * (T + T) * B * (N + F) * (4 * A + 2 * R), mfma="none")
+    # forward cells: the recurrent columns only (fc / word / localized-context terms are hoisted into dense products)
+    for lp in ("loopA", "loopC"):
+        w[f"{lp}.fwd.att_cell"] = gemm(2 * R)
+        w[f"{lp}.bwd.nn_att"] = gemm(2 * R)
+    w["loopA.fwd.lang_cell"], w["loopC.fwd.lang_cell"] = gemm(3 * R), gemm(2 * R)
+    w["loopA.bwd.nn_lang"], w["loopC.bwd.nn_lang"] = gemm(3 * R), gemm(2 * R)
+    w["loopA.fwd.h2attn"] = gemm(R, A)
+    w["loopA.bwd.nn_h2attn"] = gemm(R, A)
+    # attention of one step: projected rows once (scores), context rows once (weighted sum); backward: context rows once (d_attn),
+    # projected rows once (tanh recomputed)
+    w["loopA.fwd.attn_scores"] = dict(bytes=4 * B * (N + F) * A, flops=B * (N + F) * 4 * A, mfma="none")
+    w["loopA.fwd.attn_wsum"] = dict(bytes=4 * B * (N + F) * R, flops=2 * B * (N + F) * R, mfma="none")
+    w["loopA.bwd.attn_bwd"] = dict(bytes=4 * B * (N + F) * (A + R), flops=B * (N + F) * (8 * A + 2 * R), mfma="none")
     return w
 
 

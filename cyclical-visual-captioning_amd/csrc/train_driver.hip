@@ -10,12 +10,45 @@
 
 namespace {
 
-#define CVC_TRY(expr)             \
-    do {                          \
-        int rc_ = (expr);         \
-        ++n;                      \
-        if (rc_ != 0) return rc_; \
+// ---- measurement aid (bench.py): per-launch HIP-event pairs around every entry point the drivers call, on the launch stream.
+// Off by default; the product path never enables it.  Kinds name the role of a launch inside a step.
+enum LaunchKind { K_ZERO = 0, K_ATT_CELL, K_H2ATTN, K_SCORES, K_WSUM, K_LANG_CELL, K_PW_LANG, K_NN_LANG, K_ATTN_BWD, K_NN_H2ATTN, K_PW_ATT,
+                  K_NN_ATT, K_NKINDS };
+struct Prof {
+    bool on = false;
+    int n = 0, cap = 0;
+    hipEvent_t* ev = nullptr;      // 2 per launch
+    int* kind = nullptr;
+    int* loop = nullptr;           // 0: loop A forward, 1: loop C forward, 2: loop A backward, 3: loop C backward
+} g_prof;
+int g_prof_loop = 0;
+
+struct ProfScope {
+    hipStream_t st;
+    int slot = -1;
+    ProfScope(int kind, hipStream_t s) : st(s) {
+        if (!g_prof.on || g_prof.n >= g_prof.cap) return;
+        slot = g_prof.n++;
+        g_prof.kind[slot] = kind;
+        g_prof.loop[slot] = g_prof_loop;
+        (void)hipEventRecord(g_prof.ev[2 * slot], st);
+    }
+    ~ProfScope() {
+        if (slot >= 0) (void)hipEventRecord(g_prof.ev[2 * slot + 1], st);
+    }
+};
+
+#define CVC_TRY_K(kind, expr)          \
+    do {                               \
+        int rc_;                       \
+        {                              \
+            ProfScope ps_((kind), st); \
+            rc_ = (expr);              \
+        }                              \
+        ++n;                           \
+        if (rc_ != 0) return rc_;      \
     } while (0)
+#define CVC_TRY(expr) CVC_TRY_K(K_ZERO, expr)
 
 inline float* quad_off(float* buf, int k0) { return buf + (size_t)(k0 / 4) * 64 * 4; }
 
@@ -89,25 +122,25 @@ int run_fwd(const cvc_train_loop& L, hipStream_t st, int* launches) {
         a.h_out2 = last ? nullptr : L.h_att_prev + (size_t)(t + 1) * BR;
         a.h_dst1_q = quad_off(L.xl[rd], ha_off);
         a.h_dst2_q = quad_off(L.xa[wr], R);
-        CVC_TRY(cvc_packed_lstm_step_fwd(&a, st));
+        CVC_TRY_K(K_ATT_CELL, cvc_packed_lstm_step_fwd(&a, st));
         if (L.kind == 0) {
             // ---- additive / dot attention over regions + frames with one query (decoder_core.py:54-56, modules.py:100-159)
             const int qs = L.wp_h ? L.q_split : 1;
             float* q = L.q + (size_t)t * qs * B * A;
             if (L.wp_h) {       // split-K over the chip on the packed kernel, planes summed (+ bias) while the score pass loads the query
-                CVC_TRY(cvc_packed_linear_fwd(L.wp_h, quad_off(L.xl[rd], ha_off), R, nullptr, B, A, qs, q, A, nullptr, st));
+                CVC_TRY_K(K_H2ATTN, cvc_packed_linear_fwd(L.wp_h, quad_off(L.xl[rd], ha_off), R, nullptr, B, A, qs, q, A, nullptr, st));
             } else {
                 cvc_gemm_seg seg{L.h_att + (size_t)t * BR, nullptr, L.w_h, R, R, R, 0};
-                CVC_TRY(cvc_linear_fwd(&seg, 1, L.b_h, nullptr, B, A, q, A, st));
+                CVC_TRY_K(K_H2ATTN, cvc_linear_fwd(&seg, 1, L.b_h, nullptr, B, A, q, A, st));
             }
             cvc_attn_set sets[2];
             sets[0] = cvc_attn_set{L.ppool, L.pool, L.mask, L.frame_mask ? L.frame_mask + (size_t)t * B * N : nullptr, L.scores_ws,
                                    L.fm ? L.fm + (size_t)t * B * N : nullptr, L.attn_r + (size_t)t * B * N, nullptr, N, 0};
             sets[1] = cvc_attn_set{L.pconv, L.conv, nullptr, nullptr, L.scores_ws + (size_t)B * N, nullptr,
                                    L.attn_f + (size_t)t * B * F, nullptr, F, 0};
-            if (L.wp_h) CVC_TRY(cvc_attn_scores_qparts(L.attn_kind, q, qs, L.b_h, L.w_a, L.b_a, L.inv_temp, sets, 2, B, 1, A, st));
-            else CVC_TRY(cvc_attn_scores(L.attn_kind, q, L.w_a, L.b_a, L.inv_temp, sets, 2, B, 1, A, st));
-            CVC_TRY(cvc_attn_wsum_quad_rm(sets, 2, B, R, L.xl[rd], L.ctx + (size_t)t * BR, st));
+            if (L.wp_h) CVC_TRY_K(K_SCORES, cvc_attn_scores_qparts(L.attn_kind, q, qs, L.b_h, L.w_a, L.b_a, L.inv_temp, sets, 2, B, 1, A, st));
+            else CVC_TRY_K(K_SCORES, cvc_attn_scores(L.attn_kind, q, L.w_a, L.b_a, L.inv_temp, sets, 2, B, 1, A, st));
+            CVC_TRY_K(K_WSUM, cvc_attn_wsum_quad_rm(sets, 2, B, R, L.xl[rd], L.ctx + (size_t)t * BR, st));
         }
         // ---- language LSTM (decoder_core.py:59-62 / :106-109) + output dropout
         cvc_lstm_step l{};
@@ -120,7 +153,7 @@ int run_fwd(const cvc_train_loop& L, hipStream_t st, int* launches) {
         l.rng_state = L.p > 0.f ? L.rng_state : nullptr; l.site = L.site0 + (unsigned)t; l.p = L.p;
         l.h_dst1_q = last ? nullptr : L.xa[wr];
         l.h_dst2_q = last ? nullptr : quad_off(L.xl[wr], hl_off);
-        CVC_TRY(cvc_packed_lstm_step_fwd(&l, st));
+        CVC_TRY_K(K_LANG_CELL, cvc_packed_lstm_step_fwd(&l, st));
     }
     if (launches) *launches = n;
     return 0;
@@ -185,7 +218,7 @@ int run_bwd(const cvc_train_loop& L, hipStream_t st, int* launches) {
         // ---- language cell: d_h = dropout'(d_out[t]) + the next step's two uses of h_lang(t)
         {
             const cvc_grad_src src[3] = {g_hl_a, g_hl_b, none};
-            CVC_TRY(cvc_lstm_pointwise_bwd4(src, L.d_out + (size_t)t * BR, L.p > 0.f ? L.rng_state : nullptr, L.site0 + (unsigned)t, L.p,
+            CVC_TRY_K(K_PW_LANG, cvc_lstm_pointwise_bwd4(src, L.d_out + (size_t)t * BR, L.p > 0.f ? L.rng_state : nullptr, L.site0 + (unsigned)t, L.p,
                                             last ? nullptr : w.d_c_lang, L.g_lang + (size_t)t * BG, L.c_lang + (size_t)t * BR,
                                             L.c_lang + (size_t)(t + 1) * BR, B, R, L.dg_lang + (size_t)t * BG, w.d_c_lang, w.dgq,
                                             L.dgsum_lang, st));
@@ -198,7 +231,7 @@ int run_bwd(const cvc_train_loop& L, hipStream_t st, int* launches) {
             if (L.kind == 0) { i_ctx = ns; segs[ns++] = cvc_nn_seg{L.w_ih_lang, w.d_ctx, L.ld_ih_lang, R, R}; }
             i_ha = ns; segs[ns++] = cvc_nn_seg{L.w_ih_lang + R, w.d_ha_a, L.ld_ih_lang, R, R};
             if (t > 0) { i_hl = ns; segs[ns++] = cvc_nn_seg{L.w_hh_lang, w.d_hl_a, R, R, R}; }
-            CVC_TRY(nn(w.dgq, 4 * R, B, segs, ns, w.nn_l, out, feat_grads, st));
+            CVC_TRY_K(K_NN_LANG, nn(w.dgq, 4 * R, B, segs, ns, w.nn_l, out, feat_grads, st));
             if (i_ctx >= 0) g_ctx = out[i_ctx];
             g_ha_a = out[i_ha];
             g_hl_a = i_hl >= 0 ? out[i_hl] : none;
@@ -216,23 +249,23 @@ int run_bwd(const cvc_train_loop& L, hipStream_t st, int* launches) {
             const bool any_dp = L.d_ppool || L.d_pconv;
             const int qs = L.wp_h ? L.q_split : 1;
             const cvc_grad_src qsrc{L.q + (size_t)t * qs * B * A, A, (long long)B * A, qs};
-            CVC_TRY(cvc_attn_bwd_pair(L.attn_kind, &qsrc, L.wp_h ? L.b_h : nullptr, L.w_a, L.inv_temp, sets, 2, &g_ctx, B, 1, A, R,
+            CVC_TRY_K(K_ATTN_BWD, cvc_attn_bwd_pair(L.attn_kind, &qsrc, L.wp_h ? L.b_h : nullptr, L.w_a, L.inv_temp, sets, 2, &g_ctx, B, 1, A, R,
                                       L.dq + (size_t)t * B * A, w.dqq, L.dwa_part ? L.dwa_part + (size_t)t * B * A : nullptr,
                                       any_dp ? d_proj : nullptr, feat_grads ? d_cf : nullptr, st));
             cvc_nn_seg seg{L.w_h, w.d_ha_b, R, R, R};
-            CVC_TRY(nn(w.dqq, A, B, &seg, 1, w.nn_h, &g_ha_b, false, st));
+            CVC_TRY_K(K_NN_H2ATTN, nn(w.dqq, A, B, &seg, 1, w.nn_h, &g_ha_b, false, st));
         }
         // ---- attention cell: d_h = language cell's input + attention query + next step's recurrence
         {
             const cvc_grad_src src[3] = {g_ha_a, g_ha_b, g_ha_prev};
-            CVC_TRY(cvc_lstm_pointwise_bwd4(src, nullptr, nullptr, 0, 0.f, last ? nullptr : w.d_c_att, L.g_att + (size_t)t * BG,
+            CVC_TRY_K(K_PW_ATT, cvc_lstm_pointwise_bwd4(src, nullptr, nullptr, 0, 0.f, last ? nullptr : w.d_c_att, L.g_att + (size_t)t * BG,
                                             L.c_att + (size_t)t * BR, L.c_att + (size_t)(t + 1) * BR, B, R, L.dg_att + (size_t)t * BG,
                                             w.d_c_att, w.dgq, L.dgsum_att, st));
         }
         if (t > 0) {
             cvc_nn_seg segs[2] = {cvc_nn_seg{L.w_ih_att, w.d_hl_b, L.ld_ih_att, R, R}, cvc_nn_seg{L.w_hh_att, w.d_ha_prev, R, R, R}};
             cvc_grad_src out[2];
-            CVC_TRY(nn(w.dgq, 4 * R, B, segs, 2, w.nn_a, out, false, st));
+            CVC_TRY_K(K_NN_ATT, nn(w.dgq, 4 * R, B, segs, 2, w.nn_a, out, false, st));
             g_hl_b = out[0];
             g_ha_prev = out[1];
         }
@@ -252,6 +285,7 @@ extern "C" int cvc_train_loop_fwd(const cvc_train_loop* loop, cvc_stream_t strea
     if (!loop) return CVC_E_BADARG;
     int rc = validate(*loop, false);
     if (rc) return rc;
+    g_prof_loop = loop->kind;
     return run_fwd(*loop, (hipStream_t)stream, nullptr);
 }
 
@@ -259,7 +293,43 @@ extern "C" int cvc_train_loop_bwd(const cvc_train_loop* loop, cvc_stream_t strea
     if (!loop) return CVC_E_BADARG;
     int rc = validate(*loop, true);
     if (rc) return rc;
+    g_prof_loop = 2 + loop->kind;
     return run_bwd(*loop, (hipStream_t)stream, nullptr);
+}
+
+// ---- measurement aid: per-launch timing of the drivers' entry points (bench.py --mode train).  enable > 0: room for `enable`
+// launches (event pairs created here, recording starts); 0: stop and free.  Not thread-safe, not for captured streams.
+extern "C" int cvc_train_loop_profile(int enable) {
+    if (g_prof.ev != nullptr) {
+        for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
+        delete[] g_prof.ev; delete[] g_prof.kind; delete[] g_prof.loop;
+        g_prof = Prof{};
+    }
+    if (enable <= 0) return 0;
+    g_prof.cap = enable;
+    g_prof.ev = new hipEvent_t[2 * (size_t)enable];
+    g_prof.kind = new int[enable];
+    g_prof.loop = new int[enable];
+    for (int i = 0; i < 2 * enable; ++i)
+        if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return CVC_E_BADARG;
+    g_prof.n = 0;
+    g_prof.on = true;
+    return 0;
+}
+
+// -> number of launches recorded since cvc_train_loop_profile(n); kind[i] (LaunchKind), loop[i] (0 / 1: forward of loop A / C,
+// 2 / 3: backward), ms[i].  Waits for the recorded launches to finish.
+extern "C" int cvc_train_loop_profile_read(int* kind, int* loop, float* ms, int cap) {
+    if (!g_prof.on || !kind || !loop || !ms) return 0;
+    const int n = g_prof.n < cap ? g_prof.n : cap;
+    for (int i = 0; i < n; ++i) {
+        (void)hipEventSynchronize(g_prof.ev[2 * i + 1]);
+        float t = 0.f;
+        (void)hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
+        kind[i] = g_prof.kind[i]; loop[i] = g_prof.loop[i]; ms[i] = t;
+    }
+    g_prof.n = 0;
+    return n;
 }
 
 // launches one call enqueues (what the drivers above count): the zero fills + per step 2 cells (+ h2attn, 2 attention passes),

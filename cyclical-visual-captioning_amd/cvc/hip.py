@@ -127,6 +127,8 @@ SIGNATURES = {
     "cvc_train_loop_fwd": [C.POINTER(TrainLoop), _P],
     "cvc_train_loop_bwd": [C.POINTER(TrainLoop), _P],
     "cvc_train_loop_launches": [C.POINTER(TrainLoop), _I],
+    "cvc_train_loop_profile": [_I],
+    "cvc_train_loop_profile_read": [C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), _I],
     "cvc_attn_fwd": [_I, _P, _P, _P, _F, C.POINTER(AttnSet), _I, _I, _I, _I, _I, _P, _P],
     "cvc_attn_scores": [_I, _P, _P, _P, _F, C.POINTER(AttnSet), _I, _I, _I, _I, _P],
     "cvc_attn_scores_qparts": [_I, _P, _I, _P, _P, _P, _F, C.POINTER(AttnSet), _I, _I, _I, _I, _P],

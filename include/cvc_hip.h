@@ -836,6 +836,14 @@ long long cvc_train_loop_bwd_ws(int B, int R, int A);
 int cvc_train_loop_fwd(const cvc_train_loop* loop, cvc_stream_t stream);
 int cvc_train_loop_bwd(const cvc_train_loop* loop, cvc_stream_t stream);
 int cvc_train_loop_launches(const cvc_train_loop* loop, int backward);     /* launches one call enqueues */
+/* Measurement aid (bench.py --mode train; never enabled by the product path): HIP-event pairs around every entry point the two
+ * drivers call, on the launch stream.  cvc_train_loop_profile(n > 0) starts recording with room for n launches, (0) stops and
+ * frees; cvc_train_loop_profile_read waits for the recorded launches and returns their count, kind[i] (0 zero fill, 1 attention
+ * cell, 2 h2attn, 3 score pass, 4 weighted sum, 5 language cell, 6 / 10 gate gradients of the language / attention cell, 7 / 9 /
+ * 11 backward-data product of the language cell / h2attn / the attention cell, 8 attention backward), loop[i] (0 / 1 forward of
+ * loop A / C, 2 / 3 their backward) and ms[i]; the record is emptied. */
+int cvc_train_loop_profile(int enable);
+int cvc_train_loop_profile_read(int* kind, int* loop, float* ms, int cap);
 
 /* ---------------------------------------------------------------------------------------
  * Optimizer step of the training path (trainer.py:116-122: nn.utils.clip_grad_norm_ -> optimizer.step(); Adam with one group per

@@ -1,19 +1,20 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json from two rocprofv3 PMC passes over bench.py (separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs,
-`--kernel-trace` only, eager launches: `bench.py --no-graph`), as /opt/skills/guides/MI355X_MICROARCH.md prescribes:
+"""profiles/traffic/<config>_beam<b>_<mode>.json from two rocprofv3 PMC passes over bench.py (separate --pmc FETCH_SIZE and
+--pmc WRITE_SIZE runs, `--kernel-trace` only), as /opt/skills/guides/MI355X_MICROARCH.md prescribes:
 
     hbm_bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024
 
 FETCH_SIZE is doubled (gfx950 tallies the 128-B requests of wide coalesced reads at 64 B), both counters are in KiB.
 
-Launches of one kernel symbol that play different roles in a decode step (the packed LSTM kernel runs the attention LSTM and
-the language LSTM; the packed linear kernel runs h2attn and the vocabulary projection) are separated by their position in the
-dispatch sequence, which is fixed: --roles "skinny_gemm_packed_kernel<…true…>=att_lstm,lang_lstm".
+One kernel symbol plays several roles in a step (the packed LSTM kernel runs the attention cell and the language cell; the tile
+GEMM runs four products per beam step; the backward-data kernel runs three products per training step and loop).  The launch
+order is fixed, so a role is (symbol regex, period, which positions of the period): the dispatches of the symbol are numbered in
+order and position = number mod period.
 
 The file records the kernel symbol behind every entry and the sha256 of the kernel sources it was collected on
 (build_hip.source_hash()); bench.py refuses the numbers when that hash differs from the build it runs.
 
-usage: collect_traffic.py FETCH.db WRITE.db --config cfg2 --beam 1 [--mode decode] [--out profiles/traffic.json] [--md profiles/rNN_pmc.md]
+usage: collect_traffic.py FETCH.db WRITE.db --config cfg2 --beam 1 [--mode decode|train] [--outdir profiles/traffic] [--md file.md]
 """
 import argparse
 import json
@@ -26,27 +27,50 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "cyclical-visual-captioning_amd"))
 
-# launch name in bench.py -> (regex on the demangled-ish kernel symbol, position among that symbol's dispatches per cycle, cycle length)
-DECODE_ROLES = {
-    "att_lstm": (r"skinny_gemm_packed_kernelILi\dELb1E", 0, 2),
-    "lang_lstm": (r"skinny_gemm_packed_kernelILi\dELb1E", 1, 2),
-    "h2attn": (r"skinny_gemm_packed_kernelILi\dELb0E", 0, 2),
-    "logits": (r"skinny_gemm_packed_kernelILi\dELb0E", 1, 2),
-    "attn_scores": (r"attn_scores_kernel", 0, 1),
-    "attn_wsum": (r"attn_wsum_kernel", 0, 1),
-    "word_select": (r"top2_final_kernel", 0, 1),
-}
 
-
-# --mode train: C-ABI entry point of bench.py's training table -> kernel symbol; every dispatch of the symbol is averaged (the
-# entry points run the same kernel on a few shapes per step: both cells, both loops), as bench.py averages their durations
-TRAIN_ROLES = {
-    "cvc_linear_nn_fwd": (r"skinny_gemm_nn_split_kernel", 0, 1),
-    "cvc_packed_lstm_train_fwd": (r"skinny_gemm_packed_kernelILi\dELb1E", 0, 1),
-    "cvc_tile_gemm": (r"tile_gemm_ld2?_kernel", 0, 1),
-    "cvc_attn_score_bwd": (r"attn_score_bwd_kernel", 0, 1),
-    "cvc_attn_wsum": (r"attn_wsum_kernel", 0, 1),
-}
+def roles_for(mode, beam, T):
+    """role name (bench.py's launch name) -> (regex on the kernel symbol, period, set of positions inside the period)"""
+    if mode == "train":
+        # forward of a step: loop A = T x (attention cell, language cell), then loop C = T x (attention cell, language cell);
+        # backward: loop C first (T x (language product, attention product), none for the attention cell at t = 0), then loop A
+        # (T x (language product, h2attn product, attention product), the last one missing at t = 0)
+        lstm = r"skinny_gemm_packed_kernelILi\dELb1E"
+        nn = r"skinny_gemm_nn_split_kernel"
+        pc = 2 * T - 1
+        pa = 3 * T - 1
+        return {
+            "loopA.fwd.att_cell": (lstm, 4 * T, {j for j in range(2 * T) if j % 2 == 0}),
+            "loopA.fwd.lang_cell": (lstm, 4 * T, {j for j in range(2 * T) if j % 2 == 1}),
+            "loopC.fwd.att_cell": (lstm, 4 * T, {2 * T + j for j in range(2 * T) if j % 2 == 0}),
+            "loopC.fwd.lang_cell": (lstm, 4 * T, {2 * T + j for j in range(2 * T) if j % 2 == 1}),
+            "loopC.bwd.nn_lang": (nn, pc + pa, {j for j in range(pc) if j % 2 == 0}),
+            "loopC.bwd.nn_att": (nn, pc + pa, {j for j in range(pc) if j % 2 == 1}),
+            "loopA.bwd.nn_lang": (nn, pc + pa, {pc + j for j in range(pa) if j % 3 == 0}),
+            "loopA.bwd.nn_h2attn": (nn, pc + pa, {pc + j for j in range(pa) if j % 3 == 1}),
+            "loopA.bwd.nn_att": (nn, pc + pa, {pc + j for j in range(pa) if j % 3 == 2}),
+            "loopA.fwd.attn_scores": (r"attn_scores_kernelILi0ELi\d+ELi1E", 1, {0}),
+            "loopA.fwd.attn_wsum": (r"attn_wsum_kernelE", 1, {0}),
+            "cvc_tile_gemm": (r"tile_gemm_ld2?_kernel", 1, {0}),
+        }
+    if beam > 1:
+        # tile path: per decode one hoisted fc product, then per step the four products in this order
+        tg = r"tile_gemm_ld2?_kernel"
+        per = 1 + 4 * T
+        pos = lambda k: {1 + 4 * t + k for t in range(T)}
+        return {
+            "att_lstm": (tg, per, pos(0)), "h2attn": (tg, per, pos(1)), "lang_lstm": (tg, per, pos(2)), "logits": (tg, per, pos(3)),
+            "attn_scores": (r"attn_scores_kernel", 1, {0}),
+            "attn_wsum": (r"attn_wsum(_mq)?_kernel", 1, {0}),
+        }
+    return {
+        "att_lstm": (r"skinny_gemm_packed_kernelILi\dELb1E", 2, {0}),
+        "lang_lstm": (r"skinny_gemm_packed_kernelILi\dELb1E", 2, {1}),
+        "h2attn": (r"skinny_gemm_packed_kernelILi\dELb0E", 2, {0}),
+        "logits": (r"skinny_gemm_packed_kernelILi\dELb0E", 2, {1}),
+        "attn_scores": (r"attn_scores_kernel", 1, {0}),
+        "attn_wsum": (r"attn_wsum_kernel", 1, {0}),
+        "word_select": (r"top2_final_kernel", 1, {0}),
+    }
 
 
 def per_dispatch(path, counter):
@@ -62,6 +86,10 @@ def per_dispatch(path, counter):
     return [(n, v) for n, v, _ in cur.execute(q, (counter,))]
 
 
+def workload_key(config, beam, mode):
+    return f"{config}_beam{beam}_{mode}"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("fetch_db")
@@ -69,13 +97,15 @@ def main():
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--beam", type=int, default=1)
     ap.add_argument("--mode", default="decode")
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "traffic.json"))
+    ap.add_argument("--outdir", default=os.path.join(ROOT, "profiles", "traffic"))
     ap.add_argument("--md", default=None)
-    ap.add_argument("--skip-decodes", type=int, default=0, help="ignore the dispatches of the first N role cycles (warm-up)")
+    ap.add_argument("--skip", type=int, default=0, help="ignore the first N periods of every role (warm-up)")
     a = ap.parse_args()
     import build_hip
+    from cvc import synth
+    T = synth.CONFIGS[a.config].T
     fetch, write = per_dispatch(a.fetch_db, "FETCH_SIZE"), per_dispatch(a.write_db, "WRITE_SIZE")
-    out = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python3 bench.py --no-graph ...; "
+    out = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python3 bench.py ...; "
                    "hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch (MI355X_MICROARCH.md, HBM section: FETCH_SIZE "
                    "counts the 128-B requests of wide coalesced reads as 64 B on gfx950); tools/collect_traffic.py",
            "source_hash": build_hip.source_hash(),
@@ -86,23 +116,29 @@ def main():
     except Exception:
         out["git_head"] = None
     rows = []
-    for role, (pat, pos, cyc) in (TRAIN_ROLES if a.mode == "train" else DECODE_ROLES).items():
+    for role, (pat, period, positions) in roles_for(a.mode, a.beam, T).items():
         rx = re.compile(pat)
         f = [(n, v) for n, v in fetch if rx.search(n)]
         w = [(n, v) for n, v in write if rx.search(n)]
         if not f:
             continue
-        fsel = [v for i, (n, v) in enumerate(f) if i % cyc == pos][a.skip_decodes:]
-        wsel = [v for i, (n, v) in enumerate(w) if i % cyc == pos][a.skip_decodes:]
+        if len(f) % period != 0:
+            print(f"[collect_traffic] {role}: {len(f)} dispatches of /{pat}/ are not a multiple of the period {period}: skipped", file=sys.stderr)
+            continue
+        sel = lambda xs: [v for i, (n, v) in enumerate(xs) if i % period in positions and i // period >= a.skip]
+        fsel, wsel = sel(f), sel(w)
         if not fsel:
             continue
         fk, wk = sum(fsel) / len(fsel), (sum(wsel) / len(wsel) if wsel else 0.0)
-        sym = f[pos][0]
+        sym = next(n for i, (n, v) in enumerate(f) if i % period in positions)
         out["kernels"][role] = {"symbol": sym, "dispatches": len(fsel), "FETCH_SIZE_KiB": round(fk, 1),
                                 "WRITE_SIZE_KiB": round(wk, 1), "hbm_bytes": int(round((2 * fk + wk) * 1024))}
         rows.append((role, sym, len(fsel), fk, wk, (2 * fk + wk) * 1024))
-    json.dump(out, open(a.out, "w"), indent=1)
-    md = ["| launch | kernel symbol | dispatches | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM bytes per launch = (2F + W) x 1024 |",
+    os.makedirs(a.outdir, exist_ok=True)
+    path = os.path.join(a.outdir, workload_key(a.config, a.beam, a.mode) + ".json")
+    json.dump(out, open(path, "w"), indent=1)
+    md = [f"### {workload_key(a.config, a.beam, a.mode)}", "",
+          "| launch | kernel symbol | dispatches | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM bytes per launch = (2F + W) x 1024 |",
           "|---|---|---:|---:|---:|---:|"]
     for role, sym, n, fk, wk, b in rows:
         md.append(f"| {role} | `{sym[:90]}` | {n} | {fk:.1f} | {wk:.1f} | {b / 1e6:.1f} MB |")
@@ -111,7 +147,8 @@ def main():
     text = "\n".join(md)
     print(text)
     if a.md:
-        open(a.md, "w").write(text + "\n")
+        with open(a.md, "a") as fh:
+            fh.write(text + "\n\n")
 
 
 if __name__ == "__main__":
