@@ -17,13 +17,23 @@ OUT = os.path.join(OUT_DIR, "libcvc_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 
+# forms that were measured and do not pay: only in a library built with CVC_EXPERIMENTAL=1
+EXPERIMENTAL_SOURCES = ("gemm_gsk.hip", "gemm_packed_ks.hip")
+
+
+def experimental() -> bool:
+    return os.environ.get("CVC_EXPERIMENTAL", "0") not in ("", "0")
+
+
 def sources():
-    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    return [f for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+            if experimental() or os.path.basename(f) not in EXPERIMENTAL_SOURCES]
 
 
 def deps():
+    inc = os.path.join(os.path.dirname(HERE), "include")
     return sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + \
-        [os.path.join(os.path.dirname(HERE), "include", "cvc_hip.h")]
+        [os.path.join(inc, h) for h in ("cvc_hip.h", "cvc_hip_blocks.h", "cvc_hip_experimental.h")]
 
 
 def source_hash() -> str:
@@ -41,7 +51,7 @@ STAMP = os.path.join(OUT_DIR, "libcvc_hip.flags")     # the extra hipcc flags th
 
 
 def extra_flags() -> str:
-    return " ".join(os.environ.get("CVC_EXTRA_HIPCC_FLAGS", "").split())
+    return " ".join(os.environ.get("CVC_EXTRA_HIPCC_FLAGS", "").split() + (["-DCVC_EXPERIMENTAL"] if experimental() else []))
 
 
 def up_to_date() -> bool:
@@ -67,14 +77,16 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in sources():
         obj = os.path.join(obj_dir, os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-c", src, "-o", obj]
-        cmd += os.environ.get("CVC_EXTRA_HIPCC_FLAGS", "").split()      # e.g. -DCVC_ABL=1 for ablation builds
+        # hidden visibility: the .so exports the CVC_API declarations of include/cvc_hip.h and nothing else
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-comment", "-c", src, "-o", obj]
+        cmd += extra_flags().split()      # e.g. -DCVC_ABL=1 for ablation builds, -DCVC_EXPERIMENTAL
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
+    objs = [o for o in objs if os.path.exists(o)]
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)

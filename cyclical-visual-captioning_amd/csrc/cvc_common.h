@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/cvc_hip.h"
+#include "../../include/cvc_hip_blocks.h"
+#include "../../include/cvc_hip_experimental.h"
 
 #define CVC_WAVE 64
 #define CVC_MIN_VALUE (-1e8f)   // model/modules.py:22,98

@@ -6,6 +6,8 @@
 #include <new>
 #include <stdint.h>
 #include "../../include/cvc_hip.h"
+#include "../../include/cvc_hip_blocks.h"
+#include "../../include/cvc_hip_experimental.h"
 
 // stream-K launch shapes of the packed path (include/cvc_hip.h, "Grouped stream-K form"): host arithmetic done once per plan
 struct gsk_launch {
@@ -79,10 +81,12 @@ int run_packed(cvc_decode_plan* p, hipStream_t st) {
         attn_sets(d, t, rows, sets);
         CVC_TRY(cvc_attn_scores_qparts(d.attn_kind, d.q_parts, d.qsplit, d.b_h, d.w_a, d.b_a, d.inv_temp, sets, 2, d.B, 1, A, st));
         CVC_TRY(cvc_attn_wsum_quad(sets, 2, d.B, 1, R, XL_r, st));
+#ifdef CVC_EXPERIMENTAL
         if (d.lang_ksx)      // K-split gate GEMM, every K slice of a tile finishing one of its blocks after the in-launch exchange
             CVC_TRY(cvc_packed_lstm_ksx_fwd((const float*)d.w_lang, XL_r, 3 * R, d.b_ih_lang, d.b_hh_lang, nullptr, nullptr, nullptr, d.cl[rd],
                                             rows, R, XA_w, quad_off(XL_w, 2 * R), d.cl[wr], d.ksx_slab, d.ksx_flags, (unsigned)(t + 1), st));
         else
+#endif
         CVC_TRY(cvc_packed_lstm_fwd((const float*)d.w_lang, XL_r, 3 * R, d.b_ih_lang, d.b_hh_lang, nullptr, d.cl[rd], rows, R, XA_w,
                                     quad_off(XL_w, 2 * R), d.cl[wr], st));
         CVC_TRY(cvc_packed_linear_fwd((const float*)d.w_o, XA_w, R, d.b_o, rows, V, 1, nullptr, V, d.top2_part, st));
@@ -127,9 +131,11 @@ int run_packed_eg(cvc_decode_plan* p, hipStream_t st) {
         if (first)           // (h_lang(-1) = 0 sits in the last third of XL: K = 2R of the 3R packed columns)
             CVC_TRY(cvc_packed_lstm_late_fwd((const float*)d.w_lang, ws_lang, XL_r, 2 * R, d.b_ih_lang, d.b_hh_lang, nullptr, d.cl[rd], rows,
                                              R, XA_w, quad_off(XL_w, 2 * R), d.cl[wr], nullptr, st));
+#ifdef CVC_EXPERIMENTAL
         else if (d.lang_ksx) // K-split gate GEMM, every K slice of a tile finishing one of its blocks after the in-launch exchange
             CVC_TRY(cvc_packed_lstm_ksx_fwd((const float*)d.w_lang, XL_r, 3 * R, d.b_ih_lang, d.b_hh_lang, nullptr, nullptr, nullptr, d.cl[rd],
                                             rows, R, XA_w, quad_off(XL_w, 2 * R), d.cl[wr], d.ksx_slab, d.ksx_flags, (unsigned)(t + 1), st));
+#endif
         else
         CVC_TRY(cvc_packed_lstm_fwd((const float*)d.w_lang, XL_r, 3 * R, d.b_ih_lang, d.b_hh_lang, nullptr, d.cl[rd], rows, R, XA_w,
                                     quad_off(XL_w, 2 * R), d.cl[wr], st));
@@ -141,6 +147,7 @@ int run_packed_eg(cvc_decode_plan* p, hipStream_t st) {
     return 0;
 }
 
+#ifdef CVC_EXPERIMENTAL
 // ---- packed path, grouped stream-K schedule (7 launches per step, every one of them chip-filling):
 //   att-late    : W_att[:, emb] x relu(Emb[word]) + partial tiles of (h_lang, h_att) from the previous step's launch 6 + hoisted fc
 //                 term, cell update -> h_att(t)
@@ -200,6 +207,8 @@ int run_packed_gsk(cvc_decode_plan* p, hipStream_t st) {
     p->launches = n;
     return 0;
 }
+
+#endif  // CVC_EXPERIMENTAL
 
 // ---- tile path: beam search or more than 64 rows (12 launches per step)
 int run_tile(cvc_decode_plan* p, hipStream_t st) {
@@ -272,6 +281,9 @@ int validate(const cvc_decode_desc& d) {
     if (!d.fc || !d.conv || !d.pconv || !d.pool || !d.ppool || !d.words || !d.att_steps || !d.embed || !d.b_o || !d.b_h) return CVC_E_BADARG;
     if (d.attn_kind == CVC_ATTN_ADDITIVE && !d.w_a) return CVC_E_BADARG;
     if (!d.w_att || !d.w_lang || !d.w_h || !d.w_o || !d.gate_fc || !d.scores_r || !d.scores_f || !d.attn_f || !d.q_parts) return CVC_E_BADARG;
+#ifndef CVC_EXPERIMENTAL
+    if (d.gsk_nwg > 0 || d.lang_ksx) return CVC_E_BADARG;     // schedules of cvc_hip_experimental.h: not in this build
+#endif
     if (d.path == 0) {
         if (d.beam != 1 || d.B > 64 || (d.R & 31) || (d.E & 31) || (d.A & 31) || d.qsplit < 1) return CVC_E_BADARG;
         if (!d.w_fc || !d.top2_part || !d.xa[0] || !d.xa[1] || !d.xl[0] || !d.xl[1] || !d.ca[0] || !d.ca[1] || !d.cl[0] || !d.cl[1] ||
@@ -302,6 +314,7 @@ extern "C" int cvc_decode_plan_create(const cvc_decode_desc* desc, cvc_decode_pl
     if (!p) return CVC_E_BADARG;
     p->d = *desc;
     p->launches = 0;
+#ifdef CVC_EXPERIMENTAL
     if (desc->path == 0 && desc->gsk_nwg > 0) {
         const int R = desc->R, nt_r = R / 64, nt_v = ((desc->V + 31) / 32 + 7) / 8, nt_a = (desc->A / 32 + 7) / 8;
         const int nta[2] = {nt_r, nt_v}, nca[2] = {2 * R / 32, R / 32};
@@ -311,6 +324,7 @@ extern "C" int cvc_decode_plan_create(const cvc_decode_desc* desc, cvc_decode_pl
         if (!rc) rc = cvc_gsk_plan(ntl, nca, 2, desc->gsk_nwg, &p->gl.U, p->gl.unit0, p->gl.maxseg);
         if (rc) { delete p; return rc; }
     }
+#endif
     *plan = p;
     return 0;
 }
@@ -330,7 +344,10 @@ extern "C" int cvc_decode_greedy(cvc_decode_plan* plan, cvc_stream_t stream) {
     if (!plan || plan->d.beam != 1) return CVC_E_BADARG;
     if (plan->d.path == 0) {
         if (plan->d.emb_gate != nullptr) return run_packed_eg(plan, (hipStream_t)stream);
-        return plan->d.gsk_nwg > 0 ? run_packed_gsk(plan, (hipStream_t)stream) : run_packed(plan, (hipStream_t)stream);
+#ifdef CVC_EXPERIMENTAL
+        if (plan->d.gsk_nwg > 0) return run_packed_gsk(plan, (hipStream_t)stream);
+#endif
+        return run_packed(plan, (hipStream_t)stream);
     }
     return run_tile(plan, (hipStream_t)stream);
 }

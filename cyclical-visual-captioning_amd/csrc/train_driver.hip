@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/cvc_hip.h"
+#include "../../include/cvc_hip_blocks.h"
+#include "../../include/cvc_hip_experimental.h"
 
 namespace {
 

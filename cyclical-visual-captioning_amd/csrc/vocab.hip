@@ -782,7 +782,11 @@ __global__ __launch_bounds__(WG) void gather_rows_kernel(const float* src, const
 
 }  // namespace
 
-extern "C" const char* cvc_version(void) { return "cvc_hip 0.1 gfx950"; }
+#ifdef CVC_EXPERIMENTAL
+extern "C" const char* cvc_version(void) { return "cvc_hip 0.2 gfx950 +experimental"; }
+#else
+extern "C" const char* cvc_version(void) { return "cvc_hip 0.2 gfx950"; }
+#endif
 
 static int embed_fwd_impl(const float* table, const int64_t* idx, const float* drop, DropSpec rng, int M, int E, float* out,
                           cvc_stream_t stream) {

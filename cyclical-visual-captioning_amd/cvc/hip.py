@@ -126,7 +126,6 @@ SIGNATURES = {
     "cvc_train_loop_bwd_ws": [_I, _I, _I],
     "cvc_train_loop_fwd": [C.POINTER(TrainLoop), _P],
     "cvc_train_loop_bwd": [C.POINTER(TrainLoop), _P],
-    "cvc_train_loop_launches": [C.POINTER(TrainLoop), _I],
     "cvc_train_loop_profile": [_I],
     "cvc_train_loop_profile_read": [C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), _I],
     "cvc_attn_fwd": [_I, _P, _P, _P, _F, C.POINTER(AttnSet), _I, _I, _I, _I, _I, _P, _P],
@@ -226,8 +225,30 @@ SIGNATURES = {
     "cvc_comm_destroy": [_P],
 }
 _VOID_RETURN = {"cvc_decode_plan_destroy"}
+# Building blocks (include/cvc_hip_blocks.h) and experimental forms (include/cvc_hip_experimental.h, only in a library built with
+# CVC_EXPERIMENTAL=1) are NOT exported: they are bound through cvc_block("name").  Everything else in SIGNATURES is the exported
+# drop-in ABI of include/cvc_hip.h.
+BLOCKS = {
+    "cvc_attn_scores", "cvc_attn_wsum", "cvc_attn_scores_qparts", "cvc_attn_wsum_quad", "cvc_attn_wsum_frag", "cvc_attn_wsum_quad_rm",
+    "cvc_attn_bwd_pair", "cvc_linear_splitk_fwd", "cvc_linear_top2_fwd", "cvc_top2_final", "cvc_packed_lstm_fwd", "cvc_packed_linear_fwd",
+    "cvc_packed_lstm_embgate_fwd", "cvc_packed_lstm_embgate_ex_fwd", "cvc_packed_lstm_late_fwd", "cvc_packed_lstm_train_fwd",
+    "cvc_packed_lstm_train_pre_fwd", "cvc_packed_lstm_train_drop_fwd", "cvc_lstm_pointwise_bwd", "cvc_lstm_pointwise_bwd3",
+    "cvc_lstm_pointwise_bwd3_drop", "cvc_pack_lstm_weights", "cvc_linear_nn_planes_fwd", "cvc_beam_select_parts", "cvc_tile_lstm_finish",
+    "cvc_tile_lstm_finish_embgate", "cvc_tile_reorder_pack", "cvc_decode_num_launches", "cvc_gemm_force_generic",
+    "cvc_tile_gemm_loaders", "cvc_gru_persistent_waves8"}
+EXPERIMENTAL = {
+    "cvc_gsk_plan", "cvc_gsk_gemm", "cvc_attn_scores_qslab", "cvc_top2_slab", "cvc_packed_lstm_ks_slices", "cvc_packed_lstm_ks_fwd",
+    "cvc_packed_lstm_ksf_fwd", "cvc_packed_lstm_ksx_local", "cvc_packed_lstm_ksx_fwd", "cvc_packed_lstm_wg_blocks",
+    "cvc_packed_linear_select_fwd", "cvc_gru_persistent_halves"}
 
 _lib = None
+
+
+def _missing(name):
+    def fn(*_a, **_k):
+        raise RuntimeError(f"{name} is an experimental form (include/cvc_hip_experimental.h): this libcvc_hip.so was built without "
+                           "CVC_EXPERIMENTAL=1 (`CVC_EXPERIMENTAL=1 python cyclical-visual-captioning_amd/build_hip.py --force`)")
+    return fn
 
 
 def lib() -> C.CDLL:
@@ -239,15 +260,31 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} is missing: build it with `python cyclical-visual-captioning_amd/build_hip.py` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the caption-decode hot path.")
         l = C.CDLL(LIB_PATH)
+        l.cvc_block.restype = C.c_void_p
+        l.cvc_block.argtypes = [C.c_char_p]
         for name, argtypes in SIGNATURES.items():
+            restype = None if name in _VOID_RETURN else (C.c_longlong if name == "cvc_train_loop_bwd_ws" else C.c_int)
+            if name in BLOCKS or name in EXPERIMENTAL:
+                addr = l.cvc_block(name.encode())
+                if not addr:
+                    if name in BLOCKS:
+                        raise RuntimeError(f"{LIB_PATH}: building block {name} is not in the library's table (stale build?)")
+                    setattr(l, name, _missing(name))
+                    continue
+                setattr(l, name, C.CFUNCTYPE(restype, *argtypes)(addr))
+                continue
             fn = getattr(l, name)
             fn.argtypes = argtypes
-            fn.restype = None if name in _VOID_RETURN else C.c_int
+            fn.restype = restype
         l.cvc_version.restype = C.c_char_p
-        l.cvc_train_loop_bwd_ws.restype = C.c_longlong
         l.cvc_version.argtypes = []
         _lib = l
     return _lib
+
+
+def experimental_built() -> bool:
+    """was the loaded library built with CVC_EXPERIMENTAL=1?"""
+    return b"+experimental" in lib().cvc_version()
 
 
 def version() -> str:

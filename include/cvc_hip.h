@@ -26,6 +26,13 @@ extern "C" {
 
 typedef void* cvc_stream_t; /* hipStream_t */
 
+/* The library is built with hidden visibility: only what this header declares CVC_API is exported (the drop-in ABI: what a
+ * reference maintainer's stub binds, plus everything the host mirror's default path calls).  The per-kernel BUILDING BLOCKS the
+ * whole-decode / whole-loop drivers are composed of are declared in cvc_hip_blocks.h: not exported, reachable for unit tests and
+ * the host mirror's eager launch lists through cvc_block("name").  Forms that were measured and do not pay (kept selectable for
+ * experiments) are in cvc_hip_experimental.h and only exist in a build made with CVC_EXPERIMENTAL=1. */
+#define CVC_API __attribute__((visibility("default")))
+
 #define CVC_E_BADARG (-1)   /* a size/alignment precondition is violated            */
 #define CVC_E_TOOBIG (-2)   /* a dimension exceeds what the kernel templates cover  */
 #define CVC_E_NORCCL (-3)   /* librccl.so could not be opened (cvc_comm_* / cvc_allreduce_grads only) */
@@ -33,8 +40,10 @@ typedef void* cvc_stream_t; /* hipStream_t */
 #define CVC_ATTN_ADDITIVE 0 /* model/modules.py:100-159 AdditiveSoftAttention.forward */
 #define CVC_ATTN_DOT 1      /* model/modules.py:24-76   SoftAttention.forward         */
 
-/* library / build info: returns a static string "cvc_hip <version> gfx950" */
-const char* cvc_version(void);
+/* library / build info: returns a static string "cvc_hip <version> gfx950[ +experimental]" */
+CVC_API const char* cvc_version(void);
+/* address of a building block (cvc_hip_blocks.h; with CVC_EXPERIMENTAL=1 also of cvc_hip_experimental.h) by name, or NULL */
+CVC_API void* cvc_block(const char* name);
 
 /* ---------------------------------------------------------------------------------------
  * Attention over one or two feature sets that share the query (regions + frames,
@@ -65,26 +74,17 @@ typedef struct {
  * (no temperature, modules.py:120); kind DOT: s = (proj_n . q) * inv_temp (modules.py:34-37).
  * ctx_sum [rows, R] (nullable) receives the sum of the sets' contexts
  * (weighted_pool_feat + attn_conv, decoder_core.py:59).  Requires A % 4 == 0, R % 4 == 0. */
-int cvc_attn_fwd(int kind, const float* q, const float* w_a, const float* b_a, float inv_temp,
+CVC_API int cvc_attn_fwd(int kind, const float* q, const float* w_a, const float* b_a, float inv_temp,
                  const cvc_attn_set* sets, int nsets, int nclip, int nq, int A, int R,
                  float* ctx_sum, cvc_stream_t stream);
 
 /* The two passes of cvc_attn_fwd as separate entry points (cvc_attn_fwd == scores then wsum):
  * pass 1 streams proj [nclip,n,A] once and writes sets[].scores / frame_masked;
  * pass 2 softmaxes sets[].scores into sets[].attn and streams ctx [nclip,n,R] once. */
-int cvc_attn_scores(int kind, const float* q, const float* w_a, const float* b_a, float inv_temp,
-                    const cvc_attn_set* sets, int nsets, int nclip, int nq, int A, cvc_stream_t stream);
-int cvc_attn_wsum(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum,
-                  cvc_stream_t stream);
 /* Pass 2 writing the summed context in the packed-GEMM activation layout [R/4][64][4] (rows <= 64) */
-int cvc_attn_wsum_quad(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum_q,
-                       cvc_stream_t stream);
 /* Pass 1 with the query given as q_nparts partial sums [q_nparts][rows, A] of a split-K h2attn GEMM
  * (cvc_linear_splitk_fwd) plus its bias q_bias [A] (nullable): the partials are summed while the
  * query is loaded into LDS, so the small query GEMM can spread over the whole chip. */
-int cvc_attn_scores_qparts(int kind, const float* q_parts, int q_nparts, const float* q_bias, const float* w_a,
-                           const float* b_a, float inv_temp, const cvc_attn_set* sets, int nsets, int nclip,
-                           int nq, int A, cvc_stream_t stream);
 
 /* Backward of cvc_attn_fwd for ONE set, scores recomputed from proj (nothing but attn is
  * saved).  Inputs: d_ctx [rows,R] (nullable), d_fm [rows,n] gradient of the frame_masked
@@ -92,7 +92,7 @@ int cvc_attn_scores_qparts(int kind, const float* q_parts, int q_nparts, const f
  * is d_b_alpha); d_q [rows,A] (overwritten); d_w_part [rows,A] per-row partials of d_w_alpha
  * (additive only, nullable; the caller sums over rows -- keeps the reduction ordered);
  * d_proj [nclip,n,A] / d_ctxfeat [nclip,n,R] (ACCUMULATED into: caller zero-fills; nullable). */
-int cvc_attn_bwd(int kind, const float* q, const float* w_a, float inv_temp,
+CVC_API int cvc_attn_bwd(int kind, const float* q, const float* w_a, float inv_temp,
                  const float* proj, const float* ctx, const float* attn,
                  const float* d_ctx, const float* d_fm,
                  int nclip, int nq, int n, int A, int R,
@@ -115,14 +115,12 @@ typedef struct {
 } cvc_gemm_seg;
 
 /* y[M, Nout] (ld ldy) = concat-GEMM + bias[Nout] (nullable) + bias2[Nout] (nullable) */
-int cvc_linear_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, const float* bias2,
+CVC_API int cvc_linear_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, const float* bias2,
                    int M, int Nout, float* y, int ldy, cvc_stream_t stream);
 
 /* Split-K variant for small Nout (h2attn: Nout = A): K slice s of every segment writes its partial
  * product to y_parts + s * M * Nout (slice 0 carries the bias); the consumer sums the slices.
  * M <= 64, no gather segments. */
-int cvc_linear_splitk_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, int M, int Nout,
-                          int ksplit, float* y_parts, cvc_stream_t stream);
 
 /* Vocabulary projection with the word-selection partials fused into the epilogue
  * (captioner.py:437 + :415-422): every 32-column block writes, per row, {top-1 value, index, top-2
@@ -130,11 +128,6 @@ int cvc_linear_splitk_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias
  * logits only if asked.  cvc_top2_final merges the partials: UNK rule, word (int64, strided),
  * log-prob (nullable), and optionally next step's embedded word emb_out[row,:E] =
  * relu(table[word]) (captioner.py:424; emb_ld == 0 selects the quad layout [E/4][64][4]).  M <= 64. */
-int cvc_linear_top2_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, int M, int Nout,
-                        float* y_or_null, float* top2_part, cvc_stream_t stream);
-int cvc_top2_final(const float* part, int nblocks, int M, int unk_idx, int64_t* word, int word_stride,
-                   float* logprob, const float* table, int E, float* emb_out, int emb_ld,
-                   cvc_stream_t stream);
 
 /* Packed path of the decode engine: both operands stored MFMA-fragment-native so that waves load
  * them straight into registers (no LDS) and keep CVC_PACKED_DEPTH x 4 KB of weights in flight each.
@@ -147,41 +140,25 @@ int cvc_top2_final(const float* part, int nblocks, int M, int unk_idx, int64_t* 
  * K % 32 == 0, M <= 64.  LSTM: cell state c in quad layout [R/4][64][4]; h' goes to up to two quad
  * destinations (the next consumers' K ranges).  Linear: y row-major (split-K slices at stride
  * M*ldy, bias in slice 0) and/or the fused word-selection partials (see cvc_linear_top2_fwd). */
-int cvc_packed_lstm_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
-                        const float* gate_bias, const float* c_prev_q, int M, int R, float* h_dst1_q,
-                        float* h_dst2_q, float* c_out_q, cvc_stream_t stream);
-int cvc_packed_linear_fwd(const float* wp, const float* xq, int K, const float* bias, int M, int Nout,
-                          int ksplit, float* y, int ldy, float* top2_part, cvc_stream_t stream);
 /* Embedding-gate table form of the att-LSTM (decoder_core.py:45-50 with xt = relu(Emb[word]), captioner.py:53-68 in eval mode):
  * the embedded word's share of the gates, W_ih[:, emb columns] x relu(Emb[v]), depends on the word alone, so it is tabulated once
  * per checkpoint -- emb_gate [V][4R] fp32, gates in checkpoint order (gate * R + unit; cvc.decode.embgate_table) -- and the
  * step adds row word[m] in the epilogue: wp / xq then cover only the recurrent inputs (K = 2R: h_lang, h_att), 20 % fewer weight
  * bytes per step, and the gate GEMM no longer waits for the word.  Otherwise cvc_packed_lstm_fwd. */
-int cvc_packed_lstm_embgate_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
-                                const float* gate_bias, const float* emb_gate, const int64_t* word, const float* c_prev_q,
-                                int M, int R, float* h_dst1_q, float* h_dst2_q, float* c_out_q, cvc_stream_t stream);
 /* ... the general form.  w_cached != 0: the gate weights are read under the default cache policy (a gate matrix the caller's cache
  * plan keeps in the Infinity Cache between steps) instead of streamed non-temporally.  w_blk_stride / K: the contraction may stop
  * short of the packed matrix's K (K a multiple of 32; w_blk_stride = floats between its 32-row blocks, 0 = dense): the first
  * decode step multiplies an all-zero recurrent state, which adds nothing -- the decode driver passes K = 32 there.
  * Same results as cvc_packed_lstm_embgate_fwd over the same K. */
-int cvc_packed_lstm_embgate_ex_fwd(const float* wp, long long w_blk_stride, const float* xq, int K, const float* b_ih,
-                                   const float* b_hh, const float* gate_bias, const float* emb_gate, const int64_t* word,
-                                   const float* c_prev_q, int M, int R, float* h_dst1_q, float* h_dst2_q,
-                                   float* c_out_q, int w_cached, cvc_stream_t stream);
 /* Vocabulary projection + word selection in ONE launch (captioner.py:437 + :415-422): cvc_packed_linear_fwd's top-2 records
  * (top2_part [ceil(Nout/32)][64][6], stored write-through) are merged by the last workgroup to arrive -- counter: one word of
  * device memory, zero before the first use, left zero -- which writes word[m * word_stride] (UNK rule, ties -> lowest index) and
  * logprob[m] (nullable).  Same results as cvc_packed_linear_fwd + cvc_top2_final; measured SLOWER than the two launches at
  * config 2 (34.9 vs 20.0 + 7.4 us: arrival atomics, the acquire fence and a serial merge on one CU cost more than a launch
  * boundary), so the decode drivers do not use it.  Kept as a tested entry point. */
-int cvc_packed_linear_select_fwd(const float* wp, const float* xq, int K, const float* bias, int M, int Nout,
-                                 float* top2_part, unsigned* counter, int unk_idx, int64_t* word, int word_stride,
-                                 float* logprob, cvc_stream_t stream);
 /* A/B + test hook: 32-row weight blocks per workgroup of cvc_packed_lstm_fwd (1 = default; 2: two blocks share every
  * activation line through the CU's L1 -- halves the L2 reads, measured 60 % slower because half the CUs then do all the
  * operand splitting; same results up to the fp32 summation order over K).  Returns the previous setting; n < 1 only queries. */
-int cvc_packed_lstm_wg_blocks(int n);
 
 /* Training form of cvc_packed_lstm_fwd (nn.LSTMCell forward under autograd, decoder_core.py:45-50, 59-61): the same GEMM
  * kernel with row-major state -- c_prev / h_out / c_out [M, R] and the activated gates [M, 4R] (i, f, g, o; nullable) that
@@ -190,12 +167,7 @@ int cvc_packed_lstm_wg_blocks(int n);
  *                           (once per optimizer step; K_ih, K_hh % 4 == 0, K % 32 == 0, R % 8 == 0);
  *   cvc_pack_quad_segs    : up to 6 row-major segments [M <= 64, width_s] (the virtual concat of the cell's inputs followed
  *                           by h_prev; widths % 4 == 0, 16-byte aligned) -> xq [K/4][64][4], rows beyond M zero. */
-int cvc_packed_lstm_train_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
-                              const float* c_prev, int M, int R, float* h_out, float* c_out, float* gates_out,
-                              float* h_out2, float* h_out3, cvc_stream_t stream);   /* h_out2/3: further copies of h', nullable */
-int cvc_pack_lstm_weights(const float* w_ih, int K_ih, const float* w_hh, int K_hh, int R, float* wp,
-                          cvc_stream_t stream);
-int cvc_pack_quad_segs(const float* const* xs, const long long* ldx, const int* widths, int nseg, int M, float* xq,
+CVC_API int cvc_pack_quad_segs(const float* const* xs, const long long* ldx, const int* widths, int nseg, int M, float* xq,
                        cvc_stream_t stream);
 /* Hoisted form of the training cell: input segments whose values are known for all T steps before the loop (the embedded
  * teacher-forced words, fc_feats, the localized context of the reconstruction loop) are multiplied ONCE for all T * B rows (a dense
@@ -204,17 +176,10 @@ int cvc_pack_quad_segs(const float* const* xs, const long long* ldx, const int* 
  *                        weights -> wp over K = sum width_s (the recurrent ranges of weight_ih, then weight_hh);
  *   cvc_packed_lstm_train_pre_fwd : cvc_packed_lstm_train_fwd + gate_pre [M, 4R] (row-major, checkpoint gate order), the hoisted
  *                        ranges' contribution to this step's pre-activations. */
-int cvc_pack_lstm_segs(const float* const* ws, const long long* lds, const int* widths, int nseg, int R, float* wp,
+CVC_API int cvc_pack_lstm_segs(const float* const* ws, const long long* lds, const int* widths, int nseg, int R, float* wp,
                        cvc_stream_t stream);
-int cvc_packed_lstm_train_pre_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
-                                  const float* gate_pre, const float* c_prev, int M, int R, float* h_out, float* c_out,
-                                  float* gates_out, float* h_out2, float* h_out3, cvc_stream_t stream);
 /* ... with output = nn.Dropout(h') (decoder_core.py:62, 109) fused: h_drop_out [M, R] receives h' times the counter-based
  * keep-mask of element m * R + j (see cvc_dropout_rng); gate_pre nullable; h_out / h_out2 are the plain copies of h'. */
-int cvc_packed_lstm_train_drop_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
-                                   const float* gate_pre, const float* c_prev, int M, int R, float* h_out, float* c_out,
-                                   float* gates_out, float* h_out2, float* h_drop_out, const uint32_t* rng_state,
-                                   unsigned site, float p, cvc_stream_t stream);
 
 /* GRU over a whole sequence, one or both directions: the recurrent half of nn.GRU(batch_first, h0 = 0) as the encoder's frame
  * context uses it (backbone.py:103-106, 335-338; gate order r, z, n; n = tanh(W_in x + b_in + r * (W_hn h + b_hn)),
@@ -226,7 +191,7 @@ int cvc_packed_lstm_train_drop_fwd(const float* wp, const float* xq, int K, cons
  *   b_ih, b_hh : [ndir][3H];  hq : workspace of 2 * ndir * Kp * 64 floats (the two parities of the state, quad layout);
  *   y  : h_t of direction d at y + m * y_ld_m + t * y_ld_t + d * H.
  * M <= 64 clips, H % 8 == 0, strides multiples of 4 floats. */
-int cvc_gru_seq_fwd(const float* wp, const float* gi, long long gi_ld_m, long long gi_ld_t, const float* b_ih,
+CVC_API int cvc_gru_seq_fwd(const float* wp, const float* gi, long long gi_ld_m, long long gi_ld_t, const float* b_ih,
                     const float* b_hh, int M, int F, int H, int ndir, float* hq, float* y, long long y_ld_m,
                     long long y_ld_t, cvc_stream_t stream);
 /* Persistent form (csrc/gru_persistent.hip): same operands and results from ONE cooperative launch -- every workgroup keeps its
@@ -236,10 +201,10 @@ int cvc_gru_seq_fwd(const float* wp, const float* gi, long long gi_ld_m, long lo
  * words of device memory (arrival counters spread over memory channels); word 4 is non-zero afterwards when the (bounded) barrier wait timed out: the outputs are then
  * invalid and the caller repeats the sequence with cvc_gru_seq_fwd.  Returns CVC_E_BADARG without launching for shapes
  * outside its range (H % 128 != 0, H > 1024, or more workgroups than the device keeps resident at once). */
-int cvc_gru_persistent_sync_words(void);
+CVC_API int cvc_gru_persistent_sync_words(void);
 /* Training form of the persistent recurrence: additionally writes, for every step and direction, what autograd needs --
  * (r, z, n, W_hn h + b_hn) at gates + m * g_ld_m + t * g_ld_t + d * 4H + {0, H, 2H, 3H}. */
-int cvc_gru_seq_persistent_train_fwd(const float* wp, const float* gi, long long gi_ld_m, long long gi_ld_t,
+CVC_API int cvc_gru_seq_persistent_train_fwd(const float* wp, const float* gi, long long gi_ld_m, long long gi_ld_t,
                                      const float* b_ih, const float* b_hh, int M, int F, int H, int ndir, float* hq,
                                      float* y, long long y_ld_m, long long y_ld_t, float* gates, long long g_ld_m,
                                      long long g_ld_t, unsigned* sync, cvc_stream_t stream);
@@ -254,18 +219,16 @@ int cvc_gru_seq_persistent_train_fwd(const float* wp, const float* gi, long long
  * (cvc.gru.pack_gru_weights_t), slots = F * ndir * 3H * 64 floats, sync = cvc_gru_bwd_persistent_sync_words() words (word 4
  * non-zero afterwards = barrier time-out: outputs invalid, repeat with cvc_gru_seq_bwd).  H % 256 == 0, H <= 1024, M <= 64;
  * CVC_E_BADARG without launching otherwise. */
-int cvc_gru_bwd_persistent_sync_words(void);
-int cvc_gru_seq_bwd_persistent(const float* dy, long long dy_ld_m, long long dy_ld_t, const float* gates, long long g_ld_m,
+CVC_API int cvc_gru_bwd_persistent_sync_words(void);
+CVC_API int cvc_gru_seq_bwd_persistent(const float* dy, long long dy_ld_m, long long dy_ld_t, const float* gates, long long g_ld_m,
                                long long g_ld_t, const float* y, long long y_ld_m, long long y_ld_t, const float* wt,
                                int M, int F, int H, int ndir, float* dgi, float* dgh, float* slots, unsigned* sync,
                                cvc_stream_t stream);
-int cvc_gru_seq_bwd_ksplit(int H);
-int cvc_gru_seq_bwd(const float* dy, long long dy_ld_m, long long dy_ld_t, const float* gates, long long g_ld_m,
+CVC_API int cvc_gru_seq_bwd_ksplit(int H);
+CVC_API int cvc_gru_seq_bwd(const float* dy, long long dy_ld_m, long long dy_ld_t, const float* gates, long long g_ld_m,
                     long long g_ld_t, const float* y, long long y_ld_m, long long y_ld_t, const float* w_hh, int M,
                     int F, int H, int ndir, float* dgi, float* dgh, float* work, cvc_stream_t stream);
-int cvc_gru_persistent_waves8(int on);   /* A/B + test hook: 1 (default) = 8 waves per workgroup where H % 256 == 0, 0 = always 4 */
-int cvc_gru_persistent_halves(int on);   /* A/B + test hook: 1 = more than 32 clips run as two interleaved 32-clip recurrences (measured slower), 0 = default */
-int cvc_gru_seq_persistent_fwd(const float* wp, const float* gi, long long gi_ld_m, long long gi_ld_t,
+CVC_API int cvc_gru_seq_persistent_fwd(const float* wp, const float* gi, long long gi_ld_m, long long gi_ld_t,
                                const float* b_ih, const float* b_hh, int M, int F, int H, int ndir, float* hq,
                                float* y, long long y_ld_m, long long y_ld_t, unsigned* sync, cvc_stream_t stream);
 
@@ -277,17 +240,10 @@ int cvc_gru_seq_persistent_fwd(const float* wp, const float* gi, long long gi_ld
  * apart than dense keeps the 8 waves of a workgroup, which stream the same chunk index of 8 different blocks, off the same
  * HBM channels.
  * cvc_packed_lstm_ks_slices returns 0 when the shape is not covered (R % 64 != 0): use cvc_packed_lstm_fwd then. */
-int cvc_packed_lstm_ks_slices(int K, int R);
-int cvc_packed_lstm_ks_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
-                           const float* gate_bias, const float* c_prev_q, int M, int R, float* h_dst1_q,
-                           float* h_dst2_q, float* c_out_q, float* slab, long long w_blk_stride, cvc_stream_t stream);
 /* The same with the finish fused into the GEMM launch: partial tiles are stored write-through, the K slices of a 256-row tile
  * count their arrivals in counters[tile] and the LAST one sums the tile's slabs in slice order and does the cell update
  * (deterministic: the order of the sum does not depend on who arrives last).  counters: R / 64 words of device memory, zero
  * before the first use; every launch leaves them zero.  Dense weight pack (no block stagger). */
-int cvc_packed_lstm_ksf_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
-                            const float* gate_bias, const float* c_prev_q, int M, int R, float* h_dst1_q,
-                            float* h_dst2_q, float* c_out_q, float* slab, unsigned* counters, cvc_stream_t stream);
 /* ... with the finish shared by ALL K slices of a tile (exchange finish): slice ks of a 256-row tile finishes the tile's block ks
  * once the tile's 8 partial tiles are out (write-through slab rows + one arrival word per slice, system-scope loads on the
  * reading side: correct wherever the workgroups run; tiles are placed on one XCD for speed only).  One launch, no finishing
@@ -295,11 +251,6 @@ int cvc_packed_lstm_ksf_fwd(const float* wp, const float* xq, int K, const float
  * [R / 8], set to 1 by a slice whose bounded wait ran out); seq: non-zero and different from the previous launch's on these
  * flags; emb_gate / word: the embedding-gate form (cvc_packed_lstm_embgate_fwd), nullable.  R = 2048 (8 slices, 256 workgroups
  * of 512 threads, all resident together). */
-int cvc_packed_lstm_ksx_local(int on);   /* 1 (default): XCD-local exchange, XCC_ID-checked; 0: system-scope exchange; < 0 queries */
-int cvc_packed_lstm_ksx_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
-                            const float* gate_bias, const float* emb_gate, const int64_t* word, const float* c_prev_q,
-                            int M, int R, float* h_dst1_q, float* h_dst2_q, float* c_out_q, float* slab,
-                            unsigned* flags, unsigned seq, cvc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Grouped stream-K form of the decode step's skinny GEMMs (csrc/gemm_gsk.hip).  The gate GEMM of an LSTM cell
@@ -333,34 +284,22 @@ typedef struct cvc_gsk_segs { /* what a consumer needs to find and sum one group
 } cvc_gsk_segs;
 /* Host arithmetic of a launch: ntile[g] tiles of nchunk[g] chunks each -> U (units per workgroup for at most nwg workgroups;
  * nwg <= 0: one per CU of the current device), unit0[g] and the segments per tile maxseg[g] the slabs must hold. */
-int cvc_gsk_plan(const int* ntile, const int* nchunk, int ngroups, int nwg, int* U, int* unit0, int* maxseg);
-int cvc_gsk_gemm(const cvc_gsk_group* groups, int ngroups, int U, cvc_stream_t stream);   /* ngroups <= 3, M <= 64 rows */
 /* LATE part of a cell + finish: gates = wp[:, K range] x xq (full-K packed kernel, K % 32 == 0) + the early part's partial tiles
  * (`early` nullable: none, e.g. step 0 from the zero state) + biases; cell update as cvc_packed_lstm_fwd. */
-int cvc_packed_lstm_late_fwd(const float* wp, long long w_blk_stride, const float* xq, int K, const float* b_ih,
-                             const float* b_hh, const float* gate_bias, const float* c_prev_q, int M, int R,
-                             float* h_dst1_q, float* h_dst2_q, float* c_out_q, const cvc_gsk_segs* early,
-                             cvc_stream_t stream);
 /* cvc_attn_scores_qparts with the query given as the partial tiles of a stream-K h2attn group (A / 32 blocks) */
-int cvc_attn_scores_qslab(int kind, const cvc_gsk_segs* q, const float* q_bias, const float* w_a, const float* b_a,
-                          float inv_temp, const cvc_attn_set* sets, int nsets, int nclip, int nq, int A,
-                          cvc_stream_t stream);
 /* cvc_top2_final with the logits given as the partial tiles of a stream-K vocabulary group (ceil(V/32) blocks) + bias [V]:
  * sums the segments, top-2 with the UNK rule, log-prob, next step's embedded word (captioner.py:415-424, 437).  M <= 64. */
-int cvc_top2_slab(const cvc_gsk_segs* logits, const float* bias, int V, int M, int unk_idx, int64_t* word, int word_stride,
-                  float* logprob, const float* table, int E, float* emb_out, int emb_ld, cvc_stream_t stream);
 
 /* Packed path arithmetic.  mode 2 (default) / 1: every fp32 operand is split exactly into three bf16 terms
  * (v = hi + mid + lo) and each product taken as its six leading cross terms on the bf16 MFMA, fp32
  * accumulate -- the dropped terms are < 2^-23 relative, the level of one fp32 rounding (measured error
  * against fp64 is slightly BELOW the fp32-MFMA path's); 8 (mode 2) or 4 (mode 1) waves per workgroup.
  * mode 0: plain fp32 MFMA.  A negative mode only queries.  Returns the previous mode. */
-int cvc_gemm_packed_split(int mode);
+CVC_API int cvc_gemm_packed_split(int mode);
 
 /* Test hook: route every concat-GEMM to the generic direct-load kernel (on != 0) instead of the
  * LDS-DMA fast path that is taken when all segment widths are multiples of 128.  Returns the
  * previous setting.  Both kernels compute the same sums in different k-orders. */
-int cvc_gemm_force_generic(int on);
 
 /* nn.LSTMCell (gate order i,f,g,o; decoder_core.py:14,27,50,61): gates = concat-GEMM with
  * Nout = 4R + b_ih + b_hh; c' = sig(f) c + sig(i) tanh(g); h' = sig(o) tanh(c').
@@ -369,7 +308,7 @@ int cvc_gemm_force_generic(int on);
  * [M, 4R] (nullable) is a per-row additive pre-activation term: the decode loop hoists the
  * step-invariant part of the gate GEMM (fc_feats x W_ih[:, R:2R] + biases, decoder_core.py:46)
  * out of the T loop and passes it here.  Requires R % 8 == 0. */
-int cvc_lstm_cell_fwd(const cvc_gemm_seg* segs, int nsegs, const float* b_ih, const float* b_hh,
+CVC_API int cvc_lstm_cell_fwd(const cvc_gemm_seg* segs, int nsegs, const float* b_ih, const float* b_hh,
                       const float* gate_bias, const float* c_prev, int M, int R, float* h_out,
                       float* c_out, float* gates_out, cvc_stream_t stream);
 
@@ -377,19 +316,9 @@ int cvc_lstm_cell_fwd(const cvc_gemm_seg* segs, int nsegs, const float* b_ih, co
  * c_prev, c_new -> d_gates [M,4R] (pre-activation) and d_c_prev [M,R].  d_gates_q (nullable)
  * receives a second copy of d_gates in the quad layout [4R/4][64][4] that cvc_linear_nn_fwd reads
  * (M <= 64, R % 4 == 0 when given). */
-int cvc_lstm_pointwise_bwd(const float* d_h, const float* d_c, const float* gates,
-                           const float* c_prev, const float* c_new, int M, int R,
-                           float* d_gates, float* d_c_prev, float* d_gates_q, cvc_stream_t stream);
 /* the same with the gradients of up to three copies of h' (h has several consumers per step -- the other cell, the attention
  * query, the next step -- and a copy per consumer leaves autograd nothing to accumulate: 160 small launches per training step) */
-int cvc_lstm_pointwise_bwd3(const float* d_h, const float* d_h2, const float* d_h3, const float* d_c,
-                            const float* gates, const float* c_prev, const float* c_new, int M, int R,
-                            float* d_gates, float* d_c_prev, float* d_gates_q, cvc_stream_t stream);
 /* ... where the third copy left the cell through the fused dropout of cvc_packed_lstm_train_drop_fwd: d_h3 takes that mask */
-int cvc_lstm_pointwise_bwd3_drop(const float* d_h, const float* d_h2, const float* d_h3, const uint32_t* rng_state,
-                                 unsigned site, float p, const float* d_c, const float* gates, const float* c_prev,
-                                 const float* c_new, int M, int R, float* d_gates, float* d_c_prev, float* d_gates_q,
-                                 cvc_stream_t stream);
 
 /* Backward-data product of the skinny layers, autograd of nn.LSTMCell / nn.Linear
  * (decoder_core.py:45-50, 59-61, 99-108):  dst_s[M, ncols_s] = dY[M, K] x W_s[K, ncols_s]  for up to 6
@@ -402,20 +331,18 @@ typedef struct cvc_nn_seg {
     float* dst;          /* [M, ld_dst] */
     int ldw, ncols, ld_dst;
 } cvc_nn_seg;
-int cvc_linear_nn_fwd(const float* dy_q, int K, int M, const cvc_nn_seg* segs, int nsegs, int ksplit,
+CVC_API int cvc_linear_nn_fwd(const float* dy_q, int K, int M, const cvc_nn_seg* segs, int nsegs, int ksplit,
                       float* workspace, cvc_stream_t stream);
 /* the same without the summing launch: for ksplit > 1 the K-slice planes [ksplit][M][ntot] stay in `workspace` for a consumer
  * that sums them itself (ntot = sum_s ceil(ncols_s / 128) * 128) */
-int cvc_linear_nn_planes_fwd(const float* dy_q, int K, int M, const cvc_nn_seg* segs, int nsegs, int ksplit,
-                             float* workspace, cvc_stream_t stream);
 /* x [M <= 64, K] row-major (leading dim ldx) -> the quad layout [K/4][64][4] cvc_linear_nn_fwd reads (rows beyond M zero) */
-int cvc_pack_quad(const float* x, long long ldx, int M, int K, float* xq, cvc_stream_t stream);
+CVC_API int cvc_pack_quad(const float* x, long long ldx, int M, int K, float* xq, cvc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Word embedding and vocabulary head (captioner.py:53-68, 72-76, 266, 415-422).
  */
 /* out[m, :] = relu(table[idx[m], :]) * (drop ? drop[m, :] : 1) */
-int cvc_embed_relu_fwd(const float* table, const int64_t* idx, const float* drop, int M, int E,
+CVC_API int cvc_embed_relu_fwd(const float* table, const int64_t* idx, const float* drop, int M, int E,
                        float* out, cvc_stream_t stream);
 /* d_table[w, :] = (table[w, :] > 0) * sum_{m: idx[m] == w} drop[m, :] * d_out[m, :] for every word w that
  * occurs; no atomics and no host round trip: `order` [M] is a stable argsort of idx, so the rows of a word
@@ -423,7 +350,7 @@ int cvc_embed_relu_fwd(const float* table, const int64_t* idx, const float* drop
  * word), so a word that owns many rows (BOS / padding) does not serialise.  workspace: M * E floats.
  * The rows of the words that occur are ACCUMULATED into d_table (the caller zero-fills for a fresh gradient; several lookups of one
  * table -- the three embeddings of a cyclical pass -- add up in one buffer, call after call); other rows are left untouched. */
-int cvc_embed_relu_bwd(const float* table, const int64_t* idx, const int64_t* order, const float* drop,
+CVC_API int cvc_embed_relu_bwd(const float* table, const int64_t* idx, const int64_t* order, const float* drop,
                        const float* d_out, int M, int E, float* d_table, float* workspace,
                        cvc_stream_t stream);
 
@@ -436,33 +363,33 @@ int cvc_embed_relu_bwd(const float* table, const int64_t* idx, const int64_t* or
  *   cvc_embed_relu_rng_fwd / _bwd : cvc_embed_relu_fwd / _bwd with the mask of element (m, e) at flat index m * E + e;
  *   cvc_dropout_rng               : y[i] = x[i] * multiplier(i), n elements (16-byte aligned), for sites no producer fuses
  *                                   (its own backward: the same call on the gradient). */
-int cvc_embed_relu_rng_fwd(const float* table, const int64_t* idx, const uint32_t* rng_state, unsigned site, float p, int M,
+CVC_API int cvc_embed_relu_rng_fwd(const float* table, const int64_t* idx, const uint32_t* rng_state, unsigned site, float p, int M,
                            int E, float* out, cvc_stream_t stream);
-int cvc_embed_relu_rng_bwd(const float* table, const int64_t* idx, const int64_t* order, const uint32_t* rng_state,
+CVC_API int cvc_embed_relu_rng_bwd(const float* table, const int64_t* idx, const int64_t* order, const uint32_t* rng_state,
                            unsigned site, float p, const float* d_out, int M, int E, float* d_table, float* workspace,
                            cvc_stream_t stream);
-int cvc_dropout_rng(const float* x, long long n, const uint32_t* rng_state, unsigned site, float p, float* y,
+CVC_API int cvc_dropout_rng(const float* x, long long n, const uint32_t* rng_state, unsigned site, float p, float* y,
                     cvc_stream_t stream);
 
 /* In-place-capable row log-softmax: logp[m, :] = logits[m, :] - logsumexp(logits[m, :]) */
-int cvc_log_softmax_fwd(const float* logits, int M, int V, float* logp, cvc_stream_t stream);
+CVC_API int cvc_log_softmax_fwd(const float* logits, int M, int V, float* logp, cvc_stream_t stream);
 
 /* d_logits = d_logp - exp(logp) * rowsum(d_logp) */
-int cvc_log_softmax_bwd(const float* logp, const float* d_logp, int M, int V, float* d_logits,
+CVC_API int cvc_log_softmax_bwd(const float* logp, const float* d_logp, int M, int V, float* d_logits,
                         cvc_stream_t stream);
 
 /* Greedy word selection with UNK suppression (captioner.py:415-422): per row the top-2 of
  * logits; pick #2 iff #1 == unk_idx; ties -> lowest index.  word[m*word_stride] (int64),
  * logprob[m] = logit - logsumexp (nullable). */
-int cvc_top2_unk(const float* logits, int M, int V, int unk_idx, int64_t* word, int word_stride,
+CVC_API int cvc_top2_unk(const float* logits, int M, int V, int unk_idx, int64_t* word, int word_stride,
                  float* logprob, cvc_stream_t stream);
 
 /* Masked NLL over a [M, V] log-prob matrix (misc/utils.py:132-146, 181-192), the module-level
  * criterion API that receives log-probs:  loss_sum[0] += sum_m w[m] * -logp[m, target[m]]. */
-int cvc_nll_fwd(const float* logp, const int64_t* target, const float* w, int M, int V,
+CVC_API int cvc_nll_fwd(const float* logp, const int64_t* target, const float* w, int M, int V,
                 float* loss_sum, cvc_stream_t stream);
 /* d_logp[m, v] = -w[m] * g[0] at v == target[m], else 0 (g: device scalar upstream gradient) */
-int cvc_nll_bwd(const int64_t* target, const float* w, const float* g, int M, int V, float* d_logp,
+CVC_API int cvc_nll_bwd(const int64_t* target, const float* w, const float* g, int M, int V, float* d_logp,
                 cvc_stream_t stream);
 
 /* Fused vocabulary criterion (captioner.py:266 + :313 + misc/utils.py:132-146, 181-192) straight from raw
@@ -470,9 +397,9 @@ int cvc_nll_bwd(const int64_t* target, const float* w, const float* g, int M, in
  * index) for the cycle's argmax cut; row_loss[m] = w[m] * (lse[m] - logits[m, target[m]]);
  * loss_sum[0] = sum_m row_loss[m] in a fixed order.  Backward:
  * d_logits[m, v] = g[0] * w[m] * (exp(logits[m, v] - lse[m]) - [v == target[m]])  (g: device scalar). */
-int cvc_vocab_nll_fwd(const float* logits, const int64_t* target, const float* w, int M, int V,
+CVC_API int cvc_vocab_nll_fwd(const float* logits, const int64_t* target, const float* w, int M, int V,
                       float* lse, int64_t* argmax, float* row_loss, float* loss_sum, cvc_stream_t stream);
-int cvc_vocab_nll_bwd(const float* logits, const float* lse, const int64_t* target, const float* w,
+CVC_API int cvc_vocab_nll_bwd(const float* logits, const float* lse, const int64_t* target, const float* w,
                       const float* g, int M, int V, float* d_logits, cvc_stream_t stream);
 
 /* The same criterion folded into the finishing pass of the vocabulary head's tile GEMM (cvc_tile_gemm): parts = its K-slice slabs
@@ -480,20 +407,20 @@ int cvc_vocab_nll_bwd(const float* logits, const float* lse, const int64_t* targ
  * target[m]]) (leading dimension ld_pre; may alias slab 0), argmax (nullable), row_loss and loss_sum as cvc_vocab_nll_fwd -- the
  * [M, V] logits are never written.  Backward: d_logits = g[0] * pre (cvc_scale_by_scalar: y[i] = g[0] * x[i], n % 4 == 0).
  * V <= 8192. */
-int cvc_vocab_head_nll_fwd(const float* parts, int nparts, long long part_stride, int ld, const float* bias,
+CVC_API int cvc_vocab_head_nll_fwd(const float* parts, int nparts, long long part_stride, int ld, const float* bias,
                            const int64_t* target, const float* w, int M, int V, float* pre, int ld_pre, int64_t* argmax,
                            float* row_loss, float* loss_sum, cvc_stream_t stream);
-int cvc_scale_by_scalar(const float* x, const float* g, long long n, float* y, cvc_stream_t stream);
+CVC_API int cvc_scale_by_scalar(const float* x, const float* g, long long n, float* y, cvc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Grounder (captioner.py:132-173, dot-product branch): out[b,t,n] = xt[b,t,:] . feats[b,n,:]
  * + bias[b,t,n], filled with -1e8 where mask[b,t,n].
  */
-int cvc_grounder_fwd(const float* xt, const float* feats, const float* bias, const uint8_t* mask,
+CVC_API int cvc_grounder_fwd(const float* xt, const float* feats, const float* bias, const uint8_t* mask,
                      int B, int T, int N, int G, float* out, cvc_stream_t stream);
 /* its backward (autograd of captioner.py:160-171): d [B,T,N] is the upstream gradient with masked slots already zero;
  * d_xt[b,t,:] = sum_n d[b,t,n] feats[b,n,:], d_feats[b,n,:] = sum_t d[b,t,n] xt[b,t,:]; either output may be null. */
-int cvc_grounder_bwd(const float* d, const float* xt, const float* feats, int B, int T, int N, int G,
+CVC_API int cvc_grounder_bwd(const float* d, const float* xt, const float* feats, int B, int T, int N, int G,
                      float* d_xt, float* d_feats, cvc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
@@ -512,15 +439,15 @@ int cvc_grounder_bwd(const float* d, const float* xt, const float* feats, int B,
  *       b * stride_b + t * stride_t + n; att2_weights and ground_weights share the target):
  *       loss[i] = -sum(log_softmax(x_i, 2) * target) / max(sum(target), 1); workspace: 5 * B * T + 1 floats, kept for the backward;
  *       d_x_i[b, t, n] (contiguous) = g_i[0] / count * (softmax(x_i)[n] * targets_in_row - target[n])  (g_i: device scalars). */
-int cvc_bbox_overlaps_fwd(const float* rois, int ld_roi, const float* gt, int ld_gt, const uint8_t* frm_mask,
+CVC_API int cvc_bbox_overlaps_fwd(const float* rois, int ld_roi, const float* gt, int ld_gt, const uint8_t* frm_mask,
                           const uint8_t* pnt_mask, int ld_pnt, int B, int N, int K, float* ov, cvc_stream_t stream);
-int cvc_label_glue_fwd(const float* ov, const uint8_t* box_mask, long long bm_stride_b, long long bm_stride_k,
+CVC_API int cvc_label_glue_fwd(const float* ov, const uint8_t* box_mask, long long bm_stride_b, long long bm_stride_k,
                        long long bm_stride_t, const uint8_t* frm_mask, const uint8_t* pnt_mask, int B, int N, int K, int T,
                        uint8_t* labels, uint8_t* frm_mask_output, uint8_t* step_fmask, cvc_stream_t stream);
-int cvc_attn_nll_fwd(const float* x0, long long x0_stride_b, long long x0_stride_t, const float* x1, long long x1_stride_b,
+CVC_API int cvc_attn_nll_fwd(const float* x0, long long x0_stride_b, long long x0_stride_t, const float* x1, long long x1_stride_b,
                      long long x1_stride_t, const uint8_t* target, int B, int T, int N, float* workspace, float* loss,
                      cvc_stream_t stream);
-int cvc_attn_nll_bwd(const float* x0, long long x0_stride_b, long long x0_stride_t, const float* x1, long long x1_stride_b,
+CVC_API int cvc_attn_nll_bwd(const float* x0, long long x0_stride_b, long long x0_stride_t, const float* x1, long long x1_stride_b,
                      long long x1_stride_t, const uint8_t* target, int B, int T, int N, const float* workspace,
                      const float* g0, const float* g1, float* d_x0, float* d_x1, cvc_stream_t stream);
 
@@ -531,24 +458,20 @@ int cvc_attn_nll_bwd(const float* x0, long long x0_stride_b, long long x0_stride
  * Two stages: per-row top-`beam` (one workgroup per hypothesis), then a per-clip merge.  Outputs parent[b,k],
  * word[b,k] (int64), new score[b,k]; ties -> lowest flat (k, v) index.
  */
-int cvc_beam_select(const float* logits, const float* score_in, const uint8_t* done_in,
+CVC_API int cvc_beam_select(const float* logits, const float* score_in, const uint8_t* done_in,
                     int B, int beam, int V, int unk_idx, int first_step,
                     int64_t* parent, int64_t* word, float* score_out, uint8_t* done_out,
                     float* workspace /* >= 17 * B * beam floats */, cvc_stream_t stream);
 /* the same with the logits given as the K-slice slabs of the vocabulary GEMM, parts[s][rows, V] (slab stride part_stride floats)
  * plus bias[V] (nullable): summed in slab order while a row is loaded, so the tile path never writes the logits matrix */
-int cvc_beam_select_parts(const float* parts, int nparts, long long part_stride, const float* bias,
-                          const float* score_in, const uint8_t* done_in, int B, int beam, int V, int unk_idx,
-                          int first_step, int64_t* parent, int64_t* word, float* score_out, uint8_t* done_out,
-                          float* workspace, cvc_stream_t stream);
 /* Best hypothesis of every clip after a beam decode: words [T, B*beam] (the word chosen for row r at step t), parent
  * [T, B*beam] (its parent beam slot), att [T, B*beam, N] (region attention of the step, computed for the parent row) ->
  * seq [B, T], att_out [B, T, N] of the rank-0 hypothesis (build-defined beam rule).  T <= 256. */
-int cvc_beam_backtrack(const int64_t* words, const int64_t* parent, const float* att, int B, int beam, int T, int N,
+CVC_API int cvc_beam_backtrack(const int64_t* words, const int64_t* parent, const float* att, int B, int beam, int T, int N,
                        int64_t* seq, float* att_out, cvc_stream_t stream);
 
 /* dst[r, :] = src[(r / beam) * beam + parent[r], :] for r in [0, rows)  (state reorder) */
-int cvc_gather_rows(const float* src, const int64_t* parent, int rows, int beam, int width,
+CVC_API int cvc_gather_rows(const float* src, const int64_t* parent, int rows, int beam, int width,
                     float* dst, cvc_stream_t stream);
 
 
@@ -570,47 +493,32 @@ int cvc_gather_rows(const float* src, const int64_t* parent, int rows, int beam,
 /* A/B + test hook, returns the previous setting (< 0 only queries): 0 = every wave issues its share of the LDS-DMA copies,
  * 1 = dedicated loader waves + 8 computing waves, 2 = dedicated loader waves + 4 wide computing waves (2 weight blocks each),
  * 3 (default) = form 2 for long K loops (>= 64 k steps per workgroup), form 1 otherwise.  All forms: identical results. */
-int cvc_tile_gemm_loaders(int on);
-int cvc_tile_rows_alloc(int M);      /* rows (a multiple of 32) an activation fragment buffer for M live rows must hold */
-int cvc_tile_gemm(const void* wb, const void* xb, long long x_mblk_stride, int K, int M, int N, int ksplit,
+CVC_API int cvc_tile_rows_alloc(int M);      /* rows (a multiple of 32) an activation fragment buffer for M live rows must hold */
+CVC_API int cvc_tile_gemm(const void* wb, const void* xb, long long x_mblk_stride, int K, int M, int N, int ksplit,
                   float* parts, int ld, long long part_stride, cvc_stream_t stream);
 /* nn.LSTMCell epilogue over the slabs of a gate GEMM (packed feature order): + b_ih + b_hh + gate_bias[m / gb_div]
  * (checkpoint order [*, 4R]; the hoisted fc term, one row per clip), cell update with c_prev [M, R]; writes c_out, h_out
  * [M, R] (h_out nullable) and h' as activation fragments at up to two destinations (pointer at the segment's first k step). */
-int cvc_tile_lstm_finish(const float* parts, int nparts, long long part_stride, const float* b_ih, const float* b_hh,
-                         const float* gate_bias, int gb_div, const float* c_prev, int M, int R, float* c_out,
-                         float* h_out, void* frag1, long long frag1_stride, void* frag2, long long frag2_stride,
-                         cvc_stream_t stream);
 /* the same with the embedded word's share of the gates taken from the embedding-gate table (see cvc_packed_lstm_embgate_fwd):
  * + emb_gate[word[m], :] (checkpoint order [V, 4R]; a word outside [0, V) reads row 0).  The gate GEMM then covers K = 2R
  * (h_lang | h_att) and cvc_tile_reorder_pack is called with E = 0. */
-int cvc_tile_lstm_finish_embgate(const float* parts, int nparts, long long part_stride, const float* b_ih, const float* b_hh,
-                                 const float* gate_bias, int gb_div, const float* emb_gate, const int64_t* word, int V,
-                                 const float* c_prev, int M, int R, float* c_out, float* h_out, void* frag1,
-                                 long long frag1_stride, void* frag2, long long frag2_stride, cvc_stream_t stream);
 /* y[m, n] = sum_s parts[s][m, n] + bias[n] + bias2[n]  (nn.Linear epilogue: vocabulary logits, hoisted fc gate term) */
-int cvc_tile_linear_finish(const float* parts, int nparts, long long part_stride, int ld, const float* bias,
+CVC_API int cvc_tile_linear_finish(const float* parts, int nparts, long long part_stride, int ld, const float* bias,
                            const float* bias2, int M, int N, float* y, int ldy, cvc_stream_t stream);
 /* fp32 rows (optionally gathered through idx, optionally ReLU'd) -> activation fragments */
-int cvc_tile_pack_rows(const float* x, int ldx, const int64_t* idx, int relu, int M, int K, void* xb,
+CVC_API int cvc_tile_pack_rows(const float* x, int ldx, const int64_t* idx, int relu, int M, int K, void* xb,
                        long long x_mblk_stride, cvc_stream_t stream);
 /* Operand packers for the dense backward products (autograd of nn.Linear / nn.LSTMCell: dW = dY^T X batched over all T steps,
  * dX = dY W of the vocabulary head; reference decoder_core.py:50,61, captioner.py:266,361): any sizes, zero fill.
  * cvc_tile_pack_rows_any: x [M, K] row-major -> fragments with rows m, contraction k (k padded to a multiple of 16).
  * cvc_tile_pack_cols:     x [S, C] row-major read as its transpose -> fragments with rows c, contraction s. */
-int cvc_tile_pack_rows_any(const float* x, long long ldx, int M, int K, void* xb, long long x_mblk_stride, cvc_stream_t stream);
-int cvc_tile_pack_cols(const float* x, long long ldx, int S, int C, void* xb, long long x_mblk_stride, cvc_stream_t stream);
+CVC_API int cvc_tile_pack_rows_any(const float* x, long long ldx, int M, int K, void* xb, long long x_mblk_stride, cvc_stream_t stream);
+CVC_API int cvc_tile_pack_cols(const float* x, long long ldx, int S, int C, void* xb, long long x_mblk_stride, cvc_stream_t stream);
 /* Beam-state reorder fused with next step's operand packing: row r continues hypothesis (r / beam) * beam + parent[r]
  * (parent NULL: r).  c_*_prev[r] = c_*[src]; xa = [h_lang[src] | relu(table[word[r]]) | h_att[src]] as fragments (K = 2R + E,
  * decoder_core.py:45-48 without the hoisted fc segment; E = 0: no embedding segment, table may be NULL -- the embedding-gate
  * form); xl_hlang (lang-LSTM input, third K segment) = h_lang[src]. */
-int cvc_tile_reorder_pack(const int64_t* parent, const int64_t* word, int beam, const float* h_att, const float* c_att,
-                          const float* h_lang, const float* c_lang, const float* table, int E, int V,
-                          float* c_att_prev, float* c_lang_prev, void* xa, long long xa_stride, void* xl_hlang,
-                          long long xl_stride, int rows, int R, cvc_stream_t stream);
 /* Pass 2 of the attention writing the summed context as activation fragments (rows of the tile path) */
-int cvc_attn_wsum_frag(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, void* ctx_frag,
-                       long long frag_mblk_stride, cvc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Once-per-clip encoder, inference (model/backbone.py:189-351): the small fused pieces between its
@@ -619,16 +527,16 @@ int cvc_attn_wsum_frag(const cvc_attn_set* sets, int nsets, int nclip, int nq, i
 /* Class similarity (backbone.py:222-235): logits [B*N, ld_logits] = region features x class table^T (a cvc_tile_gemm product);
  * + bias[C] (nullable); regions with pad[b, n] != 0 filled with -1e8 in every class; softmax over the C classes;
  * out [B, C, N] (the reference's layout) and, if asked, out_rows [B*N, C] (what the region features concatenate, :274-277). */
-int cvc_class_softmax_fwd(const float* logits, long long ld_logits, const float* bias, const uint8_t* pad, int B, int N,
+CVC_API int cvc_class_softmax_fwd(const float* logits, long long ld_logits, const float* bias, const uint8_t* pad, int B, int N,
                           int C, float* out, float* out_rows, cvc_stream_t stream);
 /* out[row, :] = [ F.layer_norm(x_0[row], [d_0]) | ... ] for up to three inputs (no affine, biased variance, eps):
  * backbone.py:215-216 (fc | seg_info) and :274-277 (region | location | class-probability features). */
-int cvc_layernorm_cat_fwd(const float* const* xs, const long long* ldx, const int* widths, int nseg, long long rows, float eps,
+CVC_API int cvc_layernorm_cat_fwd(const float* const* xs, const long long* ldx, const int* widths, int nseg, long long rows, float eps,
                           float* out, long long ld_out, cvc_stream_t stream);
 /* Frame embeddings (backbone.py:325-333) after their two dense products y0 [rows, c0], y1 [rows, c1] (bias-free):
  * out [rows, c0 + c1] = relu( scale * cat(relu(y0 + b0), relu(y1 + b1)) + shift ), scale / shift = BatchNorm1d in eval mode
  * folded per channel (gamma / sqrt(running_var + eps), beta - running_mean * scale).  c0, c1 % 4 == 0. */
-int cvc_frame_embed_fwd(const float* y0, const float* b0, int c0, const float* y1, const float* b1, int c1, const float* scale,
+CVC_API int cvc_frame_embed_fwd(const float* y0, const float* b0, int c0, const float* y1, const float* b1, int c1, const float* scale,
                         const float* shift, long long rows, float* out, cvc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
@@ -695,16 +603,15 @@ typedef struct cvc_decode_desc {
     unsigned* ksx_flags;
 } cvc_decode_desc;
 typedef struct cvc_decode_plan cvc_decode_plan;
-int cvc_decode_plan_create(const cvc_decode_desc* desc, cvc_decode_plan** plan);   /* validates, copies the descriptor       */
-void cvc_decode_plan_destroy(cvc_decode_plan* plan);
+CVC_API int cvc_decode_plan_create(const cvc_decode_desc* desc, cvc_decode_plan** plan);   /* validates, copies the descriptor       */
+CVC_API void cvc_decode_plan_destroy(cvc_decode_plan* plan);
 /* next batch of the SAME shape: point the plan at other feature tensors (no copy, no new plan; a graph captured from the plan
  * keeps the old pointers -- re-capture or copy into the bound buffers instead when replaying graphs) */
-int cvc_decode_plan_set_features(cvc_decode_plan* plan, const float* fc, const float* conv, const float* pconv,
+CVC_API int cvc_decode_plan_set_features(cvc_decode_plan* plan, const float* fc, const float* conv, const float* pconv,
                                  const float* pool, const float* ppool, const uint8_t* mask);
-int cvc_decode_num_launches(const cvc_decode_plan* plan);                            /* kernels + copies per decode           */
 /* enqueue one full decode on `stream`; results land in desc.words / att_steps / logprob (greedy), + score / parent (beam) */
-int cvc_decode_greedy(cvc_decode_plan* plan, cvc_stream_t stream);
-int cvc_decode_beam(cvc_decode_plan* plan, cvc_stream_t stream);
+CVC_API int cvc_decode_greedy(cvc_decode_plan* plan, cvc_stream_t stream);
+CVC_API int cvc_decode_beam(cvc_decode_plan* plan, cvc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Training loops driven from C (round 4): the two recurrent loops of the cyclical training pass -- loop A, the teacher-forced
@@ -759,10 +666,8 @@ typedef struct cvc_lstm_step {
     const uint32_t* rng_state; unsigned site; float p;
     float *h_dst1_q, *h_dst2_q;  /* h' in the quad layout at the consumers' K offsets, nullable                           */
 } cvc_lstm_step;
-int cvc_packed_lstm_step_fwd(const cvc_lstm_step* s, cvc_stream_t stream);
+CVC_API int cvc_packed_lstm_step_fwd(const cvc_lstm_step* s, cvc_stream_t stream);
 
-int cvc_attn_wsum_quad_rm(const cvc_attn_set* sets, int nsets, int nclip, int R, float* ctx_sum_q, float* ctx_sum_rm,
-                          cvc_stream_t stream);            /* one query per clip (nq = 1), nclip <= 64 */
 
 /* sets[s]: proj / ctx / attn / n as in the forward; scores = d_scores out [rows, n] (the pre-softmax gradient; its sum is
  * d_b_alpha); frame_masked = gradient of the frame-masked output (d_fm, INPUT, nullable); ctx_out unused.  d_ctx [rows, R] is
@@ -771,12 +676,8 @@ int cvc_attn_wsum_quad_rm(const cvc_attn_set* sets, int nsets, int nclip, int R,
  * d_proj[s] / d_ctxfeat[s] (nullable): ACCUMULATED feature gradients [nclip, n, A] / [nclip, n, R].
  * q: the forward's query h2attn(h), as a finished [rows, A] tensor (nplanes = 1, q_bias null) or as the split-K planes the
  * forward's cvc_packed_linear_fwd left (+ q_bias = h2attn.bias), summed on load. */
-int cvc_attn_bwd_pair(int kind, const cvc_grad_src* q, const float* q_bias, const float* w_a, float inv_temp,
-                      const cvc_attn_set* sets, int nsets, const cvc_grad_src* d_ctx, int nclip, int nq, int A, int R,
-                      float* d_q, float* d_q_q, float* d_w_part, float* const* d_proj, float* const* d_ctxfeat,
-                      cvc_stream_t stream);
 
-int cvc_lstm_pointwise_bwd4(const cvc_grad_src* d_h /* [3] */, const float* d_hd,
+CVC_API int cvc_lstm_pointwise_bwd4(const cvc_grad_src* d_h /* [3] */, const float* d_hd,
                             const uint32_t* rng_state, unsigned site, float p, const float* d_c, const float* gates,
                             const float* c_prev, const float* c_new, int M, int R, float* d_gates, float* d_c_prev,
                             float* d_gates_q, float* dg_sum /* [M, 4R] += d_gates, nullable */, cvc_stream_t stream);
@@ -832,18 +733,17 @@ typedef struct cvc_train_loop {
     float *d_pool, *d_ppool, *d_conv, *d_pconv;    /* kind 0: accumulated feature gradients, nullable                    */
     float* bwd_ws;               /* cvc_train_loop_bwd_ws(B, R, A) floats, ZERO before the first use                     */
 } cvc_train_loop;
-long long cvc_train_loop_bwd_ws(int B, int R, int A);
-int cvc_train_loop_fwd(const cvc_train_loop* loop, cvc_stream_t stream);
-int cvc_train_loop_bwd(const cvc_train_loop* loop, cvc_stream_t stream);
-int cvc_train_loop_launches(const cvc_train_loop* loop, int backward);     /* launches one call enqueues */
+CVC_API long long cvc_train_loop_bwd_ws(int B, int R, int A);
+CVC_API int cvc_train_loop_fwd(const cvc_train_loop* loop, cvc_stream_t stream);
+CVC_API int cvc_train_loop_bwd(const cvc_train_loop* loop, cvc_stream_t stream);
 /* Measurement aid (bench.py --mode train; never enabled by the product path): HIP-event pairs around every entry point the two
  * drivers call, on the launch stream.  cvc_train_loop_profile(n > 0) starts recording with room for n launches, (0) stops and
  * frees; cvc_train_loop_profile_read waits for the recorded launches and returns their count, kind[i] (0 zero fill, 1 attention
  * cell, 2 h2attn, 3 score pass, 4 weighted sum, 5 language cell, 6 / 10 gate gradients of the language / attention cell, 7 / 9 /
  * 11 backward-data product of the language cell / h2attn / the attention cell, 8 attention backward), loop[i] (0 / 1 forward of
  * loop A / C, 2 / 3 their backward) and ms[i]; the record is emptied. */
-int cvc_train_loop_profile(int enable);
-int cvc_train_loop_profile_read(int* kind, int* loop, float* ms, int cap);
+CVC_API int cvc_train_loop_profile(int enable);
+CVC_API int cvc_train_loop_profile_read(int* kind, int* loop, float* ms, int cap);
 
 /* ---------------------------------------------------------------------------------------
  * Optimizer step of the training path (trainer.py:116-122: nn.utils.clip_grad_norm_ -> optimizer.step(); Adam with one group per
@@ -863,8 +763,8 @@ typedef struct {
     float lr, weight_decay;
 } cvc_optim_seg;
 typedef struct { int seg; int pad; long long start; } cvc_optim_chunk;
-int cvc_optim_chunk_elems(void);
-int cvc_adam_clip_step(const cvc_optim_seg* segs, int nseg, const cvc_optim_chunk* chunks, int nchunk, float max_norm,
+CVC_API int cvc_optim_chunk_elems(void);
+CVC_API int cvc_adam_clip_step(const cvc_optim_seg* segs, int nseg, const cvc_optim_chunk* chunks, int nchunk, float max_norm,
                        float inv_world, float beta1, float beta2, float eps, int write_grad, float* partial,
                        float* norm_coef, cvc_stream_t stream);
 
@@ -879,10 +779,10 @@ int cvc_adam_clip_step(const cvc_optim_seg* segs, int nseg, const cvc_optim_chun
  * by the world size; otherwise one ncclAllReduce).  Return codes: 0, CVC_E_*, or 1000 + ncclResult_t.  librccl is dlopen'ed on
  * first use.
  */
-int cvc_comm_unique_id(void* out128);
-int cvc_comm_init(int world, int rank, const void* id128, void** comm);
-int cvc_allreduce_grads(void* comm, float* grads, long long count, cvc_stream_t stream);
-int cvc_comm_destroy(void* comm);
+CVC_API int cvc_comm_unique_id(void* out128);
+CVC_API int cvc_comm_init(int world, int rank, const void* id128, void** comm);
+CVC_API int cvc_allreduce_grads(void* comm, float* grads, long long count, cvc_stream_t stream);
+CVC_API int cvc_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,105 @@
+/*
+ * cvc_hip_blocks.h -- the per-kernel building blocks of libcvc_hip.so: what the whole-decode drivers (cvc_decode_greedy / _beam),
+ * the training-loop drivers (cvc_train_loop_fwd / _bwd) and the host mirror's eager launch lists are composed of.  NOT part of the
+ * exported drop-in ABI (hidden visibility): unit tests and cvc/decode.py reach them through cvc_block("name") (cvc_hip.h).
+ * Contracts: the section of cvc_hip.h that describes the corresponding driver or core entry point (same argument conventions:
+ * raw device pointers, sizes, the launch stream; 0 / hipError_t / CVC_E_*).
+ */
+#ifndef CVC_HIP_BLOCKS_H
+#define CVC_HIP_BLOCKS_H
+#include "cvc_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int cvc_attn_scores(int kind, const float* q, const float* w_a, const float* b_a, float inv_temp,
+                    const cvc_attn_set* sets, int nsets, int nclip, int nq, int A, cvc_stream_t stream);
+int cvc_attn_wsum(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum,
+                  cvc_stream_t stream);
+int cvc_attn_scores_qparts(int kind, const float* q_parts, int q_nparts, const float* q_bias, const float* w_a,
+                           const float* b_a, float inv_temp, const cvc_attn_set* sets, int nsets, int nclip,
+                           int nq, int A, cvc_stream_t stream);
+int cvc_attn_wsum_quad(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum_q,
+                       cvc_stream_t stream);
+int cvc_attn_wsum_frag(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, void* ctx_frag,
+                       long long frag_mblk_stride, cvc_stream_t stream);
+int cvc_attn_wsum_quad_rm(const cvc_attn_set* sets, int nsets, int nclip, int R, float* ctx_sum_q, float* ctx_sum_rm,
+                          cvc_stream_t stream);            /* one query per clip (nq = 1), nclip <= 64 */
+int cvc_attn_bwd_pair(int kind, const cvc_grad_src* q, const float* q_bias, const float* w_a, float inv_temp,
+                      const cvc_attn_set* sets, int nsets, const cvc_grad_src* d_ctx, int nclip, int nq, int A, int R,
+                      float* d_q, float* d_q_q, float* d_w_part, float* const* d_proj, float* const* d_ctxfeat,
+                      cvc_stream_t stream);
+int cvc_linear_splitk_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, int M, int Nout,
+                          int ksplit, float* y_parts, cvc_stream_t stream);
+int cvc_linear_top2_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, int M, int Nout,
+                        float* y_or_null, float* top2_part, cvc_stream_t stream);
+int cvc_top2_final(const float* part, int nblocks, int M, int unk_idx, int64_t* word, int word_stride,
+                   float* logprob, const float* table, int E, float* emb_out, int emb_ld,
+                   cvc_stream_t stream);
+int cvc_packed_lstm_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
+                        const float* gate_bias, const float* c_prev_q, int M, int R, float* h_dst1_q,
+                        float* h_dst2_q, float* c_out_q, cvc_stream_t stream);
+int cvc_packed_linear_fwd(const float* wp, const float* xq, int K, const float* bias, int M, int Nout,
+                          int ksplit, float* y, int ldy, float* top2_part, cvc_stream_t stream);
+int cvc_packed_lstm_embgate_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
+                                const float* gate_bias, const float* emb_gate, const int64_t* word, const float* c_prev_q,
+                                int M, int R, float* h_dst1_q, float* h_dst2_q, float* c_out_q, cvc_stream_t stream);
+int cvc_packed_lstm_embgate_ex_fwd(const float* wp, long long w_blk_stride, const float* xq, int K, const float* b_ih,
+                                   const float* b_hh, const float* gate_bias, const float* emb_gate, const int64_t* word,
+                                   const float* c_prev_q, int M, int R, float* h_dst1_q, float* h_dst2_q,
+                                   float* c_out_q, int w_cached, cvc_stream_t stream);
+int cvc_packed_lstm_late_fwd(const float* wp, long long w_blk_stride, const float* xq, int K, const float* b_ih,
+                             const float* b_hh, const float* gate_bias, const float* c_prev_q, int M, int R,
+                             float* h_dst1_q, float* h_dst2_q, float* c_out_q, const cvc_gsk_segs* early,
+                             cvc_stream_t stream);
+int cvc_packed_lstm_train_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
+                              const float* c_prev, int M, int R, float* h_out, float* c_out, float* gates_out,
+                              float* h_out2, float* h_out3, cvc_stream_t stream);   /* h_out2/3: further copies of h', nullable */
+int cvc_packed_lstm_train_pre_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
+                                  const float* gate_pre, const float* c_prev, int M, int R, float* h_out, float* c_out,
+                                  float* gates_out, float* h_out2, float* h_out3, cvc_stream_t stream);
+int cvc_packed_lstm_train_drop_fwd(const float* wp, const float* xq, int K, const float* b_ih, const float* b_hh,
+                                   const float* gate_pre, const float* c_prev, int M, int R, float* h_out, float* c_out,
+                                   float* gates_out, float* h_out2, float* h_drop_out, const uint32_t* rng_state,
+                                   unsigned site, float p, cvc_stream_t stream);
+int cvc_lstm_pointwise_bwd(const float* d_h, const float* d_c, const float* gates,
+                           const float* c_prev, const float* c_new, int M, int R,
+                           float* d_gates, float* d_c_prev, float* d_gates_q, cvc_stream_t stream);
+int cvc_lstm_pointwise_bwd3(const float* d_h, const float* d_h2, const float* d_h3, const float* d_c,
+                            const float* gates, const float* c_prev, const float* c_new, int M, int R,
+                            float* d_gates, float* d_c_prev, float* d_gates_q, cvc_stream_t stream);
+int cvc_lstm_pointwise_bwd3_drop(const float* d_h, const float* d_h2, const float* d_h3, const uint32_t* rng_state,
+                                 unsigned site, float p, const float* d_c, const float* gates, const float* c_prev,
+                                 const float* c_new, int M, int R, float* d_gates, float* d_c_prev, float* d_gates_q,
+                                 cvc_stream_t stream);
+int cvc_pack_lstm_weights(const float* w_ih, int K_ih, const float* w_hh, int K_hh, int R, float* wp,
+                          cvc_stream_t stream);
+int cvc_linear_nn_planes_fwd(const float* dy_q, int K, int M, const cvc_nn_seg* segs, int nsegs, int ksplit,
+                             float* workspace, cvc_stream_t stream);
+int cvc_beam_select_parts(const float* parts, int nparts, long long part_stride, const float* bias,
+                          const float* score_in, const uint8_t* done_in, int B, int beam, int V, int unk_idx,
+                          int first_step, int64_t* parent, int64_t* word, float* score_out, uint8_t* done_out,
+                          float* workspace, cvc_stream_t stream);
+int cvc_tile_lstm_finish(const float* parts, int nparts, long long part_stride, const float* b_ih, const float* b_hh,
+                         const float* gate_bias, int gb_div, const float* c_prev, int M, int R, float* c_out,
+                         float* h_out, void* frag1, long long frag1_stride, void* frag2, long long frag2_stride,
+                         cvc_stream_t stream);
+int cvc_tile_lstm_finish_embgate(const float* parts, int nparts, long long part_stride, const float* b_ih, const float* b_hh,
+                                 const float* gate_bias, int gb_div, const float* emb_gate, const int64_t* word, int V,
+                                 const float* c_prev, int M, int R, float* c_out, float* h_out, void* frag1,
+                                 long long frag1_stride, void* frag2, long long frag2_stride, cvc_stream_t stream);
+int cvc_tile_reorder_pack(const int64_t* parent, const int64_t* word, int beam, const float* h_att, const float* c_att,
+                          const float* h_lang, const float* c_lang, const float* table, int E, int V,
+                          float* c_att_prev, float* c_lang_prev, void* xa, long long xa_stride, void* xl_hlang,
+                          long long xl_stride, int rows, int R, cvc_stream_t stream);
+int cvc_decode_num_launches(const cvc_decode_plan* plan);                            /* kernels + copies per decode           */
+/* test hook: every concat-GEMM on the generic direct-load kernel (see cvc_hip.h, cvc_linear_fwd) */
+int cvc_gemm_force_generic(int on);
+/* coverage hooks: select among kernel forms that the default path picks per shape (identical results) */
+int cvc_tile_gemm_loaders(int on);
+int cvc_gru_persistent_waves8(int on);   /* A/B + test hook: 1 (default) = 8 waves per workgroup where H % 256 == 0, 0 = always 4 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVC_HIP_BLOCKS_H */

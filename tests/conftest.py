@@ -15,6 +15,25 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "gpu_experimental: exercises a form of include/cvc_hip_experimental.h -- needs an MI355X AND a "
+                                       "library built with CVC_EXPERIMENTAL=1 (skipped otherwise; run with -m gpu_experimental)")
+    config.addinivalue_line("markers", "experimental: needs a library built with CVC_EXPERIMENTAL=1 (no GPU)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """tests of experimental forms are skipped unless the in-tree library carries them"""
+    built = None
+    for item in items:
+        if item.get_closest_marker("gpu_experimental") or item.get_closest_marker("experimental"):
+            if built is None:
+                try:
+                    from cvc import hip
+                    built = hip.experimental_built()
+                except Exception:
+                    built = False
+            if not built:
+                item.add_marker(pytest.mark.skip(reason="experimental forms are not in this build (CVC_EXPERIMENTAL=1 python "
+                                                        "cyclical-visual-captioning_amd/build_hip.py --force)"))
 
 
 class Golden:

@@ -10,10 +10,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "cvc_hip.h")
 
 
-def declared_functions():
-    src = open(HEADER).read()
+BLOCKS_H = os.path.join(ROOT, "include", "cvc_hip_blocks.h")
+EXPER_H = os.path.join(ROOT, "include", "cvc_hip_experimental.h")
+
+
+def declared_functions(path=HEADER):
+    src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(?:int|void|long long|const char\*)\s+(cvc_\w+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(?:int|void|void\*|long long|const char\*)\s+(cvc_\w+)\s*\(", src)))
 
 
 def test_library_builds_and_loads():
@@ -24,20 +28,41 @@ def test_library_builds_and_loads():
     assert b"gfx950" in lib.cvc_version()
 
 
-def test_every_declared_symbol_is_exported_and_bound():
+def test_exports_are_exactly_the_core_header_and_at_most_70():
+    """The .so is built with hidden visibility: its dynamic symbol table holds the CVC_API declarations of include/cvc_hip.h and
+    nothing else -- the drop-in ABI.  Building blocks and experimental forms are not exported."""
+    import subprocess
+    import build_hip
+    so = build_hip.build(verbose=False)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", so], text=True)
+    exported = sorted(l.split()[-1] for l in out.splitlines() if " T " in l)
+    core = declared_functions()
+    assert exported == core, (set(exported) ^ set(core))
+    assert len(exported) <= 70, len(exported)
+    assert not set(core) & set(declared_functions(BLOCKS_H)) and not set(core) & set(declared_functions(EXPER_H))
+
+
+def test_every_declared_symbol_is_exported_or_in_the_block_table_and_bound():
     from cvc import hip
     lib = hip.lib()
-    names = declared_functions()
-    assert len(names) >= 18
-    for n in names:
+    core, blocks, exper = declared_functions(), declared_functions(BLOCKS_H), declared_functions(EXPER_H)
+    assert len(core) >= 18
+    for n in core:
         assert hasattr(lib, n), f"{n} declared in include/cvc_hip.h but not exported"
-    bound = set(hip.SIGNATURES) | {"cvc_version"}
-    assert bound == set(names), (bound ^ set(names))
+    lib.cvc_block.restype = ctypes.c_void_p
+    for n in blocks:
+        assert lib.cvc_block(n.encode()), f"{n} declared in include/cvc_hip_blocks.h but not in the library's block table"
+    for n in exper:
+        assert bool(lib.cvc_block(n.encode())) == hip.experimental_built(), n
+    assert lib.cvc_block(b"no_such_block") is None
+    assert set(blocks) == hip.BLOCKS and set(exper) == hip.EXPERIMENTAL
+    bound = set(hip.SIGNATURES) | {"cvc_version", "cvc_block"}
+    assert bound == set(core) | set(blocks) | set(exper), (bound ^ (set(core) | set(blocks) | set(exper)))
 
 
 def test_argument_counts_match_header():
     from cvc import hip
-    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    src = "".join(re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S) for h in (HEADER, BLOCKS_H, EXPER_H))
     for name, argtypes in hip.SIGNATURES.items():
         m = re.search(r"\b" + name + r"\s*\((.*?)\)\s*;", src, flags=re.S)
         assert m, name

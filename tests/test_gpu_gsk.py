@@ -13,7 +13,7 @@ import torch
 
 from cvc import synth
 
-pytestmark = pytest.mark.gpu
+pytestmark = pytest.mark.gpu_experimental      # the grouped stream-K schedule: include/cvc_hip_experimental.h
 
 SEQ_TOL = dict(rtol=1e-4, atol=1e-4)
 

@@ -405,6 +405,7 @@ def test_multi_query_additive_scores_large_values_take_the_direct_form(dev, lib,
     assert bool(torch.isfinite(scores).all())
 
 
+@pytest.mark.gpu_experimental
 @pytest.mark.parametrize("M,R,E", [(64, 2048, 1024), (37, 256, 96), (1, 64, 32), (64, 4096, 2048)])
 def test_packed_lstm_ksplit_equals_full_k_kernel(dev, lib, M, R, E):
     """cvc_packed_lstm_ks_fwd (256 gate rows x K / S per workgroup, activations shared through LDS, slabs + finishing kernel)
@@ -463,6 +464,7 @@ def test_packed_lstm_ksplit_equals_full_k_kernel(dev, lib, M, R, E):
     close(hk, h_ref.float(), rtol=2e-5, atol=2e-5); close(ck, c_ref.float(), rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.gpu_experimental
 @pytest.mark.parametrize("M,eg,mode", [(64, False, 3), (64, True, 1), (37, True, 2), (64, True, 0), (1, False, 3)])
 def test_packed_lstm_exchange_finish_equals_full_k_kernel(dev, lib, M, eg, mode):
     """cvc_packed_lstm_ksx_fwd (K split over 8 workgroups per 256-row tile, every slice finishing one of the tile's blocks after
@@ -910,6 +912,7 @@ def test_cabi_decode_driver_equals_python_launch_list(dev, lib, B, beam, dims):
     assert all(torch.equal(x, y) for x, y in zip(a, e_drv.run()))          # replay again: state is reset inside the driver
 
 
+@pytest.mark.gpu_experimental
 @pytest.mark.parametrize("form", [True, "fused"])
 def test_decode_with_ksplit_gate_gemms_equals_default_engine(dev, lib, form):
     """Greedy decode with the K-split gate GEMMs (two-launch form and finish fused into the last-arriving slice,
@@ -932,6 +935,7 @@ def test_decode_with_ksplit_gate_gemms_equals_default_engine(dev, lib, form):
         assert all(torch.equal(x, y) for x, y in zip(a, e.run()))
 
 
+@pytest.mark.gpu_experimental
 def test_decode_with_two_block_gate_gemm_workgroups(dev, lib):
     """The selectable 64-row-workgroup form of the packed gate GEMM (cvc_packed_lstm_wg_blocks(2): two weight blocks share
     every activation line through the L1) against the default: same sequences, attention within the recurrent tolerance."""

@@ -5,6 +5,8 @@ import ctypes as C
 
 import pytest
 
+pytestmark = pytest.mark.experimental      # cvc_gsk_plan lives in include/cvc_hip_experimental.h
+
 
 def plan_py(ntile, nchunk, nwg):
     unit0, tot = [], 0

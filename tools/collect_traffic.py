@@ -122,7 +122,13 @@ def main():
         w = [(n, v) for n, v in write if rx.search(n)]
         if not f:
             continue
-        if len(f) % period != 0:
+        lead = len(f) % period
+        if lead and lead <= 2 and len(w) == len(f):
+            # one-off launches of the same kernel before the first period (the embedding-gate table is one dense product at bind
+            # time): dropped from the front
+            print(f"[collect_traffic] {role}: {len(f)} dispatches of /{pat}/ = {lead} one-off launch(es) + {len(f) // period} periods of {period}", file=sys.stderr)
+            f, w = f[lead:], w[lead:]
+        elif lead:
             print(f"[collect_traffic] {role}: {len(f)} dispatches of /{pat}/ are not a multiple of the period {period}: skipped", file=sys.stderr)
             continue
         sel = lambda xs: [v for i, (n, v) in enumerate(xs) if i % period in positions and i // period >= a.skip]
