@@ -1192,3 +1192,61 @@ def test_attn_nll_kernels_vs_fp64(dev, lib, B, T, N):
     np.testing.assert_allclose(x1.grad.cpu().double().numpy(), a1.grad.cpu().numpy(), rtol=1e-4, atol=1e-7)
     z0, z1 = F_.attn_nll(x0s.detach().transpose(0, 1), x1.detach(), torch.zeros_like(tgt))
     assert float(z0) == 0.0 and float(z1) == 0.0
+
+
+# ------------------------------------------------------------------ torch.library registration (last row)
+def test_torch_library_ops_match_the_functional_path(dev, lib, tiny):
+    """cvc::* ops (cvc/ops.py): same kernels as cvc.functional behind dispatcher-visible schemas -- forward values and gradients
+    equal the functional path's, and torch.library.opcheck accepts schema / fake / autograd registration."""
+    import cvc.ops  # noqa: F401
+    from cvc import functional as F_
+    d = tiny[0]
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    B, N, A, R, V, E = 3, 7, 16, 32, 50, 16
+    # attention, additive, with masks
+    q, w_a, b_a, proj, cf = r(B, A).requires_grad_(), r(1, A).requires_grad_(), r(1).requires_grad_(), r(B, N, A), r(B, N, R)
+    mask = torch.zeros(B, N, dtype=torch.bool, device=dev); mask[0, -2:] = True
+    fmk = torch.zeros(B, N, dtype=torch.bool, device=dev); fmk[1, :3] = True
+    c1, a1, f1 = torch.ops.cvc.attn_fwd(0, q, w_a, b_a, 1.0, proj, cf, mask, fmk)
+    (c1.sum() + 0.3 * f1.sum()).backward()
+    g_op = [t.grad.clone() for t in (q, w_a, b_a)]
+    for t in (q, w_a, b_a):
+        t.grad = None
+    _, ((c2, a2, f2),) = F_.attention(0, q, w_a, b_a, 1.0, [(proj, cf, mask, fmk)])
+    (c2.sum() + 0.3 * f2.sum()).backward()
+    close(c1, c2, rtol=1e-6, atol=1e-6); close(a1, a2, rtol=1e-6, atol=1e-7); close(f1, f2, rtol=1e-6, atol=1e-6)
+    for a_, t in zip(g_op, (q, w_a, b_a)):
+        close(a_, t.grad, rtol=1e-5, atol=1e-6)
+    # LSTM cell against torch's formula
+    x, h, c = r(B, 3 * R).requires_grad_(), r(B, R).requires_grad_(), r(B, R).requires_grad_()
+    cell = torch.nn.LSTMCell(3 * R, R).to(dev)
+    h1, c1_, _ = torch.ops.cvc.lstm_cell(x, h, c, cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)
+    (h1.sum() + 0.5 * c1_.sum()).backward()
+    got = [t.grad.clone() for t in (x, h, c, cell.weight_ih, cell.weight_hh, cell.bias_ih)]
+    for t in (x, h, c, *cell.parameters()):
+        t.grad = None
+    h2, c2_ = cell(x, (h, c))
+    (h2.sum() + 0.5 * c2_.sum()).backward()
+    close(h1, h2, rtol=2e-5, atol=2e-5); close(c1_, c2_, rtol=2e-5, atol=2e-5)
+    for a_, t in zip(got, (x, h, c, cell.weight_ih, cell.weight_hh, cell.bias_ih)):
+        close(a_, t.grad, rtol=2e-4, atol=2e-5)
+    # embedding, criterion, word selection
+    table, idx = r(V, E).requires_grad_(), torch.randint(0, V, (B, 4), generator=g).to(dev)
+    e1 = torch.ops.cvc.embed_relu(table, idx)
+    assert torch.equal(e1, torch.relu(table.detach()[idx]))
+    e1.square().sum().backward()
+    ref = table.detach().clone().requires_grad_()
+    torch.relu(ref[idx]).square().sum().backward()
+    close(table.grad, ref.grad, rtol=1e-6, atol=1e-6)
+    logits, tgt, w = r(12, V).requires_grad_(), torch.randint(0, V, (12,), generator=g).to(dev), (torch.rand(12, generator=g) > 0.3).float().to(dev)
+    loss, amax, _ = torch.ops.cvc.vocab_nll(logits, tgt, w)
+    loss.sum().backward()
+    ref = logits.detach().double().requires_grad_()
+    (-(torch.log_softmax(ref, 1)[torch.arange(12), tgt.cpu()] * w.double())).sum().backward()
+    close(logits.grad, ref.grad, rtol=1e-5, atol=1e-6)
+    assert torch.equal(amax, logits.argmax(1))
+    word, lp = torch.ops.cvc.top2_unk(logits.detach(), synth.UNK_IDX)
+    assert not (word == synth.UNK_IDX).any()
+    torch.library.opcheck(torch.ops.cvc.embed_relu, (table.detach().requires_grad_(), idx), test_utils=("test_schema", "test_faketensor"))
+    torch.library.opcheck(torch.ops.cvc.vocab_nll, (logits.detach(), tgt, w), test_utils=("test_schema", "test_faketensor"))

@@ -123,3 +123,25 @@ def test_equal_clip_shards_give_every_rank_the_same_step_count():
     # the ragged default still covers every clip exactly once (inference sharding)
     cover = [i for r in range(3) for i in range(*shard_range(10, r, 3).indices(10))]
     assert cover == list(range(10))
+
+
+def test_torch_library_ops_are_registered_with_fake_implementations():
+    """SURVEY section 8(b): the hot path's operators registered as cvc::* torch.library ops.  No GPU here: the schemas exist and the
+    fake (meta) implementations propagate shapes -- what torch.compile's tracer needs."""
+    import torch
+    import cvc.ops as ops
+    for name in ops.REGISTERED:
+        assert hasattr(torch.ops.cvc, name), name
+    m = lambda *s, dtype=torch.float32: torch.empty(*s, device="meta", dtype=dtype)
+    B, N, A, R, V, E, T = 3, 7, 16, 32, 50, 16, 4
+    assert torch.ops.cvc.embed_relu(m(V, E), m(B, T, dtype=torch.int64)).shape == (B, T, E)
+    assert torch.ops.cvc.linear(m(B, R), m(A, R), m(A)).shape == (B, A)
+    c, a, fm = torch.ops.cvc.attn_fwd(0, m(B, A), m(1, A), m(1), 1.0, m(B, N, A), m(B, N, R), None, None)
+    assert c.shape == (B, R) and a.shape == (B, N) and fm.numel() == 0
+    h, c2, g = torch.ops.cvc.lstm_cell(m(B, 3 * R), m(B, R), m(B, R), m(4 * R, 3 * R), m(4 * R, R), m(4 * R), m(4 * R))
+    assert h.shape == (B, R) and c2.shape == (B, R) and g.shape == (B, 4 * R)
+    loss, amax, lse = torch.ops.cvc.vocab_nll(m(B * T, V), m(B * T, dtype=torch.int64), m(B * T))
+    assert loss.shape == (1,) and amax.dtype == torch.int64 and lse.shape == (B * T,)
+    assert torch.ops.cvc.grounder(m(B, T, 24), m(B, N, 24), None, None).shape == (B, T, N)
+    w, lp = torch.ops.cvc.top2_unk(m(B, V), 1)
+    assert w.dtype == torch.int64 and lp.shape == (B,)
