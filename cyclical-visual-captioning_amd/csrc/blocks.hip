@@ -40,6 +40,13 @@ const Entry table[] = {
     CVC_B(cvc_gemm_force_generic),
     CVC_B(cvc_tile_gemm_loaders),
     CVC_B(cvc_gru_persistent_waves8),
+    CVC_B(cvc_relu_dropout_fwd),
+    CVC_B(cvc_relu_dropout_bwd),
+    CVC_B(cvc_bn_workspace),
+    CVC_B(cvc_bn_relu_train_fwd),
+    CVC_B(cvc_bn_relu_train_bwd),
+    CVC_B(cvc_class_softmax_bwd),
+    CVC_B(cvc_layernorm_cat_bwd),
 #ifdef CVC_EXPERIMENTAL
     CVC_B(cvc_gsk_plan),
     CVC_B(cvc_gsk_gemm),

@@ -33,35 +33,50 @@ def usable(x: torch.Tensor) -> bool:
 
 
 def usable_train(x: torch.Tensor) -> bool:
-    """Autograd path: cvc.functional.linear (tile GEMM forward for many rows, tile GEMM dW / dX in the backward)."""
-    return (ENABLED and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
-            and x.numel() // max(1, x.shape[-1]) >= MIN_ROWS)
+    """Autograd path: cvc.functional.linear (skinny / tile GEMM forward, tile GEMM dW / dX in the backward), any row count."""
+    return ENABLED and x.is_cuda and x.dtype == torch.float32 and torch.is_grad_enabled()
 
 
-def apply(layer: nn.Module, x: torch.Tensor) -> torch.Tensor:
-    """layer(x) for `nn.Linear` or `nn.Sequential(nn.Linear, nn.ReLU[, nn.Dropout])` in eval mode."""
+def _tail(rest, y, site):
+    """ReLU / Dropout modules of a block applied one by one (torch formulation); the Dropout goes through cvc.dropout.apply so that
+    its mask is the site's (in-kernel generator, or dictated by a test)"""
+    from . import dropout
+    for m in rest:
+        y = dropout.apply(m, y, site) if (isinstance(m, nn.Dropout) and site is not None) else m(y)
+    return y
+
+
+def apply(layer: nn.Module, x: torch.Tensor, site: str = None) -> torch.Tensor:
+    """layer(x) for `nn.Linear` or `nn.Sequential(nn.Linear, nn.ReLU[, nn.Dropout])`.  site: the name of the block's dropout
+    (cvc/dropout.py) -- in train() its mask comes from the in-kernel generator."""
     lin = layer if isinstance(layer, nn.Linear) else (layer[0] if isinstance(layer, nn.Sequential) and len(layer) > 0 else None)
     if not isinstance(lin, nn.Linear):
         return layer(x)
     rest = [] if layer is lin else list(layer)[1:]
     if not all(isinstance(m, (nn.ReLU, nn.Dropout)) for m in rest):
         return layer(x)
-    if usable_train(x) and x.shape[-1] % 4 == 0 and lin.out_features % 4 == 0:
-        from . import functional as F_                      # under autograd: the hot path's linear (no library GEMM either way)
-        y = F_.linear(x, lin.weight, lin.bias)
-        for m in rest:
-            y = m(y)                                        # ReLU / Dropout as the module has them
-        return y
+    if usable_train(x) and lin.out_features % 4 == 0:
+        # under autograd: the hot path's linear (tile GEMM forward, dW / dX products in the backward) and, for the reference's
+        # Linear -> ReLU -> Dropout blocks, ONE kernel for bias + ReLU + dropout with the mask generated there (csrc/encoder_train.hip)
+        from . import functional as F_, encoder_ops, dropout
+        w, xx = lin.weight, x
+        if x.shape[-1] % 4 != 0:                            # an odd input width (loc_fc: 5): zero columns up to a multiple of 4
+            pad = 4 - x.shape[-1] % 4
+            xx, w = torch.nn.functional.pad(x, (0, pad)), torch.nn.functional.pad(lin.weight, (0, pad))
+        has_relu = any(isinstance(m, nn.ReLU) for m in rest)
+        drop = next((m for m in rest if isinstance(m, nn.Dropout)), None)
+        drop_on = drop is not None and drop.training and drop.p > 0
+        if has_relu and encoder_ops.usable_train(x) and (site is not None or not drop_on) and (not drop_on or (dropout.in_kernel(x) and drop.p < 1)):
+            return encoder_ops.relu_dropout(F_.linear(xx, w, None), drop if drop_on else None, site or "", bias=lin.bias)
+        return _tail(rest, F_.linear(xx, w, lin.bias), site)
     if not usable(x) or layer.training:
         if x.is_cuda and ENABLED and x.numel() // max(1, x.shape[-1]) >= MIN_ROWS:
             hip.warn_once("dense-library", "a dense encoder layer over >= %d rows runs on the library GEMM (%s)" % (
                 MIN_ROWS, "module in train() mode without autograd" if layer.training else f"dtype {x.dtype}"))
-        return layer(x)
+        return _tail(rest, lin(x), site)
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
-    y = hip.tile_mm(x2, _weight_operand(lin))
-    if lin.bias is not None:
-        y += lin.bias
+    y = hip.tile_mm(x2, _weight_operand(lin), bias=lin.bias)
     if any(isinstance(m, nn.ReLU) for m in rest):
         y.relu_()
     return y.view(*lead, -1)

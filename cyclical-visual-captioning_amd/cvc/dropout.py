@@ -58,7 +58,11 @@ def keep_mask(site: str, shape, p: float, device) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------- in-kernel generator
 IN_KERNEL = os.environ.get("CVC_DROPOUT_KERNEL", "1") != "0"        # False: masks as tensors from torch.bernoulli (A/B)
-_SITES = {"emb_a": 1, "emb_b": 2, "emb_c": 3, "vis_embed": 4}
+_SITES = {"emb_a": 1, "emb_b": 2, "emb_c": 3, "vis_embed": 4,
+          # the once-per-clip encoder's dropouts in train() (model/backbone.py:55-79, 103-106): Linear -> ReLU -> Dropout blocks, the class
+          # table's dropout inside the class similarity, the GRU's inter-layer dropout
+          "enc.loc_fc": 16, "enc.fc_embed": 17, "enc.seg_info": 18, "enc.att0": 19, "enc.att1": 20, "enc.pool_embed": 21,
+          "enc.ctx2pool_grd": 22, "enc.vis_table": 23, "enc.gru.0": 24, "enc.gru.1": 25, "enc.gru.2": 26}
 _states = {}
 _seed: Optional[int] = None
 
@@ -150,3 +154,14 @@ def apply(module: torch.nn.Dropout, x: torch.Tensor, site: Optional[str]) -> tor
     if in_kernel(x) and x.dtype == torch.float32 and module.p < 1:
         return _DropoutRng.apply(x, rng_state(x.device), site_id(site), float(module.p))
     return module(x)
+
+
+def apply_p(x: torch.Tensor, p: float, site: str) -> torch.Tensor:
+    """F.dropout(x, p, training=True) with the mask of `site`: in-kernel generator on the GPU, dictated under `injected`, else torch's"""
+    if p <= 0:
+        return x
+    if _inject is not None:
+        return x * keep_mask(site, x.shape, p, x.device)
+    if in_kernel(x) and x.dtype == torch.float32 and p < 1:
+        return _DropoutRng.apply(x, rng_state(x.device), site_id(site), float(p))
+    return torch.nn.functional.dropout(x, p, True)

@@ -221,6 +221,8 @@ def gru_forward_train(gru: nn.GRU, x: torch.Tensor) -> torch.Tensor:
             cur = _GruLayer.apply(cur, torch.cat(g("weight_ih"), 0), torch.stack(g("weight_hh")), torch.stack(g("bias_ih")),
                                   torch.stack(g("bias_hh")), m, F)
             if gru.training and gru.dropout > 0 and l + 1 < gru.num_layers:
-                cur = torch.nn.functional.dropout(cur, gru.dropout, True)
+                # nn.GRU's inter-layer dropout with the mask of site enc.gru.<l> from the in-kernel generator (cvc/dropout.py)
+                from . import dropout as _dropout
+                cur = _dropout.apply_p(cur, gru.dropout, "enc.gru.%d" % l)
         outs.append(cur.view(F, m, ndir * H).transpose(0, 1))
     return torch.cat(outs, 0) if len(outs) > 1 else outs[0].contiguous()

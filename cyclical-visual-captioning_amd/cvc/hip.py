@@ -119,6 +119,13 @@ SIGNATURES = {
     "cvc_lstm_pointwise_bwd4": [C.POINTER(GradSrc), _P, _P, C.c_uint, _F, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P],
     "cvc_vocab_head_nll_fwd": [_P, _I, _LL, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P],
     "cvc_scale_by_scalar": [_P, _P, _LL, _P, _P],
+    "cvc_relu_dropout_fwd": [_P, _P, _LL, _I, _P, C.c_uint, _F, _P, _P],
+    "cvc_relu_dropout_bwd": [_P, _P, _LL, _P, C.c_uint, _F, _P, _P],
+    "cvc_bn_workspace": [_LL, _I],
+    "cvc_bn_relu_train_fwd": [_P, _P, _P, _F, _F, _P, _P, _LL, _I, _P, _P, _P, _P, _P],
+    "cvc_bn_relu_train_bwd": [_P, _P, _P, _P, _P, _P, _LL, _I, _P, _P, _P, _P, _P],
+    "cvc_class_softmax_bwd": [_P, _P, _P, _P, _I, _I, _I, _P, _P],
+    "cvc_layernorm_cat_bwd": [C.POINTER(_P), C.POINTER(_LL), C.POINTER(_I), _I, _LL, _F, _P, _LL, C.POINTER(_P), C.POINTER(_LL), _P],
     "cvc_bbox_overlaps_fwd": [_P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P],
     "cvc_label_glue_fwd": [_P, _P, _LL, _LL, _LL, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "cvc_attn_nll_fwd": [_P, _LL, _LL, _P, _LL, _LL, _P, _I, _I, _I, _P, _P, _P],
@@ -235,7 +242,8 @@ BLOCKS = {
     "cvc_packed_lstm_train_pre_fwd", "cvc_packed_lstm_train_drop_fwd", "cvc_lstm_pointwise_bwd", "cvc_lstm_pointwise_bwd3",
     "cvc_lstm_pointwise_bwd3_drop", "cvc_pack_lstm_weights", "cvc_linear_nn_planes_fwd", "cvc_beam_select_parts", "cvc_tile_lstm_finish",
     "cvc_tile_lstm_finish_embgate", "cvc_tile_reorder_pack", "cvc_decode_num_launches", "cvc_gemm_force_generic",
-    "cvc_tile_gemm_loaders", "cvc_gru_persistent_waves8"}
+    "cvc_tile_gemm_loaders", "cvc_gru_persistent_waves8", "cvc_relu_dropout_fwd", "cvc_relu_dropout_bwd", "cvc_bn_workspace",
+    "cvc_bn_relu_train_fwd", "cvc_bn_relu_train_bwd", "cvc_class_softmax_bwd", "cvc_layernorm_cat_bwd"}
 EXPERIMENTAL = {
     "cvc_gsk_plan", "cvc_gsk_gemm", "cvc_attn_scores_qslab", "cvc_top2_slab", "cvc_packed_lstm_ks_slices", "cvc_packed_lstm_ks_fwd",
     "cvc_packed_lstm_ksf_fwd", "cvc_packed_lstm_ksx_local", "cvc_packed_lstm_ksx_fwd", "cvc_packed_lstm_wg_blocks",
@@ -263,7 +271,7 @@ def lib() -> C.CDLL:
         l.cvc_block.restype = C.c_void_p
         l.cvc_block.argtypes = [C.c_char_p]
         for name, argtypes in SIGNATURES.items():
-            restype = None if name in _VOID_RETURN else (C.c_longlong if name == "cvc_train_loop_bwd_ws" else C.c_int)
+            restype = None if name in _VOID_RETURN else (C.c_longlong if name in ("cvc_train_loop_bwd_ws", "cvc_bn_workspace") else C.c_int)
             if name in BLOCKS or name in EXPERIMENTAL:
                 addr = l.cvc_block(name.encode())
                 if not addr:

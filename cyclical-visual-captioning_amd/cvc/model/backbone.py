@@ -56,9 +56,9 @@ def _relu_drop(layer, p):
     return nn.Sequential(layer, nn.ReLU(), nn.Dropout(p))
 
 
-def project_and_mask(feat, projector, keep):
+def project_and_mask(feat, projector, keep, site=None):
     """reference model/modules.py:162-176 (`proj_masking`) without its host-side assert."""
-    out = dense.apply(projector, feat)
+    out = dense.apply(projector, feat, site)
     return out * keep.unsqueeze(-1).to(out.dtype)
 
 
@@ -130,7 +130,9 @@ class RegionalFeatureExtractorGVD(nn.Module):
     def class_similarity(self, g_pool_feats, pad):
         """softmax over detection classes of <class classifier, region feature> + class bias, padded
         regions filled with -1e8 before the softmax.  backbone.py:216-235."""
-        table = self.vis_embed(torch.arange(self.detect_size + 1, device=g_pool_feats.device))
+        from .. import dropout
+        ve = self.vis_embed
+        table = dropout.apply(ve[2], ve[1](ve[0](torch.arange(self.detect_size + 1, device=g_pool_feats.device))), "enc.vis_table")
         sim = torch.matmul(table, g_pool_feats.transpose(1, 2)) + self.vis_classifiers_bias.view(1, -1, 1)
         return F.softmax(sim.masked_fill(pad.unsqueeze(1), MIN_VALUE), dim=1)
 
@@ -162,22 +164,27 @@ class RegionalFeatureExtractorGVD(nn.Module):
         keep = ~pnt_mask[:, 1:]
 
         fc = segs_feat.mean(dim=1)
-        seg_info = self.seg_info_embed(num[:, 3:7].float())
-        # inference on the GPU: the fused kernels of csrc/encoder_ops.hip
+        seg_info = dense.apply(self.seg_info_embed, num[:, 3:7].float(), "enc.seg_info")
+        # inference on the GPU: the fused kernels of csrc/encoder_ops.hip; under autograd: their training forms (csrc/encoder_train.hip)
         fused = encoder_ops.usable(region_feats, self) and segs_feat.dtype == torch.float32
-        if not fused and region_feats.is_cuda and not torch.is_grad_enabled():
+        fused_t = (not fused) and encoder_ops.usable_train(region_feats) and segs_feat.dtype == torch.float32
+        if not (fused or fused_t) and region_feats.is_cuda:
             hip.warn_once("encoder-ops-library", "the encoder's class-similarity softmax / layer norms / frame-embedding epilogue run "
-                          "on library kernels (module in train() mode or non-fp32 input)")
+                          "on library kernels (non-fp32 input, dictated dropout masks, or train() mode without autograd)")
         if fused:
             fc_feats = encoder_ops.layernorm_cat([fc.float(), seg_info])
+        elif fused_t:
+            fc_feats = encoder_ops.layernorm_cat_train([fc.float(), seg_info])
         else:
             fc_feats = torch.cat((F.layer_norm(fc, [self.fc_feat_size - SEG_INFO_SIZE]),
                                   F.layer_norm(seg_info, [SEG_INFO_SIZE])), dim=-1)
 
-        g_pool_feats = project_and_mask(region_feats, self.ctx2pool_grd, keep)
+        g_pool_feats = project_and_mask(region_feats, self.ctx2pool_grd, keep, "enc.ctx2pool_grd")
         sim_rows = None
         if fused:
             sim, sim_rows = encoder_ops.class_similarity(self, g_pool_feats, pnt_mask[:, 1:])
+        elif fused_t:
+            sim, sim_rows = encoder_ops.class_similarity_train(self, g_pool_feats, pnt_mask[:, 1:])
         else:
             sim = self.class_similarity(g_pool_feats, pnt_mask[:, 1:])
 
@@ -189,9 +196,11 @@ class RegionalFeatureExtractorGVD(nn.Module):
         pool_feats = g_pool_feats
         if not self.enable_BUTD:
             loc = torch.cat((proposals[:, :, :4] / 720., proposals[:, :, 4:5] / float(self.num_sampled_frm)), dim=2)
-            loc_feats = self.loc_fc(loc.detach())
+            loc_feats = dense.apply(self.loc_fc, loc.detach(), "enc.loc_fc")
             if fused:
                 pool_feats = encoder_ops.layernorm_cat([g_pool_feats, loc_feats, sim_rows])
+            elif fused_t:
+                pool_feats = encoder_ops.layernorm_cat_train([g_pool_feats, loc_feats, sim_rows])
             else:
                 label_feat = sim.transpose(1, 2)
                 pool_feats = torch.cat((F.layer_norm(g_pool_feats, [g_pool_feats.size(-1)]),
@@ -231,16 +240,19 @@ class RegionalFeatureExtractorGVD(nn.Module):
          cls_loss) = self.get_conv_pooled_feats(segs_feat, proposals, mask_boxes, num, region_feats, gt_boxes, overlaps,
                                                 sample_idx, eval_obj_ground, replicate_feat)
         keep = ~pnt_mask[:, 1:]
-        fc_feats = self.fc_embed(fc_feats)
-        pool_feats = project_and_mask(pool_feats, self.pool_embed, keep)
+        fc_feats = dense.apply(self.fc_embed, fc_feats, "enc.fc_embed")
+        pool_feats = project_and_mask(pool_feats, self.pool_embed, keep, "enc.pool_embed")
         p_pool_feats = project_and_mask(pool_feats, self.ctx2pool_fc, keep)
 
         if self.att_input_mode in ('both', 'featmap'):
             rgb, motion = conv_feats[..., :RGB_DIM], conv_feats[..., RGB_DIM:RGB_DIM + MOTION_DIM]
             if encoder_ops.usable(conv_feats, self) and dense.usable(rgb) and (self.rnn_size // 2) % 4 == 0:
                 x = encoder_ops.frame_embed(self, rgb, motion)              # GEMMs + one fused epilogue (BN folded)
+            elif (encoder_ops.usable_train(conv_feats) and self.att_embed_aux[0].training and (self.rnn_size // 2) % 4 == 0
+                  and rgb.shape[-1] % 4 == 0 and motion.shape[-1] % 4 == 0):
+                x = encoder_ops.frame_embed_train(self, rgb, motion)        # train(): in-kernel dropout, BatchNorm on batch statistics
             else:
-                x = torch.cat((dense.apply(self.att_embed[0], rgb), dense.apply(self.att_embed[1], motion)), dim=2)
+                x = torch.cat((dense.apply(self.att_embed[0], rgb, "enc.att0"), dense.apply(self.att_embed[1], motion, "enc.att1")), dim=2)
                 x = self.att_embed_aux(x.transpose(1, 2)).transpose(1, 2).contiguous()      # BatchNorm1d over channels
             x = self._frame_context(x)
             x = x.masked_fill(sample_idx_mask, 0)

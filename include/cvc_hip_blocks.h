@@ -98,6 +98,32 @@ int cvc_gemm_force_generic(int on);
 /* coverage hooks: select among kernel forms that the default path picks per shape (identical results) */
 int cvc_tile_gemm_loaders(int on);
 int cvc_gru_persistent_waves8(int on);   /* A/B + test hook: 1 (default) = 8 waves per workgroup where H % 256 == 0, 0 = always 4 */
+/* ---- training forms of the once-per-clip encoder's small pieces (csrc/encoder_train.hip; model/backbone.py:55-81, 215-235,
+ * 274-277, 325-333) -- used by the host mirror's encoder in train() mode (cvc/encoder_ops.py):
+ *   cvc_relu_dropout_fwd / _bwd : y = max(x + bias, 0) * keep-mask multiplier of (site, flat index) -- the ReLU -> Dropout tail of the
+ *       reference's Linear -> ReLU -> Dropout blocks, mask generated in the kernel (rng_state NULL or p == 0: plain ReLU);
+ *       dx = dy * multiplier * [y > 0].  N % 4 == 0.
+ *   cvc_bn_relu_train_fwd / _bwd : nn.BatchNorm1d on BATCH statistics over the rows of x [rows, C] (biased variance; running
+ *       statistics updated with `momentum` and the unbiased variance, as the module does) followed by ReLU; save_mean / save_invstd [C]
+ *       are kept for the backward, which also returns dgamma / dbeta.  workspace: cvc_bn_workspace(rows, C) floats.  C % 4 == 0.
+ *   cvc_class_softmax_bwd : backward of cvc_class_softmax_fwd: p_rows [B*N, C] its softmax output, d_rows [B*N, C] / d_sim [B, C, N]
+ *       (either nullable) the gradients of its two output layouts -> d_logits [B*N, C] (zero for padded regions).
+ *   cvc_layernorm_cat_bwd : backward of cvc_layernorm_cat_fwd: d_out [rows, ld_out] -> dxs[s] [rows, lddx[s]] (nullable per input). */
+int cvc_relu_dropout_fwd(const float* x, const float* bias, long long rows, int N, const uint32_t* rng_state, unsigned site,
+                         float p, float* y, cvc_stream_t stream);
+int cvc_relu_dropout_bwd(const float* dy, const float* y, long long n, const uint32_t* rng_state, unsigned site, float p, float* dx,
+                         cvc_stream_t stream);
+long long cvc_bn_workspace(long long rows, int C);
+int cvc_bn_relu_train_fwd(const float* x, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                          float* running_var, long long rows, int C, float* y, float* save_mean, float* save_invstd,
+                          float* workspace, cvc_stream_t stream);
+int cvc_bn_relu_train_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* save_mean,
+                          const float* save_invstd, long long rows, int C, float* dx, float* dgamma, float* dbeta,
+                          float* workspace, cvc_stream_t stream);
+int cvc_class_softmax_bwd(const float* p_rows, const float* d_rows, const float* d_sim, const uint8_t* pad, int B, int N, int C,
+                          float* d_logits, cvc_stream_t stream);
+int cvc_layernorm_cat_bwd(const float* const* xs, const long long* ldx, const int* widths, int nseg, long long rows, float eps,
+                          const float* d_out, long long ld_out, float* const* dxs, const long long* lddx, cvc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -543,3 +543,70 @@ def test_encoder_forward_wide_golden_on_the_hip_forms(tmp_path):
             np.testing.assert_allclose(res[9].cpu().numpy(), g8[name + "out.cls_loss"], rtol=2e-4, atol=1e-6)
     finally:
         dense.MIN_ROWS = min_rows
+
+
+@pytest.mark.gpu
+def test_encoder_train_mode_runs_on_own_kernels_and_matches_the_torch_formulation(tmp_path):
+    """train(): every Linear -> ReLU -> Dropout block (mask generated in the kernel), BatchNorm1d on batch statistics + ReLU, the
+    class-similarity softmax, the layer norms and the GRU's inter-layer dropout on the build's kernels (csrc/encoder_train.hip) --
+    outputs, every parameter gradient and the BatchNorm running statistics against the torch formulation of the same module fed the
+    SAME masks (the generator's host restatement, dictated through cvc.dropout.injected); no library fallback announced."""
+    import dataclasses
+    from cvc import dropout, hip
+    from cvc.model.backbone import RegionalFeatureExtractorGVD
+    from cvc.misc import utils
+    dev = torch.device("cuda:0")
+    Dw = dataclasses.replace(D, R=256, A=64, F=9, B=5)
+    tables = synth.detectron_tables(Dw, 3)
+    o = make_opts(Dw, seq_per_img=1, enable_BUTD=False, att_input_mode="both", num_sampled_frm=4, finetune_cnn=False,
+                  att_feat_size=Dw.G, fc_feat_size=synth.SEG_FEAT_DIM, t_attn_size=Dw.F, second_drop_prob=0.3, att_model="topdown",
+                  t_attn_mode="bigru", itod={i + 1: "d%d" % i for i in range(Dw.DET)},
+                  vg_cls=["vg%d" % i for i in range(tables["glove_vg_cls"].shape[0])],
+                  glove_clss=torch.from_numpy(tables["glove_clss"]), glove_vg_cls=torch.from_numpy(tables["glove_vg_cls"]),
+                  detectron_tables=tables, test_mode=False)
+    torch.manual_seed(0)
+    enc = RegionalFeatureExtractorGVD(o).to(dev).train()
+    inp = to_dev(synth.encoder_inputs(Dw, 3), dev)
+    overlaps = utils.bbox_overlaps(inp["proposals"], inp["gt_bboxs"], inp["frm_mask"] | inp["pnt_mask_in"][:, 1:].unsqueeze(-1))
+    bn = enc.att_embed_aux[0]
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    dropout.seed(424242)
+    dropout.advance(dev)
+    warned = set(hip._warned)
+    enc.zero_grad(set_to_none=True)
+    out = run_encoder(enc, inp, overlaps)
+    probe_loss(out).backward()
+    assert set(hip._warned) == warned, set(hip._warned) - warned             # no library fallback announced in train()
+    got = ([t.detach().clone() if isinstance(t, torch.Tensor) else t for t in out],
+           {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None}, bn.running_mean.clone(), bn.running_var.clone())
+    # ---- the torch formulation with the same masks
+    ps = {"enc.pool_embed": 0.3, "enc.gru.0": 0.2}
+    used = []
+
+    def masks(site, shape):
+        used.append(site)
+        return dropout.host_mask(site, shape, ps.get(site, 0.5), dev)
+    bn.running_mean.copy_(rm0); bn.running_var.copy_(rv0)
+    enc.zero_grad(set_to_none=True)
+    with dropout.injected(masks):
+        ref = run_encoder(enc, inp, overlaps)
+        probe_loss(ref).backward()
+    assert {"enc.loc_fc", "enc.fc_embed", "enc.seg_info", "enc.att0", "enc.att1", "enc.pool_embed", "enc.ctx2pool_grd", "enc.vis_table",
+            "enc.gru.0"} <= set(used), sorted(set(used))
+    for a, b in zip(got[0], ref):
+        if isinstance(a, torch.Tensor) and a.dtype.is_floating_point:
+            np.testing.assert_allclose(a.cpu().numpy(), b.detach().cpu().numpy(), rtol=2e-4, atol=2e-5)
+        elif isinstance(a, torch.Tensor):
+            assert torch.equal(a, b)
+    np.testing.assert_allclose(got[2].cpu().numpy(), bn.running_mean.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(got[3].cpu().numpy(), bn.running_var.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    checked = 0
+    rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    for k, p in enc.named_parameters():
+        if p.grad is None:
+            assert k not in got[1], k
+            continue
+        assert k in got[1], k
+        assert rel(got[1][k], p.grad) < 1e-3, (k, rel(got[1][k], p.grad))
+        checked += 1
+    assert checked >= 20
