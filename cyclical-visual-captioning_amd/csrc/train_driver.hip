@@ -205,41 +205,66 @@ int nn(const float* dy_q, int K, int M, const cvc_nn_seg* segs, int nsegs, float
     return finished ? cvc_linear_nn_fwd(dy_q, K, M, segs, nsegs, ks, ws, st) : cvc_linear_nn_planes_fwd(dy_q, K, M, segs, nsegs, ks, ws, st);
 }
 
-int run_bwd(const cvc_train_loop& L, hipStream_t st, int* launches) {
-    const int B = L.B, T = L.T, R = L.R, A = L.A, N = L.N, F = L.F;
-    const size_t BR = (size_t)B * R, BG = (size_t)B * 4 * R;
-    const BwdWs w = carve(L.bwd_ws, B, R, L.kind == 0 ? A : 0);
-    const bool feat_grads = L.kind == 0 && (L.d_pool || L.d_conv);     // the context-feature gradient reads d_ctx as a finished tensor
+inline cvc_grad_src rows_from(cvc_grad_src g, int row0) {
+    if (g.p != nullptr) g.p += (size_t)row0 * g.ld;
+    return g;
+}
+
+// Back-propagation through time of one loop, or of both loops at once (LA = loop A or null, LC = loop C or null): the loops share the
+// LSTM cells, so with both present (B_A + B_C <= 64) every backward-data product takes the two loops' gate gradients as ONE operand
+// (loop A's rows first) and streams its weights once.  The attention backward and the h2attn product belong to loop A alone.
+int run_bwd(const cvc_train_loop* LA, const cvc_train_loop* LC, hipStream_t st, int* launches) {
+    const cvc_train_loop& L0 = LA ? *LA : *LC;           // shared: T, R, weights, workspace
+    const int T = L0.T, R = L0.R;
+    const int BA = LA ? LA->B : 0, BC = LC ? LC->B : 0, M = BA + BC;
+    const int A = LA ? LA->A : 0, N = LA ? LA->N : 0, F = LA ? LA->F : 0;
+    const BwdWs w = carve(L0.bwd_ws, 64, R, A);
+    const bool feat_grads = LA != nullptr && (LA->d_pool || LA->d_conv);     // the context-feature gradient reads d_ctx as a finished tensor
     const cvc_grad_src none{nullptr, 0, 0, 0};
-    cvc_grad_src g_hl_a = none, g_hl_b = none, g_ha_prev = none;       // what step t + 1 left for step t
+    cvc_grad_src g_hl_a = none, g_hl_b = none, g_ha_prev = none;       // what step t + 1 left for step t (all M rows)
+    const cvc_train_loop* loops[2] = {LA, LC};
+    const int row0[2] = {0, BA};
     int n = 0;
-    if (L.dgsum_att) CVC_TRY(zero(L.dgsum_att, BG, st));
-    if (L.dgsum_lang) CVC_TRY(zero(L.dgsum_lang, BG, st));
+    for (int s = 0; s < 2; ++s) {
+        if (!loops[s]) continue;
+        g_prof_loop = 2 + loops[s]->kind;
+        const size_t BG = (size_t)loops[s]->B * 4 * R;
+        if (loops[s]->dgsum_att) CVC_TRY(zero(loops[s]->dgsum_att, BG, st));
+        if (loops[s]->dgsum_lang) CVC_TRY(zero(loops[s]->dgsum_lang, BG, st));
+    }
     for (int t = T - 1; t >= 0; --t) {
         const bool last = t + 1 == T;
-        // ---- language cell: d_h = dropout'(d_out[t]) + the next step's two uses of h_lang(t)
-        {
-            const cvc_grad_src src[3] = {g_hl_a, g_hl_b, none};
-            CVC_TRY_K(K_PW_LANG, cvc_lstm_pointwise_bwd4(src, L.d_out + (size_t)t * BR, L.p > 0.f ? L.rng_state : nullptr, L.site0 + (unsigned)t, L.p,
-                                            last ? nullptr : w.d_c_lang, L.g_lang + (size_t)t * BG, L.c_lang + (size_t)t * BR,
-                                            L.c_lang + (size_t)(t + 1) * BR, B, R, L.dg_lang + (size_t)t * BG, w.d_c_lang, w.dgq,
-                                            L.dgsum_lang, st));
+        // ---- language cells: d_h = dropout'(d_out[t]) + the next step's two uses of h_lang(t)
+        for (int s = 0; s < 2; ++s) {
+            if (!loops[s]) continue;
+            const cvc_train_loop& L = *loops[s];
+            g_prof_loop = 2 + L.kind;
+            const size_t BR = (size_t)L.B * R, BG = (size_t)L.B * 4 * R;
+            const cvc_grad_src src[3] = {rows_from(g_hl_a, row0[s]), rows_from(g_hl_b, row0[s]), none};
+            float* d_c = w.d_c_lang + (size_t)row0[s] * R;
+            CVC_TRY_K(K_PW_LANG, cvc_lstm_pointwise_bwd4(src, L.d_out + (size_t)t * BR, L.p > 0.f ? L.rng_state : nullptr, L.site0 + (unsigned)t,
+                                                         L.p, last ? nullptr : d_c, L.g_lang + (size_t)t * BG, L.c_lang + (size_t)t * BR,
+                                                         L.c_lang + (size_t)(t + 1) * BR, L.B, R, L.dg_lang + (size_t)t * BG, d_c, w.dgq,
+                                                         L.dgsum_lang, row0[s], st));
         }
+        g_prof_loop = 2 + L0.kind;
         cvc_grad_src g_ctx = none, g_ha_a = none, g_ha_b = none;
         {
             cvc_nn_seg segs[3];
             cvc_grad_src out[3];
             int ns = 0, i_ctx = -1, i_ha, i_hl = -1;
-            if (L.kind == 0) { i_ctx = ns; segs[ns++] = cvc_nn_seg{L.w_ih_lang, w.d_ctx, L.ld_ih_lang, R, R}; }
-            i_ha = ns; segs[ns++] = cvc_nn_seg{L.w_ih_lang + R, w.d_ha_a, L.ld_ih_lang, R, R};
-            if (t > 0) { i_hl = ns; segs[ns++] = cvc_nn_seg{L.w_hh_lang, w.d_hl_a, R, R, R}; }
-            CVC_TRY_K(K_NN_LANG, nn(w.dgq, 4 * R, B, segs, ns, w.nn_l, out, feat_grads, st));
+            if (LA) { i_ctx = ns; segs[ns++] = cvc_nn_seg{L0.w_ih_lang, w.d_ctx, L0.ld_ih_lang, R, R}; }
+            i_ha = ns; segs[ns++] = cvc_nn_seg{L0.w_ih_lang + R, w.d_ha_a, L0.ld_ih_lang, R, R};
+            if (t > 0) { i_hl = ns; segs[ns++] = cvc_nn_seg{L0.w_hh_lang, w.d_hl_a, R, R, R}; }
+            CVC_TRY_K(K_NN_LANG, nn(w.dgq, 4 * R, M, segs, ns, w.nn_l, out, feat_grads, st));
             if (i_ctx >= 0) g_ctx = out[i_ctx];
             g_ha_a = out[i_ha];
             g_hl_a = i_hl >= 0 ? out[i_hl] : none;
         }
-        if (L.kind == 0) {
-            // ---- attention (both feature sets) and h2attn
+        if (LA) {
+            // ---- attention (both feature sets) and h2attn: loop A's rows (the first BA of every operand)
+            const cvc_train_loop& L = *LA;
+            const int B = BA;
             cvc_attn_set sets[2]{};
             sets[0].proj = L.ppool; sets[0].ctx = L.pool; sets[0].attn = L.attn_r + (size_t)t * B * N; sets[0].n = N;
             sets[0].scores = L.ds_r + (size_t)t * B * N;
@@ -257,17 +282,23 @@ int run_bwd(const cvc_train_loop& L, hipStream_t st, int* launches) {
             cvc_nn_seg seg{L.w_h, w.d_ha_b, R, R, R};
             CVC_TRY_K(K_NN_H2ATTN, nn(w.dqq, A, B, &seg, 1, w.nn_h, &g_ha_b, false, st));
         }
-        // ---- attention cell: d_h = language cell's input + attention query + next step's recurrence
-        {
-            const cvc_grad_src src[3] = {g_ha_a, g_ha_b, g_ha_prev};
-            CVC_TRY_K(K_PW_ATT, cvc_lstm_pointwise_bwd4(src, nullptr, nullptr, 0, 0.f, last ? nullptr : w.d_c_att, L.g_att + (size_t)t * BG,
-                                            L.c_att + (size_t)t * BR, L.c_att + (size_t)(t + 1) * BR, B, R, L.dg_att + (size_t)t * BG,
-                                            w.d_c_att, w.dgq, L.dgsum_att, st));
+        // ---- attention cells: d_h = language cell's input + attention query (loop A) + next step's recurrence
+        for (int s = 0; s < 2; ++s) {
+            if (!loops[s]) continue;
+            const cvc_train_loop& L = *loops[s];
+            g_prof_loop = 2 + L.kind;
+            const size_t BR = (size_t)L.B * R, BG = (size_t)L.B * 4 * R;
+            const cvc_grad_src src[3] = {rows_from(g_ha_a, row0[s]), L.kind == 0 ? g_ha_b : none, rows_from(g_ha_prev, row0[s])};
+            float* d_c = w.d_c_att + (size_t)row0[s] * R;
+            CVC_TRY_K(K_PW_ATT, cvc_lstm_pointwise_bwd4(src, nullptr, nullptr, 0, 0.f, last ? nullptr : d_c, L.g_att + (size_t)t * BG,
+                                                        L.c_att + (size_t)t * BR, L.c_att + (size_t)(t + 1) * BR, L.B, R, L.dg_att + (size_t)t * BG,
+                                                        d_c, w.dgq, L.dgsum_att, row0[s], st));
         }
+        g_prof_loop = 2 + L0.kind;
         if (t > 0) {
-            cvc_nn_seg segs[2] = {cvc_nn_seg{L.w_ih_att, w.d_hl_b, L.ld_ih_att, R, R}, cvc_nn_seg{L.w_hh_att, w.d_ha_prev, R, R, R}};
+            cvc_nn_seg segs[2] = {cvc_nn_seg{L0.w_ih_att, w.d_hl_b, L0.ld_ih_att, R, R}, cvc_nn_seg{L0.w_hh_att, w.d_ha_prev, R, R, R}};
             cvc_grad_src out[2];
-            CVC_TRY_K(K_NN_ATT, nn(w.dgq, 4 * R, B, segs, 2, w.nn_a, out, false, st));
+            CVC_TRY_K(K_NN_ATT, nn(w.dgq, 4 * R, M, segs, 2, w.nn_a, out, false, st));
             g_hl_b = out[0];
             g_ha_prev = out[1];
         }
@@ -295,8 +326,18 @@ extern "C" int cvc_train_loop_bwd(const cvc_train_loop* loop, cvc_stream_t strea
     if (!loop) return CVC_E_BADARG;
     int rc = validate(*loop, true);
     if (rc) return rc;
-    g_prof_loop = 2 + loop->kind;
-    return run_bwd(*loop, (hipStream_t)stream, nullptr);
+    return loop->kind == 0 ? run_bwd(loop, nullptr, (hipStream_t)stream, nullptr) : run_bwd(nullptr, loop, (hipStream_t)stream, nullptr);
+}
+
+extern "C" int cvc_train_loops_bwd_joint(const cvc_train_loop* loop_a, const cvc_train_loop* loop_c, cvc_stream_t stream) {
+    if (!loop_a || !loop_c || loop_a->kind != 0 || loop_c->kind != 1) return CVC_E_BADARG;
+    int rc = validate(*loop_a, true);
+    if (!rc) rc = validate(*loop_c, true);
+    if (rc) return rc;
+    if (loop_a->B + loop_c->B > 64 || loop_a->T != loop_c->T || loop_a->R != loop_c->R || loop_a->w_ih_att != loop_c->w_ih_att ||
+        loop_a->w_hh_att != loop_c->w_hh_att || loop_a->w_ih_lang != loop_c->w_ih_lang || loop_a->w_hh_lang != loop_c->w_hh_lang)
+        return CVC_E_BADARG;
+    return run_bwd(loop_a, loop_c, (hipStream_t)stream, nullptr);
 }
 
 // ---- measurement aid: per-launch timing of the drivers' entry points (bench.py --mode train).  enable > 0: room for `enable`

@@ -526,7 +526,8 @@ __device__ __forceinline__ float hsrc_load(const cvc_grad_src& g, int m, int j) 
 }
 __global__ __launch_bounds__(WG) void lstm_pointwise_bwd4_kernel(HSrc3 src, const float* d_hd, DropSpec rng, const float* d_c,
                                                                  const float* gates, const float* c_prev, const float* c_new, int M,
-                                                                 int R, float* d_gates, float* d_c_prev, float* d_gates_q, float* dg_sum) {
+                                                                 int R, float* d_gates, float* d_c_prev, float* d_gates_q, float* dg_sum,
+                                                                 int q_row0) {
     const int j = blockIdx.x * WG + threadIdx.x;
     const int m = blockIdx.y;
     if (j >= R) return;
@@ -549,8 +550,8 @@ __global__ __launch_bounds__(WG) void lstm_pointwise_bwd4_kernel(HSrc3 src, cons
     d_gates[g0 + 3 * R] = d3;
     d_c_prev[o] = dcn * fg;
     if (dg_sum != nullptr) { dg_sum[g0] = s0 + d0; dg_sum[g0 + R] = s1 + d1; dg_sum[g0 + 2 * R] = s2 + d2; dg_sum[g0 + 3 * R] = s3 + d3; }
-    if (d_gates_q != nullptr) {
-        const size_t q0 = ((size_t)(j >> 2) * 64 + m) * 4 + (j & 3), qs = (size_t)(R >> 2) * 256;
+    if (d_gates_q != nullptr) {        // (q_row0: this launch's rows sit behind another loop's in a joint 64-row operand)
+        const size_t q0 = ((size_t)(j >> 2) * 64 + q_row0 + m) * 4 + (j & 3), qs = (size_t)(R >> 2) * 256;
         d_gates_q[q0] = d0;
         d_gates_q[q0 + qs] = d1;
         d_gates_q[q0 + 2 * qs] = d2;
@@ -975,16 +976,16 @@ extern "C" int cvc_lstm_pointwise_bwd3_drop(const float* d_h, const float* d_h2,
 
 extern "C" int cvc_lstm_pointwise_bwd4(const cvc_grad_src* d_h, const float* d_hd, const uint32_t* rng_state, unsigned site, float p,
                                        const float* d_c, const float* gates, const float* c_prev, const float* c_new, int M, int R,
-                                       float* d_gates, float* d_c_prev, float* d_gates_q, float* dg_sum, cvc_stream_t stream) {
+                                       float* d_gates, float* d_c_prev, float* d_gates_q, float* dg_sum, int q_row0, cvc_stream_t stream) {
     if (!d_h || !gates || !c_prev || !c_new || !d_gates || !d_c_prev || M < 1 || R < 1 || p < 0.f || p >= 1.f) return CVC_E_BADARG;
-    if (d_gates_q != nullptr && (M > 64 || (R & 3))) return CVC_E_BADARG;
+    if (d_gates_q != nullptr && (q_row0 < 0 || q_row0 + M > 64 || (R & 3))) return CVC_E_BADARG;
     HSrc3 src;
     for (int i = 0; i < 3; ++i) {
         src.s[i] = d_h[i];
         if (src.s[i].p != nullptr && (src.s[i].nplanes < 1 || src.s[i].ld < R)) return CVC_E_BADARG;
     }
     hipLaunchKernelGGL(lstm_pointwise_bwd4_kernel, dim3((R + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, src, d_hd,
-                       cvc_drop_spec(rng_state, site, p), d_c, gates, c_prev, c_new, M, R, d_gates, d_c_prev, d_gates_q, dg_sum);
+                       cvc_drop_spec(rng_state, site, p), d_c, gates, c_prev, c_new, M, R, d_gates, d_c_prev, d_gates_q, dg_sum, q_row0);
     return cvc_launch_status();
 }
 

@@ -204,10 +204,17 @@ class _VocabHeadNLL(torch.autograd.Function):
     backward is pre = w * (softmax - onehot), which the backward scales by the upstream scalar and feeds to nn.Linear's products."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, target, w):
+    def compute(x, weight, bias, target, w):
+        """the forward's arithmetic: -> (loss [1], argmax [M], pre [M, V])"""
+        parts = hip.tile_mm(_rows(x), hip.weight_operand(weight), parts_only=True)
+        return hip.vocab_head_nll_fwd(parts, bias, target.contiguous(), w.contiguous())
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, target, w, done):
+        # done: compute()'s result on the same x, formed earlier (the argmax was needed before x's final graph node existed:
+        # cvc.train_loops._Loop, joint back-propagation) -- this node then only attaches the backward
         x = _rows(x)
-        parts = hip.tile_mm(x, hip.weight_operand(weight), parts_only=True)
-        loss, amax, pre = hip.vocab_head_nll_fwd(parts, bias, target.contiguous(), w.contiguous())
+        loss, amax, pre = done if done is not None else _VocabHeadNLL.compute(x, weight, bias, target, w)
         ctx.save_for_backward(weight, bias, x, pre)
         ctx.has_bias = bias is not None
         ctx.key = ("linear", weight.data_ptr())
@@ -222,12 +229,19 @@ class _VocabHeadNLL(torch.autograd.Function):
         dy = hip.scale_by_scalar(pre, g.contiguous().reshape(1))
         ni = ctx.needs_input_grad
         d_w, d_b, d_x = _linear_backward(ctx, weight, bias, [x], dy, (ni[1], ni[2], ni[0]))
-        return d_x, d_w, d_b, None, None
+        return d_x, d_w, d_b, None, None, None
 
 
-def vocab_head_nll(x: Tensor, weight: Tensor, bias: Optional[Tensor], target: Tensor, w: Tensor) -> Tuple[Tensor, Tensor]:
-    """-> (sum_m w[m] * -log_softmax(x W^T + b)[m, target[m]] as a [1] tensor, argmax over V per row [M] int64); x [M, K]"""
-    return _VocabHeadNLL.apply(x, weight, bias, target.reshape(-1), w.reshape(-1))
+def vocab_head_nll(x: Tensor, weight: Tensor, bias: Optional[Tensor], target: Tensor, w: Tensor, done=None) -> Tuple[Tensor, Tensor]:
+    """-> (sum_m w[m] * -log_softmax(x W^T + b)[m, target[m]] as a [1] tensor, argmax over V per row [M] int64); x [M, K]
+    done: vocab_head_nll_compute()'s result for the same x"""
+    return _VocabHeadNLL.apply(x, weight, bias, target.reshape(-1), w.reshape(-1), done)
+
+
+def vocab_head_nll_compute(x: Tensor, weight: Tensor, bias: Optional[Tensor], target: Tensor, w: Tensor):
+    """the arithmetic of vocab_head_nll without its graph node (-> an opaque `done` for vocab_head_nll; done[1] is the argmax)"""
+    with torch.no_grad():
+        return _VocabHeadNLL.compute(x.detach(), weight.detach(), None if bias is None else bias.detach(), target.reshape(-1), w.reshape(-1))
 
 
 def vocab_head_nll_ok(x: Tensor, weight: Tensor) -> bool:

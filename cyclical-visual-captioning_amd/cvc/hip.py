@@ -116,7 +116,7 @@ SIGNATURES = {
     "cvc_attn_wsum_quad_rm": [C.POINTER(AttnSet), _I, _I, _I, _P, _P, _P],
     "cvc_attn_bwd_pair": [_I, C.POINTER(GradSrc), _P, _P, _F, C.POINTER(AttnSet), _I, C.POINTER(GradSrc), _I, _I, _I, _I, _P, _P, _P,
                           C.POINTER(_P), C.POINTER(_P), _P],
-    "cvc_lstm_pointwise_bwd4": [C.POINTER(GradSrc), _P, _P, C.c_uint, _F, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P],
+    "cvc_lstm_pointwise_bwd4": [C.POINTER(GradSrc), _P, _P, C.c_uint, _F, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P],
     "cvc_vocab_head_nll_fwd": [_P, _I, _LL, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P],
     "cvc_scale_by_scalar": [_P, _P, _LL, _P, _P],
     "cvc_relu_dropout_fwd": [_P, _P, _LL, _I, _P, C.c_uint, _F, _P, _P],
@@ -133,6 +133,7 @@ SIGNATURES = {
     "cvc_train_loop_bwd_ws": [_I, _I, _I],
     "cvc_train_loop_fwd": [C.POINTER(TrainLoop), _P],
     "cvc_train_loop_bwd": [C.POINTER(TrainLoop), _P],
+    "cvc_train_loops_bwd_joint": [C.POINTER(TrainLoop), C.POINTER(TrainLoop), _P],
     "cvc_train_loop_profile": [_I],
     "cvc_train_loop_profile_read": [C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), _I],
     "cvc_attn_fwd": [_I, _P, _P, _P, _F, C.POINTER(AttnSet), _I, _I, _I, _I, _I, _P, _P],

@@ -64,7 +64,7 @@ def _masked_nll_mean_from_logits(logits, target, t_major=False):
     return (total / w.sum()).reshape(()), argmax.view(target.shape)
 
 
-def _masked_nll_mean_from_head(x, weight, bias, target, t_major=False):
+def _masked_nll_mean_from_head(x, weight, bias, target, t_major=False, done=None, compute_only=False):
     """_masked_nll_mean_from_logits(x W^T + b, target) with the criterion folded into the vocabulary head's GEMM finish: the logits
     are never materialised (cvc.functional.vocab_head_nll); falls back to the two-step form for shapes that kernel does not take."""
     if not F_.vocab_head_nll_ok(x, weight):
@@ -78,7 +78,11 @@ def _masked_nll_mean_from_head(x, weight, bias, target, t_major=False):
         pre = ((target._version, t_major), tf.contiguous(), wf.contiguous(), w.sum())
         target._cvc_nll_pre = pre
     _, tf, wf, count = pre
-    total, argmax = F_.vocab_head_nll(x, weight, bias, tf, wf)
+    if compute_only:       # -> (opaque result for a later call with done=, the argmax words)
+        done = F_.vocab_head_nll_compute(x, weight, bias, tf, wf)
+        argmax = done[1]
+        return done, (argmax.view(target.shape[1], target.shape[0]).t() if t_major else argmax.view(target.shape))
+    total, argmax = F_.vocab_head_nll(x, weight, bias, tf, wf, done)
     if t_major:
         return (total / count).reshape(()), argmax.view(target.shape[1], target.shape[0]).t()
     return (total / count).reshape(()), argmax.view(target.shape)
@@ -105,13 +109,22 @@ class LMCriterion(nn.Module):
         loss, argmax = _masked_nll_mean_from_logits(logits, target, t_major)
         return (loss, *self.attention_losses(att2_weights, ground_weights, att2_target), argmax)
 
-    def from_head(self, x, head, att2_weights, ground_weights, target, att2_target, input_seq, t_major=False):
+    def from_head(self, x, head, att2_weights, ground_weights, target, att2_target, input_seq, t_major=False, done=None):
         """from_logits() fed the vocabulary head's INPUT x [rows, R] and the head module (nn.Linear): the head's GEMM and the
-        criterion run as one op, no logits tensor."""
+        criterion run as one op, no logits tensor.  done: head_words()'s first result for the same x (the arithmetic then is not
+        repeated)."""
         if not torch.cuda.is_current_stream_capturing():
             assert torch.sum(target >= self.vocab_size) == 0
-        loss, argmax = _masked_nll_mean_from_head(x, head.weight, head.bias, target, t_major)
+        loss, argmax = _masked_nll_mean_from_head(x, head.weight, head.bias, target, t_major, done=done)
         return (loss, *self.attention_losses(att2_weights, ground_weights, att2_target), argmax)
+
+    @staticmethod
+    def head_words(x, head, target, t_major=False):
+        """the head + criterion arithmetic of from_head() ahead of its graph node: -> (done, argmax words [B, T]), or None for
+        shapes the fused head does not take"""
+        if not F_.vocab_head_nll_ok(x, head.weight):
+            return None
+        return _masked_nll_mean_from_head(x, head.weight, head.bias, target, t_major, compute_only=True)
 
     @staticmethod
     def attention_losses(att2_weights, ground_weights, att2_target):

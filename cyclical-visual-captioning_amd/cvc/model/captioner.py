@@ -319,6 +319,16 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         arena = train_loops.LoopArena(1 if self.opts.train_decoder_only else 2, T, B, R, emb_all.shape[2], emb_all.device)
         out_a, fm = train_loops.decode_loop(arena, emb_all, fc_in, (pool_feats, p_pool_feats, conv_feats, p_conv_feats), region_mask,
                                             step_fmask, dc.att_lstm, dc.lang_lstm, dc.soft_attn, attn_kind, inv_temp, drop_a)
+        target = gt_caption[:, 1:T + 1].clone()
+        out_c, done = None, None
+        head = self.critLM.head_words(out_a.view(T * B, R), self.logit, target, t_major=True) if arena.joint_ok() else None
+        if head is not None:
+            # Both loops' rows fit one 64-row operand (the 32-clip shares of the 8-GPU job): loops B and C come FIRST, fed the argmax
+            # words of the head's arithmetic, and loop A's outputs pass through loop C's graph node -- its backward then holds both
+            # loops' output gradients and runs their back-propagation as one pass (cvc.train_loops._Loop).
+            done, output_seq = head
+            out_c, out_a, fm = self._loops_b_c(arena, output_seq, gt_caption, emb_all, fc_in, conv_feats, p_conv_feats, pool_feats,
+                                               p_pool_feats, region_mask, attn_kind, drop_c, joint=(out_a, fm))
         att2_weights = fm.transpose(0, 1)                                             # [B, T, N] pre-softmax (:273)
 
         # ---- grounder over all T                                                      reference :282-294
@@ -332,23 +342,29 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         if self.debug_collect is not None:
             self.debug_collect.update(ground_weights=ground_weights, att2_weights=att2_weights, roi_labels=roi_labels,
                                       frm_mask_output=frm_mask_output)
-        target = gt_caption[:, 1:T + 1].clone()
         # vocabulary head + criterion + the argmax cut of :313 as one op on the t-major rows (no logits tensor)
         lm_loss, att2_loss, ground_loss, output_seq = self.critLM.from_head(
             out_a.view(T * B, R), self.logit, att2_weights, ground_weights, target, roi_labels[:, :T, :], input_seq[:, 1:T + 1, 0],
-            t_major=True)
+            t_major=True, done=done)
         if self.opts.train_decoder_only:                                              # reference :297-307
             return lm_loss.reshape(1), att2_loss.reshape(1), ground_loss.reshape(1), cls_loss.reshape(1)
-
-        # ---- argmax cut, Loop B: localize (all T in one attention call)               reference :313-338
-        loc_emb = self._embed(output_seq, "emb_b")                                   # [B, T, E]
-        ctx_all = self.localizer_core.forward_all_steps_sum(loc_emb, conv_feats, p_conv_feats, pool_feats, p_pool_feats, region_mask)
-
-        # ---- Loop C: reconstruct from the localized regions                          reference :348-362
-        emb_all_c = self._embed(gt_caption[:, :T], "emb_c") if self.training else emb_all      # fresh dropout mask in training
-        out_c = train_loops.recon_loop(arena, emb_all_c, fc_in, ctx_all, dc.att_lstm, dc.lang_lstm, dc.soft_attn, attn_kind, drop_c)
+        if out_c is None:
+            out_c = self._loops_b_c(arena, output_seq, gt_caption, emb_all, fc_in, conv_feats, p_conv_feats, pool_feats, p_pool_feats,
+                                    region_mask, attn_kind, drop_c)
         lm_recon_loss = self.xe_criterion.from_head(out_c.view(T * B, R), self.logit, target, t_major=True)
         return (lm_loss.reshape(1), att2_loss.reshape(1), ground_loss.reshape(1), cls_loss.reshape(1), lm_recon_loss.reshape(1))
+
+    def _loops_b_c(self, arena, output_seq, gt_caption, emb_all, fc_in, conv_feats, p_conv_feats, pool_feats, p_pool_feats, region_mask,
+                   attn_kind, drop_c, joint=None):
+        """the argmax cut, loop B (localize, all T in one attention call; reference :313-338) and loop C (reconstruct from the
+        localized regions; reference :348-362)"""
+        from .. import train_loops
+        dc, T = self.decoder_core, self.seq_length
+        loc_emb = self._embed(output_seq, "emb_b")                                   # [B, T, E]
+        ctx_all = self.localizer_core.forward_all_steps_sum(loc_emb, conv_feats, p_conv_feats, pool_feats, p_pool_feats, region_mask)
+        emb_all_c = self._embed(gt_caption[:, :T], "emb_c") if self.training else emb_all      # fresh dropout mask in training
+        return train_loops.recon_loop(arena, emb_all_c, fc_in, ctx_all, dc.att_lstm, dc.lang_lstm, dc.soft_attn, attn_kind, drop_c,
+                                      joint=joint)
 
     def _vis_embed(self, xt_clamp):
         """roi_feat_extractor.vis_embed (Embedding -> ReLU -> Dropout, backbone.py:55-57) on the grounder's class indices"""

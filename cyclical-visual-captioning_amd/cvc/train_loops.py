@@ -30,6 +30,7 @@ from . import hip
 
 ENABLED = os.environ.get("CVC_TRAIN_LOOPS", "1") != "0"        # False: the per-step autograd path (A/B switch)
 PACKED_H2ATTN = os.environ.get("CVC_TRAIN_PACKED_H2ATTN", "1") != "0"   # False: h2attn of loop A on the row-major ring kernel (A/B)
+JOINT_BWD = os.environ.get("CVC_TRAIN_JOINT_BWD", "1") != "0"   # False: the two loops' back-propagation as two passes even when 2B <= 64 (A/B)
 
 Tensor = torch.Tensor
 
@@ -54,6 +55,14 @@ class LoopArena:
         self.dgsum_att, self.dgsum_lang = e(nslots, B, 4 * R), e(nslots, B, 4 * R)     # sums over the T steps, per loop (bias / fc gradients)
         self.extra = {}                 # slot 0's attention-side buffers (dq, dwa_part, ds_r, ds_f), set by its backward
         self.done = []                  # slots whose backward has run
+        self.loop_a = None              # loop A's autograd context, for the joint back-propagation run from loop C's node
+        self.joint_done = False         # the joint pass has run: loop A's node only has its dense input gradients left
+        self.a_feat_grads = None
+
+    def joint_ok(self) -> bool:
+        """Both loops' rows fit ONE 64-row operand: their back-propagation through time runs as one pass (cvc_train_loops_bwd_joint),
+        every backward-data product streaming the shared LSTM weights once for both."""
+        return bool(JOINT_BWD and self.nslots == 2 and 2 * self.B <= 64 and self.loop_a is not None and torch.is_grad_enabled())
 
     def rows(self, slot: int) -> slice:
         n = self.T * self.B
@@ -189,11 +198,15 @@ class _Loop(torch.autograd.Function):
        w_ih_a, w_hh_a, b_ih_a, b_hh_a, w_ih_l, w_hh_l, b_ih_l, b_hh_l, w_h, b_h, w_a, b_a (w_a / b_a additive attention only; loop C
        takes the attention weights too, unused in its forward: whichever loop finishes its backward LAST returns every weight's
        gradient, and autograd only accepts a gradient for an input that was a tensor)
-    outputs: out [T, B, R] (dropout(h_lang)), fm [T, B, N] (kind 0 with frame masks, else a 0-d placeholder)"""
+       pass_out, pass_fm: loop A's two outputs handed THROUGH loop C's node (cfg.joint; returned as they are): every consumer of
+       loop A then sits behind loop C's node in the graph, so that node's backward holds both loops' output gradients and runs the
+       joint back-propagation.  (Nothing of loop A's forward depends on loop C -- the localizer reads the argmax words, an integer
+       cut, captioner.py:313 -- so the order of the two nodes' backward is free.)
+    outputs: out [T, B, R] (dropout(h_lang)), fm [T, B, N] (kind 0 with frame masks, else a 0-d placeholder), pass_out, pass_fm"""
 
     @staticmethod
     def forward(ctx, cfg, arena, emb, fc, ctx_all, pool, ppool, conv, pconv, w_ih_a, w_hh_a, b_ih_a, b_hh_a, w_ih_l, w_hh_l,
-                b_ih_l, b_hh_l, w_h, b_h, w_a, b_a):
+                b_ih_l, b_hh_l, w_h, b_h, w_a, b_a, pass_out, pass_fm):
         kind, T, B, R, E = cfg.kind, arena.T, arena.B, arena.R, arena.E
         dev = emb.device
         slot = cfg.slot
@@ -264,18 +277,20 @@ class _Loop(torch.autograd.Function):
             ctx.save_for_backward(fc, w_ih_a, w_hh_a, b_ih_a, b_hh_a, w_ih_l, w_hh_l, b_ih_l, b_hh_l, w_h, b_h, w_a, b_a)
             ctx.key = ("loops", id(arena))
             F_._BATCHER.note_use(ctx.key)
+            if kind == 0:
+                arena.loop_a = ctx
         ctx.set_materialize_grads(False)
         out = buf["out"]
         if fm is None:
             fm = out.new_empty(())
-        return out, fm
+        return out, fm, pass_out, pass_fm
 
     @staticmethod
-    def backward(ctx, d_out, d_fm):
-        L, buf, keep, cfg, arena = ctx.L, ctx.buf, ctx.keep, ctx.cfg, ctx.arena
-        fc, w_ih_a, w_hh_a, b_ih_a, b_hh_a, w_ih_l, w_hh_l, b_ih_l, b_hh_l, w_h, b_h, w_a, b_a = ctx.saved_tensors
-        kind, T, B, R, E = cfg.kind, arena.T, arena.B, arena.R, arena.E
-        dev = w_ih_a.device
+    def _arm(ctx, d_out, d_fm):
+        """fill the backward half of the loop descriptor; -> (the gradients of the feature inputs, tensors to keep alive)"""
+        L, keep, cfg, arena = ctx.L, ctx.keep, ctx.cfg, ctx.arena
+        kind, T, B, R = cfg.kind, arena.T, arena.B, arena.R
+        dev = arena.emb.device
         rows = arena.rows(cfg.slot)
         ni = ctx.needs_input_grad            # (cfg, arena, emb_tb, fc, ctx_tb, pool, ppool, conv, pconv, 12 weights...)
         e = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
@@ -301,12 +316,16 @@ class _Loop(torch.autograd.Function):
                 if ni[5 + i]:
                     grads_feat[i] = torch.zeros_like(keep[src])
                     setattr(L, name, _ptr(grads_feat[i]))
-        ws = _bwd_ws(B, R, L.A if kind == 0 else 0, dev)
-        L.bwd_ws = _ptr(ws)
-        hip._check(hip.lib().cvc_train_loop_bwd(C.byref(L), hip._stream()), "cvc_train_loop_bwd")
-        arena.done.append(cfg.slot)
-        # ---- weight gradients: by whichever loop finishes its backward last, over all loops' rows at once -- BEFORE this loop's
-        # input gradients, so that the gradient buckets (486 MB) are complete, and their exchange under way, as early as possible
+        return grads_feat, live
+
+    @staticmethod
+    def backward(ctx, d_out, d_fm, d_pass_out, d_pass_fm):
+        L, cfg, arena = ctx.L, ctx.cfg, ctx.arena
+        fc, w_ih_a, w_hh_a, b_ih_a, b_hh_a, w_ih_l, w_hh_l, b_ih_l, b_hh_l, w_h, b_h, w_a, b_a = ctx.saved_tensors
+        kind, T, B, R, E = cfg.kind, arena.T, arena.B, arena.R, arena.E
+        dev = w_ih_a.device
+        rows = arena.rows(cfg.slot)
+        ni = ctx.needs_input_grad
         order = ("w_ih_a", "w_hh_a", "b_ih_a", "b_hh_a", "w_ih_l", "w_hh_l", "b_ih_l", "b_hh_l", "w_h", "b_h", "w_a", "b_a")
         owners = (w_ih_a, w_hh_a, b_ih_a, b_hh_a, w_ih_l, w_hh_l, b_ih_l, b_hh_l, w_h, b_h, w_a, b_a)
         W = dict(zip(order, owners), fc=fc)
@@ -316,9 +335,34 @@ class _Loop(torch.autograd.Function):
             arena.done = []
             return tuple(g.get(k) for k in order)
 
-        # the owner list carries every weight of both loops; a loop that does not own h2attn (loop C) still returns its share of
-        # the flush through the same tuple positions when it happens to be last
-        got = F_._BATCHER.add(ctx.key, (cfg.slot,), owners, flush)
+        got = None
+        if kind == 0 and arena.joint_done:
+            # loop C's node ran the back-propagation of both loops (and the weight gradients): only the dense input gradients are left
+            grads_feat, live = arena.a_feat_grads, None
+            arena.a_feat_grads, arena.loop_a = None, None
+        elif getattr(cfg, "joint", False):
+            a = arena.loop_a
+            grads_feat_a, live_a = _Loop._arm(a, d_pass_out, d_pass_fm)
+            grads_feat, live = _Loop._arm(ctx, d_out, None)
+            ws = _bwd_ws(2 * B, R, a.L.A, dev)
+            a.L.bwd_ws = L.bwd_ws = _ptr(ws)
+            hip._check(hip.lib().cvc_train_loops_bwd_joint(C.byref(a.L), C.byref(L), hip._stream()), "cvc_train_loops_bwd_joint")
+            arena.a_feat_grads, arena.joint_done = grads_feat_a, True
+            arena.done += [0, 1]
+            F_._BATCHER.add(ctx.key, (0,), owners, flush)
+            got = F_._BATCHER.add(ctx.key, (1,), owners, flush)
+            del live_a
+        else:
+            grads_feat, live = _Loop._arm(ctx, d_out, d_fm)
+            ws = _bwd_ws(B, R, L.A if kind == 0 else 0, dev)
+            L.bwd_ws = _ptr(ws)
+            hip._check(hip.lib().cvc_train_loop_bwd(C.byref(L), hip._stream()), "cvc_train_loop_bwd")
+            arena.done.append(cfg.slot)
+            # ---- weight gradients: by whichever loop finishes its backward last, over all loops' rows at once -- BEFORE this
+            # loop's input gradients, so that the gradient buckets (486 MB) are complete, and their exchange under way, as early
+            # as possible.  The owner list carries every weight of both loops; a loop that does not own h2attn (loop C) still
+            # returns its share of the flush through the same tuple positions when it happens to be last
+            got = F_._BATCHER.add(ctx.key, (cfg.slot,), owners, flush)
         wg = [None] * 12
         if got is not None:
             for i, gi in enumerate(got):
@@ -335,7 +379,7 @@ class _Loop(torch.autograd.Function):
         if kind == 1 and ni[4]:
             d_ctx = hip.tile_mm(DGl, hip.weight_operand(w_ih_l[:, :R], kmajor=True)).view(T, B, R).transpose(0, 1)
         del live
-        return (None, None, d_emb, d_fc, d_ctx, *grads_feat, *wg)
+        return (None, None, d_emb, d_fc, d_ctx, *grads_feat, *wg, None, None)
 
 
 def decode_loop(arena: LoopArena, emb: Tensor, fc: Optional[Tensor], feats, mask, frame_mask, att_lstm, lang_lstm, soft_attn,
@@ -346,20 +390,26 @@ def decode_loop(arena: LoopArena, emb: Tensor, fc: Optional[Tensor], feats, mask
     cfg = _Cfg(kind=0, slot=0, has_fc=fc is not None, attn_kind=attn_kind, inv_temp=inv_temp, drop=drop, mask=hip._mask(mask),
                frame_mask=hip._mask(frame_mask))
     pool, ppool, conv, pconv = feats
-    out, fm = _Loop.apply(cfg, arena, emb, fc, None, pool, ppool, conv, pconv, att_lstm.weight_ih, att_lstm.weight_hh,
-                          att_lstm.bias_ih, att_lstm.bias_hh, lang_lstm.weight_ih, lang_lstm.weight_hh, lang_lstm.bias_ih,
-                          lang_lstm.bias_hh, soft_attn.h2attn.weight, soft_attn.h2attn.bias,
-                          soft_attn.alpha_net.weight if additive else None, soft_attn.alpha_net.bias if additive else None)
+    out, fm, _, _ = _Loop.apply(cfg, arena, emb, fc, None, pool, ppool, conv, pconv, att_lstm.weight_ih, att_lstm.weight_hh,
+                                att_lstm.bias_ih, att_lstm.bias_hh, lang_lstm.weight_ih, lang_lstm.weight_hh, lang_lstm.bias_ih,
+                                lang_lstm.bias_hh, soft_attn.h2attn.weight, soft_attn.h2attn.bias,
+                                soft_attn.alpha_net.weight if additive else None, soft_attn.alpha_net.bias if additive else None,
+                                None, None)
     return out, (fm if frame_mask is not None else None)
 
 
-def recon_loop(arena: LoopArena, emb: Tensor, fc: Optional[Tensor], ctx_all: Tensor, att_lstm, lang_lstm, soft_attn, attn_kind: int, drop):
+def recon_loop(arena: LoopArena, emb: Tensor, fc: Optional[Tensor], ctx_all: Tensor, att_lstm, lang_lstm, soft_attn, attn_kind: int, drop,
+               joint=None):
     """Loop C.  ctx_all [B, T, R]: the localized context (regions + frames) of every step; soft_attn: loop A's attention module
-    (gradient conduit only, see _Loop).  -> out [T, B, R]"""
+    (gradient conduit only, see _Loop).  joint: loop A's (out, fm) when `arena.joint_ok()` -- they come back as the tensors loop A's
+    consumers must read from here on (see _Loop).  -> out [T, B, R], or (out, loop A's out, loop A's fm) with `joint`"""
     additive = attn_kind == hip.ATTN_ADDITIVE
-    cfg = _Cfg(kind=1, slot=1, has_fc=fc is not None, attn_kind=attn_kind, inv_temp=1.0, drop=drop, mask=None, frame_mask=None)
-    out, _ = _Loop.apply(cfg, arena, emb, fc, ctx_all, None, None, None, None, att_lstm.weight_ih, att_lstm.weight_hh,
-                         att_lstm.bias_ih, att_lstm.bias_hh, lang_lstm.weight_ih, lang_lstm.weight_hh, lang_lstm.bias_ih,
-                         lang_lstm.bias_hh, soft_attn.h2attn.weight, soft_attn.h2attn.bias,
-                         soft_attn.alpha_net.weight if additive else None, soft_attn.alpha_net.bias if additive else None)
-    return out
+    cfg = _Cfg(kind=1, slot=1, has_fc=fc is not None, attn_kind=attn_kind, inv_temp=1.0, drop=drop, mask=None, frame_mask=None,
+               joint=joint is not None)
+    p_out, p_fm = joint if joint is not None else (None, None)
+    out, _, p_out, p_fm = _Loop.apply(cfg, arena, emb, fc, ctx_all, None, None, None, None, att_lstm.weight_ih, att_lstm.weight_hh,
+                                      att_lstm.bias_ih, att_lstm.bias_hh, lang_lstm.weight_ih, lang_lstm.weight_hh, lang_lstm.bias_ih,
+                                      lang_lstm.bias_hh, soft_attn.h2attn.weight, soft_attn.h2attn.bias,
+                                      soft_attn.alpha_net.weight if additive else None, soft_attn.alpha_net.bias if additive else None,
+                                      p_out, p_fm)
+    return out if joint is None else (out, p_out, p_fm)

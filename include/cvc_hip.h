@@ -680,7 +680,8 @@ CVC_API int cvc_packed_lstm_step_fwd(const cvc_lstm_step* s, cvc_stream_t stream
 CVC_API int cvc_lstm_pointwise_bwd4(const cvc_grad_src* d_h /* [3] */, const float* d_hd,
                             const uint32_t* rng_state, unsigned site, float p, const float* d_c, const float* gates,
                             const float* c_prev, const float* c_new, int M, int R, float* d_gates, float* d_c_prev,
-                            float* d_gates_q, float* dg_sum /* [M, 4R] += d_gates, nullable */, cvc_stream_t stream);
+                            float* d_gates_q, float* dg_sum /* [M, 4R] += d_gates, nullable */,
+                            int q_row0 /* row of d_gates_q that row 0 goes to: q_row0 + M <= 64 */, cvc_stream_t stream);
 
 typedef struct cvc_train_loop {
     int kind;                    /* 0 = loop A (decode step with attention), 1 = loop C (reconstruction step)            */
@@ -736,6 +737,11 @@ typedef struct cvc_train_loop {
 CVC_API long long cvc_train_loop_bwd_ws(int B, int R, int A);
 CVC_API int cvc_train_loop_fwd(const cvc_train_loop* loop, cvc_stream_t stream);
 CVC_API int cvc_train_loop_bwd(const cvc_train_loop* loop, cvc_stream_t stream);
+/* Back-propagation through BOTH loops in one pass (loop_a->B + loop_c->B <= 64, same T and R -- the 32-clip shares of the 8-GPU
+ * job): the two loops share the LSTM cells, so at every step their gate gradients form ONE operand (loop A's rows first) and every
+ * backward-data product streams its weights once for both -- 3 products per step instead of 5.  Same results as the two separate
+ * calls (bwd_ws of loop_a is used). */
+CVC_API int cvc_train_loops_bwd_joint(const cvc_train_loop* loop_a, const cvc_train_loop* loop_c, cvc_stream_t stream);
 /* Measurement aid (bench.py --mode train; never enabled by the product path): HIP-event pairs around every entry point the two
  * drivers call, on the launch stream.  cvc_train_loop_profile(n > 0) starts recording with room for n launches, (0) stops and
  * frees; cvc_train_loop_profile_read waits for the recorded launches and returns their count, kind[i] (0 zero fill, 1 attention

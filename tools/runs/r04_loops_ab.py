@@ -55,7 +55,35 @@ def compare(name, d, train, mix=(0.5, 0.0, 0.0, 0.5), **over):
     assert worst < 2e-5 and gworst < 5e-4, name
 
 
+def joint_ab(name, d, train, mix=(0.5, 0.3, 0.2, 0.5), exact=True, **over):
+    """the joint back-propagation of both loops (2B <= 64) against the two separate passes: same products row for row -> same bits"""
+    model = build_model(d, synth.hot_path_state_dict(d, 7), dev, **over)
+    if train:
+        model.train()
+    f, b = to_dev(synth.clip_features(d, 7, full_mask_clip=1 if d.B > 1 else None), dev), to_dev(synth.label_glue_batch(d, 7), dev)
+    res = {}
+    for on in (False, True):
+        train_loops.JOINT_BWD = on
+        dropout.seed(123)
+        res[on] = run(model, f, b, mix)
+    train_loops.JOINT_BWD = True
+    for a, r in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, r), (name, a, r)
+    bad = [k for k, g in res[False][1].items() if (g is None) != (res[True][1][k] is None) or (g is not None and not torch.equal(g, res[True][1][k]))]
+    print(f"{name}: train={train} joint backward == two passes: {not bad} {bad[:4]}", flush=True)
+    if bad and exact:
+        raise AssertionError(name)
+    for k in bad:          # (64 rows take the backward-data kernel's two-row-tile form, 32 its one-tile form: not the same bits)
+        g, g2 = res[False][1][k], res[True][1][k]
+        e = float((g - g2).norm() / (g.norm() + 1e-30))
+        print(f"   {k}: rel {e:.2e}", flush=True)
+        assert e < 2e-5 or float(g.norm()) < 1e-6, (name, k, e)
+
+
 tiny = synth.CONFIGS["tiny"]
+joint_ab("tiny", tiny, False)
+joint_ab("tiny", tiny, True)
+joint_ab("cfg1 B=5", dataclasses.replace(synth.CONFIGS["cfg1"], B=5), True)
 compare("tiny", tiny, False)
 compare("tiny all losses", tiny, False, mix=(0.5, 0.3, 0.2, 0.5))
 compare("tiny", tiny, True)
@@ -65,6 +93,21 @@ mid = dataclasses.replace(synth.CONFIGS["cfg1"], B=5)
 compare("cfg1 B=5", mid, False)
 compare("cfg1 B=5", mid, True)
 if "--big" in sys.argv:
+    d4 = synth.CONFIGS["cfg4"]
+    joint_ab("cfg4", d4, True, exact=False)
+    compare("cfg4", d4, True)
+    model = build_model(d4, synth.hot_path_state_dict(d4, 7), dev).train()
+    f, b = to_dev(synth.clip_features(d4, 7), dev), to_dev(synth.label_glue_batch(d4, 7), dev)
+    for on in (False, True):
+        train_loops.JOINT_BWD = on
+        for _ in range(3):
+            run(model, f, b)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            run(model, f, b)
+        print(f"cfg4 fwd+bwd joint={on}: {(time.perf_counter() - t0) / 10 * 1e3:.2f} ms", flush=True)
+    train_loops.JOINT_BWD = True
+    del model
     d = synth.CONFIGS["cfg3"]
     compare("cfg3", d, True)
     sd = synth.hot_path_state_dict(d, 7)
