@@ -303,7 +303,7 @@ def run_train(args, d, dev, rank, world, steps=None, warmup=None, min_warm=None,
         L.cvc_train_loop_profile(0)
         KN = ["zero_fill", "att_cell", "h2attn", "attn_scores", "attn_wsum", "lang_cell", "gate_grad_lang", "nn_lang", "attn_bwd",
               "nn_h2attn", "gate_grad_att", "nn_att"]
-        LN = ["loopA.fwd", "loopC.fwd", "loopA.bwd", "loopC.bwd"]
+        LN = ["loopA.fwd", "loopC.fwd", "loopA.bwd", "loopC.bwd", "loops.bwd"]
         tot, cnt = {}, {}
         for i in range(nrec):
             name = f"{LN[loop[i]]}.{KN[kind[i]]}"
@@ -311,7 +311,7 @@ def run_train(args, d, dev, rank, world, steps=None, warmup=None, min_warm=None,
             cnt[name] = cnt.get(name, 0) + 1
         cnt = {k: v // nprobe for k, v in cnt.items()}
         for k, v in timers.items():                      # entry points called from Python (dense products, criteria, optimizer)
-            if k in ("cvc_train_loop_fwd", "cvc_train_loop_bwd"):
+            if k in ("cvc_train_loop_fwd", "cvc_train_loop_bwd", "cvc_train_loops_bwd_joint"):
                 continue
             tot[k] = sum(a.elapsed_time(b) for a, b in v) / nprobe
             cnt[k] = len(v) // nprobe
@@ -556,6 +556,9 @@ def train_work(d):
     w["loopA.bwd.nn_h2attn"] = gemm(R, A)
     # attention of one step: projected rows once (scores), context rows once (weighted sum); backward: context rows once (d_attn),
     # projected rows once (tanh recomputed)
+    # joint backward (2B <= 64: both loops' rows in one operand, cvc_train_loops_bwd_joint): 2B rows per product
+    gemm2 = lambda k: dict(bytes=4 * 4 * R * k + 4 * 2 * B * (k + 4 * R), flops=2 * 2 * B * 4 * R * k, mfma="split")
+    w["loops.bwd.nn_lang"], w["loops.bwd.nn_att"] = gemm2(3 * R), gemm2(2 * R)
     w["loopA.fwd.attn_scores"] = dict(bytes=4 * B * (N + F) * A, flops=B * (N + F) * 4 * A, mfma="none")
     w["loopA.fwd.attn_wsum"] = dict(bytes=4 * B * (N + F) * R, flops=2 * B * (N + F) * R, mfma="none")
     w["loopA.bwd.attn_bwd"] = dict(bytes=4 * B * (N + F) * (A + R), flops=B * (N + F) * (8 * A + 2 * R), mfma="none")

@@ -47,6 +47,8 @@ const Entry table[] = {
     CVC_B(cvc_bn_relu_train_bwd),
     CVC_B(cvc_class_softmax_bwd),
     CVC_B(cvc_layernorm_cat_bwd),
+    CVC_B(cvc_stable_order),
+    CVC_B(cvc_col_sum),
 #ifdef CVC_EXPERIMENTAL
     CVC_B(cvc_gsk_plan),
     CVC_B(cvc_gsk_gemm),

@@ -247,7 +247,8 @@ int run_bwd(const cvc_train_loop* LA, const cvc_train_loop* LC, hipStream_t st, 
                                                          L.c_lang + (size_t)(t + 1) * BR, L.B, R, L.dg_lang + (size_t)t * BG, d_c, w.dgq,
                                                          L.dgsum_lang, row0[s], st));
         }
-        g_prof_loop = 2 + L0.kind;
+        const int shared = LA && LC ? 4 : 2 + L0.kind;        // profile label of the products both loops share
+        g_prof_loop = shared;
         cvc_grad_src g_ctx = none, g_ha_a = none, g_ha_b = none;
         {
             cvc_nn_seg segs[3];
@@ -264,6 +265,7 @@ int run_bwd(const cvc_train_loop* LA, const cvc_train_loop* LC, hipStream_t st, 
         if (LA) {
             // ---- attention (both feature sets) and h2attn: loop A's rows (the first BA of every operand)
             const cvc_train_loop& L = *LA;
+            g_prof_loop = 2;
             const int B = BA;
             cvc_attn_set sets[2]{};
             sets[0].proj = L.ppool; sets[0].ctx = L.pool; sets[0].attn = L.attn_r + (size_t)t * B * N; sets[0].n = N;
@@ -294,7 +296,7 @@ int run_bwd(const cvc_train_loop* LA, const cvc_train_loop* LC, hipStream_t st, 
                                                         L.c_att + (size_t)t * BR, L.c_att + (size_t)(t + 1) * BR, L.B, R, L.dg_att + (size_t)t * BG,
                                                         d_c, w.dgq, L.dgsum_att, row0[s], st));
         }
-        g_prof_loop = 2 + L0.kind;
+        g_prof_loop = shared;
         if (t > 0) {
             cvc_nn_seg segs[2] = {cvc_nn_seg{L0.w_ih_att, w.d_hl_b, L0.ld_ih_att, R, R}, cvc_nn_seg{L0.w_hh_att, w.d_ha_prev, R, R, R}};
             cvc_grad_src out[2];

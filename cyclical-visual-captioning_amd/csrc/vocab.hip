@@ -926,6 +926,58 @@ extern "C" int cvc_vocab_head_nll_fwd(const float* parts, int nparts, long long 
     return cvc_launch_status();
 }
 
+// ---- small dense helpers of the training step that used to be library launches (a radix sort of 1 280 keys is three launches; a
+// bias gradient is a generic reduction): both deterministic, fixed summation order.
+//
+// Stable order of n int64 keys by counting: rank(i) = #{j : key[j] < key[i]} + #{j < i : key[j] == key[i]}; order[rank(i)] = i.
+// Every workgroup holds all keys in LDS (n <= 8192) and ranks 256 of them; all lanes read the same LDS word at a time (broadcast).
+__global__ __launch_bounds__(WG) void stable_order_kernel(const int64_t* key, int n, int64_t* order) {
+    extern __shared__ int64_t keys[];
+    for (int j = threadIdx.x; j < n; j += WG) keys[j] = key[j];
+    __syncthreads();
+    const int i = blockIdx.x * WG + threadIdx.x;
+    if (i >= n) return;
+    const int64_t k = keys[i];
+    int r = 0;
+    for (int j = 0; j < i; ++j) r += keys[j] <= k ? 1 : 0;
+    for (int j = i + 1; j < n; ++j) r += keys[j] < k ? 1 : 0;
+    order[r] = i;
+}
+
+// out[c] (and out2[c]) = sum over the S rows of x[s, c]: one column per lane (a wave reads 256 contiguous bytes of a row), the
+// workgroup's 4 waves take rows w, w + 4, ... and are combined in wave order.
+__global__ __launch_bounds__(WG) void col_sum_kernel(const float* x, long long ld, int S, int n, float* out, float* out2) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < n) {
+        const float* p = x + c;
+        int r = wave;
+        for (; r + 4 < S; r += 8) { s0 += p[(size_t)r * ld]; s1 += p[(size_t)(r + 4) * ld]; }
+        if (r < S) s0 += p[(size_t)r * ld];
+    }
+    part[wave][lane] = s0 + s1;
+    __syncthreads();
+    if (wave == 0 && c < n) {
+        const float v = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+        out[c] = v;
+        if (out2 != nullptr) out2[c] = v;
+    }
+}
+
+extern "C" int cvc_stable_order(const int64_t* key, int n, int64_t* order, cvc_stream_t stream) {
+    if (!key || !order || n < 1 || n > 8192) return CVC_E_BADARG;
+    hipLaunchKernelGGL(stable_order_kernel, dim3((n + WG - 1) / WG), dim3(WG), (size_t)n * 8, (hipStream_t)stream, key, n, order);
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_col_sum(const float* x, long long ld, int S, int n, float* out, float* out2, cvc_stream_t stream) {
+    if (!x || !out || S < 1 || n < 1 || ld < n) return CVC_E_BADARG;
+    hipLaunchKernelGGL(col_sum_kernel, dim3((n + 63) / 64), dim3(WG), 0, (hipStream_t)stream, x, ld, S, n, out, out2);
+    return cvc_launch_status();
+}
+
 extern "C" int cvc_scale_by_scalar(const float* x, const float* g, long long n, float* y, cvc_stream_t stream) {
     if (!x || !g || !y || n < 4 || (n & 3) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return CVC_E_BADARG;
     const long long n4 = n / 4;

@@ -180,7 +180,7 @@ def _linear_backward(ctx, weight, bias, xs, dy, ni):
             X = torch.cat([i[1] for i in items], 0) if len(items) > 1 else items[0][1]
             # (into the gradient owner's buffer when it hands one out: no AccumulateGrad add, see GRAD_SINKS)
             dw = _into_grad(weight, lambda out: hip.tile_mm(D, X, a_kmajor=True, b_kmajor=True, out=out))
-            db = _into_grad(bias, lambda out: torch.sum(D, 0, out=out) if out is not None else D.sum(0)) if ctx.has_bias else None
+            db = _into_grad(bias, lambda out: hip.col_sum(D, out)) if ctx.has_bias else None
             return dw, db
 
         res = _BATCHER.add(ctx.key, (dy, x), (weight, bias), flush)
@@ -189,7 +189,7 @@ def _linear_backward(ctx, weight, bias, xs, dy, ni):
             if not (ctx.has_bias and ni[1]):
                 d_b = None
     elif ctx.has_bias and ni[1]:
-        d_b = dy.sum(0)
+        d_b = hip.col_sum(dy)
     d_xs, k0 = [], 0
     for i, x in enumerate(xs):
         k = x.shape[1]

@@ -134,6 +134,8 @@ SIGNATURES = {
     "cvc_train_loop_fwd": [C.POINTER(TrainLoop), _P],
     "cvc_train_loop_bwd": [C.POINTER(TrainLoop), _P],
     "cvc_train_loops_bwd_joint": [C.POINTER(TrainLoop), C.POINTER(TrainLoop), _P],
+    "cvc_stable_order": [_P, _I, _P, _P],
+    "cvc_col_sum": [_P, _LL, _I, _I, _P, _P, _P],
     "cvc_train_loop_profile": [_I],
     "cvc_train_loop_profile_read": [C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), _I],
     "cvc_attn_fwd": [_I, _P, _P, _P, _F, C.POINTER(AttnSet), _I, _I, _I, _I, _I, _P, _P],
@@ -244,7 +246,7 @@ BLOCKS = {
     "cvc_lstm_pointwise_bwd3_drop", "cvc_pack_lstm_weights", "cvc_linear_nn_planes_fwd", "cvc_beam_select_parts", "cvc_tile_lstm_finish",
     "cvc_tile_lstm_finish_embgate", "cvc_tile_reorder_pack", "cvc_decode_num_launches", "cvc_gemm_force_generic",
     "cvc_tile_gemm_loaders", "cvc_gru_persistent_waves8", "cvc_relu_dropout_fwd", "cvc_relu_dropout_bwd", "cvc_bn_workspace",
-    "cvc_bn_relu_train_fwd", "cvc_bn_relu_train_bwd", "cvc_class_softmax_bwd", "cvc_layernorm_cat_bwd"}
+    "cvc_bn_relu_train_fwd", "cvc_bn_relu_train_bwd", "cvc_class_softmax_bwd", "cvc_layernorm_cat_bwd", "cvc_stable_order", "cvc_col_sum"}
 EXPERIMENTAL = {
     "cvc_gsk_plan", "cvc_gsk_gemm", "cvc_attn_scores_qslab", "cvc_top2_slab", "cvc_packed_lstm_ks_slices", "cvc_packed_lstm_ks_fwd",
     "cvc_packed_lstm_ksf_fwd", "cvc_packed_lstm_ksx_local", "cvc_packed_lstm_ksx_fwd", "cvc_packed_lstm_wg_blocks",
@@ -728,8 +730,33 @@ def _embed_order(idx: torch.Tensor) -> torch.Tensor:
     if o is None:
         if len(_order_cache) > 16:
             _order_cache.clear()
-        o = _order_cache[key] = (torch.argsort(idx, stable=True), idx)      # (idx kept alive: its address is the key)
+        o = _order_cache[key] = (stable_order(idx), idx)      # (idx kept alive: its address is the key)
     return o[0]
+
+
+def stable_order(idx: torch.Tensor) -> torch.Tensor:
+    """torch.argsort(idx, stable=True) for a 1-d int64 tensor (one launch, cvc_stable_order, up to 8192 keys)"""
+    idx = idx.contiguous()
+    if idx.dim() != 1 or idx.dtype != torch.int64 or not 1 <= idx.numel() <= 8192:
+        return torch.argsort(idx, stable=True)
+    order = torch.empty_like(idx)
+    _check(lib().cvc_stable_order(_dev(idx, torch.int64), idx.numel(), _dev(order, torch.int64), _stream()), "cvc_stable_order")
+    return order
+
+
+def col_sum(x: torch.Tensor, out: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [S, n] (unit inner stride) -> sum over rows [n], written to `out` (and `out2`) when given: bias gradients"""
+    assert x.dim() == 2 and x.dtype == torch.float32
+    if x.stride(1) != 1 or x.stride(0) < x.shape[1]:
+        x = x.contiguous()
+    S, n = x.shape
+    if out is None:
+        out = torch.empty(n, device=x.device, dtype=torch.float32)
+    assert out.is_contiguous() and out.numel() == n and (out2 is None or (out2.is_contiguous() and out2.numel() == n))
+    if not x.is_cuda:
+        raise RuntimeError("cvc.hip: col_sum input must live on the GPU (no CPU fallback for the hot path)")
+    _check(lib().cvc_col_sum(x.data_ptr(), x.stride(0), S, n, _dev(out), _dev(out2), _stream()), "cvc_col_sum")
+    return out
 
 
 def embed_relu_rng_bwd(table, idx, state, site: int, p: float, d_out, d_table=None):

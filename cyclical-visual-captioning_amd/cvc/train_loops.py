@@ -153,10 +153,11 @@ def _weight_grads(arena: LoopArena, cfg, W):
     hip.tile_mm(Dp, Hlp, out=d_ih[:, :R])
     # [B, 4R] sum over every step of every loop (accumulated by the gate-gradient kernel): the fc columns' dY (fc is the same row
     # every step) and the biases
-    DGsum = arena.dgsum_att[slots[0]] if nl == 1 else arena.dgsum_att[slots[0]:slots[-1] + 1].sum(0)
+    DGsum = arena.dgsum_att[slots[0]:slots[-1] + 1].view(nl * B, 4 * R)      # (two loops: the rows of both, summed by the products below)
     e0 = R
     if cfg.has_fc:
-        hip.tile_mm(DGsum, W["fc"], a_kmajor=True, b_kmajor=True, out=d_ih[:, R:2 * R])
+        fc2 = W["fc"] if nl == 1 else W["fc"].repeat(nl, 1)
+        hip.tile_mm(DGsum, fc2, a_kmajor=True, b_kmajor=True, out=d_ih[:, R:2 * R])
         e0 = 2 * R
     hip.tile_mm(Dp, Em, b_kmajor=True, out=d_ih[:, e0:])
     O["w_ih_a"].done()
@@ -169,13 +170,11 @@ def _weight_grads(arena: LoopArena, cfg, W):
     O["w_ih_l"].done()
     # ---- the two weight_hh + biases   (67 MB each)
     hip.tile_mm(Dp, Ha_prev, b_kmajor=True, out=O["w_hh_a"].t)
-    torch.sum(DGsum, 0, out=O["b_ih_a"].t)
-    O["b_hh_a"].t.copy_(O["b_ih_a"].t)
+    hip.col_sum(DGsum, O["b_ih_a"].t, O["b_hh_a"].t)
     for k in ("w_hh_a", "b_ih_a", "b_hh_a"):
         O[k].done()
     hip.tile_mm(Dl, Hlp, out=O["w_hh_l"].t)
-    torch.sum(arena.dgsum_lang[slots[0]:slots[-1] + 1].view(nl * B, 4 * R), 0, out=O["b_ih_l"].t)
-    O["b_hh_l"].t.copy_(O["b_ih_l"].t)
+    hip.col_sum(arena.dgsum_lang[slots[0]:slots[-1] + 1].view(nl * B, 4 * R), O["b_ih_l"].t, O["b_hh_l"].t)
     for k in ("w_hh_l", "b_ih_l", "b_hh_l"):
         O[k].done()
     # ---- h2attn / alpha_net: loop A's rows only
@@ -184,10 +183,10 @@ def _weight_grads(arena: LoopArena, cfg, W):
         DQ = x["dq"].view(n, -1)
         O["w_h"], O["b_h"] = _Out(W["w_h"]), _Out(W["b_h"])
         hip.tile_mm(DQ, arena.h_att[arena.rows(0)], a_kmajor=True, b_kmajor=True, out=O["w_h"].t)
-        torch.sum(DQ, 0, out=O["b_h"].t)
+        hip.col_sum(DQ, O["b_h"].t)
         if x.get("dwa_part") is not None:
             O["w_a"], O["b_a"] = _Out(W["w_a"]), _Out(W["b_a"])
-            torch.sum(x["dwa_part"].view(n, -1), 0, out=O["w_a"].t.view(-1))
+            hip.col_sum(x["dwa_part"].view(n, -1), O["w_a"].t.view(-1))
             O["b_a"].t.copy_((x["ds_r"].sum() + x["ds_f"].sum()).reshape(1))
     return {k: o.done() for k, o in O.items()}
 

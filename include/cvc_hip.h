@@ -747,7 +747,7 @@ CVC_API int cvc_train_loops_bwd_joint(const cvc_train_loop* loop_a, const cvc_tr
  * frees; cvc_train_loop_profile_read waits for the recorded launches and returns their count, kind[i] (0 zero fill, 1 attention
  * cell, 2 h2attn, 3 score pass, 4 weighted sum, 5 language cell, 6 / 10 gate gradients of the language / attention cell, 7 / 9 /
  * 11 backward-data product of the language cell / h2attn / the attention cell, 8 attention backward), loop[i] (0 / 1 forward of
- * loop A / C, 2 / 3 their backward) and ms[i]; the record is emptied. */
+ * loop A / C, 2 / 3 their backward, 4 a product of the joint backward that serves both loops) and ms[i]; the record is emptied. */
 CVC_API int cvc_train_loop_profile(int enable);
 CVC_API int cvc_train_loop_profile_read(int* kind, int* loop, float* ms, int cap);
 

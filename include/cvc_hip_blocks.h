@@ -125,6 +125,15 @@ int cvc_class_softmax_bwd(const float* p_rows, const float* d_rows, const float*
 int cvc_layernorm_cat_bwd(const float* const* xs, const long long* ldx, const int* widths, int nseg, long long rows, float eps,
                           const float* d_out, long long ld_out, float* const* dxs, const long long* lddx, cvc_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Small helpers of the training step (deterministic; were library launches):
+ * cvc_stable_order -- order[r] = index of the r-th key in a STABLE ascending sort of key[n] (n <= 8192): the row grouping of the
+ *   embedding backward (torch.argsort(stable=True) in the host mirror);
+ * cvc_col_sum -- out[c] (and out2[c] when given) = sum_s x[s * ld + c], s < S, c < n: bias gradients (nn.Linear / nn.LSTMCell
+ *   bias_ih and bias_hh receive the same sum). */
+int cvc_stable_order(const int64_t* key, int n, int64_t* order, cvc_stream_t stream);
+int cvc_col_sum(const float* x, long long ld, int S, int n, float* out, float* out2, cvc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1250,3 +1250,23 @@ def test_torch_library_ops_match_the_functional_path(dev, lib, tiny):
     assert not (word == synth.UNK_IDX).any()
     torch.library.opcheck(torch.ops.cvc.embed_relu, (table.detach().requires_grad_(), idx), test_utils=("test_schema", "test_faketensor"))
     torch.library.opcheck(torch.ops.cvc.vocab_nll, (logits.detach(), tgt, w), test_utils=("test_schema", "test_faketensor"))
+
+
+def test_stable_order_and_col_sum_blocks_vs_torch():
+    """the embedding backward's row grouping (== torch.argsort(stable=True), bit-exact, duplicates included) and the bias-gradient
+    column sums (fp32 sums in a different order: 1e-6 relative)"""
+    from cvc import hip
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    for n, hi in ((1, 5), (7, 3), (256, 50), (1280, 300), (1281, 9000), (8192, 17)):
+        idx = torch.randint(0, hi, (n,), generator=g).to(dev)
+        got = hip.stable_order(idx)
+        assert torch.equal(got, torch.argsort(idx, stable=True)), n
+    for S, n in ((1, 1), (5, 64), (64, 4096), (1280, 512), (1283, 1001)):
+        x = torch.randn(S, n + 3, generator=g).to(dev)[:, :n]          # row stride > n
+        ref = x.double().sum(0)
+        o1, o2 = torch.empty(n, device=dev), torch.empty(n, device=dev)
+        hip.col_sum(x, o1, o2)
+        assert torch.equal(o1, o2)
+        tol = 1e-6 * float(x.abs().double().sum(0).max())
+        assert float((o1.double() - ref).abs().max()) <= tol, (S, n)

@@ -28,8 +28,27 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "cyclical-visual-captioning_amd"))
 
 
-def roles_for(mode, beam, T):
+def roles_for(mode, beam, T, B=64):
     """role name (bench.py's launch name) -> (regex on the kernel symbol, period, set of positions inside the period)"""
+    if mode == "train" and 2 * B <= 64:
+        # joint backward of both loops (cvc_train_loops_bwd_joint): T x (language product, h2attn product, attention product), the
+        # last one missing at t = 0
+        lstm = r"skinny_gemm_packed_kernelILi\dELb1E"
+        nn = r"skinny_gemm_nn_split_kernel"
+        pa = 3 * T - 1
+        return {
+            "loopA.fwd.att_cell": (lstm, 4 * T, {j for j in range(2 * T) if j % 2 == 0}),
+            "loopA.fwd.lang_cell": (lstm, 4 * T, {j for j in range(2 * T) if j % 2 == 1}),
+            "loopC.fwd.att_cell": (lstm, 4 * T, {2 * T + j for j in range(2 * T) if j % 2 == 0}),
+            "loopC.fwd.lang_cell": (lstm, 4 * T, {2 * T + j for j in range(2 * T) if j % 2 == 1}),
+            "loops.bwd.nn_lang": (nn, pa, {j for j in range(pa) if j % 3 == 0}),
+            "loopA.bwd.nn_h2attn": (nn, pa, {j for j in range(pa) if j % 3 == 1}),
+            "loops.bwd.nn_att": (nn, pa, {j for j in range(pa) if j % 3 == 2}),
+            "loopA.fwd.attn_scores": (r"attn_scores_kernelILi0ELi\d+ELi1E", 1, {0}),
+            "loopA.fwd.attn_wsum": (r"attn_wsum_kernelE", 1, {0}),
+            "loopA.bwd.attn_bwd": (r"attn_score_bwd2", 1, {0}),
+            "cvc_tile_gemm": (r"tile_gemm_ld2?_kernel", 1, {0}),
+        }
     if mode == "train":
         # forward of a step: loop A = T x (attention cell, language cell), then loop C = T x (attention cell, language cell);
         # backward: loop C first (T x (language product, attention product), none for the attention cell at t = 0), then loop A
@@ -50,6 +69,7 @@ def roles_for(mode, beam, T):
             "loopA.bwd.nn_att": (nn, pc + pa, {pc + j for j in range(pa) if j % 3 == 2}),
             "loopA.fwd.attn_scores": (r"attn_scores_kernelILi0ELi\d+ELi1E", 1, {0}),
             "loopA.fwd.attn_wsum": (r"attn_wsum_kernelE", 1, {0}),
+            "loopA.bwd.attn_bwd": (r"attn_score_bwd2", 1, {0}),
             "cvc_tile_gemm": (r"tile_gemm_ld2?_kernel", 1, {0}),
         }
     if beam > 1:
@@ -103,7 +123,7 @@ def main():
     a = ap.parse_args()
     import build_hip
     from cvc import synth
-    T = synth.CONFIGS[a.config].T
+    T, B = synth.CONFIGS[a.config].T, synth.CONFIGS[a.config].B
     fetch, write = per_dispatch(a.fetch_db, "FETCH_SIZE"), per_dispatch(a.write_db, "WRITE_SIZE")
     out = {"_how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python3 bench.py ...; "
                    "hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 per launch (MI355X_MICROARCH.md, HBM section: FETCH_SIZE "
@@ -116,7 +136,7 @@ def main():
     except Exception:
         out["git_head"] = None
     rows = []
-    for role, (pat, period, positions) in roles_for(a.mode, a.beam, T).items():
+    for role, (pat, period, positions) in roles_for(a.mode, a.beam, T, B).items():
         rx = re.compile(pat)
         f = [(n, v) for n, v in fetch if rx.search(n)]
         w = [(n, v) for n, v in write if rx.search(n)]
