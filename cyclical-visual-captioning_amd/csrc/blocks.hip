@@ -49,6 +49,7 @@ const Entry table[] = {
     CVC_B(cvc_layernorm_cat_bwd),
     CVC_B(cvc_stable_order),
     CVC_B(cvc_col_sum),
+    CVC_B(cvc_col_sum_ws),
 #ifdef CVC_EXPERIMENTAL
     CVC_B(cvc_gsk_plan),
     CVC_B(cvc_gsk_gemm),

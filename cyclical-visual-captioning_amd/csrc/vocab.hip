@@ -930,51 +930,92 @@ extern "C" int cvc_vocab_head_nll_fwd(const float* parts, int nparts, long long 
 // bias gradient is a generic reduction): both deterministic, fixed summation order.
 //
 // Stable order of n int64 keys by counting: rank(i) = #{j : key[j] < key[i]} + #{j < i : key[j] == key[i]}; order[rank(i)] = i.
-// Every workgroup holds all keys in LDS (n <= 8192) and ranks 256 of them; all lanes read the same LDS word at a time (broadcast).
+// A workgroup ranks 32 keys: it holds all n keys in LDS, thread (key il, segment sg) counts over an eighth of the j range (all
+// lanes of a segment read the same LDS word: broadcast), the eight counts are added through LDS.
 __global__ __launch_bounds__(WG) void stable_order_kernel(const int64_t* key, int n, int64_t* order) {
     extern __shared__ int64_t keys[];
+    __shared__ int cnt[8][32];
     for (int j = threadIdx.x; j < n; j += WG) keys[j] = key[j];
     __syncthreads();
-    const int i = blockIdx.x * WG + threadIdx.x;
-    if (i >= n) return;
-    const int64_t k = keys[i];
+    const int il = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + il;
+    const int per = (n + 7) / 8;
+    const int j0 = sg * per, j1 = min(n, j0 + per);
     int r = 0;
-    for (int j = 0; j < i; ++j) r += keys[j] <= k ? 1 : 0;
-    for (int j = i + 1; j < n; ++j) r += keys[j] < k ? 1 : 0;
-    order[r] = i;
+    if (i < n) {
+        const int64_t k = keys[i];
+        // j < i: ties count; j > i: strictly smaller only.  Split at i so that the loops carry no per-element branch.
+        const int m = min(max(i, j0), j1);
+#pragma unroll 8
+        for (int j = j0; j < m; ++j) r += keys[j] <= k ? 1 : 0;
+#pragma unroll 8
+        for (int j = max(m, i + 1); j < j1; ++j) r += keys[j] < k ? 1 : 0;
+    }
+    cnt[sg][il] = r;
+    __syncthreads();
+    if (sg == 0 && i < n) {
+        int t = 0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += cnt[g][il];
+        order[t] = i;
+    }
 }
 
-// out[c] (and out2[c]) = sum over the S rows of x[s, c]: one column per lane (a wave reads 256 contiguous bytes of a row), the
-// workgroup's 4 waves take rows w, w + 4, ... and are combined in wave order.
-__global__ __launch_bounds__(WG) void col_sum_kernel(const float* x, long long ld, int S, int n, float* out, float* out2) {
+// out[c] (and out2[c]) = sum over the S rows of x[s, c].  One column per lane (a wave reads 256 contiguous bytes of a row); a
+// workgroup owns 64 columns x one chunk of rows, its 4 waves take rows w, w + 4, ... with 8 loads in flight each and are combined
+// in wave order.  More than one chunk: the chunks' sums go to a [chunks, n] workspace and a second launch of the same kernel adds
+// them, again in a fixed order.
+__global__ __launch_bounds__(WG) void col_sum_kernel(const float* x, long long ld, int S, int rows_per_chunk, int n, float* out, long long ld_out,
+                                                     float* out2) {
     __shared__ float part[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    float s0 = 0.f, s1 = 0.f;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(S, r0 + rows_per_chunk);
+    float acc[8], tail = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc[u] = 0.f;
     if (c < n) {
         const float* p = x + c;
-        int r = wave;
-        for (; r + 4 < S; r += 8) { s0 += p[(size_t)r * ld]; s1 += p[(size_t)(r + 4) * ld]; }
-        if (r < S) s0 += p[(size_t)r * ld];
+        int r = r0 + wave;
+        for (; r + 28 < r1; r += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += p[(size_t)(r + 4 * u) * ld];
+        }
+        for (; r < r1; r += 4) tail += p[(size_t)r * ld];
     }
-    part[wave][lane] = s0 + s1;
+    part[wave][lane] = (((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]))) + tail;
     __syncthreads();
     if (wave == 0 && c < n) {
         const float v = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
-        out[c] = v;
+        out[(size_t)blockIdx.y * ld_out + c] = v;
         if (out2 != nullptr) out2[c] = v;
     }
 }
 
 extern "C" int cvc_stable_order(const int64_t* key, int n, int64_t* order, cvc_stream_t stream) {
-    if (!key || !order || n < 1 || n > 8192) return CVC_E_BADARG;
-    hipLaunchKernelGGL(stable_order_kernel, dim3((n + WG - 1) / WG), dim3(WG), (size_t)n * 8, (hipStream_t)stream, key, n, order);
+    if (!key || !order || n < 1 || n > 7168) return CVC_E_BADARG;      // keys + counters within the 64 KB a workgroup may take
+    hipLaunchKernelGGL(stable_order_kernel, dim3((n + 31) / 32), dim3(WG), (size_t)n * 8, (hipStream_t)stream, key, n, order);
     return cvc_launch_status();
 }
 
-extern "C" int cvc_col_sum(const float* x, long long ld, int S, int n, float* out, float* out2, cvc_stream_t stream) {
+static int col_sum_chunks(int S) { return S <= 128 ? 1 : (S + 63) / 64 < 64 ? (S + 63) / 64 : 64; }
+
+extern "C" long long cvc_col_sum_ws(int S, int n) {
+    const int ch = col_sum_chunks(S);
+    return ch > 1 ? (long long)ch * n : 0;
+}
+
+extern "C" int cvc_col_sum(const float* x, long long ld, int S, int n, float* out, float* out2, float* ws, cvc_stream_t stream) {
     if (!x || !out || S < 1 || n < 1 || ld < n) return CVC_E_BADARG;
-    hipLaunchKernelGGL(col_sum_kernel, dim3((n + 63) / 64), dim3(WG), 0, (hipStream_t)stream, x, ld, S, n, out, out2);
+    const int ch = col_sum_chunks(S);
+    if (ch == 1) {
+        hipLaunchKernelGGL(col_sum_kernel, dim3((n + 63) / 64, 1), dim3(WG), 0, (hipStream_t)stream, x, ld, S, S, n, out, 0, out2);
+        return cvc_launch_status();
+    }
+    if (!ws) return CVC_E_BADARG;
+    const int rpc = (S + ch - 1) / ch;
+    hipLaunchKernelGGL(col_sum_kernel, dim3((n + 63) / 64, ch), dim3(WG), 0, (hipStream_t)stream, x, ld, S, rpc, n, ws, (long long)n, nullptr);
+    hipLaunchKernelGGL(col_sum_kernel, dim3((n + 63) / 64, 1), dim3(WG), 0, (hipStream_t)stream, ws, (long long)n, ch, ch, n, out, 0, out2);
     return cvc_launch_status();
 }
 

@@ -135,7 +135,8 @@ SIGNATURES = {
     "cvc_train_loop_bwd": [C.POINTER(TrainLoop), _P],
     "cvc_train_loops_bwd_joint": [C.POINTER(TrainLoop), C.POINTER(TrainLoop), _P],
     "cvc_stable_order": [_P, _I, _P, _P],
-    "cvc_col_sum": [_P, _LL, _I, _I, _P, _P, _P],
+    "cvc_col_sum": [_P, _LL, _I, _I, _P, _P, _P, _P],
+    "cvc_col_sum_ws": [_I, _I],
     "cvc_train_loop_profile": [_I],
     "cvc_train_loop_profile_read": [C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), _I],
     "cvc_attn_fwd": [_I, _P, _P, _P, _F, C.POINTER(AttnSet), _I, _I, _I, _I, _I, _P, _P],
@@ -246,7 +247,7 @@ BLOCKS = {
     "cvc_lstm_pointwise_bwd3_drop", "cvc_pack_lstm_weights", "cvc_linear_nn_planes_fwd", "cvc_beam_select_parts", "cvc_tile_lstm_finish",
     "cvc_tile_lstm_finish_embgate", "cvc_tile_reorder_pack", "cvc_decode_num_launches", "cvc_gemm_force_generic",
     "cvc_tile_gemm_loaders", "cvc_gru_persistent_waves8", "cvc_relu_dropout_fwd", "cvc_relu_dropout_bwd", "cvc_bn_workspace",
-    "cvc_bn_relu_train_fwd", "cvc_bn_relu_train_bwd", "cvc_class_softmax_bwd", "cvc_layernorm_cat_bwd", "cvc_stable_order", "cvc_col_sum"}
+    "cvc_bn_relu_train_fwd", "cvc_bn_relu_train_bwd", "cvc_class_softmax_bwd", "cvc_layernorm_cat_bwd", "cvc_stable_order", "cvc_col_sum", "cvc_col_sum_ws"}
 EXPERIMENTAL = {
     "cvc_gsk_plan", "cvc_gsk_gemm", "cvc_attn_scores_qslab", "cvc_top2_slab", "cvc_packed_lstm_ks_slices", "cvc_packed_lstm_ks_fwd",
     "cvc_packed_lstm_ksf_fwd", "cvc_packed_lstm_ksx_local", "cvc_packed_lstm_ksx_fwd", "cvc_packed_lstm_wg_blocks",
@@ -274,7 +275,7 @@ def lib() -> C.CDLL:
         l.cvc_block.restype = C.c_void_p
         l.cvc_block.argtypes = [C.c_char_p]
         for name, argtypes in SIGNATURES.items():
-            restype = None if name in _VOID_RETURN else (C.c_longlong if name in ("cvc_train_loop_bwd_ws", "cvc_bn_workspace") else C.c_int)
+            restype = None if name in _VOID_RETURN else (C.c_longlong if name in ("cvc_train_loop_bwd_ws", "cvc_bn_workspace", "cvc_col_sum_ws") else C.c_int)
             if name in BLOCKS or name in EXPERIMENTAL:
                 addr = l.cvc_block(name.encode())
                 if not addr:
@@ -333,6 +334,11 @@ def bump_weights_generation() -> int:
 
 # --------------------------------------------------------------------------- per-entry-point HIP-event timing (bench.py)
 _raw_fns = {}
+# entry points that launch nothing (sizes, switches, handles): an event pair around them would read as ~5 us of GPU time each
+_HOST_ONLY = {"cvc_tile_rows_alloc", "cvc_col_sum_ws", "cvc_train_loop_bwd_ws", "cvc_bn_workspace", "cvc_optim_chunk_elems", "cvc_version",
+              "cvc_block", "cvc_gemm_packed_split", "cvc_gemm_force_generic", "cvc_tile_gemm_loaders", "cvc_gru_persistent_waves8",
+              "cvc_decode_plan_create", "cvc_decode_plan_destroy", "cvc_decode_plan_set_features", "cvc_decode_num_launches",
+              "cvc_train_loop_profile", "cvc_train_loop_profile_read", "cvc_comm_unique_id", "cvc_comm_init", "cvc_comm_destroy"}
 
 
 def enable_timers() -> dict:
@@ -344,6 +350,8 @@ def enable_timers() -> dict:
     if _raw_fns:
         disable_timers()
     for name in SIGNATURES:
+        if name in _HOST_ONLY:
+            continue
         raw = getattr(l, name)
         _raw_fns[name] = raw
 
@@ -735,9 +743,9 @@ def _embed_order(idx: torch.Tensor) -> torch.Tensor:
 
 
 def stable_order(idx: torch.Tensor) -> torch.Tensor:
-    """torch.argsort(idx, stable=True) for a 1-d int64 tensor (one launch, cvc_stable_order, up to 8192 keys)"""
+    """torch.argsort(idx, stable=True) for a 1-d int64 tensor (one launch, cvc_stable_order, up to 7168 keys)"""
     idx = idx.contiguous()
-    if idx.dim() != 1 or idx.dtype != torch.int64 or not 1 <= idx.numel() <= 8192:
+    if idx.dim() != 1 or idx.dtype != torch.int64 or not 1 <= idx.numel() <= 7168:
         return torch.argsort(idx, stable=True)
     order = torch.empty_like(idx)
     _check(lib().cvc_stable_order(_dev(idx, torch.int64), idx.numel(), _dev(order, torch.int64), _stream()), "cvc_stable_order")
@@ -755,7 +763,9 @@ def col_sum(x: torch.Tensor, out: Optional[torch.Tensor] = None, out2: Optional[
     assert out.is_contiguous() and out.numel() == n and (out2 is None or (out2.is_contiguous() and out2.numel() == n))
     if not x.is_cuda:
         raise RuntimeError("cvc.hip: col_sum input must live on the GPU (no CPU fallback for the hot path)")
-    _check(lib().cvc_col_sum(x.data_ptr(), x.stride(0), S, n, _dev(out), _dev(out2), _stream()), "cvc_col_sum")
+    nws = int(lib().cvc_col_sum_ws(S, n))
+    ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
+    _check(lib().cvc_col_sum(x.data_ptr(), x.stride(0), S, n, _dev(out), _dev(out2), _dev(ws), _stream()), "cvc_col_sum")
     return out
 
 

@@ -127,12 +127,14 @@ int cvc_layernorm_cat_bwd(const float* const* xs, const long long* ldx, const in
 
 /* ---------------------------------------------------------------------------------------
  * Small helpers of the training step (deterministic; were library launches):
- * cvc_stable_order -- order[r] = index of the r-th key in a STABLE ascending sort of key[n] (n <= 8192): the row grouping of the
+ * cvc_stable_order -- order[r] = index of the r-th key in a STABLE ascending sort of key[n] (n <= 7168): the row grouping of the
  *   embedding backward (torch.argsort(stable=True) in the host mirror);
  * cvc_col_sum -- out[c] (and out2[c] when given) = sum_s x[s * ld + c], s < S, c < n: bias gradients (nn.Linear / nn.LSTMCell
- *   bias_ih and bias_hh receive the same sum). */
+ *   bias_ih and bias_hh receive the same sum).  ws: cvc_col_sum_ws(S, n) floats (0 -> may be null): row chunks are summed by
+ *   separate workgroups and combined by a second launch, fixed order. */
 int cvc_stable_order(const int64_t* key, int n, int64_t* order, cvc_stream_t stream);
-int cvc_col_sum(const float* x, long long ld, int S, int n, float* out, float* out2, cvc_stream_t stream);
+long long cvc_col_sum_ws(int S, int n);
+int cvc_col_sum(const float* x, long long ld, int S, int n, float* out, float* out2, float* ws, cvc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1258,11 +1258,11 @@ def test_stable_order_and_col_sum_blocks_vs_torch():
     from cvc import hip
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(3)
-    for n, hi in ((1, 5), (7, 3), (256, 50), (1280, 300), (1281, 9000), (8192, 17)):
+    for n, hi in ((1, 5), (7, 3), (33, 2), (256, 50), (1280, 300), (1281, 9000), (7168, 17)):
         idx = torch.randint(0, hi, (n,), generator=g).to(dev)
         got = hip.stable_order(idx)
         assert torch.equal(got, torch.argsort(idx, stable=True)), n
-    for S, n in ((1, 1), (5, 64), (64, 4096), (1280, 512), (1283, 1001)):
+    for S, n in ((1, 1), (5, 64), (64, 4096), (128, 100), (129, 70), (1280, 512), (1283, 1001), (5000, 130)):
         x = torch.randn(S, n + 3, generator=g).to(dev)[:, :n]          # row stride > n
         ref = x.double().sum(0)
         o1, o2 = torch.empty(n, device=dev), torch.empty(n, device=dev)

@@ -142,14 +142,19 @@ def main():
         w = [(n, v) for n, v in write if rx.search(n)]
         if not f:
             continue
-        lead = len(f) % period
-        if lead and lead <= 2 and len(w) == len(f):
-            # one-off launches of the same kernel before the first period (the embedding-gate table is one dense product at bind
-            # time): dropped from the front
-            print(f"[collect_traffic] {role}: {len(f)} dispatches of /{pat}/ = {lead} one-off launch(es) + {len(f) // period} periods of {period}", file=sys.stderr)
-            f, w = f[lead:], w[lead:]
-        elif lead:
-            print(f"[collect_traffic] {role}: {len(f)} dispatches of /{pat}/ are not a multiple of the period {period}: skipped", file=sys.stderr)
+        # one-off launches of the same kernel before the first period (the embedding-gate table is one dense product at bind
+        # time) are dropped from the front; the two passes may hold different numbers of periods (bench.py's untimed settling
+        # replays are time-bounded), so each is trimmed on its own
+        def trim(xs, what):
+            lead = len(xs) % period
+            if lead > 2:
+                print(f"[collect_traffic] {role}: {len(xs)} {what} dispatches of /{pat}/ are not a multiple of the period {period}: skipped", file=sys.stderr)
+                return None
+            if lead:
+                print(f"[collect_traffic] {role}: {len(xs)} {what} dispatches of /{pat}/ = {lead} one-off launch(es) + {len(xs) // period} periods of {period}", file=sys.stderr)
+            return xs[lead:]
+        f, w = trim(f, "FETCH"), trim(w, "WRITE")
+        if f is None or w is None:
             continue
         sel = lambda xs: [v for i, (n, v) in enumerate(xs) if i % period in positions and i // period >= a.skip]
         fsel, wsel = sel(f), sel(w)
