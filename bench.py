@@ -327,7 +327,8 @@ def run_train(args, d, dev, rank, world, steps=None, warmup=None, min_warm=None,
                 bound = "mfma" if wk.get("flops", 0) / (peak_tf * 1e12) > wk["bytes"] / (HBM_PEAK_GBS * 1e9) else "hbm"
                 ent.update(algorithmic_bytes=int(wk["bytes"]), algorithmic_flops=int(wk.get("flops", 0)), achieved_GBs=round(gbs, 1),
                            frac_hbm=round(gbs / HBM_PEAK_GBS, 4), achieved_TFLOPs=round(tf, 2), mfma_peak_TFLOPs=round(peak_tf, 1),
-                           frac_mfma=round(tf / peak_tf, 4), bound=bound, mfma=wk.get("mfma", "none"))
+                           frac_mfma=round(tf / peak_tf, 4), bound=bound, mfma=wk.get("mfma", "none"),
+                           traffic=pmc_traffic(name, args, None, mode="train", beam=1, config_name=config_name)[0])
             kernels.append(ent)
         kernels.append(dict(kernel="(library / ATen kernels and gaps: autograd glue, sorts, small reductions)", ms_per_step=round(ms_step - ours, 3),
                             share=round((ms_step - ours) / ms_step, 4)))
@@ -464,14 +465,20 @@ def run_encoder(args, d, dev, brief=False, steps=None, warmup=None):
     roof = None
     dom = next((e for e in kernels if "achieved_GBs" in e), None)
     if dom is not None:
+        # PMC traffic of the dominant entry point: per-launch average of its kernel x its launches per forward (the work
+        # figures above are per forward too)
+        traffic, tnote = pmc_traffic(dom["kernel"], args, None, mode="encoder", beam=1, config_name=args.config)
+        if traffic is not None:
+            traffic, tnote = traffic * dom["launches"], tnote + f" x {dom['launches']} launches per forward"
         if dom["kernel"] == "cvc_tile_gemm":
             peak = MFMA_BF16_PEAK_TFLOPS / 6
             roof = dict(kernel=dom["kernel"], bound="mfma", achieved=dom["achieved_TFLOPs"], peak=round(peak, 1), unit="TFLOP/s",
-                        frac=round(dom["achieved_TFLOPs"] / peak, 4), traffic=None, ms=dom["ms"],
+                        frac=round(dom["achieved_TFLOPs"] / peak, 4), traffic=traffic, traffic_source=tnote, ms=dom["ms"],
                         peak_note="fp32-equivalent flops; split products issue 6 bf16 MFMAs each: dense bf16 peak / 6")
         else:
             roof = dict(kernel=dom["kernel"], bound="hbm", achieved=dom["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4), traffic=None, ms=dom["ms"], algorithmic_bytes=dom["algorithmic_bytes"],
+                        frac=round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4), traffic=traffic, traffic_source=tnote, ms=dom["ms"],
+                        algorithmic_bytes=dom["algorithmic_bytes"],
                         note="the recurrence is a chain of F dependent steps (10.6 us each: arrival poll, state from L2, MFMAs, "
                              "write-through store): latency-bound far below either roof, DESIGN.md section 7")
     line = {
@@ -689,6 +696,7 @@ def run_decode(args, d, dev, rank, world, dist_on, beam, steps, warmup, min_warm
                 if mult * wk["flops"] / (peak * 1e12) > wk["bytes"] / (HBM_PEAK_GBS * 1e9):
                     bound = "mfma"
             ent["bound"] = bound
+            ent["traffic"] = pmc_traffic(name, args, over, beam=beam, config_name=config_name)[0]      # PMC HBM bytes per launch
         kernels.append(ent)
     kernels.sort(key=lambda e: -(e["share"] or 0))
     # dominant KERNEL, not launch: the two LSTM gate GEMMs of a step are launches of one kernel symbol; when their combined
@@ -877,7 +885,14 @@ def main():
         line["ranks_joined"] = ranks_joined
         emit(line)
     if dist_on:
+        # everything that holds work on the communicator (the captured training step, reducers' events) is gone before the
+        # group is: destroying it under a live graph aborted now and then in the one-rank tests
+        import gc
         import torch.distributed as dist
+        gc.collect()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

@@ -29,6 +29,8 @@ struct WsumArgs {
                                   // 2: as bf16 split-term fragments of the tile GEMM (gemm_tile.hip), row-block stride below
     long long frag_stride;
     float* ctx_sum_rm;            // one-query kernel: the summed context once more, row-major [rows, R] (training loops), or null
+    float raw_scale;              // several-queries kernel, != 0: the weights are `scores` * raw_scale as they are (no softmax, `attn`
+                                  // not written): out[row, :] = scale * sum_n w[row, n] X[clip, n, :] -- the dot-product score backward
 };
 
 // 4 consecutive columns of row m as the three bf16 terms (hi, mid, lo: exact truncation split, gemm_split.h) inside the
@@ -166,6 +168,10 @@ __global__ __launch_bounds__(WG) void attn_wsum_mq_kernel(WsumArgs a, int n_max)
             const int row = clip * a.nq + qbase + u;
             const float* sc = S.scores + (size_t)row * n;
             float* as = a_s + (size_t)u * n_max;
+            if (a.raw_scale != 0.f) {
+                for (int i = lane; i < n; i += 64) as[i] = sc[i] * a.raw_scale;
+                continue;
+            }
             float m = -INFINITY;
             for (int i = lane; i < n; i += 64) m = fmaxf(m, sc[i]);
             m = wave_max(m);
@@ -303,7 +309,7 @@ extern "C" int cvc_attn_scores_qslab(int kind, const cvc_gsk_segs* q, const floa
 }
 
 static int wsum_impl(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum, int ctx_quad,
-                     cvc_stream_t stream, long long frag_stride = 0, float* ctx_sum_rm = nullptr);
+                     cvc_stream_t stream, long long frag_stride = 0, float* ctx_sum_rm = nullptr, float raw_scale = 0.f);
 
 extern "C" int cvc_attn_wsum(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum,
                              cvc_stream_t stream) {
@@ -330,7 +336,7 @@ extern "C" int cvc_attn_wsum_quad_rm(const cvc_attn_set* sets, int nsets, int nc
 }
 
 static int wsum_impl(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum, int ctx_quad,
-                     cvc_stream_t stream, long long frag_stride, float* ctx_sum_rm) {
+                     cvc_stream_t stream, long long frag_stride, float* ctx_sum_rm, float raw_scale) {
     int n_max;
     int rc = check_sets(sets, nsets, nclip, nq, 0, R, &n_max);
     if (rc) return rc;
@@ -339,13 +345,16 @@ static int wsum_impl(const cvc_attn_set* sets, int nsets, int nclip, int nq, int
     wa.set[1] = nsets > 1 ? sets[1] : sets[0];
     wa.nsets = nsets; wa.nq = nq; wa.R = R; wa.ctx_sum = ctx_sum; wa.ctx_quad = ctx_quad; wa.frag_stride = frag_stride;
     wa.ctx_sum_rm = ctx_sum_rm;
+    wa.raw_scale = raw_scale;
     if (ctx_sum_rm != nullptr && nq != 1) return CVC_E_BADARG;
+    if (raw_scale != 0.f && nq < 2) return CVC_E_BADARG;
     if (nq > 1) {
         // queries of a clip in groups of QB (the largest group whose softmax rows + partials fit 64 KB of LDS): the clip's
         // context rows are read once per group; if not even 2 fit, the one-query kernel below takes every row on its own
-        int QB = nq <= 2 ? 2 : (nq <= 4 ? 4 : (nq <= 5 ? 5 : 8));
+        // (10 when it halves the passes over the clip's rows: the T = 20 localizer queries in 2 groups instead of 3)
+        int QB = nq <= 2 ? 2 : (nq <= 4 ? 4 : (nq <= 5 ? 5 : ((nq + 9) / 10 < (nq + 7) / 8 ? 10 : 8)));
         auto lds_of = [&](int qb) { return ((size_t)4 * qb * 64 * 4 + 16 + (size_t)qb * n_max) * sizeof(float); };
-        while (QB > 1 && lds_of(QB) > 64 * 1024) QB = QB == 8 ? 5 : (QB == 5 ? 4 : (QB == 4 ? 2 : 1));
+        while (QB > 1 && lds_of(QB) > 64 * 1024) QB = QB == 10 ? 8 : (QB == 8 ? 5 : (QB == 5 ? 4 : (QB == 4 ? 2 : 1)));
         if (QB > 1) {
             const size_t lds = lds_of(QB);
             dim3 g((R + 255) / 256, nclip, (nq + QB - 1) / QB);
@@ -353,16 +362,28 @@ static int wsum_impl(const cvc_attn_set* sets, int nsets, int nclip, int nq, int
                 case 2: hipLaunchKernelGGL(attn_wsum_mq_kernel<2>, g, dim3(WG), lds, (hipStream_t)stream, wa, n_max); break;
                 case 4: hipLaunchKernelGGL(attn_wsum_mq_kernel<4>, g, dim3(WG), lds, (hipStream_t)stream, wa, n_max); break;
                 case 5: hipLaunchKernelGGL(attn_wsum_mq_kernel<5>, g, dim3(WG), lds, (hipStream_t)stream, wa, n_max); break;
+                case 10: hipLaunchKernelGGL(attn_wsum_mq_kernel<10>, g, dim3(WG), lds, (hipStream_t)stream, wa, n_max); break;
                 default: hipLaunchKernelGGL(attn_wsum_mq_kernel<8>, g, dim3(WG), lds, (hipStream_t)stream, wa, n_max); break;
             }
             return cvc_launch_status();
         }
     }
+    if (raw_scale != 0.f) return CVC_E_TOOBIG;          // (the one-query kernel has no raw-weights form)
     const size_t lds2 = (4 * 64 * 4 + 16 + n_max) * sizeof(float);
     if (lds2 > 64 * 1024) return CVC_E_TOOBIG;
     dim3 g2((R + 255) / 256, nclip * nq);
     hipLaunchKernelGGL(attn_wsum_kernel, g2, dim3(WG), lds2, (hipStream_t)stream, wa);
     return cvc_launch_status();
+}
+
+// out[row, :] = scale * sum_n w[row, n] X[clip(row), n, :] for nq >= 2 rows per clip: X streamed once per group of queries (the
+// several-queries weighted sum without its softmax).  d_q of dot-product attention: w = d_scores, X = proj_context, scale = 1 / temp.
+extern "C" int cvc_attn_weighted_rows(const float* w, const float* X, int nclip, int nq, int n, int R, float scale, float* out,
+                                      cvc_stream_t stream) {
+    if (!w || !X || !out || scale == 0.f || n < 1) return CVC_E_BADARG;
+    cvc_attn_set s{};
+    s.proj = X; s.ctx = X; s.scores = const_cast<float*>(w); s.attn = const_cast<float*>(w); s.n = n;
+    return wsum_impl(&s, 1, nclip, nq, R, out, 0, stream, 0, nullptr, scale);
 }
 
 extern "C" int cvc_attn_fwd(int kind, const float* q, const float* w_a, const float* b_a, float inv_temp,

@@ -47,6 +47,7 @@ const Entry table[] = {
     CVC_B(cvc_bn_relu_train_bwd),
     CVC_B(cvc_class_softmax_bwd),
     CVC_B(cvc_layernorm_cat_bwd),
+    CVC_B(cvc_attn_weighted_rows),
     CVC_B(cvc_stable_order),
     CVC_B(cvc_col_sum),
     CVC_B(cvc_col_sum_ws),

@@ -162,7 +162,7 @@ class DecodeEngine(PackedPath, TilePath, RingPath, ExperimentalPaths):
         if self.packed:
             R = W.R
             d.path, d.qsplit = 0, self.QSPLIT
-            d.w_att, d.w_lang, d.w_h, d.w_o = ptr(W.p_att), ptr(W.p_lang), ptr(W.p_h), ptr(W.p_o)
+            d.w_att, d.w_lang, d.w_h, d.w_o = ptr(W.p_att2 if self.embgate else W.p_att), ptr(W.p_lang), ptr(W.p_h), ptr(W.p_o)
             w_fc = W.w_ih_att[:, R:2 * R]
             d.w_fc, d.ld_w_fc = w_fc.data_ptr(), w_fc.stride(0)
             d.gate_fc, d.q_parts, d.top2_part = ptr(self.gate_fc), ptr(self.q_parts), ptr(self.top2_part)

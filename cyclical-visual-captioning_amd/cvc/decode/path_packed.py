@@ -22,8 +22,11 @@ class PackedPath:
           XL = [ctx_regions + ctx_frames | h_att(t) | h_lang(t-1)]  (lang-LSTM input, K = 3R)"""
         W, R, E = self.W, self.W.R, self.W.E
         dev = self.fc.device
-        if not hasattr(W, "p_att"):
+        # derived copies are built per schedule, on its first use with this checkpoint binding (the default embedding-gate schedule
+        # never builds the full-K attention-cell pack: 168 MB at cfg2)
+        if not self.embgate and not hasattr(W, "p_att"):
             W.p_att = pack_weights(torch.cat([W.w_ih_att[:, 0:R], W.w_ih_att[:, 2 * R:2 * R + E], W.w_hh_att], 1), R)
+        if not hasattr(W, "p_lang"):
             W.p_lang = pack_weights(torch.cat([W.w_ih_lang, W.w_hh_lang], 1), R)
             W.p_h = pack_weights(W.w_h)
             W.p_o = pack_weights(W.w_o)

@@ -135,6 +135,7 @@ SIGNATURES = {
     "cvc_train_loop_bwd": [C.POINTER(TrainLoop), _P],
     "cvc_train_loops_bwd_joint": [C.POINTER(TrainLoop), C.POINTER(TrainLoop), _P],
     "cvc_stable_order": [_P, _I, _P, _P],
+    "cvc_attn_weighted_rows": [_P, _P, _I, _I, _I, _I, _F, _P, _P],
     "cvc_col_sum": [_P, _LL, _I, _I, _P, _P, _P, _P],
     "cvc_col_sum_ws": [_I, _I],
     "cvc_train_loop_profile": [_I],
@@ -247,7 +248,7 @@ BLOCKS = {
     "cvc_lstm_pointwise_bwd3_drop", "cvc_pack_lstm_weights", "cvc_linear_nn_planes_fwd", "cvc_beam_select_parts", "cvc_tile_lstm_finish",
     "cvc_tile_lstm_finish_embgate", "cvc_tile_reorder_pack", "cvc_decode_num_launches", "cvc_gemm_force_generic",
     "cvc_tile_gemm_loaders", "cvc_gru_persistent_waves8", "cvc_relu_dropout_fwd", "cvc_relu_dropout_bwd", "cvc_bn_workspace",
-    "cvc_bn_relu_train_fwd", "cvc_bn_relu_train_bwd", "cvc_class_softmax_bwd", "cvc_layernorm_cat_bwd", "cvc_stable_order", "cvc_col_sum", "cvc_col_sum_ws"}
+    "cvc_bn_relu_train_fwd", "cvc_bn_relu_train_bwd", "cvc_class_softmax_bwd", "cvc_layernorm_cat_bwd", "cvc_stable_order", "cvc_col_sum", "cvc_col_sum_ws", "cvc_attn_weighted_rows"}
 EXPERIMENTAL = {
     "cvc_gsk_plan", "cvc_gsk_gemm", "cvc_attn_scores_qslab", "cvc_top2_slab", "cvc_packed_lstm_ks_slices", "cvc_packed_lstm_ks_fwd",
     "cvc_packed_lstm_ksf_fwd", "cvc_packed_lstm_ksx_local", "cvc_packed_lstm_ksx_fwd", "cvc_packed_lstm_wg_blocks",

@@ -125,6 +125,11 @@ int cvc_class_softmax_bwd(const float* p_rows, const float* d_rows, const float*
 int cvc_layernorm_cat_bwd(const float* const* xs, const long long* ldx, const int* widths, int nseg, long long rows, float eps,
                           const float* d_out, long long ld_out, float* const* dxs, const long long* lddx, cvc_stream_t stream);
 
+/* out[row, :] = scale * sum_n w[row, n] X[row / nq, n, :] (w [nclip * nq, n], X [nclip, n, R], nq >= 2): the several-queries
+ * weighted sum of cvc_attn_wsum without its softmax -- d_q of dot-product attention (model/modules.py:24-76 under autograd) with
+ * w = d_scores, X = proj_context, scale = 1 / temp.  CVC_E_TOOBIG when no group of queries fits the LDS. */
+int cvc_attn_weighted_rows(const float* w, const float* X, int nclip, int nq, int n, int R, float scale, float* out, cvc_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Small helpers of the training step (deterministic; were library launches):
  * cvc_stable_order -- order[r] = index of the r-th key in a STABLE ascending sort of key[n] (n <= 7168): the row grouping of the

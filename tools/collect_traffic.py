@@ -14,7 +14,7 @@ order and position = number mod period.
 The file records the kernel symbol behind every entry and the sha256 of the kernel sources it was collected on
 (build_hip.source_hash()); bench.py refuses the numbers when that hash differs from the build it runs.
 
-usage: collect_traffic.py FETCH.db WRITE.db --config cfg2 --beam 1 [--mode decode|train] [--outdir profiles/traffic] [--md file.md]
+usage: collect_traffic.py FETCH.db WRITE.db --config cfg2 --beam 1 [--mode decode|train|encoder] [--outdir profiles/traffic] [--md file.md]
 """
 import argparse
 import json
@@ -30,6 +30,13 @@ sys.path.insert(0, os.path.join(ROOT, "cyclical-visual-captioning_amd"))
 
 def roles_for(mode, beam, T, B=64):
     """role name (bench.py's launch name) -> (regex on the kernel symbol, period, set of positions inside the period)"""
+    if mode == "encoder":
+        # per-launch averages; bench.py multiplies by the launches per forward
+        return {
+            "cvc_gru_seq_persistent_fwd": (r"gru_persistent_kernel", 1, {0}),
+            "cvc_tile_gemm": (r"tile_gemm_ld2?_kernel", 1, {0}),
+            "cvc_tile_pack_rows_any": (r"tile_pack_rows_(any|blk)_kernel", 1, {0}),
+        }
     if mode == "train" and 2 * B <= 64:
         # joint backward of both loops (cvc_train_loops_bwd_joint): T x (language product, h2attn product, attention product), the
         # last one missing at t = 0
@@ -46,7 +53,8 @@ def roles_for(mode, beam, T, B=64):
             "loops.bwd.nn_att": (nn, pa, {j for j in range(pa) if j % 3 == 2}),
             "loopA.fwd.attn_scores": (r"attn_scores_kernelILi0ELi\d+ELi1E", 1, {0}),
             "loopA.fwd.attn_wsum": (r"attn_wsum_kernelE", 1, {0}),
-            "loopA.bwd.attn_bwd": (r"attn_score_bwd2", 1, {0}),
+            # one role = three kernels per step: d_attn = C . d_ctx on the dot-score kernel, softmax backward, score backward
+            "loopA.bwd.attn_bwd": [(r"attn_scores_kernelILi1ELi\d+ELi1E", 1, {0}), (r"softmax_bwd2_kernel", 1, {0}), (r"attn_score_bwd2", 1, {0})],
             "cvc_tile_gemm": (r"tile_gemm_ld2?_kernel", 1, {0}),
         }
     if mode == "train":
@@ -69,7 +77,8 @@ def roles_for(mode, beam, T, B=64):
             "loopA.bwd.nn_att": (nn, pc + pa, {pc + j for j in range(pa) if j % 3 == 2}),
             "loopA.fwd.attn_scores": (r"attn_scores_kernelILi0ELi\d+ELi1E", 1, {0}),
             "loopA.fwd.attn_wsum": (r"attn_wsum_kernelE", 1, {0}),
-            "loopA.bwd.attn_bwd": (r"attn_score_bwd2", 1, {0}),
+            # one role = three kernels per step: d_attn = C . d_ctx on the dot-score kernel, softmax backward, score backward
+            "loopA.bwd.attn_bwd": [(r"attn_scores_kernelILi1ELi\d+ELi1E", 1, {0}), (r"softmax_bwd2_kernel", 1, {0}), (r"attn_score_bwd2", 1, {0})],
             "cvc_tile_gemm": (r"tile_gemm_ld2?_kernel", 1, {0}),
         }
     if beam > 1:
@@ -106,6 +115,36 @@ def per_dispatch(path, counter):
     return [(n, v) for n, v, _ in cur.execute(q, (counter,))]
 
 
+def part_bytes(role, fetch, write, pat, period, positions, skip):
+    """-> (symbol, dispatches, mean FETCH_SIZE KiB, mean WRITE_SIZE KiB) of the launches of /pat/ at `positions` of every period, or None"""
+    rx = re.compile(pat)
+    f = [(n, v) for n, v in fetch if rx.search(n)]
+    w = [(n, v) for n, v in write if rx.search(n)]
+    if not f:
+        return None
+
+    # one-off launches of the same kernel before the first period (the embedding-gate table is one dense product at bind time) are
+    # dropped from the front; the two passes may hold different numbers of periods (bench.py's untimed settling replays are
+    # time-bounded), so each is trimmed on its own
+    def trim(xs, what):
+        lead = len(xs) % period
+        if lead > 2:
+            print(f"[collect_traffic] {role}: {len(xs)} {what} dispatches of /{pat}/ are not a multiple of the period {period}: skipped", file=sys.stderr)
+            return None
+        if lead:
+            print(f"[collect_traffic] {role}: {len(xs)} {what} dispatches of /{pat}/ = {lead} one-off launch(es) + {len(xs) // period} periods of {period}", file=sys.stderr)
+        return xs[lead:]
+    f, w = trim(f, "FETCH"), trim(w, "WRITE")
+    if f is None or w is None:
+        return None
+    sel = lambda xs: [v for i, (n, v) in enumerate(xs) if i % period in positions and i // period >= skip]
+    fsel, wsel = sel(f), sel(w)
+    if not fsel:
+        return None
+    sym = next(n for i, (n, v) in enumerate(f) if i % period in positions)
+    return sym, len(fsel), sum(fsel) / len(fsel), (sum(wsel) / len(wsel) if wsel else 0.0)
+
+
 def workload_key(config, beam, mode):
     return f"{config}_beam{beam}_{mode}"
 
@@ -136,35 +175,17 @@ def main():
     except Exception:
         out["git_head"] = None
     rows = []
-    for role, (pat, period, positions) in roles_for(a.mode, a.beam, T, B).items():
-        rx = re.compile(pat)
-        f = [(n, v) for n, v in fetch if rx.search(n)]
-        w = [(n, v) for n, v in write if rx.search(n)]
-        if not f:
+    for role, spec in roles_for(a.mode, a.beam, T, B).items():
+        # a role is one kernel launch or, as a list, several launches whose bytes add up (an entry point made of several kernels)
+        parts = [part_bytes(role, fetch, write, pat, period, positions, a.skip) for pat, period, positions in (spec if isinstance(spec, list) else [spec])]
+        if any(p is None for p in parts):
             continue
-        # one-off launches of the same kernel before the first period (the embedding-gate table is one dense product at bind
-        # time) are dropped from the front; the two passes may hold different numbers of periods (bench.py's untimed settling
-        # replays are time-bounded), so each is trimmed on its own
-        def trim(xs, what):
-            lead = len(xs) % period
-            if lead > 2:
-                print(f"[collect_traffic] {role}: {len(xs)} {what} dispatches of /{pat}/ are not a multiple of the period {period}: skipped", file=sys.stderr)
-                return None
-            if lead:
-                print(f"[collect_traffic] {role}: {len(xs)} {what} dispatches of /{pat}/ = {lead} one-off launch(es) + {len(xs) // period} periods of {period}", file=sys.stderr)
-            return xs[lead:]
-        f, w = trim(f, "FETCH"), trim(w, "WRITE")
-        if f is None or w is None:
-            continue
-        sel = lambda xs: [v for i, (n, v) in enumerate(xs) if i % period in positions and i // period >= a.skip]
-        fsel, wsel = sel(f), sel(w)
-        if not fsel:
-            continue
-        fk, wk = sum(fsel) / len(fsel), (sum(wsel) / len(wsel) if wsel else 0.0)
-        sym = next(n for i, (n, v) in enumerate(f) if i % period in positions)
-        out["kernels"][role] = {"symbol": sym, "dispatches": len(fsel), "FETCH_SIZE_KiB": round(fk, 1),
+        fk, wk = sum(p[2] for p in parts), sum(p[3] for p in parts)
+        sym = " + ".join(p[0] for p in parts)
+        n = min(p[1] for p in parts)
+        out["kernels"][role] = {"symbol": sym, "dispatches": n, "FETCH_SIZE_KiB": round(fk, 1),
                                 "WRITE_SIZE_KiB": round(wk, 1), "hbm_bytes": int(round((2 * fk + wk) * 1024))}
-        rows.append((role, sym, len(fsel), fk, wk, (2 * fk + wk) * 1024))
+        rows.append((role, sym, n, fk, wk, (2 * fk + wk) * 1024))
     os.makedirs(a.outdir, exist_ok=True)
     path = os.path.join(a.outdir, workload_key(a.config, a.beam, a.mode) + ".json")
     json.dump(out, open(path, "w"), indent=1)
@@ -172,7 +193,7 @@ def main():
           "| launch | kernel symbol | dispatches | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM bytes per launch = (2F + W) x 1024 |",
           "|---|---|---:|---:|---:|---:|"]
     for role, sym, n, fk, wk, b in rows:
-        md.append(f"| {role} | `{sym[:90]}` | {n} | {fk:.1f} | {wk:.1f} | {b / 1e6:.1f} MB |")
+        md.append(f"| {role} | `{sym[:90]}`{' ...' if len(sym) > 90 else ''} | {n} | {fk:.1f} | {wk:.1f} | {b / 1e6:.1f} MB |")
     md.append("")
     md.append(f"source_hash {out['source_hash']}, git {out['git_head']}, workload {out['workload']}")
     text = "\n".join(md)
