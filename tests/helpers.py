@@ -48,7 +48,7 @@ def deciding_gaps(ref_logp, unk_idx=synth.UNK_IDX):
     return top[..., 0] - top[..., 1]
 
 
-def tie_aware_seq_equal(seq, ref_seq, ref_logp, tol=1e-4, unk_idx=synth.UNK_IDX, clear_gap=1e-3):
+def tie_aware_seq_equal(seq, ref_seq, ref_logp, tol=1e-4, unk_idx=synth.UNK_IDX, clear_gap=1e-3, stats=None):
     """Greedy sequences must match the oracle's, except where the margin that decided the oracle's own word (best against
     second-best word that is not UNK) is inside fp32 noise: then the prefix up to the tie must match and the rest of that clip is
     not comparable.  Clips whose smallest deciding margin exceeds `clear_gap` must match exactly, whole sequence."""
@@ -58,13 +58,16 @@ def tie_aware_seq_equal(seq, ref_seq, ref_logp, tol=1e-4, unk_idx=synth.UNK_IDX,
     clear = gaps.min(axis=1) > clear_gap
     assert np.array_equal(seq[clear], ref_seq[clear]), \
         f"clips with every deciding margin > {clear_gap} differ: {np.nonzero((seq != ref_seq).any(1) & clear)[0].tolist()}"
-    n_exact = 0
+    n_exact, flips, worst = 0, 0, 0.0
     for b in range(B):
         for t in range(T):
             if seq[b, t] == ref_seq[b, t]:
                 n_exact += 1
                 continue
             assert gaps[b, t] < tol, \
-                f"clip {b} step {t}: got {seq[b, t]} want {ref_seq[b, t]} with a clear margin {gaps[b, t]}"
+                f"clip {b} step {t}: got {seq[b, t]} want {ref_seq[b, t]} with a clear margin {gaps[b, t]} (tolerance {tol})"
+            flips, worst = flips + 1, max(worst, float(gaps[b, t]))
             break
+    if stats is not None:      # how close the comparison came to its tolerance (goes to the test log)
+        stats.update(clips=B, clear_clips=int(clear.sum()), flipped_clips=flips, largest_margin_at_a_flip=worst, tol=tol)
     return n_exact

@@ -36,6 +36,7 @@ def close(a, b, **tol):
 
 
 _CACHE = {}
+_TIE_STATS = {}         # test name -> how close the greedy comparison came to its tolerance (tests/helpers.py::tie_aware_seq_equal)
 _BEAM_MATCH = {}        # (config, beam) -> (identical rank-0 sequences, clips), filled by _beam_check; reported at the end of the module
 
 
@@ -145,7 +146,16 @@ def test_cfg5_full_size_greedy_and_beam5_vs_oracle(dev):
     eng = DecodeEngine(W, f, d.T, synth.UNK_IDX).capture()
     seq, att = eng.run()
     seq, att = seq.clone(), att.clone()
-    n = tie_aware_seq_equal(seq.cpu().numpy(), seq_o.numpy(), logp_o.numpy())
+    # Tolerance on the deciding margin: 3e-4 here against 1e-4 at config 2.  Both sides are fp32 -- the oracle's CPU GEMMs are
+    # no more exact than the kernels' -- and at this size a step contracts over K = 3R = 12 288 (config 2: 6 144) and the
+    # recurrence runs T = 30 steps deep (20): the log-prob noise between two fp32 evaluations grows with both, and which side of
+    # a margin of that size the oracle lands on depends on the host's BLAS kernels.  (This test failed once, in one full-suite run
+    # on one box of the pool, and in none of 16 repeats since; the kernels replay bit-identically and read no uninitialised
+    # memory -- CVC_POISON run -- so a margin-sized flip is the suspected cause; the observed margins are reported in the test
+    # log.)  Clips whose every margin exceeds 1e-3 must still match exactly, whole sequence.
+    st = {}
+    n = tie_aware_seq_equal(seq.cpu().numpy(), seq_o.numpy(), logp_o.numpy(), tol=3e-4, stats=st)
+    _TIE_STATS["cfg5 greedy"] = st
     assert n >= 0.98 * d.B * d.T
     same = (seq.cpu() == seq_o).all(1)
     close(att[same.to(dev)], att_o[same], **SEQ_TOL)
@@ -267,3 +277,5 @@ def test_zz_report_beam_match_rates():
     import warnings
     for (name, beam), (n, B) in sorted(_BEAM_MATCH.items()):
         warnings.warn(f"beam match rate {name} beam={beam}: {n}/{B} rank-0 sequences identical to the oracle's")
+    for name, st in sorted(_TIE_STATS.items()):
+        warnings.warn(f"greedy tie check {name}: {st}")
