@@ -53,6 +53,9 @@ def parse():
     p.add_argument("--min-warm-seconds", type=float, default=0.5,
                    help="untimed: keep replaying after the W warm-up steps until this much wall time has passed, so that the "
                         "timed K steps start at settled clocks (a 20-step region is 80 ms)")
+    p.add_argument("--encoder-forward-only", action="store_true",
+                   help="--mode encoder: the HIP forward and its roofline only, no per-piece / library-module comparison passes (PMC "
+                        "collection: MIOpen's GRU does not run under rocprofv3 --pmc on this pool)")
     p.add_argument("--config", default="cfg2", help="cvc.synth.CONFIGS key (cfg2 = B=64,N=100,D=2048,T=20 greedy)")
     for k in ("B", "N", "F", "R", "A", "E", "V", "T"):
         p.add_argument("--" + k, type=int, default=None)
@@ -172,7 +175,8 @@ def algorithmic_work(d, beam):
     return w
 
 
-def run_train(args, d, dev, rank, world, steps=None, warmup=None, min_warm=None, cpu_baseline=True, config_name=None, probe=True):
+def run_train(args, d, dev, rank, world, steps=None, warmup=None, min_warm=None, cpu_baseline=True, config_name=None, probe=True,
+              regions=1):
     """Cyclical training step (BASELINE configs 3-ii / 4): decode -> localize -> reconstruct forward,
     backward, one RCCL gradient all-reduce (world > 1), clip_grad_norm_(0.1), Adam.  Train-mode dropout.
     Returns the bench line (rank 0) or None."""
@@ -229,6 +233,15 @@ def run_train(args, d, dev, rank, world, steps=None, warmup=None, min_warm=None,
         return float(el_.item()), loss_
 
     el, loss = timed_region(steps)
+    region_ms = [round(el / steps * 1e3, 3)]
+    for _ in range(regions - 1):
+        # (the short `secondary` entries of the default run only: `regions` regions of K steps each, the MEDIAN reported -- one
+        # host hiccup inside a 0.3 s region moved an entry by 10 % in one collection; the lines of `--mode train` itself time
+        # exactly K steps once, as the contract says)
+        el_r, loss = timed_region(steps)
+        region_ms.append(round(el_r / steps * 1e3, 3))
+    if regions > 1:
+        el = sorted(region_ms)[len(region_ms) // 2] * steps / 1e3
     ms_step = el / steps * 1e3
     eager_ms = None
     if use_graph:                      # the same step launched eagerly (host-side launch path in the loop), for comparison
@@ -377,7 +390,7 @@ def run_train(args, d, dev, rank, world, steps=None, warmup=None, min_warm=None,
             "dtype": "f32", "data": "synthetic", "samples_per_s": round(d.B * world * steps / el, 2), "loss": float(loss),
             "config": {"workload": f"{config_name}: cyclical train step (decode+localize+reconstruct fwd, bwd, clip, Adam), train-mode dropout",
                        "B_per_gpu": d.B, "global_batch": d.B * world, "N": d.N, "F": d.F, "D": d.R, "T": d.T, "hip_graph": bool(use_graph),
-                       "eager_ms_per_step": eager_ms,
+                       "eager_ms_per_step": eager_ms, **({"timed_regions": regions, "region_ms_per_step": region_ms} if regions > 1 else {}),
                        "parallelism": f"dp{world}: clips sharded, one RCCL gradient exchange per step"},
             "roofline": roof, "cpu_baseline": cpu, "exchange": exchange, "gradient_buckets": buckets, "kernels": kernels}
         if cpu:
@@ -488,7 +501,7 @@ def run_encoder(args, d, dev, brief=False, steps=None, warmup=None):
         "config": {"workload": f"{args.config}: RegionalFeatureExtractorGVD forward (eval), raw frame features [B,{d.F},3072] + region "
                                f"features [B,{d.N},{d.G}]", "B_per_gpu": d.B, "N": d.N, "F": d.F, "D": d.R, "G": d.G},
         "roofline": roof, "cpu_baseline": None, "kernels": kernels}
-    if brief:
+    if brief or args.encoder_forward_only:
         return line
     with torch.no_grad():
         # pieces (same tensors, eval mode)
@@ -800,7 +813,7 @@ def run_secondary(args, dev):
     def train(cfg, est_ms):
         d = synth.CONFIGS[cfg]
         steps = max(3, int(secs * 1e3 / est_ms) + 1)
-        return brief(run_train(args, d, dev, 0, 1, steps=steps, warmup=2, min_warm=0.2, cpu_baseline=False, config_name=cfg))
+        return brief(run_train(args, d, dev, 0, 1, steps=steps, warmup=2, min_warm=0.2, cpu_baseline=False, config_name=cfg, regions=3))
 
     attempt("cfg3 beam=5 decode", lambda: decode("cfg3", 5, 11.0))
     attempt("cfg3 cyclical train step (B=64)", lambda: train("cfg3", 25.0))

@@ -25,11 +25,13 @@ if [ "$WHAT" = "pmc" ] || [ "$WHAT" = "all" ]; then
   pmc_pair cfg5_beam5 cfg5 5 decode --config cfg5 --beam 5 --no-graph --steps 2 --warmup 1 --no-cpu-baseline
   pmc_pair cfg3_train cfg3 1 train --mode train --config cfg3 --steps 2 --warmup 1 --no-cpu-baseline --no-train-graph
   pmc_pair cfg4_train cfg4 1 train --mode train --config cfg4 --steps 2 --warmup 1 --no-cpu-baseline --no-train-graph
-  pmc_pair cfg2_encoder cfg2 1 encoder --mode encoder --steps 2 --warmup 1
+  pmc_pair cfg2_encoder cfg2 1 encoder --mode encoder --steps 2 --warmup 1 --encoder-forward-only
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_m -o m -- python3 $R/bench.py --no-graph --steps 4 --warmup 1 --no-cpu-baseline --no-secondary > $O/pmc_mfma.log 2>&1
   python3 $R/tools/rocpd_pmc.py $(find $O/pmc_m -name "*.db" | head -1) > $O/${TAG}_pmc_mfma_busy.md 2>&1
   rm -rf $O/pmc_m
   cat $O/${TAG}_pmc_traffic.md
+  # the per-workload traffic files travel back through gpurun_out/ (copy them into profiles/traffic/ and commit)
+  rm -rf $O/traffic; cp -r $R/profiles/traffic $O/traffic
 fi
 if [ "$WHAT" = "bench" ] || [ "$WHAT" = "all" ]; then
   # the bench lines read this build's traffic (bench.py refuses a collection whose kernel-source hash is not the build's)
