@@ -48,13 +48,14 @@ def deciding_gaps(ref_logp, unk_idx=synth.UNK_IDX):
     return top[..., 0] - top[..., 1]
 
 
-def tie_aware_seq_equal(seq, ref_seq, ref_logp, tol=1e-4, unk_idx=synth.UNK_IDX, clear_gap=1e-3, stats=None):
+def tie_aware_seq_equal(seq, ref_seq, ref_logp, tol=1e-4, unk_idx=synth.UNK_IDX, clear_gap=1e-3, stats=None, gaps=None):
     """Greedy sequences must match the oracle's, except where the margin that decided the oracle's own word (best against
     second-best word that is not UNK) is inside fp32 noise: then the prefix up to the tie must match and the rest of that clip is
     not comparable.  Clips whose smallest deciding margin exceeds `clear_gap` must match exactly, whole sequence."""
     seq, ref_seq = np.asarray(seq), np.asarray(ref_seq)
     B, T = ref_seq.shape
-    gaps = deciding_gaps(ref_logp, unk_idx)
+    if gaps is None:          # (gaps given: the margins of a stored oracle run, tests/fullsize_oracle.py)
+        gaps = deciding_gaps(ref_logp, unk_idx)
     clear = gaps.min(axis=1) > clear_gap
     assert np.array_equal(seq[clear], ref_seq[clear]), \
         f"clips with every deciding margin > {clear_gap} differ: {np.nonzero((seq != ref_seq).any(1) & clear)[0].tolist()}"

@@ -358,8 +358,9 @@ def _train_mode_parity(d, seed, mix, loss_tol, grad_tol=5e-4, in_kernel=False, r
         if k.startswith("attended_roi_decoder_core.") and "lstm" in k:
             P[k] = P[k.replace("attended_roi_decoder_core.", "decoder_core.")]
     ref = O.cyclical_forward(P, O.to_torch(f), O.to_torch(b), T=d.T, vocab_size=d.V, dropout=masks)
-    ref_eval = O.cyclical_forward(P, O.to_torch(f), O.to_torch(b), T=d.T, vocab_size=d.V)
-    assert abs(float(ref[0].detach()) - float(ref_eval[0].detach())) > 1e-3          # the masks do change the pass (not an eval-mode rerun)
+    if d.B * d.T <= 256:      # (small configs only: at full size the second oracle pass costs 10 s of host time for the same sanity check)
+        ref_eval = O.cyclical_forward(P, O.to_torch(f), O.to_torch(b), T=d.T, vocab_size=d.V)
+        assert abs(float(ref[0].detach()) - float(ref_eval[0].detach())) > 1e-3          # the masks do change the pass (not an eval-mode rerun)
     O.training_loss(ref, xe_loss_weight=mix[0], w_att2=mix[1], w_cls=0.0, caption_consistency_loss_weight=mix[2]).backward()
     used = []
 

@@ -280,3 +280,24 @@ def test_label_glue_matches_reference_side_products(g1):
     assert float(ov[b["frm_mask"]].abs().max()) == 0.0
     lab = O.bbox_target(b["box_mask"][:, :, :, 1], ov)
     assert lab.dtype == torch.bool and lab.shape == (d.B, d.N)
+
+
+def test_stored_fullsize_oracle_results_are_what_the_oracle_returns():
+    """tests/golden/fullsize/cfg2_seed1236_greedy.npz (read by the -m gpu full-size tests instead of re-running the oracle on the
+    host, tests/fullsize_oracle.py) against the live oracle on the same seeded inputs: same words (up to fp32 near-ties, should the
+    host's BLAS differ from the one the file was written on), same attention maps, same deciding margins."""
+    import torch
+    from helpers import tie_aware_seq_equal
+    import fullsize_oracle as FO
+    from oracle import ref_cpu as O
+    d = synth.CONFIGS["cfg2"]
+    sd, f_np = synth.hot_path_state_dict(d, 1236), synth.clip_features(d, 1236)
+    ref, src = FO.greedy("cfg2", 1236, d, sd, f_np)
+    assert src == "fixture", "tests/golden/fullsize/cfg2_seed1236_greedy.npz is missing or was made from other inputs: run tools/make_fullsize_fixtures.py"
+    with torch.no_grad():
+        seq, att, _, logp = O.greedy_sample(O.to_torch(sd), O.to_torch(f_np), d.T, synth.UNK_IDX, return_logprobs=True)
+    n = tie_aware_seq_equal(seq.numpy(), ref["seq"], None, gaps=ref["gaps"])
+    assert n >= 0.99 * d.B * d.T
+    same = (seq.numpy() == ref["seq"]).all(1)
+    np.testing.assert_allclose(att.numpy()[same], ref["att"][same], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(FO.deciding_gaps(logp.numpy())[same], ref["gaps"][same], rtol=0, atol=2e-5)
