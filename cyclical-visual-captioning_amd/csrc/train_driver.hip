@@ -25,6 +25,18 @@ struct Prof {
 } g_prof;
 int g_prof_loop = 0;
 
+// Cache policy of the four feature tensors inside the training loops (cvc_attn_set.stream).  When they exceed the 256 MiB Infinity
+// Cache (config 3: 456 MB) nothing of them survives from one step to the next and non-temporal reads leave the L2 to the small
+// operands (queries, scores): score pass 39.5 -> 35.3 us, weighted sum 57.3 -> 52.5, attention backward 102 -> 87 us per step, the
+// step 19.46 -> 18.94 ms.  When they fit (config 4's 32-clip share: 228 MB) cacheable reads win (12.34 against 12.42 ms).
+// CVC_TRAIN_ATTN_STREAM=0 / 3 forces either (A/B).
+inline int feat_stream(const cvc_train_loop& L) {
+    static const int forced = getenv("CVC_TRAIN_ATTN_STREAM") ? atoi(getenv("CVC_TRAIN_ATTN_STREAM")) : -1;
+    if (forced >= 0) return forced & 3;
+    const unsigned long long bytes = 4ull * L.B * (L.N + L.F) * ((unsigned long long)L.A + L.R);
+    return bytes > (256ull << 20) ? 3 : 0;
+}
+
 struct ProfScope {
     hipStream_t st;
     int slot = -1;
@@ -137,9 +149,9 @@ int run_fwd(const cvc_train_loop& L, hipStream_t st, int* launches) {
             }
             cvc_attn_set sets[2];
             sets[0] = cvc_attn_set{L.ppool, L.pool, L.mask, L.frame_mask ? L.frame_mask + (size_t)t * B * N : nullptr, L.scores_ws,
-                                   L.fm ? L.fm + (size_t)t * B * N : nullptr, L.attn_r + (size_t)t * B * N, nullptr, N, 0};
+                                   L.fm ? L.fm + (size_t)t * B * N : nullptr, L.attn_r + (size_t)t * B * N, nullptr, N, feat_stream(L)};
             sets[1] = cvc_attn_set{L.pconv, L.conv, nullptr, nullptr, L.scores_ws + (size_t)B * N, nullptr,
-                                   L.attn_f + (size_t)t * B * F, nullptr, F, 0};
+                                   L.attn_f + (size_t)t * B * F, nullptr, F, feat_stream(L)};
             if (L.wp_h) CVC_TRY_K(K_SCORES, cvc_attn_scores_qparts(L.attn_kind, q, qs, L.b_h, L.w_a, L.b_a, L.inv_temp, sets, 2, B, 1, A, st));
             else CVC_TRY_K(K_SCORES, cvc_attn_scores(L.attn_kind, q, L.w_a, L.b_a, L.inv_temp, sets, 2, B, 1, A, st));
             CVC_TRY_K(K_WSUM, cvc_attn_wsum_quad_rm(sets, 2, B, R, L.xl[rd], L.ctx + (size_t)t * BR, st));
@@ -273,6 +285,7 @@ int run_bwd(const cvc_train_loop* LA, const cvc_train_loop* LC, hipStream_t st, 
             sets[0].frame_masked = L.d_fm ? const_cast<float*>(L.d_fm) + (size_t)t * B * N : nullptr;
             sets[1].proj = L.pconv; sets[1].ctx = L.conv; sets[1].attn = L.attn_f + (size_t)t * B * F; sets[1].n = F;
             sets[1].scores = L.ds_f + (size_t)t * B * F;
+            sets[0].stream = sets[1].stream = feat_stream(L);
             float* d_proj[2] = {L.d_ppool, L.d_pconv};
             float* d_cf[2] = {L.d_pool, L.d_conv};
             const bool any_dp = L.d_ppool || L.d_pconv;
