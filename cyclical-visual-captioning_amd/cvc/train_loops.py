@@ -378,6 +378,8 @@ class _Loop(torch.autograd.Function):
         if kind == 1 and ni[4]:
             d_ctx = hip.tile_mm(DGl, hip.weight_operand(w_ih_l[:, :R], kmajor=True)).view(T, B, R).transpose(0, 1)
         del live
+        if kind == 0:
+            arena.loop_a = None          # (the arena <-> context cycle would keep this loop's buffers alive until a gc pass)
         return (None, None, d_emb, d_fc, d_ctx, *grads_feat, *wg, None, None)
 
 
