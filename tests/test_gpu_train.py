@@ -574,3 +574,44 @@ def test_clip_adam_equals_clip_grad_norm_plus_torch_adam(weight_decay, max_norm)
     r3.step(); o3.step()
     for p, q in zip(pe, pf):
         assert torch.allclose(q, p, rtol=2e-6, atol=2e-7) and torch.equal(q.grad, p.grad)
+
+
+@pytest.mark.parametrize("cfg,B,train", [("tiny", None, False), ("tiny", None, True), ("cfg1", 5, True)])
+def test_joint_backward_of_both_loops_equals_the_two_passes(cfg, B, train):
+    """cvc_train_loops_bwd_joint (both loops' rows in one 64-row operand, 2B <= 64: 3 backward-data products per step instead of 5,
+    loop A's outputs passed through loop C's graph node) against cvc_train_loop_bwd twice: same kernels row for row at these
+    sizes, so the five losses and every parameter gradient must be bit-identical (all four loss terms weighted)."""
+    import dataclasses
+    from helpers import build_model, to_dev, model_call
+    from cvc import train_loops, dropout
+    dev = torch.device("cuda:0")
+    d = synth.CONFIGS[cfg] if B is None else dataclasses.replace(synth.CONFIGS[cfg], B=B)
+    assert 2 * d.B <= 64
+    model = build_model(d, synth.hot_path_state_dict(d, 7), dev)
+    if train:
+        model.train()
+    f, b = to_dev(synth.clip_features(d, 7, full_mask_clip=1 if d.B > 1 else None), dev), to_dev(synth.label_glue_batch(d, 7), dev)
+    res = {}
+    keep = train_loops.JOINT_BWD
+    try:
+        for on in (False, True):
+            train_loops.JOINT_BWD = on
+            dropout.seed(123)
+            for p in model.parameters():
+                p.grad = None
+            ls = model_call(model, f, b, False)
+            (0.5 * ls[0].mean() + 0.3 * ls[1].mean() + 0.2 * ls[3].mean() + 0.5 * ls[4].mean()).backward()
+            torch.cuda.synchronize()
+            res[on] = ([x.detach().clone() for x in ls], {k: (None if p.grad is None else p.grad.clone()) for k, p in model.named_parameters()})
+    finally:
+        train_loops.JOINT_BWD = keep
+    for a, r in zip(res[True][0], res[False][0]):
+        assert torch.equal(a, r)
+    n = 0
+    for k, g in res[False][1].items():
+        g2 = res[True][1][k]
+        assert (g is None) == (g2 is None), k
+        if g is not None:
+            assert torch.equal(g, g2), k
+            n += 1
+    assert n >= 15
