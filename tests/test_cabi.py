@@ -119,6 +119,15 @@ def test_train_loop_rejects_incomplete_descriptors():
     assert lib.cvc_train_loop_fwd(ctypes.byref(d), None) == -1 and lib.cvc_train_loop_bwd(ctypes.byref(d), None) == -1
     assert lib.cvc_train_loop_fwd(None, None) == -1
     assert lib.cvc_train_loop_bwd_ws(64, 2048, 1024) > 0 and lib.cvc_train_loop_bwd_ws(65, 2048, 1024) == 0
+    # the joint back-propagation: both descriptors, loop A first, rows fitting one 64-row operand
+    assert lib.cvc_train_loops_bwd_joint(None, None, None) == -1
+    a, c = hip.TrainLoop(), hip.TrainLoop()
+    a.kind, c.kind = 1, 0
+    assert lib.cvc_train_loops_bwd_joint(ctypes.byref(a), ctypes.byref(c), None) == -1
+    # building blocks validate on the host too
+    assert lib.cvc_stable_order(None, 4, None, None) == -1 and lib.cvc_col_sum(None, 4, 4, 4, None, None, None, None) == -1
+    assert lib.cvc_col_sum_ws(64, 4096) == 0 and lib.cvc_col_sum_ws(1280, 512) == 20 * 512
+    assert lib.cvc_attn_weighted_rows(None, None, 1, 2, 4, 4, 1.0, None, None) == -1
 
 
 def test_decode_plan_rejects_incomplete_descriptors():
