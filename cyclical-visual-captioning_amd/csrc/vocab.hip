@@ -559,6 +559,64 @@ __global__ __launch_bounds__(WG) void lstm_pointwise_bwd4_kernel(HSrc3 src, cons
     }
 }
 
+// The same arithmetic, four hidden units per thread: every operand as one 16-byte load, and the K-slice planes of a gradient source
+// requested four at a time before the first is added (the scalar form above walks a source's planes one dependent load after the
+// other -- three sources x 5-8 planes of memory latency in an 11 us launch).  Sums in the same order: same bits.
+__device__ __forceinline__ f32x4 hsrc_load4(const cvc_grad_src& g, int m, int j) {
+    if (g.p == nullptr) return f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* p = g.p + (size_t)m * g.ld + j;
+    f32x4 v = ld4(p);
+    int k = 1;
+    for (; k + 3 < g.nplanes; k += 4) {
+        const f32x4 a = ld4(p + (size_t)k * g.plane_stride), b = ld4(p + (size_t)(k + 1) * g.plane_stride);
+        const f32x4 c = ld4(p + (size_t)(k + 2) * g.plane_stride), d = ld4(p + (size_t)(k + 3) * g.plane_stride);
+        v += a; v += b; v += c; v += d;
+    }
+    for (; k < g.nplanes; ++k) v += ld4(p + (size_t)k * g.plane_stride);
+    return v;
+}
+__global__ __launch_bounds__(WG) void lstm_pointwise_bwd4v_kernel(HSrc3 src, const float* d_hd, DropSpec rng, const float* d_c,
+                                                                  const float* gates, const float* c_prev, const float* c_new, int M,
+                                                                  int R, float* d_gates, float* d_c_prev, float* d_gates_q, float* dg_sum,
+                                                                  int q_row0) {
+    const int j = (blockIdx.x * blockDim.x + threadIdx.x) * 4;      // (64-thread workgroups: 8 x M of them at R = 2048)
+    const int m = blockIdx.y;
+    if (j >= R) return;
+    const size_t o = (size_t)m * R + j, g0 = (size_t)m * 4 * R + j;
+    const f32x4 ig = ld4(gates + g0), fg = ld4(gates + g0 + R), gg = ld4(gates + g0 + 2 * R), og = ld4(gates + g0 + 3 * R);
+    const f32x4 cn = ld4(c_new + o), cp = ld4(c_prev + o);
+    f32x4 s0 = {0, 0, 0, 0}, s1 = s0, s2 = s0, s3 = s0;
+    if (dg_sum != nullptr) { s0 = ld4(dg_sum + g0); s1 = ld4(dg_sum + g0 + R); s2 = ld4(dg_sum + g0 + 2 * R); s3 = ld4(dg_sum + g0 + 3 * R); }
+    f32x4 dhd = d_hd != nullptr ? ld4(d_hd + o) : f32x4{0, 0, 0, 0};
+    const f32x4 dcin = d_c != nullptr ? ld4(d_c + o) : f32x4{0, 0, 0, 0};
+    const f32x4 h0 = hsrc_load4(src.s[0], m, j), h1 = hsrc_load4(src.s[1], m, j), h2 = hsrc_load4(src.s[2], m, j);
+    if (rng.state != nullptr) {
+        const uint32_t r0 = rng.state[0], r1 = rng.state[1], r2 = rng.state[2];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dhd[e] *= cvc_drop_mult(rng, r0, r1, r2, (uint32_t)(o + e));
+    }
+    f32x4 d0, d1, d2, d3, dcp;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float tc = tanhf(cn[e]);
+        const float dh = ((h0[e] + h1[e]) + h2[e]) + dhd[e];
+        const float dcn = dcin[e] + dh * og[e] * (1.f - tc * tc);
+        d0[e] = dcn * gg[e] * ig[e] * (1.f - ig[e]);
+        d1[e] = dcn * cp[e] * fg[e] * (1.f - fg[e]);
+        d2[e] = dcn * ig[e] * (1.f - gg[e] * gg[e]);
+        d3[e] = dh * tc * og[e] * (1.f - og[e]);
+        dcp[e] = dcn * fg[e];
+    }
+    st4(d_gates + g0, d0); st4(d_gates + g0 + R, d1); st4(d_gates + g0 + 2 * R, d2); st4(d_gates + g0 + 3 * R, d3);
+    st4(d_c_prev + o, dcp);
+    if (dg_sum != nullptr) { st4(dg_sum + g0, s0 + d0); st4(dg_sum + g0 + R, s1 + d1); st4(dg_sum + g0 + 2 * R, s2 + d2); st4(dg_sum + g0 + 3 * R, s3 + d3); }
+    if (d_gates_q != nullptr) {
+        float* q = d_gates_q + ((size_t)(j >> 2) * 64 + q_row0 + m) * 4;
+        const size_t qs = (size_t)(R >> 2) * 256;
+        st4(q, d0); st4(q + qs, d1); st4(q + 2 * qs, d2); st4(q + 3 * qs, d3);
+    }
+}
+
 // ------------------------------------------------------------------ beam bookkeeping
 // Candidate (k, v) scores: score[k] + logit[k,v] - lse[k]; -inf for v == unk; a finished hypothesis
 // only offers (k, 0) at its carried score.  The `beam` best of a clip's beam*V candidates are among the
@@ -1077,8 +1135,18 @@ extern "C" int cvc_lstm_pointwise_bwd4(const cvc_grad_src* d_h, const float* d_h
         src.s[i] = d_h[i];
         if (src.s[i].p != nullptr && (src.s[i].nplanes < 1 || src.s[i].ld < R)) return CVC_E_BADARG;
     }
-    hipLaunchKernelGGL(lstm_pointwise_bwd4_kernel, dim3((R + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, src, d_hd,
-                       cvc_drop_spec(rng_state, site, p), d_c, gates, c_prev, c_new, M, R, d_gates, d_c_prev, d_gates_q, dg_sum, q_row0);
+    // four hidden units per thread when every operand allows 16-byte accesses (the training loops' buffers all do)
+    bool vec = (R & 3) == 0;
+    auto al = [&](const void* q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
+    vec = vec && al(d_hd) && al(d_c) && al(gates) && al(c_prev) && al(c_new) && al(d_gates) && al(d_c_prev) && al(d_gates_q) && al(dg_sum);
+    for (int i = 0; i < 3; ++i)
+        if (src.s[i].p != nullptr) vec = vec && al(src.s[i].p) && (src.s[i].ld & 3) == 0 && (src.s[i].plane_stride & 3) == 0;
+    if (vec)
+        hipLaunchKernelGGL(lstm_pointwise_bwd4v_kernel, dim3((R / 4 + 63) / 64, M), dim3(64), 0, (hipStream_t)stream, src, d_hd,
+                           cvc_drop_spec(rng_state, site, p), d_c, gates, c_prev, c_new, M, R, d_gates, d_c_prev, d_gates_q, dg_sum, q_row0);
+    else
+        hipLaunchKernelGGL(lstm_pointwise_bwd4_kernel, dim3((R + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, src, d_hd,
+                           cvc_drop_spec(rng_state, site, p), d_c, gates, c_prev, c_new, M, R, d_gates, d_c_prev, d_gates_q, dg_sum, q_row0);
     return cvc_launch_status();
 }
 
