@@ -898,22 +898,14 @@ def main():
         line["ranks_joined"] = ranks_joined
         emit(line)
     if dist_on:
-        # everything that holds work on the communicator (the captured training step, reducers' events) is gone before the
-        # group is: destroying it under a live graph aborted now and then in the one-rank tests
+        # everything that holds work on the communicator (the captured training step, reducers' events) is released before the
+        # group is torn down
         import gc
         import torch.distributed as dist
         gc.collect()
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
-        if args.mode == "train" and not args.no_train_graph and dist.get_backend() == "nccl":
-            # A training step was captured WITH its RCCL kernels.  The line is out and every rank has passed the barrier: leave
-            # without c10d's communicator teardown, which aborted the interpreter about once in five runs of the one-rank tests
-            # (inside destroy_process_group, after all work had completed) -- a rank that dies there would turn a finished
-            # measurement into a failed launch.
-            sys.stdout.flush()
-            sys.stderr.flush()
-            os._exit(0)
         dist.destroy_process_group()
 
 

@@ -17,6 +17,18 @@ from .path_tile import TilePath
 from .path_ring import RingPath
 from .path_experimental import ExperimentalPaths
 
+def _capture_mode() -> str:
+    """"global" (torch's default) unless an RCCL process group is up: c10d's watchdog thread polls the events of earlier collectives
+    (the rank-count all-reduce, barriers) with hipEventQuery, which fails with hipErrorStreamCaptureUnsupported while ANOTHER thread
+    captures in global mode -- the watchdog then dies with that exception and takes the rank down.  "thread_local" confines the
+    capture's restrictions to the capturing thread (cvc.trainer does the same for the captured training step)."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        torch.cuda.synchronize()
+        return "thread_local"
+    return "global"
+
+
 class DecodeEngine(PackedPath, TilePath, RingPath, ExperimentalPaths):
     """Binds weights + one batch of clip features to preallocated state and a launch list."""
     _warm = set()
@@ -334,7 +346,7 @@ class DecodeEngine(PackedPath, TilePath, RingPath, ExperimentalPaths):
             torch.cuda.current_stream().wait_stream(s)
             DecodeEngine._warm.add(key)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode=_capture_mode()):
             self._run_once()
         self.graph = g
         return self

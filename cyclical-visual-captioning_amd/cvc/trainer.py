@@ -162,7 +162,16 @@ class Trainer:
                     self._core_step(static)
             torch.cuda.current_stream().wait_stream(s)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # With an RCCL exchange in the step, c10d's watchdog thread polls the events of the warm-up steps' collectives
+            # (hipEventQuery) while this thread captures: under the default "global" capture mode that query fails with
+            # hipErrorStreamCaptureUnsupported, the watchdog dies with the exception and takes the process down seconds later
+            # (about one run in five).  "thread_local" confines the capture's restrictions to the capturing thread.
+            # (Also without an exchange of its own, as soon as an RCCL group exists: its earlier barriers are polled the same way.)
+            import torch.distributed as dist
+            rccl_up = dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+            if rccl_up:
+                torch.cuda.synchronize()                     # the warm-up steps' collectives have completed
+            with torch.cuda.graph(g, capture_error_mode="thread_local" if rccl_up else "global"):
                 res = self._core_step(static)
             self._graph = (g, static, res)
         g, static, res = self._graph

@@ -215,10 +215,11 @@ def test_cyclical_gradients_vs_oracle_on_other_shapes(B, N, F, R, A, E, V, T):
 def _run_isolated(scenario: str, timeout: int = 900):
     """Runs _scenario_<name>() of this module in a CHILD interpreter and passes when the child printed SCENARIO-PASSED, i.e. when
     every assertion of the scenario held.  The scenarios that bring up RCCL communicators (torch.distributed "nccl" groups, the
-    C-ABI's own communicator) run this way: tearing a communicator down (c10d's destroy_process_group, ncclCommDestroy, the
-    interpreter's exit) aborted the process about once in five suite runs on this pool -- after all checks had passed, inside
-    librccl / c10d -- and took the whole pytest process, and every test after it, with it.  A child that ends abnormally AFTER
-    its checks is reported as a warning; one that fails a check (or dies before the marker) fails the test with its output."""
+    C-ABI's own communicator) run this way: c10d keeps a watchdog thread per process group, and when that thread dies it takes
+    the whole interpreter -- here: the pytest process and every test after it -- with it.  (It did, about once in five suite runs,
+    until cvc.trainer / cvc.decode captured their graphs in "thread_local" mode: the watchdog's hipEventQuery fails while another
+    thread captures in global mode.)  A child's stderr is part of the failure message, which is how that was found.  A child that
+    ends abnormally AFTER its checks is reported as a warning; one that fails a check, or dies before the marker, fails the test."""
     import os
     import subprocess
     import sys
@@ -233,8 +234,8 @@ def _run_isolated(scenario: str, timeout: int = 900):
     assert "SCENARIO-PASSED" in r.stdout, f"scenario {scenario}: rc={r.returncode}\n--- stdout\n{r.stdout[-3000:]}\n--- stderr\n{r.stderr[-8000:]}"
     assert "libcvc_hip.so" in r.stdout, "the child did not report the in-tree HIP library as loaded"
     if r.returncode != 0:
-        warnings.warn(f"scenario {scenario}: all checks passed, then the child interpreter ended with rc={r.returncode} during communicator "
-                      f"teardown: {r.stderr[-400:]!r}")
+        warnings.warn(f"scenario {scenario}: all checks passed, then the child interpreter ended with rc={r.returncode} after its checks: "
+                      f" {r.stderr[-400:]!r}")
 
 
 def _passed():
@@ -275,9 +276,8 @@ def _scenario_rccl_allreduce_cabi_one_rank():
 
 
 def _release_group(created):
-    """Tear the one-rank RCCL group down only after everything that holds work on its communicator is gone: a captured HIP graph
-    with the exchange inside (Trainer), the reducers' events, queued kernels.  Destroying the group while an instantiated graph
-    still referenced the communicator's kernels aborted the process about once in four suite runs."""
+    """Orderly teardown of the one-rank RCCL group: release what holds work on its communicator (a captured HIP graph with the
+    exchange inside, the reducers' events), drain the stream, then destroy the group."""
     import gc
     import torch.distributed as dist
     gc.collect()
