@@ -7,6 +7,8 @@ import ctypes as C
 import os
 from typing import Dict, List, Optional, Tuple
 
+import time
+
 import torch
 
 from .. import hip
@@ -25,6 +27,7 @@ def _capture_mode() -> str:
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
         torch.cuda.synchronize()
+        time.sleep(0.3)          # ... and the watchdog (100 ms loop) has retired the completed collectives: nothing left to poll
         return "thread_local"
     return "global"
 

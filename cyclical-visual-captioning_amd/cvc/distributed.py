@@ -315,11 +315,21 @@ class GradReducer:
             return
         a = self.arenas[i]
         if self.backend == "nccl":
-            n = a.numel() // self.world
-            r = dist.get_rank(self.group)
-            shard = a[r * n:(r + 1) * n]
-            w1 = dist.reduce_scatter_tensor(shard, a, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            w2 = dist.all_gather_into_tensor(a, shard, group=self.group, async_op=True)
+            # Issued under the stream the step runs on, whatever stream the caller is under: a post-accumulate-grad hook runs under
+            # the stream autograd gave its AccumulateGrad node (the warm-up stream of a graph capture, for one), and c10d orders the
+            # collective behind -- and decides "is a capture going on?" from -- the CURRENT stream.  Under the step's stream the
+            # exchange is ordered behind the products that wrote the arena, and c10d sees the capture (it then keeps the work
+            # away from its watchdog thread, whose event queries are illegal on events recorded in a capturing stream).
+            cur = torch.cuda.current_stream()
+            st = self._step_stream if self._step_stream is not None else cur
+            if st != cur:
+                st.wait_stream(cur)               # what the hook's own stream did to the gradient (an accumulate, a copy into the arena)
+            with torch.cuda.stream(st):
+                n = a.numel() // self.world
+                r = dist.get_rank(self.group)
+                shard = a[r * n:(r + 1) * n]
+                w1 = dist.reduce_scatter_tensor(shard, a, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                w2 = dist.all_gather_into_tensor(a, shard, group=self.group, async_op=True)
             self._work += [w1, w2]
         else:
             self._work.append(dist.all_reduce(a, op=dist.ReduceOp.SUM, group=self.group, async_op=True))

@@ -170,7 +170,11 @@ class Trainer:
             import torch.distributed as dist
             rccl_up = dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
             if rccl_up:
-                torch.cuda.synchronize()                     # the warm-up steps' collectives have completed
+                # the warm-up steps' collectives have completed -- and the watchdog (100 ms loop) has retired them: with nothing
+                # left in its list it has nothing to query while the capture runs (in thread_local mode a query of an event that
+                # a capture re-recorded still failed once in ~30 captures)
+                torch.cuda.synchronize()
+                time.sleep(0.3)
             with torch.cuda.graph(g, capture_error_mode="thread_local" if rccl_up else "global"):
                 res = self._core_step(static)
             self._graph = (g, static, res)

@@ -230,7 +230,14 @@ def _run_isolated(scenario: str, timeout: int = 900):
     code = (f"import sys; sys.path[:0] = {paths!r}; import test_gpu_train as t; t._scenario_{scenario}()")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    r = subprocess.run([sys.executable, "-X", "faulthandler", "-c", code], capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+    WATCHDOG = "Process group watchdog thread terminated with exception"
+    for attempt in range(3):
+        r = subprocess.run([sys.executable, "-X", "faulthandler", "-c", code], capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+        if "SCENARIO-PASSED" in r.stdout or WATCHDOG not in r.stderr:
+            break
+        # c10d's watchdog died (see the docstring): not a verdict on the scenario's checks -- run them again, and say so
+        warnings.warn(f"scenario {scenario}, attempt {attempt + 1}: c10d's watchdog thread took the child down before its checks were "
+                      f"through ({r.stderr[r.stderr.index(WATCHDOG):][:200]!r}); repeating")
     assert "SCENARIO-PASSED" in r.stdout, f"scenario {scenario}: rc={r.returncode}\n--- stdout\n{r.stdout[-3000:]}\n--- stderr\n{r.stderr[-8000:]}"
     assert "libcvc_hip.so" in r.stdout, "the child did not report the in-tree HIP library as loaded"
     if r.returncode != 0:
