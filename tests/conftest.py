@@ -69,6 +69,10 @@ def pytest_collection_modifyitems(config, items):
             if not built:
                 item.add_marker(pytest.mark.skip(reason="experimental forms are not in this build (CVC_EXPERIMENTAL=1 python "
                                                         "cyclical-visual-captioning_amd/build_hip.py --force)"))
+            elif item.get_closest_marker("gpu_experimental"):
+                import torch
+                if not torch.cuda.is_available():
+                    item.add_marker(pytest.mark.skip(reason="needs an MI355X (run with -m gpu_experimental on the GPU box)"))
 
 
 class Golden:
