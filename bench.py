@@ -80,6 +80,9 @@ def parse():
     p.add_argument("--no-train-graph", action="store_true",
                    help="--mode train: time eager steps instead of replays of the step captured into one HIP graph (forward, backward, "
                         "RCCL exchange, clip + Adam)")
+    p.add_argument("--always-exchange", action="store_true",
+                   help="--mode train at N = 1: run the gradient exchange anyway -- the per-bucket in-place reduce-scatter + all-gather on a "
+                        "ONE-rank RCCL communicator, inside the captured step -- and report what it costs (exchange.in_graph_ms)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--spawn", action="store_true",
                    help="start the rank processes through the torch.distributed.run child also for --gpus 1 (the path every N > 1 run takes)")
@@ -176,7 +179,7 @@ def algorithmic_work(d, beam):
 
 
 def run_train(args, d, dev, rank, world, steps=None, warmup=None, min_warm=None, cpu_baseline=True, config_name=None, probe=True,
-              regions=1):
+              regions=1, comm=None, always_exchange=False):
     """Cyclical training step (BASELINE configs 3-ii / 4): decode -> localize -> reconstruct forward,
     backward, one RCCL gradient all-reduce (world > 1), clip_grad_norm_(0.1), Adam.  Train-mode dropout.
     Returns the bench line (rank 0) or None."""
@@ -199,7 +202,29 @@ def run_train(args, d, dev, rank, world, steps=None, warmup=None, min_warm=None,
     model = model.to(dev).train()
     use_graph = not args.no_train_graph
     optim = build_optimizer(model, o, capturable=use_graph)
-    reducer = GradReducer(model.named_parameters())        # flat gradient arenas (also for one rank: one fill / one clip multiply)
+    # flat gradient arenas (also for one rank: one fill / one clip multiply); the exchange runs on the package's own RCCL
+    # communicator (cvc.comm.RcclComm) -- with --always-exchange also at N = 1, on a one-rank communicator
+    own_comm = None
+    if comm is None and always_exchange:
+        from cvc.comm import RcclComm
+        comm = own_comm = RcclComm.single()
+    reducer = GradReducer(model.named_parameters(), comm=comm, always_exchange=always_exchange)
+    try:
+        return _run_train_body(args, d, dev, rank, world, steps, warmup, min_warm, cpu_baseline, config_name, probe, regions, o, model,
+                               optim, reducer, use_graph)
+    finally:
+        # the reducer registers itself in process-global lists (cvc.functional.GRAD_SINKS / LATE_GRAD_LISTENERS): without this every
+        # run_train of the default run would leave its parameters and ~0.5 GB of arenas alive and its sinks in every later claim
+        reducer.remove_hooks()
+        if own_comm is not None:
+            own_comm.destroy()
+
+
+def _run_train_body(args, d, dev, rank, world, steps, warmup, min_warm, cpu_baseline, config_name, probe, regions, o, model, optim, reducer,
+                    use_graph):
+    from cvc import synth
+    from cvc.trainer import Trainer
+    from cvc.distributed import control_all_reduce
     tr = Trainer(o, None, model, optim, None, None, grad_reducer=reducer)
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     feats = {k: t(v) for k, v in synth.clip_features(d, args.seed + rank).items()}
@@ -226,11 +251,11 @@ def run_train(args, d, dev, rank, world, steps=None, warmup=None, min_warm=None,
         for _ in range(n):
             loss_ = step(batch)[0]
         torch.cuda.synchronize()
-        el_ = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        el_ = time.perf_counter() - t0
         if dist_on:
             dist.barrier()
-            dist.all_reduce(el_, op=dist.ReduceOp.MAX)
-        return float(el_.item()), loss_
+            el_ = control_all_reduce([el_], "max")[0]
+        return float(el_), loss_
 
     el, loss = timed_region(steps)
     region_ms = [round(el / steps * 1e3, 3)]
@@ -254,21 +279,29 @@ def run_train(args, d, dev, rank, world, steps=None, warmup=None, min_warm=None,
     # exposed exchange time (N > 1): the same steps with the gradient exchange switched off (every rank then trains on its own
     # shard: a measurement, not a training mode); exposed = step with exchange - step without
     exchange = None
-    if world > 1 and reducer.exchange:
-        # (eager steps on both sides: a captured graph holds the exchange it was captured with)
-        step_keep, step = step, tr.train_step
+    if reducer.exchange:
+        # the same kind of step (graph replay when the headline is one) with the exchange switched off -- a graph holds the
+        # exchange it was captured with, so a second graph is captured for the measurement
         n_x = max(3, min(steps, 10))
         el1, _ = timed_region(n_x)
         reducer.exchange, keep_overlap = False, reducer.overlap
         reducer.overlap = False
+        keep_graph, tr._graph = tr._graph, None
+        step(batch)
+        torch.cuda.synchronize()
         el0, _ = timed_region(n_x)
+        tr._graph = keep_graph
         reducer.exchange, reducer.overlap = True, keep_overlap
-        step = step_keep
+        step(batch)
         ms0, ms1 = el0 / n_x * 1e3, el1 / n_x * 1e3
         grad_bytes = sum(a.numel() * 4 for a in reducer.arenas)
-        exchange = dict(ms_per_step_without_exchange=round(ms0, 3), ms_per_step_with_exchange=round(ms1, 3), exposed_ms=round(ms1 - ms0, 3),
-                        measured_on="eager steps", gradient_bytes=grad_bytes,
-                        algorithm="per bucket: in-place reduce_scatter + all_gather on RCCL, launched from post-accumulate-grad hooks",
+        exchange = dict(ms_per_step_without_exchange=round(ms0, 3), ms_per_step_with_exchange=round(ms1, 3),
+                        in_graph_ms=round(ms1 - ms0, 3) if use_graph else None, exposed_ms=round(ms1 - ms0, 3),
+                        measured_on="HIP-graph replays (exchange captured inside the step's graph)" if use_graph else "eager steps",
+                        ranks=reducer.world, gradient_bytes=grad_bytes,
+                        algorithm="per bucket: in-place reduce_scatter + all_gather on the package's own RCCL communicator (cvc_allreduce_grads), "
+                                  "on an exchange stream forked from / joined to the step's stream by HIP events, launched the moment the "
+                                  "bucket's last gradient product is enqueued",
                         backend=reducer.backend, buckets=len(reducer.arenas))
 
     # ---- when does each gradient bucket become complete, relative to the end of the step (eager step, events on the launch
@@ -391,7 +424,9 @@ def run_train(args, d, dev, rank, world, steps=None, warmup=None, min_warm=None,
             "config": {"workload": f"{config_name}: cyclical train step (decode+localize+reconstruct fwd, bwd, clip, Adam), train-mode dropout",
                        "B_per_gpu": d.B, "global_batch": d.B * world, "N": d.N, "F": d.F, "D": d.R, "T": d.T, "hip_graph": bool(use_graph),
                        "eager_ms_per_step": eager_ms, **({"timed_regions": regions, "region_ms_per_step": region_ms} if regions > 1 else {}),
-                       "parallelism": f"dp{world}: clips sharded, one RCCL gradient exchange per step"},
+                       "parallelism": f"dp{world}: clips sharded, " + (f"one RCCL gradient exchange per step ({reducer.world}-rank communicator, "
+                                                                          f"inside the step)" if reducer.exchange else
+                                                                          "NO gradient exchange in this run (one rank; --always-exchange runs it)")},
             "roofline": roof, "cpu_baseline": cpu, "exchange": exchange, "gradient_buckets": buckets, "kernels": kernels}
         if cpu:
             line["gpu_over_cpu"] = round(line["value"] / cpu["value"], 1)
@@ -646,11 +681,10 @@ def run_decode(args, d, dev, rank, world, dist_on, beam, steps, warmup, min_warm
     torch.cuda.synchronize()
     t_local = time.perf_counter() - t0
     sync_all()
-    t = torch.tensor([t_local], device=dev, dtype=torch.float64)
+    elapsed = t_local
     if dist_on:
-        import torch.distributed as dist
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+        from cvc.distributed import control_all_reduce
+        elapsed = control_all_reduce([t_local], "max")[0]
     units = d.B * d.T * world * steps
     value = units / elapsed
     if rank != 0:
@@ -810,14 +844,16 @@ def run_secondary(args, dev):
         steps = max(3, int(secs * 1e3 / est_ms) + 1)
         return brief(run_decode(args, d, dev, 0, 1, False, beam, steps, 2, 0.15, False, {}, cfg))
 
-    def train(cfg, est_ms):
+    def train(cfg, est_ms, always_exchange=False):
         d = synth.CONFIGS[cfg]
         steps = max(3, int(secs * 1e3 / est_ms) + 1)
-        return brief(run_train(args, d, dev, 0, 1, steps=steps, warmup=2, min_warm=0.2, cpu_baseline=False, config_name=cfg, regions=3))
+        return brief(run_train(args, d, dev, 0, 1, steps=steps, warmup=2, min_warm=0.2, cpu_baseline=False, config_name=cfg, regions=3,
+                               always_exchange=always_exchange))
 
     attempt("cfg3 beam=5 decode", lambda: decode("cfg3", 5, 11.0))
     attempt("cfg3 cyclical train step (B=64)", lambda: train("cfg3", 25.0))
-    attempt("cfg4 cyclical train step, one GPU's share (B=32 per GPU; the 8-GPU job adds the gradient exchange)", lambda: train("cfg4", 15.0))
+    attempt("cfg4 cyclical train step, one GPU's share (B=32 per GPU) WITH the per-bucket RCCL exchange captured in the step, on a "
+            "one-rank communicator (what 8 ranks add is the time on the xGMI links)", lambda: train("cfg4", 15.0, always_exchange=True))
     attempt("cfg5 greedy decode", lambda: decode("cfg5", 1, 19.0))
     attempt("cfg5 beam=5 decode", lambda: decode("cfg5", 5, 48.0))
     attempt("once-per-clip encoder (cfg2 size)", lambda: brief(run_encoder(args, synth.CONFIGS["cfg2"], dev, brief=True, steps=8, warmup=2)))
@@ -860,16 +896,20 @@ def main():
     # barrier / max-over-ranks path is the same code at every N
     dist_on = under_launcher
     ranks_joined = 1
+    comm = None
     if dist_on:
+        # torch.distributed is the CONTROL plane (rendezvous, the communicator's unique id, host barriers, max over ranks) on gloo;
+        # the data plane is the package's own RCCL communicator over xGMI (cvc.comm.RcclComm): no c10d RCCL group, hence no c10d
+        # watchdog thread next to the graph captures below
         import torch.distributed as dist
+        from cvc.comm import RcclComm
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
-        one = torch.ones(1, device=dev, dtype=torch.float64)
-        dist.all_reduce(one)                                # every rank that joined adds 1: the count RCCL itself reports
-        ranks_joined = int(round(float(one.item())))
+        dist.init_process_group("gloo")
+        comm = RcclComm.from_process_group()
+        ranks_joined = comm.count_ranks()                   # every rank adds 1.0 through RCCL: the count the communicator itself reports
         if ranks_joined != args.gpus or dist.get_world_size() != args.gpus:
-            raise SystemExit(f"bench.py: {ranks_joined} rank(s) joined the process group, --gpus asked for {args.gpus}")
+            raise SystemExit(f"bench.py: {ranks_joined} rank(s) joined the RCCL communicator, --gpus asked for {args.gpus}")
 
     import dataclasses
     from cvc import synth
@@ -885,7 +925,7 @@ def main():
         if rank == 0:
             line = run_encoder(args, d, dev)
     elif args.mode == "train":
-        line = run_train(args, d, dev, rank, world)
+        line = run_train(args, d, dev, rank, world, comm=comm, always_exchange=args.always_exchange or dist_on)
     else:
         line = run_decode(args, d, dev, rank, world, dist_on, args.beam, args.steps, args.warmup, args.min_warm_seconds, True, over, args.config)
         default_run = (args.config == "cfg2" and not over and args.beam == 1 and world == 1 and not args.no_secondary and
@@ -896,6 +936,15 @@ def main():
             line["secondary_wall_s"] = round(time.perf_counter() - t0, 1)
     if rank == 0:
         line["ranks_joined"] = ranks_joined
+        # LAST key of the line (a log that keeps only the tail of stdout still shows it): every measurement's headline numbers
+        summ = [dict(name="headline: " + line["config"]["workload"], value=line["value"], unit=line["unit"], ms_per_step=line["ms_per_step"],
+                     roofline_frac=(line.get("roofline") or {}).get("frac"))]
+        for e in line.get("secondary", []):
+            summ.append(dict(name=e.get("name"), value=e.get("value"), unit=e.get("unit"), ms_per_step=e.get("ms_per_step"),
+                             roofline_kernel=(e.get("roofline") or {}).get("kernel"), roofline_frac=(e.get("roofline") or {}).get("frac"),
+                             **({"exchange_in_graph_ms": e["exchange"].get("in_graph_ms")} if e.get("exchange") else {}),
+                             **({"error": e["error"]} if "error" in e else {})))
+        line["summary"] = summ
         emit(line)
     if dist_on:
         # everything that holds work on the communicator (the captured training step, reducers' events) is released before the
@@ -905,7 +954,7 @@ def main():
         gc.collect()
         torch.cuda.synchronize()
         dist.barrier()
-        torch.cuda.synchronize()
+        comm.destroy()
         dist.destroy_process_group()
 
 

@@ -7,7 +7,6 @@ import ctypes as C
 import os
 from typing import Dict, List, Optional, Tuple
 
-import time
 
 import torch
 
@@ -20,14 +19,14 @@ from .path_ring import RingPath
 from .path_experimental import ExperimentalPaths
 
 def _capture_mode() -> str:
-    """"global" (torch's default) unless an RCCL process group is up: c10d's watchdog thread polls the events of earlier collectives
-    (the rank-count all-reduce, barriers) with hipEventQuery, which fails with hipErrorStreamCaptureUnsupported while ANOTHER thread
-    captures in global mode -- the watchdog then dies with that exception and takes the rank down.  "thread_local" confines the
-    capture's restrictions to the capturing thread (cvc.trainer does the same for the captured training step)."""
+    """"global" (torch's default) unless a c10d "nccl" process group is up in this process: its watchdog thread polls the events of
+    earlier collectives with hipEventQuery, which fails with hipErrorStreamCaptureUnsupported while ANOTHER thread captures in
+    global mode -- the watchdog then dies with that exception and takes the rank down.  "thread_local" confines the capture's
+    restrictions to the capturing thread; the decode graph contains no collective, so no event of that group is ever recorded in
+    the capturing stream.  (The package's own runs -- bench.py, cvc.main -- keep torch.distributed on gloo and the exchange on
+    cvc.comm.RcclComm: no such thread exists there.)"""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
-        torch.cuda.synchronize()
-        time.sleep(0.3)          # ... and the watchdog (100 ms loop) has retired the completed collectives: nothing left to poll
         return "thread_local"
     return "global"
 

@@ -24,8 +24,13 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: str = "nccl") -> Tuple[int, int, int]:
-    """(rank, world, local_rank) from torchrun's environment; initialises the process group."""
+def init_from_env(backend: str = "rccl") -> Tuple[int, int, int]:
+    """(rank, world, local_rank) from torchrun's environment; initialises the process group.
+
+    backend "rccl" (the default on GPUs): torch.distributed on "gloo" as the CONTROL plane only (rendezvous, the communicator's
+    unique id, host-side barriers, object broadcasts) -- the gradient exchange itself runs on the package's own RCCL communicator
+    (cvc.comm.RcclComm, `exchange_comm()` below), which has no watchdog thread and can be captured into the step's HIP graph.
+    "nccl": c10d's RCCL process group for control and data (eager steps only).  "gloo": CPU tests."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -35,8 +40,40 @@ def init_from_env(backend: str = "nccl") -> Tuple[int, int, int]:
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group(backend)
+            if backend == "rccl":
+                torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
     return rank, world, local_rank
+
+
+_EXCHANGE_COMM = None
+
+
+def exchange_comm(create: bool = True):
+    """The process's RCCL communicator for the gradient exchange (cvc.comm.RcclComm), built once over the initialised
+    torch.distributed group (its unique id travels on the control plane); None without a group or without a GPU."""
+    global _EXCHANGE_COMM
+    if _EXCHANGE_COMM is None and create and dist.is_available() and dist.is_initialized() and torch.cuda.is_available():
+        from .comm import RcclComm
+        _EXCHANGE_COMM = RcclComm.from_process_group()
+    return _EXCHANGE_COMM
+
+
+def destroy_exchange_comm():
+    global _EXCHANGE_COMM
+    if _EXCHANGE_COMM is not None:
+        _EXCHANGE_COMM.destroy()
+        _EXCHANGE_COMM = None
+
+
+def control_all_reduce(values, op: str = "max"):
+    """all-reduce of a few host numbers over the control plane (CPU tensor on gloo, device tensor on c10d-"nccl") -> list"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return list(values)
+    on_gpu = dist.get_backend() == "nccl"
+    t = torch.tensor(list(values), dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()) if on_gpu else "cpu")
+    dist.all_reduce(t, op={"max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN, "sum": dist.ReduceOp.SUM}[op])
+    return t.tolist()
 
 
 def shard_range(n: int, rank: int, world: int, equal: bool = False) -> slice:
@@ -92,8 +129,12 @@ class GradReducer:
       before BPTT of the decode loop starts and is exchanged under it; everything that is touched at every time step (LSTM
       cells, h2attn, alpha_net, embedding) completes at t = 0.  Each LSTM weight matrix is its own bucket (its deferred
       dW GEMM finishes separately), biases ride with their cell's weight_hh.
-    * With RCCL ("nccl") a bucket goes as in-place reduce_scatter + all_gather over the xGMI mesh, two calls on the
-      communicator's stream issued back to back from the hook; other backends (gloo in the CPU tests) use one all_reduce.
+    * On RCCL a bucket goes as in-place reduce_scatter + all_gather over the xGMI mesh, two calls issued back to back the
+      moment the bucket is complete.  Transport `comm=` (cvc.comm.RcclComm, the package's own communicator -- the default on
+      GPUs): the pair is enqueued on a dedicated exchange stream behind an event of the step's stream, and finalize() makes the
+      step's stream wait for it; no host object, no watchdog thread, capturable into the step's HIP graph.  Transport c10d
+      (`comm=None` with an initialised group): "nccl" issues the same pair through torch.distributed (eager steps only), other
+      backends (gloo in the CPU tests) use one all_reduce.
     * Parameters that never receive a gradient are found on the first step (every rank must see the same
       set: checked) and keep `.grad = None` from then on, as in the reference -- optimizers skip them (no weight decay, no Adam
       state); their arena slots stay zero, so message sizes never depend on None-ness.
@@ -103,12 +144,20 @@ class GradReducer:
     """
 
     def __init__(self, named_params: Iterable[Tuple[str, torch.nn.Parameter]], bucket_mb: float = 0.0, group=None,
-                 overlap: bool = True, world: Optional[int] = None, always_exchange: bool = False):
+                 overlap: bool = True, world: Optional[int] = None, always_exchange: bool = False, comm=None):
         """always_exchange: issue the collectives even in a one-rank group (tests: the RCCL path on a single GPU).
-        bucket_mb > 0 additionally splits the 'rest' bucket into pieces of at most that size (tests use tiny buckets)."""
+        bucket_mb > 0 additionally splits the 'rest' bucket into pieces of at most that size (tests use tiny buckets).
+        comm: a cvc.comm.RcclComm -- the exchange then runs on it (backend "rccl") instead of on torch.distributed."""
         self.group = group
-        self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
-        self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        self.comm = comm
+        if comm is not None:
+            self.world = comm.world
+            self.backend = "rccl"
+        else:
+            self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+            self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        self._comm_stream = None                              # the exchange stream of the `comm` transport (made on first use)
+        self._comm_pending = False
         seen, params = set(), []
         for name, p in named_params:
             if p.requires_grad and id(p) not in seen:       # shared LSTM cells are listed once
@@ -169,7 +218,7 @@ class GradReducer:
         self._arrived: List[set] = [set() for _ in groups]
         self._names: Dict[int, str] = {id(p): n for b in groups for n, p in b}
         self._work: List = []
-        self.exchange = self.world > 1 or (always_exchange and dist.is_initialized())
+        self.exchange = self.world > 1 or (always_exchange and (comm is not None or dist.is_initialized()))
         self.overlap = overlap and self.exchange
         # hooks also without an exchange: the first step learns which parameters ever receive a gradient (see finalize)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for b in groups for _, p in b]
@@ -220,6 +269,10 @@ class GradReducer:
     def claim(self, p):
         i = self._bucket_of.get(id(p))
         if i is None or id(p) in self._dead or id(p) in self._written or self._launched[i]:
+            return None
+        if id(p) in self._hooked or id(p) in self._arrived[i]:
+            # another producer's gradient already sits in the view (AccumulateGrad ran, or an earlier in-place write): an
+            # overwriting product would drop it -- the caller accumulates instead (compute(None) + grad.add_)
             return None
         v = self._views[id(p)]
         if p.grad is None or p.grad.data_ptr() != v.data_ptr():
@@ -314,7 +367,19 @@ class GradReducer:
         if not self.exchange:
             return
         a = self.arenas[i]
-        if self.backend == "nccl":
+        if self.comm is not None:
+            # own communicator: the pair goes on the exchange stream, behind everything the step's stream (and the hook's own
+            # stream, see below) has enqueued so far; plain HIP events order it -- eagerly or as edges of the captured graph
+            cur = torch.cuda.current_stream()
+            st = self._step_stream if self._step_stream is not None else cur
+            if st != cur:
+                st.wait_stream(cur)
+            if self._comm_stream is None:
+                self._comm_stream = torch.cuda.Stream(device=a.device)
+            self._comm_stream.wait_stream(st)
+            self.comm.all_reduce_(a, self._comm_stream)
+            self._comm_pending = True
+        elif self.backend == "nccl":
             # Issued under the stream the step runs on, whatever stream the caller is under: a post-accumulate-grad hook runs under
             # the stream autograd gave its AccumulateGrad node (the warm-up stream of a graph capture, for one), and c10d orders the
             # collective behind -- and decides "is a capture going on?" from -- the CURRENT stream.  Under the step's stream the
@@ -348,13 +413,16 @@ class GradReducer:
                 import zlib
                 sig = [zlib.crc32("\n".join(sorted(self._names[q] for q in (s_ | l_))).encode()) + (len(s_) << 32)
                        for s_, l_ in zip(self._seen_first, self._seen_late)]
-                counts = torch.tensor(sig, dtype=torch.int64, device=self.arenas[0].device)
-                lo, hi = counts.clone(), counts.clone()
-                dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
-                dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
-                if not torch.equal(lo, hi):
-                    raise RuntimeError("GradReducer: ranks disagree on which parameters receive gradients: "
-                                       f"{lo.tolist()} vs {hi.tolist()}")
+                if self.world > 1 and dist.is_initialized():
+                    # (over the control plane: a CPU tensor unless the group is c10d-"nccl")
+                    on_gpu = dist.get_backend(self.group) == "nccl"
+                    counts = torch.tensor(sig, dtype=torch.int64, device=self.arenas[0].device if on_gpu else "cpu")
+                    lo, hi = counts.clone(), counts.clone()
+                    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+                    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+                    if not torch.equal(lo, hi):
+                        raise RuntimeError("GradReducer: ranks disagree on which parameters receive gradients: "
+                                           f"{lo.tolist()} vs {hi.tolist()}")
                 self._expected = [len(s_) for s_ in self._seen_first]
             for i in range(len(self.buckets)):
                 if not self._launched[i]:
@@ -362,6 +430,14 @@ class GradReducer:
             for w in self._work:
                 w.wait()
             self._work.clear()
+            if self._comm_pending:
+                # the step's stream continues (clip + Adam read the arenas) behind the exchange stream
+                st = self._step_stream if self._step_stream is not None else torch.cuda.current_stream()
+                st.wait_stream(self._comm_stream)
+                cur = torch.cuda.current_stream()
+                if cur != st:
+                    cur.wait_stream(self._comm_stream)
+                self._comm_pending = False
             if average:
                 for a in self.arenas:
                     a.mul_(1.0 / self.world)

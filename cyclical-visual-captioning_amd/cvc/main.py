@@ -21,7 +21,7 @@ from torch.utils.data import DataLoader
 from . import opts as cvc_opts
 from . import synth
 from .data_synth import SyntheticCaptionDataset, collate
-from .distributed import GradReducer, init_from_env, shard_range
+from .distributed import GradReducer, init_from_env, shard_range, exchange_comm, destroy_exchange_comm
 from .misc import utils
 from .model.create_model import build_model
 from .trainer import Trainer, build_optimizer
@@ -112,7 +112,10 @@ def main(argv=None):
     lr_history = histories.get("lr_history", {})
 
     optimizer = build_optimizer(model, opt)
-    reducer = GradReducer(model.named_parameters())        # flat gradient arenas; exchanges only when world > 1
+    # flat gradient arenas; exchanges only when world > 1 -- on the package's own RCCL communicator (--dist_backend rccl, the
+    # default: torch.distributed on gloo is the control plane only), whose collectives are captured into the step's HIP graph
+    comm = exchange_comm() if (world > 1 and opt.dist_backend == "rccl") else None
+    reducer = GradReducer(model.named_parameters(), comm=comm)
     trainer = Trainer(opt, full, model, optimizer, loader, val_loader, grad_reducer=reducer)
     scheduler = ReduceLROnPlateau(optimizer, 'max', patience=opt.patience, min_lr=opt.min_lr)
     tb = utils.set_tb_logger(opt.tb_log_dir, opt.exp_name, opt.resume) if (rank == 0 and opt.tensorboard and not opt.inference_only) else None
@@ -152,6 +155,9 @@ def main(argv=None):
                 torch.save(model.state_dict(), os.path.join(save_dir, "model-best.pth"))
                 with open(os.path.join(save_dir, "infos_" + opt.id + "-best.pkl"), "wb") as f:
                     pickle.dump(infos, f)
+    if comm is not None:
+        trainer._graphs.clear()                               # captured steps hold work on the communicator
+        destroy_exchange_comm()
     return 0
 
 

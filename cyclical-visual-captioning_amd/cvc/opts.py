@@ -117,7 +117,7 @@ _CYCLICAL = [
 ]
 _BUILD = [
     ("--hip_graph", dict(type=int, default=1)),             # capture the T-step decode loop in a HIP graph
-    ("--dist_backend", dict(type=str, default="nccl")),     # "nccl" is RCCL on ROCm; "gloo" for CPU tests
+    ("--dist_backend", dict(type=str, default="rccl")),     # "rccl": own RCCL communicator for the exchange + gloo control plane; "nccl": c10d's RCCL group (eager steps); "gloo": CPU tests
     ("--warm_start_mode", dict(type=str, default="reference")),  # "reference" = suffix/last-wins, "corrected"
     ("--results_dir", dict(type=str, default="results")),   # where eval writes the densecap / grounding JSON
     ("--detectron_weights_dir", dict(type=str, default="data/detectron_weights")),  # fc7 / cls_score pickles

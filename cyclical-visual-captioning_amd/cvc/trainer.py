@@ -27,6 +27,43 @@ def _trim(t, n, dim=1):
     return t.narrow(dim, 0, n)
 
 
+SHAPE_BUCKETS = 4         # trimmed lengths are rounded up to one of this many sizes per axis (graphed training: one graph per shape)
+
+
+def bucket_len(n: int, full: int, buckets: int = SHAPE_BUCKETS) -> int:
+    """n rounded up to the next of `buckets` evenly spaced lengths <= full (the loader's padded length).  What lies between n and
+    the bucket's length is the loader's OWN padding -- zero rows with their mask bit set (dataloader_anet.py:376-388), exactly what
+    a shorter clip of the batch already carries up to the batch maximum (trainer.py:63-69) -- so the step computes the same
+    function of the batch; only the set of distinct shapes becomes small enough to keep one captured graph per shape."""
+    if buckets <= 0 or n >= full:
+        return min(n, full)
+    step = -(-full // buckets)
+    return min(full, -(-n // step) * step)
+
+
+def _shape_key(b) -> tuple:
+    out = []
+    for k in sorted(b):
+        v = b[k]
+        if isinstance(v, torch.Tensor):
+            out.append((k, tuple(v.shape), str(v.dtype)))
+        elif isinstance(v, dict):
+            out.append((k, tuple((kk, tuple(vv.shape), str(vv.dtype)) for kk, vv in sorted(v.items()) if isinstance(vv, torch.Tensor))))
+    return tuple(out)
+
+
+def _copy_into(static, b):
+    for k, v in b.items():
+        if isinstance(v, torch.Tensor):
+            static[k].copy_(v, non_blocking=True)
+        elif isinstance(v, dict):
+            for kk, vv in v.items():
+                if isinstance(vv, torch.Tensor):
+                    static[k][kk].copy_(vv, non_blocking=True)
+        else:
+            static[k] = v
+
+
 class Trainer:
     def __init__(self, opts, dataset, model, optimizer, train_loader, val_loader, scorer=None, grad_reducer=None):
         self.opts = opts
@@ -39,19 +76,38 @@ class Trainer:
         self.grad_reducer = grad_reducer
         self.device = next(model.parameters()).device
         self._graph = None            # HIP-graph state of train_step_graphed
+        # ---- train(): one captured graph per (bucketed) batch shape
+        self.shape_buckets = SHAPE_BUCKETS if bool(getattr(opts, "hip_graph", 0)) else 0
+        self._graphs = {}             # shape key -> (graph, static inputs, static result)
+        self._shape_seen = {}         # shape key -> eager steps taken at that shape
+        self._eager_steps = 0
+        self._graph_pool = None
+        self._side = None
+        self._graph_broken = False
+        self.graph_stats = dict(eager=0, replayed=0, captured=0)
 
     # ------------------------------------------------------------------ batch plumbing
     def _prepare(self, batch, train: bool):
         seg_feat, iseq, gts_seq, num, proposals, bboxs, box_mask, seg_id, region_feat, frm_mask, sample_idx, ppl_mask = batch
         n_prop = max(int(num[:, 1].max()), 1)
+        if train and self.shape_buckets:
+            n_prop = bucket_len(n_prop, proposals.size(1), self.shape_buckets)
         proposals, ppl_mask, region_feat = _trim(proposals, n_prop), _trim(ppl_mask, n_prop), _trim(region_feat, n_prop)
         if train:
             n_box = max(int(num[:, 2].max()), 1)
+            if self.shape_buckets:
+                n_box = bucket_len(n_box, bboxs.size(1), self.shape_buckets)
             bboxs, box_mask = _trim(bboxs, n_box), _trim(box_mask, n_box, 2)
             frm_mask = _trim(_trim(frm_mask, n_prop), n_box, 2)
         dev = self.device
-        to = lambda x: x.to(dev, non_blocking=True) if isinstance(x, torch.Tensor) else x   # async from pinned memory
-        seg = {k: to(v) for k, v in seg_feat.items()} if isinstance(seg_feat, dict) else to(seg_feat).float()
+        # async from pinned memory; a trimmed view that already lives on the device is made dense (the kernels take contiguous tensors)
+        to = lambda x: x.to(dev, non_blocking=True).contiguous() if isinstance(x, torch.Tensor) else x
+        if isinstance(seg_feat, dict):
+            # pre-extracted features (cvc.model.captioner.PrecomputedRegionFeatures): their region axis is trimmed with the proposals
+            reg = {"pool_feats": n_prop, "p_pool_feats": n_prop, "g_pool_feats": n_prop, "pnt_mask": n_prop + 1}
+            seg = {k: to(_trim(v, reg[k]) if (k in reg and v.size(1) > reg[k]) else v) for k, v in seg_feat.items()}
+        else:
+            seg = to(seg_feat).float()
         mask_ppls = to(ppl_mask)
         pnt_mask = torch.cat((mask_ppls.new_zeros(mask_ppls.size(0), 1), mask_ppls), dim=1)
         return dict(segs_feat=seg, input_seqs=to(iseq), gt_seqs=to(gts_seq), num=to(num), ppls=to(proposals),
@@ -147,10 +203,7 @@ class Trainer:
         the captured step when it runs on RCCL (backend "nccl": the collectives are issued on the communicator's stream behind
         events of the capturing stream, which stream capture records as graph dependencies); other backends (gloo) cannot be
         captured.  Returns a static tensor [loss, lm, att2, cls, recon] (clone to keep)."""
-        red = self.grad_reducer
-        if red is not None and red.exchange and red.backend != "nccl":
-            raise RuntimeError(f"train_step_graphed: the gradient exchange on backend {red.backend!r} cannot be captured into a HIP "
-                               "graph (only RCCL collectives are stream operations); use train_step")
+        self._check_capturable()
         b = self._prepare(batch, True)
         if self._graph is None:
             static = {k: (v.clone() if isinstance(v, torch.Tensor) else ({kk: vv.clone() for kk, vv in v.items()} if isinstance(v, dict) else v))
@@ -162,33 +215,106 @@ class Trainer:
                     self._core_step(static)
             torch.cuda.current_stream().wait_stream(s)
             g = torch.cuda.CUDAGraph()
-            # With an RCCL exchange in the step, c10d's watchdog thread polls the events of the warm-up steps' collectives
-            # (hipEventQuery) while this thread captures: under the default "global" capture mode that query fails with
-            # hipErrorStreamCaptureUnsupported, the watchdog dies with the exception and takes the process down seconds later
-            # (about one run in five).  "thread_local" confines the capture's restrictions to the capturing thread.
-            # (Also without an exchange of its own, as soon as an RCCL group exists: its earlier barriers are polled the same way.)
-            import torch.distributed as dist
-            rccl_up = dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
-            if rccl_up:
-                # the warm-up steps' collectives have completed -- and the watchdog (100 ms loop) has retired them: with nothing
-                # left in its list it has nothing to query while the capture runs (in thread_local mode a query of an event that
-                # a capture re-recorded still failed once in ~30 captures)
-                torch.cuda.synchronize()
-                time.sleep(0.3)
-            with torch.cuda.graph(g, capture_error_mode="thread_local" if rccl_up else "global"):
+            with torch.cuda.graph(g, capture_error_mode=self._capture_mode()):
                 res = self._core_step(static)
             self._graph = (g, static, res)
         g, static, res = self._graph
-        for k, v in b.items():
-            if isinstance(v, torch.Tensor):
-                static[k].copy_(v)
-            elif isinstance(v, dict):
-                for kk, vv in v.items():
-                    static[k][kk].copy_(vv)
+        _copy_into(static, b)
         sync = getattr(self.optimizer, "sync_hyperparameters", None)
         if sync is not None:
             sync()                                # a scheduler may have moved the learning rates since the capture
         g.replay()
+        self._weights_changed()
+        return res
+
+    def _check_capturable(self):
+        """The gradient exchange inside a captured step must be a pure stream operation: the package's own RCCL communicator
+        (GradReducer(comm=...), backend "rccl").  torch.distributed's collectives are refused -- gloo is host-side, and c10d's
+        "nccl" group keeps a watchdog thread whose event queries race with the capture (round-4 finding: it killed about one
+        capture in five; there is no way to fence it off short of waiting it out, which this code no longer does)."""
+        red = self.grad_reducer
+        if red is not None and red.exchange and red.backend != "rccl":
+            raise RuntimeError(f"train_step_graphed: the gradient exchange on torch.distributed backend {red.backend!r} cannot be captured "
+                               "into a HIP graph; build the GradReducer with comm=cvc.distributed.exchange_comm() (cvc.comm.RcclComm), "
+                               "or use train_step")
+
+    @staticmethod
+    def _capture_mode() -> str:
+        """"thread_local" when somebody's c10d "nccl" group is up in this process (its watchdog polls events from another thread:
+        under "global" capture mode those queries fail and the watchdog takes the process down); nothing of that group is part of
+        the captured step, so there is nothing to wait for."""
+        import torch.distributed as dist
+        up = dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"
+        return "thread_local" if up else "global"
+
+    def graph_capable(self) -> bool:
+        """train() replays captured steps when: --hip_graph is on, the optimizer keeps its step state on the device (ClipAdam or a
+        capturable torch optimizer), and the gradient exchange (if any) is a stream operation."""
+        if not self.shape_buckets or self.device.type != "cuda":
+            return False
+        if getattr(self.optimizer, "clip_and_step", None) is None and not all(g.get("capturable", False) for g in self.optimizer.param_groups):
+            return False
+        red = self.grad_reducer
+        return red is None or not red.exchange or red.backend == "rccl"
+
+    def train_step_bucketed(self, b):
+        """One optimisation step on a prepared batch, replayed from the HIP graph of its shape when there is one.  A shape's first
+        occurrence runs eagerly -- that IS the training step, and it is the warm-up the capture needs (allocator, lazy workspaces);
+        the very first steps of a run are eager whatever their shape (the reducer learns and compacts its arenas on step one, the
+        optimizer builds its segment table on step two).  From its second occurrence on a shape is captured once (capturing runs
+        nothing) and replayed.  Eager and replayed steps are the same launches on the same buffers: bit-identical results.
+        Returns [loss, lm, att2, cls, recon] on the device (static for replayed steps: read or clone before the next step)."""
+        key = _shape_key(b)
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+            self._graph_pool = torch.cuda.graph_pool_handle()
+        ent = self._graphs.get(key)
+        if ent is None and (self._graph_broken or self._eager_steps < 2 or self._shape_seen.get(key, 0) < 1):
+            cur = torch.cuda.current_stream()
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                res = self._core_step(b)
+            cur.wait_stream(self._side)
+            res.record_stream(cur)
+            for v in b.values():                     # the batch's tensors were used on the side stream: allocator ownership
+                for t_ in (v.values() if isinstance(v, dict) else (v,)):
+                    if isinstance(t_, torch.Tensor) and t_.is_cuda:
+                        t_.record_stream(self._side)
+            self._eager_steps += 1
+            self._shape_seen[key] = self._shape_seen.get(key, 0) + 1
+            self.graph_stats["eager"] += 1
+            self._weights_changed()
+            return res
+        if ent is None:
+            self._check_capturable()
+            static = {k: (v.clone() if isinstance(v, torch.Tensor) else ({kk: vv.clone() for kk, vv in v.items()} if isinstance(v, dict) else v))
+                      for k, v in b.items()}
+            torch.cuda.current_stream().synchronize()
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode=self._capture_mode()):
+                    res = self._core_step(static)
+            except Exception as ex:      # noqa: BLE001 -- a model whose step cannot be captured (a host read inside the forward, a
+                # library fallback that allocates) trains eagerly from here on; said once, loudly
+                from . import hip
+                hip.warn_once("trainer.capture", f"the training step could not be captured into a HIP graph ({type(ex).__name__}: "
+                              f"{str(ex)[:300]}); training continues with eager steps")
+                self._graph_broken = True
+                torch.cuda.synchronize()
+                if self.grad_reducer is not None:
+                    self.grad_reducer.zero_grad()
+                else:
+                    self.optimizer.zero_grad(set_to_none=False)
+                return self.train_step_bucketed(b)
+            ent = self._graphs[key] = (g, static, res)
+            self.graph_stats["captured"] += 1
+        g, static, res = ent
+        _copy_into(static, b)
+        sync = getattr(self.optimizer, "sync_hyperparameters", None)
+        if sync is not None:
+            sync()
+        g.replay()
+        self.graph_stats["replayed"] += 1
         self._weights_changed()
         return res
 
@@ -200,21 +326,45 @@ class Trainer:
         n_steps = len(self.train_loader) - 1                 # the reference drops the last batch (:55)
         # batch k+1 is staged into HBM on a side stream while step k runs
         batches = DevicePrefetcher(self.train_loader, lambda raw: self._prepare(raw, True), self.device, limit=n_steps)
+        graphed = self.graph_capable()
+        if self.opts.att_model != 'cyclical':
+            raise ValueError('Unknown att_model: {}'.format(self.opts.att_model))
+        n = self.opts.batch_size * self.opts.seq_per_img
+        acc, pending, last = None, 0, None           # device-side sums of [loss, lm, att2, cls, recon] since the last read-back
+
+        def flush(step):
+            """ONE host read per display interval (the reference reads four scalars per step, trainer.py:124-135): the meters get
+            the interval's means with the interval's weight, `.val` the latest step's values"""
+            nonlocal acc, pending
+            if acc is None:
+                return
+            sums, cur = torch.stack([acc, last]).tolist()
+            for name, i in (("lm", 1), ("attn", 2), ("cls", 3), ("recon", 4)):
+                meters[name].update(sums[i] / pending, n * pending)
+                meters[name].val = cur[i]
+            acc, pending = None, 0
+
+        step = -1
         for step, b in enumerate(batches):
             meters["data"].update(time.time() - end)
-            _, lm, att2, cls, rec = self.train_step_prepared(b)
-            n = self.opts.batch_size * self.opts.seq_per_img
-            lm_v, att2_v, cls_v, rec_v = torch.stack([lm, att2, cls, rec]).tolist()      # one host sync per step
-            meters["lm"].update(lm_v, n); meters["attn"].update(att2_v, n)
-            meters["cls"].update(cls_v, n); meters["recon"].update(rec_v, n)
-            meters["batch"].update(time.time() - end)
-            end = time.time()
+            if graphed:
+                res = self.train_step_bucketed(b)
+            else:
+                res = torch.stack([x.reshape(()) for x in self.train_step_prepared(b)])
+            acc = res.clone() if acc is None else acc.add_(res)
+            last, pending = res, pending + 1
             if step % self.opts.disp_interval == 0:
+                flush(step)
+                meters["batch"].update((time.time() - end))
                 print('Epoch: [{0}][{1}/{2}]\tTime {b.val:.3f} ({b.avg:.3f})\tData {d.val:.3f} ({d.avg:.3f})\t'
                       'LM Loss {l.val:.4f} ({l.avg:.4f})\tAttn Loss {a.val:.4f} ({a.avg:.4f})\t'
                       'Cls Loss {c.val:.4f} ({c.avg:.4f})\tRecon Loss {r.val:.4f} ({r.avg:.4f})'.format(
                           epoch, step, n_steps, b=meters["batch"], d=meters["data"], l=meters["lm"], a=meters["attn"],
                           c=meters["cls"], r=meters["recon"]))
+            else:
+                meters["batch"].update(time.time() - end)      # (launch time of an asynchronous step; display steps include the wait)
+            end = time.time()
+        flush(step)
         if tb_logger:
             tb_logger.add_scalar('train/learning_rate', self.optimizer.param_groups[0]['lr'], epoch)
             tb_logger.add_scalar('train/lm_loss', meters["lm"].avg, epoch)

@@ -114,3 +114,23 @@ def g2():
 @pytest.fixture(scope="session")
 def g3():
     return Golden("g3_shards.npz")
+
+
+_G9 = {}
+
+
+def load_g9(prefix, inputs_digest=None):
+    """tests/golden/g9_fullsize_ref.npz: what the REFERENCE itself (imported in the build container, tools/make_golden.py g9) returns
+    at BASELINE's full sizes on cvc.synth's seeded inputs -- `cfg2.greedy.` / `cfg5.greedy.` (seq, att2_weights, gaps) and
+    `cfg3.cyclical.` (losses, ground_weights, grad_norm.* / grad_at.* / grad_none.*).  inputs_digest: checked against the stored
+    digest of the WHOLE input arrays (a changed generator or config must not be compared with stale reference results)."""
+    if "z" not in _G9:
+        _G9["z"] = np.load(os.path.join(GOLDEN, "g9_fullsize_ref.npz"))
+    z = _G9["z"]
+    out = {k[len(prefix):]: z[k] for k in z.files if k.startswith(prefix)}
+    assert out, prefix
+    if inputs_digest is not None:
+        assert str(out["inputs_digest"]) == inputs_digest, (
+            f"tests/golden/g9_fullsize_ref.npz [{prefix}] was made from other inputs than cvc.synth generates now: "
+            "re-run `python tools/make_golden.py g9` in the build container")
+    return out

@@ -72,3 +72,57 @@ def tie_aware_seq_equal(seq, ref_seq, ref_logp, tol=1e-4, unk_idx=synth.UNK_IDX,
     if stats is not None:      # how close the comparison came to its tolerance (goes to the test log)
         stats.update(clips=B, clear_clips=int(clear.sum()), flipped_clips=flips, largest_margin_at_a_flip=worst, tol=tol)
     return n_exact
+
+
+LOGPROB_TOL = 1e-4      # the stated fp32 tolerance on a log-prob after T recurrent steps and a log-softmax over V
+
+
+def referee_seq_check(seq, logprob, ref, label, ref_seq=None):
+    """Greedy words of a GPU run against the fp64 REFEREE (tests/fullsize_oracle.py::greedy: the oracle on .double() inputs).
+
+    seq [B, T] and logprob [B, T] (the GPU's log-prob of its own selected word, DecodeEngine.logprob) ; ref holds seq64, gaps64,
+    top2_64, lp64_top2, dev32 (and the fp32 oracle's seq / gaps).  Rule (round-4 review item 5 -- the tolerance is measured, not
+    chosen):
+      * at every step a clip has followed the referee's words so far, the GPU's word must be one of the referee's two best
+        non-UNK words, and its log-prob must be within LOGPROB_TOL of the referee's log-prob of that word -- the largest such
+        deviation, dev_gpu, is the measured accuracy of the GPU path at this size;
+      * the GPU's word may differ from the referee's only where the referee's deciding margin is below
+        2 * max(dev_gpu, dev32): a margin is a difference of two log-probs, each off by at most the measured deviation
+        (dev32 = the fp32 CPU oracle's own measured deviation from the referee); after such a flip the clip is not comparable;
+      * everywhere else: equality with the referee.
+    A failure names clip, step and the three margins (referee, fp32 oracle, the GPU's implied one).  -> stats dict."""
+    seq, logprob = np.asarray(seq), np.asarray(logprob, dtype=np.float64)
+    seq64, gaps64, top2, lp2, dev32 = ref["seq64"], ref["gaps64"], ref["top2_64"], ref["lp64_top2"], ref["dev32"]
+    seq32, gaps32 = ref["seq"], ref["gaps"]
+    B, T = seq64.shape
+    assert seq.shape == (B, T) and logprob.shape == (B, T)
+    dev_gpu, flips, compared = 0.0, [], 0
+    for b in range(B):
+        for t in range(T):
+            w = int(seq[b, t])
+            which = 0 if w == top2[b, t, 0] else (1 if w == top2[b, t, 1] else -1)
+            margins = (f"referee margin {gaps64[b, t]:.3e}, fp32-oracle margin {gaps32[b, t]:.3e} (oracle word {seq32[b, t]}), "
+                       f"referee words {top2[b, t].tolist()} with log-probs {lp2[b, t].tolist()}, GPU log-prob of its word {logprob[b, t]:.6f}")
+            assert which >= 0, f"{label}: clip {b} step {t}: the GPU selected word {w}, not one of the referee's two best: {margins}"
+            dv = abs(logprob[b, t] - lp2[b, t, which])
+            assert dv <= LOGPROB_TOL, f"{label}: clip {b} step {t}: log-prob of word {w} is {dv:.3e} from the referee's (> {LOGPROB_TOL}): {margins}"
+            dev_gpu = max(dev_gpu, dv)
+            compared += 1
+            if w != seq64[b, t]:
+                flips.append((b, t, float(gaps64[b, t]), float(gaps32[b, t]), float(logprob[b, t] - lp2[b, t, 0]), margins))
+                break
+    d32 = float(dev32.max())
+    tol = 2.0 * max(dev_gpu, d32)
+    for b, t, g64, g32, implied, margins in flips:
+        assert g64 < tol, (f"{label}: clip {b} step {t}: the GPU's word differs from the referee's where the referee's margin {g64:.3e} "
+                           f"exceeds the derived tie tolerance {tol:.3e} (= 2 x max(measured GPU deviation {dev_gpu:.3e}, measured fp32-oracle "
+                           f"deviation {d32:.3e})); GPU-implied margin {implied:.3e}; {margins}")
+    stats = dict(clips=B, steps_compared=compared, dev_gpu=dev_gpu, dev_fp32_oracle=d32, derived_tie_tol=tol, flips=len(flips),
+                 largest_referee_margin_at_a_flip=max([f_[2] for f_ in flips], default=0.0),
+                 smallest_referee_margin=float(gaps64.min()),
+                 oracle32_equals_referee=bool((seq32 == seq64).all()))
+    if ref_seq is not None:        # (the REFERENCE's own words, tests/golden/g9_fullsize_ref.npz)
+        stats["reference_equals_referee"] = bool((np.asarray(ref_seq) == seq64).all())
+        stats["gpu_equals_reference_clips"] = int((seq == np.asarray(ref_seq)).all(1).sum())
+    print(f"[referee] {label}: {stats}")
+    return stats

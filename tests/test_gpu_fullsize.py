@@ -99,67 +99,70 @@ def test_cfg3_cyclical_forward_backward_full_size_vs_oracle(dev):
     five losses and every parameter gradient against the oracle's autograd (K = 8192 backward-data GEMMs inside BPTT
     over T = 20, the LDS-DMA ring kernel at R = 2048, the T-batched weight-gradient products)."""
     from helpers import build_model, to_dev, model_call
+    from conftest import load_g9
     import fullsize_oracle as FO
     seed = 1303
     d, sd, f = _inputs("cfg3", seed)
     b = synth.label_glue_batch(d, seed)
     ref, _src = FO.cyclical_eval("cfg3", seed, d, sd, f, b)
+    # ... and against the REFERENCE's own _forward_3_loops + autograd on the same inputs (tests/golden/g9_fullsize_ref.npz)
+    g9 = load_g9("cfg3.cyclical.", FO.inputs_digest(sd, f, b))
     model = build_model(d, sd, dev)
     model.debug_collect = {}
     out = model_call(model, to_dev(f, dev), to_dev(b, dev), False)
     assert len(out) == 5
-    for got, want in zip(out, ref["losses"]):
-        assert got.shape == (1,)
-        assert float(got.detach()) == pytest.approx(float(want), rel=1e-4, abs=1e-5)
-    # a10 at full size: grounder output element-wise (masked slots are exactly -1e8 on both sides)
-    close(model.debug_collect["ground_weights"], ref["ground_weights"], rtol=1e-4, atol=2e-4)
     (0.5 * out[0].mean() + 0.5 * out[4].mean()).backward()
-    checked = 0
-    for n, p in model.named_parameters():
-        if n.startswith("roi_feat_extractor") or not ("grad_norm." + n in ref or "grad_none." + n in ref):
-            continue
-        if "grad_none." + n in ref:
-            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
-            continue
-        # the oracle's gradient is kept as its 2-norm + its elements at a fixed random sample (the whole set is 500 MB): the
-        # sampled error, scaled from m sampled to all numel elements, against 5e-4 of the whole norm, and the two norms against
-        # each other
-        norm = float(ref["grad_norm." + n])
-        idx = torch.from_numpy(FO.sample_index(n, p.numel()))
-        got = p.grad.detach().reshape(-1).cpu().double()
-        err = float((got[idx] - torch.from_numpy(ref["grad_at." + n])).norm()) * (p.numel() / idx.numel()) ** 0.5
-        assert err <= 5e-4 * norm + 1e-6, (n, err, norm)
-        assert abs(float(got.norm()) - norm) <= 2e-4 * norm + 1e-6, (n, float(got.norm()), norm)
-        checked += 1
-    assert checked >= 15
+    grads = {n: (None if p.grad is None else p.grad.detach().reshape(-1).cpu().double()) for n, p in model.named_parameters()
+             if not n.startswith("roi_feat_extractor")}
+    for src, want in (("oracle", ref), ("reference", g9)):
+        for got, w_ in zip(out, want["losses"]):
+            assert got.shape == (1,)
+            assert float(got.detach()) == pytest.approx(float(w_), rel=1e-4, abs=1e-5), src
+        # a10 at full size: grounder output element-wise (masked slots are exactly -1e8 on both sides)
+        close(model.debug_collect["ground_weights"], want["ground_weights"], rtol=1e-4, atol=2e-4)
+        checked = 0
+        for n, got in grads.items():
+            if not ("grad_norm." + n in want or "grad_none." + n in want):
+                continue
+            if "grad_none." + n in want:
+                assert got is None or float(got.abs().max()) == 0.0, (src, n)
+                continue
+            # the gradient is kept as its 2-norm + its elements at a fixed random sample (the whole set is 500 MB): the sampled
+            # error, scaled from m sampled to all numel elements, against 5e-4 of the whole norm, and the two norms against each other
+            norm = float(want["grad_norm." + n])
+            idx = torch.from_numpy(FO.sample_index(n, got.numel()))
+            err = float((got[idx] - torch.from_numpy(want["grad_at." + n])).norm()) * (got.numel() / idx.numel()) ** 0.5
+            assert err <= 5e-4 * norm + 1e-6, (src, n, err, norm)
+            assert abs(float(got.norm()) - norm) <= 2e-4 * norm + 1e-6, (src, n, float(got.norm()), norm)
+            checked += 1
+        assert checked >= 15, (src, checked)
 
 
 def test_cfg5_full_size_greedy_and_beam5_vs_oracle(dev):
     """BASELINE config 5 at its real size: B=64, N=300, F=480, D=4096, A=E=2048, T=30 -- greedy through the packed
     engine, then beam=5 (320 rows)."""
-    from helpers import to_dev, tie_aware_seq_equal
+    from helpers import to_dev, referee_seq_check
+    from conftest import load_g9
     import fullsize_oracle as FO
     from cvc.decode import DecodeEngine, DecodeWeights
     seed = 1505
     d, sd, f_np = _inputs("cfg5", seed)
     ref, _src = FO.greedy("cfg5", seed, d, sd, f_np)
-    seq_o, att_o = torch.from_numpy(ref["seq"]), torch.from_numpy(ref["att"])
+    g9 = load_g9("cfg5.greedy.", FO.inputs_digest(sd, f_np))           # the REFERENCE's own _sample at this size
+    seq_o, att_o = torch.from_numpy(g9["seq"]), torch.from_numpy(g9["att2_weights"])
     W, f = DecodeWeights(to_dev(sd, dev)), to_dev(f_np, dev)
     eng = DecodeEngine(W, f, d.T, synth.UNK_IDX).capture()
     seq, att = eng.run()
     seq, att = seq.clone(), att.clone()
-    # Tolerance on the deciding margin: 3e-4 here against 1e-4 at config 2.  Both sides are fp32 -- the oracle's CPU GEMMs are
-    # no more exact than the kernels' -- and at this size a step contracts over K = 3R = 12 288 (config 2: 6 144) and the
-    # recurrence runs T = 30 steps deep (20): the log-prob noise between two fp32 evaluations grows with both, and which side of
-    # a margin of that size the oracle lands on depends on the host's BLAS kernels.  (This test failed once, in one full-suite run
-    # on one box of the pool, and in none of 16 repeats since; the kernels replay bit-identically and read no uninitialised
-    # memory -- CVC_POISON run -- so a margin-sized flip is the suspected cause; the observed margins are reported in the test
-    # log.)  Clips whose every margin exceeds 1e-3 must still match exactly, whole sequence.
-    st = {}
-    n = tie_aware_seq_equal(seq.cpu().numpy(), seq_o.numpy(), None, tol=3e-4, stats=st, gaps=ref["gaps"])
+    # The tie rule is settled by an fp64 referee (tests/helpers.py::referee_seq_check; round 4 had widened a hand-chosen tolerance
+    # after one flake): the GPU's words are held to the fp64 oracle's wherever its margin exceeds twice the MEASURED log-prob
+    # deviation (GPU vs referee, asserted <= 1e-4, and fp32 CPU oracle vs referee -- both printed), and a failure names clip, step
+    # and all three margins.
+    st = referee_seq_check(seq.cpu().numpy(), eng.logprob.t().cpu().numpy(), ref, "cfg5 greedy", ref_seq=g9["seq"])
     _TIE_STATS["cfg5 greedy"] = st
-    assert n >= 0.98 * d.B * d.T
+    assert st["reference_equals_referee"]
     same = (seq.cpu() == seq_o).all(1)
+    assert int(same.sum()) >= 0.95 * d.B
     close(att[same.to(dev)], att_o[same], **SEQ_TOL)
     seq2, att2 = eng.run()
     assert torch.equal(seq, seq2) and torch.equal(att, att2)

@@ -213,40 +213,30 @@ def test_cyclical_gradients_vs_oracle_on_other_shapes(B, N, F, R, A, E, V, T):
 
 
 def _run_isolated(scenario: str, timeout: int = 900):
-    """Runs _scenario_<name>() of this module in a CHILD interpreter and passes when the child printed SCENARIO-PASSED, i.e. when
-    every assertion of the scenario held.  The scenarios that bring up RCCL communicators (torch.distributed "nccl" groups, the
-    C-ABI's own communicator) run this way: c10d keeps a watchdog thread per process group, and when that thread dies it takes
-    the whole interpreter -- here: the pytest process and every test after it -- with it.  (It did, about once in five suite runs,
-    until cvc.trainer / cvc.decode captured their graphs in "thread_local" mode: the watchdog's hipEventQuery fails while another
-    thread captures in global mode.)  A child's stderr is part of the failure message, which is how that was found.  A child that
-    ends abnormally AFTER its checks is reported as a warning; one that fails a check, or dies before the marker, fails the test."""
+    """Runs _scenario_<name>() of this module in a CHILD interpreter; passes when the child printed SCENARIO-PASSED -- which it
+    prints AFTER its teardown (communicator destroyed, process group released) -- and exited with code 0.  The scenarios that bring
+    up RCCL communicators run this way so that a communicator never outlives its test inside the long-lived pytest process.  No
+    retries: the exchange runs on the package's own communicator (cvc.comm.RcclComm), which has no watchdog thread that could die
+    under a graph capture (round 4 re-ran children that c10d's watchdog had killed; that code is gone with its cause)."""
     import os
     import subprocess
     import sys
-    import warnings
     here = os.path.dirname(os.path.abspath(__file__))
     root = os.path.dirname(here)
     paths = [root, os.path.join(root, "cyclical-visual-captioning_amd"), here]
     code = (f"import sys; sys.path[:0] = {paths!r}; import test_gpu_train as t; t._scenario_{scenario}()")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    WATCHDOG = "Process group watchdog thread terminated with exception"
-    for attempt in range(3):
-        r = subprocess.run([sys.executable, "-X", "faulthandler", "-c", code], capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
-        if "SCENARIO-PASSED" in r.stdout or WATCHDOG not in r.stderr:
-            break
-        # c10d's watchdog died (see the docstring): not a verdict on the scenario's checks -- run them again, and say so
-        warnings.warn(f"scenario {scenario}, attempt {attempt + 1}: c10d's watchdog thread took the child down before its checks were "
-                      f"through ({r.stderr[r.stderr.index(WATCHDOG):][:200]!r}); repeating")
-    assert "SCENARIO-PASSED" in r.stdout, f"scenario {scenario}: rc={r.returncode}\n--- stdout\n{r.stdout[-3000:]}\n--- stderr\n{r.stderr[-8000:]}"
+    r = subprocess.run([sys.executable, "-X", "faulthandler", "-c", code], capture_output=True, text=True, timeout=timeout, env=env, cwd=root)
+    report = f"scenario {scenario}: rc={r.returncode}\n--- stdout\n{r.stdout[-3000:]}\n--- stderr\n{r.stderr[-8000:]}"
+    assert "SCENARIO-PASSED" in r.stdout, report
     assert "libcvc_hip.so" in r.stdout, "the child did not report the in-tree HIP library as loaded"
-    if r.returncode != 0:
-        warnings.warn(f"scenario {scenario}: all checks passed, then the child interpreter ended with rc={r.returncode} after its checks: "
-                      f" {r.stderr[-400:]!r}")
+    assert r.returncode == 0, report
 
 
 def _passed():
-    """the child's marker: every check held; names the loaded library (the product path, not a fallback)"""
+    """the child's marker, printed after the scenario's teardown: every check held and everything was released in order; names the
+    loaded library (the product path, not a fallback)"""
     from cvc import hip
     hip.lib()
     with open("/proc/self/maps") as fh:
@@ -278,92 +268,131 @@ def _scenario_rccl_allreduce_cabi_one_rank():
     torch.cuda.synchronize()
     assert torch.equal(arena, want)
     assert L.cvc_allreduce_grads(None, arena.data_ptr(), 4, s) == -1          # bad arguments are rejected, not executed
-    _passed()
     hip._check(L.cvc_comm_destroy(comm), "cvc_comm_destroy")
-
-
-def _release_group(created):
-    """Orderly teardown of the one-rank RCCL group: release what holds work on its communicator (a captured HIP graph with the
-    exchange inside, the reducers' events), drain the stream, then destroy the group."""
-    import gc
-    import torch.distributed as dist
-    gc.collect()
+    # the Python face of the same calls (cvc.comm.RcclComm), an odd element count (the all-reduce branch needs world > 1: here the
+    # pair runs with a one-element shard), the rank count through the communicator, destroy twice
+    from cvc.comm import RcclComm
+    c = RcclComm.single()
+    assert c.count_ranks() == 1
+    odd = torch.randn(1001, device=dev)
+    keep = odd.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    c.all_reduce_(odd, side)
+    torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    if created and dist.is_initialized():
-        dist.barrier()
-        torch.cuda.synchronize()
-        dist.destroy_process_group()
+    assert torch.equal(odd, keep)
+    with pytest.raises(TypeError):
+        c.all_reduce_(odd.double())
+    c.destroy()
+    c.destroy()
+    with pytest.raises(RuntimeError, match="destroyed"):
+        c.all_reduce_(odd)
+    _passed()
 
 
 def test_gradient_exchange_on_rccl_one_rank_equals_no_exchange():
-    """torch.distributed "nccl" (= RCCL) process group of one rank, no torchrun: a training step whose GradReducer issues the
-    in-place reduce_scatter + all_gather from the autograd hooks must leave bit-identical parameters to the same step without
-    any exchange; the step captured into a HIP graph WITH that exchange replays bit-identically; a non-RCCL backend is refused."""
+    """The package's own RCCL communicator with one rank, no torch.distributed at all: a training step whose GradReducer issues the
+    in-place reduce_scatter + all_gather per bucket (exchange stream, HIP events) must leave bit-identical parameters to the same
+    step without any exchange; the step captured into a HIP graph WITH that exchange replays bit-identically; an exchange that is
+    not a stream operation (gloo, c10d's "nccl") is refused under capture."""
     _run_isolated("gradient_exchange_on_rccl_one_rank")
 
 
 def _scenario_gradient_exchange_on_rccl_one_rank():
-    import torch.distributed as dist
+    from cvc.comm import RcclComm
     from cvc.distributed import GradReducer
     dev = torch.device("cuda:0")
     d = synth.CONFIGS["tiny"]
-    created = False
-    if not dist.is_initialized():
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29653", rank=0, world_size=1, device_id=dev)
-        created = True
+    comm = RcclComm.single()
+    keep = []          # trainers (and the HIP graph one of them captured) stay alive until the checks have passed
 
-    keep = []          # trainers (and the HIP graph one of them captured) stay alive until the checks have passed: see _run_isolated
-
-    def body():
-        finals = []
-        for exch in (False, True):
-            o, model, batch, Trainer, build_optimizer = _setup(dev, d, train_decoder_only=False)
-            model.eval()                                                  # no dropout: both runs are deterministic
-            red = GradReducer(model.named_parameters(), always_exchange=exch)
-            assert red.exchange == exch and (red.backend == "nccl")
-            tr = Trainer(o, None, model, build_optimizer(model, o), None, None, grad_reducer=red)
-            for _ in range(3):                                             # step 0 learns the arrivals, 1-2 launch from hooks
-                tr.train_step(batch)
-            torch.cuda.synchronize()
-            finals.append({k: v.detach().clone() for k, v in model.state_dict().items()})
-            red.remove_hooks()
-        for k in finals[0]:
-            assert torch.equal(finals[0][k], finals[1][k]), k
-        # the whole step INCLUDING the RCCL exchange captured into one HIP graph: replays must reproduce the eager steps with the
-        # same exchange bit for bit (3 warm-up steps + 3 replays against 6 eager steps)
+    finals = []
+    for exch in (False, True):
         o, model, batch, Trainer, build_optimizer = _setup(dev, d, train_decoder_only=False)
-        model.eval()
-        red = GradReducer(model.named_parameters(), always_exchange=True)
-        tr = Trainer(o, None, model, build_optimizer(model, o, capturable=True), None, None, grad_reducer=red)
-        res = [tr.train_step_graphed(batch).clone() for _ in range(3)]
+        model.eval()                                                  # no dropout: both runs are deterministic
+        red = GradReducer(model.named_parameters(), comm=comm, always_exchange=exch)
+        assert red.exchange == exch and red.backend == "rccl" and red.world == 1
+        tr = Trainer(o, None, model, build_optimizer(model, o), None, None, grad_reducer=red)
+        for _ in range(3):                                             # step 0 learns the arrivals, 1-2 launch from hooks / sinks
+            tr.train_step(batch)
         torch.cuda.synchronize()
-        graphed = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        if exch:
+            assert red._comm_stream is not None and not red._comm_pending      # the exchange did run, and was joined
+        finals.append({k: v.detach().clone() for k, v in model.state_dict().items()})
         red.remove_hooks()
-        keep.append(tr)
-        o, model, batch, Trainer, build_optimizer = _setup(dev, d, train_decoder_only=False)
-        model.eval()
-        red = GradReducer(model.named_parameters(), always_exchange=True)
-        tr = Trainer(o, None, model, build_optimizer(model, o, capturable=True), None, None, grad_reducer=red)
-        eager = [tr.train_step(batch) for _ in range(6)]
-        torch.cuda.synchronize()
-        red.remove_hooks()
-        for k in graphed:
-            assert torch.equal(graphed[k], model.state_dict()[k]), k
-        assert float(res[-1][0]) == float(eager[-1][0])
-        # a backend whose collectives are not stream operations cannot be captured: refused loudly
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k
+    # the whole step INCLUDING the RCCL exchange captured into one HIP graph: replays must reproduce the eager steps with the
+    # same exchange bit for bit (3 warm-up steps + 3 replays against 6 eager steps)
+    o, model, batch, Trainer, build_optimizer = _setup(dev, d, train_decoder_only=False)
+    model.eval()
+    red = GradReducer(model.named_parameters(), comm=comm, always_exchange=True)
+    tr = Trainer(o, None, model, build_optimizer(model, o, capturable=True), None, None, grad_reducer=red)
+    res = [tr.train_step_graphed(batch).clone() for _ in range(3)]
+    torch.cuda.synchronize()
+    graphed = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    red.remove_hooks()
+    keep.append(tr)
+    o, model, batch, Trainer, build_optimizer = _setup(dev, d, train_decoder_only=False)
+    model.eval()
+    red = GradReducer(model.named_parameters(), comm=comm, always_exchange=True)
+    tr = Trainer(o, None, model, build_optimizer(model, o, capturable=True), None, None, grad_reducer=red)
+    eager = [tr.train_step(batch) for _ in range(6)]
+    torch.cuda.synchronize()
+    red.remove_hooks()
+    for k in graphed:
+        assert torch.equal(graphed[k], model.state_dict()[k]), k
+    assert float(res[-1][0]) == float(eager[-1][0])
+    # exchanges that are not stream operations cannot be captured: refused loudly (gloo: host-side; c10d "nccl": its watchdog)
+    for backend in ("gloo", "nccl"):
         o, model, batch, Trainer, build_optimizer = _setup(dev, d)
         red = GradReducer(model.named_parameters(), world=2)
-        red.backend = "gloo"
+        red.backend = backend
         tr = Trainer(o, None, model, build_optimizer(model, o, capturable=True), None, None, grad_reducer=red)
         with pytest.raises(RuntimeError, match="cannot be captured"):
             tr.train_step_graphed(batch)
         red.remove_hooks()
+    del keep[:], tr
+    import gc
+    gc.collect()
+    comm.destroy()
+    _passed()
 
-    try:
-        body()
-        _passed()
-    finally:
-        _release_group(created)
+
+def test_gradient_exchange_on_c10d_nccl_group_eager():
+    """The legacy transport: torch.distributed "nccl" (= RCCL) process group of one rank, eager steps only -- the in-place
+    reduce_scatter + all_gather issued through c10d from the hooks leaves bit-identical parameters to the step without exchange."""
+    _run_isolated("gradient_exchange_on_c10d_nccl_eager")
+
+
+def _scenario_gradient_exchange_on_c10d_nccl_eager():
+    import torch.distributed as dist
+    from cvc.distributed import GradReducer
+    dev = torch.device("cuda:0")
+    d = synth.CONFIGS["tiny"]
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29653", rank=0, world_size=1, device_id=dev)
+    finals = []
+    for exch in (False, True):
+        o, model, batch, Trainer, build_optimizer = _setup(dev, d, train_decoder_only=False)
+        model.eval()
+        red = GradReducer(model.named_parameters(), always_exchange=exch)
+        assert red.exchange == exch and red.backend == "nccl" and red.comm is None
+        tr = Trainer(o, None, model, build_optimizer(model, o), None, None, grad_reducer=red)
+        for _ in range(3):
+            tr.train_step(batch)
+        torch.cuda.synchronize()
+        finals.append({k: v.detach().clone() for k, v in model.state_dict().items()})
+        red.remove_hooks()
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+    _passed()
 
 
 # ------------------------------------------------------------------ train-mode (dropout ON) parity with dictated masks
@@ -457,31 +486,25 @@ def _train_mode_parity(d, seed, mix, loss_tol, grad_tol=5e-4, in_kernel=False, r
 def test_train_mode_cyclical_pass_cfg4_share_on_rccl_arenas_vs_oracle():
     """BASELINE config 4 as far as one GPU can prove it: ONE rank's share of the 8-GPU job (B = 32 clips, D = 2048, T = 20), train
     mode with the masks generated in the kernels, the gradients living in the GradReducer's flat arenas (486 MB at this size) and
-    exchanged over RCCL ("nccl", a one-rank group: in-place reduce_scatter + all_gather per bucket, the branch every rank of the
-    8-GPU job runs) -- five losses and every parameter gradient against the oracle's autograd."""
+    exchanged over RCCL (the package's own communicator, one rank: in-place reduce_scatter + all_gather per bucket, the branch
+    every rank of the 8-GPU job runs) -- five losses and every parameter gradient against the oracle's autograd."""
     _run_isolated("cfg4_share_on_rccl_arenas")
 
 
 def _scenario_cfg4_share_on_rccl_arenas():
-    import torch.distributed as dist
+    from cvc.comm import RcclComm
     from cvc.distributed import GradReducer
-    dev = torch.device("cuda:0")
-    created = False
-    if not dist.is_initialized():
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29655", rank=0, world_size=1, device_id=dev)
-        created = True
-    try:
-        mk = lambda model: GradReducer(model.named_parameters(), always_exchange=True)
-        model, red = _train_mode_parity(synth.CONFIGS["cfg4"], 1404, (0.5, 0.0, 0.5), loss_tol=1e-4, in_kernel=True, reducer=mk)
-        assert red.backend == "nccl" and red.exchange
-        total = sum(a.numel() * 4 for a in red.arenas)
-        assert total > 480e6, total                                        # the real message: every trainable tensor of the hot path
-        assert all(a.numel() % red.world == 0 for a in red.arenas)        # equal shards: the reduce_scatter + all_gather branch
-        red.remove_hooks()
-        del model, red
-        _passed()
-    finally:
-        _release_group(created)
+    comm = RcclComm.single()
+    mk = lambda model: GradReducer(model.named_parameters(), comm=comm, always_exchange=True)
+    model, red = _train_mode_parity(synth.CONFIGS["cfg4"], 1404, (0.5, 0.0, 0.5), loss_tol=1e-4, in_kernel=True, reducer=mk)
+    assert red.backend == "rccl" and red.exchange and red._comm_stream is not None
+    total = sum(a.numel() * 4 for a in red.arenas)
+    assert total > 480e6, total                                        # the real message: every trainable tensor of the hot path
+    assert all(a.numel() % red.world == 0 for a in red.arenas)        # equal shards: the reduce_scatter + all_gather branch
+    red.remove_hooks()
+    del model, red
+    comm.destroy()
+    _passed()
 
 
 @pytest.mark.parametrize("cfg,mix", [("tiny", (0.5, 0.05, 0.5)), ("tiny", (0.5, 0.0, 0.5)), ("cfg1", (0.5, 0.0, 0.5))])
@@ -674,3 +697,64 @@ def test_joint_backward_of_both_loops_equals_the_two_passes(cfg, B, train):
             assert torch.equal(g, g2), k
             n += 1
     assert n >= 15
+
+
+# ------------------------------------------------------------------ Trainer.train(): one captured graph per bucketed batch shape
+def _ragged_batches(dev, d, seed, counts):
+    """batches in the 12-tuple contract whose clips carry fewer proposals / boxes than the loader's padded lengths: what lies beyond a
+    clip's count is the loader's padding (zero feature rows, mask bits set -- dataloader_anet.py:376-388)"""
+    from helpers import to_dev
+    out = []
+    for j, (n_max, k_max) in enumerate(counts):
+        f = synth.clip_features(d, seed + j)
+        b = synth.label_glue_batch(d, seed + j)
+        rng = np.random.default_rng(seed + j)
+        n_b = rng.integers(max(1, n_max // 2), n_max + 1, size=d.B); n_b[0] = n_max
+        k_b = rng.integers(1, k_max + 1, size=d.B); k_b[-1] = k_max
+        for c in range(d.B):
+            for key in ("pool_feats", "p_pool_feats", "g_pool_feats"):
+                f[key][c, n_b[c]:] = 0
+            f["pnt_mask"][c, 1 + n_b[c]:] = True
+            b["box_mask"][c, 0, k_b[c]:, :] = True
+            b["num"][c, 1], b["num"][c, 2] = n_b[c], k_b[c]
+        f, b = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in f.items()}, {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in b.items()}
+        out.append((f, b["input_seq"], b["gt_seq"], b["num"], b["proposals"], b["gt_bboxs"], b["box_mask"],
+                    ["v_x_segment_%02d" % i for i in range(d.B)], torch.zeros(d.B, d.N, 1), b["frm_mask"], b["sample_idx"],
+                    f["pnt_mask"][:, 1:].clone()))
+    return out
+
+
+def test_trainer_train_replays_one_graph_per_bucketed_shape_bit_equal_to_eager(capsys):
+    """Trainer.train() (the drop-in for the reference's trainer.py:39-150) on batches whose per-batch trimming (trainer.py:63-69)
+    gives three different shapes: lengths are rounded up to shape buckets, a shape's first occurrence runs eagerly, from its second
+    occurrence on the step is captured once and replayed -- parameters after the epoch and every displayed loss bit-equal to the
+    same epoch run with eager steps only; the losses are read back once per display interval."""
+    import dataclasses
+    from cvc import dropout
+    from cvc.trainer import bucket_len
+    dev = torch.device("cuda:0")
+    d = dataclasses.replace(synth.CONFIGS["tiny"], B=4, N=40, K=8)
+    counts = [(40, 8), (17, 3), (9, 5)]
+    assert [bucket_len(n, 40) for n, _ in counts] == [40, 20, 10] and [bucket_len(k, 8) for _, k in counts] == [8, 4, 6]
+    batches = _ragged_batches(dev, d, 77, counts) * 3 + _ragged_batches(dev, d, 77, counts)[:1]     # train() drops the last batch
+    finals, shown, stats = [], [], []
+    for graphed in (False, True):
+        o, model, _batch, Trainer, build_optimizer = _setup(dev, d, train_decoder_only=False)
+        o.disp_interval, o.hip_graph = 4, 1
+        tr = Trainer(o, None, model, build_optimizer(model, o, capturable=True), batches, None)
+        assert tr.graph_capable()
+        tr._graph_broken = not graphed                       # eager run: same bucketed shapes, no capture
+        dropout.seed(4711)
+        tr.train(0)
+        torch.cuda.synchronize()
+        finals.append({k: v.detach().clone() for k, v in model.state_dict().items()})
+        shown.append([ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("Epoch")])
+        stats.append(dict(tr.graph_stats))
+        shapes = sorted({(k[0], k[1]) for key in tr._shape_seen for k in key if k[0] == "ppls"})
+        assert [s_[1][1] for s_ in shapes] == [10, 20, 40], shapes
+    assert stats[0] == dict(eager=9, replayed=0, captured=0) and stats[1] == dict(eager=3, replayed=6, captured=3), stats
+    assert len(shown[0]) == 3                                  # steps 0, 4, 8
+    strip = lambda ln: ln.split("LM Loss")[1]                   # (wall-clock columns differ)
+    assert [strip(x) for x in shown[0]] == [strip(x) for x in shown[1]], (shown[0], shown[1])
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k

@@ -576,6 +576,109 @@ def g7_sentinel(path):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+# ------------------------------------------------------------------------------------ G9 (full size, from the reference itself)
+def _greedy_ref(d, seed):
+    """the reference's own _sample (captioner.py:384-443) on cvc.synth's seeded inputs -> seq, att2_weights, the non-UNK deciding
+    margins of every step (best minus second-best log-prob over the words that are not UNK, :415-422)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fullsize_oracle as FO
+    sd, feats_np = synth.hot_path_state_dict(d, seed), synth.clip_features(d, seed)
+    batch_np = synth.label_glue_batch(d, seed)
+    ft, bt = feats_to_torch(feats_np, False), {k: t(v) for k, v in batch_np.items()}
+    model = build_reference_model(d, sd, ft)
+    logits = []
+    hk = model.logit.register_forward_hook(lambda m, i, o: logits.append(o.detach().clone()))
+    with torch.no_grad():
+        seq, att2, _ = model_call(model, bt, ft, True)
+    hk.remove()
+    logp = torch.log_softmax(torch.stack(logits, 1), 2)
+    return dict(seq=seq.numpy(), att2_weights=att2.numpy(), gaps=FO.deciding_gaps(logp.numpy()),
+                inputs_digest=np.array(FO.inputs_digest(sd, feats_np)))
+
+
+def g9_fullsize_ref(path):
+    """BASELINE's benchmark sizes pinned to the REFERENCE (round-4 review item 3): its greedy sampler at config 2 and config 5,
+    its cyclical pass (_forward_3_loops, captioner.py:196-382) at config 3 in eval mode with the objective 0.5 lm + 0.5 lm_recon
+    (five losses, ground_weights, per-parameter gradient norms + the elements at tests/fullsize_oracle.py::sample_index).  The
+    inputs are cvc.synth's (config, seed) -- the seeds the GPU tests use; a digest of the WHOLE input arrays is stored."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import time
+    import fullsize_oracle as FO
+    torch.set_num_threads(os.cpu_count() or 8)
+    out = OrderedDict()
+    for cfg, seed in (("cfg2", 1236), ("cfg5", 1505)):
+        t0 = time.time()
+        put(out, cfg + ".greedy.", _greedy_ref(synth.CONFIGS[cfg], seed))
+        out[cfg + ".greedy.seed"] = np.asarray(seed)
+        print(cfg, "greedy: %.0f s" % (time.time() - t0), flush=True)
+    d, seed = synth.CONFIGS["cfg3"], 1303
+    t0 = time.time()
+    sd, feats_np, batch_np = synth.hot_path_state_dict(d, seed), synth.clip_features(d, seed), synth.label_glue_batch(d, seed)
+    ft, bt = feats_to_torch(feats_np, False), {k: t(v) for k, v in batch_np.items()}
+    model = build_reference_model(d, sd, ft)
+    grabbed = {}
+    orig = model._grounder
+
+    def spy(xt, att_feats, mask, bias=None, min_value=-1e8):
+        r = orig(xt, att_feats, mask, bias, min_value)
+        grabbed["ground_weights"] = r.detach().clone()
+        return r
+    model._grounder = spy
+    losses = model_call(model, bt, ft, False)
+    loss_mix(losses).backward()
+    name = "cfg3.cyclical."
+    out[name + "seed"] = np.asarray(seed)
+    out[name + "inputs_digest"] = np.array(FO.inputs_digest(sd, feats_np, batch_np))
+    out[name + "losses"] = np.array([float(x.detach().mean()) for x in losses], dtype=np.float64)
+    out[name + "ground_weights"] = grabbed["ground_weights"].numpy()
+    for n, p in model.named_parameters():
+        if n.startswith("roi_feat_extractor."):
+            continue
+        if p.grad is None:
+            out[name + "grad_none." + n] = np.asarray(1)
+            continue
+        g = p.grad.double().reshape(-1)
+        out[name + "grad_norm." + n] = np.asarray(float(g.norm()))
+        out[name + "grad_at." + n] = g[torch.from_numpy(FO.sample_index(n, g.numel()))].numpy()
+    print("cfg3 cyclical: %.0f s" % (time.time() - t0), flush=True)
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+# ------------------------------------------------------------------------------------ G10 (embedding_vocab_plus_1)
+def g10_vocab_plus_1(path):
+    """opts.embedding_vocab_plus_1 = True (opts.py:197, captioner.py:53-60, 72-76): the embedding table and the vocabulary head
+    get V + 1 rows while every vocab_size-relative computation (the grounder's clamp :283, the criterion's range check
+    utils.py:134, bbox_target) keeps V.  Tiny dims: greedy sample + per-step log-probs, the cyclical pass's losses and every
+    gradient (eval mode)."""
+    d = synth.CONFIGS["tiny"]
+    seed = 1240
+    sd = synth.hot_path_state_dict(d, seed, vocab_plus_1=True)
+    feats_np = synth.clip_features(d, seed)
+    batch_np = synth.label_glue_batch(d, seed)
+    out = OrderedDict()
+    out["meta.seed"] = np.asarray(seed)
+    ft = feats_to_torch(feats_np, False)
+    bt = {k: t(v) for k, v in batch_np.items()}
+    model = build_reference_model(d, sd, ft, embedding_vocab_plus_1=True)
+    assert model.logit.weight.shape[0] == d.V + 1 and model.embed[0].weight.shape[0] == d.V + 1
+    logits = []
+    hk = model.logit.register_forward_hook(lambda m, i, o: logits.append(o.detach().clone()))
+    with torch.no_grad():
+        seq, att2, _ = model_call(model, bt, ft, True)
+    hk.remove()
+    put(out, "a8.", dict(seq=seq, att2_weights=att2, logp=torch.log_softmax(torch.stack(logits, 1), 2)))
+    ft = feats_to_torch(feats_np, True)
+    model = build_reference_model(d, sd, ft, embedding_vocab_plus_1=True)
+    losses = model_call(model, bt, ft, False)
+    put(out, "a9.cyc.", {"loss%d" % i: l for i, l in enumerate(losses)})
+    loss = loss_mix(losses)
+    put(out, "a9.cyc.", dict(total=loss))
+    put(out, "a9.cyc.", grads_of(model, ft, loss))
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
 if __name__ == "__main__":
     gdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gdir, exist_ok=True)
@@ -587,7 +690,11 @@ if __name__ == "__main__":
             "g5": lambda: g5_encoder(os.path.join(gdir, "g5_encoder.npz")),
             "g6": lambda: g6_dataloader(os.path.join(gdir, "g6_dataloader.npz")),
             "g7": lambda: g7_sentinel(os.path.join(gdir, "g7_sentinel.npz")),
-            "g8": lambda: g8_encoder_wide(os.path.join(gdir, "g8_encoder_wide.npz"))}
+            "g8": lambda: g8_encoder_wide(os.path.join(gdir, "g8_encoder_wide.npz")),
+            "g9": lambda: g9_fullsize_ref(os.path.join(gdir, "g9_fullsize_ref.npz")),      # ~10 min, 30 GB: only when named
+            "g10": lambda: g10_vocab_plus_1(os.path.join(gdir, "g10_vocab_plus_1.npz"))}
+    if "--fullsize" in only:
+        only = [x for x in only if x != "--fullsize"] + ["g9"]
     for name, job in jobs.items():
-        if not only or name in only:
+        if (not only and name != "g9") or name in only:
             job()
