@@ -35,10 +35,70 @@ struct NNSeg {
 
 struct NNArgs {
     const float* xq;    // dY, quad layout [K/4][64][4]
-    float* part;        // [ksplit][M][ntot] partial planes (unused when ksplit == 1)
-    int K, M, nseg, ksplit, ntot, nslab;
+    const float* xq2;   // 128-row form only: the second 64-row group's dY (rows 64 .. 64 + M2 - 1 of the product)
+    float* part;        // [ksplit][M][ntot] partial planes (unused when ksplit == 1); 128-row form: [ksplit][128][ntot]
+    int K, M, M2, nseg, ksplit, ntot, nslab;
     NNSeg seg[NN_MAX_SEG];
 };
+
+// ---- cross-wave sum + store, shared by the three kernels below.  The four waves of a workgroup hold partial accumulators of the
+// same 128-column x (32 MT)-row tile (they split K).  Round k makes wave k the owner of a quarter of the tile -- the MT (row block,
+// column quad group) pairs p = k MT .. k MT + MT - 1, pair p = (mt = p / 4, q = p % 4) -- : every wave writes its registers of that
+// quarter to LDS as 16-byte vectors (lane-linear: conflict-free ds_write_b128), one barrier, the owner reads the four copies and
+// sums them in the fixed order (w0 + w2) + (w1 + w3).  Rounds alternate between two buffers, so one barrier per round is enough
+// (a buffer is rewritten two rounds later, behind the barrier its reader has passed after reading).  Every wave then stores its
+// quarter straight from registers: accumulator register 4 q + rr of column tile c is output column 32 q + 16 kh + 4 rr + c of row
+// 32 mt + (lane & 31), so the four column tiles give 16 contiguous bytes per (q, rr).
+// (Round 4 summed through two [128][rows + 1] planes with 32-bit LDS accesses, three dependent rounds with two or three waves
+// idle, and stored one dword per thread and iteration: 13.7 + 9.1 us of an 87 us launch by in-kernel timestamps.)
+template <int MT>
+__device__ __forceinline__ void nn_cross_wave_store(f32x16 (&acc)[4][MT], char* lds, int wave, int lane, float* out, size_t ld, int cbase,
+                                                    int nvalid, int M, int M2) {
+    constexpr int BUF = 4 * 4 * MT * 1024;                  // bytes per buffer: 4 waves x (4 MT vectors) x 1 KiB
+    const int i = lane & 31, kh = lane >> 5;
+    f32x4 fin[MT][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        char* const buf = lds + (k & 1) * BUF;
+        char* const mine = buf + wave * (4 * MT * 1024) + lane * 16;
+#pragma unroll
+        for (int pl = 0; pl < MT; ++pl) {
+            const int p = k * MT + pl, mt = p >> 2, q = p & 3;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 v = {acc[c][mt][4 * q], acc[c][mt][4 * q + 1], acc[c][mt][4 * q + 2], acc[c][mt][4 * q + 3]};
+                *reinterpret_cast<f32x4*>(mine + (pl * 4 + c) * 1024) = v;
+            }
+        }
+        __syncthreads();
+        if (wave == k) {
+#pragma unroll
+            for (int pl = 0; pl < MT; ++pl)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const char* src = buf + (pl * 4 + c) * 1024 + lane * 16;
+                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(src), s1 = *reinterpret_cast<const f32x4*>(src + 4 * MT * 1024);
+                    const f32x4 s2 = *reinterpret_cast<const f32x4*>(src + 2 * 4 * MT * 1024);
+                    const f32x4 s3 = *reinterpret_cast<const f32x4*>(src + 3 * 4 * MT * 1024);
+                    fin[pl][c] = (s0 + s2) + (s1 + s3);
+                }
+        }
+    }
+#pragma unroll
+    for (int pl = 0; pl < MT; ++pl) {
+        const int p = wave * MT + pl, mt = p >> 2, q = p & 3;
+        const int m = mt * 32 + i;
+        const bool row_ok = M2 < 0 ? m < M : (m < 64 ? m < M : m - 64 < M2);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int nl = 32 * q + 16 * kh + 4 * rr;
+            if (row_ok && nl < nvalid) {
+                const f32x4 v = {fin[pl][0][rr], fin[pl][1][rr], fin[pl][2][rr], fin[pl][3][rr]};
+                st4(out + (size_t)m * ld + cbase + nl, v);
+            }
+        }
+    }
+}
 
 template <int MT>
 struct NNFrag {
@@ -49,8 +109,7 @@ struct NNFrag {
 template <int MT>
 __global__ __launch_bounds__(256, CVC_NN_WGS) void skinny_gemm_nn_kernel(NNArgs a) {
     constexpr int NW = 4;
-    constexpr int LDM = MT * 32 + 1;
-    __shared__ float red[2 * 128 * LDM];
+    __shared__ __attribute__((aligned(16))) char lds[2 * 16 * MT * 1024];       // the two exchange buffers of nn_cross_wave_store
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, kh = lane >> 5;
@@ -156,46 +215,12 @@ __global__ __launch_bounds__(256, CVC_NN_WGS) void skinny_gemm_nn_kernel(NNArgs 
         }
     }
 
-    // ---- cross-wave sum, fixed order (w0 + w2) + (w1 + w3), through two LDS planes A / B
-    // (acc reg r -> column-tile row (r&3) + 8*(r>>2) + 4*kh, i.e. output column 4*row + c; lane&31 -> batch row).
-    // Reads are issued 16 at a time (one accumulator vector) so that LDS latency is paid once per vector.
-    float* const planeA = red;
-    float* const planeB = red + 128 * LDM;
-    auto put = [&](float* plane) __attribute__((always_inline)) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    plane[(4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + c) * LDM + mt * 32 + i] = acc[c][mt][r];
-    };
-    auto add = [&](const float* plane) __attribute__((always_inline)) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                f32x16 t;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) t[r] = plane[(4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + c) * LDM + mt * 32 + i];
-                acc[c][mt] += t;
-            }
-    };
-    if (wave == 2) put(planeA);
-    if (wave == 3) put(planeB);
-    __syncthreads();
-    if (wave == 0) add(planeA);
-    if (wave == 1) { add(planeB); put(planeB); }
-    __syncthreads();
-    if (wave == 0) { add(planeB); put(planeA); }
-    __syncthreads();
-
-    const int M = a.M;
+    // ---- cross-wave sum in the fixed order (w0 + w2) + (w1 + w3) and store (nn_cross_wave_store above)
     float* out;
     size_t ld;
     int cbase;
     if (a.ksplit > 1) {
-        out = a.part + (size_t)kslice * M * a.ntot;
+        out = a.part + (size_t)kslice * a.M * a.ntot;
         ld = (size_t)a.ntot;
         cbase = sg.slab0 * 128 + n0;          // plane columns are slab-padded: segment s starts at slab0 * 128
     } else {
@@ -203,12 +228,7 @@ __global__ __launch_bounds__(256, CVC_NN_WGS) void skinny_gemm_nn_kernel(NNArgs 
         ld = (size_t)sg.ld_dst;
         cbase = n0;
     }
-    const int nvalid = sg.ncols - n0 < 128 ? sg.ncols - n0 : 128;
-    for (int u = tid; u < 128 * MT * 32; u += NW * 64) {
-        const int nl = u & 127, m = u >> 7;
-        if (m >= M || nl >= nvalid) continue;
-        out[(size_t)m * ld + cbase + nl] = red[nl * LDM + m];
-    }
+    nn_cross_wave_store<MT>(acc, lds, wave, lane, out, ld, cbase, sg.ncols - n0 < 128 ? sg.ncols - n0 : 128, a.M, -1);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -233,9 +253,8 @@ struct NNFrag2 {
 template <int MT>
 __global__ __launch_bounds__(256, 1) void skinny_gemm_nn_split_kernel(NNArgs a) {
     constexpr int NW = 4;
-    constexpr int LDM = MT * 32 + 1;
     constexpr int D = CVC_NNS_DEPTH;
-    __shared__ float red[2 * 128 * LDM];
+    __shared__ __attribute__((aligned(16))) char lds[2 * 16 * MT * 1024];       // the two exchange buffers of nn_cross_wave_store
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 31, kh = lane >> 5;
@@ -288,20 +307,45 @@ __global__ __launch_bounds__(256, 1) void skinny_gemm_nn_split_kernel(NNArgs a) 
         Split3 X[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) X[mt] = split8(f.x[mt][0], f.x[mt][1]);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        // The split of column tile c + 1's weights (36 VALU instructions) is issued between the 24 MFMAs of column tile c: a wave
+        // issues in order, and an MFMA that finds the matrix pipe busy (32 cycles per MFMA) holds back everything behind it -- VALU
+        // work placed between two MFMAs runs in the shadow of the first.
+        auto wsplit = [&](int c) __attribute__((always_inline)) {
             const f32x4 wa = {f.w[0][c], f.w[1][c], f.w[2][c], f.w[3][c]};
             const f32x4 wb = {f.w[4][c], f.w[5][c], f.w[6][c], f.w[7][c]};
-            const Split3 W = split8(wa, wb);
+            return split8(wa, wb);
+        };
+        Split3 Wn = wsplit(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const Split3 W = Wn;
+#if CVC_NN128_SCHED
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            if (c < 3) Wn = wsplit(c + 1);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
+#if defined(CVC_NN128_ABL) && CVC_NN128_ABL == 1          // ablation: no MFMAs (memory + split work only)
+                asm volatile("" ::"v"(W.hi), "v"(W.mid), "v"(W.lo), "v"(X[mt].hi), "v"(X[mt].mid), "v"(X[mt].lo));
+#else
                 acc[c][mt] = mfma_bf16(W.mid, X[mt].mid, acc[c][mt]);
                 acc[c][mt] = mfma_bf16(W.lo, X[mt].hi, acc[c][mt]);
                 acc[c][mt] = mfma_bf16(W.hi, X[mt].lo, acc[c][mt]);
                 acc[c][mt] = mfma_bf16(W.mid, X[mt].hi, acc[c][mt]);
                 acc[c][mt] = mfma_bf16(W.hi, X[mt].mid, acc[c][mt]);
                 acc[c][mt] = mfma_bf16(W.hi, X[mt].hi, acc[c][mt]);
+#endif
             }
+#if CVC_NN128_SCHED && !(defined(CVC_NN128_ABL) && CVC_NN128_ABL == 1)
+            if (c < 3) {
+#pragma unroll
+                for (int k = 0; k < 24; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // two VALU instructions of the next tile's split
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
     };
 
@@ -347,44 +391,260 @@ __global__ __launch_bounds__(256, 1) void skinny_gemm_nn_split_kernel(NNArgs a) 
                     acc[c][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e][c], x[mt][e], acc[c][mt], 0, 0, 0);
     }
 
-    // ---- cross-wave sum and store: identical to skinny_gemm_nn_kernel
-    float* const planeA = red;
-    float* const planeB = red + 128 * LDM;
-    auto put = [&](float* plane) __attribute__((always_inline)) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    plane[(4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + c) * LDM + mt * 32 + i] = acc[c][mt][r];
-    };
-    auto add = [&](const float* plane) __attribute__((always_inline)) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                f32x16 t;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) t[r] = plane[(4 * ((r & 3) + 8 * (r >> 2) + 4 * kh) + c) * LDM + mt * 32 + i];
-                acc[c][mt] += t;
-            }
-    };
-    if (wave == 2) put(planeA);
-    if (wave == 3) put(planeB);
-    __syncthreads();
-    if (wave == 0) add(planeA);
-    if (wave == 1) { add(planeB); put(planeB); }
-    __syncthreads();
-    if (wave == 0) { add(planeB); put(planeA); }
-    __syncthreads();
-
-    const int M = a.M;
+    // ---- cross-wave sum in the fixed order (w0 + w2) + (w1 + w3) and store (nn_cross_wave_store above)
     float* out;
     size_t ld;
     int cbase;
     if (a.ksplit > 1) {
-        out = a.part + (size_t)kslice * M * a.ntot;
+        out = a.part + (size_t)kslice * a.M * a.ntot;
+        ld = (size_t)a.ntot;
+        cbase = sg.slab0 * 128 + n0;          // plane columns are slab-padded: segment s starts at slab0 * 128
+    } else {
+        out = sg.dst;
+        ld = (size_t)sg.ld_dst;
+        cbase = n0;
+    }
+    nn_cross_wave_store<MT>(acc, lds, wave, lane, out, ld, cbase, sg.ncols - n0 < 128 ? sg.ncols - n0 : 128, a.M, -1);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// 128-row form of the split-product kernel (round 5): TWO 64-row operand groups (the two loops of the cyclical pass at B = 64 each,
+// captioner.py:242-270 and :348-362, which share the LSTM cells) against ONE stream of the weights -- config 3's back-propagation
+// then runs 3 backward-data products per step instead of 5.  Same tiling (128 output columns x one K slice per workgroup, 4 waves
+// interleaved over the slice's 8-row groups, two groups per K = 16 step, the six cross terms in the same order, the same cross-wave
+// sum), so a row's result has the bits the 64-row kernel gives it under the same K split.
+// Registers: 4 x 4 accumulator tiles = 256 registers per lane; what is left of the 512 holds a ring of WEIGHT fragments only
+// (32 registers per K = 16 step) -- the dY operand of both groups travels through LDS instead: per step and wave 8 KiB =
+// [k half of the step][quad row pair][group] x 1 KiB, copied by LDS-DMA (global_load_lds_dwordx4: a quad row of 64 batch rows IS
+// 1 KiB contiguous in the quad layout) into a wave-private ring, read back as ds_read_b128.  A step's copies are issued before
+// its weight loads, loads return in order, so ONE counted vmcnt covers both.  The ring shares its LDS with the cross-wave sum.
+typedef __attribute__((address_space(3))) void* nn_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* nn_glb_ptr_t;
+#ifndef CVC_NN128_DEPTH
+#define CVC_NN128_DEPTH 3
+#endif
+#ifndef CVC_NN128_SCHED
+#define CVC_NN128_SCHED 1
+#endif
+
+
+struct NNW8 { f32x4 w[8]; };
+
+__global__ __launch_bounds__(256, 1) void skinny_gemm_nn_split128_kernel(NNArgs a) {
+    constexpr int NW = 4, MT = 4, D = CVC_NN128_DEPTH;
+    constexpr int XSLOT = 8 * 1024;                         // bytes per wave and ring slot
+    constexpr int RED_BYTES = 2 * 16 * MT * 1024, RING_BYTES = NW * D * XSLOT;      // exchange buffers of nn_cross_wave_store / dY ring
+    __shared__ __attribute__((aligned(16))) char lds[RED_BYTES > RING_BYTES ? RED_BYTES : RING_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 31, kh = lane >> 5;
+    const int kslice = (int)blockIdx.x % a.ksplit, slab = (int)blockIdx.x / a.ksplit;
+    int s = 0;
+    for (int t = 1; t < a.nseg; ++t)
+        if (slab >= a.seg[t].slab0) s = t;
+    const NNSeg sg = a.seg[s];
+    const int n0 = (slab - sg.slab0) * 128;
+    int col = n0 + 4 * i;
+    col = col + 4 <= sg.ncols ? col : sg.ncols - 4;
+
+    const int ngroup = a.K >> 3;
+    const int g_lo = ngroup * kslice / a.ksplit, g_hi = ngroup * (kslice + 1) / a.ksplit;
+    const int ng = g_hi - g_lo;
+    const int n_my = ng > wave ? (ng - wave + NW - 1) / NW : 0;      // groups g_lo + wave + 4*j
+    const int n2 = n_my >> 1;                                         // double groups; an odd last group runs on the fp32 MFMA
+    const size_t ldw = (size_t)sg.ldw;
+    const float* wp[4];
+    wp[0] = sg.w + (size_t)((g_lo + wave) * 8 + kh * 4) * ldw + col;
+#pragma unroll
+    for (int e = 1; e < 4; ++e) wp[e] = wp[e - 1] + ldw;
+    const size_t WSTEP = (size_t)NW * 8 * ldw;
+    // LDS-DMA sources: lane l copies batch row l of a quad row; per double group [h][kh][group]
+    const float* xs[2] = {a.xq + ((size_t)(g_lo + wave) * 2 * 64 + lane) * 4, a.xq2 + ((size_t)(g_lo + wave) * 2 * 64 + lane) * 4};
+    constexpr size_t XSTEP = (size_t)NW * 2 * 256;          // floats between a wave's consecutive groups
+    char* const ring = lds + wave * D * XSLOT;
+
+    // Every load of the K loop is issued from inline assembly, and waited for by the counted s_waitcnt statements below: hipcc's own
+    // wait-count pass is exact for register loads alone, but with LDS-DMA copies in the loop it falls back to vmcnt(0) at the loop
+    // head (one step in D fully drained).  Loads it cannot see only make the waits it computes for its own accesses stricter.
+    const unsigned ring_lds = (unsigned)(uintptr_t)(nn_lds_ptr_t)ring;
+    auto issue = [&](NNW8& f, int pos) __attribute__((always_inline)) {
+        const unsigned dst = ring_lds + pos * XSLOT;
+#if defined(CVC_NN128_ABL) && CVC_NN128_ABL == 3          // ablation: no loads (compute side only)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) asm volatile("" : "=v"(f.w[k]) : "s"(dst));
+        return;
+#endif
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                                 :
+                                 : "v"(xs[g] + h * XSTEP + q * 256), "s"(dst + ((h * 2 + q) * 2 + g) * 1024)
+                                 : "m0", "memory");
+        xs[0] += 2 * XSTEP;
+        xs[1] += 2 * XSTEP;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(f.w[h * 4 + e]) : "v"(wp[e]));
+                wp[e] += WSTEP;
+            }
+    };
+
+    f32x16 acc[4][MT];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][mt][r] = 0.f;
+#ifdef CVC_NN128_TS            // diagnostic build: s_memrealtime (100 MHz) at entry / K loop done / sums done / stores done, wave 0 of every workgroup
+    unsigned long long ts0 = __builtin_readcyclecounter(), ts1 = 0, ts2 = 0;
+    const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+
+    // byte offset of this lane's first fragment inside a ring slot; it passes through every wait statement below, so the ring reads
+    // of a step (addressed from it) cannot be scheduled above the step's wait
+    unsigned lane_off = (unsigned)(wave * D * XSLOT + kh * 2048 + i * 16);
+    auto compute = [&](const NNW8& f, int pos) __attribute__((always_inline)) {
+        const char* src = lds + lane_off + pos * XSLOT;
+        Split3 X[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const char* p = src + (mt >> 1) * 1024 + (mt & 1) * 512;
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(p), x1 = *reinterpret_cast<const f32x4*>(p + 4096);
+#if defined(CVC_NN128_ABL) && CVC_NN128_ABL == 2          // ablation: no split of the dY operand (wrong numbers, same instruction mix otherwise)
+            X[mt].hi = __builtin_bit_cast(u32x4, x0); X[mt].mid = __builtin_bit_cast(u32x4, x1); X[mt].lo = X[mt].hi ^ X[mt].mid;
+#else
+            X[mt] = split8(x0, x1);
+#endif
+        }
+        // The split of column tile c + 1's weights (36 VALU instructions) is issued between the 24 MFMAs of column tile c: a wave
+        // issues in order, and an MFMA that finds the matrix pipe busy (32 cycles per MFMA) holds back everything behind it -- VALU
+        // work placed between two MFMAs runs in the shadow of the first.  (Carrying the NEXT step's dY split into the last column
+        // tile's shadow as well needs a second set of split registers: with it the kernel spills an accumulator tile inside the K
+        // loop and a step takes 5 400 clocks instead of 4 960 -- measured, not kept.)
+        auto wsplit = [&](int c) __attribute__((always_inline)) {
+            const f32x4 wa = {f.w[0][c], f.w[1][c], f.w[2][c], f.w[3][c]};
+            const f32x4 wb = {f.w[4][c], f.w[5][c], f.w[6][c], f.w[7][c]};
+            return split8(wa, wb);
+        };
+        Split3 Wn = wsplit(0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const Split3 W = Wn;
+#if CVC_NN128_SCHED
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            if (c < 3) Wn = wsplit(c + 1);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#if defined(CVC_NN128_ABL) && CVC_NN128_ABL == 1          // ablation: no MFMAs (memory + split work only)
+                asm volatile("" ::"v"(W.hi), "v"(W.mid), "v"(W.lo), "v"(X[mt].hi), "v"(X[mt].mid), "v"(X[mt].lo));
+#else
+                acc[c][mt] = mfma_bf16(W.mid, X[mt].mid, acc[c][mt]);
+                acc[c][mt] = mfma_bf16(W.lo, X[mt].hi, acc[c][mt]);
+                acc[c][mt] = mfma_bf16(W.hi, X[mt].lo, acc[c][mt]);
+                acc[c][mt] = mfma_bf16(W.mid, X[mt].hi, acc[c][mt]);
+                acc[c][mt] = mfma_bf16(W.hi, X[mt].mid, acc[c][mt]);
+                acc[c][mt] = mfma_bf16(W.hi, X[mt].hi, acc[c][mt]);
+#endif
+            }
+#if CVC_NN128_SCHED && !(defined(CVC_NN128_ABL) && CVC_NN128_ABL == 1)
+            if (c < 3) {
+#pragma unroll
+                for (int k = 0; k < 24; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // two VALU instructions of the next tile's split
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+    };
+    // wait until at most `cnt` younger loads (16 per step) are outstanding; the step's weight registers and the ring offset pass
+    // through the statement, so nothing that reads them is scheduled above it
+#define CVC_NN128_WAIT(f, cnt)                                                                                                   \
+    asm volatile("s_waitcnt vmcnt(%9)"                                                                                             \
+                 : "+v"((f).w[0]), "+v"((f).w[1]), "+v"((f).w[2]), "+v"((f).w[3]), "+v"((f).w[4]), "+v"((f).w[5]), "+v"((f).w[6]), \
+                   "+v"((f).w[7]), "+v"(lane_off)                                                                                  \
+                 : "n"(cnt))
+    auto wait_for = [&](NNW8& f, int later) __attribute__((always_inline)) {
+        if (later >= 3) CVC_NN128_WAIT(f, 48);
+        else if (later == 2) CVC_NN128_WAIT(f, 32);
+        else if (later == 1) CVC_NN128_WAIT(f, 16);
+        else CVC_NN128_WAIT(f, 0);
+    };
+
+    NNW8 wr[D];
+    if (n2 >= D) {
+        // (the steady state's loads are unconditional from the prologue on: a conditionally issued load in front of the loop
+        // degrades hipcc's counted vmcnt inside it to 0)
+#pragma unroll
+        for (int t = 0; t < D - 1; ++t) issue(wr[t], t);
+        int j = 0;
+        for (; j + 2 * D - 1 <= n2; j += D) {
+#pragma unroll
+            for (int t = 0; t < D; ++t) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue(wr[(t + D - 1) % D], (t + D - 1) % D);
+                __builtin_amdgcn_sched_barrier(0);            // requests first (the scheduler would sink them behind the MFMAs)
+                CVC_NN128_WAIT(wr[t], 16 * (D - 1));
+                compute(wr[t], t);
+            }
+        }
+        // tail: D .. 2 D - 2 steps are left, D - 1 of them already requested; j % D == 0
+#pragma unroll
+        for (int t = 0; t < 2 * D - 2; ++t) {
+            const int st = j + t;
+            if (st < n2) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + D - 1 < n2) issue(wr[(t + D - 1) % D], (t + D - 1) % D);
+                __builtin_amdgcn_sched_barrier(0);
+                const int later = n2 - 1 - st;
+                wait_for(wr[t % D], later < D - 1 ? later : D - 1);
+                compute(wr[t % D], t % D);
+            }
+        }
+    } else {
+        for (int j = 0; j < n2; ++j) {
+            issue(wr[0], 0);
+            CVC_NN128_WAIT(wr[0], 0);
+            compute(wr[0], 0);
+        }
+    }
+#undef CVC_NN128_WAIT
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (nothing the compiler can see moves above the K loop's last wait)
+    if (n_my & 1) {                                           // odd last group: exact fp32 products on the fp32 MFMA
+        f32x4 w[4], x[MT];
+        const float* xo[2] = {xs[0] - lane * 4 + ((size_t)kh * 64 + i) * 4, xs[1] - lane * 4 + ((size_t)kh * 64 + i) * 4};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = ld4(wp[e]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) x[mt] = ld4(xo[mt >> 1] + (mt & 1) * 128);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[c][mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[e][c], x[mt][e], acc[c][mt], 0, 0, 0);
+    }
+
+#ifdef CVC_NN128_TS
+    ts1 = __builtin_readcyclecounter();
+#endif
+    // ---- cross-wave sum and store (nn_cross_wave_store; its buffers take over the ring's LDS: every wave is through with it)
+    __syncthreads();
+    float* out;
+    size_t ld;
+    int cbase;
+    if (a.ksplit > 1) {
+        out = a.part + (size_t)kslice * 128 * a.ntot;
         ld = (size_t)a.ntot;
         cbase = sg.slab0 * 128 + n0;
     } else {
@@ -392,12 +652,35 @@ __global__ __launch_bounds__(256, 1) void skinny_gemm_nn_split_kernel(NNArgs a) 
         ld = (size_t)sg.ld_dst;
         cbase = n0;
     }
-    const int nvalid = sg.ncols - n0 < 128 ? sg.ncols - n0 : 128;
-    for (int u = tid; u < 128 * MT * 32; u += NW * 64) {
-        const int nl = u & 127, m = u >> 7;
-        if (m >= M || nl >= nvalid) continue;
-        out[(size_t)m * ld + cbase + nl] = red[nl * LDM + m];
+#ifdef CVC_NN128_TS
+    ts2 = __builtin_readcyclecounter();
+#endif
+    nn_cross_wave_store<MT>(acc, lds, wave, lane, out, ld, cbase, sg.ncols - n0 < 128 ? sg.ncols - n0 : 128, a.M, a.M2);
+#ifdef CVC_NN128_TS
+    if (lane == 0) {      // the record lands behind the planes (the measurement script allocates room): [wg][wave][6]
+        unsigned long long* rec = reinterpret_cast<unsigned long long*>(a.part + (size_t)a.ksplit * 128 * a.ntot) + ((size_t)blockIdx.x * 4 + wave) * 6;
+        rec[0] = rt0; rec[1] = ts1 - ts0; rec[2] = ts2 - ts1; rec[3] = __builtin_readcyclecounter() - ts2; rec[4] = __builtin_amdgcn_s_memrealtime();
+        rec[5] = (unsigned long long)n2;
     }
+#endif
+}
+
+// dst[seg][m][n] = sum over planes of the 128-row form (rows 64 .. of a plane / of dst = the second group), fixed order
+__global__ __launch_bounds__(256) void nn_reduce128_kernel(NNArgs a) {
+    const int m = blockIdx.y;
+    if (m < 64 ? m >= a.M : m - 64 >= a.M2) return;
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= a.ntot) return;
+    int s = 0;
+    for (int t = 1; t < a.nseg; ++t)
+        if (c >= a.seg[t].slab0 * 128) s = t;
+    const NNSeg sg = a.seg[s];
+    const int n = c - sg.slab0 * 128;
+    if (n >= sg.ncols) return;
+    const float* p = a.part + (size_t)m * a.ntot + c;
+    f32x4 v = ld4(p);
+    for (int k = 1; k < a.ksplit; ++k) v += ld4(p + (size_t)k * 128 * a.ntot);
+    st4(sg.dst + (size_t)m * sg.ld_dst + n, v);
 }
 
 // dst[seg][m][n] = sum over planes, fixed order
@@ -481,5 +764,36 @@ static int linear_nn_impl(const float* dy_q, int K, int M, const cvc_nn_seg* seg
     else hipLaunchKernelGGL((skinny_gemm_nn_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, a);
     if (ksplit > 1 && reduce)
         hipLaunchKernelGGL(nn_reduce_kernel, dim3((a.ntot / 4 + 255) / 256, M), dim3(256), 0, (hipStream_t)stream, a);
+    return cvc_launch_status();
+}
+
+// 128-row form: rows 0 .. M - 1 from dy_q, rows 64 .. 64 + M2 - 1 from dy_q2 (both in the 64-row quad layout, rows beyond M / M2
+// zero), ONE stream of the weights.  Results: K-slice planes [ksplit][128][ntot] in `workspace` (reduce = 0, ksplit > 1) or the
+// segments' dst [128 rows, ld_dst] (row 64 + m = row m of the second group).  Split-product arithmetic only.
+extern "C" int cvc_linear_nn_planes2_fwd(const float* dy_q, const float* dy_q2, int K, int M, int M2, const cvc_nn_seg* segs, int nsegs,
+                                         int ksplit, float* workspace, int reduce, cvc_stream_t stream) {
+    if (!dy_q || !dy_q2 || !segs || nsegs < 1 || nsegs > NN_MAX_SEG || M < 1 || M > 64 || M2 < 1 || M2 > 64 || K < 8 || (K & 7) ||
+        ksplit < 1 || ((uintptr_t)dy_q & 15) || ((uintptr_t)dy_q2 & 15))
+        return CVC_E_BADARG;
+    if (cvc_gemm_split_mode == 0) return CVC_E_BADARG;
+    if (ksplit > K / 8) ksplit = K / 8;
+    NNArgs a{};
+    a.xq = dy_q; a.xq2 = dy_q2; a.K = K; a.M = M; a.M2 = M2; a.nseg = nsegs; a.ksplit = ksplit; a.part = workspace;
+    int slab = 0;
+    for (int s = 0; s < nsegs; ++s) {
+        const cvc_nn_seg& g = segs[s];
+        if (!g.w || !g.dst || g.ncols < 4 || (g.ncols & 3) || (g.ldw & 3) || (g.ld_dst & 3) || g.ldw < g.ncols ||
+            g.ld_dst < g.ncols || ((uintptr_t)g.w & 15) || ((uintptr_t)g.dst & 15))
+            return CVC_E_BADARG;
+        a.seg[s].w = g.w; a.seg[s].dst = g.dst; a.seg[s].ldw = g.ldw; a.seg[s].ncols = g.ncols; a.seg[s].ld_dst = g.ld_dst;
+        a.seg[s].slab0 = slab;
+        slab += (g.ncols + 127) / 128;
+    }
+    a.nslab = slab;
+    a.ntot = slab * 128;
+    if (ksplit > 1 && !workspace) return CVC_E_BADARG;
+    hipLaunchKernelGGL(skinny_gemm_nn_split128_kernel, dim3(slab * ksplit), dim3(256), 0, (hipStream_t)stream, a);
+    if (ksplit > 1 && reduce)
+        hipLaunchKernelGGL(nn_reduce128_kernel, dim3((a.ntot / 4 + 255) / 256, 128), dim3(256), 0, (hipStream_t)stream, a);
     return cvc_launch_status();
 }

@@ -784,6 +784,31 @@ __global__ __launch_bounds__(256) void tile_reorder_pack_kernel(ReorderArgs a) {
 }  // namespace
 
 static int cvc_tile_loader_waves = 3;
+// Rows are walked in chunks of 2 MH 32-row blocks (MH <= 5 accumulator tiles per wave).  Up to 320 rows: one chunk (the decode
+// engine's beam rows).  More (the dense products of the training pass: 1 280 .. 8 192 rows): the chunk height that needs the least
+// time by a two-term model -- workgroups run in rounds of one per CU (126 KB of LDS each) and a workgroup's time grows with its
+// MH + a fixed part -- so that a launch does not end in a mostly empty round: dW of an LSTM weight block (8 192 x 2 048 outputs) is
+// 16 x 26 = 416 workgroups at MH = 5 (two rounds, the second 62 % full) and 16 x 32 = 512 at MH = 4 (two full rounds of shorter
+// workgroups): 0.37 -> see DESIGN.md section 4 of the split-product roof.
+static int tile_rows_per_chunk(int mblk, int col_wgs) {
+    if (mblk < 10) return (mblk + 1) / 2;
+    if (mblk == 10) return 5;
+    static const int cus = [] {
+        hipDeviceProp_t p;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess || p.multiProcessorCount < 1) return 256;
+        return p.multiProcessorCount;
+    }();
+    int best = 5;
+    double best_t = 1e30;
+    for (int mh = 5; mh >= 3; --mh) {
+        const long long wgs = (long long)col_wgs * ((mblk + 2 * mh - 1) / (2 * mh));
+        const double t = (double)((wgs + cus - 1) / cus) * (mh + 0.6);
+        if (t < best_t - 1e-9) { best_t = t; best = mh; }
+    }
+    return best;
+}
+
 // test / A-B hook: 0 = every wave copies its share of a stage (tile_gemm_kernel), 1 = dedicated loader waves + 8 computing waves,
 // 2 = dedicated loader waves + 4 wide computing waves (tile_gemm_ld2_kernel), 3 = 2 for long K loops, 1 otherwise (default)
 extern "C" int cvc_tile_gemm_loaders(int on) {
@@ -801,8 +826,7 @@ extern "C" int cvc_tile_gemm(const void* wb, const void* xb, long long x_mblk_st
     a.M = M; a.N = N; a.ntile = (N + 127) / 128; a.ksplit = ksplit; a.parts = parts; a.ld = ld; a.part_stride = part_stride;
     const int mblk = (M + 31) / 32;
     const hipStream_t st = (hipStream_t)stream;
-    // rows are walked in chunks of 2 MH blocks; MH = 5 (320 rows) per chunk when there are more than 320
-    int MH = mblk >= 10 ? 5 : (mblk + 1) / 2;
+    const int MH = tile_rows_per_chunk(mblk, a.ntile * ksplit);
     const int chunks = (mblk + 2 * MH - 1) / (2 * MH);
     const dim3 grid(a.ntile * ksplit, chunks);
 #ifndef CVC_TILE_LOADERS
@@ -846,10 +870,18 @@ extern "C" int cvc_tile_gemm(const void* wb, const void* xb, long long x_mblk_st
 }
 
 extern "C" int cvc_tile_rows_alloc(int M) {
+    // rows a fragment buffer must hold (zero beyond M) for ANY chunk height cvc_tile_gemm may pick for these rows
     const int mblk = (M + 31) / 32;
-    const int MH = mblk >= 10 ? 5 : (mblk + 1) / 2;
-    const int chunks = (mblk + 2 * MH - 1) / (2 * MH);
-    return chunks * 2 * MH * 32;
+    if (mblk <= 10) {
+        const int MH = mblk == 10 ? 5 : (mblk + 1) / 2;
+        return 2 * MH * 32;
+    }
+    int rows = 0;
+    for (int mh = 3; mh <= 5; ++mh) {
+        const int r = (mblk + 2 * mh - 1) / (2 * mh) * 2 * mh * 32;
+        rows = r > rows ? r : rows;
+    }
+    return rows;
 }
 
 static int tile_lstm_finish_impl(const float* parts, int nparts, long long part_stride, const float* b_ih, const float* b_hh,

@@ -175,7 +175,7 @@ int run_fwd(const cvc_train_loop& L, hipStream_t st, int* launches) {
 
 // ---------------------------------------------------------------------------------------------------------------- backward
 struct BwdWs {
-    float *dgq, *dqq, *d_ctx, *d_ha_a, *d_ha_b, *d_ha_prev, *d_hl_a, *d_hl_b, *d_c_att, *d_c_lang;
+    float *dgq, *dgq2, *dqq, *d_ctx, *d_ha_a, *d_ha_b, *d_ha_prev, *d_hl_a, *d_hl_b, *d_c_att, *d_c_lang;
     float *nn_l, *nn_h, *nn_a;       // K-slice planes of the three backward-data products of a step (each lives until its consumers ran)
     long long total;
 };
@@ -183,15 +183,18 @@ BwdWs carve(float* base, int B, int R, int A) {
     BwdWs w{};
     size_t o = 0;
     auto take = [&](size_t floats) { float* p = base ? base + o : nullptr; o += (floats + 63) / 64 * 64; return p; };
-    (void)B;
+    // B > 64: the 128-row joint form (two 64-row operand groups, loop C's rows from row 64 on): a second quad operand, 128-row
+    // gradient rows and planes
+    const size_t rows = B > 64 ? 128 : 64;
     w.dgq = take((size_t)R * 256);                        // d_gates, quad layout [4R/4][64][4]
+    w.dgq2 = rows > 64 ? take((size_t)R * 256) : w.dgq;   // ... of the second group
     w.dqq = take((size_t)(A > 0 ? A : 4) / 4 * 256);      // d_q, quad layout [A/4][64][4]
-    const size_t br = (size_t)64 * R;
+    const size_t br = rows * R;
     w.d_ctx = take(br); w.d_ha_a = take(br); w.d_ha_b = take(br); w.d_ha_prev = take(br);
     w.d_hl_a = take(br); w.d_hl_b = take(br); w.d_c_att = take(br); w.d_c_lang = take(br);
     // planes of cvc_linear_nn_planes_fwd: ksplit * M * ntot floats with ksplit * slabs <= max(256, slabs)
     const size_t slabs_max = (size_t)(3 * R + 127) / 128;
-    const size_t plane = (size_t)64 * 128 * (slabs_max > 512 ? slabs_max : 512);
+    const size_t plane = rows * 128 * (slabs_max > 512 ? slabs_max : 512);
     w.nn_l = take(plane); w.nn_h = take(plane); w.nn_a = take(plane);
     w.total = (long long)o;
     return w;
@@ -200,7 +203,8 @@ BwdWs carve(float* base, int B, int R, int A) {
 // Backward-data product with the K split cvc/hip.py::linear_nn chooses (one resident round of workgroups, >= 16 K rows per wave),
 // WITHOUT the summing launch: out[s] describes where segment s's gradient lives -- the K-slice planes in `ws` (summed by the
 // consumer) or, unsplit, the segment's own dst.
-int nn(const float* dy_q, int K, int M, const cvc_nn_seg* segs, int nsegs, float* ws, cvc_grad_src* out, bool finished, hipStream_t st) {
+int nn(const float* dy_q, int K, int M, const cvc_nn_seg* segs, int nsegs, float* ws, cvc_grad_src* out, bool finished, hipStream_t st,
+       const float* dy_q2 = nullptr, int M2 = 0) {
     int slabs = 0;
     for (int s = 0; s < nsegs; ++s) slabs += (segs[s].ncols + 127) / 128;
     const int resident = cvc_gemm_packed_split(-1) != 0 ? 256 : 512;
@@ -209,11 +213,13 @@ int nn(const float* dy_q, int K, int M, const cvc_nn_seg* segs, int nsegs, float
     if (ks < 1) ks = 1;
     const long long ntot = (long long)slabs * 128;
     int slab = 0;
+    const int mrows = dy_q2 ? 128 : M;                  // rows of a plane (128-row form: the second group's rows start at row 64)
     for (int s = 0; s < nsegs; ++s) {
         if (ks == 1 || finished) out[s] = cvc_grad_src{segs[s].dst, segs[s].ld_dst, 0, 1};
-        else out[s] = cvc_grad_src{ws + (size_t)slab * 128, ntot, (long long)M * ntot, ks};
+        else out[s] = cvc_grad_src{ws + (size_t)slab * 128, ntot, (long long)mrows * ntot, ks};
         slab += (segs[s].ncols + 127) / 128;
     }
+    if (dy_q2) return cvc_linear_nn_planes2_fwd(dy_q, dy_q2, K, M, M2, segs, nsegs, ks, ws, finished ? 1 : 0, st);
     return finished ? cvc_linear_nn_fwd(dy_q, K, M, segs, nsegs, ks, ws, st) : cvc_linear_nn_planes_fwd(dy_q, K, M, segs, nsegs, ks, ws, st);
 }
 
@@ -223,19 +229,26 @@ inline cvc_grad_src rows_from(cvc_grad_src g, int row0) {
 }
 
 // Back-propagation through time of one loop, or of both loops at once (LA = loop A or null, LC = loop C or null): the loops share the
-// LSTM cells, so with both present (B_A + B_C <= 64) every backward-data product takes the two loops' gate gradients as ONE operand
-// (loop A's rows first) and streams its weights once.  The attention backward and the h2attn product belong to loop A alone.
+// LSTM cells, so with both present every backward-data product takes the two loops' gate gradients in one launch and streams its
+// weights once -- as ONE 64-row operand (loop A's rows first) when B_A + B_C <= 64, as two 64-row operand groups on the 128-row
+// form of the product otherwise (config 3: 64 + 64 rows; 3 products per step instead of 5).  The attention backward and the h2attn product belong to loop A alone.
 int run_bwd(const cvc_train_loop* LA, const cvc_train_loop* LC, hipStream_t st, int* launches) {
     const cvc_train_loop& L0 = LA ? *LA : *LC;           // shared: T, R, weights, workspace
     const int T = L0.T, R = L0.R;
-    const int BA = LA ? LA->B : 0, BC = LC ? LC->B : 0, M = BA + BC;
+    const int BA = LA ? LA->B : 0, BC = LC ? LC->B : 0;
+    // both loops, more rows than ONE 64-row operand holds: two operand groups against one stream of the weights (the 128-row
+    // form of the backward-data product, gemm_nn.hip) -- loop A's rows are rows 0 .., loop C's rows 64 .. of every gradient
+    const bool two = LA && LC && BA + BC > 64;
+    const int M = two ? BA : BA + BC;
     const int A = LA ? LA->A : 0, N = LA ? LA->N : 0, F = LA ? LA->F : 0;
-    const BwdWs w = carve(L0.bwd_ws, 64, R, A);
+    const BwdWs w = carve(L0.bwd_ws, two ? 128 : 64, R, A);
     const bool feat_grads = LA != nullptr && (LA->d_pool || LA->d_conv);     // the context-feature gradient reads d_ctx as a finished tensor
     const cvc_grad_src none{nullptr, 0, 0, 0};
     cvc_grad_src g_hl_a = none, g_hl_b = none, g_ha_prev = none;       // what step t + 1 left for step t (all M rows)
     const cvc_train_loop* loops[2] = {LA, LC};
-    const int row0[2] = {0, BA};
+    const int row0[2] = {0, two ? 64 : BA};
+    const int qrow0[2] = {0, two ? 0 : BA};              // row inside the loop's quad operand
+    float* const dgq[2] = {w.dgq, two ? w.dgq2 : w.dgq};
     int n = 0;
     for (int s = 0; s < 2; ++s) {
         if (!loops[s]) continue;
@@ -256,8 +269,8 @@ int run_bwd(const cvc_train_loop* LA, const cvc_train_loop* LC, hipStream_t st, 
             float* d_c = w.d_c_lang + (size_t)row0[s] * R;
             CVC_TRY_K(K_PW_LANG, cvc_lstm_pointwise_bwd4(src, L.d_out + (size_t)t * BR, L.p > 0.f ? L.rng_state : nullptr, L.site0 + (unsigned)t,
                                                          L.p, last ? nullptr : d_c, L.g_lang + (size_t)t * BG, L.c_lang + (size_t)t * BR,
-                                                         L.c_lang + (size_t)(t + 1) * BR, L.B, R, L.dg_lang + (size_t)t * BG, d_c, w.dgq,
-                                                         L.dgsum_lang, row0[s], st));
+                                                         L.c_lang + (size_t)(t + 1) * BR, L.B, R, L.dg_lang + (size_t)t * BG, d_c, dgq[s],
+                                                         L.dgsum_lang, qrow0[s], st));
         }
         const int shared = LA && LC ? 4 : 2 + L0.kind;        // profile label of the products both loops share
         g_prof_loop = shared;
@@ -269,7 +282,7 @@ int run_bwd(const cvc_train_loop* LA, const cvc_train_loop* LC, hipStream_t st, 
             if (LA) { i_ctx = ns; segs[ns++] = cvc_nn_seg{L0.w_ih_lang, w.d_ctx, L0.ld_ih_lang, R, R}; }
             i_ha = ns; segs[ns++] = cvc_nn_seg{L0.w_ih_lang + R, w.d_ha_a, L0.ld_ih_lang, R, R};
             if (t > 0) { i_hl = ns; segs[ns++] = cvc_nn_seg{L0.w_hh_lang, w.d_hl_a, R, R, R}; }
-            CVC_TRY_K(K_NN_LANG, nn(w.dgq, 4 * R, M, segs, ns, w.nn_l, out, feat_grads, st));
+            CVC_TRY_K(K_NN_LANG, nn(w.dgq, 4 * R, M, segs, ns, w.nn_l, out, feat_grads, st, two ? w.dgq2 : nullptr, BC));
             if (i_ctx >= 0) g_ctx = out[i_ctx];
             g_ha_a = out[i_ha];
             g_hl_a = i_hl >= 0 ? out[i_hl] : none;
@@ -307,13 +320,13 @@ int run_bwd(const cvc_train_loop* LA, const cvc_train_loop* LC, hipStream_t st, 
             float* d_c = w.d_c_att + (size_t)row0[s] * R;
             CVC_TRY_K(K_PW_ATT, cvc_lstm_pointwise_bwd4(src, nullptr, nullptr, 0, 0.f, last ? nullptr : d_c, L.g_att + (size_t)t * BG,
                                                         L.c_att + (size_t)t * BR, L.c_att + (size_t)(t + 1) * BR, L.B, R, L.dg_att + (size_t)t * BG,
-                                                        d_c, w.dgq, L.dgsum_att, row0[s], st));
+                                                        d_c, dgq[s], L.dgsum_att, qrow0[s], st));
         }
         g_prof_loop = shared;
         if (t > 0) {
             cvc_nn_seg segs[2] = {cvc_nn_seg{L0.w_ih_att, w.d_hl_b, L0.ld_ih_att, R, R}, cvc_nn_seg{L0.w_hh_att, w.d_ha_prev, R, R, R}};
             cvc_grad_src out[2];
-            CVC_TRY_K(K_NN_ATT, nn(w.dgq, 4 * R, M, segs, 2, w.nn_a, out, false, st));
+            CVC_TRY_K(K_NN_ATT, nn(w.dgq, 4 * R, M, segs, 2, w.nn_a, out, false, st, two ? w.dgq2 : nullptr, BC));
             g_hl_b = out[0];
             g_ha_prev = out[1];
         }
@@ -325,7 +338,7 @@ int run_bwd(const cvc_train_loop* LA, const cvc_train_loop* LC, hipStream_t st, 
 }  // namespace
 
 extern "C" long long cvc_train_loop_bwd_ws(int B, int R, int A) {
-    if (B < 1 || B > 64 || R < 32 || A < 0) return 0;
+    if (B < 1 || B > 128 || R < 32 || A < 0) return 0;      /* B > 64: the joint pass of two loops with B_A + B_C rows */
     return carve(nullptr, B, R, A).total;
 }
 
@@ -349,7 +362,7 @@ extern "C" int cvc_train_loops_bwd_joint(const cvc_train_loop* loop_a, const cvc
     int rc = validate(*loop_a, true);
     if (!rc) rc = validate(*loop_c, true);
     if (rc) return rc;
-    if (loop_a->B + loop_c->B > 64 || loop_a->T != loop_c->T || loop_a->R != loop_c->R || loop_a->w_ih_att != loop_c->w_ih_att ||
+    if (loop_a->B + loop_c->B > 128 || (loop_a->B + loop_c->B > 64 && cvc_gemm_packed_split(-1) == 0) || loop_a->T != loop_c->T || loop_a->R != loop_c->R || loop_a->w_ih_att != loop_c->w_ih_att ||
         loop_a->w_hh_att != loop_c->w_hh_att || loop_a->w_ih_lang != loop_c->w_ih_lang || loop_a->w_hh_lang != loop_c->w_hh_lang)
         return CVC_E_BADARG;
     return run_bwd(loop_a, loop_c, (hipStream_t)stream, nullptr);

@@ -31,6 +31,7 @@ from . import hip
 ENABLED = os.environ.get("CVC_TRAIN_LOOPS", "1") != "0"        # False: the per-step autograd path (A/B switch)
 PACKED_H2ATTN = os.environ.get("CVC_TRAIN_PACKED_H2ATTN", "1") != "0"   # False: h2attn of loop A on the row-major ring kernel (A/B)
 JOINT_BWD = os.environ.get("CVC_TRAIN_JOINT_BWD", "1") != "0"   # False: the two loops' back-propagation as two passes even when 2B <= 64 (A/B)
+JOINT_BWD_128 = os.environ.get("CVC_TRAIN_JOINT_BWD_128", "1") != "0"   # False: no joint pass for 64 < 2B <= 128 (A/B)
 
 Tensor = torch.Tensor
 
@@ -60,9 +61,11 @@ class LoopArena:
         self.a_feat_grads = None
 
     def joint_ok(self) -> bool:
-        """Both loops' rows fit ONE 64-row operand: their back-propagation through time runs as one pass (cvc_train_loops_bwd_joint),
-        every backward-data product streaming the shared LSTM weights once for both."""
-        return bool(JOINT_BWD and self.nslots == 2 and 2 * self.B <= 64 and self.loop_a is not None and torch.is_grad_enabled())
+        """Both loops' back-propagation through time runs as one pass (cvc_train_loops_bwd_joint), every backward-data product streaming
+        the shared LSTM weights once for both: their rows as ONE 64-row operand (2 B <= 64: config 4's share) or as two 64-row operand
+        groups on the 128-row form of the product (config 3: B = 64; split-product arithmetic only)."""
+        fits = 2 * self.B <= 64 or (JOINT_BWD_128 and hip.gemm_packed_split(-1) != 0)
+        return bool(JOINT_BWD and fits and self.nslots == 2 and self.loop_a is not None and torch.is_grad_enabled())
 
     def rows(self, slot: int) -> slice:
         n = self.T * self.B

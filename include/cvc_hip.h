@@ -737,10 +737,11 @@ typedef struct cvc_train_loop {
 CVC_API long long cvc_train_loop_bwd_ws(int B, int R, int A);
 CVC_API int cvc_train_loop_fwd(const cvc_train_loop* loop, cvc_stream_t stream);
 CVC_API int cvc_train_loop_bwd(const cvc_train_loop* loop, cvc_stream_t stream);
-/* Back-propagation through BOTH loops in one pass (loop_a->B + loop_c->B <= 64, same T and R -- the 32-clip shares of the 8-GPU
- * job): the two loops share the LSTM cells, so at every step their gate gradients form ONE operand (loop A's rows first) and every
- * backward-data product streams its weights once for both -- 3 products per step instead of 5.  Same results as the two separate
- * calls (bwd_ws of loop_a is used). */
+/* Back-propagation through BOTH loops in one pass (same T and R): the two loops share the LSTM cells, so at every step every
+ * backward-data product takes both loops' gate gradients and streams its weights once -- 3 products per step instead of 5.
+ * loop_a->B + loop_c->B <= 64 (the 32-clip shares of the 8-GPU job): ONE 64-row operand, loop A's rows first.  Up to 64 + 64 rows
+ * (config 3): two 64-row operand groups on the 128-row form of the product (split-product arithmetic only).  Same results as the two
+ * separate calls under the same K split (bwd_ws: cvc_train_loop_bwd_ws(loop_a->B + loop_c->B, R, A) floats, the one of loop_a is used). */
 CVC_API int cvc_train_loops_bwd_joint(const cvc_train_loop* loop_a, const cvc_train_loop* loop_c, cvc_stream_t stream);
 /* Measurement aid (bench.py --mode train; never enabled by the product path): HIP-event pairs around every entry point the two
  * drivers call, on the launch stream.  cvc_train_loop_profile(n > 0) starts recording with room for n launches, (0) stops and

@@ -76,6 +76,12 @@ int cvc_pack_lstm_weights(const float* w_ih, int K_ih, const float* w_hh, int K_
                           cvc_stream_t stream);
 int cvc_linear_nn_planes_fwd(const float* dy_q, int K, int M, const cvc_nn_seg* segs, int nsegs, int ksplit,
                              float* workspace, cvc_stream_t stream);
+/* cvc_linear_nn_planes_fwd for TWO 64-row operand groups against one stream of the weights (the two loops of the cyclical pass at
+ * B = 64 each share the LSTM cells, captioner.py:86-87): rows 0 .. M - 1 from dy_q, rows 64 .. 64 + M2 - 1 from dy_q2; planes are
+ * [ksplit][128][ntot]; with reduce != 0 (or ksplit == 1) the result goes to the segments' dst [128 rows, ld_dst].  Under the same K
+ * split a row gets the bits cvc_linear_nn_planes_fwd gives it. */
+int cvc_linear_nn_planes2_fwd(const float* dy_q, const float* dy_q2, int K, int M, int M2, const cvc_nn_seg* segs, int nsegs,
+                              int ksplit, float* workspace, int reduce, cvc_stream_t stream);
 int cvc_beam_select_parts(const float* parts, int nparts, long long part_stride, const float* bias,
                           const float* score_in, const uint8_t* done_in, int B, int beam, int V, int unk_idx,
                           int first_step, int64_t* parent, int64_t* word, float* score_out, uint8_t* done_out,

@@ -118,7 +118,9 @@ def test_train_loop_rejects_incomplete_descriptors():
     d = hip.TrainLoop()
     assert lib.cvc_train_loop_fwd(ctypes.byref(d), None) == -1 and lib.cvc_train_loop_bwd(ctypes.byref(d), None) == -1
     assert lib.cvc_train_loop_fwd(None, None) == -1
-    assert lib.cvc_train_loop_bwd_ws(64, 2048, 1024) > 0 and lib.cvc_train_loop_bwd_ws(65, 2048, 1024) == 0
+    assert lib.cvc_train_loop_bwd_ws(64, 2048, 1024) > 0 and lib.cvc_train_loop_bwd_ws(129, 2048, 1024) == 0
+    # (65 .. 128 rows: the joint pass of two loops on the 128-row form of the backward-data product -- twice the rows, twice the planes)
+    assert lib.cvc_train_loop_bwd_ws(128, 2048, 1024) > 1.9 * lib.cvc_train_loop_bwd_ws(64, 2048, 1024)
     # the joint back-propagation: both descriptors, loop A first, rows fitting one 64-row operand
     assert lib.cvc_train_loops_bwd_joint(None, None, None) == -1
     a, c = hip.TrainLoop(), hip.TrainLoop()

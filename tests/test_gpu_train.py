@@ -658,17 +658,19 @@ def test_clip_adam_equals_clip_grad_norm_plus_torch_adam(weight_decay, max_norm)
         assert torch.allclose(q, p, rtol=2e-6, atol=2e-7) and torch.equal(q.grad, p.grad)
 
 
-@pytest.mark.parametrize("cfg,B,train", [("tiny", None, False), ("tiny", None, True), ("cfg1", 5, True)])
+@pytest.mark.parametrize("cfg,B,train", [("tiny", None, False), ("tiny", None, True), ("cfg1", 5, True), ("tiny", 64, True),
+                                         ("tiny", 40, False), ("tiny", 33, True)])
 def test_joint_backward_of_both_loops_equals_the_two_passes(cfg, B, train):
-    """cvc_train_loops_bwd_joint (both loops' rows in one 64-row operand, 2B <= 64: 3 backward-data products per step instead of 5,
-    loop A's outputs passed through loop C's graph node) against cvc_train_loop_bwd twice: same kernels row for row at these
-    sizes, so the five losses and every parameter gradient must be bit-identical (all four loss terms weighted)."""
+    """cvc_train_loops_bwd_joint (3 backward-data products per step instead of 5, loop A's outputs passed through loop C's graph
+    node) against cvc_train_loop_bwd twice -- both loops' rows in one 64-row operand (2B <= 64), or as two 64-row operand groups on
+    the 128-row form of the product (B = 33, 40, 64: config 3's case): same kernels row for row under the same K split (which these
+    sizes have), so the five losses and every parameter gradient must be bit-identical (all four loss terms weighted)."""
     import dataclasses
     from helpers import build_model, to_dev, model_call
     from cvc import train_loops, dropout
     dev = torch.device("cuda:0")
     d = synth.CONFIGS[cfg] if B is None else dataclasses.replace(synth.CONFIGS[cfg], B=B)
-    assert 2 * d.B <= 64
+    assert 2 * d.B <= 128
     model = build_model(d, synth.hot_path_state_dict(d, 7), dev)
     if train:
         model.train()
@@ -758,3 +760,60 @@ def test_trainer_train_replays_one_graph_per_bucketed_shape_bit_equal_to_eager(c
     assert [strip(x) for x in shown[0]] == [strip(x) for x in shown[1]], (shown[0], shown[1])
     for k in finals[0]:
         assert torch.equal(finals[0][k], finals[1][k]), k
+
+
+@pytest.mark.parametrize("K,widths,MA,MC,ksplit", [(8192, (2048, 2048, 2048), 64, 64, 5), (8192, (2048, 2048), 64, 64, 8),
+                                                  (4096, (1024, 512, 132), 33, 64, 3), (264, (128, 36), 64, 40, 1),
+                                                  (1000, (260,), 7, 1, 4), (128, (32, 32, 32), 64, 64, 1)])
+def test_backward_data_product_128_rows_equals_two_64_row_products(K, widths, MA, MC, ksplit):
+    """cvc_linear_nn_planes2_fwd (two 64-row operand groups against ONE stream of the weights: what lets the two loops of the
+    cyclical pass share a backward-data product at B = 64 each) against cvc_linear_nn_fwd on each group alone under the same K
+    split: the same bits for every row, through the plane output (+ the consumer-side plane sum), the reduce form and ksplit = 1;
+    odd numbers of 8-row groups per wave (fp32-MFMA tail), a ragged last column slab, single rows."""
+    import ctypes as C
+    from cvc import hip
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(K + MA)
+    ntot_cols = sum(widths)
+    W = (torch.randn(K, ntot_cols + 8, generator=g) * 0.05).to(dev)
+    dA, dC = (torch.randn(MA, K, generator=g)).to(dev), (torch.randn(MC, K, generator=g)).to(dev)
+    qA, qC = hip.pack_quad(dA), hip.pack_quad(dC)
+    ranges, c0 = [], 0
+    for n in widths:
+        ranges.append((W, c0, n))
+        c0 += n
+    want_a = hip.linear_nn(qA, MA, K, ranges, ksplit=ksplit)
+    want_c = hip.linear_nn(qC, MC, K, ranges, ksplit=ksplit)
+    # fp64 sanity of the reference itself
+    ref = (dA.double() @ W.double()[:, :widths[0]]).float()
+    assert float((want_a[0] - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-5
+    L = hip.lib()
+    slabs = sum((n + 127) // 128 for n in widths)
+    ntot = slabs * 128
+    for reduce in (1, 0):
+        arr = (hip.NNSeg * len(widths))()
+        outs = []
+        for i, (w, c, n) in enumerate(ranges):
+            o = torch.full((128, n), float("nan"), device=dev)
+            arr[i] = hip.NNSeg(w.data_ptr() + 4 * c, o.data_ptr(), w.stride(0), n, n)
+            outs.append(o)
+        ws = torch.full((max(ksplit, 1) * 128 * ntot,), float("nan"), device=dev)
+        hip._check(L.cvc_linear_nn_planes2_fwd(qA.data_ptr(), qC.data_ptr(), K, MA, MC, arr, len(widths), ksplit, ws.data_ptr(), reduce,
+                                               hip._stream()), "cvc_linear_nn_planes2_fwd")
+        torch.cuda.synchronize()
+        if reduce or ksplit == 1:
+            got = outs
+        else:
+            # the planes, summed in plane order as the consumers do (cvc_grad_src)
+            planes = ws.view(ksplit, 128, ntot)
+            got, s0 = [], 0
+            for n in widths:
+                acc = planes[0, :, s0:s0 + n].clone()
+                for k in range(1, ksplit):
+                    acc += planes[k, :, s0:s0 + n]
+                got.append(acc)
+                s0 += (n + 127) // 128 * 128
+        for o, wa, wc in zip(got, want_a, want_c):
+            assert torch.equal(o[:MA], wa) and torch.equal(o[64:64 + MC], wc)
+            if reduce or ksplit == 1:      # rows nobody owns are not written
+                assert bool(torch.isnan(o[MA:64]).all()) and bool(torch.isnan(o[64 + MC:]).all())
