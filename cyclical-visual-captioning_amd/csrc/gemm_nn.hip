@@ -243,6 +243,9 @@ __global__ __launch_bounds__(256, CVC_NN_WGS) void skinny_gemm_nn_kernel(NNArgs 
 #ifndef CVC_NNS_DEPTH
 #define CVC_NNS_DEPTH 4
 #endif
+#ifndef CVC_NNS_SCHED
+#define CVC_NNS_SCHED 1
+#endif
 
 template <int MT>
 struct NNFrag2 {
@@ -307,9 +310,8 @@ __global__ __launch_bounds__(256, 1) void skinny_gemm_nn_split_kernel(NNArgs a) 
         Split3 X[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) X[mt] = split8(f.x[mt][0], f.x[mt][1]);
-        // The split of column tile c + 1's weights (36 VALU instructions) is issued between the 24 MFMAs of column tile c: a wave
-        // issues in order, and an MFMA that finds the matrix pipe busy (32 cycles per MFMA) holds back everything behind it -- VALU
-        // work placed between two MFMAs runs in the shadow of the first.
+        // the split of column tile c + 1's weights is issued between the MFMAs of column tile c (a wave issues in order: VALU work
+        // behind an MFMA that waits for the matrix pipe waits with it; between two MFMAs it runs in the first one's shadow)
         auto wsplit = [&](int c) __attribute__((always_inline)) {
             const f32x4 wa = {f.w[0][c], f.w[1][c], f.w[2][c], f.w[3][c]};
             const f32x4 wb = {f.w[4][c], f.w[5][c], f.w[6][c], f.w[7][c]};
@@ -319,29 +321,25 @@ __global__ __launch_bounds__(256, 1) void skinny_gemm_nn_split_kernel(NNArgs a) 
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const Split3 W = Wn;
-#if CVC_NN128_SCHED
+#if CVC_NNS_SCHED
             __builtin_amdgcn_sched_barrier(0);
 #endif
             if (c < 3) Wn = wsplit(c + 1);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-#if defined(CVC_NN128_ABL) && CVC_NN128_ABL == 1          // ablation: no MFMAs (memory + split work only)
-                asm volatile("" ::"v"(W.hi), "v"(W.mid), "v"(W.lo), "v"(X[mt].hi), "v"(X[mt].mid), "v"(X[mt].lo));
-#else
                 acc[c][mt] = mfma_bf16(W.mid, X[mt].mid, acc[c][mt]);
                 acc[c][mt] = mfma_bf16(W.lo, X[mt].hi, acc[c][mt]);
                 acc[c][mt] = mfma_bf16(W.hi, X[mt].lo, acc[c][mt]);
                 acc[c][mt] = mfma_bf16(W.mid, X[mt].hi, acc[c][mt]);
                 acc[c][mt] = mfma_bf16(W.hi, X[mt].mid, acc[c][mt]);
                 acc[c][mt] = mfma_bf16(W.hi, X[mt].hi, acc[c][mt]);
-#endif
             }
-#if CVC_NN128_SCHED && !(defined(CVC_NN128_ABL) && CVC_NN128_ABL == 1)
+#if CVC_NNS_SCHED
             if (c < 3) {
 #pragma unroll
-                for (int k = 0; k < 24; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // two VALU instructions of the next tile's split
+                for (int k = 0; k < 6 * MT; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, MT == 1 ? 6 : 3, 0);   // its share of the next tile's split
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
