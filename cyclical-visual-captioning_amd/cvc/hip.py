@@ -343,12 +343,17 @@ _HOST_ONLY = {"cvc_tile_rows_alloc", "cvc_col_sum_ws", "cvc_train_loop_bwd_ws", 
               "cvc_train_loop_profile", "cvc_train_loop_profile_read", "cvc_comm_unique_id", "cvc_comm_init", "cvc_comm_destroy"}
 
 
+TIMED_SHAPES: dict = {}      # enable_timers(): entry point -> [(K, M, N)] of its launches (cvc_tile_gemm: the dense products' work)
+
+
 def enable_timers() -> dict:
     """Bracket every C-ABI launch with a HIP-event pair on the launch stream (torch's current stream, which is the stream
-    handed to the entry point).  Returns the dict that fills up: entry-point name -> [(start_event, end_event)].
+    handed to the entry point).  Returns the dict that fills up: entry-point name -> [(start_event, end_event)]; the (K, M, N) of
+    every cvc_tile_gemm launch go to TIMED_SHAPES (what bench.py prices the dense products' roofline with).
     Measurement aid for bench.py (--mode train); the product path never enables it."""
     l = lib()
     timers: dict = {}
+    TIMED_SHAPES.clear()
     if _raw_fns:
         disable_timers()
     for name in SIGNATURES:
@@ -363,6 +368,8 @@ def enable_timers() -> dict:
             rc = _raw(*args)
             e1.record()
             timers.setdefault(_name, []).append((e0, e1))
+            if _name == "cvc_tile_gemm":      # (wb, xb, x_mblk_stride, K, M, N, ksplit, ...)
+                TIMED_SHAPES.setdefault(_name, []).append((int(args[3]), int(args[4]), int(args[5]), int(args[6])))
             return rc
         setattr(l, name, timed)
     return timers

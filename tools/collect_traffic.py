@@ -37,6 +37,25 @@ def roles_for(mode, beam, T, B=64):
             "cvc_tile_gemm": (r"tile_gemm_ld2?_kernel", 1, {0}),
             "cvc_tile_pack_rows_any": (r"tile_pack_rows_(any|blk)_kernel", 1, {0}),
         }
+    if mode == "train" and 64 < 2 * B <= 128:
+        # joint backward of both loops on the 128-row form of the backward-data product (two 64-row operand groups): per step the
+        # language product and the attention product (missing at t = 0) on skinny_gemm_nn_split128_kernel, h2attn on the 64-row kernel
+        lstm = r"skinny_gemm_packed_kernelILi\dELb1E"
+        nn2 = r"skinny_gemm_nn_split128_kernel"
+        pa = 2 * T - 1
+        return {
+            "loopA.fwd.att_cell": (lstm, 4 * T, {j for j in range(2 * T) if j % 2 == 0}),
+            "loopA.fwd.lang_cell": (lstm, 4 * T, {j for j in range(2 * T) if j % 2 == 1}),
+            "loopC.fwd.att_cell": (lstm, 4 * T, {2 * T + j for j in range(2 * T) if j % 2 == 0}),
+            "loopC.fwd.lang_cell": (lstm, 4 * T, {2 * T + j for j in range(2 * T) if j % 2 == 1}),
+            "loops.bwd.nn_lang": (nn2, pa, {j for j in range(pa) if j % 2 == 0}),
+            "loops.bwd.nn_att": (nn2, pa, {j for j in range(pa) if j % 2 == 1}),
+            "loopA.bwd.nn_h2attn": (r"skinny_gemm_nn_split_kernel", 1, {0}),
+            "loopA.fwd.attn_scores": (r"attn_scores_kernelILi0ELi\d+ELi1E", 1, {0}),
+            "loopA.fwd.attn_wsum": (r"attn_wsum_kernelE", 1, {0}),
+            "loopA.bwd.attn_bwd": [(r"attn_scores_kernelILi1ELi\d+ELi1E", 1, {0}), (r"softmax_bwd2_kernel", 1, {0}), (r"attn_score_bwd2", 1, {0})],
+            "cvc_tile_gemm": (r"tile_gemm_ld2?_kernel", 1, {0}),
+        }
     if mode == "train" and 2 * B <= 64:
         # joint backward of both loops (cvc_train_loops_bwd_joint): T x (language product, h2attn product, attention product), the
         # last one missing at t = 0

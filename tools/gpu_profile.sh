@@ -2,8 +2,8 @@
 #   PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, --kernel-trace only) of EVERY benched workload -> profiles/traffic/*.json
 #   (tools/collect_traffic.py), the matrix-pipe-busy counters, bench lines, rocprofv3 kernel-trace summaries of the same commands,
 #   the decode-step timeline.
-#   usage (GPU box): bash tools/gpu_profile.sh r04 [pmc|bench|all]
-TAG=${1:-r04}
+#   usage (GPU box): bash tools/gpu_profile.sh r05 [pmc|bench|all]
+TAG=${1:-r05}
 WHAT=${2:-all}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -26,9 +26,18 @@ if [ "$WHAT" = "pmc" ] || [ "$WHAT" = "all" ]; then
   pmc_pair cfg3_train cfg3 1 train --mode train --config cfg3 --steps 2 --warmup 1 --no-cpu-baseline --no-train-graph
   pmc_pair cfg4_train cfg4 1 train --mode train --config cfg4 --steps 2 --warmup 1 --no-cpu-baseline --no-train-graph
   pmc_pair cfg2_encoder cfg2 1 encoder --mode encoder --steps 2 --warmup 1 --encoder-forward-only
-  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_m -o m -- python3 $R/bench.py --no-graph --steps 4 --warmup 1 --no-cpu-baseline --no-secondary > $O/pmc_mfma.log 2>&1
-  python3 $R/tools/rocpd_pmc.py $(find $O/pmc_m -name "*.db" | head -1) > $O/${TAG}_pmc_mfma_busy.md 2>&1
-  rm -rf $O/pmc_m
+  # matrix-pipe busy per launch role (tools/rocpd_mfma_busy.py): greedy decode, beam decode, the training step
+  rm -f $O/${TAG}_pmc_mfma_busy.md
+  mfma_pass() {   # config, beam, mode, bench args...
+    local cfg=$1 beam=$2 mode=$3; shift 3
+    rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $O/pmc_m -o m -- python3 $R/bench.py "$@" > $O/pmc_mfma_${cfg}_${mode}_b${beam}.log 2>&1
+    python3 $R/tools/rocpd_mfma_busy.py $(find $O/pmc_m -name "*.db" | head -1) --config $cfg --beam $beam --mode $mode >> $O/${TAG}_pmc_mfma_busy.md 2>&1
+    echo >> $O/${TAG}_pmc_mfma_busy.md
+    rm -rf $O/pmc_m
+  }
+  mfma_pass cfg2 1 decode --no-graph --steps 4 --warmup 1 --no-cpu-baseline --no-secondary
+  mfma_pass cfg3 5 decode --config cfg3 --beam 5 --no-graph --steps 3 --warmup 1 --no-cpu-baseline
+  mfma_pass cfg3 1 train --mode train --config cfg3 --steps 2 --warmup 1 --no-cpu-baseline --no-train-graph
   cat $O/${TAG}_pmc_traffic.md
   # the per-workload traffic files travel back through gpurun_out/ (copy them into profiles/traffic/ and commit)
   rm -rf $O/traffic; cp -r $R/profiles/traffic $O/traffic
@@ -62,7 +71,9 @@ if [ "$WHAT" = "bench" ] || [ "$WHAT" = "all" ]; then
   rm -rf $O/kt
   # the N-rank entry path at N = 1 (bench.py starts its rank processes itself): decode line and config 4's per-GPU training step
   python3 $R/bench.py --gpus 1 --spawn --steps 20 --warmup 5 --no-secondary > $O/bench_${TAG}_spawn1_greedy.json 2> $O/bench_spawn.err
+  # (the N-rank path runs the gradient exchange whatever N is: here the per-bucket RS + AG on a ONE-rank RCCL communicator, inside the captured step)
   python3 $R/bench.py --gpus 1 --spawn --mode train --config cfg4 --steps 30 --warmup 3 --no-cpu-baseline > $O/bench_${TAG}_spawn1_train_cfg4.json 2>> $O/bench_spawn.err
+  python3 $R/bench.py --mode train --config cfg4 --always-exchange --steps 30 --warmup 3 --no-cpu-baseline > $O/bench_${TAG}_train_cfg4_exchange.json 2>> $O/bench_train.err
   head -c 600 $O/bench_${TAG}_greedy.json; echo
   for f in beam5 cfg5_greedy cfg5_beam5 train train_cfg4; do python3 -c "
 import json,sys
