@@ -295,6 +295,7 @@ extern "C" int cvc_attn_scores_qparts(int kind, const float* q_parts, int q_npar
     return run_scores(kind, q_parts, w_a, b_a, inv_temp, sets, nsets, nclip, nq, A, (hipStream_t)stream, q_nparts, q_bias);
 }
 
+#ifdef CVC_EXPERIMENTAL
 extern "C" int cvc_attn_scores_qslab(int kind, const cvc_gsk_segs* q, const float* q_bias, const float* w_a, const float* b_a,
                                      float inv_temp, const cvc_attn_set* sets, int nsets, int nclip, int nq, int A,
                                      cvc_stream_t stream) {
@@ -307,6 +308,7 @@ extern "C" int cvc_attn_scores_qslab(int kind, const cvc_gsk_segs* q, const floa
     if (kind != CVC_ATTN_ADDITIVE && kind != CVC_ATTN_DOT) return CVC_E_BADARG;
     return run_scores(kind, q->slab, w_a, b_a, inv_temp, sets, nsets, nclip, nq, A, (hipStream_t)stream, 1, q_bias, q);
 }
+#endif
 
 static int wsum_impl(const cvc_attn_set* sets, int nsets, int nclip, int nq, int R, float* ctx_sum, int ctx_quad,
                      cvc_stream_t stream, long long frag_stride = 0, float* ctx_sum_rm = nullptr, float raw_scale = 0.f);

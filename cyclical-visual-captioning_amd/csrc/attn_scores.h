@@ -2,7 +2,9 @@
 // the same streaming dot product) and the grounder (captioner.py:154-158).  See attn_fwd.hip.
 #pragma once
 #include "cvc_common.h"
-#include "gsk.h"
+#ifdef CVC_EXPERIMENTAL
+#include "gsk.h"          // the stream-K query form (cvc_attn_scores_qslab) exists in experimental builds only
+#endif
 #include <type_traits>
 
 namespace {
@@ -26,8 +28,10 @@ struct ScoreArgs {
     float inv_temp;
     int nq, A;                     // nq = queries handled by this launch
     int nq_total, q0;              // row = clip * nq_total + q0 + qi
+#ifdef CVC_EXPERIMENTAL
     int q_from_slab;               // the query is the sum of a stream-K group's partial tiles (gsk.h) instead of q / q_nparts
     GskSegs q_slab;
+#endif
 };
 
 // QG = queries per group: the group's accumulators are independent chains for the VALU and its LDS reads / wave reductions are
@@ -57,6 +61,7 @@ __global__ __launch_bounds__(SCORE_WG) void attn_scores_kernel(ScoreArgs a) {
 
     for (int i = tid * 4; i < nq_pad * A; i += SCORE_WG * 4) {
         f32x4 v = {0, 0, 0, 0};
+#ifdef CVC_EXPERIMENTAL
         if (i < nq * A && a.q_from_slab) {
             // column block col / 32 of the h2attn group: tile = blk / 8, its segments summed in order; row = the query's batch row
             const int col = i % A, row = clip * a.nq_total + a.q0 + i / A, blk = col >> 5;
@@ -65,7 +70,9 @@ __global__ __launch_bounds__(SCORE_WG) void attn_scores_kernel(ScoreArgs a) {
             v = ld4(src);
             for (int p = 1; p < nseg; ++p) v += ld4(src + (size_t)p * (8 * 2048));
             if (a.q_bias != nullptr) v += ld4(a.q_bias + col);
-        } else if (i < nq * A) {
+        } else
+#endif
+        if (i < nq * A) {
             const float* src = a.q + ((size_t)clip * a.nq_total + a.q0 + i / A) * a.q_ld + i % A;
             v = ld4(src);
             for (int p = 1; p < a.q_nparts; ++p) v += ld4(src + (size_t)p * a.q_part_stride);
@@ -224,7 +231,7 @@ int launch_scores(const ScoreArgs& a, dim3 grid, size_t lds, hipStream_t st) {
 // a clip (plus alpha_net's weight) fit 64 KB of LDS.
 inline int run_scores(int kind, const float* q, const float* w_a, const float* b_a, float inv_temp,
                       const cvc_attn_set* sets, int nsets, int nclip, int nq, int A, hipStream_t st,
-                      int q_nparts = 1, const float* q_bias = nullptr, const GskSegs* q_slab = nullptr, long long q_ld = 0,
+                      int q_nparts = 1, const float* q_bias = nullptr, const void* q_slab = nullptr, long long q_ld = 0,
                       long long q_part_stride = 0) {
     int q_per_launch = (int)((64 * 1024) / ((size_t)A * 4)) - 1;
     if (q_per_launch < 1) return CVC_E_TOOBIG;
@@ -242,8 +249,12 @@ inline int run_scores(int kind, const float* q, const float* w_a, const float* b
     sa.q_nparts = q_nparts < 1 ? 1 : q_nparts; sa.q_bias = q_bias;
     sa.q_ld = q_ld > 0 ? q_ld : A;
     sa.q_part_stride = q_part_stride > 0 ? q_part_stride : (long long)nclip * nq * A;
+#ifdef CVC_EXPERIMENTAL
     sa.q_from_slab = q_slab != nullptr;
-    sa.q_slab = q_slab != nullptr ? *q_slab : GskSegs{};
+    sa.q_slab = q_slab != nullptr ? *static_cast<const GskSegs*>(q_slab) : GskSegs{};
+#else
+    if (q_slab != nullptr) return CVC_E_BADARG;
+#endif
     dim3 g1(sa.chunks0 + chunks1, nclip);
     for (int q0 = 0; q0 < nq; q0 += q_per_launch) {
         sa.q0 = q0;

@@ -481,7 +481,8 @@ __global__ __launch_bounds__(256, 1) void skinny_gemm_nn_split128_kernel(NNArgs 
                     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                                  :
                                  : "v"(xs[g] + h * XSTEP + q * 256), "s"(dst + ((h * 2 + q) * 2 + g) * 1024)
-                                 : "m0", "memory");
+                                 : "memory");      // (writes m0: nothing else in this kernel reads it -- LDS accesses need no
+                                                   // m0 on gfx9+, and hipcc sets m0 itself right before any use of its own)
         xs[0] += 2 * XSTEP;
         xs[1] += 2 * XSTEP;
 #pragma unroll

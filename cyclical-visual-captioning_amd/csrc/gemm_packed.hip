@@ -54,6 +54,8 @@ struct PackedArgs {
     long long gru_gi_ld;
     float* gru_y[2];          // this step's output rows of direction d: row m at + m * gru_y_ld, H columns
     long long gru_y_ld;
+    float* gru_gates[2];      // training form (nullable): (r, z, n, W_hn h + b_hn) of this step, row m at + m * gru_g_ld, columns [4][H]
+    long long gru_g_ld;
     // embedding-gate table (cvc_packed_lstm_embgate_fwd): the embedded word's share of the gates is a row gather, not a GEMM
     const float* emb_gate;    // [V][4R] = relu(Emb[v]) x W_ih[:, emb columns]^T, checkpoint gate order (gate * R + unit), or null
     const int64_t* word;      // [M] the word of every batch row
@@ -419,7 +421,7 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
 
     if constexpr (GRU) {
         if (ework) {
-            f32x4 hv;
+            f32x4 hv, gr, gz, gn, gh;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int jj = eqd * 4 + e;
@@ -427,11 +429,18 @@ __global__ __launch_bounds__(NW * 64) void skinny_gemm_packed_kernel(PackedArgs 
 #pragma unroll
                 for (int g = 0; g < 3; ++g) pre[g] = sum_partials<NWK>(ered, g * 8 + jj, LDM, em);
                 const float rg = fast_sigmoid(pre[0] + eadd[0][e]), zg = fast_sigmoid(pre[1] + eadd[1][e]);
-                const float ng = fast_tanh(eadd[2][e] + rg * (pre[2] + eadd[3][e]));
+                const float hn = pre[2] + eadd[3][e];
+                const float ng = fast_tanh(eadd[2][e] + rg * hn);
                 hv[e] = ng + zg * (ecp[e] - ng);                       // (1 - z) n + z h
+                gr[e] = rg; gz[e] = zg; gn[e] = ng; gh[e] = hn;
             }
             st4(a.h_dst1_q + eqoff, hv);
             st4((blockIdx.y == 0 ? a.gru_y[0] : a.gru_y[1]) + (size_t)em * a.gru_y_ld + ejq, hv);
+            float* gp = blockIdx.y == 0 ? a.gru_gates[0] : a.gru_gates[1];
+            if (gp != nullptr) {          // what autograd keeps of the step (cvc_gru_seq_train_fwd)
+                gp += (size_t)em * a.gru_g_ld + ejq;
+                st4(gp, gr); st4(gp + a.R, gz); st4(gp + 2 * a.R, gn); st4(gp + 3 * a.R, gh);
+            }
         }
     } else if (LSTM) {
         // unit u -> (batch row m fastest, quad-of-hidden qd in 0..1): a thread finishes 4 hidden units
@@ -784,9 +793,29 @@ __global__ __launch_bounds__(256) void zero_kernel(float* p, long long n) {
 }
 }  // namespace
 
+static int gru_seq_impl(const float* wp, const float* gi, long long gi_ld_m, long long gi_ld_t, const float* b_ih, const float* b_hh, int M,
+                        int F, int H, int ndir, float* hq, float* y, long long y_ld_m, long long y_ld_t, float* gates, long long g_ld_m,
+                        long long g_ld_t, cvc_stream_t stream);
+
 extern "C" int cvc_gru_seq_fwd(const float* wp, const float* gi, long long gi_ld_m, long long gi_ld_t, const float* b_ih,
                                const float* b_hh, int M, int F, int H, int ndir, float* hq, float* y, long long y_ld_m,
                                long long y_ld_t, cvc_stream_t stream) {
+    return gru_seq_impl(wp, gi, gi_ld_m, gi_ld_t, b_ih, b_hh, M, F, H, ndir, hq, y, y_ld_m, y_ld_t, nullptr, 0, 0, stream);
+}
+
+// Training form of the per-step recurrence (any H % 8 == 0 -- config 5's encoder width H = 2048 is beyond what the persistent
+// form keeps in registers): additionally writes (r, z, n, W_hn h + b_hn) of every step and direction, as
+// cvc_gru_seq_persistent_train_fwd does.
+extern "C" int cvc_gru_seq_train_fwd(const float* wp, const float* gi, long long gi_ld_m, long long gi_ld_t, const float* b_ih,
+                                     const float* b_hh, int M, int F, int H, int ndir, float* hq, float* y, long long y_ld_m,
+                                     long long y_ld_t, float* gates, long long g_ld_m, long long g_ld_t, cvc_stream_t stream) {
+    if (!gates || (g_ld_m & 3) || (g_ld_t & 3)) return CVC_E_BADARG;
+    return gru_seq_impl(wp, gi, gi_ld_m, gi_ld_t, b_ih, b_hh, M, F, H, ndir, hq, y, y_ld_m, y_ld_t, gates, g_ld_m, g_ld_t, stream);
+}
+
+static int gru_seq_impl(const float* wp, const float* gi, long long gi_ld_m, long long gi_ld_t, const float* b_ih, const float* b_hh, int M,
+                        int F, int H, int ndir, float* hq, float* y, long long y_ld_m, long long y_ld_t, float* gates, long long g_ld_m,
+                        long long g_ld_t, cvc_stream_t stream) {
     if (!wp || !gi || !b_ih || !b_hh || !hq || !y || M < 1 || M > 64 || F < 1 || H < 8 || (H & 7) || ndir < 1 || ndir > 2 ||
         (gi_ld_m & 3) || (gi_ld_t & 3) || (y_ld_m & 3) || (y_ld_t & 3))
         return CVC_E_BADARG;
@@ -798,7 +827,7 @@ extern "C" int cvc_gru_seq_fwd(const float* wp, const float* gi, long long gi_ld
     PackedArgs a{};
     a.nquad = Kp / 4; a.M = M; a.Nout = 4 * H; a.R = H; a.bias = b_ih; a.bias2 = b_hh; a.ksplit = 1;
     a.wp = wp; a.gru_w_stride = (long long)(H / 8) * (Kp / 4) * 128; a.gru_h_stride = hsz;
-    a.gru_gi_ld = gi_ld_m; a.gru_y_ld = y_ld_m;
+    a.gru_gi_ld = gi_ld_m; a.gru_y_ld = y_ld_m; a.gru_g_ld = g_ld_m;
     a.wstride = (long long)a.nquad * 128;
     const dim3 grid(H / 8, ndir);
     for (int s = 0; s < F; ++s) {
@@ -808,6 +837,7 @@ extern "C" int cvc_gru_seq_fwd(const float* wp, const float* gi, long long gi_ld
             const long long t = d == 0 ? s : F - 1 - s;
             a.gru_gi[d] = gi + t * gi_ld_t + (long long)d * 3 * H;
             a.gru_y[d] = y + t * y_ld_t + (long long)d * H;
+            a.gru_gates[d] = gates ? gates + t * g_ld_t + (long long)d * 4 * H : nullptr;
         }
         if (cvc_gemm_split_mode == 2) {
             if (M <= 32) hipLaunchKernelGGL((skinny_gemm_packed_kernel<1, true, CVC_PACKED_DEPTH8, true, 8, true>), grid, dim3(512), 0, st, a);

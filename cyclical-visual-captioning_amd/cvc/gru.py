@@ -10,10 +10,12 @@ config 2).  Here a layer is
      - per step (cvc_gru_seq_fwd, csrc/gemm_packed.hip): F launches of the packed gate-GEMM kernel in its GRU form, W_hh of
        both directions (25 MB at H = 1024) re-read from the Infinity Cache every step -- any H % 8 == 0, and the fallback
        when the persistent form cannot run or reports a barrier time-out.
-`gru_forward` is the inference path (no autograd).  `gru_forward_train` is the same recurrence under autograd (persistent form
-only: H % 128 == 0, H <= 1024): the forward additionally keeps every step's gates, the backward walks the sequence backwards
-on cvc_gru_seq_bwd (gate arithmetic + dgh W_hh per step on the LSTM cells' backward-data kernel) and takes dW_ih, dW_hh, dX and
-the biases from dense products over all steps on the tile GEMM; inter-layer dropout stays a torch op between the layers."""
+`gru_forward` is the inference path (no autograd).  `gru_forward_train` is the same recurrence under autograd: the forward
+additionally keeps every step's gates -- persistent form for H % 128 == 0, H <= 1024, else the per-step training form
+(cvc_gru_seq_train_fwd, any H % 8 == 0: config 5's width, rnn_size 4096 -> H = 2048, is beyond what 256 CUs keep in registers:
+W_hh of both directions is 151 MB as split bf16 terms against 128 MB of vector registers on the chip) -- the backward walks the
+sequence backwards (persistent for H % 256 == 0, H <= 1024, else cvc_gru_seq_bwd: gate arithmetic + dgh W_hh per step on the LSTM
+cells' backward-data kernel) and takes dW_ih, dW_hh, dX and the biases from dense products over all steps on the tile GEMM."""
 from __future__ import annotations
 
 from typing import Dict, List, Tuple
@@ -61,8 +63,11 @@ def supported(gru: nn.Module, x: torch.Tensor) -> bool:
 
 
 def supported_train(gru: nn.Module, x: torch.Tensor) -> bool:
-    """... the autograd path takes (it needs the persistent form of the recurrence)."""
-    return supported(gru, x) and gru.hidden_size % 128 == 0 and gru.hidden_size <= 1024
+    """... the autograd path takes: the same (the persistent forms where they exist, the per-step forms for every other width)."""
+    return supported(gru, x)
+
+
+last_train_form = None     # "persistent" / "steps": which forward form the last autograd layer ran
 
 
 def _layer_operands(gru: nn.GRU):
@@ -152,13 +157,23 @@ class _GruLayer(torch.autograd.Function):
         wp = torch.stack([pack_gru_weights(w_hh[d], H) for d in range(ndir)])
         y = torch.empty(F * m, ndir * H, device=x.device, dtype=torch.float32)
         gates = torch.empty(F * m, ndir * 4 * H, device=x.device, dtype=torch.float32)
-        sync = torch.zeros(int(L.cvc_gru_persistent_sync_words()), device=x.device, dtype=torch.int32)
-        slots = torch.empty((F + 1) * ndir * H * 64, device=x.device, dtype=torch.float32)
-        rc = L.cvc_gru_seq_persistent_train_fwd(wp.data_ptr(), gi.data_ptr(), ndir * 3 * H, m * ndir * 3 * H, b_ih.contiguous().data_ptr(),
-                                                b_hh.contiguous().data_ptr(), m, F, H, ndir, slots.data_ptr(), y.data_ptr(), ndir * H,
-                                                m * ndir * H, gates.data_ptr(), ndir * 4 * H, m * ndir * 4 * H, sync.data_ptr(), st)
-        if rc != 0 or int(sync[4]) != 0:          # (host sync: this path is not graph-capturable, see backbone.py)
-            raise GruUnavailable("cvc.gru: the persistent recurrence could not run (rc=%d, barrier word=%d)" % (rc, int(sync[4]) if rc == 0 else -1))
+        global last_train_form
+        b_ih, b_hh = b_ih.contiguous(), b_hh.contiguous()
+        done = False
+        if PERSISTENT and H % 128 == 0 and H <= 1024:
+            sync = torch.zeros(int(L.cvc_gru_persistent_sync_words()), device=x.device, dtype=torch.int32)
+            slots = torch.empty((F + 1) * ndir * H * 64, device=x.device, dtype=torch.float32)
+            rc = L.cvc_gru_seq_persistent_train_fwd(wp.data_ptr(), gi.data_ptr(), ndir * 3 * H, m * ndir * 3 * H, b_ih.data_ptr(),
+                                                    b_hh.data_ptr(), m, F, H, ndir, slots.data_ptr(), y.data_ptr(), ndir * H,
+                                                    m * ndir * H, gates.data_ptr(), ndir * 4 * H, m * ndir * 4 * H, sync.data_ptr(), st)
+            done = rc == 0 and int(sync[4]) == 0      # (host read: a barrier time-out repeats the layer in the per-step form)
+        if not done:
+            # per-step training form: any H % 8 == 0 (and the fallback of the persistent form), one launch per time step
+            hq = torch.empty(2 * ndir * ((H + 31) // 32 * 32) * 64, device=x.device, dtype=torch.float32)
+            hip._check(L.cvc_gru_seq_train_fwd(wp.data_ptr(), gi.data_ptr(), ndir * 3 * H, m * ndir * 3 * H, b_ih.data_ptr(), b_hh.data_ptr(),
+                                               m, F, H, ndir, hq.data_ptr(), y.data_ptr(), ndir * H, m * ndir * H, gates.data_ptr(),
+                                               ndir * 4 * H, m * ndir * 4 * H, st), "cvc_gru_seq_train_fwd")
+        last_train_form = "persistent" if done else "steps"
         ctx.save_for_backward(x, w_ih, w_hh, gates, y)
         ctx.dims = (m, F, H, ndir)
         return y

@@ -228,7 +228,7 @@ class RegionalFeatureExtractorGVD(nn.Module):
         elif x.is_cuda and HIP_GRU:
             why = ("a HIP graph is being captured (the persistent recurrence reports time-outs through a host read)" if capturing else
                    f"{type(enc).__name__} / hidden size {enc.hidden_size} is outside the HIP recurrence's range "
-                   "(nn.GRU, batch_first, H % 8 == 0; under autograd H % 128 == 0 and H <= 1024)")
+                   "(nn.GRU, batch_first, bias, H % 8 == 0)")
             hip.warn_once("gru-library:" + why[:24], "frame-context RNN runs on the library module (MIOpen): " + why)
         enc.flatten_parameters()
         return enc(x)[0]

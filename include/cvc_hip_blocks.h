@@ -76,6 +76,12 @@ int cvc_pack_lstm_weights(const float* w_ih, int K_ih, const float* w_hh, int K_
                           cvc_stream_t stream);
 int cvc_linear_nn_planes_fwd(const float* dy_q, int K, int M, const cvc_nn_seg* segs, int nsegs, int ksplit,
                              float* workspace, cvc_stream_t stream);
+/* Training form of the per-step recurrence: additionally writes, for every step and direction, what autograd needs --
+ * (r, z, n, W_hn h + b_hn) at gates + m * g_ld_m + t * g_ld_t + d * 4H + {0, H, 2H, 3H} (as cvc_gru_seq_persistent_train_fwd).
+ * Any H % 8 == 0: the form config 5's encoder width (rnn_size 4096 -> H = 2048, backbone.py:103-104) trains on. */
+int cvc_gru_seq_train_fwd(const float* wp, const float* gi, long long gi_ld_m, long long gi_ld_t, const float* b_ih,
+                          const float* b_hh, int M, int F, int H, int ndir, float* hq, float* y, long long y_ld_m,
+                          long long y_ld_t, float* gates, long long g_ld_m, long long g_ld_t, cvc_stream_t stream);
 /* cvc_linear_nn_planes_fwd for TWO 64-row operand groups against one stream of the weights (the two loops of the cyclical pass at
  * B = 64 each share the LSTM cells, captioner.py:86-87): rows 0 .. M - 1 from dy_q, rows 64 .. 64 + M2 - 1 from dy_q2; planes are
  * [ksplit][128][ntot]; with reduce != 0 (or ksplit == 1) the result goes to the segments' dst [128 rows, ld_dst].  Under the same K
