@@ -34,6 +34,7 @@ const Entry table[] = {
     CVC_B(cvc_linear_nn_planes_fwd),
     CVC_B(cvc_linear_nn_planes2_fwd),
     CVC_B(cvc_gru_seq_train_fwd),
+    CVC_B(cvc_lstm_pointwise_bwd4_pair),
     CVC_B(cvc_beam_select_parts),
     CVC_B(cvc_tile_lstm_finish),
     CVC_B(cvc_tile_lstm_finish_embgate),

@@ -228,6 +228,31 @@ inline cvc_grad_src rows_from(cvc_grad_src g, int row0) {
     return g;
 }
 
+// the gate-gradient kernels of a step: both loops' in ONE launch when both are there (cvc_lstm_pointwise_bwd4_pair; 80 launches of
+// ~10 us per training step become 40), else (or when an operand is not 16-byte aligned) one launch per loop
+int gate_grads(const cvc_train_loop* const* loops, const cvc_pw_bwd_args* pw, int R, int kind, hipStream_t st, int* count) {
+    int n = 0;
+    if (loops[0] && loops[1]) {
+        g_prof_loop = 4;
+        int rc;
+        {
+            ProfScope ps_(kind, st);
+            rc = cvc_lstm_pointwise_bwd4_pair(&pw[0], &pw[1], R, st);
+        }
+        if (rc == 0) { *count += 1; return 0; }
+        if (rc != CVC_E_BADARG) return rc;
+    }
+    for (int s = 0; s < 2; ++s) {
+        if (!loops[s]) continue;
+        g_prof_loop = 2 + loops[s]->kind;
+        const cvc_pw_bwd_args& a = pw[s];
+        CVC_TRY_K(kind, cvc_lstm_pointwise_bwd4(a.d_h, a.d_hd, a.rng_state, a.site, a.p, a.d_c, a.gates, a.c_prev, a.c_new, a.M, R, a.d_gates,
+                                                a.d_c_prev, a.d_gates_q, a.dg_sum, a.q_row0, st));
+    }
+    *count += n;
+    return 0;
+}
+
 // Back-propagation through time of one loop, or of both loops at once (LA = loop A or null, LC = loop C or null): the loops share the
 // LSTM cells, so with both present every backward-data product takes the two loops' gate gradients in one launch and streams its
 // weights once -- as ONE 64-row operand (loop A's rows first) when B_A + B_C <= 64, as two 64-row operand groups on the 128-row
@@ -260,17 +285,19 @@ int run_bwd(const cvc_train_loop* LA, const cvc_train_loop* LC, hipStream_t st, 
     for (int t = T - 1; t >= 0; --t) {
         const bool last = t + 1 == T;
         // ---- language cells: d_h = dropout'(d_out[t]) + the next step's two uses of h_lang(t)
-        for (int s = 0; s < 2; ++s) {
-            if (!loops[s]) continue;
-            const cvc_train_loop& L = *loops[s];
-            g_prof_loop = 2 + L.kind;
-            const size_t BR = (size_t)L.B * R, BG = (size_t)L.B * 4 * R;
-            const cvc_grad_src src[3] = {rows_from(g_hl_a, row0[s]), rows_from(g_hl_b, row0[s]), none};
-            float* d_c = w.d_c_lang + (size_t)row0[s] * R;
-            CVC_TRY_K(K_PW_LANG, cvc_lstm_pointwise_bwd4(src, L.d_out + (size_t)t * BR, L.p > 0.f ? L.rng_state : nullptr, L.site0 + (unsigned)t,
-                                                         L.p, last ? nullptr : d_c, L.g_lang + (size_t)t * BG, L.c_lang + (size_t)t * BR,
-                                                         L.c_lang + (size_t)(t + 1) * BR, L.B, R, L.dg_lang + (size_t)t * BG, d_c, dgq[s],
-                                                         L.dgsum_lang, qrow0[s], st));
+        {
+            cvc_pw_bwd_args pw[2];
+            for (int s = 0; s < 2; ++s) {
+                if (!loops[s]) continue;
+                const cvc_train_loop& L = *loops[s];
+                const size_t BR = (size_t)L.B * R, BG = (size_t)L.B * 4 * R;
+                float* d_c = w.d_c_lang + (size_t)row0[s] * R;
+                pw[s] = cvc_pw_bwd_args{{rows_from(g_hl_a, row0[s]), rows_from(g_hl_b, row0[s]), none}, L.d_out + (size_t)t * BR,
+                                        L.p > 0.f ? L.rng_state : nullptr, L.site0 + (unsigned)t, L.p, last ? nullptr : d_c,
+                                        L.g_lang + (size_t)t * BG, L.c_lang + (size_t)t * BR, L.c_lang + (size_t)(t + 1) * BR, L.B,
+                                        L.dg_lang + (size_t)t * BG, d_c, dgq[s], L.dgsum_lang, qrow0[s]};
+            }
+            if (int rc_ = gate_grads(loops, pw, R, K_PW_LANG, st, &n)) return rc_;
         }
         const int shared = LA && LC ? 4 : 2 + L0.kind;        // profile label of the products both loops share
         g_prof_loop = shared;
@@ -311,16 +338,18 @@ int run_bwd(const cvc_train_loop* LA, const cvc_train_loop* LC, hipStream_t st, 
             CVC_TRY_K(K_NN_H2ATTN, nn(w.dqq, A, B, &seg, 1, w.nn_h, &g_ha_b, false, st));
         }
         // ---- attention cells: d_h = language cell's input + attention query (loop A) + next step's recurrence
-        for (int s = 0; s < 2; ++s) {
-            if (!loops[s]) continue;
-            const cvc_train_loop& L = *loops[s];
-            g_prof_loop = 2 + L.kind;
-            const size_t BR = (size_t)L.B * R, BG = (size_t)L.B * 4 * R;
-            const cvc_grad_src src[3] = {rows_from(g_ha_a, row0[s]), L.kind == 0 ? g_ha_b : none, rows_from(g_ha_prev, row0[s])};
-            float* d_c = w.d_c_att + (size_t)row0[s] * R;
-            CVC_TRY_K(K_PW_ATT, cvc_lstm_pointwise_bwd4(src, nullptr, nullptr, 0, 0.f, last ? nullptr : d_c, L.g_att + (size_t)t * BG,
-                                                        L.c_att + (size_t)t * BR, L.c_att + (size_t)(t + 1) * BR, L.B, R, L.dg_att + (size_t)t * BG,
-                                                        d_c, dgq[s], L.dgsum_att, qrow0[s], st));
+        {
+            cvc_pw_bwd_args pw[2];
+            for (int s = 0; s < 2; ++s) {
+                if (!loops[s]) continue;
+                const cvc_train_loop& L = *loops[s];
+                const size_t BR = (size_t)L.B * R, BG = (size_t)L.B * 4 * R;
+                float* d_c = w.d_c_att + (size_t)row0[s] * R;
+                pw[s] = cvc_pw_bwd_args{{rows_from(g_ha_a, row0[s]), L.kind == 0 ? g_ha_b : none, rows_from(g_ha_prev, row0[s])}, nullptr,
+                                        nullptr, 0, 0.f, last ? nullptr : d_c, L.g_att + (size_t)t * BG, L.c_att + (size_t)t * BR,
+                                        L.c_att + (size_t)(t + 1) * BR, L.B, L.dg_att + (size_t)t * BG, d_c, dgq[s], L.dgsum_att, qrow0[s]};
+            }
+            if (int rc_ = gate_grads(loops, pw, R, K_PW_ATT, st, &n)) return rc_;
         }
         g_prof_loop = shared;
         if (t > 0) {

@@ -575,13 +575,13 @@ __device__ __forceinline__ f32x4 hsrc_load4(const cvc_grad_src& g, int m, int j)
     for (; k < g.nplanes; ++k) v += ld4(p + (size_t)k * g.plane_stride);
     return v;
 }
-__global__ __launch_bounds__(WG) void lstm_pointwise_bwd4v_kernel(HSrc3 src, const float* d_hd, DropSpec rng, const float* d_c,
-                                                                  const float* gates, const float* c_prev, const float* c_new, int M,
-                                                                  int R, float* d_gates, float* d_c_prev, float* d_gates_q, float* dg_sum,
-                                                                  int q_row0) {
+__device__ __forceinline__ void lstm_pointwise_bwd4v_body(const HSrc3& src, const float* d_hd, const DropSpec& rng, const float* d_c,
+                                                          const float* gates, const float* c_prev, const float* c_new, int M,
+                                                          int R, float* d_gates, float* d_c_prev, float* d_gates_q, float* dg_sum,
+                                                          int q_row0) {
     const int j = (blockIdx.x * blockDim.x + threadIdx.x) * 4;      // (64-thread workgroups: 8 x M of them at R = 2048)
     const int m = blockIdx.y;
-    if (j >= R) return;
+    if (j >= R || m >= M) return;
     const size_t o = (size_t)m * R + j, g0 = (size_t)m * 4 * R + j;
     const f32x4 ig = ld4(gates + g0), fg = ld4(gates + g0 + R), gg = ld4(gates + g0 + 2 * R), og = ld4(gates + g0 + 3 * R);
     const f32x4 cn = ld4(c_new + o), cp = ld4(c_prev + o);
@@ -616,6 +616,25 @@ __global__ __launch_bounds__(WG) void lstm_pointwise_bwd4v_kernel(HSrc3 src, con
         st4(q, d0); st4(q + qs, d1); st4(q + 2 * qs, d2); st4(q + 3 * qs, d3);
     }
 }
+__global__ __launch_bounds__(WG) void lstm_pointwise_bwd4v_kernel(HSrc3 src, const float* d_hd, DropSpec rng, const float* d_c,
+                                                                  const float* gates, const float* c_prev, const float* c_new, int M,
+                                                                  int R, float* d_gates, float* d_c_prev, float* d_gates_q, float* dg_sum,
+                                                                  int q_row0) {
+    lstm_pointwise_bwd4v_body(src, d_hd, rng, d_c, gates, c_prev, c_new, M, R, d_gates, d_c_prev, d_gates_q, dg_sum, q_row0);
+}
+// Two independent gate-gradient launches as ONE (blockIdx.z picks the argument set): the two loops of the cyclical pass share the
+// LSTM cells, and in the joint back-propagation their gate-gradient kernels of a step are two ~10 us, latency-bound launches of the
+// same shape -- 80 launches per training step become 40.
+struct PwOne {
+    HSrc3 src; const float* d_hd; DropSpec rng; const float *d_c, *gates, *c_prev, *c_new; int M; float *d_gates, *d_c_prev, *d_gates_q, *dg_sum;
+    int q_row0;
+};
+__global__ __launch_bounds__(WG) void lstm_pointwise_bwd4v_pair_kernel(PwOne a, PwOne b, int R) {
+    // (uniform branch, not an indexed argument array: indexing kernel arguments makes hipcc copy them to scratch)
+    if (blockIdx.z == 0) lstm_pointwise_bwd4v_body(a.src, a.d_hd, a.rng, a.d_c, a.gates, a.c_prev, a.c_new, a.M, R, a.d_gates, a.d_c_prev, a.d_gates_q, a.dg_sum, a.q_row0);
+    else lstm_pointwise_bwd4v_body(b.src, b.d_hd, b.rng, b.d_c, b.gates, b.c_prev, b.c_new, b.M, R, b.d_gates, b.d_c_prev, b.d_gates_q, b.dg_sum, b.q_row0);
+}
+
 
 // ------------------------------------------------------------------ beam bookkeeping
 // Candidate (k, v) scores: score[k] + logit[k,v] - lse[k]; -inf for v == unk; a finished hypothesis
@@ -1147,6 +1166,34 @@ extern "C" int cvc_lstm_pointwise_bwd4(const cvc_grad_src* d_h, const float* d_h
     else
         hipLaunchKernelGGL(lstm_pointwise_bwd4_kernel, dim3((R + WG - 1) / WG, M), dim3(WG), 0, (hipStream_t)stream, src, d_hd,
                            cvc_drop_spec(rng_state, site, p), d_c, gates, c_prev, c_new, M, R, d_gates, d_c_prev, d_gates_q, dg_sum, q_row0);
+    return cvc_launch_status();
+}
+
+// cvc_lstm_pointwise_bwd4 for two argument sets in one launch (vector form only: every operand 16-byte aligned, R % 4 == 0)
+extern "C" int cvc_lstm_pointwise_bwd4_pair(const cvc_pw_bwd_args* x, const cvc_pw_bwd_args* y, int R, cvc_stream_t stream) {
+    if (!x || !y || R < 4 || (R & 3)) return CVC_E_BADARG;
+    PwOne o[2];
+    const cvc_pw_bwd_args* in[2] = {x, y};
+    auto al = [&](const void* q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
+    for (int k = 0; k < 2; ++k) {
+        const cvc_pw_bwd_args& a = *in[k];
+        if (!a.gates || !a.c_prev || !a.c_new || !a.d_gates || !a.d_c_prev || a.M < 1 || a.p < 0.f || a.p >= 1.f) return CVC_E_BADARG;
+        if (a.d_gates_q != nullptr && (a.q_row0 < 0 || a.q_row0 + a.M > 64)) return CVC_E_BADARG;
+        bool vec = al(a.d_hd) && al(a.d_c) && al(a.gates) && al(a.c_prev) && al(a.c_new) && al(a.d_gates) && al(a.d_c_prev) && al(a.d_gates_q) && al(a.dg_sum);
+        for (int i = 0; i < 3; ++i) {
+            o[k].src.s[i] = a.d_h[i];
+            if (a.d_h[i].p != nullptr) {
+                if (a.d_h[i].nplanes < 1 || a.d_h[i].ld < R) return CVC_E_BADARG;
+                vec = vec && al(a.d_h[i].p) && (a.d_h[i].ld & 3) == 0 && (a.d_h[i].plane_stride & 3) == 0;
+            }
+        }
+        if (!vec) return CVC_E_BADARG;
+        o[k].d_hd = a.d_hd; o[k].rng = cvc_drop_spec(a.rng_state, a.site, a.p); o[k].d_c = a.d_c; o[k].gates = a.gates; o[k].c_prev = a.c_prev;
+        o[k].c_new = a.c_new; o[k].M = a.M; o[k].d_gates = a.d_gates; o[k].d_c_prev = a.d_c_prev; o[k].d_gates_q = a.d_gates_q;
+        o[k].dg_sum = a.dg_sum; o[k].q_row0 = a.q_row0;
+    }
+    const int Mmax = x->M > y->M ? x->M : y->M;
+    hipLaunchKernelGGL(lstm_pointwise_bwd4v_pair_kernel, dim3((R / 4 + 63) / 64, Mmax, 2), dim3(64), 0, (hipStream_t)stream, o[0], o[1], R);
     return cvc_launch_status();
 }
 

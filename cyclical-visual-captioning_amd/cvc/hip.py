@@ -84,6 +84,13 @@ class GradSrc(C.Structure):
     _fields_ = [("p", C.c_void_p), ("ld", C.c_longlong), ("plane_stride", C.c_longlong), ("nplanes", C.c_int)]
 
 
+class PwBwdArgs(C.Structure):
+    """cvc_pw_bwd_args of include/cvc_hip_blocks.h (one argument set of cvc_lstm_pointwise_bwd4_pair), field for field"""
+    _fields_ = ([("d_h", GradSrc * 3), ("d_hd", C.c_void_p), ("rng_state", C.c_void_p), ("site", C.c_uint), ("p", C.c_float)] +
+                [(n, C.c_void_p) for n in ("d_c", "gates", "c_prev", "c_new")] + [("M", C.c_int)] +
+                [(n, C.c_void_p) for n in ("d_gates", "d_c_prev", "d_gates_q", "dg_sum")] + [("q_row0", C.c_int)])
+
+
 class LstmStep(C.Structure):
     """cvc_lstm_step of include/cvc_hip.h ("Training loops driven from C"), field for field"""
     _fields_ = ([("wp", C.c_void_p), ("xq", C.c_void_p), ("K", C.c_int), ("M", C.c_int), ("R", C.c_int)] +
@@ -166,6 +173,7 @@ SIGNATURES = {
     "cvc_beam_backtrack": [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P],
     "cvc_gru_seq_fwd": [_P, _P, _LL, _LL, _P, _P, _I, _I, _I, _I, _P, _P, _LL, _LL, _P],
     "cvc_gru_seq_train_fwd": [_P, _P, _LL, _LL, _P, _P, _I, _I, _I, _I, _P, _P, _LL, _LL, _P, _LL, _LL, _P],
+    "cvc_lstm_pointwise_bwd4_pair": [C.POINTER(PwBwdArgs), C.POINTER(PwBwdArgs), _I, _P],
     "cvc_gru_persistent_halves": [_I],
     "cvc_gru_persistent_waves8": [_I],
     "cvc_gru_persistent_sync_words": [],
@@ -247,7 +255,7 @@ BLOCKS = {
     "cvc_attn_bwd_pair", "cvc_linear_splitk_fwd", "cvc_linear_top2_fwd", "cvc_top2_final", "cvc_packed_lstm_fwd", "cvc_packed_linear_fwd",
     "cvc_packed_lstm_embgate_fwd", "cvc_packed_lstm_embgate_ex_fwd", "cvc_packed_lstm_late_fwd", "cvc_packed_lstm_train_fwd",
     "cvc_packed_lstm_train_pre_fwd", "cvc_packed_lstm_train_drop_fwd", "cvc_lstm_pointwise_bwd", "cvc_lstm_pointwise_bwd3",
-    "cvc_lstm_pointwise_bwd3_drop", "cvc_pack_lstm_weights", "cvc_linear_nn_planes_fwd", "cvc_linear_nn_planes2_fwd", "cvc_gru_seq_train_fwd", "cvc_beam_select_parts", "cvc_tile_lstm_finish",
+    "cvc_lstm_pointwise_bwd3_drop", "cvc_pack_lstm_weights", "cvc_linear_nn_planes_fwd", "cvc_linear_nn_planes2_fwd", "cvc_gru_seq_train_fwd", "cvc_lstm_pointwise_bwd4_pair", "cvc_beam_select_parts", "cvc_tile_lstm_finish",
     "cvc_tile_lstm_finish_embgate", "cvc_tile_reorder_pack", "cvc_decode_num_launches", "cvc_gemm_force_generic",
     "cvc_tile_gemm_loaders", "cvc_gru_persistent_waves8", "cvc_relu_dropout_fwd", "cvc_relu_dropout_bwd", "cvc_bn_workspace",
     "cvc_bn_relu_train_fwd", "cvc_bn_relu_train_bwd", "cvc_class_softmax_bwd", "cvc_layernorm_cat_bwd", "cvc_stable_order", "cvc_col_sum", "cvc_col_sum_ws", "cvc_attn_weighted_rows"}

@@ -82,6 +82,21 @@ int cvc_linear_nn_planes_fwd(const float* dy_q, int K, int M, const cvc_nn_seg* 
 int cvc_gru_seq_train_fwd(const float* wp, const float* gi, long long gi_ld_m, long long gi_ld_t, const float* b_ih,
                           const float* b_hh, int M, int F, int H, int ndir, float* hq, float* y, long long y_ld_m,
                           long long y_ld_t, float* gates, long long g_ld_m, long long g_ld_t, cvc_stream_t stream);
+/* cvc_lstm_pointwise_bwd4 (include/cvc_hip.h) for TWO independent argument sets in ONE launch: the gate-gradient kernels of the two
+ * loops of the cyclical pass at a step of their joint back-propagation (same cell, same shape, ~10 us each and latency-bound).
+ * Vector form only (every pointer 16-byte aligned, R % 4 == 0): CVC_E_BADARG otherwise, and the caller launches them one by one. */
+typedef struct cvc_pw_bwd_args {
+    cvc_grad_src d_h[3];
+    const float* d_hd;
+    const uint32_t* rng_state;
+    unsigned site;
+    float p;
+    const float *d_c, *gates, *c_prev, *c_new;
+    int M;
+    float *d_gates, *d_c_prev, *d_gates_q, *dg_sum;
+    int q_row0;
+} cvc_pw_bwd_args;
+int cvc_lstm_pointwise_bwd4_pair(const cvc_pw_bwd_args* a, const cvc_pw_bwd_args* b, int R, cvc_stream_t stream);
 /* cvc_linear_nn_planes_fwd for TWO 64-row operand groups against one stream of the weights (the two loops of the cyclical pass at
  * B = 64 each share the LSTM cells, captioner.py:86-87): rows 0 .. M - 1 from dy_q, rows 64 .. 64 + M2 - 1 from dy_q2; planes are
  * [ksplit][128][ntot]; with reduce != 0 (or ksplit == 1) the result goes to the segments' dst [128 rows, ld_dst].  Under the same K

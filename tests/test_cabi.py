@@ -99,16 +99,18 @@ def test_train_loop_descriptor_layouts_match_the_c_compiler(tmp_path):
     import subprocess
     from cvc import hip
     src = tmp_path / "probe.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(void) { printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n", '
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\n#include "%s"\nint main(void) { printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n", '
                    'sizeof(cvc_train_loop), offsetof(cvc_train_loop, inv_temp), offsetof(cvc_train_loop, ld_ih_att), '
                    'offsetof(cvc_train_loop, w_h), offsetof(cvc_train_loop, site0), offsetof(cvc_train_loop, out), '
-                   'offsetof(cvc_train_loop, xa), offsetof(cvc_train_loop, bwd_ws), sizeof(cvc_lstm_step)); return 0; }\n' % HEADER)
+                   'offsetof(cvc_train_loop, xa), offsetof(cvc_train_loop, bwd_ws), sizeof(cvc_lstm_step)); '
+                   'printf(" %%zu %%zu %%zu", sizeof(cvc_pw_bwd_args), offsetof(cvc_pw_bwd_args, d_c), offsetof(cvc_pw_bwd_args, q_row0)); return 0; }\n' % (HEADER, HEADER.replace("cvc_hip.h", "cvc_hip_blocks.h")))
     exe = tmp_path / "probe"
     subprocess.check_call(["gcc", "-o", str(exe), str(src)])
     got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
     D = hip.TrainLoop
+    P = hip.PwBwdArgs
     want = [ctypes.sizeof(D), D.inv_temp.offset, D.ld_ih_att.offset, D.w_h.offset, D.site0.offset, D.out.offset, D.xa.offset,
-            D.bwd_ws.offset, ctypes.sizeof(hip.LstmStep)]
+            D.bwd_ws.offset, ctypes.sizeof(hip.LstmStep), ctypes.sizeof(P), P.d_c.offset, P.q_row0.offset]
     assert got == want, (got, want)
 
 
