@@ -99,6 +99,11 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
     def device(self):
         return self.logit.weight.device
 
+    def step_capturable(self) -> bool:
+        """True when a whole training step of this model can be captured into a HIP graph (cvc.trainer.Trainer.train): the hot
+        path on pre-extracted features.  With the once-per-clip encoder in front (raw features) it cannot: see Trainer.graph_capable."""
+        return isinstance(self.roi_feat_extractor, PrecomputedRegionFeatures)
+
     def init_hidden(self, batch_size, num_layers):
         """reference :96-101"""
         z = torch.zeros(num_layers, batch_size, self.rnn_size, device=self.device)

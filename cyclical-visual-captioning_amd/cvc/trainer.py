@@ -252,6 +252,12 @@ class Trainer:
         capturable torch optimizer), and the gradient exchange (if any) is a stream operation."""
         if not self.shape_buckets or self.device.type != "cuda":
             return False
+        # the model's whole step must consist of stream operations: the decode / localize / reconstruct path on pre-extracted
+        # features is; the once-per-clip encoder is not (its persistent GRU reports barrier time-outs through a host read, widths
+        # outside the HIP forms run in the library) -- raw-feature runs through the encoder train with eager steps
+        cap = getattr(self.model, "step_capturable", None)
+        if cap is None or not cap():
+            return False
         if getattr(self.optimizer, "clip_and_step", None) is None and not all(g.get("capturable", False) for g in self.optimizer.param_groups):
             return False
         red = self.grad_reducer
