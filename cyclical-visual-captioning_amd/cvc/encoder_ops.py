@@ -167,11 +167,21 @@ class _BatchNormRelu(torch.autograd.Function):
 def batchnorm_relu_train(x: torch.Tensor, bn: nn.BatchNorm1d) -> torch.Tensor:
     """att_embed_aux in train(): x [..., C] normalised per channel over all leading positions (what BatchNorm1d does on the
     transposed [B, C, F] tensor, backbone.py:332), then ReLU"""
-    momentum = 0.1 if bn.momentum is None else bn.momentum
     if bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
-    return _BatchNormRelu.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
-                                bn.running_var if bn.track_running_stats else None, bn.eps, momentum)
+    # momentum None = cumulative moving average, factor 1 / num_batches_tracked (nn.BatchNorm1d; the host read is the module's own)
+    if bn.momentum is None:
+        momentum = 1.0 / float(bn.num_batches_tracked) if (bn.track_running_stats and bn.num_batches_tracked is not None) else 0.0
+    else:
+        momentum = bn.momentum
+    y = _BatchNormRelu.apply(x, bn.weight, bn.bias, bn.running_mean if bn.track_running_stats else None,
+                             bn.running_var if bn.track_running_stats else None, bn.eps, momentum)
+    if bn.track_running_stats:
+        # the kernel updated the running statistics through raw pointers: their version counters did not move, and the eval-mode
+        # fold of this layer (cached on weights generation + data_ptr + _version) would keep the old statistics after a train()
+        # forward that no optimizer step follows (round-4 advisor finding)
+        hip.bump_weights_generation()
+    return y
 
 
 class _ClassSoftmax(torch.autograd.Function):

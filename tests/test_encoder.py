@@ -616,3 +616,33 @@ def test_encoder_train_mode_runs_on_own_kernels_and_matches_the_torch_formulatio
         assert rel(got[1][k], p.grad) < 1e-3, (k, rel(got[1][k], p.grad))
         checked += 1
     assert checked >= 20
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("momentum", [0.1, None])
+def test_batchnorm_train_kernel_updates_running_stats_like_the_module_and_invalidates_the_eval_fold(momentum):
+    """cvc.encoder_ops.batchnorm_relu_train (att_embed_aux in train(), backbone.py:81, 332): the kernel writes running_mean /
+    running_var through raw pointers -- their version counters do not move -- so the call itself bumps the weights generation the
+    eval-mode fold is cached on (round-4 advisor finding: train() forward, then eval() without an optimizer step, reused the old
+    statistics); momentum=None is nn.BatchNorm1d's cumulative average (factor 1 / num_batches_tracked), not 0.1."""
+    import torch.nn as nn
+    from cvc import encoder_ops, hip
+    dev = torch.device("cuda:0")
+    C_, rows = 48, 96
+    g = torch.Generator().manual_seed(3)
+    ref = nn.BatchNorm1d(C_, momentum=momentum)
+    with torch.no_grad():
+        ref.weight.copy_(torch.rand(C_, generator=g) + 0.5); ref.bias.copy_(torch.randn(C_, generator=g) * 0.1)
+    mine = nn.BatchNorm1d(C_, momentum=momentum).to(dev)
+    mine.load_state_dict(ref.state_dict())
+    ref.train(); mine.train()
+    for step in range(3):
+        x = torch.randn(rows, C_, generator=g) * (1 + step) + step
+        gen0 = hip.weights_generation()
+        y = encoder_ops.batchnorm_relu_train(x.to(dev).requires_grad_(True), mine)
+        assert hip.weights_generation() > gen0                  # whatever is cached on the old statistics is stale now
+        want = torch.relu(ref(x))
+        np.testing.assert_allclose(y.detach().cpu().numpy(), want.detach().numpy(), rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(mine.running_mean.cpu().numpy(), ref.running_mean.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(mine.running_var.cpu().numpy(), ref.running_var.numpy(), rtol=1e-5, atol=1e-6)
+        assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == step + 1
