@@ -641,8 +641,9 @@ static int launch_packed(const PackedArgs& a_in, int blocks, hipStream_t st) {
         // (gate weights with the default cache policy: cvc_packed_lstm_embgate_ex_fwd's w_cached)
         // (measured alternatives at cfg2: the language cell's 201 MB instead -- its launch 54.2 -> 48.8 us, the attention cell's back
         // to 40.5: 323-325 k against 326 k; both matrices: over the cache's size, slower than none)
-        if (cvc_gemm_split_mode == 2 && a.w_cached && a.M > 32) {
-            hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, true, CVC_PACKED_DEPTH8, true, 8, false, 1, false, true>), grid, dim3(512), 0, st, a);
+        if (cvc_gemm_split_mode == 2 && a.w_cached) {
+            if (a.M > 32) hipLaunchKernelGGL((skinny_gemm_packed_kernel<2, true, CVC_PACKED_DEPTH8, true, 8, false, 1, false, true>), grid, dim3(512), 0, st, a);
+            else hipLaunchKernelGGL((skinny_gemm_packed_kernel<1, true, CVC_PACKED_DEPTH8, true, 8, false, 1, false, true>), grid, dim3(512), 0, st, a);
             return cvc_launch_status();
         }
     }
@@ -782,6 +783,7 @@ extern "C" int cvc_packed_lstm_step_fwd(const cvc_lstm_step* s, cvc_stream_t str
     a.h_rm = s->h_out; a.h_rm2 = s->h_out2; a.h_rm3 = s->h_drop_out;
     a.h3_drop = cvc_drop_spec(s->rng_state, s->site, s->p);
     a.h_dst1_q = s->h_dst1_q; a.h_dst2_q = s->h_dst2_q;
+    a.w_cached = s->w_cached ? 1 : 0;
     return launch_packed<true>(a, s->R / 8, (hipStream_t)stream);
 }
 

@@ -10,6 +10,10 @@
 #include "../../include/cvc_hip_blocks.h"
 #include "../../include/cvc_hip_experimental.h"
 
+#ifndef CVC_TRAIN_ATT_W_CACHED_DEFAULT
+#define CVC_TRAIN_ATT_W_CACHED_DEFAULT 2
+#endif
+
 namespace {
 
 // ---- measurement aid (bench.py): per-launch HIP-event pairs around every entry point the drivers call, on the launch stream.
@@ -35,6 +39,22 @@ inline int feat_stream(const cvc_train_loop& L) {
     if (forced >= 0) return forced & 3;
     const unsigned long long bytes = 4ull * L.B * (L.N + L.F) * ((unsigned long long)L.A + L.R);
     return bytes > (256ull << 20) ? 3 : 0;
+}
+
+// Cache policy of the attention cell's gate matrix in the forward loops (134 MB at D = 2048: it fits the 256 MiB Infinity Cache).
+// Loop C launches nothing but the two cells per step -- the language cell streams its weights non-temporally -- so the attention
+// cell's matrix survives from step to step: 44.7 -> 40.3 us per launch at config 3, 33.1 -> 29.3 at config 4's share.  In loop A the
+// attention passes run in between: when they read the features non-temporally (the features exceed the cache, config 3:
+// feat_stream) the matrix survives them as well (44.7 -> 41.0 us); when the features are cacheable themselves (config 4's share:
+// 228 MB) the two compete and everything in the loop gets slower (attention cell 33.3 -> 36.6, weighted sum 29.7 -> 33.8 us), so
+// there loop A keeps streaming its weights.  Step: 17.72 -> 17.52 ms (config 3), 12.00 -> 11.91 ms (config 4's share).
+// CVC_TRAIN_ATT_W_CACHED: 0 = never, 1 = loop C only, 2 = this policy (default), 3 = both loops always (A/B).
+inline int att_w_cached(const cvc_train_loop& L) {
+    static const int mode = getenv("CVC_TRAIN_ATT_W_CACHED") ? atoi(getenv("CVC_TRAIN_ATT_W_CACHED")) : CVC_TRAIN_ATT_W_CACHED_DEFAULT;
+    const unsigned long long bytes = 4ull * 4 * L.R * 2 * L.R;
+    if (bytes > (200ull << 20) || mode <= 0) return 0;
+    if (L.kind == 1) return 1;
+    return mode >= 3 || (mode == 2 && feat_stream(L) != 0);
 }
 
 struct ProfScope {
@@ -136,6 +156,7 @@ int run_fwd(const cvc_train_loop& L, hipStream_t st, int* launches) {
         a.h_out2 = last ? nullptr : L.h_att_prev + (size_t)(t + 1) * BR;
         a.h_dst1_q = quad_off(L.xl[rd], ha_off);
         a.h_dst2_q = quad_off(L.xa[wr], R);
+        a.w_cached = att_w_cached(L);
         CVC_TRY_K(K_ATT_CELL, cvc_packed_lstm_step_fwd(&a, st));
         if (L.kind == 0) {
             // ---- additive / dot attention over regions + frames with one query (decoder_core.py:54-56, modules.py:100-159)

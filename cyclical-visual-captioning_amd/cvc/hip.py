@@ -96,7 +96,7 @@ class LstmStep(C.Structure):
     _fields_ = ([("wp", C.c_void_p), ("xq", C.c_void_p), ("K", C.c_int), ("M", C.c_int), ("R", C.c_int)] +
                 [(n, C.c_void_p) for n in ("b_ih", "b_hh", "gate_pre", "row_bias", "row_index", "c_prev", "c_out", "gates_out", "h_out",
                                            "h_out2", "h_drop_out", "rng_state")] +
-                [("site", C.c_uint), ("p", C.c_float), ("h_dst1_q", C.c_void_p), ("h_dst2_q", C.c_void_p)])
+                [("site", C.c_uint), ("p", C.c_float), ("h_dst1_q", C.c_void_p), ("h_dst2_q", C.c_void_p), ("w_cached", C.c_int)])
 
 
 class TrainLoop(C.Structure):

@@ -665,6 +665,8 @@ typedef struct cvc_lstm_step {
     float* h_drop_out;           /* [M, R] nn.Dropout(h') with the counter-based mask (rng_state null or p == 0: h'), nullable */
     const uint32_t* rng_state; unsigned site; float p;
     float *h_dst1_q, *h_dst2_q;  /* h' in the quad layout at the consumers' K offsets, nullable                           */
+    int w_cached;                /* 1: the gate weights are read under the default cache policy (they fit the Infinity Cache and
+                                  * nothing between two launches evicts them) instead of streamed non-temporally */
 } cvc_lstm_step;
 CVC_API int cvc_packed_lstm_step_fwd(const cvc_lstm_step* s, cvc_stream_t stream);
 
