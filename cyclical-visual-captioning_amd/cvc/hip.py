@@ -14,7 +14,8 @@ from typing import List, Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcvc_hip.so")
+# (CVC_LIB: a variant library for A/B measurements -- tools/runs/build_variant.sh; the product loads the in-tree build)
+LIB_PATH = os.environ.get("CVC_LIB") or os.path.join(_HERE, "lib", "libcvc_hip.so")
 
 ATTN_ADDITIVE, ATTN_DOT = 0, 1
 

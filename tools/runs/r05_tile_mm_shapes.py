@@ -11,6 +11,8 @@ from cvc import hip
 if len(sys.argv) > 1:
     hip.LIB_PATH = os.path.abspath(sys.argv[1])
 hip.lib()
+if os.environ.get("LOADERS"):          # A/B: 1 = 8 computing waves, 2 = 4 wide computing waves, 3 = per launch (library default)
+    hip.lib().cvc_tile_gemm_loaders(int(os.environ["LOADERS"]))
 dev = torch.device("cuda:0")
 B = int(os.environ.get("B", "64"))
 S, n, R, E, V = 2 * 20 * B, 20 * B, 2048, 1024, 5000
