@@ -22,6 +22,10 @@ def _worker(rank, world, port, q):
         from cvc.distributed import GradReducer, init_from_env, shard_range
         r, w, _ = init_from_env("gloo")
         assert (r, w) == (rank, world)
+        # the control plane's small all-reduce (bench.py's max over ranks, barriers' companion): host numbers over gloo
+        from cvc.distributed import control_all_reduce
+        assert control_all_reduce([float(rank), 10.0 - rank], "max") == [float(world - 1), 10.0]
+        assert control_all_reduce([1.0], "sum") == [float(world)]
         z = np.load(os.path.join(GOLDEN, "g3_shards.npz"))
         names = sorted(k[len("mean.grad."):] for k in z.keys() if k.startswith("mean.grad.") and not k.endswith(".is_none"))
         dead = sorted(k[len("mean.grad."):-len(".is_none")] for k in z.keys() if k.startswith("mean.grad.") and k.endswith(".is_none"))

@@ -145,3 +145,45 @@ def test_torch_library_ops_are_registered_with_fake_implementations():
     assert torch.ops.cvc.grounder(m(B, T, 24), m(B, N, 24), None, None).shape == (B, T, N)
     w, lp = torch.ops.cvc.top2_unk(m(B, V), 1)
     assert w.dtype == torch.int64 and lp.shape == (B,)
+
+
+def test_shape_buckets_of_the_training_loop():
+    """cvc.trainer.bucket_len: the per-batch trimmed lengths (reference trainer.py:63-69) rounded up to a few sizes per axis so that
+    Trainer.train() keeps one captured graph per shape; never below the batch's own maximum, never above the loader's padded length."""
+    from cvc.trainer import bucket_len, _shape_key
+    import torch
+    for full in (1, 7, 100, 1000):
+        seen = set()
+        for n in range(1, full + 1):
+            b = bucket_len(n, full)
+            assert n <= b <= full
+            seen.add(b)
+        assert len(seen) <= 4 and full in seen
+    assert bucket_len(5, 100, buckets=0) == 5                      # buckets off: the reference's exact trimming
+    assert bucket_len(150, 100) == 100
+    a = dict(x=torch.zeros(2, 3), f=dict(p=torch.zeros(2, 5)), ids=["a"])
+    b = dict(x=torch.ones(2, 3), f=dict(p=torch.ones(2, 5)), ids=["b"])
+    c = dict(x=torch.ones(2, 4), f=dict(p=torch.ones(2, 5)), ids=["b"])
+    assert _shape_key(a) == _shape_key(b) != _shape_key(c)
+
+
+def test_grad_reducer_does_not_hand_out_a_view_another_producer_already_wrote():
+    """GradReducer.claim (the gradient-sink protocol of the dense weight-gradient products): a parameter whose post-accumulate hook
+    has fired, or whose view was already written this step, is NOT handed out for an overwriting write (round-4 advisor finding: the
+    deferred flush could overwrite what AccumulateGrad had added)."""
+    import torch
+    from cvc.distributed import GradReducer
+    p, q = torch.nn.Parameter(torch.zeros(4, 4)), torch.nn.Parameter(torch.zeros(3))
+    red = GradReducer([("a.weight", p), ("b.bias", q)])
+    try:
+        red.zero_grad()
+        v = red.claim(p)
+        assert v is not None and v.data_ptr() == p.grad.data_ptr()
+        assert red.claim(p) is None                                  # handed out once per step
+        (q * 2.0).sum().backward()                                   # autograd accumulates into q's view; its hook fires
+        assert red.claim(q) is None
+        red.finalize()
+        red.zero_grad()
+        assert red.claim(q) is not None                              # a new step: free again
+    finally:
+        red.remove_hooks()
