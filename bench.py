@@ -911,6 +911,7 @@ def main():
     dist_on = under_launcher
     ranks_joined = 1
     comm = None
+    rccl_error = None
     if dist_on:
         # torch.distributed is the CONTROL plane (rendezvous, the communicator's unique id, host barriers, max over ranks) on gloo;
         # the data plane is the package's own RCCL communicator over xGMI (cvc.comm.RcclComm): no c10d RCCL group, hence no c10d
@@ -920,8 +921,21 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("gloo")
-        comm = RcclComm.from_process_group()
-        ranks_joined = comm.count_ranks()                   # every rank adds 1.0 through RCCL: the count the communicator itself reports
+        try:
+            comm = RcclComm.from_process_group()
+            ranks_joined = comm.count_ranks()               # every rank adds 1.0 through RCCL: the count the communicator itself reports
+        except Exception as e:
+            # the decode path shards by clips and has no data-path collective: its measurement does not
+            # depend on the communicator, so a box on which RCCL cannot be brought up still gets its decode line -- with the
+            # failure in it and the ranks counted on the control plane.  The training step exchanges gradients: fatal there.
+            if args.mode == "train":
+                raise
+            from cvc.distributed import control_all_reduce
+            comm = None
+            rccl_error = f"{type(e).__name__}: {e}"[:300]
+            print(f"bench.py: rank {rank}: RCCL communicator unavailable ({rccl_error}); decode has no collective, continuing",
+                  file=sys.stderr, flush=True)
+            ranks_joined = int(round(control_all_reduce([1.0], "sum")[0]))
         if ranks_joined != args.gpus or dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: {ranks_joined} rank(s) joined the RCCL communicator, --gpus asked for {args.gpus}")
 
@@ -950,6 +964,8 @@ def main():
             line["secondary_wall_s"] = round(time.perf_counter() - t0, 1)
     if rank == 0:
         line["ranks_joined"] = ranks_joined
+        if rccl_error is not None:
+            line["rccl"] = "unavailable, ranks counted on the gloo control plane: " + rccl_error
         # LAST key of the line (a log that keeps only the tail of stdout still shows it): every measurement's headline numbers
         summ = [dict(name="headline: " + line["config"]["workload"], value=line["value"], unit=line["unit"], ms_per_step=line["ms_per_step"],
                      roofline_frac=(line.get("roofline") or {}).get("frac"))]
@@ -968,7 +984,8 @@ def main():
         gc.collect()
         torch.cuda.synchronize()
         dist.barrier()
-        comm.destroy()
+        if comm is not None:
+            comm.destroy()
         dist.destroy_process_group()
 
 

@@ -52,8 +52,15 @@ class RcclComm:
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("RcclComm.from_process_group: torch.distributed is not initialised (use RcclComm.single() for one rank)")
         world, rank = dist.get_world_size(group), dist.get_rank(group)
-        box = [cls.unique_id() if rank == 0 else None]
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = cls.unique_id()
+            except Exception as e:          # every rank must learn of it: the others are about to wait for this broadcast
+                box[0] = e
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if isinstance(box[0], Exception):
+            raise RuntimeError(f"RcclComm.from_process_group: rank 0 could not draw the unique id: {box[0]}")
         return cls(world, rank, box[0])
 
     def all_reduce_(self, flat: torch.Tensor, stream: Optional["torch.cuda.Stream"] = None) -> None:

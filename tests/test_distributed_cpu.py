@@ -89,6 +89,18 @@ def _worker(rank, world, port, q):
         # clip sharding covers the batch exactly once
         cover = [shard_range(7, r_, 2) for r_ in range(2)]
         assert cover[0].start == 0 and cover[0].stop == cover[1].start and cover[1].stop == 7
+        # the data plane's rendezvous: when rank 0 cannot draw RCCL's unique id, EVERY rank gets the error (no rank is left waiting
+        # for a broadcast that never comes)
+        from cvc.comm import RcclComm
+
+        def no_id():
+            raise OSError("librccl is not here")
+        real_id, RcclComm.unique_id = RcclComm.unique_id, staticmethod(no_id)
+        try:
+            with pytest.raises(RuntimeError, match="rank 0 could not draw the unique id.*librccl is not here"):
+                RcclComm.from_process_group()
+        finally:
+            RcclComm.unique_id = real_id
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, "ok"))
