@@ -40,12 +40,11 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec); ~6.3 TB/s measured achievable
-MFMA_F32_PEAK_TFLOPS = 157.3
-MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 32x32x16 (same guide); the packed GEMMs issue 6 bf16 MFMAs per fp32 product
+from bench_common import HBM_PEAK_GBS, MFMA_F32_PEAK_TFLOPS, MFMA_BF16_PEAK_TFLOPS, usable_cores, pmc_traffic  # noqa: E402
+from bench_train import run_train  # noqa: E402
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=300, help="timed steps (default: >= 1 s of decodes at cfg2)")
@@ -90,60 +89,7 @@ def parse():
     p.add_argument("--secondary-seconds", type=float, default=0.35, help="timed seconds per secondary measurement")
     p.add_argument("--cpu-repeats", type=int, default=3)
     p.add_argument("--seed", type=int, default=1234)
-    return p.parse_args()
-
-
-def usable_cores() -> int:
-    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota
-    (os.cpu_count() reports the whole host and oversubscribes a containerised run)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except Exception:
-        try:
-            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
-            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-            if q > 0:
-                n = min(n, max(1, q // per))
-        except Exception:
-            pass
-    return max(1, n)
-
-
-def pmc_traffic(kernel, args, over, mode="decode", beam=None, config_name=None):
-    """HBM bytes per launch of `kernel` from the tracked PMC collection of THIS workload (profiles/traffic/<config>_beam<b>_<mode>.json,
-    written by tools/collect_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this very command).
-    The file records the hash of the kernel sources it was collected on; numbers from any other build are REFUSED
-    (traffic = null plus the reason) instead of printed as if they were current."""
-    cfg = config_name or args.config
-    b = args.beam if beam is None else beam
-    from cvc import synth as _synth
-    # cfg2 and cfg3 are the same sizes: a decode collection of one serves the other
-    names = [cfg] + [c for c in _synth.CONFIGS if c != cfg and cfg in _synth.CONFIGS and _synth.CONFIGS[c] == _synth.CONFIGS[cfg]]
-    path = None
-    for c in names:
-        cand = os.path.join(ROOT, "profiles", "traffic", f"{c}_beam{b}_{mode}.json")
-        if os.path.exists(cand):
-            path = cand
-            break
-    if path is None:
-        return None, f"profiles/traffic/{cfg}_beam{b}_{mode}.json absent"
-    if over:
-        return None, "dimension overrides on the command line: the tracked collection is for the named config"
-    try:
-        tf = json.load(open(path))
-    except Exception as e:
-        return None, f"{os.path.relpath(path, ROOT)} unreadable: {e}"
-    import build_hip
-    have = build_hip.source_hash()
-    if tf.get("source_hash") != have:
-        return None, f"stale: collected on kernel sources {tf.get('source_hash')}, this build is {have}"
-    ent = tf.get("kernels", {}).get(kernel)
-    if not ent:
-        return None, f"no PMC entry for {kernel} in {os.path.relpath(path, ROOT)}"
-    return int(ent["hbm_bytes"]), f"{ent['symbol'][:110]} ({ent['dispatches']} dispatches; 2 x FETCH_SIZE + WRITE_SIZE, KiB units; {os.path.basename(path)})"
+    return p.parse_args(argv)
 
 
 def algorithmic_work(d, beam):
@@ -176,276 +122,6 @@ def algorithmic_work(d, beam):
     w["lang_late"] = dict(bound="hbm", bytes=4 * (4 * R * R + 8 * R) + 4 * rows * (R + 3 * R) + int(tile_b * n_lstm_tiles * segs(2 * R)),
                           flops=2 * rows * 4 * R * R)
     return w
-
-
-def run_train(args, d, dev, rank, world, steps=None, warmup=None, min_warm=None, cpu_baseline=True, config_name=None, probe=True,
-              regions=1, comm=None, always_exchange=False):
-    """Cyclical training step (BASELINE configs 3-ii / 4): decode -> localize -> reconstruct forward,
-    backward, one RCCL gradient all-reduce (world > 1), clip_grad_norm_(0.1), Adam.  Train-mode dropout.
-    Returns the bench line (rank 0) or None."""
-    steps = args.steps if steps is None else steps
-    warmup = args.warmup if warmup is None else warmup
-    min_warm = args.min_warm_seconds if min_warm is None else min_warm
-    config_name = config_name or args.config
-    import argparse as ap
-    from cvc import synth, opts as cvc_opts
-    from cvc.model.captioner import DecodeAndGroundCaptionerGVDROI, PrecomputedRegionFeatures
-    from cvc.trainer import Trainer, build_optimizer
-    from cvc.distributed import GradReducer
-    o = cvc_opts.parse_opt([])
-    o.vocab_size, o.itow, o.wtoi = d.V, {str(i): "w%d" % i for i in range(d.V)}, {"UNK": synth.UNK_IDX}
-    o.seq_length, o.rnn_size, o.input_encoding_size, o.att_hid_size = d.T, d.R, d.E, d.A
-    o.detect_size, o.vis_encoding_size, o.train_decoder_only = d.DET, d.G, False
-    o.xe_loss_weight, o.caption_consistency_loss_weight, o.learning_rate, o.batch_size = 0.5, 0.5, 1e-4, d.B
-    model = DecodeAndGroundCaptionerGVDROI(o, roi_extractor=PrecomputedRegionFeatures(d.DET, d.G))
-    model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.hot_path_state_dict(d, args.seed).items()}, strict=False)
-    model = model.to(dev).train()
-    use_graph = not args.no_train_graph
-    optim = build_optimizer(model, o, capturable=use_graph)
-    # flat gradient arenas (also for one rank: one fill / one clip multiply); the exchange runs on the package's own RCCL
-    # communicator (cvc.comm.RcclComm) -- with --always-exchange also at N = 1, on a one-rank communicator
-    own_comm = None
-    if comm is None and always_exchange:
-        from cvc.comm import RcclComm
-        comm = own_comm = RcclComm.single()
-    reducer = GradReducer(model.named_parameters(), comm=comm, always_exchange=always_exchange)
-    try:
-        return _run_train_body(args, d, dev, rank, world, steps, warmup, min_warm, cpu_baseline, config_name, probe, regions, o, model,
-                               optim, reducer, use_graph)
-    finally:
-        # the reducer registers itself in process-global lists (cvc.functional.GRAD_SINKS / LATE_GRAD_LISTENERS): without this every
-        # run_train of the default run would leave its parameters and ~0.5 GB of arenas alive and its sinks in every later claim
-        reducer.remove_hooks()
-        if own_comm is not None:
-            own_comm.destroy()
-
-
-def _run_train_body(args, d, dev, rank, world, steps, warmup, min_warm, cpu_baseline, config_name, probe, regions, o, model, optim, reducer,
-                    use_graph):
-    from cvc import synth
-    from cvc.trainer import Trainer
-    from cvc.distributed import control_all_reduce
-    tr = Trainer(o, None, model, optim, None, None, grad_reducer=reducer)
-    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
-    feats = {k: t(v) for k, v in synth.clip_features(d, args.seed + rank).items()}
-    b = {k: t(v) for k, v in synth.label_glue_batch(d, args.seed + rank).items()}
-    batch = (feats, b["input_seq"], b["gt_seq"], b["num"].cpu(), b["proposals"], b["gt_bboxs"], b["box_mask"],
-             ["v_x_segment_%02d" % i for i in range(d.B)], torch.zeros(d.B, d.N, 1), b["frm_mask"], b["sample_idx"],
-             feats["pnt_mask"][:, 1:])
-    import torch.distributed as dist
-    dist_on = dist.is_available() and dist.is_initialized()
-    step = tr.train_step_graphed if use_graph else tr.train_step
-    w0 = time.perf_counter()
-    for _ in range(warmup):
-        step(batch)
-    torch.cuda.synchronize()
-    while time.perf_counter() - w0 < min_warm:
-        step(batch)
-        torch.cuda.synchronize()
-
-    def timed_region(n):
-        if dist_on:
-            dist.barrier()
-            torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(n):
-            loss_ = step(batch)[0]
-        torch.cuda.synchronize()
-        el_ = time.perf_counter() - t0
-        if dist_on:
-            dist.barrier()
-            el_ = control_all_reduce([el_], "max")[0]
-        return float(el_), loss_
-
-    el, loss = timed_region(steps)
-    region_ms = [round(el / steps * 1e3, 3)]
-    for _ in range(regions - 1):
-        # (the short `secondary` entries of the default run only: `regions` regions of K steps each, the MEDIAN reported -- one
-        # host hiccup inside a 0.3 s region moved an entry by 10 % in one collection; the lines of `--mode train` itself time
-        # exactly K steps once, as the contract says)
-        el_r, loss = timed_region(steps)
-        region_ms.append(round(el_r / steps * 1e3, 3))
-    if regions > 1:
-        el = sorted(region_ms)[len(region_ms) // 2] * steps / 1e3
-    ms_step = el / steps * 1e3
-    eager_ms = None
-    if use_graph:                      # the same step launched eagerly (host-side launch path in the loop), for comparison
-        n_e = max(3, min(steps, 10))
-        tr.train_step(batch)
-        step_keep, step = step, tr.train_step
-        el_e, _ = timed_region(n_e)
-        step = step_keep
-        eager_ms = round(el_e / n_e * 1e3, 3)
-    # exposed exchange time (N > 1): the same steps with the gradient exchange switched off (every rank then trains on its own
-    # shard: a measurement, not a training mode); exposed = step with exchange - step without
-    exchange = None
-    if reducer.exchange:
-        # the same kind of step (graph replay when the headline is one) with the exchange switched off -- a graph holds the
-        # exchange it was captured with, so a second graph is captured for the measurement
-        n_x = max(3, min(steps, 10))
-        el1, _ = timed_region(n_x)
-        reducer.exchange, keep_overlap = False, reducer.overlap
-        reducer.overlap = False
-        keep_graph, tr._graph = tr._graph, None
-        step(batch)
-        torch.cuda.synchronize()
-        el0, _ = timed_region(n_x)
-        tr._graph = keep_graph
-        reducer.exchange, reducer.overlap = True, keep_overlap
-        step(batch)
-        ms0, ms1 = el0 / n_x * 1e3, el1 / n_x * 1e3
-        grad_bytes = sum(a.numel() * 4 for a in reducer.arenas)
-        exchange = dict(ms_per_step_without_exchange=round(ms0, 3), ms_per_step_with_exchange=round(ms1, 3),
-                        in_graph_ms=round(ms1 - ms0, 3) if use_graph else None, exposed_ms=round(ms1 - ms0, 3),
-                        measured_on="HIP-graph replays (exchange captured inside the step's graph)" if use_graph else "eager steps",
-                        ranks=reducer.world, gradient_bytes=grad_bytes,
-                        algorithm="per bucket: in-place reduce_scatter + all_gather on the package's own RCCL communicator (cvc_allreduce_grads), "
-                                  "on an exchange stream forked from / joined to the step's stream by HIP events, launched the moment the "
-                                  "bucket's last gradient product is enqueued",
-                        backend=reducer.backend, buckets=len(reducer.arenas))
-
-    # ---- when does each gradient bucket become complete, relative to the end of the step (eager step, events on the launch
-    # stream)?  At N > 1 a bucket's exchange is enqueued at that moment, behind the product that completed it.
-    buckets = None
-    if rank == 0 and probe:
-        reducer.track_ready = True
-        tr.train_step(batch)
-        end_ev = torch.cuda.Event(enable_timing=True)
-        end_ev.record()
-        torch.cuda.synchronize()
-        reducer.track_ready = False
-        buckets = []
-        total_b = sum(a.numel() * 4 for a in reducer.arenas)
-        for i, a in enumerate(reducer.arenas):
-            ev = reducer.ready_events.get(i)
-            names = [n_ for n_, _ in reducer.buckets[i]]
-            buckets.append(dict(bucket=i, first=names[0], tensors=len(names), bytes=a.numel() * 4,
-                                ready_ms_before_step_end=None if ev is None else round(ev.elapsed_time(end_ev), 3),
-                                complete_by=(reducer.last_done_how[i] if i < len(getattr(reducer, "last_done_how", [])) else None) or "finalize",
-                                launched=bool(reducer.exchange)))
-        early = sum(b_["bytes"] for b_ in buckets if (b_["ready_ms_before_step_end"] or 0) >= 1.5)
-        buckets = dict(total_bytes=total_b, bytes_ready_1p5ms_before_end=early, fraction=round(early / total_b, 4), per_bucket=buckets)
-
-    # ---- GPU time of one step by launch role: HIP events around every C-ABI launch (eager steps, launch stream); the launches
-    # INSIDE the two C-driven loops come from the drivers' own per-launch event pairs (cvc_train_loop_profile)
-    roof, kernels, cpu, timed_note = None, [], None, None
-    if rank == 0 and probe:
-        import ctypes as C
-        from cvc import hip
-        L = hip.lib()
-        work = train_work(d)
-        nprobe = 2
-        tr.train_step(batch)
-        torch.cuda.synchronize()
-        cap = 4 * 16 * d.T * (nprobe + 1)
-        hip._check(L.cvc_train_loop_profile(cap), "cvc_train_loop_profile")
-        timers = hip.enable_timers()
-        for _ in range(nprobe):
-            tr.train_step(batch)
-        torch.cuda.synchronize()
-        hip.disable_timers()
-        kind, loop, ms = (C.c_int * cap)(), (C.c_int * cap)(), (C.c_float * cap)()
-        nrec = L.cvc_train_loop_profile_read(kind, loop, ms, cap)
-        L.cvc_train_loop_profile(0)
-        KN = ["zero_fill", "att_cell", "h2attn", "attn_scores", "attn_wsum", "lang_cell", "gate_grad_lang", "nn_lang", "attn_bwd",
-              "nn_h2attn", "gate_grad_att", "nn_att"]
-        LN = ["loopA.fwd", "loopC.fwd", "loopA.bwd", "loopC.bwd", "loops.bwd"]
-        tot, cnt = {}, {}
-        for i in range(nrec):
-            name = f"{LN[loop[i]]}.{KN[kind[i]]}"
-            tot[name] = tot.get(name, 0.0) + ms[i] / nprobe
-            cnt[name] = cnt.get(name, 0) + 1
-        cnt = {k: v // nprobe for k, v in cnt.items()}
-        for k, v in timers.items():                      # entry points called from Python (dense products, criteria, optimizer)
-            if k in ("cvc_train_loop_fwd", "cvc_train_loop_bwd", "cvc_train_loops_bwd_joint"):
-                continue
-            tot[k] = sum(a.elapsed_time(b) for a, b in v) / nprobe
-            cnt[k] = len(v) // nprobe
-        # the dense products (cvc_tile_gemm: hoisted input products, every weight gradient, the vocabulary head): their work is the
-        # sum over the launches the probe pass saw -- fp32-equivalent flops 2 M N K, operand fragments read once (6 B per element:
-        # three bf16 terms) + the K-slice slabs written
-        shapes = hip.TIMED_SHAPES.get("cvc_tile_gemm", [])
-        if shapes and cnt.get("cvc_tile_gemm"):
-            per = len(shapes) // nprobe
-            fl = sum(2.0 * K_ * M_ * N_ for K_, M_, N_, _ks in shapes) / nprobe
-            by = sum(6.0 * K_ * (M_ + N_) + 4.0 * M_ * N_ * ks_ for K_, M_, N_, ks_ in shapes) / nprobe
-            work["cvc_tile_gemm"] = dict(bytes=by / per, flops=fl / per, mfma="split")
-        ours = sum(tot.values())
-        for name in sorted(tot, key=lambda k: -tot[k]):
-            ent = dict(kernel=name, launches_per_step=cnt[name], ms_per_step=round(tot[name], 3), avg_us=round(tot[name] / max(1, cnt[name]) * 1e3, 2),
-                       share=round(tot[name] / ms_step, 4))
-            wk = work.get(name)
-            if wk:      # work per LAUNCH of this role
-                avg_s = tot[name] / cnt[name] * 1e-3
-                gbs, tf = wk["bytes"] / avg_s / 1e9, wk.get("flops", 0) / avg_s / 1e12
-                peak_tf = MFMA_BF16_PEAK_TFLOPS / 6 if wk.get("mfma") == "split" else MFMA_F32_PEAK_TFLOPS
-                bound = "mfma" if wk.get("flops", 0) / (peak_tf * 1e12) > wk["bytes"] / (HBM_PEAK_GBS * 1e9) else "hbm"
-                ent.update(algorithmic_bytes=int(wk["bytes"]), algorithmic_flops=int(wk.get("flops", 0)), achieved_GBs=round(gbs, 1),
-                           frac_hbm=round(gbs / HBM_PEAK_GBS, 4), achieved_TFLOPs=round(tf, 2), mfma_peak_TFLOPs=round(peak_tf, 1),
-                           frac_mfma=round(tf / peak_tf, 4), bound=bound, mfma=wk.get("mfma", "none"),
-                           traffic=pmc_traffic(name, args, None, mode="train", beam=1, config_name=config_name)[0])
-            kernels.append(ent)
-        # (these are event-timed EAGER launches; the step itself is timed as a graph replay, so the rows need not add up to it: the
-        # difference -- launch gaps of the eager pass against library kernels and gaps of the replay -- is stated, not booked as a row)
-        timed_note = dict(sum_of_rows_ms=round(ours, 3), step_ms=round(ms_step, 3),
-                          note="rows: HIP events around eager launches (probe pass); step: HIP-graph replay" if use_graph else "rows and step: eager")
-        dom = next((e for e in kernels if "bound" in e), None)
-        if dom is not None:
-            traffic, note = pmc_traffic(dom["kernel"], args, None, mode="train", beam=1, config_name=config_name)
-            if dom["bound"] == "mfma":
-                roof = dict(kernel=dom["kernel"], bound="mfma", achieved=dom["achieved_TFLOPs"], peak=dom["mfma_peak_TFLOPs"],
-                            unit="TFLOP/s", frac=dom["frac_mfma"], traffic=traffic, traffic_source=note, avg_us=dom["avg_us"],
-                            share=dom["share"], launches_per_step=dom["launches_per_step"], algorithmic_flops=dom["algorithmic_flops"],
-                            algorithmic_bytes=dom["algorithmic_bytes"],
-                            peak_note="fp32-equivalent flops; split-product kernels issue 6 bf16 MFMAs per fp32 product, so their "
-                                      "roof is the dense bf16 peak / 6" if dom["mfma"] == "split" else "f32 MFMA 32x32x2")
-            else:
-                roof = dict(kernel=dom["kernel"], bound="hbm", achieved=dom["achieved_GBs"], peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=dom["frac_hbm"], traffic=traffic, traffic_source=note, avg_us=dom["avg_us"], share=dom["share"],
-                            algorithmic_bytes=dom["algorithmic_bytes"])
-        # ---- CPU baseline: the oracle's cyclical forward + autograd backward on this box's host cores, one step of the
-        # same workload (eval-mode dropout: the reference's train-mode backward does not run on torch 2.x, SURVEY 8(c)(i))
-        if world == 1 and cpu_baseline and not args.no_cpu_baseline:
-            from oracle import ref_cpu as O
-            ncores = usable_cores()
-            torch.set_num_threads(ncores)
-            f_np, b_np = synth.clip_features(d, args.seed), synth.label_glue_batch(d, args.seed)
-            sd_np = synth.hot_path_state_dict(d, args.seed)
-            best = None
-            for rep in range(1 + max(1, args.cpu_repeats - 1)):
-                P = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in O.to_torch(sd_np).items()}
-                for k in list(P):
-                    if k.startswith("attended_roi_decoder_core.") and "lstm" in k:
-                        P[k] = P[k.replace("attended_roi_decoder_core.", "decoder_core.")]
-                c0 = time.perf_counter()
-                ls = O.cyclical_forward(P, O.to_torch(f_np), O.to_torch(b_np), T=d.T, vocab_size=d.V)
-                O.training_loss(ls, xe_loss_weight=0.5, w_att2=0.0, w_cls=0.0, caption_consistency_loss_weight=0.5).backward()
-                dt = time.perf_counter() - c0
-                if rep > 0 or args.cpu_repeats == 1:
-                    best = dt if best is None else min(best, dt)
-                del P, ls
-            cpu = dict(value=round(d.B * d.T / best, 1), unit="decode-steps/s", cores=torch.get_num_threads(), kind="port",
-                       sample=f"one cyclical forward + backward of the same workload (B={d.B}, T={d.T}; no optimizer step), warm-up 1, "
-                              f"best of {max(1, args.cpu_repeats - 1)}; torch {torch.__version__} CPU autograd, {ncores} host cores",
-                       seconds=round(best, 3))
-    if rank == 0:
-        line = {
-            "metric": "cyclical train decode-steps/sec (BxT per fwd+bwd+update)", "value": round(d.B * d.T * world * steps / el, 1),
-            "unit": "decode-steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
-            "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "samples_per_s": round(d.B * world * steps / el, 2), "loss": float(loss),
-            "config": {"workload": f"{config_name}: cyclical train step (decode+localize+reconstruct fwd, bwd, clip, Adam), train-mode dropout",
-                       "B_per_gpu": d.B, "global_batch": d.B * world, "N": d.N, "F": d.F, "D": d.R, "T": d.T, "hip_graph": bool(use_graph),
-                       "eager_ms_per_step": eager_ms, **({"timed_regions": regions, "region_ms_per_step": region_ms} if regions > 1 else {}),
-                       "parallelism": f"dp{world}: clips sharded, " + (f"one RCCL gradient exchange per step ({reducer.world}-rank communicator, "
-                                                                          f"inside the step)" if reducer.exchange else
-                                                                          "NO gradient exchange in this run (one rank; --always-exchange runs it)")},
-            "roofline": roof, "cpu_baseline": cpu, "exchange": exchange, "gradient_buckets": buckets, "kernel_timing": timed_note,
-            "kernels": kernels}
-        if cpu:
-            line["gpu_over_cpu"] = round(line["value"] / cpu["value"], 1)
-        return line
-    return None
 
 
 def run_encoder(args, d, dev, brief=False, steps=None, warmup=None):
@@ -606,32 +282,6 @@ def run_encoder(args, d, dev, brief=False, steps=None, warmup=None):
         backbone.HIP_GRU = True
     line.update(ms_per_step_with_library_gru=round(ms_library, 3), pieces_ms=piece_ms)
     return line
-
-
-def train_work(d):
-    """Algorithmic bytes / flops PER LAUNCH of the roles inside the two C-driven training loops (cyclical pass; SURVEY.md section
-    8(d) training formulas).  Weights stream once per launch; M = B rows.  `mfma`: which matrix instruction executes the products.
-    Names = bench.py's launch roles (loop.direction.role, csrc/train_driver.hip)."""
-    B, N, F, R, A = d.B, d.N, d.F, d.R, d.A
-    gemm = lambda k, nout=4 * R: dict(bytes=4 * nout * k + 4 * B * (k + nout), flops=2 * B * nout * k, mfma="split")
-    w = {}
-    # forward cells: the recurrent columns only (fc / word / localized-context terms are hoisted into dense products)
-    for lp in ("loopA", "loopC"):
-        w[f"{lp}.fwd.att_cell"] = gemm(2 * R)
-        w[f"{lp}.bwd.nn_att"] = gemm(2 * R)
-    w["loopA.fwd.lang_cell"], w["loopC.fwd.lang_cell"] = gemm(3 * R), gemm(2 * R)
-    w["loopA.bwd.nn_lang"], w["loopC.bwd.nn_lang"] = gemm(3 * R), gemm(2 * R)
-    w["loopA.fwd.h2attn"] = gemm(R, A)
-    w["loopA.bwd.nn_h2attn"] = gemm(R, A)
-    # attention of one step: projected rows once (scores), context rows once (weighted sum); backward: context rows once (d_attn),
-    # projected rows once (tanh recomputed)
-    # joint backward (2B <= 64: both loops' rows in one operand, cvc_train_loops_bwd_joint): 2B rows per product
-    gemm2 = lambda k: dict(bytes=4 * 4 * R * k + 4 * 2 * B * (k + 4 * R), flops=2 * 2 * B * 4 * R * k, mfma="split")
-    w["loops.bwd.nn_lang"], w["loops.bwd.nn_att"] = gemm2(3 * R), gemm2(2 * R)
-    w["loopA.fwd.attn_scores"] = dict(bytes=4 * B * (N + F) * A, flops=B * (N + F) * 4 * A, mfma="none")
-    w["loopA.fwd.attn_wsum"] = dict(bytes=4 * B * (N + F) * R, flops=2 * B * (N + F) * R, mfma="none")
-    w["loopA.bwd.attn_bwd"] = dict(bytes=4 * B * (N + F) * (A + R), flops=B * (N + F) * (8 * A + 2 * R), mfma="none")
-    return w
 
 
 def spawn_ranks(args) -> int:
@@ -874,6 +524,37 @@ def run_secondary(args, dev):
     return out
 
 
+def run_secondary_ranks(args, dev, rank, world, comm):
+    """ALL RANKS (bench.py --gpus N under a launcher, decode mode, default config).  BASELINE config 4: the cyclical training step at
+    B = 32 clips per rank with the per-bucket RCCL exchange inside the captured step, `exchange.exposed_ms` and the efficiency against
+    the same process's exchange-off step.  No rank-0-only probe passes (bench_train.py's symmetry rule); whether the entry can run
+    at all (a communicator exists) is the same on every rank by construction.  Returns the list for `secondary` (rank 0) or []."""
+    from cvc import synth
+    from cvc.distributed import control_all_reduce
+    name = (f"cfg4 cyclical train step, {world} rank(s): B=32 per GPU (global {32 * world}), the per-bucket RCCL exchange captured in the "
+            f"step on the {world}-rank communicator")
+    t0 = time.perf_counter()
+    if comm is None:
+        ent = {"error": "no RCCL communicator in this run (see `rccl`): the training step needs its exchange"}
+    else:
+        d = synth.CONFIGS["cfg4"]
+        steps = max(3, int(args.secondary_seconds * 1e3 / 12.0) + 1)
+        err = None
+        try:
+            ln = run_train(args, d, dev, rank, world, steps=steps, warmup=2, min_warm=0.2, cpu_baseline=False, config_name="cfg4",
+                           regions=3, comm=comm, always_exchange=True, probe=True)
+        except Exception as ex:      # noqa: BLE001 -- recorded in the entry; the decode line still goes out
+            ln, err = None, f"{type(ex).__name__}: {ex}"[:400]
+        # a failure on ANY rank is every rank's failure (the others may have finished their steps or not: nothing further runs)
+        bad = control_all_reduce([1.0 if err else 0.0], "max")[0] > 0
+        ent = {"error": err or "the step failed on another rank"} if bad else (brief(ln) if rank == 0 else {})
+    if rank != 0:
+        return []
+    ent["name"] = name
+    ent["wall_s"] = round(time.perf_counter() - t0, 2)
+    return [ent]
+
+
 def main():
     args = parse()
     under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
@@ -909,7 +590,8 @@ def main():
     # under a launcher (RANK set) the process group is always initialised, also for a single rank, so that the
     # barrier / max-over-ranks path is the same code at every N
     dist_on = under_launcher
-    ranks_joined = 1
+    ranks_joined = None                # counted THROUGH RCCL (one 1.0 per rank summed by the communicator itself), or null
+    ranks_control_plane = 1            # counted on the gloo control plane (says nothing about RCCL)
     comm = None
     rccl_error = None
     if dist_on:
@@ -918,25 +600,31 @@ def main():
         # watchdog thread next to the graph captures below
         import torch.distributed as dist
         from cvc.comm import RcclComm
+        from cvc.distributed import control_all_reduce
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("gloo")
+        ranks_control_plane = int(round(control_all_reduce([1.0], "sum")[0]))
+        if ranks_control_plane != args.gpus or dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: {ranks_control_plane} rank(s) joined the process group, --gpus asked for {args.gpus}")
+        # every rank ends up on the same side of the fallback: RcclComm.from_process_group() agrees on the outcome over the control
+        # plane before it returns (a rank-local ncclCommInitRank failure reaches every rank), so either all ranks hold a
+        # communicator or all of them take the branch below
         try:
             comm = RcclComm.from_process_group()
-            ranks_joined = comm.count_ranks()               # every rank adds 1.0 through RCCL: the count the communicator itself reports
+            ranks_joined = comm.count_ranks()
         except Exception as e:
             # the decode path shards by clips and has no data-path collective: its measurement does not
             # depend on the communicator, so a box on which RCCL cannot be brought up still gets its decode line -- with the
-            # failure in it and the ranks counted on the control plane.  The training step exchanges gradients: fatal there.
+            # failure in it, `ranks_joined` null and the ranks counted on the control plane only.  The training step exchanges
+            # gradients: fatal there.
             if args.mode == "train":
                 raise
-            from cvc.distributed import control_all_reduce
             comm = None
             rccl_error = f"{type(e).__name__}: {e}"[:300]
             print(f"bench.py: rank {rank}: RCCL communicator unavailable ({rccl_error}); decode has no collective, continuing",
                   file=sys.stderr, flush=True)
-            ranks_joined = int(round(control_all_reduce([1.0], "sum")[0]))
-        if ranks_joined != args.gpus or dist.get_world_size() != args.gpus:
+        if ranks_joined is not None and ranks_joined != args.gpus:
             raise SystemExit(f"bench.py: {ranks_joined} rank(s) joined the RCCL communicator, --gpus asked for {args.gpus}")
 
     import dataclasses
@@ -956,23 +644,39 @@ def main():
         line = run_train(args, d, dev, rank, world, comm=comm, always_exchange=args.always_exchange or dist_on)
     else:
         line = run_decode(args, d, dev, rank, world, dist_on, args.beam, args.steps, args.warmup, args.min_warm_seconds, True, over, args.config)
-        default_run = (args.config == "cfg2" and not over and args.beam == 1 and world == 1 and not args.no_secondary and
+        default_cfg = (args.config == "cfg2" and not over and args.beam == 1 and not args.no_secondary and
                        args.gsk is None and args.embgate is None and args.gate_ksplit is None and not args.no_graph)
-        if rank == 0 and default_run:
+        if default_cfg and world == 1 and not dist_on:
             t0 = time.perf_counter()
             line["secondary"] = run_secondary(args, dev)
             line["secondary_wall_s"] = round(time.perf_counter() - t0, 1)
+        elif default_cfg and dist_on:
+            # N ranks (the driver's `bench.py --gpus N`, or --spawn at N = 1): after the decode measurement EVERY rank runs BASELINE
+            # config 4's training step -- B = 32 clips per rank, the six-bucket RCCL exchange captured inside the step's graph -- so
+            # that one command on an 8-GPU node measures config 4 (global B = 256) with its exposed exchange time
+            t0 = time.perf_counter()
+            sec = run_secondary_ranks(args, dev, rank, world, comm)
+            if rank == 0:
+                line["secondary"] = sec
+                line["secondary_wall_s"] = round(time.perf_counter() - t0, 1)
     if rank == 0:
+        import build_hip
         line["ranks_joined"] = ranks_joined
+        line["ranks_control_plane"] = ranks_control_plane
         if rccl_error is not None:
-            line["rccl"] = "unavailable, ranks counted on the gloo control plane: " + rccl_error
+            line["rccl"] = "unavailable (ranks_joined is null; ranks_control_plane counts the gloo group): " + rccl_error
+        # which library ran: a CVC_LIB variant (A/B builds) can never be taken for the in-tree product build
+        line["library"] = dict(path=os.path.relpath(hip.LIB_PATH, ROOT) if hip.LIB_PATH.startswith(ROOT) else hip.LIB_PATH,
+                               in_tree_default=not os.environ.get("CVC_LIB"), version=hip.version(),
+                               source_hash=build_hip.source_hash(), note="source_hash = sha256 of the kernel sources in this tree")
         # LAST key of the line (a log that keeps only the tail of stdout still shows it): every measurement's headline numbers
         summ = [dict(name="headline: " + line["config"]["workload"], value=line["value"], unit=line["unit"], ms_per_step=line["ms_per_step"],
                      roofline_frac=(line.get("roofline") or {}).get("frac"))]
         for e in line.get("secondary", []):
             summ.append(dict(name=e.get("name"), value=e.get("value"), unit=e.get("unit"), ms_per_step=e.get("ms_per_step"),
                              roofline_kernel=(e.get("roofline") or {}).get("kernel"), roofline_frac=(e.get("roofline") or {}).get("frac"),
-                             **({"exchange_in_graph_ms": e["exchange"].get("in_graph_ms")} if e.get("exchange") else {}),
+                             **({"exchange_in_graph_ms": e["exchange"].get("in_graph_ms"),
+                                 "exchange_efficiency": e["exchange"].get("efficiency_vs_exchange_off")} if e.get("exchange") else {}),
                              **({"error": e["error"]} if "error" in e else {})))
         line["summary"] = summ
         emit(line)

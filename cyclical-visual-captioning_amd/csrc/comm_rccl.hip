@@ -4,6 +4,7 @@
 // the CPU-side symbol checks load the library on boxes without RCCL.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <string.h>
 #include "../../include/cvc_hip.h"
 
@@ -32,10 +33,19 @@ struct Rccl {
 Rccl& rccl() {
     static Rccl r;
     if (r.handle == nullptr) {
-        const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-        for (const char* n : names) {
-            r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-            if (r.handle) break;
+        // CVC_RCCL_LIB = full path of the RCCL build to use (a site's own build; the CPU suite's stand-in, tests/stub_rccl).  A bare
+        // "librccl.so" resolves to whatever the process already holds under that name -- under PyTorch-ROCm that is torch's bundled
+        // RCCL (libtorch_hip.so NEEDs it through an RPATH, which outranks LD_LIBRARY_PATH) -- so a path is the only way to pick another.
+        // When the variable is set and the library cannot be opened, nothing else is tried: the caller asked for THAT library.
+        const char* forced = getenv("CVC_RCCL_LIB");
+        if (forced && forced[0]) {
+            r.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        } else {
+            const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+            for (const char* n : names) {
+                r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+                if (r.handle) break;
+            }
         }
         if (r.handle) {
             r.get_id = (GetUniqueId_t)dlsym(r.handle, "ncclGetUniqueId");

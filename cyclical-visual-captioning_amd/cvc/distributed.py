@@ -367,7 +367,11 @@ class GradReducer:
         if not self.exchange:
             return
         a = self.arenas[i]
-        if self.comm is not None:
+        if self.comm is not None and not a.is_cuda:
+            # the CPU tests' stand-in transport (RcclComm(host_buffers=True) over tests/stub_rccl): the same cvc_allreduce_grads
+            # call on a host arena, synchronous -- no streams to fork or join
+            self.comm.all_reduce_(a, None)
+        elif self.comm is not None:
             # own communicator: the pair goes on the exchange stream, behind everything the step's stream (and the hook's own
             # stream, see below) has enqueued so far; plain HIP events order it -- eagerly or as edges of the captured graph
             cur = torch.cuda.current_stream()

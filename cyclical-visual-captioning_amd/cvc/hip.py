@@ -353,7 +353,15 @@ _HOST_ONLY = {"cvc_tile_rows_alloc", "cvc_col_sum_ws", "cvc_train_loop_bwd_ws", 
               "cvc_train_loop_profile", "cvc_train_loop_profile_read", "cvc_comm_unique_id", "cvc_comm_init", "cvc_comm_destroy"}
 
 
-TIMED_SHAPES: dict = {}      # enable_timers(): entry point -> [(K, M, N)] of its launches (cvc_tile_gemm: the dense products' work)
+TIMED_SHAPES: dict = {}      # enable_timers(): entry point -> the sizes of each of its launches (what bench.py prices a role's work with)
+_SHAPE_ARGS = {
+    "cvc_tile_gemm": lambda a: (int(a[3]), int(a[4]), int(a[5]), int(a[6])),            # (wb, xb, x_mblk_stride, K, M, N, ksplit, ...)
+    "cvc_tile_pack_rows_any": lambda a: (int(a[2]), int(a[3])),                         # (x, ldx, M, K, ...)
+    "cvc_tile_pack_cols": lambda a: (int(a[2]), int(a[3])),                             # (x, ldx, S, C, ...)
+    "cvc_pack_lstm_segs": lambda a: (sum(int(a[2][i]) for i in range(int(a[3]))), int(a[4])),     # (ws, lds, widths, nseg, R, ...) -> (K, R)
+    # (kind, q, w_a, inv_temp, proj, ctx, attn, d_ctx, d_fm, nclip, nq, n, A, R, d_scores, d_q, d_w_part, d_proj, d_ctxfeat)
+    "cvc_attn_bwd": lambda a: (int(a[9]), int(a[10]), int(a[11]), int(a[12]), int(a[13]), bool(a[7]), bool(a[17]), bool(a[18])),
+}
 
 
 def enable_timers() -> dict:
@@ -378,8 +386,9 @@ def enable_timers() -> dict:
             rc = _raw(*args)
             e1.record()
             timers.setdefault(_name, []).append((e0, e1))
-            if _name == "cvc_tile_gemm":      # (wb, xb, x_mblk_stride, K, M, N, ksplit, ...)
-                TIMED_SHAPES.setdefault(_name, []).append((int(args[3]), int(args[4]), int(args[5]), int(args[6])))
+            pick = _SHAPE_ARGS.get(_name)
+            if pick is not None:
+                TIMED_SHAPES.setdefault(_name, []).append(pick(args))
             return rc
         setattr(l, name, timed)
     return timers

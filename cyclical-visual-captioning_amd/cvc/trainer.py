@@ -34,7 +34,11 @@ def bucket_len(n: int, full: int, buckets: int = SHAPE_BUCKETS) -> int:
     """n rounded up to the next of `buckets` evenly spaced lengths <= full (the loader's padded length).  What lies between n and
     the bucket's length is the loader's OWN padding -- zero rows with their mask bit set (dataloader_anet.py:376-388), exactly what
     a shorter clip of the batch already carries up to the batch maximum (trainer.py:63-69) -- so the step computes the same
-    function of the batch; only the set of distinct shapes becomes small enough to keep one captured graph per shape."""
+    function of the batch, only the set of distinct shapes becomes small enough to keep one captured graph per shape.
+    ONE EXCEPTION, handled by the caller (Trainer._prepare): a clip whose proposals are ALL masked.  The reference's mask fill is the
+    finite -1e8 (model/modules.py:122-129), so such a row's softmax is uniform over all N positions of the trimmed axis and its
+    context the mean of N rows; a longer axis changes that N.  A batch that contains a clip with zero proposals is therefore
+    trimmed exactly as the reference trims it, never bucketed."""
     if buckets <= 0 or n >= full:
         return min(n, full)
     step = -(-full // buckets)
@@ -77,7 +81,12 @@ class Trainer:
         self.device = next(model.parameters()).device
         self._graph = None            # HIP-graph state of train_step_graphed
         # ---- train(): one captured graph per (bucketed) batch shape
+        # shape buckets exist for ONE purpose -- a small set of shapes to keep captured graphs for -- so they are active only while
+        # train() replays graphs (decided at the start of every train(): graph_capable()); an eager run (raw features through an
+        # encoder that cannot be captured, a c10d / gloo exchange, a non-capturable optimizer, the CPU) trims exactly as the
+        # reference does (trainer.py:63-69) and pays for no padding
         self.shape_buckets = SHAPE_BUCKETS if bool(getattr(opts, "hip_graph", 0)) else 0
+        self._active_buckets = 0
         self._graphs = {}             # shape key -> (graph, static inputs, static result)
         self._shape_seen = {}         # shape key -> eager steps taken at that shape
         self._eager_steps = 0
@@ -90,13 +99,15 @@ class Trainer:
     def _prepare(self, batch, train: bool):
         seg_feat, iseq, gts_seq, num, proposals, bboxs, box_mask, seg_id, region_feat, frm_mask, sample_idx, ppl_mask = batch
         n_prop = max(int(num[:, 1].max()), 1)
-        if train and self.shape_buckets:
-            n_prop = bucket_len(n_prop, proposals.size(1), self.shape_buckets)
+        # a clip with zero proposals is a uniform softmax over the trimmed axis (bucket_len's exception): trim such a batch exactly
+        buckets = self._active_buckets if (train and int(num[:, 1].min()) > 0) else 0
+        if buckets:
+            n_prop = bucket_len(n_prop, proposals.size(1), buckets)
         proposals, ppl_mask, region_feat = _trim(proposals, n_prop), _trim(ppl_mask, n_prop), _trim(region_feat, n_prop)
         if train:
             n_box = max(int(num[:, 2].max()), 1)
-            if self.shape_buckets:
-                n_box = bucket_len(n_box, bboxs.size(1), self.shape_buckets)
+            if buckets:
+                n_box = bucket_len(n_box, bboxs.size(1), buckets)
             bboxs, box_mask = _trim(bboxs, n_box), _trim(box_mask, n_box, 2)
             frm_mask = _trim(_trim(frm_mask, n_prop), n_box, 2)
         dev = self.device
@@ -273,7 +284,6 @@ class Trainer:
         key = _shape_key(b)
         if self._side is None:
             self._side = torch.cuda.Stream(self.device)
-            self._graph_pool = torch.cuda.graph_pool_handle()
         ent = self._graphs.get(key)
         if ent is None and (self._graph_broken or self._eager_steps < 2 or self._shape_seen.get(key, 0) < 1):
             cur = torch.cuda.current_stream()
@@ -298,7 +308,10 @@ class Trainer:
             torch.cuda.current_stream().synchronize()
             g = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode=self._capture_mode()):
+                # (every shape's graph allocates from its OWN private pool: graphs replay in data-dependent order, and PyTorch only
+                # guarantees a shared pool for graphs replayed in capture order -- a later graph's intermediates could alias an
+                # earlier graph's static result.  288 GB of HBM pay for one live set per shape, at most 16 shapes)
+                with torch.cuda.graph(g, capture_error_mode=self._capture_mode()):
                     res = self._core_step(static)
             except Exception as ex:      # noqa: BLE001 -- a model whose step cannot be captured (a host read inside the forward, a
                 # library fallback that allocates) trains eagerly from here on; said once, loudly
@@ -330,9 +343,10 @@ class Trainer:
         self.model.train()
         end = time.time()
         n_steps = len(self.train_loader) - 1                 # the reference drops the last batch (:55)
+        graphed = self.graph_capable()
+        self._active_buckets = self.shape_buckets if graphed else 0       # (read by _prepare, which the prefetcher calls)
         # batch k+1 is staged into HBM on a side stream while step k runs
         batches = DevicePrefetcher(self.train_loader, lambda raw: self._prepare(raw, True), self.device, limit=n_steps)
-        graphed = self.graph_capable()
         if self.opts.att_model != 'cyclical':
             raise ValueError('Unknown att_model: {}'.format(self.opts.att_model))
         n = self.opts.batch_size * self.opts.seq_per_img

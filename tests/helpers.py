@@ -126,3 +126,41 @@ def referee_seq_check(seq, logprob, ref, label, ref_seq=None):
         stats["gpu_equals_reference_clips"] = int((seq == np.asarray(ref_seq)).all(1).sum())
     print(f"[referee] {label}: {stats}")
     return stats
+
+
+class RecordingComm:
+    """Same interface as cvc.comm.RcclComm, any `world`, NO transport: `all_reduce_` records the call and moves no data.  Two logs:
+      * host_log   -- (numel, section) per Python-level call: eager launches and the calls made while a step is being CAPTURED;
+      * device log -- one entry per collective that actually EXECUTES on the stream it was issued on, written by two tiny device ops
+                      (scatter + counter increment) that are captured with the step: a graph replay appends its collectives exactly
+                      as a replay on RCCL would put them on the wire.
+    A run is rank-symmetric iff the logs of the run as rank 0 and of the run as rank 1 are identical call for call: that is what
+    keeps N real ranks from waiting for a collective their peers never issue (bench_train.py's rule; tests/test_gpu_train.py)."""
+
+    def __init__(self, world: int, rank: int, device, cap: int = 1 << 16):
+        self.world, self.rank, self.device = int(world), int(rank), device
+        self.section = ""
+        self.host_log = []
+        self._log = torch.zeros(cap, dtype=torch.int64, device=device)
+        self._pos = torch.zeros(1, dtype=torch.int64, device=device)
+
+    def mark(self, section: str):
+        self.section = section
+
+    def all_reduce_(self, flat, stream=None):
+        assert flat.is_cuda and flat.dtype == torch.float32 and flat.is_contiguous()
+        assert flat.numel() % (64 * self.world) == 0, "arenas are padded to equal, 256-byte aligned shards (the RS + AG branch)"
+        self.host_log.append((flat.numel(), self.section))
+        with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream()):
+            self._log.scatter_(0, self._pos, torch.full((1,), flat.numel(), dtype=torch.int64, device=flat.device))
+            self._pos.add_(1)
+
+    def device_log(self):
+        torch.cuda.synchronize()
+        return self._log[:int(self._pos.item())].tolist()
+
+    def count_ranks(self) -> int:
+        return self.world
+
+    def destroy(self):
+        pass

@@ -178,3 +178,105 @@ def test_late_flushed_weight_stays_live_and_in_the_arena():
     with pytest.raises(RuntimeError, match="received no gradient on the first step"):
         (dead * 2).sum().backward()
     red.remove_hooks()
+
+
+# ------------------------------------------------------------------ cvc_allreduce_grads at world 2, without GPUs
+STUB_SRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stub_rccl", "stub_rccl.c")
+
+
+def _build_stub(dirname) -> str:
+    """tests/stub_rccl/stub_rccl.c -> <dirname>/librccl.so (host pointers over POSIX shared memory; test infrastructure)"""
+    import subprocess
+    out = os.path.join(str(dirname), "librccl.so")
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", out, STUB_SRC, "-lpthread", "-lrt"])
+    return out
+
+
+def _stub_worker(rank, world, port, q):
+    """One rank of the stub-transport test.  CVC_RCCL_LIB (set by the parent) names the stub: csrc/comm_rccl.hip opens that path
+    instead of the "librccl.so" the process already holds (torch's bundled RCCL, loaded through libtorch_hip.so's RPATH)."""
+    try:
+        import ctypes as C
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+        from cvc import hip
+        from cvc.comm import RcclComm
+        from cvc.distributed import GradReducer, init_from_env
+        init_from_env("gloo")
+        L = hip.lib()
+        # ---- argument checks of the C-ABI itself: rank >= world, bad world, null pointers
+        h = C.c_void_p()
+        uid = (C.c_char * 128)()
+        assert L.cvc_comm_unique_id(uid) == 0 and uid.raw.startswith(b"/cvc_stub_rccl_"), "the stub is not the library that was opened"
+        for w_, r_ in ((2, 2), (2, 5), (2, -1), (0, 0)):
+            assert L.cvc_comm_init(w_, r_, uid, C.byref(h)) == -1, (w_, r_)          # CVC_E_BADARG
+        assert L.cvc_comm_init(2, 0, None, C.byref(h)) == -1 and L.cvc_comm_init(2, 0, uid, None) == -1
+        # ---- the production rendezvous: rank 0 draws the id, gloo carries it, every rank joins, every rank agrees it worked
+        comm = RcclComm.from_process_group(host_buffers=True)
+        assert (comm.world, comm.rank) == (world, rank)
+        assert comm.count_ranks() == world                         # count = 1: not divisible by 2 -> the all-reduce branch
+        assert L.cvc_allreduce_grads(comm._h, None, 8, None) == -1 and L.cvc_allreduce_grads(comm._h, uid, 0, None) == -1
+        # ---- in-place reduce-scatter + all-gather: the sum of shard r lands at grads + r * n, the gather fills the rest
+        rng = np.random.default_rng(100)
+        mine_all = [rng.standard_normal(4096).astype(np.float32) for _ in range(world)]       # every rank can compute every rank's input
+        for count in (4096, 2, 130, 4095, 1, 3):                   # even -> RS + AG pair; odd -> one all-reduce
+            bufs = [m[:count].copy() for m in mine_all]
+            want = bufs[0].copy()
+            for r_ in range(1, world):
+                want = want + bufs[r_]                             # rank order, fp32: what the stub computes, bit for bit
+            t = torch.from_numpy(bufs[rank].copy())
+            comm.all_reduce_(t)
+            assert np.array_equal(t.numpy(), want), (count, rank)
+            both = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(both, t)
+            assert torch.equal(both[0], both[1]), count            # bitwise equal across ranks
+        # ---- the reducer's bookkeeping on this transport: arenas, buckets, hooks, sinks as on RCCL; CPU arenas, no streams
+        z = np.load(os.path.join(GOLDEN, "g3_shards.npz"))
+        names = sorted(k[len("mean.grad."):] for k in z.keys() if k.startswith("mean.grad.") and not k.endswith(".is_none"))
+        params = [(n, torch.nn.Parameter(torch.zeros(z["full.grad." + n].shape))) for n in names]
+        red = GradReducer(params, bucket_mb=0.01, comm=comm)
+        assert red.backend == "rccl" and red.world == world and red.exchange and len(red.buckets) > 2
+        assert all(a.numel() % (64 * world) == 0 for a in red.arenas)           # equal, aligned shards: the RS + AG branch
+        for step in range(3):
+            red.zero_grad()
+            for n, p in params:
+                (p * torch.from_numpy(z["shard%d.grad.%s" % (rank, n)]).clone()).sum().backward()
+            if step == 2:
+                assert any(red._launched)                                       # buckets left from inside backward
+            red.finalize()
+            for n, p in params:
+                np.testing.assert_allclose(p.grad.numpy(), z["mean.grad." + n], rtol=1e-6, atol=1e-8)
+            flat = torch.cat(list(red.arenas))
+            both = [torch.zeros_like(flat) for _ in range(world)]
+            dist.all_gather(both, flat)
+            assert torch.equal(both[0], both[1])
+        red.remove_hooks()
+        dist.barrier()
+        comm.destroy()
+        with pytest.raises(RuntimeError, match="destroyed"):
+            comm.all_reduce_(torch.zeros(4))
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="host-buffer stand-in transport: CPU machines only (a GPU box runs the real RCCL tests)")
+def test_allreduce_grads_cabi_world_2_over_a_stub_librccl(tmp_path, monkeypatch):
+    """cvc_allreduce_grads (csrc/comm_rccl.hip) has only ever run with world == 1 on hardware: `rank * n == 0`, nothing on a link.
+    Here two processes load the product's libcvc_hip.so, which dlopens a stand-in librccl.so built from tests/stub_rccl/ (found
+    through CVC_RCCL_LIB: a bare "librccl.so" resolves to torch's bundled RCCL, already in the process), and run cvc_comm_init(2, r) + cvc_allreduce_grads on host
+    buffers: the in-place reduce-scatter lands the sum of shard r at grads + r * n, the all-gather fills the rest, both ranks
+    bitwise equal, odd counts take the all-reduce branch, rank >= world is CVC_E_BADARG; then GradReducer(comm=...) runs its
+    bucket bookkeeping over the same transport against the G3 shard-mean fixture."""
+    monkeypatch.setenv("CVC_RCCL_LIB", _build_stub(tmp_path))          # inherited by the two fresh interpreters below
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_stub_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert all(r[1] == "ok" for r in res), res

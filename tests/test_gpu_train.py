@@ -762,6 +762,105 @@ def test_trainer_train_replays_one_graph_per_bucketed_shape_bit_equal_to_eager(c
         assert torch.equal(finals[0][k], finals[1][k]), k
 
 
+# ------------------------------------------------------------------ rank symmetry: every rank issues the same collectives
+def test_bench_train_issues_identical_collectives_as_rank_0_and_as_rank_1():
+    """bench.py --mode train at N > 1 (round-5 review: rank 0 alone ran probe steps with the exchange on -- six collectives per step
+    the other ranks never joined -- and the run could not finish).  run_train() is run here twice in one process, as rank 0 and as
+    rank 1 of a RECORDING world-2 communicator (tests/helpers.py::RecordingComm: same interface as cvc.comm.RcclComm, no
+    transport): the two logs -- Python-level calls with the bench section they belong to, and the collectives that executed on the
+    device, graph replays included -- must be identical call for call."""
+    import bench
+    import bench_train
+    from helpers import RecordingComm
+    dev = torch.device("cuda:0")
+    d = synth.CONFIGS["tiny"]
+    args = bench.parse(["--mode", "train", "--config", "tiny", "--steps", "3", "--warmup", "1", "--min-warm-seconds", "0.0", "--no-cpu-baseline"])
+    logs = []
+    for rank in (0, 1):
+        comm = RecordingComm(2, rank, dev)
+        line = bench_train.run_train(args, d, dev, rank, 2, comm=comm, always_exchange=True, cpu_baseline=False, config_name="tiny")
+        assert (line is not None) == (rank == 0)
+        logs.append((list(comm.host_log), comm.device_log()))
+        if rank == 0:
+            assert line["n_gpus"] == 2 and line["exchange"]["ranks"] == 2 and line["exchange"]["buckets"] >= 4
+            assert all(b["launched"] for b in line["gradient_buckets"]["per_bucket"])
+            assert {k["kernel"] for k in line["kernels"]} >= {"cvc_tile_gemm", "cvc_adam_clip_step", "loopA.fwd.lang_cell"}
+    (h0, d0), (h1, d1) = logs
+    assert h0 == h1, [(a, b) for a, b in zip(h0, h1) if a != b][:5]
+    assert d0 == d1 and len(d0) > len(h0)                    # (replays execute collectives no Python call stands for)
+    sections = [s_ for _, s_ in h0]
+    # every pass that runs steps reached the communicator -- on both ranks alike
+    assert {"warm", "eager", "exchange_probe", "bucket_probe", "role_probe"} <= set(sections), sorted(set(sections))
+
+
+def test_trainer_train_issues_identical_collectives_whatever_each_ranks_batch_shapes_are():
+    """cvc.main's epoch loop (Trainer.train: the replacement of reference main.py:169 + trainer.py:39-150) with DIFFERENT batch shapes
+    per rank: rank 0 meets a shape for the first time (eager step) while rank 1 replays a captured one, and so on.  Both must put
+    the same sequence of collectives on their exchange streams -- same count per step, same bucket sizes, same order."""
+    import dataclasses
+    from cvc import dropout
+    from cvc.distributed import GradReducer
+    from helpers import RecordingComm
+    dev = torch.device("cuda:0")
+    d = dataclasses.replace(synth.CONFIGS["tiny"], B=4, N=40, K=8)
+    shapes = [(40, 8), (17, 3), (9, 5)]
+    order = {0: [0, 1, 2, 0, 1, 2, 0, 1, 2, 0], 1: [2, 2, 0, 2, 0, 1, 1, 1, 0, 2]}     # (train() drops the last batch)
+    dev_logs, host_counts, stats = [], [], []
+    for rank in (0, 1):
+        pool = _ragged_batches(dev, d, 77 + rank, shapes)
+        batches = [pool[i] for i in order[rank]]
+        o, model, _batch, Trainer, build_optimizer = _setup(dev, d, train_decoder_only=False)
+        o.disp_interval, o.hip_graph = 4, 1
+        comm = RecordingComm(2, rank, dev)
+        red = GradReducer(model.named_parameters(), comm=comm)
+        tr = Trainer(o, None, model, build_optimizer(model, o, capturable=True), batches, None, grad_reducer=red)
+        assert tr.graph_capable() and red.exchange and red.world == 2
+        dropout.seed(4711)
+        tr.train(0)
+        dev_logs.append(comm.device_log())
+        host_counts.append(len(comm.host_log))
+        stats.append(dict(tr.graph_stats))
+        red.remove_hooks()
+    assert stats[0] == dict(eager=3, replayed=6, captured=3), stats
+    assert stats[1] == dict(eager=4, replayed=5, captured=3), stats       # (its first two steps are eager whatever their shape)
+    assert dev_logs[0] == dev_logs[1], (len(dev_logs[0]), len(dev_logs[1]))
+    nb = len(red.arenas)
+    assert len(dev_logs[0]) == 9 * nb                         # one exchange of every bucket per step, eager or replayed
+    for k in range(1, 9):                                     # steps 1.. (compacted arenas): the same bucket sizes in the same order
+        assert dev_logs[0][k * nb:(k + 1) * nb] == dev_logs[0][nb:2 * nb], k
+
+
+def test_bucketed_and_exactly_trimmed_steps_agree_on_losses_and_gradients():
+    """Shape buckets pad a batch's region / box axes with the loader's own padding (zero rows, mask bits set): one step with
+    buckets = 0 (the reference's trimming, trainer.py:63-69) and one with buckets = 4 on a batch whose per-clip counts differ must
+    give the same losses and gradients within fp32 summation noise (round-5 advisor: only graphed-vs-eager under the SAME bucketing
+    was tested)."""
+    import dataclasses
+    from cvc import dropout
+    dev = torch.device("cuda:0")
+    d = dataclasses.replace(synth.CONFIGS["tiny"], B=4, N=40, K=8)
+    batch = _ragged_batches(dev, d, 91, [(17, 3)])[0]
+    got = []
+    for buckets in (0, 4):
+        o, model, _b, Trainer, build_optimizer = _setup(dev, d, train_decoder_only=False)
+        model.eval()                                          # no dropout: the masks' index space follows the padded shapes
+        tr = Trainer(o, None, model, build_optimizer(model, o), None, None)
+        tr._active_buckets = buckets
+        b = tr._prepare(batch, True)
+        assert b["ppls"].shape[1] == (20 if buckets else 17) and b["gt_bboxs"].shape[1] == (4 if buckets else 3)
+        out = tr._call(b)
+        loss = tr.loss_mix(out)[0]
+        model.zero_grad(set_to_none=True)
+        loss.backward()
+        got.append(([float(x.reshape(-1)[0]) for x in out], {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}))
+    (l0, g0), (l1, g1) = got
+    np.testing.assert_allclose(l0, l1, rtol=2e-5, atol=1e-6)
+    assert g0.keys() == g1.keys()
+    for k in g0:
+        err = float((g0[k] - g1[k]).norm()) / (float(g0[k].norm()) + 1e-12)
+        assert err < 2e-5, (k, err)
+
+
 @pytest.mark.parametrize("K,widths,MA,MC,ksplit", [(8192, (2048, 2048, 2048), 64, 64, 5), (8192, (2048, 2048), 64, 64, 8),
                                                   (4096, (1024, 512, 132), 33, 64, 3), (264, (128, 36), 64, 40, 1),
                                                   (1000, (260,), 7, 1, 4), (128, (32, 32, 32), 64, 64, 1)])

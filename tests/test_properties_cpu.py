@@ -167,6 +167,33 @@ def test_shape_buckets_of_the_training_loop():
     assert _shape_key(a) == _shape_key(b) != _shape_key(c)
 
 
+def test_prepare_buckets_only_under_graph_replay_and_never_a_batch_with_an_all_masked_clip():
+    """Trainer._prepare (reference trainer.py:63-69): exact per-batch trimming unless train() is replaying graphs (round-5 advisor:
+    buckets were on whenever --hip_graph was, also for runs that can never replay); and a batch that contains a clip with zero
+    proposals is trimmed exactly even then -- the reference's finite -1e8 fill makes that clip's softmax uniform over the trimmed
+    axis (modules.py:122-129), so padding the axis would change its context."""
+    import argparse
+    import torch
+    from cvc.trainer import Trainer
+    B, N, K = 3, 100, 20
+    o = argparse.Namespace(hip_graph=1, att_model="cyclical")
+    tr = Trainer(o, None, torch.nn.Linear(2, 2), None, None, None)
+    assert tr.shape_buckets == 4 and tr._active_buckets == 0 and not tr.graph_capable()      # CPU: never graph-capable
+
+    def batch(counts, boxes):
+        num = torch.tensor([[0, c, k] for c, k in zip(counts, boxes)])
+        return (torch.zeros(B, 5, 8), torch.zeros(B, 1, 4, dtype=torch.long), torch.zeros(B, 1, 4, dtype=torch.long), num,
+                torch.zeros(B, N, 7), torch.zeros(B, K, 5), torch.zeros(B, 1, K, 4, dtype=torch.bool), ["v_segment_0"] * B,
+                torch.zeros(B, N, 6), torch.zeros(B, N, K, dtype=torch.bool), torch.zeros(B, dtype=torch.long), torch.zeros(B, N, dtype=torch.bool))
+
+    shapes = lambda b: (b["ppls"].shape[1], b["ppls_feat"].shape[1], b["pnt_mask"].shape[1], b["gt_bboxs"].shape[1], tuple(b["mask_frms"].shape[1:]))
+    assert shapes(tr._prepare(batch([26, 7, 3], [3, 1, 2]), True)) == (26, 26, 27, 3, (26, 3))          # eager run: the reference's trimming
+    tr._active_buckets = tr.shape_buckets                                                                  # what train() sets when it replays graphs
+    assert shapes(tr._prepare(batch([26, 7, 3], [3, 1, 2]), True)) == (50, 50, 51, 5, (50, 5))
+    assert shapes(tr._prepare(batch([26, 0, 3], [3, 1, 2]), True)) == (26, 26, 27, 3, (26, 3))          # a clip without proposals: exact
+    assert shapes(tr._prepare(batch([26, 7, 3], [3, 1, 2]), False))[:3] == (26, 26, 27)                  # eval never buckets
+
+
 def test_grad_reducer_does_not_hand_out_a_view_another_producer_already_wrote():
     """GradReducer.claim (the gradient-sink protocol of the dense weight-gradient products): a parameter whose post-accumulate hook
     has fired, or whose view was already written this step, is NOT handed out for an overwriting write (round-4 advisor finding: the
