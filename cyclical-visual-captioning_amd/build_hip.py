@@ -66,6 +66,33 @@ def up_to_date() -> bool:
     return all(os.path.getmtime(f) <= t for f in deps())
 
 
+# Kernels whose correctness leans on hand-written inline assembly (loads issued and waited for by statements the compiler cannot
+# see through): their registers must never travel through scratch, where a value still in flight would be stored stale.  The
+# build FAILS if the compiler reports scratch or spills for one of them (hipcc -Rpass-analysis=kernel-resource-usage), so that a
+# compiler bump cannot regress this silently; the 128-row-vs-64-row bit-equality test in the default GPU suite is the other guard.
+NO_SCRATCH_KERNELS = {"gemm_nn.hip": ("skinny_gemm_nn_split128_kernel",)}
+
+
+def check_no_scratch(src: str, remarks: str):
+    import re
+    want = NO_SCRATCH_KERNELS.get(os.path.basename(src), ())
+    seen = set()
+    for block in remarks.split("remark: Function Name: ")[1:]:
+        name = block.split()[0]
+        hit = next((k for k in want if k in name), None)
+        if hit is None:
+            continue
+        seen.add(hit)
+        vals = {k: int(v) for k, v in re.findall(r"remark:\s+(ScratchSize \[bytes/lane\]|SGPRs Spill|VGPRs Spill): (\d+)", block)}
+        bad = {k: v for k, v in vals.items() if v != 0}
+        if bad or len(vals) < 3:
+            raise RuntimeError(f"{os.path.basename(src)}: kernel {name} must not use scratch or spill (inline-assembly loads in "
+                               f"flight): {vals}")
+    missing = set(want) - seen
+    if missing:
+        raise RuntimeError(f"{os.path.basename(src)}: no resource-usage remark for {sorted(missing)} (renamed kernel?)")
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and up_to_date():
         return OUT
@@ -80,12 +107,20 @@ def build(force: bool = False, verbose: bool = True) -> str:
         # hidden visibility: the .so exports the CVC_API declarations of include/cvc_hip.h and nothing else
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-comment", "-c", src, "-o", obj]
         cmd += extra_flags().split()      # e.g. -DCVC_ABL=1 for ablation builds, -DCVC_EXPERIMENTAL
+        checked = os.path.basename(src) in NO_SCRATCH_KERNELS
+        if checked:
+            cmd.append("-Rpass-analysis=kernel-resource-usage")
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((cmd, subprocess.Popen(cmd)))
-    for cmd, p in procs:
+        procs.append((cmd, src, checked, subprocess.Popen(cmd, stderr=subprocess.PIPE if checked else None, text=checked or None)))
+    for cmd, src, checked, p in procs:
+        err = p.communicate()[1] if checked else None
         if p.wait() != 0:
+            if err:
+                sys.stderr.write("\n".join(l for l in err.splitlines() if "kernel-resource-usage" not in l)[-8000:] + "\n")
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
+        if checked:
+            check_no_scratch(src, err)
     objs = [o for o in objs if os.path.exists(o)]
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"]
     if verbose:

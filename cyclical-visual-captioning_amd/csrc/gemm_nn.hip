@@ -481,15 +481,19 @@ __global__ __launch_bounds__(256, 1) void skinny_gemm_nn_split128_kernel(NNArgs 
                     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                                  :
                                  : "v"(xs[g] + h * XSTEP + q * 256), "s"(dst + ((h * 2 + q) * 2 + g) * 1024)
-                                 : "memory");      // (writes m0: nothing else in this kernel reads it -- LDS accesses need no
-                                                   // m0 on gfx9+, and hipcc sets m0 itself right before any use of its own)
+                                 : "memory", "m0");      // (m0 is declared clobbered: the compiler re-materialises it before any
+                                                         // use of its own)
         xs[0] += 2 * XSTEP;
         xs[1] += 2 * XSTEP;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(f.w[h * 4 + e]) : "v"(wp[e]));
+                // (early-clobber output: the destination never shares registers with the address; the value becomes valid only at
+                // the CVC_NN128_WAIT statement it passes through ("+v") -- every read of it sits behind that statement.  What the
+                // compiler could still do between the two is MOVE the register: the build refuses scratch / spills for this kernel
+                // (build_hip.NO_SCRATCH_KERNELS) and the bit-equality test against the 64-row kernel runs in the default GPU suite)
+                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(f.w[h * 4 + e]) : "v"(wp[e]));
                 wp[e] += WSTEP;
             }
     };

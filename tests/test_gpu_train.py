@@ -789,8 +789,9 @@ def test_bench_train_issues_identical_collectives_as_rank_0_and_as_rank_1():
     assert h0 == h1, [(a, b) for a, b in zip(h0, h1) if a != b][:5]
     assert d0 == d1 and len(d0) > len(h0)                    # (replays execute collectives no Python call stands for)
     sections = [s_ for _, s_ in h0]
-    # every pass that runs steps reached the communicator -- on both ranks alike
-    assert {"warm", "eager", "exchange_probe", "bucket_probe", "role_probe"} <= set(sections), sorted(set(sections))
+    # every pass that launches eager steps (or captures) reached the communicator from Python -- on both ranks alike; the timed
+    # region and the exchange probe's exchange-on steps are graph replays (device log only)
+    assert {"warm", "eager", "bucket_probe", "role_probe"} <= set(sections), sorted(set(sections))
 
 
 def test_trainer_train_issues_identical_collectives_whatever_each_ranks_batch_shapes_are():
