@@ -64,8 +64,13 @@ __global__ __launch_bounds__(OPT_WG) void optim_sumsq_kernel(const OptSeg* segs,
 
 // one workgroup: partial sums in chunk order -> norm, clip coefficient; every segment's step count += 1
 __global__ __launch_bounds__(OPT_WG) void optim_finalize_kernel(const OptSeg* segs, int nseg, const float* partial, int nchunk, float max_norm,
-                                                                float inv, float* out /* [0] = norm of the averaged gradient, [1] = coef */) {
+                                                                float inv, float* out /* [0] = norm of the averaged gradient, [1] = coef */,
+                                                                const int* skip) {
     __shared__ float red[OPT_WG / 64];
+    if (skip && *skip != 0) {                  // the step is void (a launch of it reported invalid outputs): no step count moves
+        if (threadIdx.x == 0) { out[0] = 0.f; out[1] = 0.f; }
+        return;
+    }
     // fixed assignment (thread t sums partials t, t + 256, ...) and a fixed combine: deterministic
     float acc = 0.f;
     for (int i = threadIdx.x; i < nchunk; i += OPT_WG) acc += partial[i];
@@ -80,10 +85,17 @@ __global__ __launch_bounds__(OPT_WG) void optim_finalize_kernel(const OptSeg* se
 }
 
 __global__ __launch_bounds__(OPT_WG) void optim_adam_kernel(const OptSeg* segs, const OptChunk* chunks, const float* norm_coef, float beta1,
-                                                            float beta2, float eps, int write_grad) {
+                                                            float beta2, float eps, int write_grad, const int* skip) {
     const OptChunk c = chunks[blockIdx.x];
     const OptSeg s = segs[c.seg];
     const long long end = c.start + OPT_CHUNK < s.n ? c.start + OPT_CHUNK : s.n;
+    if (skip && *skip != 0) {
+        // void step: p, m, v stay as they are.  write_grad == 2 promised the caller zeroed gradients (the next step's zero_grad()
+        // is folded into this pass): kept -- the void step's gradients are garbage anyway
+        if (write_grad == 2)
+            for (long long i = c.start + threadIdx.x; i < end; i += OPT_WG) s.g[i] = 0.f;
+        return;
+    }
     const float coef = norm_coef[1];
     const float t = s.step[0];                                             // already incremented by the finalize launch
     // bias corrections as torch computes them (1 - beta^t in fp32 via pow)
@@ -134,7 +146,7 @@ extern "C" int cvc_optim_chunk_elems(void) { return OPT_CHUNK; }
 
 extern "C" int cvc_adam_clip_step(const cvc_optim_seg* segs, int nseg, const cvc_optim_chunk* chunks, int nchunk, float max_norm,
                                   float inv_world, float beta1, float beta2, float eps, int write_grad, float* partial,
-                                  float* norm_coef, cvc_stream_t stream) {
+                                  float* norm_coef, const int* skip, cvc_stream_t stream) {
     static_assert(sizeof(cvc_optim_seg) == sizeof(OptSeg) && sizeof(cvc_optim_chunk) == sizeof(OptChunk), "table layouts");
     if (!segs || !chunks || !partial || !norm_coef || nseg < 1 || nchunk < 1 || inv_world <= 0.f || beta1 < 0.f || beta1 >= 1.f ||
         beta2 < 0.f || beta2 >= 1.f || eps < 0.f)
@@ -143,7 +155,7 @@ extern "C" int cvc_adam_clip_step(const cvc_optim_seg* segs, int nseg, const cvc
     const OptSeg* s = reinterpret_cast<const OptSeg*>(segs);
     const OptChunk* c = reinterpret_cast<const OptChunk*>(chunks);
     hipLaunchKernelGGL(optim_sumsq_kernel, dim3(nchunk), dim3(OPT_WG), 0, st, s, c, partial);
-    hipLaunchKernelGGL(optim_finalize_kernel, dim3(1), dim3(OPT_WG), 0, st, s, nseg, partial, nchunk, max_norm, inv_world, norm_coef);
-    hipLaunchKernelGGL(optim_adam_kernel, dim3(nchunk), dim3(OPT_WG), 0, st, s, c, norm_coef, beta1, beta2, eps, write_grad);
+    hipLaunchKernelGGL(optim_finalize_kernel, dim3(1), dim3(OPT_WG), 0, st, s, nseg, partial, nchunk, max_norm, inv_world, norm_coef, skip);
+    hipLaunchKernelGGL(optim_adam_kernel, dim3(nchunk), dim3(OPT_WG), 0, st, s, c, norm_coef, beta1, beta2, eps, write_grad, skip);
     return cvc_launch_status();
 }

@@ -157,6 +157,7 @@ class GradReducer:
             self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
             self.backend = dist.get_backend(group) if dist.is_initialized() else "none"
         self._comm_stream = None                              # the exchange stream of the `comm` transport (made on first use)
+        self._status_f = None                                 # exchange buffer of the step's status word (finalize(status=...))
         self._comm_pending = False
         seen, params = set(), []
         for name, p in named_params:
@@ -403,9 +404,27 @@ class GradReducer:
         else:
             self._work.append(dist.all_reduce(a, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def finalize(self, average: bool = True):
+    def _exchange_status(self, status: torch.Tensor):
+        """The step's status word (cvc.hip.step_status: non-zero = a launch of this rank's step reported invalid outputs) summed over
+        the ranks, so that EVERY rank voids the step -- the void rank's gradients are already part of every rank's arenas -- and
+        every rank re-runs it later (cvc.trainer.Trainer.train).  One more in-place exchange on the exchange stream, behind the
+        buckets; a 64 x world float buffer keeps it on the same reduce-scatter + all-gather branch as the arenas."""
+        if self._status_f is None:
+            self._status_f = torch.zeros(64 * max(self.world, 1), device=status.device, dtype=torch.float32)
+        st = self._step_stream if self._step_stream is not None else torch.cuda.current_stream()
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=status.device)
+        self._comm_stream.wait_stream(st)
+        with torch.cuda.stream(self._comm_stream):
+            self._status_f[0:1].copy_(status)
+            self.comm.all_reduce_(self._status_f, self._comm_stream)
+            status.copy_(self._status_f[0:1] != 0)
+        self._comm_pending = True
+
+    def finalize(self, average: bool = True, status: Optional[torch.Tensor] = None):
         """Call after backward(): exchanges what the hooks did not, waits.  average=True leaves every gradient divided by
-        the world size; average=False leaves SUMS for clip_() to fold the 1/G into its single multiply."""
+        the world size; average=False leaves SUMS for clip_() to fold the 1/G into its single multiply.  status: the step's status
+        word (deferred error words); with an exchange on the package's communicator it is combined over the ranks as well."""
         if self._late_after_launch:
             late, self._late_after_launch = sorted(set(self._late_after_launch)), []
             raise RuntimeError(f"GradReducer: a weight gradient was written after its bucket's exchange had been launched "
@@ -434,6 +453,10 @@ class GradReducer:
             for w in self._work:
                 w.wait()
             self._work.clear()
+            if status is not None and self.world > 1:
+                if self.comm is None or not status.is_cuda:
+                    raise RuntimeError("GradReducer.finalize(status=...): the status word travels on the package's RCCL communicator only")
+                self._exchange_status(status)
             if self._comm_pending:
                 # the step's stream continues (clip + Adam read the arenas) behind the exchange stream
                 st = self._step_stream if self._step_stream is not None else torch.cuda.current_stream()

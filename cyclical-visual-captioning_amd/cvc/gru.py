@@ -166,7 +166,9 @@ class _GruLayer(torch.autograd.Function):
             rc = L.cvc_gru_seq_persistent_train_fwd(wp.data_ptr(), gi.data_ptr(), ndir * 3 * H, m * ndir * 3 * H, b_ih.data_ptr(),
                                                     b_hh.data_ptr(), m, F, H, ndir, slots.data_ptr(), y.data_ptr(), ndir * H,
                                                     m * ndir * H, gates.data_ptr(), ndir * 4 * H, m * ndir * 4 * H, sync.data_ptr(), st)
-            done = rc == 0 and int(sync[4]) == 0      # (host read: a barrier time-out repeats the layer in the per-step form)
+            # (eagerly a host read: a barrier time-out repeats the layer in the per-step form; in deferred mode -- captured training
+            # steps, cvc.hip.defer_errors -- the word is OR-ed into the step's status word and the step is re-run later if it was set)
+            done = rc == 0 and hip.error_word_ok(sync[4:5])
         if not done:
             # per-step training form: any H % 8 == 0 (and the fallback of the persistent form), one launch per time step
             hq = torch.empty(2 * ndir * ((H + 31) // 32 * 32) * 64, device=x.device, dtype=torch.float32)
@@ -195,7 +197,7 @@ class _GruLayer(torch.autograd.Function):
             rc = L.cvc_gru_seq_bwd_persistent(dy.data_ptr(), ndir * H, m * ndir * H, gates.data_ptr(), ndir * 4 * H, m * ndir * 4 * H,
                                               y.data_ptr(), ndir * H, m * ndir * H, wt.data_ptr(), m, F, H, ndir, dgi.data_ptr(),
                                               dgh.data_ptr(), slots.data_ptr(), sync.data_ptr(), st)
-            done = rc == 0 and int(sync[4]) == 0
+            done = rc == 0 and hip.error_word_ok(sync[4:5])
         if not done:
             ks = int(L.cvc_gru_seq_bwd_ksplit(H))
             work = torch.empty(ndir * (2 * m * H + 3 * H * 64 + ks * m * ((H + 127) // 128) * 128), device=x.device, dtype=torch.float32)

@@ -241,7 +241,7 @@ SIGNATURES = {
     "cvc_decode_greedy": [_P, _P],
     "cvc_decode_beam": [_P, _P],
     "cvc_optim_chunk_elems": [],
-    "cvc_adam_clip_step": [_P, _I, _P, _I, _F, _F, _F, _F, _F, _I, _P, _P, _P],
+    "cvc_adam_clip_step": [_P, _I, _P, _I, _F, _F, _F, _F, _F, _I, _P, _P, _P, _P],
     "cvc_comm_unique_id": [_P],
     "cvc_comm_init": [_I, _I, _P, C.POINTER(C.c_void_p)],
     "cvc_allreduce_grads": [_P, _P, _LL, _P],
@@ -342,6 +342,48 @@ def bump_weights_generation() -> int:
     global _weights_generation
     _weights_generation += 1
     return _weights_generation
+
+
+# --------------------------------------------------------------------------- deferred error words (graph-captured training steps)
+# The persistent GRU kernels (csrc/gru_persistent.hip, gru_bwd_persistent.hip) separate their time steps by a barrier in device
+# memory with a BOUNDED spin: when a peer workgroup never arrives (the grid is not co-resident) the kernel raises an error word in
+# its sync buffer instead of hanging the GPU, and its outputs are invalid.  Eagerly the caller reads that word on the host and
+# repeats the layer in the per-step form -- a host read per layer, which nothing that is captured into a HIP graph can contain.
+# Deferred mode keeps the verdict ON THE DEVICE: every launch ORs its error word into ONE status word (a stream operation), the
+# optimizer pass reads it and leaves the parameters, moments and step counts untouched when it is set (cvc_adam_clip_step's `skip`),
+# and the trainer reads it back together with the losses once per display interval, re-running the few steps it names on the
+# per-step forms (cvc.trainer.Trainer.train).  A time-out therefore costs one re-run step, never a corrupted update.
+_step_status: dict = {}
+_deferred_status = None
+
+
+def step_status(device) -> torch.Tensor:
+    """the device's status word: int32[1], non-zero = some launch of the current step reported invalid outputs"""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    t = _step_status.get(key)
+    if t is None:
+        t = _step_status[key] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", key))
+    return t
+
+
+def defer_errors(status) -> None:
+    """status = a step_status() tensor: error words are OR-ed into it from now on (no host reads); None: back to host reads"""
+    global _deferred_status
+    _deferred_status = status
+
+
+def errors_deferred() -> bool:
+    return _deferred_status is not None
+
+
+def error_word_ok(word: torch.Tensor) -> bool:
+    """`word`: a one-element int32 view of a launch's error word.  Deferred mode: OR it into the status word (stream operation,
+    capturable) and report True -- the verdict is taken later; otherwise read it now (host sync)."""
+    if _deferred_status is not None:
+        _deferred_status.bitwise_or_(word)
+        return True
+    return int(word) == 0
 
 
 # --------------------------------------------------------------------------- per-entry-point HIP-event timing (bench.py)

@@ -27,6 +27,9 @@ from .model.create_model import build_model
 from .trainer import Trainer, build_optimizer
 
 
+LAST_TRAINER = None
+
+
 def main(argv=None):
     parser = cvc_opts.build_parser()
     parser.add_argument("--synthetic_clips", type=int, default=128)
@@ -117,6 +120,8 @@ def main(argv=None):
     comm = exchange_comm() if (world > 1 and opt.dist_backend == "rccl") else None
     reducer = GradReducer(model.named_parameters(), comm=comm)
     trainer = Trainer(opt, full, model, optimizer, loader, val_loader, grad_reducer=reducer)
+    global LAST_TRAINER
+    LAST_TRAINER = trainer                                     # (tests and notebooks: graph / deferred-error statistics of the run)
     scheduler = ReduceLROnPlateau(optimizer, 'max', patience=opt.patience, min_lr=opt.min_lr)
     tb = utils.set_tb_logger(opt.tb_log_dir, opt.exp_name, opt.resume) if (rank == 0 and opt.tensorboard and not opt.inference_only) else None
 

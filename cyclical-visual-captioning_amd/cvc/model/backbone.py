@@ -213,11 +213,32 @@ class RegionalFeatureExtractorGVD(nn.Module):
         return (per_caption(fc_feats), segs_feat, per_caption(pool_feats), per_caption(g_pool_feats),
                 per_caption(pnt_mask), per_caption(overlaps), sample_idx_mask, cls_pred, cls_loss)
 
+    def reports_error_words(self) -> bool:
+        """the frame-context GRU's persistent forms (csrc/gru_persistent.hip, gru_bwd_persistent.hip) raise an error word on a
+        barrier time-out"""
+        return HIP_GRU and isinstance(self.context_enc, nn.GRU) and self.att_input_mode in ('both', 'featmap')
+
+    def step_capturable(self, deferred_errors: bool = False) -> bool:
+        """Can a training step through this encoder be captured into a HIP graph?  Everything here is stream work -- dense layers on
+        the tile GEMM, the fused encoder kernels, the GRU's recurrences -- except: (i) the persistent recurrences' error words, read
+        by the host unless the caller runs in deferred mode; (ii) the library fallbacks (an nn.LSTM frame encoder or a GRU width
+        outside H % 8 == 0 runs in MIOpen, whose workspace handling is not ours to capture); (iii) collect_cls_pred's boolean
+        gathers (host-sized outputs)."""
+        if self.collect_cls_pred:
+            return False
+        if self.att_input_mode not in ('both', 'featmap'):
+            return True                                        # no frame path, no recurrence
+        enc = self.context_enc
+        if not (HIP_GRU and isinstance(enc, nn.GRU) and enc.batch_first and enc.bias and enc.hidden_size % 8 == 0):
+            return False
+        return bool(deferred_errors)
+
     def _frame_context(self, x):
         """The 2-layer bidirectional frame-context RNN (backbone.py:103-106, 335-338): HIP kernels where they apply, else the
         library module -- and then says why, once."""
         enc = self.context_enc
-        capturing = x.is_cuda and torch.cuda.is_current_stream_capturing()
+        # (a capture may contain the HIP recurrence only in deferred mode: no host read of the persistent forms' error words)
+        capturing = x.is_cuda and torch.cuda.is_current_stream_capturing() and not hip.errors_deferred()
         if HIP_GRU and not torch.is_grad_enabled() and gru_hip.supported(enc, x):
             return gru_hip.gru_forward(enc, x)                        # inference: persistent / per-step recurrence + tile GEMM
         if HIP_GRU and torch.is_grad_enabled() and gru_hip.supported_train(enc, x) and not capturing:

@@ -99,10 +99,21 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
     def device(self):
         return self.logit.weight.device
 
-    def step_capturable(self) -> bool:
+    def step_capturable(self, deferred_errors: bool = False) -> bool:
         """True when a whole training step of this model can be captured into a HIP graph (cvc.trainer.Trainer.train): the hot
-        path on pre-extracted features.  With the once-per-clip encoder in front (raw features) it cannot: see Trainer.graph_capable."""
-        return isinstance(self.roi_feat_extractor, PrecomputedRegionFeatures)
+        path on pre-extracted features always; with the once-per-clip encoder in front (raw features, the reference's own flow:
+        trainer.py:39-150 -> model/backbone.py:298-351) when the encoder says so -- its persistent recurrence kernels report barrier
+        time-outs through error words, which a captured step can only carry in deferred mode (cvc.hip.defer_errors)."""
+        ext = self.roi_feat_extractor
+        if isinstance(ext, PrecomputedRegionFeatures):
+            return True
+        cap = getattr(ext, "step_capturable", None)
+        return bool(cap is not None and cap(deferred_errors=deferred_errors))
+
+    def reports_error_words(self) -> bool:
+        """does a step of this model launch kernels that report through error words (the encoder's persistent GRU)?"""
+        rep = getattr(self.roi_feat_extractor, "reports_error_words", None)
+        return bool(rep is not None and rep())
 
     def init_hidden(self, batch_size, num_layers):
         """reference :96-101"""

@@ -108,18 +108,23 @@ class ClipAdam(torch.optim.Adam):
 
     # ------------------------------------------------------------------ the step
     @torch.no_grad()
-    def clip_and_step(self, max_norm: float, inv_world: float = 1.0, write_grad: bool = True, zero_grad: bool = False):
+    def clip_and_step(self, max_norm: float, inv_world: float = 1.0, write_grad: bool = True, zero_grad: bool = False,
+                      skip: Optional[torch.Tensor] = None):
         """clip_grad_norm_(all parameters, max_norm) then step(), on the device.  inv_world = 1 / ranks when the gradients are sums
         over ranks (cvc.distributed.GradReducer.finalize(average=False)).  zero_grad: leave every gradient this step consumed
         ZERO (the next step's zero_grad() folded into the pass; instead of the clipped gradient write_grad leaves).  Returns the
-        norm as a device scalar."""
+        norm as a device scalar.  skip: a device int32 word (cvc.hip.step_status); non-zero when the pass executes = the step is void,
+        nothing but the gradients' zeroing happens (see include/cvc_hip.h)."""
+        if skip is not None and not (skip.is_cuda and skip.dtype == torch.int32 and skip.numel() >= 1):
+            raise TypeError("ClipAdam.clip_and_step: skip must be an int32 tensor on the GPU")
         t = self._build_table()
         if t is None:
             return None
         _key, seg_t, chunk_t, partial, norm_coef, nseg, nchunk, betas, eps = t
         hip._check(hip.lib().cvc_adam_clip_step(seg_t.data_ptr(), nseg, chunk_t.data_ptr(), nchunk, float(max_norm), float(inv_world),
                                                 betas[0], betas[1], eps, 2 if zero_grad else (1 if write_grad else 0), partial.data_ptr(),
-                                                norm_coef.data_ptr(), hip._stream()), "cvc_adam_clip_step")
+                                                norm_coef.data_ptr(), skip.data_ptr() if skip is not None else None, hip._stream()),
+                   "cvc_adam_clip_step")
         self.last_norm = norm_coef[0]
         return self.last_norm
 

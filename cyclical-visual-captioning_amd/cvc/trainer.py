@@ -87,6 +87,10 @@ class Trainer:
         # reference does (trainer.py:63-69) and pays for no padding
         self.shape_buckets = SHAPE_BUCKETS if bool(getattr(opts, "hip_graph", 0)) else 0
         self._active_buckets = 0
+        # deferred error words (cvc.hip.defer_errors): the step's status word while train() runs a model whose persistent kernels
+        # report time-outs (the once-per-clip encoder's GRU) as captured / replayed steps; None otherwise
+        self._status = None
+        self.deferred_stats = dict(void_steps=0, rerun_steps=0)
         self._graphs = {}             # shape key -> (graph, static inputs, static result)
         self._shape_seen = {}         # shape key -> eager steps taken at that shape
         self._eager_steps = 0
@@ -173,17 +177,19 @@ class Trainer:
             self.optimizer.zero_grad(set_to_none=set_to_none and fused is None)
             loss.backward()
             if fused is not None:
-                fused(self.opts.grad_clip, 1.0)
+                fused(self.opts.grad_clip, 1.0, **({'skip': self._status} if self._status is not None else {}))
                 return
             nn.utils.clip_grad_norm_(self.model.parameters(), self.opts.grad_clip)
         else:
             red.zero_grad()
             loss.backward()
-            red.finalize(average=False)                      # the one exchange step of the path
+            # the one exchange step of the path (+ the step's status word, so that every rank voids -- and later re-runs -- the
+            # same steps: a void step's gradients have already been summed into every rank's arenas)
+            red.finalize(average=False, status=self._status)
             if fused is not None:
                 # (the arenas hold sums over ranks: 1 / G folded into the coefficient; the gradients are read here for the last
                 # time, so the pass leaves them zero and the next step's zero_grad() has nothing to fill)
-                fused(self.opts.grad_clip, 1.0 / red.world, zero_grad=True)
+                fused(self.opts.grad_clip, 1.0 / red.world, zero_grad=True, **({'skip': self._status} if self._status is not None else {}))
                 red.mark_zeroed()
                 return
             red.clip_(self.opts.grad_clip, summed=True)
@@ -204,8 +210,16 @@ class Trainer:
         out = self._call(b)
         loss, lm, att2, cls, rec = self.loss_mix(out)
         self._backward_and_update(loss, set_to_none=False)
-        return torch.stack([loss.detach().reshape(()), lm.detach().reshape(()), att2.detach().reshape(()),
-                            cls.detach().reshape(()), rec.detach().reshape(())])
+        res = torch.stack([loss.detach().reshape(()), lm.detach().reshape(()), att2.detach().reshape(()),
+                           cls.detach().reshape(()), rec.detach().reshape(())])
+        st = self._status
+        if st is not None:
+            # deferred error words: a step some launch declared void contributes nothing to the loss sums and says so in a sixth
+            # element; the word is cleared at the END of the step (whoever sets it before a step voids that step: tests do)
+            void = st != 0
+            res = torch.cat((torch.where(void, torch.zeros_like(res), res), void.to(res.dtype)))
+            st.zero_()
+        return res
 
     def train_step_graphed(self, batch):
         """Same step as train_step, captured once into a HIP graph and replayed: the per-step Python / launch overhead
@@ -267,12 +281,68 @@ class Trainer:
         # features is; the once-per-clip encoder is not (its persistent GRU reports barrier time-outs through a host read, widths
         # outside the HIP forms run in the library) -- raw-feature runs through the encoder train with eager steps
         cap = getattr(self.model, "step_capturable", None)
-        if cap is None or not cap():
+        if cap is None or not cap(deferred_errors=self._can_defer()):
             return False
         if getattr(self.optimizer, "clip_and_step", None) is None and not all(g.get("capturable", False) for g in self.optimizer.param_groups):
             return False
         red = self.grad_reducer
         return red is None or not red.exchange or red.backend == "rccl"
+
+    def _can_defer(self) -> bool:
+        """deferred error words need an optimizer pass that honours the status word (cvc.optim.ClipAdam) and, with an exchange, a
+        transport that can carry the word inside the step (the package's RCCL communicator)"""
+        red = self.grad_reducer
+        return getattr(self.optimizer, "clip_and_step", None) is not None and self.device.type == "cuda" and \
+            (red is None or not red.exchange or red.backend == "rccl")
+
+    def _needs_deferral(self) -> bool:
+        need = getattr(self.model, "reports_error_words", None)
+        return bool(need is not None and need())
+
+    def deferred_errors(self):
+        """Context manager: error words of the model's persistent kernels go to the device's status word instead of being read by
+        the host (train() uses it whenever it replays graphs over a model that has such kernels; bench.py for the same step)."""
+        import contextlib
+        from . import hip
+
+        @contextlib.contextmanager
+        def cm():
+            if not (self._needs_deferral() and self._can_defer()):
+                yield False
+                return
+            self._status = hip.step_status(self.device)
+            self._status.zero_()
+            hip.defer_errors(self._status)
+            try:
+                yield True
+            finally:
+                hip.defer_errors(None)
+                self._status = None
+        return cm()
+
+    def rerun_void_steps(self, batches):
+        """The steps of `batches` (prepared, on the device) were void: some persistent launch reported a barrier time-out, the
+        optimizer pass left the parameters alone.  They are taken again here, eagerly, on the per-step forms (which have no barrier)
+        with host-checked error words.  Every rank of a multi-GPU run calls this with the same number of batches (the status word
+        travels with the gradient exchange).  Returns the five loss values of each re-run step."""
+        from . import gru, hip
+        hip.warn_once("trainer.void-steps", "a persistent recurrence kernel reported a barrier time-out inside a captured training step; "
+                      "the step left the parameters untouched and is re-run on the per-step forms (reported once; counts in "
+                      "Trainer.deferred_stats)")
+        keep = (gru.PERSISTENT, gru.BWD_PERSISTENT, self._status)
+        hip.defer_errors(None)
+        gru.PERSISTENT = gru.BWD_PERSISTENT = False
+        self._status = None
+        out = []
+        try:
+            for b in batches:
+                out.append(torch.stack([x.reshape(()) for x in self.train_step_prepared(b)]))
+                self.deferred_stats["rerun_steps"] += 1
+        finally:
+            gru.PERSISTENT, gru.BWD_PERSISTENT, self._status = keep
+            if self._status is not None:
+                hip.defer_errors(self._status)
+        return out
 
     def train_step_bucketed(self, b):
         """One optimisation step on a prepared batch, replayed from the HIP graph of its shape when there is one.  A shape's first
@@ -350,41 +420,67 @@ class Trainer:
         if self.opts.att_model != 'cyclical':
             raise ValueError('Unknown att_model: {}'.format(self.opts.att_model))
         n = self.opts.batch_size * self.opts.seq_per_img
-        acc, pending, last = None, 0, None           # device-side sums of [loss, lm, att2, cls, recon] since the last read-back
+        acc, pending, last = None, 0, None           # device-side sums of [loss, lm, att2, cls, recon (, void)] since the last read-back
+        kept = []                                    # deferred error words: the interval's prepared batches (a void step is re-run)
+        KEEP_MAX = 16                                # ... at most this many are held (377 MB each at config-2 size), then a read-back
+        void_flags = None
 
-        def flush(step):
+        def flush():
             """ONE host read per display interval (the reference reads four scalars per step, trainer.py:124-135): the meters get
-            the interval's means with the interval's weight, `.val` the latest step's values"""
+            the interval's means with the interval's weight, `.val` the latest step's values.  Deferred error words: the same read
+            tells which steps of the interval were void; they are re-run now and their losses join the interval's sums."""
             nonlocal acc, pending
             if acc is None:
                 return
-            sums, cur = torch.stack([acc, last]).tolist()
+            if deferred:
+                sums, cur, flags = torch.cat([acc, last, void_flags[:pending]]).split([6, 6, pending])
+                sums, cur, flags = sums.tolist(), cur.tolist(), flags.tolist()
+                void = [i for i, f in enumerate(flags) if f != 0]
+                if void:
+                    self.deferred_stats["void_steps"] += len(void)
+                    for r in self.rerun_void_steps([kept[i] for i in void]):
+                        r = r.tolist()
+                        sums[:5] = [a + b_ for a, b_ in zip(sums[:5], r)]
+                        if void[-1] == pending - 1:
+                            cur[:5] = r
+                kept.clear()
+            else:
+                sums, cur = torch.stack([acc, last]).tolist()
             for name, i in (("lm", 1), ("attn", 2), ("cls", 3), ("recon", 4)):
                 meters[name].update(sums[i] / pending, n * pending)
                 meters[name].val = cur[i]
             acc, pending = None, 0
 
         step = -1
-        for step, b in enumerate(batches):
-            meters["data"].update(time.time() - end)
-            if graphed:
-                res = self.train_step_bucketed(b)
-            else:
-                res = torch.stack([x.reshape(()) for x in self.train_step_prepared(b)])
-            acc = res.clone() if acc is None else acc.add_(res)
-            last, pending = res, pending + 1
-            if step % self.opts.disp_interval == 0:
-                flush(step)
-                meters["batch"].update((time.time() - end))
-                print('Epoch: [{0}][{1}/{2}]\tTime {b.val:.3f} ({b.avg:.3f})\tData {d.val:.3f} ({d.avg:.3f})\t'
-                      'LM Loss {l.val:.4f} ({l.avg:.4f})\tAttn Loss {a.val:.4f} ({a.avg:.4f})\t'
-                      'Cls Loss {c.val:.4f} ({c.avg:.4f})\tRecon Loss {r.val:.4f} ({r.avg:.4f})'.format(
-                          epoch, step, n_steps, b=meters["batch"], d=meters["data"], l=meters["lm"], a=meters["attn"],
-                          c=meters["cls"], r=meters["recon"]))
-            else:
-                meters["batch"].update(time.time() - end)      # (launch time of an asynchronous step; display steps include the wait)
-            end = time.time()
-        flush(step)
+        import contextlib
+        with (self.deferred_errors() if graphed else contextlib.nullcontext(False)) as deferred:
+            if deferred:
+                void_flags = torch.zeros(KEEP_MAX, device=self.device)
+            for step, b in enumerate(batches):
+                meters["data"].update(time.time() - end)
+                if graphed:
+                    res = self.train_step_bucketed(b)
+                else:
+                    res = torch.stack([x.reshape(()) for x in self.train_step_prepared(b)])
+                acc = res.clone() if acc is None else acc.add_(res)
+                if deferred:
+                    void_flags[pending:pending + 1].copy_(res[5:6])
+                    kept.append(b)
+                last, pending = res, pending + 1
+                if step % self.opts.disp_interval == 0:
+                    flush()
+                    meters["batch"].update((time.time() - end))
+                    print('Epoch: [{0}][{1}/{2}]\tTime {b.val:.3f} ({b.avg:.3f})\tData {d.val:.3f} ({d.avg:.3f})\t'
+                          'LM Loss {l.val:.4f} ({l.avg:.4f})\tAttn Loss {a.val:.4f} ({a.avg:.4f})\t'
+                          'Cls Loss {c.val:.4f} ({c.avg:.4f})\tRecon Loss {r.val:.4f} ({r.avg:.4f})'.format(
+                              epoch, step, n_steps, b=meters["batch"], d=meters["data"], l=meters["lm"], a=meters["attn"],
+                              c=meters["cls"], r=meters["recon"]))
+                else:
+                    if deferred and pending >= KEEP_MAX:
+                        flush()
+                    meters["batch"].update(time.time() - end)      # (launch time of an asynchronous step; display steps include the wait)
+                end = time.time()
+            flush()
         if tb_logger:
             tb_logger.add_scalar('train/learning_rate', self.optimizer.param_groups[0]['lr'], epoch)
             tb_logger.add_scalar('train/lm_loss', meters["lm"].avg, epoch)

@@ -762,6 +762,9 @@ CVC_API int cvc_train_loop_profile_read(int* kind, int* loop, float* ms, int cap
  * (amsgrad = False) on (p, g * coef, m, v) in ONE pass; write_grad == 1 also stores the clipped gradient back, as clip_grad_norm_
  * leaves it; write_grad == 2 stores ZERO instead -- the next step's zero_grad() folded into this pass (the gradients of a step
  * are read here for the last time).  Three launches, nothing read back by the host (graph-capturable).
+ *   skip   : NULL, or a DEVICE int: when it is non-zero at execution time the step is VOID -- no parameter, moment or step count
+ *            changes (write_grad == 2 still leaves the gradients zero).  The training step's status word (cvc.hip.step_status):
+ *            a persistent GRU launch whose barrier timed out marks the step, the host re-runs it later (cvc/trainer.py).
  *   segs   : DEVICE array of nseg parameter segments;   chunks : DEVICE array of nchunk (segment, start) pairs covering every
  *            segment in pieces of cvc_optim_chunk_elems() elements (start a multiple of it), in any fixed order;
  *   partial: nchunk floats of scratch;   norm_coef: 2 floats out -- [0] the norm of the (averaged) gradient, [1] the coefficient. */
@@ -775,7 +778,7 @@ typedef struct { int seg; int pad; long long start; } cvc_optim_chunk;
 CVC_API int cvc_optim_chunk_elems(void);
 CVC_API int cvc_adam_clip_step(const cvc_optim_seg* segs, int nseg, const cvc_optim_chunk* chunks, int nchunk, float max_norm,
                        float inv_world, float beta1, float beta2, float eps, int write_grad, float* partial,
-                       float* norm_coef, cvc_stream_t stream);
+                       float* norm_coef, const int* skip, cvc_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Multi-GPU training: the one exchange step of the path.  The reference reduces gradients inside nn.DataParallel

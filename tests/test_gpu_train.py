@@ -102,12 +102,17 @@ def test_main_entry_point_raw_features_through_encoder(tmp_path):
     (cvc/model/backbone.py) and its parameters are trained and checkpointed under the reference's key names."""
     import os
     from cvc import main as cvc_main
-    rc = cvc_main.main(["--no_cfg", "--synthetic_raw", "--max_epochs", "1", "--batch_size", "4", "--synthetic_clips", "8",
+    rc = cvc_main.main(["--no_cfg", "--synthetic_raw", "--max_epochs", "1", "--batch_size", "4", "--synthetic_clips", "28",
                         "--num_prop_per_frm", "7", "--t_attn_size", "5", "--rnn_size", "32", "--att_hid_size", "16",
                         "--input_encoding_size", "16", "--seq_length", "4", "--vis_encoding_size", "24", "--att_feat_size", "24",
                         "--tensorboard", "0", "--disp_interval", "100", "--checkpoint_path", str(tmp_path) + "/",
                         "--exp_name", "raw", "--learning_rate", "0.001"])
     assert rc == 0
+    # the reference's own training flow (raw features through the encoder every step) runs the captured step since round 6: the
+    # persistent GRU's error words stay on the device (cvc.hip.defer_errors)
+    st = cvc_main.LAST_TRAINER.graph_stats
+    assert st["captured"] >= 1 and st["replayed"] >= 3 and st["eager"] + st["replayed"] == 6, st      # (a new trimmed shape = one more eager step)
+    assert cvc_main.LAST_TRAINER.deferred_stats == dict(void_steps=0, rerun_steps=0)
     sd = torch.load(os.path.join(tmp_path, "raw", "model-best.pth"), map_location="cpu")
     for k in ("roi_feat_extractor.context_enc.weight_hh_l1_reverse", "roi_feat_extractor.att_embed.1.0.weight",
               "roi_feat_extractor.att_embed_aux.0.running_var", "roi_feat_extractor.pool_embed.0.weight",
@@ -760,6 +765,108 @@ def test_trainer_train_replays_one_graph_per_bucketed_shape_bit_equal_to_eager(c
     assert [strip(x) for x in shown[0]] == [strip(x) for x in shown[1]], (shown[0], shown[1])
     for k in finals[0]:
         assert torch.equal(finals[0][k], finals[1][k]), k
+
+
+# ------------------------------------------------------------------ raw features through the encoder: captured steps, deferred error words
+def _raw_setup(dev, n_clips=28, bs=4, H2=256, seed=3, F=6):
+    """model with the once-per-clip encoder in front (cvc.model.create_model.build_model on raw synthetic features), its loader
+    batches and options -- what cvc.main builds for --synthetic_raw; rnn_size 2 * H2 so that the GRU's persistent forms apply
+    (forward H % 128 == 0, backward H % 256 == 0)"""
+    from cvc import opts as cvc_opts
+    from cvc.data_synth import SyntheticCaptionDataset, collate
+    from cvc.model.create_model import build_model
+    from cvc.trainer import Trainer, build_optimizer
+    o = cvc_opts.build_parser().parse_args(["--batch_size", str(bs), "--num_prop_per_frm", "7", "--t_attn_size", str(F), "--rnn_size", str(2 * H2),
+                                            "--att_hid_size", "64", "--input_encoding_size", "32", "--seq_length", "4",
+                                            "--vis_encoding_size", "24", "--att_feat_size", "24", "--learning_rate", "0.001"])
+    o.test_mode = False
+    dims = synth.Dims(B=bs, N=7, F=F, R=2 * H2, A=64, E=32, T=4, G=24, K=7)
+    full = SyntheticCaptionDataset(dims, n_clips, seed, "training", raw=True)
+    o.vocab_size, o.itow, o.wtoi, o.itod, o.detect_size = full.vocab_size, full.itow, full.wtoi, full.itod, dims.DET
+    o.glove_clss, o.glove_vg_cls = torch.from_numpy(full.glove_clss), torch.from_numpy(full.glove_vg_cls)
+    o.vg_cls, o.detectron_tables = full.vg_cls, full.tables
+    o.disp_interval, o.hip_graph = 3, 1
+    torch.manual_seed(seed)
+    model = build_model(o, dev)
+    batches = [collate([full[i] for i in range(j, j + bs)]) for j in range(0, n_clips, bs)]
+    return o, model, batches, Trainer, build_optimizer
+
+
+def test_raw_feature_training_replays_captured_steps_bit_equal_to_eager(capsys):
+    """Round-5 review, missing 3: the reference's own training configuration (raw frame + region features through the encoder
+    every step, main.py:216-228 -> trainer.py:39-150 -> model/backbone.py:298-351) trained eagerly because the persistent GRU
+    kernels' error words were read by the host.  They now stay on the device (OR-ed into the step's status word, read back with
+    the losses once per display interval): Trainer.train() captures and replays the step, bit-equal to the same epoch of eager
+    steps -- parameters, BatchNorm running statistics, every displayed loss."""
+    from cvc import dropout, gru
+    dev = torch.device("cuda:0")
+    finals, shown, stats, forms = [], [], [], []
+    for graphed in (False, True):
+        o, model, batches, Trainer, build_optimizer = _raw_setup(dev)
+        tr = Trainer(o, None, model, build_optimizer(model, o), batches, None)
+        assert tr.graph_capable() and model.reports_error_words() and model.step_capturable(deferred_errors=True)
+        assert not model.step_capturable(deferred_errors=False)
+        tr._graph_broken = not graphed
+        dropout.seed(99)
+        gru.last_train_form = gru.last_bwd_form = None
+        tr.train(0)
+        torch.cuda.synchronize()
+        finals.append({k: v.detach().clone() for k, v in model.state_dict().items()})
+        shown.append([ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("Epoch")])
+        stats.append(dict(tr.graph_stats))
+        forms.append((gru.last_train_form, gru.last_bwd_form))
+        assert tr.deferred_stats == dict(void_steps=0, rerun_steps=0)
+    assert stats[0] == dict(eager=6, replayed=0, captured=0) and stats[1] == dict(eager=2, replayed=4, captured=1), stats
+    assert forms[0] == ("persistent", "persistent"), forms          # the persistent recurrences ran (and were captured)
+    strip = lambda ln: ln.split("LM Loss")[1]
+    assert len(shown[0]) == 2 and [strip(x) for x in shown[0]] == [strip(x) for x in shown[1]], (shown[0], shown[1])
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k
+
+
+def test_void_step_leaves_parameters_untouched_and_is_rerun():
+    """Deferred error words end to end: the status word set before a replayed step (what a persistent launch does on a barrier
+    time-out) voids THAT step on the device -- parameters, Adam moments and step counts as before, its losses out of the sums --
+    and the interval's read-back re-runs it on the per-step forms: the epoch ends with every batch trained exactly once."""
+    from cvc import dropout, gru, hip
+    dev = torch.device("cuda:0")
+    o, model, batches, Trainer, build_optimizer = _raw_setup(dev, n_clips=32)
+    opt = build_optimizer(model, o)
+    tr = Trainer(o, None, model, opt, batches, None)
+    dropout.seed(5)
+    # steps 0, 1 eager, 2 capture + replay, 3 .. 6 replay; step 4 is voided by hand
+    orig = tr.train_step_bucketed
+    seen, snap = [], {}
+
+    def spy(b):
+        k = len(seen)
+        if k == 4:
+            torch.cuda.synchronize()
+            snap["before"] = {n: p.detach().clone() for n, p in model.named_parameters()}
+            snap["steps"] = [float(opt.state[p]["step"]) for p in model.parameters() if p in opt.state]
+            hip.step_status(dev).fill_(1)
+        res = orig(b)
+        if k == 4:
+            torch.cuda.synchronize()
+            snap["after"] = {n: p.detach().clone() for n, p in model.named_parameters()}
+            snap["steps_after"] = [float(opt.state[p]["step"]) for p in model.parameters() if p in opt.state]
+            snap["res"] = res.clone()
+            snap["reruns_so_far"] = tr.deferred_stats["rerun_steps"]
+        seen.append(k)
+        return res
+    tr.train_step_bucketed = spy
+    gru.last_train_form = None
+    tr.train(0)
+    torch.cuda.synchronize()
+    assert len(seen) == 7
+    for n in snap["before"]:
+        assert torch.equal(snap["before"][n], snap["after"][n]), n                 # the void step changed no parameter
+    assert snap["steps"] == snap["steps_after"] and set(snap["steps"]) == {4.0}   # ... and no step count
+    assert snap["res"].tolist() == [0.0, 0.0, 0.0, 0.0, 0.0, 1.0] and snap["reruns_so_far"] == 0
+    assert tr.deferred_stats == dict(void_steps=1, rerun_steps=1)                  # read back at the interval's end, re-run once
+    assert {float(opt.state[p]["step"]) for p in model.parameters() if p in opt.state} == {7.0}      # 7 batches, 7 updates
+    assert gru.PERSISTENT and gru.BWD_PERSISTENT and not hip.errors_deferred()     # switches restored
+    assert int(hip.step_status(dev)) == 0
 
 
 # ------------------------------------------------------------------ rank symmetry: every rank issues the same collectives
