@@ -59,9 +59,11 @@ def parse(argv=None):
     for k in ("B", "N", "F", "R", "A", "E", "V", "T"):
         p.add_argument("--" + k, type=int, default=None)
     p.add_argument("--beam", type=int, default=1)
-    p.add_argument("--mode", default="decode", choices=["decode", "train", "encoder"],
+    p.add_argument("--mode", default="decode", choices=["decode", "train", "encoder", "e2e-train", "e2e-eval"],
                    help="decode = headline metric (default); train = cyclical fwd+bwd+all-reduce+Adam step (configs 3-ii / 4); "
-                        "encoder = the once-per-clip region / frame encoder (SURVEY 8(f) rank 1, library ops) per piece")
+                        "encoder = the once-per-clip region / frame encoder (SURVEY 8(f) rank 1, library ops) per piece; "
+                        "e2e-train / e2e-eval = the reference's real flow, raw features through the encoder into the hot path every "
+                        "step (bench_e2e.py; --config also takes `refdefault`, the reference's default shape)")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--gate-ksplit", type=int, default=None, choices=[0, 1, 2],
                    help="packed path: 1 = K-split gate GEMMs (activations shared through LDS + finishing kernel), 0 = full-K "
@@ -477,7 +479,7 @@ def run_decode(args, d, dev, rank, world, dist_on, beam, steps, warmup, min_warm
 
 def brief(line):
     """One secondary entry: what was measured, its time and its roofline (the per-kernel table stays with the headline)."""
-    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "exchange", "gradient_buckets")
+    keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "exchange", "gradient_buckets", "role_split")
     out = {k: line[k] for k in keep if k in line and line[k] is not None}
     ks = [k for k in line.get("kernels", []) if "kernel" in k][:4]
     out["top_kernels"] = [{kk: k[kk] for kk in ("kernel", "avg_us", "ms", "ms_per_step", "share", "frac_hbm", "frac_mfma") if kk in k} for k in ks]
@@ -521,6 +523,15 @@ def run_secondary(args, dev):
     attempt("cfg5 greedy decode", lambda: decode("cfg5", 1, 19.0))
     attempt("cfg5 beam=5 decode", lambda: decode("cfg5", 5, 48.0))
     attempt("once-per-clip encoder (cfg2 size)", lambda: brief(run_encoder(args, synth.CONFIGS["cfg2"], dev, brief=True, steps=8, warmup=2)))
+    # the reference's real flow: raw features through the encoder into the hot path every step (bench_e2e.py; CPU baselines of these
+    # are in the `--mode e2e-*` lines under profiles/: a host pass of this size takes 10 - 30 s)
+    from bench_e2e import dims_of, run_e2e
+
+    def e2e(cfg, what, steps):
+        return brief(run_e2e(args, dims_of(cfg), dev, what, steps=steps, warmup=2, config_name=cfg, cpu_baseline=False))
+    attempt("end-to-end train step, raw features through the encoder (cfg2 size), HIP-graph replay", lambda: e2e("cfg2", "train", 5))
+    attempt("end-to-end eval, raw features: encoder + greedy decode (cfg2 size)", lambda: e2e("cfg2", "eval", 8))
+    attempt("end-to-end train step at the reference's default shape (B=48, N=1000, F=480, R=1024)", lambda: e2e("refdefault", "train", 5))
     return out
 
 
@@ -632,7 +643,8 @@ def main():
     from cvc import hip
     hip.lib()
 
-    d = synth.CONFIGS[args.config]
+    from bench_e2e import dims_of, run_e2e
+    d = dims_of(args.config)
     over = {k: getattr(args, k) for k in ("B", "N", "F", "R", "A", "E", "V", "T") if getattr(args, k) is not None}
     if over:
         d = dataclasses.replace(d, **over)
@@ -640,6 +652,9 @@ def main():
     if args.mode == "encoder":
         if rank == 0:
             line = run_encoder(args, d, dev)
+    elif args.mode in ("e2e-train", "e2e-eval"):
+        if rank == 0:
+            line = run_e2e(args, d, dev, "eval" if args.mode == "e2e-eval" else "train")
     elif args.mode == "train":
         line = run_train(args, d, dev, rank, world, comm=comm, always_exchange=args.always_exchange or dist_on)
     else:

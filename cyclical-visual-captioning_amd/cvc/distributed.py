@@ -238,6 +238,23 @@ class GradReducer:
         self._step_stream = None
         self.ready_events: Dict[int, "torch.cuda.Event"] = {}
 
+    def bind_stream(self, stream) -> None:
+        """Re-create the parameters' gradient accumulators under `stream`.  autograd runs an AccumulateGrad node on the stream that
+        was current when the node was CREATED, and a registered post-accumulate hook keeps the node alive for the whole run: nodes
+        made when this reducer was built (typically under the default stream) make every backward pass fork to that stream and
+        back for each accumulated gradient -- in a captured step that is a graph with one side branch per parameter.  The trainer
+        calls this once with the stream its steps run on (eager, capture and replay alike), before its first step."""
+        if not self._hooks or not self.arenas or not self.arenas[0].is_cuda:
+            return
+        for h in self._hooks:
+            h.remove()
+        self._hooks.clear()
+        import gc
+        gc.collect()                                          # the old accumulators die with their last reference (the hooks)
+        with torch.cuda.stream(stream):
+            self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for b in self.buckets for _, p in b]
+        self._bound_stream = stream
+
     # ------------------------------------------------------------------ gradient bookkeeping
     def mark_zeroed(self):
         """The optimizer step left every gradient it consumed zero (cvc.optim.ClipAdam.clip_and_step(zero_grad=True)): the next

@@ -234,13 +234,15 @@ class Trainer:
             static = {k: (v.clone() if isinstance(v, torch.Tensor) else ({kk: vv.clone() for kk, vv in v.items()} if isinstance(v, dict) else v))
                       for k, v in b.items()}
             s = torch.cuda.Stream()
+            if self.grad_reducer is not None:
+                self.grad_reducer.bind_stream(s)                    # gradient accumulators on the stream of warm-up AND capture
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 for _ in range(3):                                  # warm-up on a side stream (allocator, lazy init, Adam state)
                     self._core_step(static)
             torch.cuda.current_stream().wait_stream(s)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode=self._capture_mode()):
+            with torch.cuda.graph(g, stream=s, capture_error_mode=self._capture_mode()):
                 res = self._core_step(static)
             self._graph = (g, static, res)
         g, static, res = self._graph
@@ -353,7 +355,11 @@ class Trainer:
         Returns [loss, lm, att2, cls, recon] on the device (static for replayed steps: read or clone before the next step)."""
         key = _shape_key(b)
         if self._side is None:
+            # ONE stream for eager steps, captures and replays; the reducer's gradient accumulators are re-created under it (a node
+            # made under another stream would fork every backward pass -- and every captured graph -- once per parameter)
             self._side = torch.cuda.Stream(self.device)
+            if self.grad_reducer is not None:
+                self.grad_reducer.bind_stream(self._side)
         ent = self._graphs.get(key)
         if ent is None and (self._graph_broken or self._eager_steps < 2 or self._shape_seen.get(key, 0) < 1):
             cur = torch.cuda.current_stream()
@@ -381,7 +387,7 @@ class Trainer:
                 # (every shape's graph allocates from its OWN private pool: graphs replay in data-dependent order, and PyTorch only
                 # guarantees a shared pool for graphs replayed in capture order -- a later graph's intermediates could alias an
                 # earlier graph's static result.  288 GB of HBM pay for one live set per shape, at most 16 shapes)
-                with torch.cuda.graph(g, capture_error_mode=self._capture_mode()):
+                with torch.cuda.graph(g, stream=self._side, capture_error_mode=self._capture_mode()):
                     res = self._core_step(static)
             except Exception as ex:      # noqa: BLE001 -- a model whose step cannot be captured (a host read inside the forward, a
                 # library fallback that allocates) trains eagerly from here on; said once, loudly

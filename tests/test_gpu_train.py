@@ -964,8 +964,11 @@ def test_bucketed_and_exactly_trimmed_steps_agree_on_losses_and_gradients():
     (l0, g0), (l1, g1) = got
     np.testing.assert_allclose(l0, l1, rtol=2e-5, atol=1e-6)
     assert g0.keys() == g1.keys()
+    # (a gradient that is zero in exact arithmetic -- alpha_net.bias shifts every score of a softmax alike -- is rounding noise on
+    # both sides: the error is measured against the parameter's own gradient norm or 1e-4 of the largest one, whichever is larger)
+    top = max(float(g.norm()) for g in g0.values())
     for k in g0:
-        err = float((g0[k] - g1[k]).norm()) / (float(g0[k].norm()) + 1e-12)
+        err = float((g0[k] - g1[k]).norm()) / max(float(g0[k].norm()), 1e-4 * top)
         assert err < 2e-5, (k, err)
 
 
