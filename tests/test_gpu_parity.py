@@ -385,14 +385,16 @@ def test_split_product_gemm_is_fp32_grade(dev, lib, M, K, N):
 @pytest.mark.parametrize("nq", [2, 5, 7])
 def test_multi_query_additive_scores_large_values_take_the_direct_form(dev, lib, nq):
     """Several additive queries per clip use tanh(p + q) = 1 - 2 / (1 + 2^(Cp) 2^(Cq)) with the two factors computed separately
-    (one transcendental per element instead of two); values beyond |20| must fall back to the direct form -- per feature row
-    for p, per workgroup for q -- or the product would overflow / flush.  Checked against fp64 with planted large entries of
-    both signs (p = 45 with q = -44 is tanh(1), not tanh(inf))."""
+    (one transcendental per element-query instead of two; csrc/attn_scores.h, round 6).  A workgroup whose queries hold a value
+    beyond |10.4| runs the direct form (the product of the factors could overflow / flush); inside a factored workgroup C p is
+    clamped to +-62, which changes nothing: with |q| <= 10.4 such a p has tanh(p + q) = +-1 to the last bit either way.  Checked
+    against fp64 with planted large entries of both signs (p = 45 with q = -44 is tanh(1), not tanh(inf))."""
     g = torch.Generator().manual_seed(nq)
     nclip, N, A, R = 3, 70, 256, 64
     P = torch.randn(nclip, N, A, generator=g)
     q = torch.randn(nclip * nq, A, generator=g)
-    P[0, 3, 5], P[0, 3, 6], P[1, 40, 0] = 45.0, -60.0, 21.0             # rows 3 / 40 of clips 0 / 1: direct form for the row
+    P[0, 3, 5], P[0, 3, 6], P[1, 40, 0] = 45.0, -60.0, 21.0             # clip 0: direct form (its q below); clip 1: factored, p = 21 unclamped
+    P[1, 41, 3], P[1, 42, 4], P[1, 42, 5] = 45.0, -60.0, 1e30           # clip 1, factored form: clamped p (saturated tanh)
     q[nq * 2 + 1, 7] = -44.0                                                # clip 2: direct form for the whole workgroup
     q[0, 5] = -44.0                                                         # clip 0, query 0: p + q = 1 at [3, 5]
     w = torch.randn(A, generator=g) * 0.2
