@@ -10,6 +10,7 @@
 //        memory (the dense dW / dX products of the host side read them), dgh_t of the own units to the step's exchange slot
 //        with write-through stores; arrival.
 #include "cvc_common.h"
+#include <stdlib.h>
 #include "gemm_split.h"
 
 namespace {
@@ -197,9 +198,22 @@ int launch_bwd(GruBArgs& a, int ndir, hipStream_t st) {
         return CVC_E_BADARG;
     }
     if ((long long)per_cu * cus < (long long)grid.x * grid.y) return CVC_E_BADARG;
-    if (hipLaunchCooperativeKernel((const void*)gru_bwd_persistent_kernel<NKS>, grid, dim3(512), params, 0, st) != hipSuccess) {
-        (void)hipGetLastError();
-        return CVC_E_BADARG;
+    // An ORDINARY launch, not hipLaunchCooperativeKernel (round 6).  Co-residency is what the kernel needs, and the occupancy check
+    // above plus the stream's in-order execution give it (the grid is at most one workgroup per CU on an otherwise idle chip);
+    // what the cooperative launch adds is a trip through the runtime's device-wide cooperative queue -- and with it a state of the
+    // runtime's hardware queues in which, once any other stream capture has happened in the process, EVERY later kernel of the
+    // step took 10 - 25 us longer (the captured end-to-end training step 91 -> 122 ms; tools/runs/r06_e2e_after_decode.py,
+    // GPU_MAX_HW_QUEUES <= 2 or per-step GRU forms made it disappear).  A grid that is not resident after all is caught as before:
+    // the barrier's spin is bounded and raises the error word (the caller falls back / the step is voided and re-run).
+    // CVC_GRU_COOPERATIVE=1 restores the cooperative launch (A/B).
+    static const bool coop = [] { const char* e = getenv("CVC_GRU_COOPERATIVE"); return e && e[0] == '1'; }();
+    if (coop) {
+        if (hipLaunchCooperativeKernel((const void*)gru_bwd_persistent_kernel<NKS>, grid, dim3(512), params, 0, st) != hipSuccess) {
+            (void)hipGetLastError();
+            return CVC_E_BADARG;
+        }
+    } else {
+        hipLaunchKernelGGL((gru_bwd_persistent_kernel<NKS>), grid, dim3(512), 0, st, a);
     }
     return cvc_launch_status();
 }

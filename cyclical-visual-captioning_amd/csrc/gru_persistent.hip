@@ -16,6 +16,7 @@
 //     other 31 hit its L2.  The spin is bounded: if a peer never arrives (not all workgroups resident) the kernel raises the
 //     error word instead of hanging the GPU, and the host falls back to the per-step form.
 #include "cvc_common.h"
+#include <stdlib.h>
 #include "gemm_split.h"
 
 namespace {
@@ -270,9 +271,22 @@ int launch_persistent(GruPArgs& a, int ndir, hipStream_t st) {
     if (hipGetDevice(&devid) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid) != hipSuccess)
         return CVC_E_BADARG;
     if ((long long)per_cu * cus < (long long)grid.x * grid.y) return CVC_E_BADARG;     // would not be co-resident
-    if (hipLaunchCooperativeKernel((const void*)gru_persistent_kernel<NH, MT, NC, NW>, grid, dim3(NW * 64), params, 0, st) != hipSuccess) {
-        (void)hipGetLastError();
-        return CVC_E_BADARG;
+    // An ORDINARY launch, not hipLaunchCooperativeKernel (round 6).  Co-residency is what the kernel needs, and the occupancy check
+    // above plus the stream's in-order execution give it (the grid is at most one workgroup per CU on an otherwise idle chip);
+    // what the cooperative launch adds is a trip through the runtime's device-wide cooperative queue -- and with it a state of the
+    // runtime's hardware queues in which, once any other stream capture has happened in the process, EVERY later kernel of the
+    // step took 10 - 25 us longer (the captured end-to-end training step 91 -> 122 ms; tools/runs/r06_e2e_after_decode.py,
+    // GPU_MAX_HW_QUEUES <= 2 or per-step GRU forms made it disappear).  A grid that is not resident after all is caught as before:
+    // the barrier's spin is bounded and raises the error word (the caller falls back / the step is voided and re-run).
+    // CVC_GRU_COOPERATIVE=1 restores the cooperative launch (A/B).
+    static const bool coop = [] { const char* e = getenv("CVC_GRU_COOPERATIVE"); return e && e[0] == '1'; }();
+    if (coop) {
+        if (hipLaunchCooperativeKernel((const void*)gru_persistent_kernel<NH, MT, NC, NW>, grid, dim3(NW * 64), params, 0, st) != hipSuccess) {
+            (void)hipGetLastError();
+            return CVC_E_BADARG;
+        }
+    } else {
+        hipLaunchKernelGGL((gru_persistent_kernel<NH, MT, NC, NW>), grid, dim3(NW * 64), 0, st, a);
     }
     return cvc_launch_status();
 }
