@@ -127,6 +127,35 @@ __global__ __launch_bounds__(WG) void ctxfeat_bwd_kernel(const float* attn, cons
     }
 }
 
+// d_feat[clip, i, :] += sum_q attn[q * sa_q + clip * sa_c + i] * g[(q * sg_q + clip * sg_c) * R + :]   -- the context-feature gradient
+// of ALL nq queries of a clip in one pass: a workgroup = (256 columns, a chunk of feature rows, clip) stages the nq gradient rows'
+// columns in LDS once, then every wave walks its feature rows with the nq weights of a row as scalars -- each row of d_feat is read
+// and written ONCE (ctxfeat_bwd_kernel re-reads and re-writes the whole tensor per query: 20 x 2 x 304 MB at config 3 with T = 20).
+// Strides cover both callers: the training loop's arenas ([T][B][n] weights, [T][128][R] gradients: sa_q = B n, sa_c = n,
+// sg_q = 128, sg_c = 1) and cvc_attn_bwd's [clip][q] rows (sa_q = n, sa_c = nq n, sg_q = 1, sg_c = nq).
+constexpr int CFB_ROWS = 64, CFB_MAXQ = 32;
+__global__ __launch_bounds__(WG) void ctxfeat_bwd_batched_kernel(const float* attn, long long sa_q, long long sa_c, const float* g,
+                                                                 long long sg_q, long long sg_c, int nq, int n, int R, float* d_feat) {
+    __shared__ f32x4 gs[CFB_MAXQ][64];
+    const int cb = blockIdx.x, chunk = blockIdx.y, clip = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = cb * 256 + lane * 4;
+    const bool ok = col < R;
+    for (int q = wave; q < nq; q += 4)
+        gs[q][lane] = ok ? ld4(g + ((size_t)q * sg_q + (size_t)clip * sg_c) * R + col) : f32x4{0, 0, 0, 0};
+    __syncthreads();
+    const int i_end = min(n, (chunk + 1) * CFB_ROWS);
+    const float* aw = attn + (size_t)clip * sa_c;
+    for (int i = chunk * CFB_ROWS + wave; i < i_end; i += 4) {
+        f32x4 acc = {0, 0, 0, 0};
+        for (int q = 0; q < nq; ++q) acc += aw[(size_t)q * sa_q + i] * gs[q][lane];
+        if (ok) {
+            float* D = d_feat + ((size_t)clip * n + i) * R + col;
+            st4(D, ld4(D) + acc);
+        }
+    }
+}
+
 // out[clip, i, :] = sum_q w[clip][q * ws_q + i * ws_i] * rows[clip, q, :]   (i < ni, q < nq; rows [nclip, nq, R], out [nclip, ni, R])
 // -- the two small per-clip products of the grounder's backward: a workgroup = (256 columns, output row i, clip); waves split q
 __global__ __launch_bounds__(WG) void weighted_rows_kernel(const float* w, long long w_clip, int ws_q, int ws_i, const float* rows,
@@ -157,6 +186,15 @@ __global__ __launch_bounds__(WG) void grounder_epilogue_kernel(const float* bias
     out[i] = v;
 }
 
+// context-feature gradient of the [clip][q] row layout (cvc_attn_bwd): one pass for several queries per clip, the per-query kernel for one
+inline void ctxfeat_rows(const float* attn, const float* d_ctx, int nclip, int nq, int n, int R, float* d_ctxfeat, hipStream_t st) {
+    if (nq > 1 && nq <= CFB_MAXQ)
+        hipLaunchKernelGGL(ctxfeat_bwd_batched_kernel, dim3((R + 255) / 256, (n + CFB_ROWS - 1) / CFB_ROWS, nclip), dim3(WG), 0, st, attn,
+                           (long long)n, (long long)nq * n, d_ctx, 1LL, (long long)nq, nq, n, R, d_ctxfeat);
+    else
+        hipLaunchKernelGGL(ctxfeat_bwd_kernel, dim3((R + 255) / 256, nclip), dim3(WG), 0, st, attn, d_ctx, nq, n, R, d_ctxfeat);
+}
+
 }  // namespace
 
 extern "C" int cvc_attn_bwd(int kind, const float* q, const float* w_a, float inv_temp, const float* proj,
@@ -183,8 +221,7 @@ extern "C" int cvc_attn_bwd(int kind, const float* q, const float* w_a, float in
         int rc = cvc_attn_weighted_rows(d_scores, proj, nclip, nq, n, A, inv_temp, d_q, stream);
         if (rc != CVC_E_TOOBIG) {
             if (rc) return rc;
-            if (d_ctxfeat != nullptr && d_ctx != nullptr)
-                hipLaunchKernelGGL(ctxfeat_bwd_kernel, dim3((R + 255) / 256, nclip), dim3(WG), 0, st, attn, d_ctx, nq, n, R, d_ctxfeat);
+            if (d_ctxfeat != nullptr && d_ctx != nullptr) ctxfeat_rows(attn, d_ctx, nclip, nq, n, R, d_ctxfeat, st);
             return cvc_launch_status();
         }
     }
@@ -197,9 +234,15 @@ extern "C" int cvc_attn_bwd(int kind, const float* q, const float* w_a, float in
         if (d_proj != nullptr) hipLaunchKernelGGL((attn_score_bwd_kernel<CVC_ATTN_DOT, true>), grid, dim3(WG), 0, st, a);
         else hipLaunchKernelGGL((attn_score_bwd_kernel<CVC_ATTN_DOT, false>), grid, dim3(WG), 0, st, a);
     }
-    if (d_ctxfeat != nullptr && d_ctx != nullptr)
-        hipLaunchKernelGGL(ctxfeat_bwd_kernel, dim3((R + 255) / 256, nclip), dim3(WG), 0, st, attn, d_ctx, nq, n, R,
-                           d_ctxfeat);
+    if (d_ctxfeat != nullptr && d_ctx != nullptr) ctxfeat_rows(attn, d_ctx, nclip, nq, n, R, d_ctxfeat, st);
+    return cvc_launch_status();
+}
+
+// the training loop's form: every step's weights [T][B][n] and context gradients [T][128][R] (cvc_train_loop.d_ctx_all)
+extern "C" int cvc_ctxfeat_bwd_steps(const float* attn, const float* d_ctx_all, int T, int B, int n, int R, float* d_feat, cvc_stream_t stream) {
+    if (!attn || !d_ctx_all || !d_feat || T < 1 || T > CFB_MAXQ || B < 1 || n < 1 || (R & 3)) return CVC_E_BADARG;
+    hipLaunchKernelGGL(ctxfeat_bwd_batched_kernel, dim3((R + 255) / 256, (n + CFB_ROWS - 1) / CFB_ROWS, B), dim3(WG), 0, (hipStream_t)stream,
+                       attn, (long long)B * n, (long long)n, d_ctx_all, 128LL, 1LL, T, n, R, d_feat);
     return cvc_launch_status();
 }
 

@@ -289,6 +289,9 @@ int run_bwd(const cvc_train_loop* LA, const cvc_train_loop* LC, hipStream_t st, 
     const int A = LA ? LA->A : 0, N = LA ? LA->N : 0, F = LA ? LA->F : 0;
     const BwdWs w = carve(L0.bwd_ws, two ? 128 : 64, R, A);
     const bool feat_grads = LA != nullptr && (LA->d_pool || LA->d_conv);     // the context-feature gradient reads d_ctx as a finished tensor
+    // ... of every step, kept in LA->d_ctx_all and turned into d_pool / d_conv by ONE pass after the loop (each feature row read and
+    // written once) -- per step it is a read-modify-write of both feature tensors: 2 x 304 MB x T at config 3
+    const bool feat_batched = feat_grads && LA->d_ctx_all != nullptr && T <= 32;
     const cvc_grad_src none{nullptr, 0, 0, 0};
     cvc_grad_src g_hl_a = none, g_hl_b = none, g_ha_prev = none;       // what step t + 1 left for step t (all M rows)
     const cvc_train_loop* loops[2] = {LA, LC};
@@ -327,7 +330,8 @@ int run_bwd(const cvc_train_loop* LA, const cvc_train_loop* LC, hipStream_t st, 
             cvc_nn_seg segs[3];
             cvc_grad_src out[3];
             int ns = 0, i_ctx = -1, i_ha, i_hl = -1;
-            if (LA) { i_ctx = ns; segs[ns++] = cvc_nn_seg{L0.w_ih_lang, w.d_ctx, L0.ld_ih_lang, R, R}; }
+            float* d_ctx_t = feat_batched ? LA->d_ctx_all + (size_t)t * 128 * R : w.d_ctx;
+            if (LA) { i_ctx = ns; segs[ns++] = cvc_nn_seg{L0.w_ih_lang, d_ctx_t, L0.ld_ih_lang, R, R}; }
             i_ha = ns; segs[ns++] = cvc_nn_seg{L0.w_ih_lang + R, w.d_ha_a, L0.ld_ih_lang, R, R};
             if (t > 0) { i_hl = ns; segs[ns++] = cvc_nn_seg{L0.w_hh_lang, w.d_hl_a, R, R, R}; }
             CVC_TRY_K(K_NN_LANG, nn(w.dgq, 4 * R, M, segs, ns, w.nn_l, out, feat_grads, st, two ? w.dgq2 : nullptr, BC));
@@ -354,7 +358,7 @@ int run_bwd(const cvc_train_loop* LA, const cvc_train_loop* LC, hipStream_t st, 
             const cvc_grad_src qsrc{L.q + (size_t)t * qs * B * A, A, (long long)B * A, qs};
             CVC_TRY_K(K_ATTN_BWD, cvc_attn_bwd_pair(L.attn_kind, &qsrc, L.wp_h ? L.b_h : nullptr, L.w_a, L.inv_temp, sets, 2, &g_ctx, B, 1, A, R,
                                       L.dq + (size_t)t * B * A, w.dqq, L.dwa_part ? L.dwa_part + (size_t)t * B * A : nullptr,
-                                      any_dp ? d_proj : nullptr, feat_grads ? d_cf : nullptr, st));
+                                      any_dp ? d_proj : nullptr, (feat_grads && !feat_batched) ? d_cf : nullptr, st));
             cvc_nn_seg seg{L.w_h, w.d_ha_b, R, R, R};
             CVC_TRY_K(K_NN_H2ATTN, nn(w.dqq, A, B, &seg, 1, w.nn_h, &g_ha_b, false, st));
         }
@@ -380,6 +384,11 @@ int run_bwd(const cvc_train_loop* LA, const cvc_train_loop* LC, hipStream_t st, 
             g_hl_b = out[0];
             g_ha_prev = out[1];
         }
+    }
+    if (feat_batched) {
+        g_prof_loop = 2;
+        if (LA->d_pool) CVC_TRY_K(K_ATTN_BWD, cvc_ctxfeat_bwd_steps(LA->attn_r, LA->d_ctx_all, T, BA, N, R, LA->d_pool, st));
+        if (LA->d_conv) CVC_TRY_K(K_ATTN_BWD, cvc_ctxfeat_bwd_steps(LA->attn_f, LA->d_ctx_all, T, BA, F, R, LA->d_conv, st));
     }
     if (launches) *launches = n;
     return 0;

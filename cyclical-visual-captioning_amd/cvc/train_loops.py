@@ -318,6 +318,10 @@ class _Loop(torch.autograd.Function):
                 if ni[5 + i]:
                     grads_feat[i] = torch.zeros_like(keep[src])
                     setattr(L, name, _ptr(grads_feat[i]))
+            if grads_feat[0] is not None or grads_feat[2] is not None:
+                # every step's context gradient, so that the context-feature gradients are one pass after the loop (cvc_hip.h)
+                x["d_ctx_all"] = e(T, 128, R)
+                L.d_ctx_all = _ptr(x["d_ctx_all"])
         return grads_feat, live
 
     @staticmethod

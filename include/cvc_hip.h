@@ -735,6 +735,10 @@ typedef struct cvc_train_loop {
     float *ds_r, *ds_f;          /* kind 0: [T][B][N], [T][B][F] gradients of the pre-softmax scores                     */
     float *d_pool, *d_ppool, *d_conv, *d_pconv;    /* kind 0: accumulated feature gradients, nullable                    */
     float* bwd_ws;               /* cvc_train_loop_bwd_ws(B, R, A) floats, ZERO before the first use                     */
+    float* d_ctx_all;            /* kind 0, nullable: [T][128][R] floats.  With d_pool / d_conv: the context gradient of EVERY step
+                                  * is kept here and the context-feature gradients d_pool[b,n,:] += sum_t attn_t[b,n] d_ctx_t[b,:]
+                                  * are taken in ONE pass after the loop (each feature row read and written once) instead of a
+                                  * read-modify-write of both feature tensors at every step                               */
 } cvc_train_loop;
 CVC_API long long cvc_train_loop_bwd_ws(int B, int R, int A);
 CVC_API int cvc_train_loop_fwd(const cvc_train_loop* loop, cvc_stream_t stream);

@@ -29,6 +29,10 @@ int cvc_attn_bwd_pair(int kind, const cvc_grad_src* q, const float* q_bias, cons
                       const cvc_attn_set* sets, int nsets, const cvc_grad_src* d_ctx, int nclip, int nq, int A, int R,
                       float* d_q, float* d_q_q, float* d_w_part, float* const* d_proj, float* const* d_ctxfeat,
                       cvc_stream_t stream);
+/* d_feat[b, i, :] += sum_t attn[t][b][i] * d_ctx_all[t][b (of 128 rows)][:]  (t < T <= 32): the context-feature gradient of all T
+ * steps of the training loop in one pass over d_feat [B, n, R] (cvc_train_loop.d_ctx_all; reference: the `bmm(att, context)` of
+ * modules.py:66-69 / 150-153 under autograd, accumulated over the T decoder steps of captioner.py:242-270) */
+int cvc_ctxfeat_bwd_steps(const float* attn, const float* d_ctx_all, int T, int B, int n, int R, float* d_feat, cvc_stream_t stream);
 int cvc_linear_splitk_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, int M, int Nout,
                           int ksplit, float* y_parts, cvc_stream_t stream);
 int cvc_linear_top2_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, int M, int Nout,

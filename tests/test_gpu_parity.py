@@ -845,6 +845,24 @@ def test_a9_cyclical_cfg1_golden(g2, dev, lib):
         assert params[dead].grad is None
 
 
+@pytest.mark.parametrize("T,B,n,R", [(20, 64, 100, 2048), (4, 3, 7, 32), (32, 5, 130, 260), (1, 2, 65, 8)])
+def test_context_feature_gradient_of_all_steps_in_one_pass(dev, lib, T, B, n, R):
+    """cvc_ctxfeat_bwd_steps: d_feat[b, i, :] += sum_t attn[t, b, i] d_ctx[t, b, :] with the training loop's arenas ([T][B][n]
+    weights, [T][128][R] context gradients) -- the accumulated `bmm(att, context)` backward of modules.py:66-69 / 150-153 over the T
+    decoder steps -- against fp64; accumulates onto what d_feat already holds (the localizer's share)."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(T * 1000 + n)
+    attn = torch.softmax(torch.randn(T, B, n, generator=g), -1).to(dev)
+    d_ctx = torch.randn(T, 128, R, generator=g).to(dev)
+    base = torch.randn(B, n, R, generator=g).to(dev)
+    out = base.clone()
+    fn = lib.lib().cvc_ctxfeat_bwd_steps
+    assert fn(attn.data_ptr(), d_ctx.data_ptr(), T, B, n, R, out.data_ptr(), None) == 0
+    ref = base.double() + torch.einsum("tbi,tbr->bir", attn.double(), d_ctx[:, :B].double())
+    close(out, ref.float(), rtol=1e-5, atol=1e-5)
+    assert fn(attn.data_ptr(), d_ctx.data_ptr(), 33, B, n, R, out.data_ptr(), None) == -1          # T beyond the staged rows: refused
+
+
 # ------------------------------------------------------------------ beam search (build-defined)
 def test_beam_vs_oracle(tiny, g1, dev):
     from oracle import ref_cpu as O
