@@ -135,7 +135,8 @@ __global__ __launch_bounds__(WG) void ctxfeat_bwd_kernel(const float* attn, cons
 // sg_q = 128, sg_c = 1) and cvc_attn_bwd's [clip][q] rows (sa_q = n, sa_c = nq n, sg_q = 1, sg_c = nq).
 constexpr int CFB_ROWS = 64, CFB_MAXQ = 32;
 __global__ __launch_bounds__(WG) void ctxfeat_bwd_batched_kernel(const float* attn, long long sa_q, long long sa_c, const float* g,
-                                                                 long long sg_q, long long sg_c, int nq, int n, int R, float* d_feat) {
+                                                                 long long sg_q, long long sg_c, int nq, int n, int R, float* d_feat,
+                                                                 float scale) {
     __shared__ f32x4 gs[CFB_MAXQ][64];
     const int cb = blockIdx.x, chunk = blockIdx.y, clip = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -151,8 +152,50 @@ __global__ __launch_bounds__(WG) void ctxfeat_bwd_batched_kernel(const float* at
         for (int q = 0; q < nq; ++q) acc += aw[(size_t)q * sa_q + i] * gs[q][lane];
         if (ok) {
             float* D = d_feat + ((size_t)clip * n + i) * R + col;
-            st4(D, ld4(D) + acc);
+            st4(D, ld4(D) + scale * acc);
         }
+    }
+}
+
+// d_proj[clip, i, :] += sum_t d_s[t][clip][i] * w * (1 - tanh^2(P[clip, i, :] + q_t[clip, :]))   (additive attention, all T steps of
+// the training loop in one pass): the projected-feature gradient of captioner.py:242-270's T decoder steps.  Per step it is a
+// read-modify-write of [B, n, A] inside the score backward; here a workgroup = (256 columns, a chunk of feature rows, clip) stages the
+// T queries' columns in LDS (K-slice planes of the h2attn product summed on load, + bias), then every wave walks its rows: the row's
+// P once, T tanh evaluations per element in registers, ONE read-modify-write of d_proj.
+__global__ __launch_bounds__(WG) void dproj_steps_kernel(const float* q, long long q_step, long long q_plane, int q_nplanes, const float* q_bias,
+                                                         const float* w_a, const float* proj, const float* ds, int T, int B, int n, int A,
+                                                         float* d_proj) {
+    __shared__ f32x4 qs[CFB_MAXQ][64];
+    const int cb = blockIdx.x, chunk = blockIdx.y, clip = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = cb * 256 + lane * 4;
+    const bool ok = col < A;
+    for (int t = wave; t < T; t += 4) {
+        f32x4 v = {0, 0, 0, 0};
+        if (ok) {
+            const float* qp = q + (size_t)t * q_step + (size_t)clip * A + col;
+            v = ld4(qp);
+            for (int k = 1; k < q_nplanes; ++k) v += ld4(qp + (size_t)k * q_plane);
+            if (q_bias != nullptr) v += ld4(q_bias + col);
+        }
+        qs[t][lane] = v;
+    }
+    __syncthreads();
+    if (!ok) return;
+    const f32x4 w4 = ld4(w_a + col);
+    const int i_end = min(n, (chunk + 1) * CFB_ROWS);
+    for (int i = chunk * CFB_ROWS + wave; i < i_end; i += 4) {
+        const f32x4 p = ld4(proj + ((size_t)clip * n + i) * A + col);
+        f32x4 acc = {0, 0, 0, 0};
+        for (int t = 0; t < T; ++t) {
+            const float d = ds[((size_t)t * B + clip) * n + i];
+            const f32x4 x = p + qs[t][lane];
+            f32x4 th;
+            th.x = fast_tanh(x.x); th.y = fast_tanh(x.y); th.z = fast_tanh(x.z); th.w = fast_tanh(x.w);
+            acc += d * (1.f - th * th);
+        }
+        float* D = d_proj + ((size_t)clip * n + i) * A + col;
+        st4(D, ld4(D) + w4 * acc);
     }
 }
 
@@ -190,7 +233,7 @@ __global__ __launch_bounds__(WG) void grounder_epilogue_kernel(const float* bias
 inline void ctxfeat_rows(const float* attn, const float* d_ctx, int nclip, int nq, int n, int R, float* d_ctxfeat, hipStream_t st) {
     if (nq > 1 && nq <= CFB_MAXQ)
         hipLaunchKernelGGL(ctxfeat_bwd_batched_kernel, dim3((R + 255) / 256, (n + CFB_ROWS - 1) / CFB_ROWS, nclip), dim3(WG), 0, st, attn,
-                           (long long)n, (long long)nq * n, d_ctx, 1LL, (long long)nq, nq, n, R, d_ctxfeat);
+                           (long long)n, (long long)nq * n, d_ctx, 1LL, (long long)nq, nq, n, R, d_ctxfeat, 1.0f);
     else
         hipLaunchKernelGGL(ctxfeat_bwd_kernel, dim3((R + 255) / 256, nclip), dim3(WG), 0, st, attn, d_ctx, nq, n, R, d_ctxfeat);
 }
@@ -214,13 +257,18 @@ extern "C" int cvc_attn_bwd(int kind, const float* q, const float* w_a, float in
         if (rc) return rc;
     }
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3(rows), dim3(WG), 0, st, attn, d_fm, n, d_ctx != nullptr ? 1 : 0, d_scores);
-    if (kind == CVC_ATTN_DOT && d_proj == nullptr && nq > 1) {
+    if (kind == CVC_ATTN_DOT && nq > 1 && (d_proj == nullptr || nq <= CFB_MAXQ)) {
         // several dot-product queries per clip (the T localizer queries): d_q[row, :] = (1 / temp) sum_n d_s[row, n] P[clip, n, :]
         // is the several-queries weighted sum with d_s as the weights -- the clip's rows streamed once per group of queries instead
         // of once per query (20 passes at T = 20: 363 us for the frame features of config 3)
         int rc = cvc_attn_weighted_rows(d_scores, proj, nclip, nq, n, A, inv_temp, d_q, stream);
         if (rc != CVC_E_TOOBIG) {
             if (rc) return rc;
+            // d_proj[clip, i, :] += (1 / temp) sum_q d_s[clip, q, i] q[clip, q, :]: the same one-pass weighted rows with d_s as the
+            // weights and the queries as the rows (per query it was a read-modify-write of [nclip, n, A]: 20 passes at T = 20)
+            if (d_proj != nullptr)
+                hipLaunchKernelGGL(ctxfeat_bwd_batched_kernel, dim3((A + 255) / 256, (n + CFB_ROWS - 1) / CFB_ROWS, nclip), dim3(WG), 0, st,
+                                   d_scores, (long long)n, (long long)nq * n, q, 1LL, (long long)nq, nq, n, A, d_proj, inv_temp);
             if (d_ctxfeat != nullptr && d_ctx != nullptr) ctxfeat_rows(attn, d_ctx, nclip, nq, n, R, d_ctxfeat, st);
             return cvc_launch_status();
         }
@@ -242,7 +290,15 @@ extern "C" int cvc_attn_bwd(int kind, const float* q, const float* w_a, float in
 extern "C" int cvc_ctxfeat_bwd_steps(const float* attn, const float* d_ctx_all, int T, int B, int n, int R, float* d_feat, cvc_stream_t stream) {
     if (!attn || !d_ctx_all || !d_feat || T < 1 || T > CFB_MAXQ || B < 1 || n < 1 || (R & 3)) return CVC_E_BADARG;
     hipLaunchKernelGGL(ctxfeat_bwd_batched_kernel, dim3((R + 255) / 256, (n + CFB_ROWS - 1) / CFB_ROWS, B), dim3(WG), 0, (hipStream_t)stream,
-                       attn, (long long)B * n, (long long)n, d_ctx_all, 128LL, 1LL, T, n, R, d_feat);
+                       attn, (long long)B * n, (long long)n, d_ctx_all, 128LL, 1LL, T, n, R, d_feat, 1.0f);
+    return cvc_launch_status();
+}
+
+extern "C" int cvc_dproj_bwd_steps(const float* q, long long q_step, long long q_plane, int q_nplanes, const float* q_bias, const float* w_a,
+                                   const float* proj, const float* ds, int T, int B, int n, int A, float* d_proj, cvc_stream_t stream) {
+    if (!q || !w_a || !proj || !ds || !d_proj || T < 1 || T > CFB_MAXQ || B < 1 || n < 1 || (A & 3) || q_nplanes < 1) return CVC_E_BADARG;
+    hipLaunchKernelGGL(dproj_steps_kernel, dim3((A + 255) / 256, (n + CFB_ROWS - 1) / CFB_ROWS, B), dim3(WG), 0, (hipStream_t)stream, q, q_step,
+                       q_plane, q_nplanes, q_bias, w_a, proj, ds, T, B, n, A, d_proj);
     return cvc_launch_status();
 }
 

@@ -292,6 +292,9 @@ int run_bwd(const cvc_train_loop* LA, const cvc_train_loop* LC, hipStream_t st, 
     // ... of every step, kept in LA->d_ctx_all and turned into d_pool / d_conv by ONE pass after the loop (each feature row read and
     // written once) -- per step it is a read-modify-write of both feature tensors: 2 x 304 MB x T at config 3
     const bool feat_batched = feat_grads && LA->d_ctx_all != nullptr && T <= 32;
+    // the projected-feature gradients likewise (additive attention): everything their one pass reads -- the queries q_t, the score
+    // gradients d_s_t, the projected features -- is kept by the loops anyway
+    const bool dproj_batched = LA != nullptr && (LA->d_ppool || LA->d_pconv) && LA->attn_kind == CVC_ATTN_ADDITIVE && T <= 32;
     const cvc_grad_src none{nullptr, 0, 0, 0};
     cvc_grad_src g_hl_a = none, g_hl_b = none, g_ha_prev = none;       // what step t + 1 left for step t (all M rows)
     const cvc_train_loop* loops[2] = {LA, LC};
@@ -358,7 +361,7 @@ int run_bwd(const cvc_train_loop* LA, const cvc_train_loop* LC, hipStream_t st, 
             const cvc_grad_src qsrc{L.q + (size_t)t * qs * B * A, A, (long long)B * A, qs};
             CVC_TRY_K(K_ATTN_BWD, cvc_attn_bwd_pair(L.attn_kind, &qsrc, L.wp_h ? L.b_h : nullptr, L.w_a, L.inv_temp, sets, 2, &g_ctx, B, 1, A, R,
                                       L.dq + (size_t)t * B * A, w.dqq, L.dwa_part ? L.dwa_part + (size_t)t * B * A : nullptr,
-                                      any_dp ? d_proj : nullptr, (feat_grads && !feat_batched) ? d_cf : nullptr, st));
+                                      (any_dp && !dproj_batched) ? d_proj : nullptr, (feat_grads && !feat_batched) ? d_cf : nullptr, st));
             cvc_nn_seg seg{L.w_h, w.d_ha_b, R, R, R};
             CVC_TRY_K(K_NN_H2ATTN, nn(w.dqq, A, B, &seg, 1, w.nn_h, &g_ha_b, false, st));
         }
@@ -384,6 +387,15 @@ int run_bwd(const cvc_train_loop* LA, const cvc_train_loop* LC, hipStream_t st, 
             g_hl_b = out[0];
             g_ha_prev = out[1];
         }
+    }
+    if (dproj_batched) {
+        const cvc_train_loop& L = *LA;
+        g_prof_loop = 2;
+        const int qs = L.wp_h ? L.q_split : 1;
+        const long long q_step = (long long)qs * BA * A, q_plane = (long long)BA * A;
+        const float* qb = L.wp_h ? L.b_h : nullptr;
+        if (L.d_ppool) CVC_TRY_K(K_ATTN_BWD, cvc_dproj_bwd_steps(L.q, q_step, q_plane, qs, qb, L.w_a, L.ppool, L.ds_r, T, BA, N, A, L.d_ppool, st));
+        if (L.d_pconv) CVC_TRY_K(K_ATTN_BWD, cvc_dproj_bwd_steps(L.q, q_step, q_plane, qs, qb, L.w_a, L.pconv, L.ds_f, T, BA, F, A, L.d_pconv, st));
     }
     if (feat_batched) {
         g_prof_loop = 2;

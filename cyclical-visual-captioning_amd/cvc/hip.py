@@ -125,6 +125,7 @@ SIGNATURES = {
     "cvc_attn_bwd_pair": [_I, C.POINTER(GradSrc), _P, _P, _F, C.POINTER(AttnSet), _I, C.POINTER(GradSrc), _I, _I, _I, _I, _P, _P, _P,
                           C.POINTER(_P), C.POINTER(_P), _P],
     "cvc_ctxfeat_bwd_steps": [_P, _P, _I, _I, _I, _I, _P, _P],
+    "cvc_dproj_bwd_steps": [_P, _LL, _LL, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "cvc_lstm_pointwise_bwd4": [C.POINTER(GradSrc), _P, _P, C.c_uint, _F, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P],
     "cvc_vocab_head_nll_fwd": [_P, _I, _LL, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P],
     "cvc_scale_by_scalar": [_P, _P, _LL, _P, _P],
@@ -254,7 +255,7 @@ _VOID_RETURN = {"cvc_decode_plan_destroy"}
 # drop-in ABI of include/cvc_hip.h.
 BLOCKS = {
     "cvc_attn_scores", "cvc_attn_wsum", "cvc_attn_scores_qparts", "cvc_attn_wsum_quad", "cvc_attn_wsum_frag", "cvc_attn_wsum_quad_rm",
-    "cvc_attn_bwd_pair", "cvc_ctxfeat_bwd_steps", "cvc_linear_splitk_fwd", "cvc_linear_top2_fwd", "cvc_top2_final", "cvc_packed_lstm_fwd", "cvc_packed_linear_fwd",
+    "cvc_attn_bwd_pair", "cvc_ctxfeat_bwd_steps", "cvc_dproj_bwd_steps", "cvc_linear_splitk_fwd", "cvc_linear_top2_fwd", "cvc_top2_final", "cvc_packed_lstm_fwd", "cvc_packed_linear_fwd",
     "cvc_packed_lstm_embgate_fwd", "cvc_packed_lstm_embgate_ex_fwd", "cvc_packed_lstm_late_fwd", "cvc_packed_lstm_train_fwd",
     "cvc_packed_lstm_train_pre_fwd", "cvc_packed_lstm_train_drop_fwd", "cvc_lstm_pointwise_bwd", "cvc_lstm_pointwise_bwd3",
     "cvc_lstm_pointwise_bwd3_drop", "cvc_pack_lstm_weights", "cvc_linear_nn_planes_fwd", "cvc_linear_nn_planes2_fwd", "cvc_gru_seq_train_fwd", "cvc_lstm_pointwise_bwd4_pair", "cvc_beam_select_parts", "cvc_tile_lstm_finish",

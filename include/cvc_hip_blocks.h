@@ -33,6 +33,11 @@ int cvc_attn_bwd_pair(int kind, const cvc_grad_src* q, const float* q_bias, cons
  * steps of the training loop in one pass over d_feat [B, n, R] (cvc_train_loop.d_ctx_all; reference: the `bmm(att, context)` of
  * modules.py:66-69 / 150-153 under autograd, accumulated over the T decoder steps of captioner.py:242-270) */
 int cvc_ctxfeat_bwd_steps(const float* attn, const float* d_ctx_all, int T, int B, int n, int R, float* d_feat, cvc_stream_t stream);
+/* d_proj[b, i, :] += sum_t d_s[t][b][i] * w_a * (1 - tanh^2(proj[b, i, :] + q_t[b, :]))  (additive attention; t < T <= 32): the
+ * projected-feature gradient of all T steps in one pass.  q: [T] blocks of q_step floats, each q_nplanes planes ([B, A], q_plane
+ * floats apart) summed on load (+ q_bias): the h2attn outputs the forward kept (cvc_train_loop.q). */
+int cvc_dproj_bwd_steps(const float* q, long long q_step, long long q_plane, int q_nplanes, const float* q_bias, const float* w_a,
+                        const float* proj, const float* ds, int T, int B, int n, int A, float* d_proj, cvc_stream_t stream);
 int cvc_linear_splitk_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, int M, int Nout,
                           int ksplit, float* y_parts, cvc_stream_t stream);
 int cvc_linear_top2_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, int M, int Nout,

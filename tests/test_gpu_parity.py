@@ -863,6 +863,29 @@ def test_context_feature_gradient_of_all_steps_in_one_pass(dev, lib, T, B, n, R)
     assert fn(attn.data_ptr(), d_ctx.data_ptr(), 33, B, n, R, out.data_ptr(), None) == -1          # T beyond the staged rows: refused
 
 
+@pytest.mark.parametrize("T,B,n,A,planes", [(20, 64, 100, 1024, 4), (4, 3, 7, 16, 1), (32, 5, 130, 260, 2)])
+def test_projected_feature_gradient_of_all_steps_in_one_pass(dev, lib, T, B, n, A, planes):
+    """cvc_dproj_bwd_steps: d_proj[b, i, :] += sum_t d_s[t, b, i] w (1 - tanh^2(P[b, i, :] + q_t[b, :])), q_t given as the K-slice
+    planes of the h2attn product + bias (what the training loop keeps), against fp64 autograd of the additive score
+    (modules.py:112-120) summed over the T steps."""
+    g = torch.Generator().manual_seed(T * 100 + n)
+    qp = (torch.randn(T, planes, B, A, generator=g) * 0.5).to(dev)
+    qb = (torch.randn(A, generator=g) * 0.1).to(dev)
+    w = (torch.randn(A, generator=g) * 0.3).to(dev)
+    P = torch.randn(B, n, A, generator=g).to(dev)
+    ds = torch.randn(T, B, n, generator=g).to(dev)
+    base = torch.randn(B, n, A, generator=g).to(dev)
+    out = base.clone()
+    rc = lib.lib().cvc_dproj_bwd_steps(qp.data_ptr(), planes * B * A, B * A, planes, qb.data_ptr(), w.data_ptr(), P.data_ptr(), ds.data_ptr(),
+                                       T, B, n, A, out.data_ptr(), None)
+    assert rc == 0
+    Pd = P.double().requires_grad_(True)
+    q = qp.double().sum(1) + qb.double()                                   # [T, B, A]
+    scores = (torch.tanh(Pd.unsqueeze(0) + q.unsqueeze(2)) * w.double()).sum(-1)        # [T, B, n]
+    (scores * ds.double()).sum().backward()
+    close(out, (base.double() + Pd.grad).float(), rtol=2e-5, atol=2e-5)
+
+
 # ------------------------------------------------------------------ beam search (build-defined)
 def test_beam_vs_oracle(tiny, g1, dev):
     from oracle import ref_cpu as O
