@@ -55,6 +55,14 @@ def roles_for(mode, beam, T, B=64):
             "loopA.fwd.attn_wsum": (r"attn_wsum_kernelE", 1, {0}),
             "loopA.bwd.attn_bwd": [(r"attn_scores_kernelILi1ELi\d+ELi1E", 1, {0}), (r"softmax_bwd2_kernel", 1, {0}), (r"attn_score_bwd2", 1, {0})],
             "cvc_tile_gemm": (r"tile_gemm_ld2?_kernel", 1, {0}),
+            # entry points called from Python (round 6: every timed row of the bench line carries its PMC traffic): per-launch averages
+            "cvc_adam_clip_step": [(r"optim_sumsq_kernel", 1, {0}), (r"optim_finalize_kernel", 1, {0}), (r"optim_adam_kernel", 1, {0})],
+            "cvc_tile_pack_cols": (r"tile_pack_cols_kernel", 1, {0}),
+            "cvc_tile_pack_rows_any": (r"tile_pack_rows_(any|blk)_kernel", 1, {0}),
+            "cvc_pack_lstm_segs": (r"pack_lstm_w_kernel", 1, {0}),
+            # the localizer's T-query attention backward (two launches per step: regions, frames): d_attn on the several-queries dot
+            # score kernel, softmax backward, d_q as weighted rows
+            "cvc_attn_bwd": [(r"attn_scores_kernelILi1ELi\d+ELi[45]E", 1, {0}), (r"softmax_bwd_kernel", 1, {0}), (r"attn_wsum_mq_kernel", 1, {0})],
         }
     if mode == "train" and 2 * B <= 64:
         # joint backward of both loops (cvc_train_loops_bwd_joint): T x (language product, h2attn product, attention product), the
@@ -75,6 +83,14 @@ def roles_for(mode, beam, T, B=64):
             # one role = three kernels per step: d_attn = C . d_ctx on the dot-score kernel, softmax backward, score backward
             "loopA.bwd.attn_bwd": [(r"attn_scores_kernelILi1ELi\d+ELi1E", 1, {0}), (r"softmax_bwd2_kernel", 1, {0}), (r"attn_score_bwd2", 1, {0})],
             "cvc_tile_gemm": (r"tile_gemm_ld2?_kernel", 1, {0}),
+            # entry points called from Python (round 6: every timed row of the bench line carries its PMC traffic): per-launch averages
+            "cvc_adam_clip_step": [(r"optim_sumsq_kernel", 1, {0}), (r"optim_finalize_kernel", 1, {0}), (r"optim_adam_kernel", 1, {0})],
+            "cvc_tile_pack_cols": (r"tile_pack_cols_kernel", 1, {0}),
+            "cvc_tile_pack_rows_any": (r"tile_pack_rows_(any|blk)_kernel", 1, {0}),
+            "cvc_pack_lstm_segs": (r"pack_lstm_w_kernel", 1, {0}),
+            # the localizer's T-query attention backward (two launches per step: regions, frames): d_attn on the several-queries dot
+            # score kernel, softmax backward, d_q as weighted rows
+            "cvc_attn_bwd": [(r"attn_scores_kernelILi1ELi\d+ELi[45]E", 1, {0}), (r"softmax_bwd_kernel", 1, {0}), (r"attn_wsum_mq_kernel", 1, {0})],
         }
     if mode == "train":
         # forward of a step: loop A = T x (attention cell, language cell), then loop C = T x (attention cell, language cell);
@@ -99,6 +115,14 @@ def roles_for(mode, beam, T, B=64):
             # one role = three kernels per step: d_attn = C . d_ctx on the dot-score kernel, softmax backward, score backward
             "loopA.bwd.attn_bwd": [(r"attn_scores_kernelILi1ELi\d+ELi1E", 1, {0}), (r"softmax_bwd2_kernel", 1, {0}), (r"attn_score_bwd2", 1, {0})],
             "cvc_tile_gemm": (r"tile_gemm_ld2?_kernel", 1, {0}),
+            # entry points called from Python (round 6: every timed row of the bench line carries its PMC traffic): per-launch averages
+            "cvc_adam_clip_step": [(r"optim_sumsq_kernel", 1, {0}), (r"optim_finalize_kernel", 1, {0}), (r"optim_adam_kernel", 1, {0})],
+            "cvc_tile_pack_cols": (r"tile_pack_cols_kernel", 1, {0}),
+            "cvc_tile_pack_rows_any": (r"tile_pack_rows_(any|blk)_kernel", 1, {0}),
+            "cvc_pack_lstm_segs": (r"pack_lstm_w_kernel", 1, {0}),
+            # the localizer's T-query attention backward (two launches per step: regions, frames): d_attn on the several-queries dot
+            # score kernel, softmax backward, d_q as weighted rows
+            "cvc_attn_bwd": [(r"attn_scores_kernelILi1ELi\d+ELi[45]E", 1, {0}), (r"softmax_bwd_kernel", 1, {0}), (r"attn_wsum_mq_kernel", 1, {0})],
         }
     if beam > 1:
         # tile path: per decode one hoisted fc product, then per step the four products in this order

@@ -2,8 +2,8 @@
 #   PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs, --kernel-trace only) of EVERY benched workload -> profiles/traffic/*.json
 #   (tools/collect_traffic.py), the matrix-pipe-busy counters, bench lines, rocprofv3 kernel-trace summaries of the same commands,
 #   the decode-step timeline.
-#   usage (GPU box): bash tools/gpu_profile.sh r05 [pmc|bench|all]
-TAG=${1:-r05}
+#   usage (GPU box): bash tools/gpu_profile.sh r06 [pmc|bench|all]
+TAG=${1:-r06}
 WHAT=${2:-all}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -74,6 +74,14 @@ if [ "$WHAT" = "bench" ] || [ "$WHAT" = "all" ]; then
   # (the N-rank path runs the gradient exchange whatever N is: here the per-bucket RS + AG on a ONE-rank RCCL communicator, inside the captured step)
   python3 $R/bench.py --gpus 1 --spawn --mode train --config cfg4 --steps 30 --warmup 3 --no-cpu-baseline > $O/bench_${TAG}_spawn1_train_cfg4.json 2>> $O/bench_spawn.err
   python3 $R/bench.py --mode train --config cfg4 --always-exchange --steps 30 --warmup 3 --no-cpu-baseline > $O/bench_${TAG}_train_cfg4_exchange.json 2>> $O/bench_train.err
+  # round 6: the N-rank entry path of the DEFAULT command (decode + config 4's training step run by every rank), the reference's
+  # real flow end to end (raw features through the encoder), the VALU issue rates behind the score pass's cost model
+  python3 $R/bench.py --gpus 1 --spawn --steps 20 --warmup 5 > $O/bench_${TAG}_spawn1_default.json 2>> $O/bench_spawn.err
+  for c in cfg2 refdefault; do
+    python3 $R/bench.py --mode e2e-train --config $c --steps 10 --warmup 2 > $O/bench_${TAG}_e2e_train_$c.json 2>> $O/bench_e2e.err
+    python3 $R/bench.py --mode e2e-eval --config $c --steps 10 --warmup 2 > $O/bench_${TAG}_e2e_eval_$c.json 2>> $O/bench_e2e.err
+  done
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -Wno-unused-result $R/tools/valu_rates.hip -o /tmp/valu_rates 2>/dev/null && /tmp/valu_rates > $O/${TAG}_valu_rates.log
   head -c 600 $O/bench_${TAG}_greedy.json; echo
   for f in beam5 cfg5_greedy cfg5_beam5 train train_cfg4; do python3 -c "
 import json,sys
