@@ -301,13 +301,13 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
     def _loop_plan(self, B, like):
         """(attention kind, 1 / temperature, dropout spec of loop A, of loop C) when the two recurrent loops of this pass can run
         as one C-driven autograd node each (cvc/train_loops.py), else None (per-step path: dictated dropout masks, library
-        dropout, more than 64 clips, widths the packed kernels do not take)."""
+        dropout, widths the packed kernels do not take).  More than 64 clips: groups of <= 64 (cvc.train_loops.clip_groups)."""
         from .. import train_loops
         from .modules import AdditiveSoftAttention
         dc, rc = self.decoder_core, self.attended_roi_decoder_core
         sa = dc.soft_attn
         R, E, A = self.rnn_size, self.embed[0].weight.shape[1], sa.h2attn.weight.shape[0]
-        if not train_loops.eligible(B, R, E, A, like) or dropout.active():
+        if not train_loops.eligible(B, R, E, A, like, self.seq_length) or dropout.active():
             return None
         if not (dc.att_lstm.weight_ih.is_contiguous() and dc.lang_lstm.weight_ih.is_contiguous() and sa.h2attn.weight.is_contiguous()):
             return None
@@ -332,19 +332,37 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         num_rois = pool_feats.shape[1]
         dc = self.decoder_core
         fc_in = fc_feats if self.opts.global_img_in_attn_lstm else None
-        arena = train_loops.LoopArena(1 if self.opts.train_decoder_only else 2, T, B, R, emb_all.shape[2], emb_all.device)
-        out_a, fm = train_loops.decode_loop(arena, emb_all, fc_in, (pool_feats, p_pool_feats, conv_feats, p_conv_feats), region_mask,
-                                            step_fmask, dc.att_lstm, dc.lang_lstm, dc.soft_attn, attn_kind, inv_temp, drop_a)
+        # the loops take 64 clips: a larger batch runs them once per group of clips (clips are independent through both loops), each
+        # group with its own arena; what is batch-wide below (head, criteria, grounder, localizer, embeddings) is one call over all B
+        groups = train_loops.clip_groups(B)
+        nslots = 1 if self.opts.train_decoder_only else 2
+        arenas = [train_loops.LoopArena(nslots, T, b1 - b0, R, emb_all.shape[2], emb_all.device) for b0, b1 in groups]
+        feats = (pool_feats, p_pool_feats, conv_feats, p_conv_feats)
+        cut = (lambda x, b0, b1: x) if len(groups) == 1 else (lambda x, b0, b1: None if x is None else x[b0:b1])
+        cut_t = (lambda x, b0, b1: x) if len(groups) == 1 else (lambda x, b0, b1: None if x is None else x[:, b0:b1].contiguous())
+        join_t = (lambda xs: xs[0]) if len(groups) == 1 else (lambda xs: None if xs[0] is None else torch.cat(xs, 1))      # [T, b, .] -> [T, B, .]
+        for a_ in arenas:
+            a_.sole = len(groups) == 1           # several groups: a weight's gradient has several producers (see LoopArena.sole)
+
+        def grp_drop(spec, g):
+            """a group's own dropout sites (site0 + 64 g + t): without it clip i of every group would draw clip i's mask of group 0"""
+            return None if spec is None else (spec[0], spec[1] + 64 * g, spec[2])
+
+        parts = [train_loops.decode_loop(arenas[g], cut(emb_all, b0, b1), cut(fc_in, b0, b1), tuple(cut(f, b0, b1) for f in feats),
+                                         cut(region_mask, b0, b1), cut_t(step_fmask, b0, b1), dc.att_lstm, dc.lang_lstm, dc.soft_attn,
+                                         attn_kind, inv_temp, grp_drop(drop_a, g)) for g, (b0, b1) in enumerate(groups)]
+        out_a = join_t([p_[0] for p_ in parts])
+        fm = join_t([p_[1] for p_ in parts])
         target = gt_caption[:, 1:T + 1].clone()
         out_c, done = None, None
-        head = self.critLM.head_words(out_a.view(T * B, R), self.logit, target, t_major=True) if arena.joint_ok() else None
+        head = self.critLM.head_words(out_a.view(T * B, R), self.logit, target, t_major=True) if all(a.joint_ok() for a in arenas) else None
         if head is not None:
-            # Both loops' rows fit one 64-row operand (the 32-clip shares of the 8-GPU job): loops B and C come FIRST, fed the argmax
-            # words of the head's arithmetic, and loop A's outputs pass through loop C's graph node -- its backward then holds both
-            # loops' output gradients and runs their back-propagation as one pass (cvc.train_loops._Loop).
+            # A group's two loops fit the joint back-propagation (64 + 64 rows: config 3; 32 + 32: the shares of the 8-GPU job): loops B
+            # and C come FIRST, fed the argmax words of the head's arithmetic, and loop A's outputs pass through loop C's graph node
+            # -- its backward then holds both loops' output gradients and runs their back-propagation as one pass (cvc.train_loops._Loop).
             done, output_seq = head
-            out_c, out_a, fm = self._loops_b_c(arena, output_seq, gt_caption, emb_all, fc_in, conv_feats, p_conv_feats, pool_feats,
-                                               p_pool_feats, region_mask, attn_kind, drop_c, joint=(out_a, fm))
+            out_c, out_a, fm = self._loops_b_c(arenas, groups, output_seq, gt_caption, emb_all, fc_in, conv_feats, p_conv_feats, pool_feats,
+                                               p_pool_feats, region_mask, attn_kind, drop_c, joint=[(p_[0], p_[1]) for p_ in parts])
         att2_weights = fm.transpose(0, 1)                                             # [B, T, N] pre-softmax (:273)
 
         # ---- grounder over all T                                                      reference :282-294
@@ -365,22 +383,36 @@ class DecodeAndGroundCaptionerGVDROI(nn.Module):
         if self.opts.train_decoder_only:                                              # reference :297-307
             return lm_loss.reshape(1), att2_loss.reshape(1), ground_loss.reshape(1), cls_loss.reshape(1)
         if out_c is None:
-            out_c = self._loops_b_c(arena, output_seq, gt_caption, emb_all, fc_in, conv_feats, p_conv_feats, pool_feats, p_pool_feats,
+            out_c = self._loops_b_c(arenas, groups, output_seq, gt_caption, emb_all, fc_in, conv_feats, p_conv_feats, pool_feats, p_pool_feats,
                                     region_mask, attn_kind, drop_c)
         lm_recon_loss = self.xe_criterion.from_head(out_c.view(T * B, R), self.logit, target, t_major=True)
         return (lm_loss.reshape(1), att2_loss.reshape(1), ground_loss.reshape(1), cls_loss.reshape(1), lm_recon_loss.reshape(1))
 
-    def _loops_b_c(self, arena, output_seq, gt_caption, emb_all, fc_in, conv_feats, p_conv_feats, pool_feats, p_pool_feats, region_mask,
-                   attn_kind, drop_c, joint=None):
+    def _loops_b_c(self, arenas, groups, output_seq, gt_caption, emb_all, fc_in, conv_feats, p_conv_feats, pool_feats, p_pool_feats,
+                   region_mask, attn_kind, drop_c, joint=None):
         """the argmax cut, loop B (localize, all T in one attention call; reference :313-338) and loop C (reconstruct from the
-        localized regions; reference :348-362)"""
+        localized regions; reference :348-362).  Loop B and the embeddings are one call over the whole batch; loop C runs once per
+        group of <= 64 clips (cvc.train_loops.clip_groups).  -> out_c [T, B, R], or (out_c, loop A's out, loop A's fm) with `joint`
+        (per group: loop A's (out, fm) of that group)"""
         from .. import train_loops
         dc, T = self.decoder_core, self.seq_length
         loc_emb = self._embed(output_seq, "emb_b")                                   # [B, T, E]
         ctx_all = self.localizer_core.forward_all_steps_sum(loc_emb, conv_feats, p_conv_feats, pool_feats, p_pool_feats, region_mask)
         emb_all_c = self._embed(gt_caption[:, :T], "emb_c") if self.training else emb_all      # fresh dropout mask in training
-        return train_loops.recon_loop(arena, emb_all_c, fc_in, ctx_all, dc.att_lstm, dc.lang_lstm, dc.soft_attn, attn_kind, drop_c,
-                                      joint=joint)
+        one = len(groups) == 1
+        outs = []
+        for g, (b0, b1) in enumerate(groups):
+            sl = (lambda x: x) if one else (lambda x: None if x is None else x[b0:b1])
+            drop = None if drop_c is None else (drop_c[0], drop_c[1] + 64 * g, drop_c[2])
+            outs.append(train_loops.recon_loop(arenas[g], sl(emb_all_c), sl(fc_in), sl(ctx_all), dc.att_lstm, dc.lang_lstm, dc.soft_attn,
+                                               attn_kind, drop, joint=None if joint is None else joint[g]))
+        if one:
+            return outs[0]
+        if joint is None:
+            return torch.cat(outs, 1)
+        fms = [o[2] for o in outs]
+        return (torch.cat([o[0] for o in outs], 1), torch.cat([o[1] for o in outs], 1),
+                None if fms[0] is None else torch.cat(fms, 1))
 
     def _vis_embed(self, xt_clamp):
         """roi_feat_extractor.vis_embed (Embedding -> ReLU -> Dropout, backbone.py:55-57) on the grounder's class indices"""

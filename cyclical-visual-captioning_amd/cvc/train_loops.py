@@ -36,10 +36,32 @@ JOINT_BWD_128 = os.environ.get("CVC_TRAIN_JOINT_BWD_128", "1") != "0"   # False:
 Tensor = torch.Tensor
 
 
-def eligible(B: int, R: int, E: int, A: int, like: Tensor) -> bool:
+MAX_CLIPS = 256           # per GPU; a loop takes 64 clips, a larger batch runs as several 64-clip groups (clip_groups)
+CHUNKED = os.environ.get("CVC_TRAIN_LOOP_GROUPS", "1") != "0"           # False: more than 64 clips -> the per-step path, as before round 6 (A/B)
+
+
+def eligible(B: int, R: int, E: int, A: int, like: Tensor, T: int = 1) -> bool:
     """shapes / placement the C-driven loops take (everything else keeps the per-step path)"""
-    return bool(ENABLED and like.is_cuda and like.dtype == torch.float32 and 1 <= B <= 64 and R % 32 == 0 and E % 16 == 0
+    b_ok = 1 <= B <= 64 or (CHUNKED and B <= MAX_CLIPS and T <= 64)
+    return bool(ENABLED and like.is_cuda and like.dtype == torch.float32 and b_ok and R % 32 == 0 and E % 16 == 0
                 and A % 8 == 0 and F_.PACKED_LSTM_FORWARD and hip.gemm_packed_split(-1) >= 0)
+
+
+def clip_groups(B: int):
+    """[(b0, b1)]: the batch as groups of at most 64 clips.  A loop is 64 rows wide (the packed gate GEMM's operand, the
+    backward-data product's row group); clips are independent through both loops, so a larger per-GPU batch (reference
+    cfgs/cyclical.yml: 48; a 288 GB part invites 128+) runs the loops once per group -- own arena, own joint back-propagation, own
+    weight-gradient products, which autograd sums -- while everything batch-wide (embedding, vocabulary head and criteria,
+    grounder, localizer) stays one call over all B clips.  Even groups (96 -> 48 + 48): both groups' joint backward then takes the
+    same kernel form."""
+    n = (B + 63) // 64
+    base, extra = divmod(B, n)
+    out, b0 = [], 0
+    for g in range(n):
+        b1 = b0 + base + (1 if g < extra else 0)
+        out.append((b0, b1))
+        b0 = b1
+    return out
 
 
 class LoopArena:
@@ -59,6 +81,11 @@ class LoopArena:
         self.loop_a = None              # loop A's autograd context, for the joint back-propagation run from loop C's node
         self.joint_done = False         # the joint pass has run: loop A's node only has its dense input gradients left
         self.a_feat_grads = None
+        # True: this arena's weight-gradient products are the parameters' ONLY producers this step, so a gradient written straight into
+        # a sink (the reducer's arena view) is announced final and its bucket's exchange may leave at once.  False (the batch runs as
+        # several 64-clip groups, each with its own arena): the groups' gradients are summed -- the first to arrive may still write in
+        # place, but nothing is final before autograd has accumulated the others (the bucket then leaves from the parameter's hook)
+        self.sole = True
 
     def joint_ok(self) -> bool:
         """Both loops' back-propagation through time runs as one pass (cvc_train_loops_bwd_joint), every backward-data product streaming
@@ -120,8 +147,9 @@ class _Out:
     """where one weight's gradient goes: the owner's .grad buffer itself when a gradient sink hands it out (cvc.functional.
     GRAD_SINKS: written in place, autograd gets None), else a fresh tensor returned through autograd"""
 
-    def __init__(self, param: Optional[Tensor]):
+    def __init__(self, param: Optional[Tensor], final: bool = True):
         self.param = param
+        self.final = final
         self.buf, self.sink = F_.claim_grad(param) if param is not None else (None, None)
         self.t = self.buf if self.buf is not None else (torch.empty_like(param) if param is not None else None)
         self.announced = False
@@ -130,7 +158,7 @@ class _Out:
         """-> what the Function returns for this weight.  With a sink: announced as the parameter's COMPLETE gradient of this backward
         (the loops' flush is its only producer), so its bucket's exchange can leave behind the product that was just enqueued."""
         if self.sink is not None and not self.announced:
-            self.sink.written(self.param, final=True)
+            self.sink.written(self.param, final=self.final)
             self.announced = True
         return None if self.sink is not None else self.t
 
@@ -146,7 +174,7 @@ def _weight_grads(arena: LoopArena, cfg, W):
     nl = len(slots)
     DGa, DGl = arena.dg_att[rows], arena.dg_lang[rows]
     Hl, Ha_prev, Ha, Cx, Em = arena.h_lang_prev[rows], arena.h_att_prev[rows], arena.h_att[rows], arena.ctx[rows], arena.emb[rows]
-    O = {k: _Out(W[k]) for k in ("w_ih_a", "w_hh_a", "b_ih_a", "b_hh_a", "w_ih_l", "w_hh_l", "b_ih_l", "b_hh_l")}
+    O = {k: _Out(W[k], arena.sole) for k in ("w_ih_a", "w_hh_a", "b_ih_a", "b_hh_a", "w_ih_l", "w_hh_l", "b_ih_l", "b_hh_l")}
     # Largest gradient bucket first (cvc.distributed.GradReducer: every LSTM weight matrix is its own bucket, the biases ride with
     # weight_hh), each announced as soon as its products are enqueued: its exchange then runs under the products that follow.
     # ---- attention cell weight_ih = [h_lang | (fc) | emb]   (168 MB at D = 2048)
@@ -184,11 +212,11 @@ def _weight_grads(arena: LoopArena, cfg, W):
     if 0 in slots and arena.extra:
         x = arena.extra
         DQ = x["dq"].view(n, -1)
-        O["w_h"], O["b_h"] = _Out(W["w_h"]), _Out(W["b_h"])
+        O["w_h"], O["b_h"] = _Out(W["w_h"], arena.sole), _Out(W["b_h"], arena.sole)
         hip.tile_mm(DQ, arena.h_att[arena.rows(0)], a_kmajor=True, b_kmajor=True, out=O["w_h"].t)
         hip.col_sum(DQ, O["b_h"].t)
         if x.get("dwa_part") is not None:
-            O["w_a"], O["b_a"] = _Out(W["w_a"]), _Out(W["b_a"])
+            O["w_a"], O["b_a"] = _Out(W["w_a"], arena.sole), _Out(W["b_a"], arena.sole)
             hip.col_sum(x["dwa_part"].view(n, -1), O["w_a"].t.view(-1))
             O["b_a"].t.copy_((x["ds_r"].sum() + x["ds_f"].sum()).reshape(1))
     return {k: o.done() for k, o in O.items()}

@@ -182,11 +182,13 @@ def test_decode_weights_cache_follows_parameter_updates(graphed):
 
 
 @pytest.mark.parametrize("B,N,F,R,A,E,V,T", [(33, 20, 16, 256, 64, 32, 50, 2), (64, 3, 5, 128, 16, 16, 50, 4),
-                                             (1, 3, 1, 256, 16, 16, 50, 4), (8, 7, 1, 128, 32, 16, 97, 2)])
+                                             (1, 3, 1, 256, 16, 16, 50, 4), (8, 7, 1, 128, 32, 16, 97, 2),
+                                             (96, 9, 6, 128, 32, 16, 50, 3), (128, 5, 4, 256, 32, 32, 50, 3), (130, 4, 3, 128, 16, 16, 50, 2)])
 def test_cyclical_gradients_vs_oracle_on_other_shapes(B, N, F, R, A, E, V, T):
     """Losses and every parameter gradient of the cyclical pass (eval-mode dropout) against the CPU oracle's autograd on
     shapes the golden fixtures do not cover: two MFMA row tiles / ragged M, a single clip, one frame, widths that take the
-    backward-data GEMM's partial slabs."""
+    backward-data GEMM's partial slabs; round 6: more than 64 clips per GPU -- the C-driven loops run once per group of <= 64 clips
+    (96 -> 48 + 48, 128 -> 64 + 64, 130 -> 44 + 43 + 43), batch-wide pieces once, the groups' weight gradients summed."""
     import dataclasses
     from helpers import build_model, to_dev, model_call
     from oracle import ref_cpu as O
@@ -215,6 +217,42 @@ def test_cyclical_gradients_vs_oracle_on_other_shapes(B, N, F, R, A, E, V, T):
         assert err <= 5e-4 * float(want.norm()) + 1e-6, (n, err, float(want.norm()))   # alpha_net.bias: true gradient ~0
         checked += 1
     assert checked >= 15
+    if B > 64:
+        from cvc import train_loops
+        assert train_loops.eligible(B, R, E, A, p, T) and len(train_loops.clip_groups(B)) == (B + 63) // 64
+
+
+def test_more_than_64_clips_graphed_step_equals_eager_with_reducer_and_train_mode_dropout():
+    """B = 96 per GPU, train mode (in-kernel dropout: every group of clips draws its own sites), gradient arenas with the exchange on
+    a one-rank communicator: the step captured into a HIP graph is bit-equal to the eager step, and the reducer's buckets leave only
+    after BOTH groups' weight gradients are in (a first group's in-place write is not final)."""
+    import dataclasses
+    from cvc import dropout
+    from cvc.comm import RcclComm
+    from cvc.distributed import GradReducer
+    dev = torch.device("cuda:0")
+    d = dataclasses.replace(synth.CONFIGS["tiny"], B=96, N=9, F=6, R=128, A=32, E=16, V=50, T=3)
+    finals = []
+    for graphed in (False, True):
+        o, model, batch, Trainer, build_optimizer = _setup(dev, d, train_decoder_only=False)
+        model.train()
+        comm = RcclComm.single()
+        red = GradReducer(model.named_parameters(), comm=comm, always_exchange=True)
+        try:
+            tr = Trainer(o, None, model, build_optimizer(model, o, capturable=True), None, None, grad_reducer=red)
+            dropout.seed(31)
+            # (train_step_graphed takes 3 warm-up steps before its capture: 3 + 3 replays against 6 eager steps)
+            for _ in range(3 if graphed else 6):
+                res = tr.train_step_graphed(batch) if graphed else tr.train_step(batch)
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(res[0]).all())
+            finals.append({k: v.detach().clone() for k, v in model.state_dict().items()})
+            tr._graph = None
+        finally:
+            red.remove_hooks()
+            comm.destroy()
+    for k in finals[0]:
+        assert torch.equal(finals[0][k], finals[1][k]), k
 
 
 def _run_isolated(scenario: str, timeout: int = 900):
