@@ -510,8 +510,8 @@ def run_secondary(args, dev):
         steps = max(3, int(secs * 1e3 / est_ms) + 1)
         return brief(run_decode(args, d, dev, 0, 1, False, beam, steps, 2, 0.15, False, {}, cfg))
 
-    def train(cfg, est_ms, always_exchange=False):
-        d = synth.CONFIGS[cfg]
+    def train(cfg, est_ms, always_exchange=False, B=None):
+        d = synth.CONFIGS[cfg] if B is None else dataclasses.replace(synth.CONFIGS[cfg], B=B)
         steps = max(3, int(secs * 1e3 / est_ms) + 1)
         return brief(run_train(args, d, dev, 0, 1, steps=steps, warmup=2, min_warm=0.2, cpu_baseline=False, config_name=cfg, regions=3,
                                always_exchange=always_exchange))
@@ -523,6 +523,8 @@ def run_secondary(args, dev):
     attempt("cfg3 cyclical train step (B=64)", lambda: train("cfg3", 25.0))
     attempt("cfg4 cyclical train step, one GPU's share (B=32 per GPU) WITH the per-bucket RCCL exchange captured in the step, on a "
             "one-rank communicator (what 8 ranks add is the time on the xGMI links)", lambda: train("cfg4", 15.0, always_exchange=True))
+    attempt("cfg3 cyclical train step at B=128 per GPU (two 64-clip groups of the C-driven loops, batch-wide head / criteria / localizer)",
+            lambda: train("cfg3", 40.0, B=128))
     attempt("cfg5 greedy decode", lambda: decode("cfg5", 1, 19.0))
     attempt("cfg5 beam=5 decode", lambda: decode("cfg5", 5, 48.0))
     attempt("once-per-clip encoder (cfg2 size)", lambda: brief(run_encoder(args, synth.CONFIGS["cfg2"], dev, brief=True, steps=8, warmup=2)))
