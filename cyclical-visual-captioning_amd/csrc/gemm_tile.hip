@@ -387,7 +387,31 @@ struct LstmFinishArgs {
 // per k step 144 -> 84 KB at MH = 5; the LDS was busy ~78 % of the MFMA time), and the k step's barrier sits BEFORE the last row
 // tile's MFMAs -- its fragments are in registers by then -- so that the next stage's first fragments are read under those
 // MFMAs instead of in a bubble at the top of every stage.
-template <int MH, int NL>
+#ifdef CVC_TILE_TS
+// diagnostic build (-DCVC_TILE_TS, tools/runs/r06_tile_ts.py): who waits for whom at the per-k-step barrier?  Workgroup (0, 0), k steps
+// 8 .. 71: [0][s] = computing wave 0: {arrival at barrier s + 1, release}; [1][s] = loader wave 0: {its stage's data complete (vmcnt),
+// release of barrier s, copies of stage s + 2 issued}.  100 MHz constant clock (s_memrealtime).
+__device__ unsigned long long cvc_tile_ts_buf[2][64][3];
+__device__ unsigned long long cvc_tile_clk_buf[4];        // computing wave 0 of workgroup (0, 0): {realtime, shader clock} at k step 8 and 71
+extern "C" __attribute__((visibility("default"))) int cvc_tile_ts_read(unsigned long long* dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(cvc_tile_ts_buf), sizeof(cvc_tile_ts_buf)) == hipSuccess ? 0 : -1;
+}
+extern "C" __attribute__((visibility("default"))) int cvc_tile_clk_read(unsigned long long* dst) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(cvc_tile_clk_buf), sizeof(cvc_tile_clk_buf)) == hipSuccess ? 0 : -1;
+}
+#define CVC_TILE_TS_REC(who, s, k) do { if (lane == 0 && blockIdx.x == 0 && blockIdx.y == 0 && (s) >= 8 && (s) < 72) \
+        cvc_tile_ts_buf[who][(s) - 8][k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CVC_TILE_TS_REC(who, s, k) do {} while (0)
+#endif
+
+// REGLOAD (round 6): the loader waves copy a stage with ordinary register loads + ds_write_b128 instead of LDS-DMA.  In-kernel
+// timestamps (tools/runs/r06_tile_ts.py) showed where the k step's 1.86 us (pure MFMA: 0.8) goes: a loader wave spends 1.55 us ISSUING
+// its ~10 global_load_lds instructions of a stage (~150 ns each: the instruction holds the wave until the texture path has taken it)
+// and the computing waves wait 0.4 us per step at the barrier -- the copy is bound by the issue rate of four waves, not by the
+// memory system (every wave copying: 0.96 us per stage).  A register load issues in a few cycles and is fully asynchronous: two
+// register sets per loader wave, a stage requested two k steps before it is written to LDS, three LDS stages as before.
+template <int MH, int NL, bool REGLOAD = false>
 __global__ __launch_bounds__((4 + NL) * 64) void tile_gemm_ld2_kernel(TileArgs a) {
     constexpr int NX = 2 * MH;
     constexpr int NF = (4 + NX) * 3;
@@ -406,6 +430,57 @@ __global__ __launch_bounds__((4 + NL) * 64) void tile_gemm_ld2_kernel(TileArgs a
     const int s_lo = (int)((long long)a.ksteps * ks / a.ksplit), s_hi = (int)((long long)a.ksteps * (ks + 1) / a.ksplit);
     const int nst = s_hi - s_lo;
 
+    if constexpr (REGLOAD) {
+      if (wave >= 4) {
+        const int lw = wave - 4;
+        constexpr int ND = (NF + NL - 1) / NL;            // pieces per loader wave and stage (a wrapped duplicate where NF % NL != 0)
+        const uint16_t* src[ND];
+        int dst[ND];
+#pragma unroll
+        for (int j = 0; j < ND; ++j) {
+            int f = lw + NL * j;
+            if (f >= NF) f -= NF;
+            const int g = f < 12 ? f : f - 12;
+            const int blk = g / 3, pl = g - blk * 3;
+            if (f < 12) src[j] = a.wb + ((size_t)(tile * 4 + blk) * a.ksteps + s_lo) * KSTEP + pl * FRAG + lane * 8;
+            else src[j] = a.xb + (size_t)(mb0 + blk) * a.x_mblk_stride + (size_t)s_lo * KSTEP + pl * FRAG + lane * 8;
+            dst[j] = f * 1024 + lane * 16;
+        }
+        u32x4 ra[ND], rb[ND];
+        // every load is issued unconditionally (a stage index past the end re-reads the last stage): a conditional load inside the
+        // pipelined loop would degrade the compiler's counted vmcnt waits to vmcnt(0)
+        auto ld = [&](u32x4 (&r)[ND], int st) __attribute__((always_inline)) {
+            const int sc = st < nst ? st : nst - 1;
+#pragma unroll
+            for (int j = 0; j < ND; ++j) r[j] = *reinterpret_cast<const u32x4*>(src[j] + (size_t)sc * KSTEP);
+        };
+        auto stg = [&](const u32x4 (&r)[ND], int st) __attribute__((always_inline)) {
+            char* base = lds + (st % 3) * STAGE;
+#pragma unroll
+            for (int j = 0; j < ND; ++j) *reinterpret_cast<u32x4*>(base + dst[j]) = r[j];
+        };
+        if (nst <= 0) return;
+        ld(ra, 0); ld(rb, 1);
+        stg(ra, 0); ld(ra, 2);
+        stg(rb, 1); ld(rb, 3);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                               // barrier 0: stages 0 and 1 are in LDS
+        // iteration s (after barrier s): stage s + 2 (requested two iterations ago) -> LDS buffer (s + 2) % 3, whose stage s - 1 every
+        // computing wave has finished; the set then takes stage s + 4; barrier s + 1 publishes stage s + 1 (written one iteration ago)
+        for (int s = 0; s + 1 < nst; s += 2) {
+            if (s + 2 < nst) stg(ra, s + 2);
+            ld(ra, s + 4);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                           // barrier s + 1
+            if (s + 2 >= nst) break;
+            if (s + 3 < nst) stg(rb, s + 3);
+            ld(rb, s + 5);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                           // barrier s + 2
+        }
+        return;
+      }
+    } else
     if (wave >= 4) {
         // ---------------- loader wave (as in tile_gemm_ld_kernel); one barrier per stage, in step with the computing waves
         const int lw = wave - 4;
@@ -443,8 +518,11 @@ __global__ __launch_bounds__((4 + NL) * 64) void tile_gemm_ld2_kernel(TileArgs a
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            if (lw == 0) CVC_TILE_TS_REC(1, s, 0);
             __builtin_amdgcn_s_barrier();
+            if (lw == 0) CVC_TILE_TS_REC(1, s, 1);
             if (s + 2 < nst) issue(s + 2, buf == 0 ? 2 : buf - 1);
+            if (lw == 0) CVC_TILE_TS_REC(1, s, 2);
             buf = buf == 2 ? 0 : buf + 1;
         }
         return;
@@ -509,7 +587,15 @@ __global__ __launch_bounds__((4 + NL) * 64) void tile_gemm_ld2_kernel(TileArgs a
         mma(xl, MH - 1);
         __builtin_amdgcn_sched_barrier(0);
         if (s + 1 < nst) {
+            if (wave == 0) CVC_TILE_TS_REC(0, s + 1, 0);
+#ifdef CVC_TILE_TS
+            if (wave == 0 && lane == 0 && blockIdx.x == 0 && blockIdx.y == 0 && (s == 8 || s == 71)) {
+                cvc_tile_clk_buf[s == 8 ? 0 : 2] = __builtin_amdgcn_s_memrealtime();
+                cvc_tile_clk_buf[s == 8 ? 1 : 3] = __builtin_amdgcn_s_memtime();
+            }
+#endif
             __builtin_amdgcn_s_barrier();                           // barrier s + 1
+            if (wave == 0) CVC_TILE_TS_REC(0, s + 1, 1);
             first_frags(nbuf);
         }
         buf = nbuf;
@@ -813,7 +899,7 @@ static int tile_rows_per_chunk(int mblk, int col_wgs) {
 // 2 = dedicated loader waves + 4 wide computing waves (tile_gemm_ld2_kernel), 3 = 2 for long K loops, 1 otherwise (default)
 extern "C" int cvc_tile_gemm_loaders(int on) {
     const int prev = cvc_tile_loader_waves;
-    if (on >= 0) cvc_tile_loader_waves = on > 3 ? 3 : on;
+    if (on >= 0) cvc_tile_loader_waves = on > 4 ? 3 : on;
     return prev;
 }
 
@@ -835,6 +921,18 @@ extern "C" int cvc_tile_gemm(const void* wb, const void* xb, long long x_mblk_st
     // form 2 (4 wide computing waves) pays on long K loops (measured: lang / att gate GEMMs -2..3 us, the short-K vocabulary
     // head and h2attn +2 us each); the default picks per launch
     const bool wide = cvc_tile_loader_waves == 2 || (cvc_tile_loader_waves == 3 && a.ksteps / ksplit >= 64);
+    if (CVC_TILE_LOADERS > 0 && cvc_tile_loader_waves == 4) {             // 4 wide computing waves + register-load loader waves (A/B)
+        constexpr int NL = CVC_TILE_LOADERS > 0 ? CVC_TILE_LOADERS : 1;
+        const dim3 blk((4 + NL) * 64);
+        switch (MH) {
+            case 1: hipLaunchKernelGGL((tile_gemm_ld2_kernel<1, NL, true>), grid, blk, 0, st, a); break;
+            case 2: hipLaunchKernelGGL((tile_gemm_ld2_kernel<2, NL, true>), grid, blk, 0, st, a); break;
+            case 3: hipLaunchKernelGGL((tile_gemm_ld2_kernel<3, NL, true>), grid, blk, 0, st, a); break;
+            case 4: hipLaunchKernelGGL((tile_gemm_ld2_kernel<4, NL, true>), grid, blk, 0, st, a); break;
+            default: hipLaunchKernelGGL((tile_gemm_ld2_kernel<5, NL, true>), grid, blk, 0, st, a); break;
+        }
+        return cvc_launch_status();
+    }
     if (CVC_TILE_LOADERS > 0 && wide) {
         constexpr int NL = CVC_TILE_LOADERS > 0 ? CVC_TILE_LOADERS : 1;
         const dim3 blk((4 + NL) * 64);

@@ -552,12 +552,12 @@ def test_tile_gemm_vs_fp64(dev, lib, M, K, N, ksplit):
     err32 = float(((x @ w.t()).double() - ref).norm() / ref.norm())
     assert err <= max(2.0 * err32, 3e-7), (err, err32)
     assert torch.equal(parts, lib.tile_gemm(wb, xb, 0, K, M, N, ksplit))
-    # the three forms of the kernel (every wave copies / loader waves + 8 computing waves / loader waves + 4 wide computing
-    # waves) take the same products in the same order: bit-identical slabs
+    # the forms of the kernel (every wave copies / loader waves + 8 computing waves / loader waves + 4 wide computing waves / the
+    # same with register-load loader waves, round 6) take the same products in the same order: bit-identical slabs
     L = lib.lib()
     prev = L.cvc_tile_gemm_loaders(-1)
     try:
-        for form in (0, 1, 2):
+        for form in (0, 1, 2, 4):
             L.cvc_tile_gemm_loaders(form)
             assert torch.equal(parts, lib.tile_gemm(wb, xb, 0, K, M, N, ksplit)), form
     finally:
