@@ -619,6 +619,126 @@ __global__ __launch_bounds__((4 + NL) * 64) void tile_gemm_ld2_kernel(TileArgs a
     }
 }
 
+// ---- 256 x 256 form (round 6) ---------------------------------------------------------------------------------------------------
+// For the large products (every dW of the training step, the encoder's dense layers, the GRU's input projections): a workgroup of
+// four waves, one per SIMD, owns 256 weight rows x 256 activation rows; a wave a 128 x 128 quarter = 4 x 4 accumulator tiles (256
+// registers).  Per k step a wave reads 24 fragments from LDS for 96 MFMAs (the 128 x 320 form: 21 for 60) and the workgroup moves
+// 48 KB into LDS for 384 MFMAs (42 KB for 240): a third less data motion per MFMA -- which is what the kernel pays for twice, in
+// LDS / fabric time and, the clock being power-limited inside these kernels (1.5 - 1.67 GHz), in clock.
+// Round 5 built this tile with every wave issuing its share of the stage as LDS-DMA copies and measured it SLOWER (513 against
+// 474 us on dW of an LSTM block): an LDS-DMA instruction holds its wave ~150 ns (tools/runs/r06_tile_ts.py), twelve of them per k
+// step next to 2 us of MFMAs.  Here the copies are register loads (a few issue cycles each, fully asynchronous) written to LDS with
+// ds_write_b128: one register set per wave, a stage requested one (~2 us) k step before it is written, three LDS stages, one barrier
+// per k step.  Same products in the same order per output element as the other forms: bit-identical results (tested).
+// Requires M % 256 == 0, N % 256 == 0 (the operands' fragment buffers then hold whole tiles); grid = (N / 256 * ksplit, M / 256).
+__global__ __launch_bounds__(256, 1) void tile_gemm_big_kernel(TileArgs a) {
+    constexpr int NF = 16 * 3;                  // fragments per stage: 8 weight blocks + 8 row blocks, three terms each
+    constexpr int STAGE = NF * 1024;
+    constexpr int ND = NF / 4;                  // pieces per wave and stage
+    __shared__ __attribute__((aligned(16))) char lds[3 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntile = a.N >> 8;
+    const int tile = (int)blockIdx.x % ntile, ks = (int)blockIdx.x / ntile;
+    const int mb0 = (int)blockIdx.y * 8;
+    const int s_lo = (int)((long long)a.ksteps * ks / a.ksplit), s_hi = (int)((long long)a.ksteps * (ks + 1) / a.ksplit);
+    const int nst = s_hi - s_lo;
+    if (nst <= 0) return;
+    const int wn = wave & 1, wm = wave >> 1;    // this wave's weight blocks 4 wn .. + 3, row tiles 4 wm .. + 3
+
+    // ---- copies: piece f = wave * 12 + j of a stage.  Wave-uniform base addresses (scalar registers) + ONE per-lane offset: the
+    // twelve pointers must not cost 24 vector registers next to 256 accumulators
+    const char* sbase[ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+        const int f = wave * ND + j;
+        const int g = f < 24 ? f : f - 24;
+        const int blk = g / 3, pl = g - blk * 3;
+        const uint16_t* p0 = f < 24 ? a.wb + ((size_t)(tile * 8 + blk) * a.ksteps + s_lo) * KSTEP + pl * FRAG
+                                     : a.xb + (size_t)(mb0 + blk) * a.x_mblk_stride + (size_t)s_lo * KSTEP + pl * FRAG;
+        sbase[j] = reinterpret_cast<const char*>(p0);
+    }
+    const unsigned lane_off = lane * 16;
+    const unsigned wdst = wave * ND * 1024 + lane * 16;           // this wave's pieces are consecutive fragments of the stage
+    u32x4 ra[ND];
+    auto ld = [&](u32x4 (&r)[ND], int st) __attribute__((always_inline)) {       // unconditional (past the end: the last stage again)
+        const size_t so = (size_t)(st < nst ? st : nst - 1) * (KSTEP * 2);
+#pragma unroll
+        for (int j = 0; j < ND; ++j) r[j] = *reinterpret_cast<const u32x4*>(sbase[j] + so + lane_off);
+    };
+    auto stg = [&](const u32x4 (&r)[ND], int st) __attribute__((always_inline)) {
+        char* base = lds + (st % 3) * STAGE + wdst;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) *reinterpret_cast<u32x4*>(base + j * 1024) = r[j];
+    };
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][t][r] = 0.f;
+    auto frag = [&](int buf, int f) __attribute__((always_inline)) {
+        return *reinterpret_cast<const u32x4*>(lds + buf * STAGE + lane * 16 + f * 1024);
+    };
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        u32x4 w[4][3], x[2][3];
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) w[b][pl] = frag(buf, (4 * wn + b) * 3 + pl);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) x[0][pl] = frag(buf, 24 + (4 * wm) * 3 + pl);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t + 1 < 4) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) x[(t + 1) & 1][pl] = frag(buf, 24 + (4 * wm + t + 1) * 3 + pl);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x4* xt = x[t & 1];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                acc[b][t] = mfma_bf16(xt[1], w[b][1], acc[b][t]);
+                acc[b][t] = mfma_bf16(xt[0], w[b][2], acc[b][t]);
+                acc[b][t] = mfma_bf16(xt[2], w[b][0], acc[b][t]);
+                acc[b][t] = mfma_bf16(xt[0], w[b][1], acc[b][t]);
+                acc[b][t] = mfma_bf16(xt[1], w[b][0], acc[b][t]);
+                acc[b][t] = mfma_bf16(xt[0], w[b][0], acc[b][t]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    ld(ra, 0); stg(ra, 0);
+    ld(ra, 1); stg(ra, 1);
+    ld(ra, 2);
+    __syncthreads();                                                // stages 0 and 1 are in LDS, stage 2 is on its way
+    // iteration s: stage s + 2 (requested one iteration = one ~2 us k step ago) -> LDS buffer (s + 2) % 3, which held stage s - 1 --
+    // every wave left it before the barrier that ended iteration s - 1 --, the register set then takes stage s + 3; stage s is
+    // multiplied; the closing barrier publishes stage s + 2 and releases buffer s % 3.  (ONE register set: with two, next to 256
+    // accumulator registers, the compiler spilled the copies themselves.)
+    for (int s = 0; s < nst; ++s) {
+        if (s + 2 < nst) stg(ra, s + 2);
+        ld(ra, s + 3);
+        compute(s % 3);
+        __syncthreads();
+    }
+    float* out = a.parts + (size_t)ks * a.part_stride;
+    const int kh = lane >> 5;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int n = (tile * 8 + 4 * wn + b) * 32 + (lane & 31);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int mbase = (mb0 + 4 * wm + t) * 32 + 4 * kh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[(size_t)(mbase + (r & 3) + 8 * (r >> 2)) * a.ld + n] = acc[b][t][r];
+        }
+    }
+}
+
 // NP = number of slabs when it is 1 / 2 / 4 / 8 (their reads are then issued together), 0 = any number (one after the other)
 template <int NP>
 __global__ __launch_bounds__(256) void tile_lstm_finish_kernel(LstmFinishArgs a) {
@@ -897,6 +1017,16 @@ static int tile_rows_per_chunk(int mblk, int col_wgs) {
 
 // test / A-B hook: 0 = every wave copies its share of a stage (tile_gemm_kernel), 1 = dedicated loader waves + 8 computing waves,
 // 2 = dedicated loader waves + 4 wide computing waves (tile_gemm_ld2_kernel), 3 = 2 for long K loops, 1 otherwise (default)
+static int cvc_tile_big = 0, cvc_tile_big_min_wgs = 192;      // OFF by default (see below); min_wgs == 1: any grid (tests, A/B)
+// test / A-B hook: 1 = the 256 x 256 form where it applies, 0 (default) = never; min_wgs > 0 sets the smallest grid it is taken for.
+// Returns the previous on / off setting.
+extern "C" int cvc_tile_gemm_big(int on, int min_wgs) {
+    const int prev = cvc_tile_big;
+    if (on >= 0) cvc_tile_big = on ? 1 : 0;
+    if (min_wgs > 0) cvc_tile_big_min_wgs = min_wgs;
+    return prev;
+}
+
 extern "C" int cvc_tile_gemm_loaders(int on) {
     const int prev = cvc_tile_loader_waves;
     if (on >= 0) cvc_tile_loader_waves = on > 4 ? 3 : on;
@@ -912,6 +1042,19 @@ extern "C" int cvc_tile_gemm(const void* wb, const void* xb, long long x_mblk_st
     a.M = M; a.N = N; a.ntile = (N + 127) / 128; a.ksplit = ksplit; a.parts = parts; a.ld = ld; a.part_stride = part_stride;
     const int mblk = (M + 31) / 32;
     const hipStream_t st = (hipStream_t)stream;
+    // the 256 x 256 form for large products made of whole tiles (see tile_gemm_big_kernel); cvc_tile_gemm_big(0) switches it off (A/B)
+    // (measured, round 6: standalone with cold caches it wins on ONE nearly full round of workgroups -- dW of an LSTM block, 8192 x
+    // 2048 outputs = 256 workgroups: 463 -> 413 us, a k step at 85 % of the power-limited MFMA time against 68 % -- and loses on grids
+    // of many rounds -- GRU input projections 3.34 -> 3.70 ms: one workgroup per CU leaves every round's prologue and its 256 KB
+    // epilogue uncovered, 11.25 rounds run as 12 -- and on grids below a round.  INSIDE the training step the six dW products it
+    // applies to did not get faster (22 dense launches 3.69 -> 3.76 ms at config 3, 2.09 -> 2.25 at config 4's share): off by
+    // default, cvc_tile_gemm_big(1, 0) selects it)
+    const long long big_wgs = (long long)(M >> 8) * (N >> 8) * ksplit;
+    if (cvc_tile_big != 0 && (M & 255) == 0 && (N & 255) == 0 && M >= 512 && big_wgs >= cvc_tile_big_min_wgs &&
+        (big_wgs <= 256 || cvc_tile_big_min_wgs == 1)) {
+        hipLaunchKernelGGL(tile_gemm_big_kernel, dim3((N >> 8) * ksplit, M >> 8), dim3(256), 0, st, a);
+        return cvc_launch_status();
+    }
     const int MH = tile_rows_per_chunk(mblk, a.ntile * ksplit);
     const int chunks = (mblk + 2 * MH - 1) / (2 * MH);
     const dim3 grid(a.ntile * ksplit, chunks);

@@ -125,6 +125,7 @@ SIGNATURES = {
     "cvc_attn_bwd_pair": [_I, C.POINTER(GradSrc), _P, _P, _F, C.POINTER(AttnSet), _I, C.POINTER(GradSrc), _I, _I, _I, _I, _P, _P, _P,
                           C.POINTER(_P), C.POINTER(_P), _P],
     "cvc_ctxfeat_bwd_steps": [_P, _P, _I, _I, _I, _I, _P, _P],
+    "cvc_tile_gemm_big": [_I, _I],
     "cvc_dproj_bwd_steps": [_P, _LL, _LL, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "cvc_lstm_pointwise_bwd4": [C.POINTER(GradSrc), _P, _P, C.c_uint, _F, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P],
     "cvc_vocab_head_nll_fwd": [_P, _I, _LL, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P],
@@ -255,7 +256,7 @@ _VOID_RETURN = {"cvc_decode_plan_destroy"}
 # drop-in ABI of include/cvc_hip.h.
 BLOCKS = {
     "cvc_attn_scores", "cvc_attn_wsum", "cvc_attn_scores_qparts", "cvc_attn_wsum_quad", "cvc_attn_wsum_frag", "cvc_attn_wsum_quad_rm",
-    "cvc_attn_bwd_pair", "cvc_ctxfeat_bwd_steps", "cvc_dproj_bwd_steps", "cvc_linear_splitk_fwd", "cvc_linear_top2_fwd", "cvc_top2_final", "cvc_packed_lstm_fwd", "cvc_packed_linear_fwd",
+    "cvc_attn_bwd_pair", "cvc_ctxfeat_bwd_steps", "cvc_dproj_bwd_steps", "cvc_tile_gemm_big", "cvc_linear_splitk_fwd", "cvc_linear_top2_fwd", "cvc_top2_final", "cvc_packed_lstm_fwd", "cvc_packed_linear_fwd",
     "cvc_packed_lstm_embgate_fwd", "cvc_packed_lstm_embgate_ex_fwd", "cvc_packed_lstm_late_fwd", "cvc_packed_lstm_train_fwd",
     "cvc_packed_lstm_train_pre_fwd", "cvc_packed_lstm_train_drop_fwd", "cvc_lstm_pointwise_bwd", "cvc_lstm_pointwise_bwd3",
     "cvc_lstm_pointwise_bwd3_drop", "cvc_pack_lstm_weights", "cvc_linear_nn_planes_fwd", "cvc_linear_nn_planes2_fwd", "cvc_gru_seq_train_fwd", "cvc_lstm_pointwise_bwd4_pair", "cvc_beam_select_parts", "cvc_tile_lstm_finish",
@@ -391,7 +392,7 @@ def error_word_ok(word: torch.Tensor) -> bool:
 # --------------------------------------------------------------------------- per-entry-point HIP-event timing (bench.py)
 _raw_fns = {}
 # entry points that launch nothing (sizes, switches, handles): an event pair around them would read as ~5 us of GPU time each
-_HOST_ONLY = {"cvc_tile_rows_alloc", "cvc_col_sum_ws", "cvc_train_loop_bwd_ws", "cvc_bn_workspace", "cvc_optim_chunk_elems", "cvc_version",
+_HOST_ONLY = {"cvc_tile_gemm_big", "cvc_tile_rows_alloc", "cvc_col_sum_ws", "cvc_train_loop_bwd_ws", "cvc_bn_workspace", "cvc_optim_chunk_elems", "cvc_version",
               "cvc_block", "cvc_gemm_packed_split", "cvc_gemm_force_generic", "cvc_tile_gemm_loaders", "cvc_gru_persistent_waves8",
               "cvc_decode_plan_create", "cvc_decode_plan_destroy", "cvc_decode_plan_set_features", "cvc_decode_num_launches",
               "cvc_train_loop_profile", "cvc_train_loop_profile_read", "cvc_comm_unique_id", "cvc_comm_init", "cvc_comm_destroy"}

@@ -38,6 +38,10 @@ int cvc_ctxfeat_bwd_steps(const float* attn, const float* d_ctx_all, int T, int 
  * floats apart) summed on load (+ q_bias): the h2attn outputs the forward kept (cvc_train_loop.q). */
 int cvc_dproj_bwd_steps(const float* q, long long q_step, long long q_plane, int q_nplanes, const float* q_bias, const float* w_a,
                         const float* proj, const float* ds, int T, int B, int n, int A, float* d_proj, cvc_stream_t stream);
+/* test / A-B hook of cvc_tile_gemm's 256 x 256 form (round 6, OFF by default: measured no gain inside the training step; applies to
+ * M % 256 == 0, N % 256 == 0, M >= 512 and min_wgs .. 256 workgroups, any grid with min_wgs = 1): on = 1 / 0 / -1 (query only),
+ * min_wgs > 0 sets the threshold.  Returns the previous on / off setting. */
+int cvc_tile_gemm_big(int on, int min_wgs);
 int cvc_linear_splitk_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, int M, int Nout,
                           int ksplit, float* y_parts, cvc_stream_t stream);
 int cvc_linear_top2_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, int M, int Nout,

@@ -528,7 +528,8 @@ def test_packed_lstm_exchange_finish_equals_full_k_kernel(dev, lib, M, eg, mode)
 
 
 @pytest.mark.parametrize("M,K,N,ksplit", [(320, 6144, 8192, 4), (320, 2048, 5000, 6), (150, 512, 130, 3), (65, 32, 50, 2),
-                                          (700, 256, 256, 1), (1, 16, 1, 1)])
+                                          (700, 256, 256, 1), (1, 16, 1, 1), (512, 96, 256, 1), (768, 400, 512, 2), (2560, 2048, 1024, 1),
+                                          (1024, 48, 256, 3)])
 def test_tile_gemm_vs_fp64(dev, lib, M, K, N, ksplit):
     """cvc_tile_gemm (rows > 64: both operands as bf16 split-term fragments, LDS-DMA ring, K split over workgroups): the slab
     sum against fp64 with an error no worse than an fp32 GEMM's, round trip of the fragment packers, and run-to-run
@@ -562,6 +563,13 @@ def test_tile_gemm_vs_fp64(dev, lib, M, K, N, ksplit):
             assert torch.equal(parts, lib.tile_gemm(wb, xb, 0, K, M, N, ksplit)), form
     finally:
         L.cvc_tile_gemm_loaders(prev)
+    # ... and the 256 x 256 form (whole tiles only; forced here for any grid size)
+    if M % 256 == 0 and N % 256 == 0 and M >= 512:
+        prev_big = L.cvc_tile_gemm_big(1, 1)
+        try:
+            assert torch.equal(parts, lib.tile_gemm(wb, xb, 0, K, M, N, ksplit))
+        finally:
+            L.cvc_tile_gemm_big(prev_big, 192)
     # a K segment of a wider activation buffer: point at its first k step
     if K >= 64:
         xw = torch.zeros(ra // 32, (K + 32) // 16, 3, 2, 32, 8, dtype=torch.int16, device=dev)

@@ -10,11 +10,17 @@ from cvc.decode import pack_weights_tile, to_frag
 dev = torch.device("cuda:0")
 shapes = [("att_lstm", 320, 5120, 8192, 4), ("lang_lstm", 320, 6144, 8192, 4), ("h2attn", 320, 2048, 1024, 16),
           ("logits", 320, 2048, 5000, 6), ("lang cfg5", 320, 12288, 16384, 2), ("lang b=1 M=150", 150, 6144, 8192, 4)]
+big_shapes = [("dW lstm block", 8192, 2560, 2048, 1), ("dW emb block", 8192, 2560, 1024, 1), ("GRU input proj", 30720, 2048, 6144, 1),
+              ("GRU dW_ih", 6144, 30720, 2048, 1), ("frame embed", 30720, 2048, 1024, 1), ("head dX", 1280, 5008, 2048, 1),
+              ("hoisted gates", 1280, 1024, 8192, 1)]
+if os.environ.get("BIG"):
+    shapes = big_shapes
 if len(sys.argv) > 1:
     shapes = [s for s in shapes if s[0].startswith(sys.argv[1])]
 modes = [int(a) for a in sys.argv[2:]] or [1]
 for mode in modes:
-  hip.lib().cvc_tile_gemm_loaders(mode)
+  hip.lib().cvc_tile_gemm_loaders(mode if mode < 10 else 3)
+  hip.lib().cvc_tile_gemm_big(1 if mode >= 10 else 0, 1)          # mode 10: the 256 x 256 form where it applies
   print("loader waves:", mode)
   for name, M, K, N, ks in shapes:
       x = torch.randn(M, K, device=dev)
