@@ -516,9 +516,6 @@ def run_secondary(args, dev):
         return brief(run_train(args, d, dev, 0, 1, steps=steps, warmup=2, min_warm=0.2, cpu_baseline=False, config_name=cfg, regions=3,
                                always_exchange=always_exchange))
 
-    if os.environ.get("CVC_BENCH_E2E_FIRST"):          # (diagnostic: does the order of the secondaries matter?)
-        from bench_e2e import dims_of as _d, run_e2e as _r
-        attempt("e2e train first (diagnostic)", lambda: brief(_r(args, _d("cfg2"), dev, "train", steps=5, warmup=2, config_name="cfg2", cpu_baseline=False)))
     attempt("cfg3 beam=5 decode", lambda: decode("cfg3", 5, 11.0))
     attempt("cfg3 cyclical train step (B=64)", lambda: train("cfg3", 25.0))
     attempt("cfg4 cyclical train step, one GPU's share (B=32 per GPU) WITH the per-bucket RCCL exchange captured in the step, on a "
