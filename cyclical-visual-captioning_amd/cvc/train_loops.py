@@ -52,16 +52,9 @@ def clip_groups(B: int):
     backward-data product's row group); clips are independent through both loops, so a larger per-GPU batch (reference
     cfgs/cyclical.yml: 48; a 288 GB part invites 128+) runs the loops once per group -- own arena, own joint back-propagation, own
     weight-gradient products, which autograd sums -- while everything batch-wide (embedding, vocabulary head and criteria,
-    grounder, localizer) stays one call over all B clips.  Even groups (96 -> 48 + 48): both groups' joint backward then takes the
-    same kernel form."""
-    n = (B + 63) // 64
-    base, extra = divmod(B, n)
-    out, b0 = [], 0
-    for g in range(n):
-        b1 = b0 + base + (1 if g < extra else 0)
-        out.append((b0, b1))
-        b0 = b1
-    return out
+    grounder, localizer) stays one call over all B clips.  Full groups first (96 -> 64 + 32, 130 -> 64 + 64 + 2): a cell launch
+    costs the same for 33 .. 64 rows and ~20 % less for <= 32, and a last group of <= 32 clips takes the one-operand joint backward."""
+    return [(b0, min(b0 + 64, B)) for b0 in range(0, B, 64)]
 
 
 class LoopArena:

@@ -188,7 +188,7 @@ def test_cyclical_gradients_vs_oracle_on_other_shapes(B, N, F, R, A, E, V, T):
     """Losses and every parameter gradient of the cyclical pass (eval-mode dropout) against the CPU oracle's autograd on
     shapes the golden fixtures do not cover: two MFMA row tiles / ragged M, a single clip, one frame, widths that take the
     backward-data GEMM's partial slabs; round 6: more than 64 clips per GPU -- the C-driven loops run once per group of <= 64 clips
-    (96 -> 48 + 48, 128 -> 64 + 64, 130 -> 44 + 43 + 43), batch-wide pieces once, the groups' weight gradients summed."""
+    (96 -> 64 + 32, 128 -> 64 + 64, 130 -> 64 + 64 + 2), batch-wide pieces once, the groups' weight gradients summed."""
     import dataclasses
     from helpers import build_model, to_dev, model_call
     from oracle import ref_cpu as O
