@@ -592,6 +592,10 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: n_gpus must be the number of ranks that run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    if os.environ.get("CVC_BENCH_DEVICE") is not None:
+        # test knob: every rank on THIS device (two rank processes time-slicing the one GPU of a test box, exchanging through the
+        # stand-in librccl of tests/stub_rccl -- real RCCL refuses two ranks on one device); never set by a measurement
+        local_rank = int(os.environ["CVC_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if args.tile_loaders is not None:

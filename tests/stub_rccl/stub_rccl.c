@@ -8,7 +8,9 @@
  * Semantics follow rccl.h for the calls used: ncclReduceScatter(send, recv, recvcount): recv = sum over ranks of
  * send[rank * recvcount ...]; ncclAllGather(send, recv, sendcount): recv[r * sendcount ...] = rank r's send; ncclAllReduce;
  * in-place forms (recv inside send / send inside recv) as RCCL defines them.  Sums run in rank order.  float only (ncclFloat = 7),
- * ncclSum only (0).  Streams are ignored: every call completes before it returns.  Built by the test: gcc -shared -fPIC -lpthread -lrt.
+ * ncclSum only (0).  Every call completes before it returns; any count (pieces of 4 MiB through the shared slots).  Host pointers
+ * (the CPU suite) or device pointers (two rank processes on one GPU: copied through the host on the caller's stream, see below).
+ * Built by the test: gcc -shared -fPIC -lpthread -lrt -ldl.
  */
 #define _GNU_SOURCE
 #include <fcntl.h>
@@ -94,56 +96,120 @@ int ncclCommInitRank(void** comm, int world, ncclUniqueId id, int rank) {
     return ncclSuccess;
 }
 
-static int check(const Comm* c, size_t floats_per_rank, int type, int op) {
-    if (!c || type != 7 || (op != 0 && op != -1) || floats_per_rank > STUB_MAX_FLOATS) return ncclInvalidArgument;
-    return ncclSuccess;
+/* ---- device buffers (round 6: two REAL rank processes sharing the one GPU of a test box) --------------------------------------
+ * hipPointerGetAttributes / hipMemcpyAsync / hipStreamSynchronize are looked up in the process (libamdhip64 is there whenever the
+ * caller has device pointers); a device buffer is copied to the host on the caller's stream, exchanged as a host buffer, and copied
+ * back -- synchronously: such a call is a stream operation only in the sense that it is ordered behind the stream's earlier work,
+ * and it CANNOT be captured into a HIP graph (the tests run eager steps). */
+#include <dlfcn.h>
+typedef struct { int type; int device; void* devicePointer; void* hostPointer; int isManaged; unsigned allocationFlags; } StubPtrAttr;
+static int (*p_attr)(StubPtrAttr*, const void*);
+static int (*p_copy)(void*, const void*, size_t, int, void*);
+static int (*p_sync)(void*);
+static int (*p_lasterr)(void);
+static int is_device(const void* ptr) {
+    if (!p_attr) {
+        p_attr = (int (*)(StubPtrAttr*, const void*))dlsym(RTLD_DEFAULT, "hipPointerGetAttributes");
+        p_copy = (int (*)(void*, const void*, size_t, int, void*))dlsym(RTLD_DEFAULT, "hipMemcpyAsync");
+        p_sync = (int (*)(void*))dlsym(RTLD_DEFAULT, "hipStreamSynchronize");
+        p_lasterr = (int (*)(void))dlsym(RTLD_DEFAULT, "hipGetLastError");
+    }
+    if (!p_attr || !p_copy || !p_sync) return 0;
+    StubPtrAttr at;
+    memset(&at, 0, sizeof at);
+    if (p_attr(&at, ptr) != 0) { if (p_lasterr) (void)p_lasterr(); return 0; }      /* an ordinary host pointer: not registered with HIP */
+    return at.type == 2 /* hipMemoryTypeDevice */;
 }
 
-int ncclAllReduce(const void* send, void* recv, size_t count, int type, int op, void* comm, void* stream) {
-    (void)stream;
-    Comm* c = comm;
-    if (check(c, count, type, op) || !send || !recv) return ncclInvalidArgument;
+static int check(const Comm* c, int type, int op) { return (!c || type != 7 || (op != 0 && op != -1)) ? ncclInvalidArgument : ncclSuccess; }
+
+/* host primitives, any count: pieces of STUB_MAX_FLOATS through the shared slots */
+static void allreduce_host(Comm* c, float* buf, size_t n) {
     Fabric* f = c->f;
-    memcpy(f->slot[c->rank], send, count * sizeof(float));
-    pthread_barrier_wait(&f->bar);
-    float* out = recv;
-    for (size_t i = 0; i < count; ++i) {
-        float s = f->slot[0][i];
-        for (int r = 1; r < c->world; ++r) s += f->slot[r][i];
-        out[i] = s;
+    float* tmp = malloc((n < STUB_MAX_FLOATS ? n : STUB_MAX_FLOATS) * sizeof(float));
+    for (size_t off = 0; off < n; off += STUB_MAX_FLOATS) {
+        const size_t m = n - off < STUB_MAX_FLOATS ? n - off : STUB_MAX_FLOATS;
+        memcpy(f->slot[c->rank], buf + off, m * sizeof(float));
+        pthread_barrier_wait(&f->bar);
+        for (size_t i = 0; i < m; ++i) {
+            float s = f->slot[0][i];
+            for (int r = 1; r < c->world; ++r) s += f->slot[r][i];         /* rank order */
+            tmp[i] = s;
+        }
+        pthread_barrier_wait(&f->bar);
+        memcpy(buf + off, tmp, m * sizeof(float));
     }
-    pthread_barrier_wait(&f->bar);
+    free(tmp);
+}
+
+static void allgather_host(Comm* c, const float* send, float* recv, size_t sendcount) {
+    Fabric* f = c->f;
+    /* (send may lie inside recv: staged before anything of recv is written) */
+    for (size_t off = 0; off < sendcount; off += STUB_MAX_FLOATS) {
+        const size_t m = sendcount - off < STUB_MAX_FLOATS ? sendcount - off : STUB_MAX_FLOATS;
+        memcpy(f->slot[c->rank], send + off, m * sizeof(float));
+        pthread_barrier_wait(&f->bar);
+        for (int r = 0; r < c->world; ++r) memcpy(recv + (size_t)r * sendcount + off, f->slot[r], m * sizeof(float));
+        pthread_barrier_wait(&f->bar);
+    }
+}
+
+/* run `body` on host copies of a device buffer pair: in (n_in floats at send), out (n_out floats at recv) */
+#define STUB_D2H 2
+#define STUB_H2D 1
+
+int ncclAllReduce(const void* send, void* recv, size_t count, int type, int op, void* comm, void* stream) {
+    Comm* c = comm;
+    if (check(c, type, op) || !send || !recv || count < 1) return ncclInvalidArgument;
+    if (is_device(send)) {
+        float* h = malloc(count * sizeof(float));
+        if (p_copy(h, send, count * sizeof(float), STUB_D2H, stream) != 0 || p_sync(stream) != 0) { free(h); return ncclSystemError; }
+        allreduce_host(c, h, count);
+        const int rc = p_copy(recv, h, count * sizeof(float), STUB_H2D, stream) != 0 || p_sync(stream) != 0;
+        free(h);
+        return rc ? ncclSystemError : ncclSuccess;
+    }
+    if (recv != send) memmove(recv, send, count * sizeof(float));
+    allreduce_host(c, recv, count);
     return ncclSuccess;
 }
 
 int ncclReduceScatter(const void* send, void* recv, size_t recvcount, int type, int op, void* comm, void* stream) {
-    (void)stream;
     Comm* c = comm;
-    if (check(c, recvcount * (c ? (size_t)c->world : 1), type, op) || !send || !recv) return ncclInvalidArgument;
-    Fabric* f = c->f;
-    memcpy(f->slot[c->rank], send, recvcount * (size_t)c->world * sizeof(float));          /* staged first: recv may lie inside send */
-    pthread_barrier_wait(&f->bar);
-    float* out = recv;
-    const size_t off = (size_t)c->rank * recvcount;
-    for (size_t i = 0; i < recvcount; ++i) {
-        float s = f->slot[0][off + i];
-        for (int r = 1; r < c->world; ++r) s += f->slot[r][off + i];
-        out[i] = s;
-    }
-    pthread_barrier_wait(&f->bar);
-    return ncclSuccess;
+    if (check(c, type, op) || !send || !recv || recvcount < 1) return ncclInvalidArgument;
+    const size_t n = recvcount * (size_t)c->world;
+    float* h = malloc(n * sizeof(float));                 /* the whole send buffer, staged: recv may lie inside send */
+    const int dev = is_device(send);
+    if (dev) { if (p_copy(h, send, n * sizeof(float), STUB_D2H, stream) != 0 || p_sync(stream) != 0) { free(h); return ncclSystemError; } }
+    else memcpy(h, send, n * sizeof(float));
+    allreduce_host(c, h, n);                               /* every rank sums everything; a rank keeps ITS shard */
+    const float* mine = h + (size_t)c->rank * recvcount;
+    int rc = 0;
+    if (dev) rc = p_copy(recv, mine, recvcount * sizeof(float), STUB_H2D, stream) != 0 || p_sync(stream) != 0;
+    else memcpy(recv, mine, recvcount * sizeof(float));
+    free(h);
+    return rc ? ncclSystemError : ncclSuccess;
 }
 
 int ncclAllGather(const void* send, void* recv, size_t sendcount, int type, void* comm, void* stream) {
-    (void)stream;
     Comm* c = comm;
-    if (check(c, sendcount, type, -1) || !send || !recv) return ncclInvalidArgument;
-    Fabric* f = c->f;
-    memcpy(f->slot[c->rank], send, sendcount * sizeof(float));
-    pthread_barrier_wait(&f->bar);
-    float* out = recv;
-    for (int r = 0; r < c->world; ++r) memcpy(out + (size_t)r * sendcount, f->slot[r], sendcount * sizeof(float));
-    pthread_barrier_wait(&f->bar);
+    if (check(c, type, -1) || !send || !recv || sendcount < 1) return ncclInvalidArgument;
+    const size_t n = sendcount * (size_t)c->world;
+    if (is_device(send)) {
+        float* hs = malloc(sendcount * sizeof(float));
+        float* hr = malloc(n * sizeof(float));
+        int rc = p_copy(hs, send, sendcount * sizeof(float), STUB_D2H, stream) != 0 || p_sync(stream) != 0;
+        if (!rc) {
+            allgather_host(c, hs, hr, sendcount);
+            rc = p_copy(recv, hr, n * sizeof(float), STUB_H2D, stream) != 0 || p_sync(stream) != 0;
+        }
+        free(hs); free(hr);
+        return rc ? ncclSystemError : ncclSuccess;
+    }
+    float* hs = malloc(sendcount * sizeof(float));        /* send may lie inside recv */
+    memcpy(hs, send, sendcount * sizeof(float));
+    allgather_host(c, hs, recv, sendcount);
+    free(hs);
     return ncclSuccess;
 }
 

@@ -188,7 +188,7 @@ def _build_stub(dirname) -> str:
     """tests/stub_rccl/stub_rccl.c -> <dirname>/librccl.so (host pointers over POSIX shared memory; test infrastructure)"""
     import subprocess
     out = os.path.join(str(dirname), "librccl.so")
-    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", out, STUB_SRC, "-lpthread", "-lrt"])
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", out, STUB_SRC, "-lpthread", "-lrt", "-ldl"])
     return out
 
 
