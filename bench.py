@@ -89,6 +89,9 @@ def parse(argv=None):
                    help="start the rank processes through the torch.distributed.run child also for --gpus 1 (the path every N > 1 run takes)")
     p.add_argument("--no-secondary", action="store_true", help="default decode run: skip the short runs of the other configs")
     p.add_argument("--secondary-seconds", type=float, default=0.35, help="timed seconds per secondary measurement")
+    p.add_argument("--watchdog-seconds", type=float, default=2400.0,
+                   help="a run still going after this much wall time writes every thread's Python stack to stderr and exits 3 (a hung "
+                        "bench must not hold a GPU box until somebody's outer limit; 0 = off).  SIGTERM writes the stacks as well.")
     p.add_argument("--cpu-repeats", type=int, default=3)
     p.add_argument("--seed", type=int, default=1234)
     return p.parse_args(argv)
@@ -574,6 +577,11 @@ def main():
 
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
+    import faulthandler
+    import signal
+    faulthandler.register(signal.SIGTERM, all_threads=True, chain=True)      # a launcher that gives up on us learns where we were
+    if args.watchdog_seconds > 0:
+        faulthandler.dump_traceback_later(args.watchdog_seconds, exit=True)
     if (args.gpus > 1 or args.spawn) and not under_launcher:
         # N ranks were asked for and nobody started them: do it here, BEFORE anything below touches a GPU
         raise SystemExit(spawn_ranks(args))

@@ -108,17 +108,39 @@ static int (*p_copy)(void*, const void*, size_t, int, void*);
 static int (*p_sync)(void*);
 static int (*p_lasterr)(void);
 static int is_device(const void* ptr) {
-    if (!p_attr) {
-        p_attr = (int (*)(StubPtrAttr*, const void*))dlsym(RTLD_DEFAULT, "hipPointerGetAttributes");
-        p_copy = (int (*)(void*, const void*, size_t, int, void*))dlsym(RTLD_DEFAULT, "hipMemcpyAsync");
-        p_sync = (int (*)(void*))dlsym(RTLD_DEFAULT, "hipStreamSynchronize");
-        p_lasterr = (int (*)(void))dlsym(RTLD_DEFAULT, "hipGetLastError");
+    static int looked;
+    if (!looked) {
+        /* the HIP runtime ALREADY in the process (never loaded from here): Python loads extension modules RTLD_LOCAL, so the global
+           scope usually does not show it -- ask for the loaded object by its soname */
+        static const char* names[] = {"libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6", 0};
+        void* h = RTLD_DEFAULT;
+        if (!dlsym(h, "hipPointerGetAttributes")) {
+            h = 0;
+            for (int i = 0; names[i] && !h; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD);
+        }
+        looked = 1;
+        if (h || dlsym(RTLD_DEFAULT, "hipPointerGetAttributes")) {
+            if (!h) h = RTLD_DEFAULT;
+            p_attr = (int (*)(StubPtrAttr*, const void*))dlsym(h, "hipPointerGetAttributes");
+            p_copy = (int (*)(void*, const void*, size_t, int, void*))dlsym(h, "hipMemcpyAsync");
+            p_sync = (int (*)(void*))dlsym(h, "hipStreamSynchronize");
+            p_lasterr = (int (*)(void))dlsym(h, "hipGetLastError");
+        }
+        const char* e = getenv("CVC_STUB_TRACE");
+        if (e && e[0] == '1') fprintf(stderr, "[stub_rccl] HIP runtime in the process: %s\n", p_attr ? "found" : "not found (host pointers only)");
     }
     if (!p_attr || !p_copy || !p_sync) return 0;
     StubPtrAttr at;
     memset(&at, 0, sizeof at);
     if (p_attr(&at, ptr) != 0) { if (p_lasterr) (void)p_lasterr(); return 0; }      /* an ordinary host pointer: not registered with HIP */
     return at.type == 2 /* hipMemoryTypeDevice */;
+}
+
+/* CVC_STUB_TRACE=1: one stderr line per call (rank, call, count) -- two ranks whose lines differ issued different collectives */
+static void trace(const Comm* c, const char* what, size_t count, const void* send) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("CVC_STUB_TRACE"); on = e && e[0] == '1'; }
+    if (on) fprintf(stderr, "[stub_rccl] rank %d %s count %zu %s\n", c ? c->rank : -1, what, count, is_device(send) ? "device" : "host");
 }
 
 static int check(const Comm* c, int type, int op) { return (!c || type != 7 || (op != 0 && op != -1)) ? ncclInvalidArgument : ncclSuccess; }
@@ -161,6 +183,7 @@ static void allgather_host(Comm* c, const float* send, float* recv, size_t sendc
 int ncclAllReduce(const void* send, void* recv, size_t count, int type, int op, void* comm, void* stream) {
     Comm* c = comm;
     if (check(c, type, op) || !send || !recv || count < 1) return ncclInvalidArgument;
+    trace(c, "all_reduce", count, send);
     if (is_device(send)) {
         float* h = malloc(count * sizeof(float));
         if (p_copy(h, send, count * sizeof(float), STUB_D2H, stream) != 0 || p_sync(stream) != 0) { free(h); return ncclSystemError; }
@@ -178,6 +201,7 @@ int ncclReduceScatter(const void* send, void* recv, size_t recvcount, int type, 
     Comm* c = comm;
     if (check(c, type, op) || !send || !recv || recvcount < 1) return ncclInvalidArgument;
     const size_t n = recvcount * (size_t)c->world;
+    trace(c, "reduce_scatter", recvcount, send);
     float* h = malloc(n * sizeof(float));                 /* the whole send buffer, staged: recv may lie inside send */
     const int dev = is_device(send);
     if (dev) { if (p_copy(h, send, n * sizeof(float), STUB_D2H, stream) != 0 || p_sync(stream) != 0) { free(h); return ncclSystemError; } }
@@ -195,6 +219,7 @@ int ncclAllGather(const void* send, void* recv, size_t sendcount, int type, void
     Comm* c = comm;
     if (check(c, type, -1) || !send || !recv || sendcount < 1) return ncclInvalidArgument;
     const size_t n = sendcount * (size_t)c->world;
+    trace(c, "all_gather", sendcount, send);
     if (is_device(send)) {
         float* hs = malloc(sendcount * sizeof(float));
         float* hr = malloc(n * sizeof(float));

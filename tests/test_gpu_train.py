@@ -814,10 +814,17 @@ def _two_rank_env(tmp_path):
     src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stub_rccl", "stub_rccl.c")
     out = os.path.join(str(tmp_path), "librccl.so")
     subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", out, src, "-lpthread", "-lrt", "-ldl"])
-    env = dict(os.environ, CVC_RCCL_LIB=out, CVC_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, CVC_RCCL_LIB=out, CVC_BENCH_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0", CVC_STUB_TRACE="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     return env
+
+
+def _took_the_device_path(stderr):
+    """the stand-in's call trace: every collective of the run was handed DEVICE buffers and was staged on the caller's stream (a device
+    pointer mistaken for a host pointer would be read by the CPU through the PCIe aperture, unordered with the stream)"""
+    calls = [l for l in stderr.splitlines() if l.startswith("[stub_rccl] rank")]
+    return len(calls) > 0 and all(l.endswith(" device") for l in calls)
 
 
 def _launch_two(script_args, env, timeout=600):
@@ -848,6 +855,7 @@ def test_bench_train_finishes_with_two_real_rank_processes(tmp_path):
     r = _launch_two([os.path.join(root, "bench.py"), "--gpus", "2", "--mode", "train", "--config", "tiny", "--no-train-graph", "--steps", "3",
                      "--warmup", "1", "--min-warm-seconds", "0.2", "--no-cpu-baseline"], env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert _took_the_device_path(r.stderr), r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
@@ -868,6 +876,7 @@ def test_two_rank_training_step_equals_the_single_process_step_on_the_whole_batc
     script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "two_rank_step.py")
     r = _launch_two([script, str(tmp_path)], env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert _took_the_device_path(r.stderr), r.stderr[-2000:]
     assert r.stdout.count("TWO-RANK-STEP-OK") == 2, r.stdout[-2000:]
 
 
