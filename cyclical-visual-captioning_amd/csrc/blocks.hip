@@ -18,6 +18,7 @@ const Entry table[] = {
     CVC_B(cvc_attn_bwd_pair),
     CVC_B(cvc_ctxfeat_bwd_steps),
     CVC_B(cvc_tile_gemm_big),
+    CVC_B(cvc_tile_gemm_plan),
     CVC_B(cvc_dproj_bwd_steps),
     CVC_B(cvc_linear_splitk_fwd),
     CVC_B(cvc_linear_top2_fwd),

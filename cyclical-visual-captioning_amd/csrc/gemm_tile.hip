@@ -1110,6 +1110,27 @@ extern "C" int cvc_tile_gemm(const void* wb, const void* xb, long long x_mblk_st
     return cvc_launch_status();
 }
 
+// The split of K and the grid cvc_tile_gemm launches for it, chosen HERE (callers used to derive the split from a row-chunk count of
+// their own that the chunk-height choice above no longer matches): the largest split whose grid still is ONE round of workgroups
+// (<= one per compute unit) with at least 8 k steps per slice; 1 when even the unsplit grid is more than a round.
+extern "C" int cvc_tile_gemm_plan(int M, int N, int K, int* ksplit, int* chunk_rows, int* workgroups) {
+    if (M < 1 || N < 1 || K < 16 || (K & 15)) return CVC_E_BADARG;
+    const int mblk = (M + 31) / 32, ntile = (N + 127) / 128, ksteps = K / 16;
+    const int cus = 256;
+    int ks = ksteps / 8 < 1 ? 1 : ksteps / 8;
+    if (ks > cus / ntile) ks = cus / ntile < 1 ? 1 : cus / ntile;
+    int mh = 0, wgs = 0;
+    for (; ks >= 1; --ks) {
+        mh = tile_rows_per_chunk(mblk, ntile * ks);
+        wgs = ntile * ks * ((mblk + 2 * mh - 1) / (2 * mh));
+        if (wgs <= cus || ks == 1) break;
+    }
+    if (ksplit) *ksplit = ks;
+    if (chunk_rows) *chunk_rows = 2 * mh * 32;
+    if (workgroups) *workgroups = wgs;
+    return 0;
+}
+
 extern "C" int cvc_tile_rows_alloc(int M) {
     // rows a fragment buffer must hold (zero beyond M) for ANY chunk height cvc_tile_gemm may pick for these rows
     const int mblk = (M + 31) / 32;

@@ -8,6 +8,7 @@ handed over are raw `data_ptr()`s and the current HIP stream handle.
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import os
 from typing import List, Optional, Sequence
 
@@ -126,6 +127,7 @@ SIGNATURES = {
                           C.POINTER(_P), C.POINTER(_P), _P],
     "cvc_ctxfeat_bwd_steps": [_P, _P, _I, _I, _I, _I, _P, _P],
     "cvc_tile_gemm_big": [_I, _I],
+    "cvc_tile_gemm_plan": [_I, _I, _I, _P, _P, _P],
     "cvc_dproj_bwd_steps": [_P, _LL, _LL, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P],
     "cvc_lstm_pointwise_bwd4": [C.POINTER(GradSrc), _P, _P, C.c_uint, _F, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _I, _P],
     "cvc_vocab_head_nll_fwd": [_P, _I, _LL, _I, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P],
@@ -256,7 +258,7 @@ _VOID_RETURN = {"cvc_decode_plan_destroy"}
 # drop-in ABI of include/cvc_hip.h.
 BLOCKS = {
     "cvc_attn_scores", "cvc_attn_wsum", "cvc_attn_scores_qparts", "cvc_attn_wsum_quad", "cvc_attn_wsum_frag", "cvc_attn_wsum_quad_rm",
-    "cvc_attn_bwd_pair", "cvc_ctxfeat_bwd_steps", "cvc_dproj_bwd_steps", "cvc_tile_gemm_big", "cvc_linear_splitk_fwd", "cvc_linear_top2_fwd", "cvc_top2_final", "cvc_packed_lstm_fwd", "cvc_packed_linear_fwd",
+    "cvc_attn_bwd_pair", "cvc_ctxfeat_bwd_steps", "cvc_dproj_bwd_steps", "cvc_tile_gemm_big", "cvc_tile_gemm_plan", "cvc_linear_splitk_fwd", "cvc_linear_top2_fwd", "cvc_top2_final", "cvc_packed_lstm_fwd", "cvc_packed_linear_fwd",
     "cvc_packed_lstm_embgate_fwd", "cvc_packed_lstm_embgate_ex_fwd", "cvc_packed_lstm_late_fwd", "cvc_packed_lstm_train_fwd",
     "cvc_packed_lstm_train_pre_fwd", "cvc_packed_lstm_train_drop_fwd", "cvc_lstm_pointwise_bwd", "cvc_lstm_pointwise_bwd3",
     "cvc_lstm_pointwise_bwd3_drop", "cvc_pack_lstm_weights", "cvc_linear_nn_planes_fwd", "cvc_linear_nn_planes2_fwd", "cvc_gru_seq_train_fwd", "cvc_lstm_pointwise_bwd4_pair", "cvc_beam_select_parts", "cvc_tile_lstm_finish",
@@ -392,7 +394,7 @@ def error_word_ok(word: torch.Tensor) -> bool:
 # --------------------------------------------------------------------------- per-entry-point HIP-event timing (bench.py)
 _raw_fns = {}
 # entry points that launch nothing (sizes, switches, handles): an event pair around them would read as ~5 us of GPU time each
-_HOST_ONLY = {"cvc_tile_gemm_big", "cvc_tile_rows_alloc", "cvc_col_sum_ws", "cvc_train_loop_bwd_ws", "cvc_bn_workspace", "cvc_optim_chunk_elems", "cvc_version",
+_HOST_ONLY = {"cvc_tile_gemm_big", "cvc_tile_rows_alloc", "cvc_tile_gemm_plan", "cvc_col_sum_ws", "cvc_train_loop_bwd_ws", "cvc_bn_workspace", "cvc_optim_chunk_elems", "cvc_version",
               "cvc_block", "cvc_gemm_packed_split", "cvc_gemm_force_generic", "cvc_tile_gemm_loaders", "cvc_gru_persistent_waves8",
               "cvc_decode_plan_create", "cvc_decode_plan_destroy", "cvc_decode_plan_set_features", "cvc_decode_num_launches",
               "cvc_train_loop_profile", "cvc_train_loop_profile_read", "cvc_comm_unique_id", "cvc_comm_init", "cvc_comm_destroy"}
@@ -1144,6 +1146,14 @@ class TileOperand:
             pass
 
 
+@functools.lru_cache(maxsize=None)
+def tile_gemm_plan(M: int, N: int, K: int):
+    """(ksplit, rows per workgroup, workgroups) of the tile GEMM for an [M, K] x [N, K]^T product (cvc_tile_gemm_plan)"""
+    ks, rows, wgs = C.c_int(0), C.c_int(0), C.c_int(0)
+    _check(lib().cvc_tile_gemm_plan(int(M), int(N), int(K), C.addressof(ks), C.addressof(rows), C.addressof(wgs)), "cvc_tile_gemm_plan")
+    return ks.value, rows.value, wgs.value
+
+
 def tile_mm(a, b, a_kmajor: bool = False, b_kmajor: bool = False, out: Optional[torch.Tensor] = None, parts_only: bool = False,
             bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """C[M, N] = sum_k A[m, k] B[n, k] on the tile GEMM (split products on the bf16 MFMA, fp32 accumulate, fp32-grade error):
@@ -1156,8 +1166,7 @@ def tile_mm(a, b, a_kmajor: bool = False, b_kmajor: bool = False, out: Optional[
     assert A.K == B.K, (A.rows, A.K, B.rows, B.K)
     M, N, L, st = A.rows, B.rows, lib(), _stream()
     Kp = (A.K + 15) // 16 * 16
-    ntile, chunks = (N + 127) // 128, (tile_rows_alloc(M) + 319) // 320
-    ks = max(1, min(256 // max(1, ntile * chunks), (Kp // 16) // 8))
+    ks = tile_gemm_plan(M, N, Kp)[0]               # chosen where the grid is chosen (csrc/gemm_tile.hip::cvc_tile_gemm_plan)
     if out is None:
         out = torch.empty(0 if parts_only else M, N, device=A.frags.device, dtype=torch.float32)
     elif not (out.is_cuda and out.dtype == torch.float32 and tuple(out.shape) == (M, N) and out.stride(1) == 1

@@ -42,6 +42,11 @@ int cvc_dproj_bwd_steps(const float* q, long long q_step, long long q_plane, int
  * M % 256 == 0, N % 256 == 0, M >= 512 and min_wgs .. 256 workgroups, any grid with min_wgs = 1): on = 1 / 0 / -1 (query only),
  * min_wgs > 0 sets the threshold.  Returns the previous on / off setting. */
 int cvc_tile_gemm_big(int on, int min_wgs);
+/* The K split to pass as `ksplit` for a dense product (callers without a split of their own: the backward pass's dense products) and
+ * the grid cvc_tile_gemm launches for it: the largest split with >= 8 k steps per slice whose grid is at most one round of
+ * workgroups (one per compute unit), else 1.  chunk_rows = rows one workgroup walks, workgroups = the grid size.  Host only; any of
+ * the three outputs may be NULL.  CVC_E_BADARG for M, N < 1 or K not a positive multiple of 16. */
+int cvc_tile_gemm_plan(int M, int N, int K, int* ksplit, int* chunk_rows, int* workgroups);
 int cvc_linear_splitk_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, int M, int Nout,
                           int ksplit, float* y_parts, cvc_stream_t stream);
 int cvc_linear_top2_fwd(const cvc_gemm_seg* segs, int nsegs, const float* bias, int M, int Nout,

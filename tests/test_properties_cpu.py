@@ -214,3 +214,22 @@ def test_grad_reducer_does_not_hand_out_a_view_another_producer_already_wrote():
         assert red.claim(q) is not None                              # a new step: free again
     finally:
         red.remove_hooks()
+
+
+def test_tile_gemm_plan_is_one_round_of_workgroups_or_unsplit():
+    """cvc_tile_gemm_plan (host only): the K split the dense backward products pass to cvc_tile_gemm and the grid that call launches --
+    a split > 1 only while the grid stays within one round (256 workgroups) and every slice keeps >= 8 k steps; rows per workgroup a
+    chunk height cvc_tile_rows_alloc covers."""
+    from cvc import hip
+    for M in (20, 320, 640, 1280, 2560, 3200, 4096, 8192, 30720):
+        for N in (128, 512, 1024, 2048, 4096, 8000):
+            for K in (16, 128, 512, 1280, 2048, 3072):
+                ks, rows, wgs = hip.tile_gemm_plan(M, N, K)
+                ntile = (N + 127) // 128
+                assert ks >= 1 and rows % 64 == 0 and 64 <= rows <= 320
+                assert wgs == ntile * ks * -(-((M + 31) // 32 * 32) // rows)
+                assert hip.tile_rows_alloc(M) >= -(-M // rows) * rows or M <= 320
+                if ks > 1:
+                    assert wgs <= 256 and (K // 16) // ks >= 8
+    import ctypes
+    assert hip.lib().cvc_tile_gemm_plan(0, 128, 16, None, None, None) == -1 and hip.lib().cvc_tile_gemm_plan(64, 128, 24, None, None, None) == -1
