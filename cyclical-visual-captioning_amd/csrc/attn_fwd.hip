@@ -63,11 +63,15 @@ __device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) 
     return r;
 }
 
-__global__ __launch_bounds__(WG) void attn_wsum_kernel(WsumArgs a) {
+// HOIST (n <= 512 in every set): the softmax rows of both feature sets are made together before the first context byte is
+// requested -- their score loads, the two block-wide maxima and the two block-wide sums each share ONE exchange (2 barriers instead
+// of 8 ahead of the streaming loops); per set the same partial sums in the same order as the per-set form: bit-identical weights.
+template <bool HOIST>
+__global__ __launch_bounds__(WG) void attn_wsum_kernel(WsumArgs a, int n_max) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4* part = reinterpret_cast<f32x4*>(smem);      // [4 waves][64 lanes]
-    float* red = smem + 4 * 64 * 4;                    // [4]
-    float* a_s = red + 16;                             // [n_max]
+    float* red = smem + 4 * 64 * 4;                    // [16]
+    float* a_s = red + 16;                             // [n_max]  (HOIST: [sets][n_max])
     const int row = blockIdx.y, cb = blockIdx.x;
     const int clip = row / a.nq;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -76,9 +80,48 @@ __global__ __launch_bounds__(WG) void attn_wsum_kernel(WsumArgs a) {
     const bool col_ok = col < R;
     f32x4 total = {0, 0, 0, 0};
 
+    if constexpr (HOIST) {
+        float v[2][2], m[2], sum[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int n = s < a.nsets ? a.set[s].n : 0;
+            const float* sc = a.set[s].scores + (size_t)row * n;
+            v[s][0] = tid < n ? sc[tid] : -INFINITY;
+            v[s][1] = tid + WG < n ? sc[tid + WG] : -INFINITY;
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            m[s] = wave_max(fmaxf(v[s][0], v[s][1]));
+            if (lane == 0) red[s * 4 + wave] = m[s];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int n = s < a.nsets ? a.set[s].n : 0;
+            m[s] = fmaxf(fmaxf(fmaxf(red[s * 4], red[s * 4 + 1]), red[s * 4 + 2]), red[s * 4 + 3]);
+            float part_sum = 0.f;
+            if (tid < n) { v[s][0] = expf(v[s][0] - m[s]); part_sum += v[s][0]; }
+            if (tid + WG < n) { v[s][1] = expf(v[s][1] - m[s]); part_sum += v[s][1]; }
+            part_sum = wave_sum(part_sum);
+            if (lane == 0) red[8 + s * 4 + wave] = part_sum;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int n = s < a.nsets ? a.set[s].n : 0;
+            sum[s] = ((red[8 + s * 4] + red[8 + s * 4 + 1]) + red[8 + s * 4 + 2]) + red[8 + s * 4 + 3];
+            float* as = a_s + (size_t)s * n_max;
+            if (tid < n) { const float p = v[s][0] / sum[s]; as[tid] = p; if (cb == 0) a.set[s].attn[(size_t)row * n + tid] = p; }
+            if (tid + WG < n) { const float p = v[s][1] / sum[s]; as[tid + WG] = p; if (cb == 0) a.set[s].attn[(size_t)row * n + tid + WG] = p; }
+        }
+        __syncthreads();
+    }
+
     for (int s = 0; s < a.nsets; ++s) {
         const cvc_attn_set& S = a.set[s];
         const int n = S.n;
+        if constexpr (HOIST) a_s = red + 16 + (size_t)s * n_max;
+        else {
         const float* sc = S.scores + (size_t)row * n;
         // softmax over n (torch.softmax: exp(x - max) / sum)
         float m = -INFINITY;
@@ -97,6 +140,7 @@ __global__ __launch_bounds__(WG) void attn_wsum_kernel(WsumArgs a) {
             if (cb == 0) S.attn[(size_t)row * n + i] = p;
         }
         __syncthreads();
+        }
         if (S.ctx_out == nullptr && a.ctx_sum == nullptr) continue;
 
         const float* C = S.ctx + (size_t)clip * n * R + col;
@@ -140,12 +184,19 @@ __global__ __launch_bounds__(WG) void attn_wsum_kernel(WsumArgs a) {
 // Several queries per clip (beams of a clip, the T localizer queries of a clip): one workgroup = (clip, 256-column block,
 // group of up to QB queries).  The clip's context rows are streamed ONCE for the whole group and accumulated into QB register
 // accumulators; the one-query kernel above would re-read them per query (5 x the bytes at beam 5).
-template <int QB>
-__global__ __launch_bounds__(WG) void attn_wsum_mq_kernel(WsumArgs a, int n_max) {
+// NW waves per workgroup split the clip's rows: 4, or 8 (beam groups of up to 5 queries over long feature sets: a launch is only
+// (R / 256) x clips workgroups -- two per compute unit -- so four waves each leave a CU with 8 waves and 64 KB of loads in flight)
+// HOIST: the softmax rows of BOTH feature sets are made before the first context byte is requested, every wave working on its
+// (set, query) pairs together (their score loads, reductions and exponentials interleave: one latency chain instead of one per
+// round and set), values in registers (n <= 512); a_s holds [sets][QB][n_max].  Same arithmetic in the same order as the per-set
+// form (lane-strided max / sum, wave reductions): bit-identical weights.
+template <int QB, int NW = 4, bool HOIST = false>
+__global__ __launch_bounds__(NW * 64) void attn_wsum_mq_kernel(WsumArgs a, int n_max) {
+    constexpr int WG = NW * 64;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    f32x4* part = reinterpret_cast<f32x4*>(smem);      // [4 waves][QB][64 lanes]
-    float* red = smem + 4 * QB * 64 * 4;               // [16]
-    float* a_s = red + 16;                             // [QB][n_max]
+    f32x4* part = reinterpret_cast<f32x4*>(smem);      // [NW waves][QB][64 lanes]
+    float* red = smem + NW * QB * 64 * 4;              // [16]
+    float* a_s = red + 16;                             // [QB][n_max]  (HOIST: [sets][QB][n_max])
     const int clip = blockIdx.y, cb = blockIdx.x;
     const int qbase = blockIdx.z * QB;
     const int nqb = min(QB, a.nq - qbase);
@@ -157,9 +208,60 @@ __global__ __launch_bounds__(WG) void attn_wsum_mq_kernel(WsumArgs a, int n_max)
 #pragma unroll
     for (int u = 0; u < QB; ++u) total[u] = f32x4{0, 0, 0, 0};
 
+    if constexpr (HOIST) {
+        constexpr int PV = 8;                              // scores per lane and pair (n <= 512)
+        constexpr int PP = (2 * QB + NW - 1) / NW;         // pairs per wave
+        for (int s = 0; s < a.nsets; ++s)
+            for (int u = nqb; u < QB; ++u)
+                for (int i = tid; i < a.set[s].n; i += WG) a_s[((size_t)s * QB + u) * n_max + i] = 0.f;
+        const int npairs = a.nsets * nqb;
+        float v[PP][PV];
+#pragma unroll
+        for (int j = 0; j < PP; ++j) {
+            const int p = wave + j * NW;
+            if (p < npairs) {
+                const int s = p / nqb, u = p - s * nqb, n = a.set[s].n;
+                const float* sc = a.set[s].scores + (size_t)(clip * a.nq + qbase + u) * n;
+#pragma unroll
+                for (int k = 0; k < PV; ++k) v[j][k] = lane + 64 * k < n ? sc[lane + 64 * k] : -INFINITY;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PP; ++j) {
+            const int p = wave + j * NW;
+            if (p < npairs) {
+                const int s = p / nqb, u = p - s * nqb, n = a.set[s].n;
+                const int row = clip * a.nq + qbase + u;
+                float* as = a_s + ((size_t)s * QB + u) * n_max;
+                if (a.raw_scale != 0.f) {
+#pragma unroll
+                    for (int k = 0; k < PV; ++k) if (lane + 64 * k < n) as[lane + 64 * k] = v[j][k] * a.raw_scale;
+                    continue;
+                }
+                float m = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < PV; ++k) if (lane + 64 * k < n) m = fmaxf(m, v[j][k]);
+                m = wave_max(m);
+                float sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < PV; ++k) if (lane + 64 * k < n) { v[j][k] = expf(v[j][k] - m); sum += v[j][k]; }
+                sum = wave_sum(sum);
+#pragma unroll
+                for (int k = 0; k < PV; ++k) if (lane + 64 * k < n) {
+                    const float pr = v[j][k] / sum;
+                    as[lane + 64 * k] = pr;
+                    if (cb == 0) a.set[s].attn[(size_t)row * n + lane + 64 * k] = pr;
+                }
+            }
+        }
+        __syncthreads();
+    }
+
     for (int s = 0; s < a.nsets; ++s) {
         const cvc_attn_set& S = a.set[s];
         const int n = S.n;
+        if constexpr (HOIST) a_s = red + 16 + (size_t)s * QB * n_max;
+        else {
         for (int u = nqb; u < QB; ++u)                  // unused slots of the group weigh nothing: the FMA loop has no branches
             for (int i = tid; i < n; i += WG) a_s[(size_t)u * n_max + i] = 0.f;
         // softmax over n per query (torch.softmax: exp(x - max) / sum): one WAVE per query, reductions inside the wave -- the
@@ -189,6 +291,7 @@ __global__ __launch_bounds__(WG) void attn_wsum_mq_kernel(WsumArgs a, int n_max)
             }
         }
         __syncthreads();
+        }
         if (S.ctx_out == nullptr && a.ctx_sum == nullptr) continue;
 
         const float* C = S.ctx + (size_t)clip * n * R + col;
@@ -199,30 +302,30 @@ __global__ __launch_bounds__(WG) void attn_wsum_mq_kernel(WsumArgs a, int n_max)
             constexpr bool STREAM = decltype(stream_tag)::value;
 #define LDF(ptr) (STREAM ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ptr)) : ld4(ptr))
             int i = wave;
-            for (; i + 28 < n; i += 32) {                  // 8 rows (8 KB per wave) in flight
+            for (; i + 7 * NW < n; i += 8 * NW) {          // 8 rows (8 KB per wave) in flight
                 f32x4 c[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) c[k] = LDF(C + (size_t)(i + 4 * k) * R);
+                for (int k = 0; k < 8; ++k) c[k] = LDF(C + (size_t)(i + NW * k) * R);
 #pragma unroll
                 for (int u = 0; u < QB; ++u) {
                     const float* as = a_s + (size_t)u * n_max;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) acc[u] += as[i + 4 * k] * c[k];
+                    for (int k = 0; k < 8; ++k) acc[u] += as[i + NW * k] * c[k];
                 }
             }
-            for (; i + 12 < n; i += 16) {
-                const f32x4 c0 = LDF(C + (size_t)i * R), c1 = LDF(C + (size_t)(i + 4) * R);
-                const f32x4 c2 = LDF(C + (size_t)(i + 8) * R), c3 = LDF(C + (size_t)(i + 12) * R);
+            for (; i + 3 * NW < n; i += 4 * NW) {
+                const f32x4 c0 = LDF(C + (size_t)i * R), c1 = LDF(C + (size_t)(i + NW) * R);
+                const f32x4 c2 = LDF(C + (size_t)(i + 2 * NW) * R), c3 = LDF(C + (size_t)(i + 3 * NW) * R);
 #pragma unroll
                 for (int u = 0; u < QB; ++u) {
                     const float* as = a_s + (size_t)u * n_max;
                     acc[u] += as[i] * c0;
-                    acc[u] += as[i + 4] * c1;
-                    acc[u] += as[i + 8] * c2;
-                    acc[u] += as[i + 12] * c3;
+                    acc[u] += as[i + NW] * c1;
+                    acc[u] += as[i + 2 * NW] * c2;
+                    acc[u] += as[i + 3 * NW] * c3;
                 }
             }
-            for (; i < n; i += 4) {
+            for (; i < n; i += NW) {
                 const f32x4 c0 = LDF(C + (size_t)i * R);
 #pragma unroll
                 for (int u = 0; u < QB; ++u) acc[u] += a_s[(size_t)u * n_max + i] * c0;
@@ -239,8 +342,10 @@ __global__ __launch_bounds__(WG) void attn_wsum_mq_kernel(WsumArgs a, int n_max)
 #pragma unroll
             for (int u = 0; u < QB; ++u) {
                 if (u < nqb) {
-                    const f32x4 v = (part[(0 * QB + u) * 64 + lane] + part[(1 * QB + u) * 64 + lane]) +
-                                    (part[(2 * QB + u) * 64 + lane] + part[(3 * QB + u) * 64 + lane]);
+                    f32x4 v = (part[(0 * QB + u) * 64 + lane] + part[(1 * QB + u) * 64 + lane]) +
+                              (part[(2 * QB + u) * 64 + lane] + part[(3 * QB + u) * 64 + lane]);
+                    if (NW == 8) v += (part[(4 * QB + u) * 64 + lane] + part[(5 * QB + u) * 64 + lane]) +
+                                      (part[(6 * QB + u) * 64 + lane] + part[(7 * QB + u) * 64 + lane]);
                     if (S.ctx_out != nullptr) st4(S.ctx_out + (size_t)(clip * a.nq + qbase + u) * R + col, v);
                     total[u] += v;
                 }
@@ -355,11 +460,29 @@ static int wsum_impl(const cvc_attn_set* sets, int nsets, int nclip, int nq, int
         // context rows are read once per group; if not even 2 fit, the one-query kernel below takes every row on its own
         // (10 when it halves the passes over the clip's rows: the T = 20 localizer queries in 2 groups instead of 3)
         int QB = nq <= 2 ? 2 : (nq <= 4 ? 4 : (nq <= 5 ? 5 : ((nq + 9) / 10 < (nq + 7) / 8 ? 10 : 8)));
-        auto lds_of = [&](int qb) { return ((size_t)4 * qb * 64 * 4 + 16 + (size_t)qb * n_max) * sizeof(float); };
+        auto lds_of = [&](int qb, int nw = 4) { return ((size_t)nw * qb * 64 * 4 + 16 + (size_t)qb * n_max) * sizeof(float); };
         while (QB > 1 && lds_of(QB) > 64 * 1024) QB = QB == 10 ? 8 : (QB == 8 ? 5 : (QB == 5 ? 4 : (QB == 4 ? 2 : 1)));
         if (QB > 1) {
-            const size_t lds = lds_of(QB);
             dim3 g((R + 255) / 256, nclip, (nq + QB - 1) / QB);
+            // beam decode's group of 5 (CVC_WSUM_MQ_WAVES=4|8 and CVC_WSUM_MQ_HOIST=0|1: A/B): both sets' softmax rows up front where
+            // they fit (config 3: 61.6 -> 57.7 us, config 5: 165.6 -> 136.3 us = 0.76 of HBM); with it, 8 waves per workgroup are
+            // slightly ahead on a grid of two workgroups per CU (config 3: 56.2 us) and slightly behind on four (config 5: 138.2)
+            static const int waves_env = [] { const char* e = getenv("CVC_WSUM_MQ_WAVES"); return e ? atoi(e) : 0; }();
+            static const int hoist_env = [] { const char* e = getenv("CVC_WSUM_MQ_HOIST"); return e ? atoi(e) : -1; }();
+            const long long wgs = (long long)g.x * g.y * g.z;
+            if (QB == 5 && n_max <= 512) {
+                const bool eight = waves_env == 8 || (waves_env != 4 && wgs <= 2 * 256);
+                auto lds_h = [&](int nw) { return ((size_t)nw * 5 * 64 * 4 + 16 + (size_t)nsets * 5 * n_max) * sizeof(float); };
+                const bool hoist = hoist_env != 0 && lds_h(eight ? 8 : 4) <= 64 * 1024;
+                const hipStream_t st = (hipStream_t)stream;
+                if (hoist && eight) { hipLaunchKernelGGL((attn_wsum_mq_kernel<5, 8, true>), g, dim3(512), lds_h(8), st, wa, n_max); return cvc_launch_status(); }
+                if (hoist) { hipLaunchKernelGGL((attn_wsum_mq_kernel<5, 4, true>), g, dim3(256), lds_h(4), st, wa, n_max); return cvc_launch_status(); }
+                if (eight && lds_of(5, 8) <= 64 * 1024) {
+                    hipLaunchKernelGGL((attn_wsum_mq_kernel<5, 8>), g, dim3(512), lds_of(5, 8), st, wa, n_max);
+                    return cvc_launch_status();
+                }
+            }
+            const size_t lds = lds_of(QB);
             switch (QB) {
                 case 2: hipLaunchKernelGGL(attn_wsum_mq_kernel<2>, g, dim3(WG), lds, (hipStream_t)stream, wa, n_max); break;
                 case 4: hipLaunchKernelGGL(attn_wsum_mq_kernel<4>, g, dim3(WG), lds, (hipStream_t)stream, wa, n_max); break;
@@ -374,7 +497,11 @@ static int wsum_impl(const cvc_attn_set* sets, int nsets, int nclip, int nq, int
     const size_t lds2 = (4 * 64 * 4 + 16 + n_max) * sizeof(float);
     if (lds2 > 64 * 1024) return CVC_E_TOOBIG;
     dim3 g2((R + 255) / 256, nclip * nq);
-    hipLaunchKernelGGL(attn_wsum_kernel, g2, dim3(WG), lds2, (hipStream_t)stream, wa);
+    static const int hoist1_env = [] { const char* e = getenv("CVC_WSUM_HOIST"); return e ? atoi(e) : -1; }();      // A/B: 0
+    if (n_max <= 2 * WG && hoist1_env != 0)
+        hipLaunchKernelGGL(attn_wsum_kernel<true>, g2, dim3(WG), lds2 + (size_t)n_max * sizeof(float), (hipStream_t)stream, wa, n_max);
+    else
+        hipLaunchKernelGGL(attn_wsum_kernel<false>, g2, dim3(WG), lds2, (hipStream_t)stream, wa, n_max);
     return cvc_launch_status();
 }
 

@@ -252,9 +252,13 @@ int run_tile(cvc_decode_plan* p, hipStream_t st) {
         CVC_TRY(cvc_tile_lstm_finish(d.parts_gate, d.ks_gate, gs, d.b_ih_lang, d.b_hh_lang, nullptr, 1, d.c_lang_prev, rows, R,
                                      d.c_lang, d.h_lang, d.xhf, d.xhf_stride, nullptr, 0, st));
         CVC_TRY(cvc_tile_gemm(d.w_o, d.xhf, d.xhf_stride, R, rows, V, d.ks_o, d.parts_o, V, (long long)rows * V, st));
-        // (summing the slabs inside the beam row scan -- cvc_beam_select_parts -- measured 54 us against 12 + 24 us for this
-        // finishing launch plus the scan of the finished logits: six strided reads per element in the scan's row loop)
-        CVC_TRY(cvc_tile_linear_finish(d.parts_o, d.ks_o, (long long)rows * V, V, d.b_o, nullptr, rows, V, d.logits, V, st));
+        // beams: the selection's row scan sums the K-slice slabs itself (round 6: its float4 form, slab 0 + ... + bias in the finishing
+        // pass's order -- the same logits bit for bit; the GENERAL scan doing that had measured 54 us against 12 + 24 us in round 4);
+        // the finished matrix is neither written nor read back.  CVC_BEAM_FINISH=1 keeps the separate pass (A/B).
+        static const bool keep_finish = [] { const char* e = getenv("CVC_BEAM_FINISH"); return e && e[0] == '1'; }();
+        const bool fused_sel = beam > 1 && !keep_finish && (V & 3) == 0 && (d.ks_o == 2 || d.ks_o == 4 || d.ks_o == 6 || d.ks_o == 8);
+        if (!fused_sel)
+            CVC_TRY(cvc_tile_linear_finish(d.parts_o, d.ks_o, (long long)rows * V, V, d.b_o, nullptr, rows, V, d.logits, V, st));
         int64_t* word_next = d.words + (size_t)(t + 1) * rows;
         const int64_t* parent = nullptr;
         if (beam == 1) {
@@ -262,9 +266,10 @@ int run_tile(cvc_decode_plan* p, hipStream_t st) {
         } else {
             const int srd = t & 1, swr = (t + 1) & 1;
             int64_t* par = d.parent + (size_t)t * rows;
-            CVC_TRY(cvc_beam_select(d.logits, d.score + (size_t)srd * rows, d.done + (size_t)srd * rows, B, beam, V, d.unk_idx,
-                                    t == 0 ? 1 : 0, par, word_next, d.score + (size_t)swr * rows, d.done + (size_t)swr * rows,
-                                    d.beam_ws, st));
+            CVC_TRY(cvc_beam_select_parts(fused_sel ? d.parts_o : d.logits, fused_sel ? d.ks_o : 1, fused_sel ? (long long)rows * V : 0,
+                                          fused_sel ? d.b_o : nullptr, d.score + (size_t)srd * rows, d.done + (size_t)srd * rows, B, beam, V,
+                                          d.unk_idx, t == 0 ? 1 : 0, par, word_next, d.score + (size_t)swr * rows,
+                                          d.done + (size_t)swr * rows, d.beam_ws, st));
             parent = par;
         }
         if (t + 1 < d.T)

@@ -714,9 +714,11 @@ __global__ __launch_bounds__(WG) void beam_rowtop_kernel(const float* logits, in
 // loop and bias branch serialised its 20 loads per thread), log-sum-exp from per-wave (max, sum) pairs, and the `beam` best
 // found per WAVE without a barrier (shuffles only), then merged by wave 0 -- the row's top `beam` are among the 4 x beam wave
 // winners, so the result is the general kernel's (ties broken towards the lower index in both).  3 barriers instead of 19.
-template <int NG>      // float4 groups per thread: V <= NG * 1024
-__global__ __launch_bounds__(WG) void beam_rowtop4_kernel(const float* logits, int beam, int V, int unk, float* cand_v, int* cand_i,
-                                                          float* lse_out) {
+// NP > 0: the logits are still the NP K-slice slabs of the vocabulary GEMM (+ bias): summed on load in the finishing pass's order
+// (slab 0 + slab 1 + ... + bias, cvc_tile_linear_finish), so the finished matrix is never written or read back.
+template <int NG, int NP = 0>      // float4 groups per thread: V <= NG * 1024
+__global__ __launch_bounds__(WG) void beam_rowtop4_kernel(const float* logits, long long part_stride, const float* bias, int beam, int V,
+                                                          int unk, float* cand_v, int* cand_i, float* lse_out) {
     __shared__ float wm[4], ws[4];
     __shared__ float wv[4 * BEAM_MAX];
     __shared__ int wi[4 * BEAM_MAX];
@@ -726,7 +728,17 @@ __global__ __launch_bounds__(WG) void beam_rowtop4_kernel(const float* logits, i
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const int e = (tid + g * WG) * 4;
-        v4[g] = e < V ? ld4(x + e) : f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (e < V) {
+            v4[g] = ld4(x + e);
+            if constexpr (NP > 0) {
+                f32x4 pv[NP];
+#pragma unroll
+                for (int p = 1; p < NP; ++p) pv[p] = ld4(x + (size_t)p * part_stride + e);
+#pragma unroll
+                for (int p = 1; p < NP; ++p) v4[g] += pv[p];
+                if (bias != nullptr) v4[g] += ld4(bias + e);
+            }
+        } else v4[g] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     }
     float m = -INFINITY;
 #pragma unroll
@@ -1221,9 +1233,19 @@ extern "C" int cvc_beam_select_parts(const float* logits, int nparts, long long 
     float* cand_v = workspace;
     int* cand_i = reinterpret_cast<int*>(workspace + (size_t)rows * BEAM_MAX);
     float* lse = workspace + (size_t)rows * BEAM_MAX * 2;
-    if (nparts == 1 && bias == nullptr && (V & 3) == 0 && ((uintptr_t)logits & 15) == 0 && 4 * BEAM_MAX <= 64) {
-#define CVC_RT4(NG_) hipLaunchKernelGGL(beam_rowtop4_kernel<NG_>, dim3(rows), dim3(WG), 0, (hipStream_t)stream, logits, beam, V, \
-                                        unk_idx, cand_v, cand_i, lse)
+    const bool aligned = (V & 3) == 0 && ((uintptr_t)logits & 15) == 0 && 4 * BEAM_MAX <= 64;
+    const bool slabs = aligned && (nparts == 2 || nparts == 4 || nparts == 6 || nparts == 8) && (part_stride & 3) == 0 &&
+                       ((uintptr_t)bias & 15) == 0;
+    // (a ONE-workgroup-per-clip form -- 2 * beam waves scanning the clip's rows, both merges in LDS, no second launch -- was built
+    // and measured in round 6: bit-identical, but 36 us against 25 us for the two launches below at 64 clips x beam 5, V = 5000,
+    // 6 slabs: 64 workgroups pulling 600 KB each ingest at ~20 GB/s per compute unit; 320 row workgroups spread the same bytes
+    // over the chip)
+    if ((aligned && nparts == 1 && bias == nullptr) || slabs) {
+#define CVC_RT4P(NG_, NP_) hipLaunchKernelGGL((beam_rowtop4_kernel<NG_, NP_>), dim3(rows), dim3(WG), 0, (hipStream_t)stream, logits, \
+                                              part_stride, bias, beam, V, unk_idx, cand_v, cand_i, lse)
+#define CVC_RT4(NG_) do { switch (slabs ? nparts : 0) { case 2: CVC_RT4P(NG_, 2); break; case 4: CVC_RT4P(NG_, 4); break; \
+                                                         case 6: CVC_RT4P(NG_, 6); break; case 8: CVC_RT4P(NG_, 8); break; \
+                                                         default: CVC_RT4P(NG_, 0); break; } } while (0)
         switch ((V + 4 * WG - 1) / (4 * WG)) {
             case 1: CVC_RT4(1); break;
             case 2: CVC_RT4(2); break;
@@ -1235,6 +1257,7 @@ extern "C" int cvc_beam_select_parts(const float* logits, int nparts, long long 
             default: CVC_RT4(8); break;
         }
 #undef CVC_RT4
+#undef CVC_RT4P
     } else
         hipLaunchKernelGGL(beam_rowtop_kernel, dim3(rows), dim3(WG), 0, (hipStream_t)stream, logits, nparts, part_stride, bias, beam,
                            V, unk_idx, cand_v, cand_i, lse);

@@ -116,18 +116,23 @@ class TilePath:
                                                                 ptr(W.b_hh_lang), None, 1, ptr(self.t_c_lang_prev), rows, R,
                                                                 ptr(self.t_c_lang), ptr(self.t_h_lang), xh_p, xh_s, None, 0)))
             out.append(("logits", L.cvc_tile_gemm, (ptr(W.t_o), xh_p, xh_s, R, rows, V, self.ks_o, ptr(self.parts_o), V, rows * V)))
-            out.append(("logits_finish", L.cvc_tile_linear_finish, (ptr(self.parts_o), self.ks_o, rows * V, V, ptr(W.b_o), None, rows, V,
-                                                                    ptr(self.logits), V)))
+            # beams: the selection sums the K-slice slabs itself (in the finishing pass's order: same logits bit for bit), the
+            # finished [rows, V] matrix is neither written nor read back; CVC_BEAM_FINISH=1 keeps the separate pass (A/B)
+            fused_sel = beam > 1 and self.ks_o in (2, 4, 6, 8) and V % 4 == 0 and os.environ.get("CVC_BEAM_FINISH") != "1"
+            if not fused_sel:
+                out.append(("logits_finish", L.cvc_tile_linear_finish, (ptr(self.parts_o), self.ks_o, rows * V, V, ptr(W.b_o), None, rows, V,
+                                                                        ptr(self.logits), V)))
             if beam == 1:
                 out.append(("word_select", L.cvc_top2_unk, (ptr(self.logits), rows, V, self.unk, ptr(self.words[t + 1]), 1,
                                                             ptr(self.logprob[t]))))
                 parent = None
             else:
                 srd, swr = t & 1, (t + 1) & 1
-                out.append(("word_select", L.cvc_beam_select, (ptr(self.logits), ptr(self.score[srd]), ptr(self.done[srd]), B,
-                                                               beam, V, self.unk, 1 if t == 0 else 0, ptr(self.parent[t]),
-                                                               ptr(self.words[t + 1]), ptr(self.score[swr]),
-                                                               ptr(self.done[swr]), ptr(self.beam_ws))))
+                src = (ptr(self.parts_o), self.ks_o, rows * V, ptr(W.b_o)) if fused_sel else (ptr(self.logits), 1, 0, None)
+                out.append(("word_select", L.cvc_beam_select_parts, src + (ptr(self.score[srd]), ptr(self.done[srd]), B,
+                                                                           beam, V, self.unk, 1 if t == 0 else 0, ptr(self.parent[t]),
+                                                                           ptr(self.words[t + 1]), ptr(self.score[swr]),
+                                                                           ptr(self.done[swr]), ptr(self.beam_ws))))
                 parent = ptr(self.parent[t])
             if t + 1 < self.T:
                 out.append(("beam_reorder", L.cvc_tile_reorder_pack, (parent, ptr(self.words[t + 1]), beam, ptr(self.t_h_att),

@@ -983,6 +983,22 @@ def beam_select(logits, score_in, done_in, B: int, beam: int, unk_idx: int, firs
     return parent, word, score, done
 
 
+def beam_select_parts(parts, bias, score_in, done_in, B: int, beam: int, unk_idx: int, first_step: bool):
+    """beam_select over logits that still are the K-slice slabs [nparts, rows, V] of the vocabulary GEMM (+ bias [V]): summed while
+    the rows are scanned, in the finishing pass's order (cvc_beam_select_parts)"""
+    nparts, rows, V = parts.shape
+    dev = parts.device
+    parent = torch.empty(B * beam, dtype=torch.int64, device=dev)
+    word = torch.empty(B * beam, dtype=torch.int64, device=dev)
+    score = torch.empty(B * beam, dtype=torch.float32, device=dev)
+    done = torch.empty(B * beam, dtype=torch.uint8, device=dev)
+    ws = torch.empty(17 * B * beam, dtype=torch.float32, device=dev)
+    _check(lib().cvc_beam_select_parts(_dev(parts), nparts, rows * V, _dev(bias), _dev(score_in), _dev(done_in, torch.uint8), B, beam, V,
+                                       int(unk_idx), 1 if first_step else 0, parent.data_ptr(), word.data_ptr(), _dev(score),
+                                       _dev(done, torch.uint8), _dev(ws), _stream()), "cvc_beam_select_parts")
+    return parent, word, score, done
+
+
 def gather_rows(src, parent, beam: int):
     rows, width = src.shape
     dst = torch.empty_like(src)

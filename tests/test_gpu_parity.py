@@ -348,6 +348,29 @@ def test_beam_bookkeeping_ops_vs_bruteforce(dev, lib, B, beam, V, first):
     close(logp, masked.max(1)[0].float(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("B,beam,V,nparts", [(64, 5, 5000, 6), (5, 3, 1024, 2), (2, 8, 6144, 4), (3, 4, 8192, 8), (4, 5, 5000, 3),
+                                             (3, 2, 50, 4)])
+def test_beam_select_over_gemm_slabs_equals_select_over_the_finished_logits(dev, lib, B, beam, V, nparts):
+    """cvc_beam_select_parts (the beam decode's selection reads the vocabulary GEMM's K-slice slabs + bias itself, round 6) against
+    cvc_beam_select over the matrix cvc_tile_linear_finish makes of the same slabs: the scan adds slab 0 + slab 1 + ... + bias in
+    that pass's order, so parents, words, scores and done flags are EQUAL, bit for bit -- in the float4 form of the row scan
+    (V % 4 == 0, 2 / 4 / 6 / 8 slabs) and in the general scan (the last two cases)."""
+    g = torch.Generator(device="cpu").manual_seed(B * 1000 + beam * 10 + nparts)
+    rows, unk = B * beam, 1
+    parts = (torch.randn(nparts, rows, V, generator=g) * 1.5).to(dev)
+    bias = torch.randn(V, generator=g).to(dev)
+    score = torch.randn(rows, generator=g).to(dev)
+    done = (torch.rand(rows, generator=g) < 0.2).to(torch.uint8).to(dev)
+    logits = torch.empty(rows, V, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.lib().cvc_tile_linear_finish(parts.data_ptr(), nparts, rows * V, V, bias.data_ptr(), None, rows, V, logits.data_ptr(), V, st) == 0
+    for first in (False, True):
+        want = lib.beam_select(logits, score, done if not first else torch.zeros_like(done), B, beam, unk, first)
+        got = lib.beam_select_parts(parts, bias, score, done if not first else torch.zeros_like(done), B, beam, unk, first)
+        for a, b_, what in zip(got, want, ("parent", "word", "score", "done")):
+            assert torch.equal(a, b_), (what, first)
+
+
 @pytest.mark.parametrize("M,K,N", [(64, 6144, 8192), (64, 2048, 5000), (17, 256, 96)])
 def test_split_product_gemm_is_fp32_grade(dev, lib, M, K, N):
     """The packed GEMM's default arithmetic (every fp32 operand split exactly into three bf16 terms, six cross

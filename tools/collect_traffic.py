@@ -52,7 +52,7 @@ def roles_for(mode, beam, T, B=64):
             "loops.bwd.nn_att": (nn2, pa, {j for j in range(pa) if j % 2 == 1}),
             "loopA.bwd.nn_h2attn": (r"skinny_gemm_nn_split_kernel", 1, {0}),
             "loopA.fwd.attn_scores": (r"attn_scores_kernelILi0ELi\d+ELi1E", 1, {0}),
-            "loopA.fwd.attn_wsum": (r"attn_wsum_kernelE", 1, {0}),
+            "loopA.fwd.attn_wsum": (r"attn_wsum_kernelI", 1, {0}),
             "loopA.bwd.attn_bwd": [(r"attn_scores_kernelILi1ELi\d+ELi1E", 1, {0}), (r"softmax_bwd2_kernel", 1, {0}), (r"attn_score_bwd2", 1, {0})],
             "cvc_tile_gemm": (r"tile_gemm_ld2?_kernel", 1, {0}),
             # entry points called from Python (round 6: every timed row of the bench line carries its PMC traffic): per-launch averages
@@ -79,7 +79,7 @@ def roles_for(mode, beam, T, B=64):
             "loopA.bwd.nn_h2attn": (nn, pa, {j for j in range(pa) if j % 3 == 1}),
             "loops.bwd.nn_att": (nn, pa, {j for j in range(pa) if j % 3 == 2}),
             "loopA.fwd.attn_scores": (r"attn_scores_kernelILi0ELi\d+ELi1E", 1, {0}),
-            "loopA.fwd.attn_wsum": (r"attn_wsum_kernelE", 1, {0}),
+            "loopA.fwd.attn_wsum": (r"attn_wsum_kernelI", 1, {0}),
             # one role = three kernels per step: d_attn = C . d_ctx on the dot-score kernel, softmax backward, score backward
             "loopA.bwd.attn_bwd": [(r"attn_scores_kernelILi1ELi\d+ELi1E", 1, {0}), (r"softmax_bwd2_kernel", 1, {0}), (r"attn_score_bwd2", 1, {0})],
             "cvc_tile_gemm": (r"tile_gemm_ld2?_kernel", 1, {0}),
@@ -111,7 +111,7 @@ def roles_for(mode, beam, T, B=64):
             "loopA.bwd.nn_h2attn": (nn, pc + pa, {pc + j for j in range(pa) if j % 3 == 1}),
             "loopA.bwd.nn_att": (nn, pc + pa, {pc + j for j in range(pa) if j % 3 == 2}),
             "loopA.fwd.attn_scores": (r"attn_scores_kernelILi0ELi\d+ELi1E", 1, {0}),
-            "loopA.fwd.attn_wsum": (r"attn_wsum_kernelE", 1, {0}),
+            "loopA.fwd.attn_wsum": (r"attn_wsum_kernelI", 1, {0}),
             # one role = three kernels per step: d_attn = C . d_ctx on the dot-score kernel, softmax backward, score backward
             "loopA.bwd.attn_bwd": [(r"attn_scores_kernelILi1ELi\d+ELi1E", 1, {0}), (r"softmax_bwd2_kernel", 1, {0}), (r"attn_score_bwd2", 1, {0})],
             "cvc_tile_gemm": (r"tile_gemm_ld2?_kernel", 1, {0}),
