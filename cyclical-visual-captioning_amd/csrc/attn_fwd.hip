@@ -80,6 +80,25 @@ __global__ __launch_bounds__(WG) void attn_wsum_kernel(WsumArgs a, int n_max) {
     const bool col_ok = col < R;
     f32x4 total = {0, 0, 0, 0};
 
+    // HOIST: the first context rows of set 0 (what the streaming loop's first round takes) are requested BEFORE the softmax rows
+    // are made -- they do not depend on them, and their HBM latency passes under the score loads and the two exchanges
+    f32x4 pre[4] = {};
+    bool pre_ok = false;
+    if constexpr (HOIST) {
+        const cvc_attn_set& S0 = a.set[0];
+        pre_ok = col_ok && S0.n >= 16 && (S0.ctx_out != nullptr || a.ctx_sum != nullptr);
+        if (pre_ok) {
+            const float* C0 = S0.ctx + (size_t)clip * S0.n * R + col + (size_t)wave * R;
+            if (S0.stream & 2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pre[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(C0 + (size_t)(4 * k) * R));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) pre[k] = ld4(C0 + (size_t)(4 * k) * R);
+            }
+        }
+    }
+
     if constexpr (HOIST) {
         float v[2][2], m[2], sum[2];
 #pragma unroll
@@ -150,6 +169,13 @@ __global__ __launch_bounds__(WG) void attn_wsum_kernel(WsumArgs a, int n_max) {
             constexpr bool STREAM = decltype(stream_tag)::value;
 #define LDF(ptr) (STREAM ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ptr)) : ld4(ptr))
             int i = wave;
+            if (HOIST && s == 0 && pre_ok) {               // (n >= 16: the round the loop below would have started with)
+                acc0 += a_s[i] * pre[0];
+                acc1 += a_s[i + 4] * pre[1];
+                acc2 += a_s[i + 8] * pre[2];
+                acc3 += a_s[i + 12] * pre[3];
+                i += 16;
+            }
             for (; i + 12 < n; i += 16) {
                 f32x4 c0 = LDF(C + (size_t)i * R), c1 = LDF(C + (size_t)(i + 4) * R);
                 f32x4 c2 = LDF(C + (size_t)(i + 8) * R), c3 = LDF(C + (size_t)(i + 12) * R);
@@ -208,6 +234,8 @@ __global__ __launch_bounds__(NW * 64) void attn_wsum_mq_kernel(WsumArgs a, int n
 #pragma unroll
     for (int u = 0; u < QB; ++u) total[u] = f32x4{0, 0, 0, 0};
 
+    // (requesting set 0's first round of context rows before the softmax rows, as attn_wsum_kernel does, was measured SLOWER here:
+    // 56 -> 62 us at config 3, 136 -> 147 us at config 5 -- 30 to 40 more live registers per lane)
     if constexpr (HOIST) {
         constexpr int PV = 8;                              // scores per lane and pair (n <= 512)
         constexpr int PP = (2 * QB + NW - 1) / NW;         // pairs per wave
