@@ -89,6 +89,10 @@ def parse(argv=None):
                    help="start the rank processes through the torch.distributed.run child also for --gpus 1 (the path every N > 1 run takes)")
     p.add_argument("--no-secondary", action="store_true", help="default decode run: skip the short runs of the other configs")
     p.add_argument("--secondary-seconds", type=float, default=0.35, help="timed seconds per secondary measurement")
+    p.add_argument("--secondary-timeout", type=float, default=600.0,
+                   help="bench.py --gpus N under a launcher: if the all-ranks training secondary (config 4, the exchange captured in the "
+                        "step) has not returned after this many seconds, rank 0 prints the decode line with the secondary's entry saying "
+                        "so and every rank exits 0 -- a hang in the N-rank exchange must not cost the decode measurement")
     p.add_argument("--watchdog-seconds", type=float, default=2400.0,
                    help="a run still going after this much wall time writes every thread's Python stack to stderr and exits 3 (a hung "
                         "bench must not hold a GPU box until somebody's outer limit; 0 = off).  SIGTERM writes the stacks as well.")
@@ -550,6 +554,9 @@ def run_secondary_ranks(args, dev, rank, world, comm):
     name = (f"cfg4 cyclical train step, {world} rank(s): B=32 per GPU (global {32 * world}), the per-bucket RCCL exchange captured in the "
             f"step on the {world}-rank communicator")
     t0 = time.perf_counter()
+    if os.environ.get("CVC_BENCH_TEST_HANG_SECONDARY") == "1":      # test hook (tests/test_gpu_train.py): a secondary that never returns
+        while True:
+            time.sleep(1.0)
     if comm is None:
         ent = {"error": "no RCCL communicator in this run (see `rccl`): the training step needs its exchange"}
     else:
@@ -569,6 +576,31 @@ def run_secondary_ranks(args, dev, rank, world, comm):
     ent["name"] = name
     ent["wall_s"] = round(time.perf_counter() - t0, 2)
     return [ent]
+
+
+def _secondary_guard(args, rank, world, line, finish):
+    """A timer over the all-ranks training secondary of `bench.py --gpus N`: that step holds the only collectives of the run (the
+    decode path has none), captured into a HIP graph on an N-rank communicator no 1-GPU box can rehearse.  If it does not return within
+    --secondary-timeout seconds, every rank writes its Python stacks to stderr, rank 0 prints the decode line -- already measured, with
+    `secondary[0].error` saying what happened -- and the process leaves with status 0 without waiting for the GPU (os._exit: a
+    collective that never completes cannot be synchronised with)."""
+    import faulthandler
+    import threading
+
+    def fire():
+        try:
+            faulthandler.dump_traceback(all_threads=True)
+            if rank == 0:
+                line["secondary"] = [{"name": f"cfg4 cyclical train step, {world} rank(s)",
+                                      "error": f"did not return within --secondary-timeout = {args.secondary_timeout:.0f} s (stacks on stderr); "
+                                               "the decode line above it is complete"}]
+                finish(line)
+        finally:
+            os._exit(0)
+    t = threading.Timer(args.secondary_timeout, fire) if args.secondary_timeout > 0 else threading.Timer(1e9, lambda: None)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def main():
@@ -662,6 +694,30 @@ def main():
     over = {k: getattr(args, k) for k in ("B", "N", "F", "R", "A", "E", "V", "T") if getattr(args, k) is not None}
     if over:
         d = dataclasses.replace(d, **over)
+
+    def finish(line):
+        """rank 0: the run-level keys + the summary, then the ONE line"""
+        import build_hip
+        line["ranks_joined"] = ranks_joined
+        line["ranks_control_plane"] = ranks_control_plane
+        if rccl_error is not None:
+            line["rccl"] = "unavailable (ranks_joined is null; ranks_control_plane counts the gloo group): " + rccl_error
+        # which library ran: a CVC_LIB variant (A/B builds) can never be taken for the in-tree product build
+        line["library"] = dict(path=os.path.relpath(hip.LIB_PATH, ROOT) if hip.LIB_PATH.startswith(ROOT) else hip.LIB_PATH,
+                               in_tree_default=not os.environ.get("CVC_LIB"), version=hip.version(),
+                               source_hash=build_hip.source_hash(), note="source_hash = sha256 of the kernel sources in this tree")
+        # LAST key of the line (a log that keeps only the tail of stdout still shows it): every measurement's headline numbers
+        summ = [dict(name="headline: " + line["config"]["workload"], value=line["value"], unit=line["unit"], ms_per_step=line["ms_per_step"],
+                     roofline_frac=(line.get("roofline") or {}).get("frac"))]
+        for e in line.get("secondary", []):
+            summ.append(dict(name=e.get("name"), value=e.get("value"), unit=e.get("unit"), ms_per_step=e.get("ms_per_step"),
+                             roofline_kernel=(e.get("roofline") or {}).get("kernel"), roofline_frac=(e.get("roofline") or {}).get("frac"),
+                             **({"exchange_in_graph_ms": e["exchange"].get("in_graph_ms"),
+                                 "exchange_efficiency": e["exchange"].get("efficiency_vs_exchange_off")} if e.get("exchange") else {}),
+                             **({"error": e["error"]} if "error" in e else {})))
+        line["summary"] = summ
+        emit(line)
+
     line = None
     if args.mode == "encoder":
         if rank == 0:
@@ -684,31 +740,14 @@ def main():
             # config 4's training step -- B = 32 clips per rank, the six-bucket RCCL exchange captured inside the step's graph -- so
             # that one command on an 8-GPU node measures config 4 (global B = 256) with its exposed exchange time
             t0 = time.perf_counter()
+            guard = _secondary_guard(args, rank, world, line, lambda ln: finish(ln))
             sec = run_secondary_ranks(args, dev, rank, world, comm)
+            guard.cancel()
             if rank == 0:
                 line["secondary"] = sec
                 line["secondary_wall_s"] = round(time.perf_counter() - t0, 1)
     if rank == 0:
-        import build_hip
-        line["ranks_joined"] = ranks_joined
-        line["ranks_control_plane"] = ranks_control_plane
-        if rccl_error is not None:
-            line["rccl"] = "unavailable (ranks_joined is null; ranks_control_plane counts the gloo group): " + rccl_error
-        # which library ran: a CVC_LIB variant (A/B builds) can never be taken for the in-tree product build
-        line["library"] = dict(path=os.path.relpath(hip.LIB_PATH, ROOT) if hip.LIB_PATH.startswith(ROOT) else hip.LIB_PATH,
-                               in_tree_default=not os.environ.get("CVC_LIB"), version=hip.version(),
-                               source_hash=build_hip.source_hash(), note="source_hash = sha256 of the kernel sources in this tree")
-        # LAST key of the line (a log that keeps only the tail of stdout still shows it): every measurement's headline numbers
-        summ = [dict(name="headline: " + line["config"]["workload"], value=line["value"], unit=line["unit"], ms_per_step=line["ms_per_step"],
-                     roofline_frac=(line.get("roofline") or {}).get("frac"))]
-        for e in line.get("secondary", []):
-            summ.append(dict(name=e.get("name"), value=e.get("value"), unit=e.get("unit"), ms_per_step=e.get("ms_per_step"),
-                             roofline_kernel=(e.get("roofline") or {}).get("kernel"), roofline_frac=(e.get("roofline") or {}).get("frac"),
-                             **({"exchange_in_graph_ms": e["exchange"].get("in_graph_ms"),
-                                 "exchange_efficiency": e["exchange"].get("efficiency_vs_exchange_off")} if e.get("exchange") else {}),
-                             **({"error": e["error"]} if "error" in e else {})))
-        line["summary"] = summ
-        emit(line)
+        finish(line)
     if dist_on:
         # everything that holds work on the communicator (the captured training step, reducers' events) is released before the
         # group is torn down

@@ -866,6 +866,26 @@ def test_bench_train_finishes_with_two_real_rank_processes(tmp_path):
     assert d["config"]["global_batch"] == 2 * d["config"]["B_per_gpu"] and len(d["kernels"]) > 10
 
 
+def test_bench_at_two_ranks_still_prints_its_decode_line_when_the_training_secondary_hangs(tmp_path):
+    """`bench.py --gpus 2` (the driver's command: decode line + the all-ranks config-4 training secondary, the only part of the run
+    with collectives).  The secondary is made to hang (test hook): after --secondary-timeout every rank dumps its stacks and leaves
+    with status 0, rank 0 having printed the decode line -- complete, n_gpus = 2 -- with the secondary's entry saying it timed out."""
+    import json
+    import os
+    env = dict(_two_rank_env(tmp_path), CVC_BENCH_TEST_HANG_SECONDARY="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = _launch_two([os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--min-warm-seconds", "0.1",
+                     "--no-cpu-baseline", "--secondary-timeout", "5"], env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_joined"] == 2 and d["value"] > 0 and d["steps"] == 3
+    assert len(d["secondary"]) == 1 and "did not return within" in d["secondary"][0]["error"]
+    assert d["summary"][-1]["error"] == d["secondary"][0]["error"]
+    assert "run_secondary_ranks" in r.stderr                       # the stacks name the place
+
+
 def test_two_rank_training_step_equals_the_single_process_step_on_the_whole_batch(tmp_path):
     """Two rank processes (one GPU, stand-in transport), each with its half of a batch: one eager training step with
     GradReducer(comm = RcclComm.from_process_group()) + ClipAdam(1 / G folded into the clip) must leave both ranks with bitwise EQUAL
