@@ -591,7 +591,7 @@ def _secondary_guard(args, rank, world, line, finish):
         try:
             faulthandler.dump_traceback(all_threads=True)
             if rank == 0:
-                line["secondary"] = [{"name": f"cfg4 cyclical train step, {world} rank(s)",
+                line["secondary"] = [{"name": f"RCCL communicator + cfg4 cyclical train step, {world} rank(s)",
                                       "error": f"did not return within --secondary-timeout = {args.secondary_timeout:.0f} s (stacks on stderr); "
                                                "the decode line above it is complete"}]
                 finish(line)
@@ -664,9 +664,12 @@ def main():
         ranks_control_plane = int(round(control_all_reduce([1.0], "sum")[0]))
         if ranks_control_plane != args.gpus or dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: {ranks_control_plane} rank(s) joined the process group, --gpus asked for {args.gpus}")
-        # every rank ends up on the same side of the fallback: RcclComm.from_process_group() agrees on the outcome over the control
-        # plane before it returns (a rank-local ncclCommInitRank failure reaches every rank), so either all ranks hold a
-        # communicator or all of them take the branch below
+
+    def make_comm():
+        """The data plane: the package's own RCCL communicator, and the ranks counted through it.  Every rank ends up on the same side
+        of the fallback: RcclComm.from_process_group() agrees on the outcome over the control plane before it returns (a rank-local
+        ncclCommInitRank failure reaches every rank), so either all ranks hold a communicator or all of them take the except branch."""
+        nonlocal comm, ranks_joined, rccl_error
         try:
             comm = RcclComm.from_process_group()
             ranks_joined = comm.count_ranks()
@@ -683,6 +686,12 @@ def main():
                   file=sys.stderr, flush=True)
         if ranks_joined is not None and ranks_joined != args.gpus:
             raise SystemExit(f"bench.py: {ranks_joined} rank(s) joined the RCCL communicator, --gpus asked for {args.gpus}")
+
+    # --mode train needs the communicator for what it measures; a decode run measures FIRST (no collective in that path) and brings
+    # the communicator up afterwards, inside the timed guard below: neither a communicator that cannot be created nor one whose
+    # creation never returns can cost the decode line
+    if dist_on and args.mode == "train":
+        make_comm()
 
     import dataclasses
     from cvc import synth
@@ -735,15 +744,17 @@ def main():
             t0 = time.perf_counter()
             line["secondary"] = run_secondary(args, dev)
             line["secondary_wall_s"] = round(time.perf_counter() - t0, 1)
-        elif default_cfg and dist_on:
-            # N ranks (the driver's `bench.py --gpus N`, or --spawn at N = 1): after the decode measurement EVERY rank runs BASELINE
-            # config 4's training step -- B = 32 clips per rank, the six-bucket RCCL exchange captured inside the step's graph -- so
-            # that one command on an 8-GPU node measures config 4 (global B = 256) with its exposed exchange time
+        elif dist_on:
+            # N ranks (the driver's `bench.py --gpus N`, or --spawn at N = 1): the decode line is measured; now the communicator
+            # (`ranks_joined` is counted through it) and, for the default configuration, BASELINE config 4's training step run by
+            # EVERY rank -- B = 32 clips per rank, the six-bucket RCCL exchange captured inside the step's graph -- so that one
+            # command on an 8-GPU node measures config 4 (global B = 256) with its exposed exchange time.  All of it under a timer.
             t0 = time.perf_counter()
             guard = _secondary_guard(args, rank, world, line, lambda ln: finish(ln))
-            sec = run_secondary_ranks(args, dev, rank, world, comm)
+            make_comm()
+            sec = run_secondary_ranks(args, dev, rank, world, comm) if default_cfg else None
             guard.cancel()
-            if rank == 0:
+            if rank == 0 and sec is not None:
                 line["secondary"] = sec
                 line["secondary_wall_s"] = round(time.perf_counter() - t0, 1)
     if rank == 0:
