@@ -196,6 +196,42 @@ def test_attention_fwd_bwd_vs_oracle(dev, lib, kind, nclip, nq, N, A, R):
         close(got[1][nq:2 * nq], torch.full((nq, N), 1.0 / N), rtol=1e-5, atol=0)   # all-masked clip: uniform
 
 
+@pytest.mark.parametrize("nq", [1, 5, 3])
+@pytest.mark.parametrize("N,F,R", [(512, 16, 300), (513, 15, 256), (15, 512, 260), (16, 17, 2048), (1, 600, 64)])
+def test_two_set_weighted_sum_at_the_edges_of_its_hoisted_forms(dev, lib, nq, N, F, R):
+    """The weighted sums' round-6 forms -- both feature sets' softmax rows made up front (n <= 512 in every set), the one-query form's
+    first round of context rows requested before them (n >= 16), 4 or 8 waves per workgroup for groups of 5 queries -- at the sizes
+    where each condition flips, against torch fp64: region + frame attention of one decoder step, masks on the region set, one clip
+    fully masked, R beside a 256-column block."""
+    from cvc import functional as F_
+    g = torch.Generator().manual_seed(N * 31 + F * 7 + R + nq)
+    nclip, A = 3, 24
+    rows = nclip * nq
+    q = torch.randn(rows, A, generator=g).to(dev)
+    w_a, b_a = (torch.randn(1, A, generator=g) * 0.3).to(dev), torch.randn(1, generator=g).to(dev)
+    pr, cr = torch.randn(nclip, N, A, generator=g).to(dev), torch.randn(nclip, N, R, generator=g).to(dev)
+    pf, cf = torch.randn(nclip, F, A, generator=g).to(dev), torch.randn(nclip, F, R, generator=g).to(dev)
+    mask = (torch.rand(nclip, N, generator=g) < 0.3).to(dev)
+    mask[1] = True
+    total, ((c_r, a_r, _), (c_f, a_f, _)) = F_.attention(lib.ATTN_ADDITIVE, q, w_a, b_a, 1.0, [(pr, cr, mask, None), (pf, cf, None, None)])
+
+    def ref(proj, ctx, m):
+        pe, ce = proj.double().repeat_interleave(nq, 0), ctx.double().repeat_interleave(nq, 0)
+        sc = (torch.tanh(pe + q.double()[:, None, :]) * w_a.double()).sum(-1) + b_a.double()
+        if m is not None:
+            sc = sc.masked_fill(m.repeat_interleave(nq, 0), -1e8)
+        a = torch.softmax(sc, 1)
+        return a, torch.bmm(a[:, None, :], ce).squeeze(1)
+    ar, xr = ref(pr, cr, mask)
+    af, xf = ref(pf, cf, None)
+    close(a_r, ar.float(), rtol=2e-5, atol=2e-6)
+    close(a_f, af.float(), rtol=2e-5, atol=2e-6)
+    close(c_r, xr.float(), rtol=2e-5, atol=2e-5)
+    close(c_f, xf.float(), rtol=2e-5, atol=2e-5)
+    close(total, (xr + xf).float(), rtol=2e-5, atol=2e-5)
+    close(a_r[nq:2 * nq], torch.full((nq, N), 1.0 / N, device=dev), rtol=1e-5, atol=0)        # the all-masked clip: uniform
+
+
 # ------------------------------------------------------------------ concat-GEMM kernels (both code paths)
 @pytest.mark.parametrize("M,Nout,ks,gather", [
     (64, 8192, (2048, 2048, 1024, 2048), True),     # att-LSTM shape of cfg2 (LDS-DMA fast path)
