@@ -56,6 +56,31 @@ struct ScoreArgs {
 // factors stay inside [2^-92, 2^92]: no overflow, no denormal, no inf * 0.  A workgroup with a larger query runs the direct form
 // below, unchanged.  (Round 2 tried the factoring with a per-element fallback inside one loop body: 186 VGPRs, slower.  Here the
 // choice is workgroup-uniform and the two forms are separate loops.)
+template <int NPL>
+__device__ __forceinline__ f32x4 sum_planes_fixed(const float* src, long long stride) {
+    f32x4 pv[NPL];
+#pragma unroll
+    for (int p = 0; p < NPL; ++p) pv[p] = ld4(src + (size_t)p * stride);
+    f32x4 v = pv[0];
+#pragma unroll
+    for (int p = 1; p < NPL; ++p) v += pv[p];
+    return v;
+}
+// plane 0 + plane 1 + ... (in that order, whatever the count)
+__device__ __forceinline__ f32x4 sum_planes(const float* src, int n, long long stride) {
+    switch (n) {
+        case 1: return ld4(src);
+        case 2: return sum_planes_fixed<2>(src, stride);
+        case 4: return sum_planes_fixed<4>(src, stride);
+        case 8: return sum_planes_fixed<8>(src, stride);
+        case 16: return sum_planes_fixed<16>(src, stride);
+        default: break;
+    }
+    f32x4 v = ld4(src);
+    for (int p = 1; p < n; ++p) v += ld4(src + (size_t)p * stride);
+    return v;
+}
+
 template <int KIND, int NCH, int QG>
 __global__ __launch_bounds__(SCORE_WG) void attn_scores_kernel(ScoreArgs a) {
     constexpr bool FACTORABLE = KIND == CVC_ATTN_ADDITIVE && QG > 1;
@@ -93,8 +118,10 @@ __global__ __launch_bounds__(SCORE_WG) void attn_scores_kernel(ScoreArgs a) {
 #endif
         if (i < nq * A) {
             const float* src = a.q + ((size_t)clip * a.nq_total + a.q0 + i / A) * a.q_ld + i % A;
-            v = ld4(src);
-            for (int p = 1; p < a.q_nparts; ++p) v += ld4(src + (size_t)p * a.q_part_stride);
+            // the K-slice planes of the h2attn product, summed in plane order: all of a thread's loads are requested before the first
+            // add (as a loop over a run-time count they were q_nparts dependent trips to L2 -- 8 in the greedy decode -- in front of
+            // every workgroup's first feature row, and a launch is ONE round of workgroups: nothing covered them)
+            v = sum_planes(src, a.q_nparts, a.q_part_stride);
             if (a.q_bias != nullptr) v += ld4(a.q_bias + (i % A));
         }
         if (KIND == CVC_ATTN_ADDITIVE) v *= EXP_C;
