@@ -68,9 +68,10 @@ def parse(argv=None):
     p.add_argument("--gate-ksplit", type=int, default=None, choices=[0, 1, 2],
                    help="packed path: 1 = K-split gate GEMMs (activations shared through LDS + finishing kernel), 0 = full-K "
                         "kernel; default = cvc.decode.GATE_KSPLIT_DEFAULT")
-    p.add_argument("--tile-loaders", type=int, default=None, choices=[0, 1, 2, 3],
+    p.add_argument("--tile-loaders", type=int, default=None, choices=[0, 1, 2, 3, 4],
                    help="tile GEMM form (A/B): 0 = every wave copies, 1 = loader waves + 8 computing waves, 2 = loader waves + 4 wide "
-                        "computing waves (default of the library)")
+                        "computing waves, 3 = 2 for long K loops, 1 otherwise (default of the library), 4 = register-load loader "
+                        "waves (in the beam step: lang / att gate GEMMs 148 -> 153 / 103 -> 107 us, slower)")
     p.add_argument("--lstm-blocks", type=int, default=None, choices=[1, 2],
                    help="packed decode LSTM gate GEMM (A/B): 32-row weight blocks per workgroup (library default 1)")
     p.add_argument("--gsk", type=int, default=None, choices=[0, 1],
